@@ -1,0 +1,108 @@
+"""Environment-variable registry.
+
+Every environment variable the framework reads is declared here once, with a
+parser and a default, and is read lazily so tests can monkeypatch
+``os.environ``.  ``environment_variables`` is the set of names the head copies
+to remote workers (the reference copies ``vllm.envs.environment_variables``,
+reference ``src/launch.py:198-208``); worker-specific names are excluded by the
+executor (reference ``src/launch.py:64-72``).
+
+Variable names keep the reference's spelling where the meaning is the same
+(``VLLM_HOST_IP``, ``VLLM_SERVER_PORT``, ``VLLM_EXECUTE_MODEL_TIMEOUT_SECONDS``,
+``VLLM_HTTP_TIMEOUT_KEEP_ALIVE``, ``VLLM_PP_LAYER_PARTITION``,
+``VLLM_USE_MODELSCOPE``) so an operator's ``.env`` files carry over.
+"""
+from __future__ import annotations
+
+import os
+from typing import Any, Callable, Dict
+
+
+def _bool(name: str, default: bool) -> Callable[[], bool]:
+    def get() -> bool:
+        v = os.environ.get(name)
+        if v is None:
+            return default
+        return v.strip().lower() in ("1", "true", "yes", "on")
+    return get
+
+
+def _int(name: str, default: int) -> Callable[[], int]:
+    return lambda: int(os.environ.get(name, default))
+
+
+def _float(name: str, default: float) -> Callable[[], float]:
+    return lambda: float(os.environ.get(name, default))
+
+
+def _str(name: str, default: Any = None) -> Callable[[], Any]:
+    return lambda: os.environ.get(name, default)
+
+
+environment_variables: Dict[str, Callable[[], Any]] = {
+    # --- control plane ---------------------------------------------------
+    # IP other nodes use to reach this node (head: rendezvous address).
+    "VLLM_HOST_IP": _str("VLLM_HOST_IP", ""),
+    # TCP port of the head's worker-registration RPC server.
+    "VLLM_SERVER_PORT": _int("VLLM_SERVER_PORT", 30044),
+    # Shared secret for the RPC handshake (HMAC-SHA256 challenge/response).
+    "VLLM_RPC_SECRET": _str("VLLM_RPC_SECRET", ""),
+    # Address the head's RPC server binds to.
+    "VLLM_RPC_BIND": _str("VLLM_RPC_BIND", "0.0.0.0"),
+    # Seconds a remote worker waits between reconnect attempts.
+    "VLLM_REMOTE_RETRY_SECONDS": _float("VLLM_REMOTE_RETRY_SECONDS", 10.0),
+    # Cap on GPUs the head uses for its own (forked) workers; -1 = all.
+    "VLLM_HEAD_LOCAL_DEVICES": _int("VLLM_HEAD_LOCAL_DEVICES", -1),
+    # Seconds the head waits for enough remote workers to register; 0 = forever.
+    "VLLM_WORKER_REGISTRATION_TIMEOUT": _float("VLLM_WORKER_REGISTRATION_TIMEOUT", 0.0),
+    # Per-call RPC timeouts.
+    "VLLM_EXECUTE_MODEL_TIMEOUT_SECONDS": _float("VLLM_EXECUTE_MODEL_TIMEOUT_SECONDS", 300.0),
+    "VLLM_RPC_TIMEOUT": _float("VLLM_RPC_TIMEOUT", 600.0),
+    "VLLM_HEARTBEAT_SECONDS": _float("VLLM_HEARTBEAT_SECONDS", 0.0),
+    # --- http ------------------------------------------------------------
+    "VLLM_HTTP_TIMEOUT_KEEP_ALIVE": _int("VLLM_HTTP_TIMEOUT_KEEP_ALIVE", 5),
+    "VLLM_API_KEY": _str("VLLM_API_KEY", None),
+    # --- engine ----------------------------------------------------------
+    "VLLM_USE_V1": _bool("VLLM_USE_V1", True),
+    "VLLM_PP_LAYER_PARTITION": _str("VLLM_PP_LAYER_PARTITION", None),
+    "VLLM_USE_MODELSCOPE": _bool("VLLM_USE_MODELSCOPE", False),
+    "VLLM_LOGGING_LEVEL": _str("VLLM_LOGGING_LEVEL", "INFO"),
+    "VLLM_CACHE_ROOT": _str("VLLM_CACHE_ROOT", os.path.expanduser("~/.cache/vllm_distributed_amd")),
+    # --- device / kernels --------------------------------------------------
+    # "hip" | "torch" | "auto": which implementation ops.* dispatch to.
+    "VDAMD_OPS_BACKEND": _str("VDAMD_OPS_BACKEND", "auto"),
+    # "auto" | "rccl" | "torch": data-plane collective backend on GPU.
+    "VDAMD_COMM_BACKEND": _str("VDAMD_COMM_BACKEND", "auto"),
+    # Enable the peer-mapped direct all-reduce for small messages.
+    "VDAMD_CUSTOM_ALL_REDUCE": _bool("VDAMD_CUSTOM_ALL_REDUCE", True),
+    "VDAMD_CUSTOM_ALL_REDUCE_MAX_BYTES": _int("VDAMD_CUSTOM_ALL_REDUCE_MAX_BYTES", 8 << 20),
+    # Capture decode steps in hipGraphs.
+    "VDAMD_USE_HIP_GRAPH": _bool("VDAMD_USE_HIP_GRAPH", True),
+    # Assert identical collective sequence numbers on all ranks (debug).
+    "VDAMD_CHECK_COLLECTIVE_ORDER": _bool("VDAMD_CHECK_COLLECTIVE_ORDER", False),
+    # Emit roctx ranges / per-step timing.
+    "VDAMD_TRACE": _bool("VDAMD_TRACE", False),
+    "VDAMD_PROFILE_DIR": _str("VDAMD_PROFILE_DIR", "/tmp/vdamd_profile"),
+    # Test-only fault hook: "rank:step" => that rank exits at that step.
+    "VDAMD_FAULT_DIE_AT": _str("VDAMD_FAULT_DIE_AT", None),
+    # Data-plane NIC selection, honoured by RCCL / gloo.
+    "NCCL_SOCKET_IFNAME": _str("NCCL_SOCKET_IFNAME", None),
+    "GLOO_SOCKET_IFNAME": _str("GLOO_SOCKET_IFNAME", None),
+    "NCCL_DEBUG": _str("NCCL_DEBUG", None),
+    "HSA_ENABLE_IPC_MODE_LEGACY": _str("HSA_ENABLE_IPC_MODE_LEGACY", None),
+}
+
+
+def __getattr__(name: str) -> Any:
+    try:
+        return environment_variables[name]()
+    except KeyError:
+        raise AttributeError(f"module {__name__!r} has no attribute {name!r}") from None
+
+
+def __dir__():
+    return list(environment_variables.keys())
+
+
+def is_set(name: str) -> bool:
+    return name in os.environ
