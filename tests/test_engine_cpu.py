@@ -1,0 +1,120 @@
+"""End-to-end on CPU: tiny random-init models through the whole engine."""
+import pytest
+import torch
+
+from vllm_distributed_amd import LLM, SamplingParams
+from vllm_distributed_amd.parallel import state as pstate
+
+
+@pytest.fixture(autouse=True)
+def _fresh_groups():
+    pstate.destroy_model_parallel()
+    yield
+    pstate.destroy_model_parallel()
+
+
+def _hf_style_greedy(llm, prompt_ids, n):
+    """Reference: recompute the full sequence from scratch for every token with
+    a fresh engine-free forward (no KV cache reuse across steps)."""
+    from vllm_distributed_amd.models.layers.attention import AttentionMetadata, set_forward_context
+    runner = llm.engine.core.executor.driver.worker.model_runner
+    model = runner.model
+    bs = runner.block_size
+    ids = list(prompt_ids)
+    out = []
+    for _ in range(n):
+        t = len(ids)
+        nb = (t + bs - 1) // bs
+        # use scratch blocks at the END of the cache so we do not disturb live state
+        blocks = list(range(runner.num_blocks - nb, runner.num_blocks))
+        pos = torch.arange(t, dtype=torch.int32)
+        slots = torch.tensor([blocks[p // bs] * bs + p % bs for p in range(t)], dtype=torch.int32)
+        md = AttentionMetadata(
+            num_decodes=0, num_decode_tokens=0, num_prefills=1, num_prefill_tokens=t,
+            slot_mapping=slots, block_table=torch.tensor([blocks], dtype=torch.int32),
+            seq_lens=torch.tensor([t], dtype=torch.int32),
+            query_start_loc=torch.tensor([0, t], dtype=torch.int32), max_query_len=t, max_seq_len=t,
+            prefill_query_start_loc=torch.tensor([0, t], dtype=torch.int32), max_prefill_query_len=t)
+        with torch.inference_mode():
+            set_forward_context(md, pos)
+            h = model(torch.tensor(ids, dtype=torch.int32), pos, None)
+            set_forward_context(None)
+            tok = int(model.compute_logits(h[-1:]).argmax(-1))
+        ids.append(tok)
+        out.append(tok)
+    return out
+
+
+@pytest.mark.parametrize("model", ["llama-tiny", "opt-tiny", "qwen3-moe-tiny"])
+def test_greedy_matches_recompute_reference(model):
+    llm = LLM(model=model, device="cpu", dtype="float32", max_model_len=128, block_size=16,
+              num_gpu_blocks_override=64, max_num_seqs=8)
+    prompts = [[5, 9, 200, 17, 3, 3, 8], list(range(10, 45)), [7]]
+    sp = SamplingParams(temperature=0.0, max_tokens=12, ignore_eos=True)
+    outs = llm.generate(prompts, sp)
+    for p, o in zip(prompts, outs):
+        assert o.finished and len(o.outputs[0].token_ids) == 12
+        assert o.outputs[0].token_ids == _hf_style_greedy(llm, p, 12)
+    llm.shutdown()
+
+
+def test_chunked_prefill_and_batching_do_not_change_tokens():
+    kw = dict(model="llama-tiny", device="cpu", dtype="float32", max_model_len=256, block_size=16,
+              num_gpu_blocks_override=128, enable_prefix_caching=False)
+    prompts = [list(range(3, 100)), list(range(50, 61)), [9, 8, 7, 6, 5] * 9]
+    sp = SamplingParams(temperature=0.0, max_tokens=10, ignore_eos=True)
+    llm = LLM(max_num_batched_tokens=512, **kw)
+    ref = [o.outputs[0].token_ids for o in llm.generate(prompts, sp)]
+    llm.shutdown()
+    pstate.destroy_model_parallel()
+    llm = LLM(max_num_batched_tokens=16, **kw)     # forces many prefill chunks
+    got = [o.outputs[0].token_ids for o in llm.generate(prompts, sp)]
+    llm.shutdown()
+    assert got == ref
+
+
+def test_prefix_cache_hit_and_same_tokens():
+    llm = LLM(model="llama-tiny", device="cpu", dtype="float32", max_model_len=256, block_size=16,
+              num_gpu_blocks_override=128, enable_prefix_caching=True)
+    shared = list(range(20, 20 + 70))
+    sp = SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True)
+    a = llm.generate([shared + [1, 2, 3]], sp)[0]
+    b = llm.generate([shared + [1, 2, 3]], sp)[0]
+    assert a.outputs[0].token_ids == b.outputs[0].token_ids
+    assert b.metrics.num_cached_tokens == 64     # 4 full blocks of the 73-token prompt
+    llm.shutdown()
+
+
+def test_preemption_recompute_keeps_outputs():
+    kw = dict(model="llama-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,
+              enable_prefix_caching=False)
+    prompts = [list(range(2, 40)), list(range(100, 140)), list(range(200, 230))]
+    sp = SamplingParams(temperature=0.0, max_tokens=40, ignore_eos=True)
+    llm = LLM(num_gpu_blocks_override=64, **kw)
+    ref = [o.outputs[0].token_ids for o in llm.generate(prompts, sp)]
+    llm.shutdown()
+    pstate.destroy_model_parallel()
+    llm = LLM(num_gpu_blocks_override=11, **kw)    # too few blocks for all three to finish
+    got = [o.outputs[0].token_ids for o in llm.generate(prompts, sp)]
+    assert llm.engine.core.scheduler.num_preemptions > 0
+    llm.shutdown()
+    assert got == ref
+
+
+def test_sampling_seeded_and_stop_conditions():
+    llm = LLM(model="llama-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,
+              num_gpu_blocks_override=64)
+    p = [[4, 5, 6, 7]]
+    sp = SamplingParams(temperature=0.9, top_p=0.9, top_k=50, seed=1234, max_tokens=16, ignore_eos=True)
+    a = llm.generate(p, sp)[0].outputs[0].token_ids
+    b = llm.generate(p, sp)[0].outputs[0].token_ids
+    assert a == b and len(a) == 16
+    g = llm.generate(p, SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))[0].outputs[0].token_ids
+    stop_tok = g[3]
+    o = llm.generate(p, SamplingParams(temperature=0, max_tokens=8, ignore_eos=True,
+                                       stop_token_ids=[stop_tok]))[0]
+    assert o.outputs[0].finish_reason == "stop"
+    assert o.outputs[0].token_ids == g[:g.index(stop_tok) + 1]
+    lp = llm.generate(p, SamplingParams(temperature=0, max_tokens=3, ignore_eos=True, logprobs=2))[0]
+    assert len(lp.outputs[0].logprobs) == 3 and lp.outputs[0].cumulative_logprob < 0
+    llm.shutdown()

@@ -1,0 +1,337 @@
+"""Configuration objects.
+
+One picklable-by-value ``VllmConfig`` aggregates everything a worker needs;
+the head ships it to spawned workers as a process argument and to remote
+workers as an RPC argument (reference ``src/launch.py:27,85-87,162,238,280,
+295,300``).  The fields the executor reads keep the reference's names:
+``parallel_config.{world_size,tensor_parallel_size,pipeline_parallel_size}``,
+``scheduler_config.async_scheduling``, ``kv_transfer_config``.
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import asdict, dataclass, field
+from typing import Any, Dict, List, Optional
+
+from . import envs
+from .logger import init_logger
+
+logger = init_logger(__name__)
+
+_CONFIG_DIR = os.path.join(os.path.dirname(__file__), "models", "configs")
+
+# model-name -> bundled HF-style config file (no network on the GPU box)
+_BUILTIN_ALIASES = {
+    "meta-llama/meta-llama-3-8b": "llama-3-8b.json",
+    "meta-llama/meta-llama-3-8b-instruct": "llama-3-8b.json",
+    "meta-llama/llama-3.1-8b": "llama-3-8b.json",
+    "llama-3-8b": "llama-3-8b.json",
+    "meta-llama/meta-llama-3-70b": "llama-3-70b.json",
+    "meta-llama/meta-llama-3-70b-instruct": "llama-3-70b.json",
+    "llama-3-70b": "llama-3-70b.json",
+    "facebook/opt-125m": "opt-125m.json",
+    "opt-125m": "opt-125m.json",
+    "llama-tiny": "llama-tiny.json",
+    "opt-tiny": "opt-tiny.json",
+    "qwen3-moe-tiny": "qwen3-moe-tiny.json",
+    "qwen/qwen3-coder-480b-a35b-instruct": "qwen3-coder-480b-a35b.json",
+    "koushd/qwen3-coder-480b-a35b-instruct-awq": "qwen3-coder-480b-a35b.json",
+    "qwen/qwen3-8b": "qwen3-8b.json",
+    "qwen3-8b": "qwen3-8b.json",
+    "mistralai/mistral-7b-v0.1": "mistral-7b.json",
+    "mistral-7b": "mistral-7b.json",
+}
+
+
+def load_hf_config(model: str) -> Dict[str, Any]:
+    """HF ``config.json`` as a dict: from a local directory, else a bundled file."""
+    if os.path.isdir(model):
+        path = os.path.join(model, "config.json")
+        if os.path.isfile(path):
+            with open(path) as f:
+                return json.load(f)
+    if os.path.isfile(model) and model.endswith(".json"):
+        with open(model) as f:
+            return json.load(f)
+    # HF hub cache layout: $HF_HOME/hub/models--org--name/snapshots/<rev>/config.json
+    hub = os.environ.get("HUGGINGFACE_HUB_CACHE") or os.path.join(
+        os.environ.get("HF_HOME", os.path.expanduser("~/.cache/huggingface")), "hub")
+    cand = os.path.join(hub, "models--" + model.replace("/", "--"), "snapshots")
+    if os.path.isdir(cand):
+        for rev in sorted(os.listdir(cand)):
+            path = os.path.join(cand, rev, "config.json")
+            if os.path.isfile(path):
+                with open(path) as f:
+                    return json.load(f)
+    alias = _BUILTIN_ALIASES.get(model.lower())
+    if alias is not None:
+        with open(os.path.join(_CONFIG_DIR, alias)) as f:
+            return json.load(f)
+    raise FileNotFoundError(
+        f"no config.json for model {model!r} (not a local directory, not in the HF cache, "
+        f"not bundled; bundled: {sorted(set(_BUILTIN_ALIASES.values()))})")
+
+
+def resolve_model_path(model: str) -> Optional[str]:
+    """Directory holding weights/tokenizer for ``model`` or None."""
+    if os.path.isdir(model):
+        return model
+    hub = os.environ.get("HUGGINGFACE_HUB_CACHE") or os.path.join(
+        os.environ.get("HF_HOME", os.path.expanduser("~/.cache/huggingface")), "hub")
+    cand = os.path.join(hub, "models--" + model.replace("/", "--"), "snapshots")
+    if os.path.isdir(cand):
+        revs = sorted(os.listdir(cand))
+        if revs:
+            return os.path.join(cand, revs[-1])
+    return None
+
+
+@dataclass
+class ModelConfig:
+    model: str = "llama-tiny"
+    tokenizer: Optional[str] = None
+    served_model_name: Optional[List[str]] = None
+    dtype: str = "auto"                # auto|bfloat16|float16|float32
+    seed: int = 0
+    max_model_len: Optional[int] = None
+    load_format: str = "auto"          # auto|safetensors|dummy
+    quantization: Optional[str] = None  # None|awq
+    trust_remote_code: bool = False
+    revision: Optional[str] = None
+    hf_overrides: Dict[str, Any] = field(default_factory=dict)
+    # populated by __post_init__
+    hf_config: Dict[str, Any] = field(default_factory=dict)
+
+    def __post_init__(self) -> None:
+        if not self.hf_config:
+            self.hf_config = dict(load_hf_config(self.model))
+        self.hf_config.update(self.hf_overrides or {})
+        if self.tokenizer is None:
+            self.tokenizer = self.model
+        if self.served_model_name is None:
+            self.served_model_name = [self.model]
+        elif isinstance(self.served_model_name, str):
+            self.served_model_name = [self.served_model_name]
+        if self.dtype == "auto":
+            td = self.hf_config.get("torch_dtype", "bfloat16")
+            self.dtype = {"float16": "float16", "half": "float16", "float32": "float32",
+                          "bfloat16": "bfloat16"}.get(str(td), "bfloat16")
+        if self.dtype in ("half", "fp16"):
+            self.dtype = "float16"
+        if self.dtype in ("bf16",):
+            self.dtype = "bfloat16"
+        if self.dtype in ("float", "fp32"):
+            self.dtype = "float32"
+        derived = self.derived_max_model_len()
+        if self.max_model_len is None:
+            self.max_model_len = derived
+        if self.quantization is None:
+            q = self.hf_config.get("quantization_config") or {}
+            if q.get("quant_method") == "awq":
+                self.quantization = "awq"
+        if self.load_format == "auto" and resolve_model_path(self.model) is None:
+            logger.warning("no weights found for %s: using deterministic random init "
+                           "(load_format=dummy)", self.model)
+            self.load_format = "dummy"
+
+    # ------------------------------------------------------------ accessors
+    def derived_max_model_len(self) -> int:
+        c = self.hf_config
+        for key in ("max_position_embeddings", "n_positions", "max_sequence_length", "seq_length"):
+            if key in c and c[key]:
+                return int(c[key])
+        return 2048
+
+    @property
+    def architecture(self) -> str:
+        archs = self.hf_config.get("architectures") or []
+        if archs:
+            return archs[0]
+        mt = self.hf_config.get("model_type", "llama")
+        return {"llama": "LlamaForCausalLM", "opt": "OPTForCausalLM",
+                "qwen3_moe": "Qwen3MoeForCausalLM", "qwen2": "Qwen2ForCausalLM",
+                "qwen3": "Qwen3ForCausalLM", "mistral": "MistralForCausalLM"}.get(mt, mt)
+
+    @property
+    def hidden_size(self) -> int:
+        return int(self.hf_config["hidden_size"])
+
+    @property
+    def num_hidden_layers(self) -> int:
+        return int(self.hf_config.get("num_hidden_layers", self.hf_config.get("n_layer", 0)))
+
+    @property
+    def num_attention_heads(self) -> int:
+        return int(self.hf_config["num_attention_heads"])
+
+    @property
+    def num_kv_heads(self) -> int:
+        return int(self.hf_config.get("num_key_value_heads") or self.num_attention_heads)
+
+    @property
+    def head_dim(self) -> int:
+        hd = self.hf_config.get("head_dim")
+        return int(hd) if hd else self.hidden_size // self.num_attention_heads
+
+    @property
+    def vocab_size(self) -> int:
+        return int(self.hf_config["vocab_size"])
+
+    @property
+    def torch_dtype(self):
+        import torch
+        return {"bfloat16": torch.bfloat16, "float16": torch.float16,
+                "float32": torch.float32}[self.dtype]
+
+    @property
+    def dtype_bytes(self) -> int:
+        return {"bfloat16": 2, "float16": 2, "float32": 4}[self.dtype]
+
+    def get_num_kv_heads(self, tp: int) -> int:
+        return max(1, self.num_kv_heads // tp)
+
+
+@dataclass
+class CacheConfig:
+    block_size: int = 16
+    gpu_memory_utilization: float = 0.90
+    num_gpu_blocks_override: Optional[int] = None
+    enable_prefix_caching: bool = True
+    cache_dtype: str = "auto"
+    cpu_kv_bytes: int = 1 << 30        # KV budget when running on CPU
+    # filled in by the engine after memory profiling
+    num_gpu_blocks: Optional[int] = None
+
+
+@dataclass
+class ParallelConfig:
+    tensor_parallel_size: int = 1
+    pipeline_parallel_size: int = 1
+    data_parallel_size: int = 1
+    enable_expert_parallel: bool = False
+    # uni | distributed | spmd  ("external_launcher" is accepted as "spmd",
+    # "mp" as "distributed") or an Executor subclass
+    distributed_executor_backend: Any = None
+    pp_layer_partition: Optional[str] = None
+    disable_custom_all_reduce: bool = False
+    world_size: int = field(init=False, default=1)
+
+    def __post_init__(self) -> None:
+        self.world_size = self.tensor_parallel_size * self.pipeline_parallel_size
+        if self.pp_layer_partition is None:
+            self.pp_layer_partition = envs.VLLM_PP_LAYER_PARTITION
+        b = self.distributed_executor_backend
+        if isinstance(b, str):
+            b = {"external_launcher": "spmd", "mp": "distributed", "ray": "distributed",
+                 "uniproc": "uni"}.get(b, b)
+            self.distributed_executor_backend = b
+
+    def rank_of(self, pp_rank: int, tp_rank: int, dp_rank: int = 0) -> int:
+        """Rank layout ``[DP][PP][TP]``; with DP=1 this is the reference's
+        ``rank = pp_rank * TP + tp_rank`` (``src/launch.py:215,234,278``)."""
+        return (dp_rank * self.pipeline_parallel_size + pp_rank) * self.tensor_parallel_size + tp_rank
+
+    def coords_of(self, rank: int):
+        tp = rank % self.tensor_parallel_size
+        pp = (rank // self.tensor_parallel_size) % self.pipeline_parallel_size
+        dp = rank // (self.tensor_parallel_size * self.pipeline_parallel_size)
+        return dp, pp, tp
+
+
+@dataclass
+class SchedulerConfig:
+    max_num_batched_tokens: Optional[int] = None
+    max_num_seqs: int = 256
+    max_model_len: int = 2048
+    enable_chunked_prefill: bool = True
+    async_scheduling: bool = False
+    policy: str = "fcfs"               # fcfs | priority
+    long_prefill_token_threshold: int = 0
+
+    def __post_init__(self) -> None:
+        if self.max_num_batched_tokens is None:
+            self.max_num_batched_tokens = 8192 if self.enable_chunked_prefill else max(
+                self.max_model_len, 8192)
+        if not self.enable_chunked_prefill and self.max_num_batched_tokens < self.max_model_len:
+            raise ValueError("max_num_batched_tokens must be >= max_model_len without chunked prefill")
+        self.max_num_batched_tokens = max(self.max_num_batched_tokens, 1)
+
+
+@dataclass
+class DeviceConfig:
+    device: str = "auto"               # auto|cuda|cpu
+
+    def __post_init__(self) -> None:
+        if self.device == "auto":
+            from .utils import current_platform
+            self.device = "cuda" if current_platform.is_rocm() else "cpu"
+
+
+@dataclass
+class KVTransferConfig:
+    """Disaggregated prefill/decode: who produces and who consumes KV blocks."""
+    kv_connector: str = "SharedStorageConnector"
+    kv_role: str = "kv_both"           # kv_producer | kv_consumer | kv_both
+    kv_connector_extra_config: Dict[str, Any] = field(default_factory=dict)
+
+
+@dataclass
+class CompilationConfig:
+    """Decode-graph capture settings (hipGraph replaces a tracing compiler)."""
+    use_hip_graph: bool = True
+    capture_sizes: Optional[List[int]] = None
+    max_capture_size: int = 512
+
+    def sizes(self, max_num_seqs: int) -> List[int]:
+        if self.capture_sizes:
+            return sorted(set(int(s) for s in self.capture_sizes))
+        out, s = [], 1
+        top = min(self.max_capture_size, max_num_seqs)
+        while s < 8 and s <= top:
+            out.append(s)
+            s *= 2
+        s = 8
+        while s <= top:
+            out.append(s)
+            s += 8 if s < 64 else (16 if s < 256 else 64)
+        if top not in out and top >= 1:
+            out.append(top)
+        return sorted(set(out))
+
+
+@dataclass
+class ObservabilityConfig:
+    collect_step_timing: bool = True
+    otlp_traces_endpoint: Optional[str] = None
+
+
+@dataclass
+class VllmConfig:
+    model_config: ModelConfig = field(default_factory=ModelConfig)
+    cache_config: CacheConfig = field(default_factory=CacheConfig)
+    parallel_config: ParallelConfig = field(default_factory=ParallelConfig)
+    scheduler_config: SchedulerConfig = field(default_factory=SchedulerConfig)
+    device_config: DeviceConfig = field(default_factory=DeviceConfig)
+    compilation_config: CompilationConfig = field(default_factory=CompilationConfig)
+    observability_config: ObservabilityConfig = field(default_factory=ObservabilityConfig)
+    kv_transfer_config: Optional[KVTransferConfig] = None
+
+    def __post_init__(self) -> None:
+        self.scheduler_config.max_model_len = self.model_config.max_model_len
+        pc, mc = self.parallel_config, self.model_config
+        if mc.num_attention_heads % pc.tensor_parallel_size != 0:
+            raise ValueError(f"num_attention_heads ({mc.num_attention_heads}) must be divisible "
+                             f"by tensor_parallel_size ({pc.tensor_parallel_size})")
+        if pc.pipeline_parallel_size > mc.num_hidden_layers:
+            raise ValueError("pipeline_parallel_size exceeds the number of layers")
+
+    def to_dict(self) -> Dict[str, Any]:
+        d = asdict(self)
+        be = d["parallel_config"].get("distributed_executor_backend")
+        if be is not None and not isinstance(be, str):
+            d["parallel_config"]["distributed_executor_backend"] = getattr(be, "__name__", str(be))
+        return d
+
+
+EngineConfig = VllmConfig

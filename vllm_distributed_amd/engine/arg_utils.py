@@ -1,0 +1,145 @@
+"""Engine arguments: dataclass <-> CLI <-> ``VllmConfig``.
+
+The flag names follow the CLI the reference drives through vLLM's parser
+(``.env.server:11``: ``-tp``, ``-pp``, ``--max-model-len``,
+``--served-model-name`` ...; reference ``src/launch.py:399``:
+``AsyncEngineArgs.from_cli_args``).
+"""
+from __future__ import annotations
+
+import argparse
+import dataclasses
+import json
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional
+
+from ..config import (CacheConfig, CompilationConfig, DeviceConfig, KVTransferConfig, ModelConfig,
+                      ObservabilityConfig, ParallelConfig, SchedulerConfig, VllmConfig)
+
+
+@dataclass
+class EngineArgs:
+    model: str = "llama-tiny"
+    tokenizer: Optional[str] = None
+    served_model_name: Optional[List[str]] = None
+    dtype: str = "auto"
+    seed: int = 0
+    max_model_len: Optional[int] = None
+    load_format: str = "auto"
+    quantization: Optional[str] = None
+    trust_remote_code: bool = False
+    revision: Optional[str] = None
+    hf_overrides: Optional[Dict[str, Any]] = None
+    tensor_parallel_size: int = 1
+    pipeline_parallel_size: int = 1
+    data_parallel_size: int = 1
+    enable_expert_parallel: bool = False
+    distributed_executor_backend: Any = None
+    disable_custom_all_reduce: bool = False
+    block_size: Optional[int] = None
+    gpu_memory_utilization: float = 0.90
+    num_gpu_blocks_override: Optional[int] = None
+    enable_prefix_caching: bool = True
+    kv_cache_dtype: str = "auto"
+    max_num_batched_tokens: Optional[int] = None
+    max_num_seqs: int = 256
+    enable_chunked_prefill: bool = True
+    async_scheduling: bool = False
+    scheduling_policy: str = "fcfs"
+    long_prefill_token_threshold: int = 0
+    device: str = "auto"
+    enforce_eager: bool = False
+    hip_graph_sizes: Optional[List[int]] = None
+    max_capture_size: int = 512
+    kv_transfer_config: Optional[Dict[str, Any]] = None
+    disable_log_stats: bool = False
+
+    # ---------------------------------------------------------------- CLI
+    @staticmethod
+    def add_cli_args(parser: argparse.ArgumentParser) -> argparse.ArgumentParser:
+        g = parser.add_argument_group("engine")
+        g.add_argument("--model", type=str, default=EngineArgs.model)
+        g.add_argument("--tokenizer", type=str, default=None)
+        g.add_argument("--served-model-name", nargs="+", default=None)
+        g.add_argument("--dtype", type=str, default="auto",
+                       choices=["auto", "bfloat16", "float16", "float32", "half", "float", "bf16", "fp16"])
+        g.add_argument("--seed", type=int, default=0)
+        g.add_argument("--max-model-len", type=int, default=None)
+        g.add_argument("--load-format", type=str, default="auto", choices=["auto", "safetensors", "dummy"])
+        g.add_argument("--quantization", "-q", type=str, default=None, choices=[None, "awq"])
+        g.add_argument("--trust-remote-code", action="store_true")
+        g.add_argument("--revision", type=str, default=None)
+        g.add_argument("--hf-overrides", type=json.loads, default=None)
+        g.add_argument("--tensor-parallel-size", "-tp", type=int, default=1)
+        g.add_argument("--pipeline-parallel-size", "-pp", type=int, default=1)
+        g.add_argument("--data-parallel-size", "-dp", type=int, default=1)
+        g.add_argument("--enable-expert-parallel", action="store_true")
+        g.add_argument("--distributed-executor-backend", type=str, default=None)
+        g.add_argument("--disable-custom-all-reduce", action="store_true")
+        g.add_argument("--block-size", type=int, default=None, choices=[16, 32, 64, 128])
+        g.add_argument("--gpu-memory-utilization", type=float, default=0.90)
+        g.add_argument("--num-gpu-blocks-override", type=int, default=None)
+        g.add_argument("--enable-prefix-caching", action=argparse.BooleanOptionalAction, default=True)
+        g.add_argument("--kv-cache-dtype", type=str, default="auto")
+        g.add_argument("--max-num-batched-tokens", type=int, default=None)
+        g.add_argument("--max-num-seqs", type=int, default=256)
+        g.add_argument("--enable-chunked-prefill", action=argparse.BooleanOptionalAction, default=True)
+        g.add_argument("--async-scheduling", action="store_true")
+        g.add_argument("--scheduling-policy", type=str, default="fcfs", choices=["fcfs", "priority"])
+        g.add_argument("--long-prefill-token-threshold", type=int, default=0)
+        g.add_argument("--device", type=str, default="auto", choices=["auto", "cuda", "cpu"])
+        g.add_argument("--enforce-eager", action="store_true",
+                       help="do not capture decode steps in hipGraphs")
+        g.add_argument("--hip-graph-sizes", "--cuda-graph-sizes", type=int, nargs="*", default=None)
+        g.add_argument("--max-capture-size", type=int, default=512)
+        g.add_argument("--kv-transfer-config", type=json.loads, default=None)
+        g.add_argument("--disable-log-stats", action="store_true")
+        return parser
+
+    @classmethod
+    def from_cli_args(cls, args: argparse.Namespace) -> "EngineArgs":
+        names = [f.name for f in dataclasses.fields(cls)]
+        return cls(**{n: getattr(args, n) for n in names if hasattr(args, n)})
+
+    # ------------------------------------------------------------- config
+    def create_engine_config(self) -> VllmConfig:
+        model_config = ModelConfig(
+            model=self.model, tokenizer=self.tokenizer, served_model_name=self.served_model_name,
+            dtype=self.dtype, seed=self.seed, max_model_len=self.max_model_len,
+            load_format=self.load_format, quantization=self.quantization,
+            trust_remote_code=self.trust_remote_code, revision=self.revision,
+            hf_overrides=self.hf_overrides or {})
+        device_config = DeviceConfig(self.device)
+        block_size = self.block_size or (64 if device_config.device == "cuda" else 16)
+        cache_config = CacheConfig(block_size=block_size,
+                                   gpu_memory_utilization=self.gpu_memory_utilization,
+                                   num_gpu_blocks_override=self.num_gpu_blocks_override,
+                                   enable_prefix_caching=self.enable_prefix_caching,
+                                   cache_dtype=self.kv_cache_dtype)
+        parallel_config = ParallelConfig(
+            tensor_parallel_size=self.tensor_parallel_size,
+            pipeline_parallel_size=self.pipeline_parallel_size,
+            data_parallel_size=self.data_parallel_size,
+            enable_expert_parallel=self.enable_expert_parallel,
+            distributed_executor_backend=self.distributed_executor_backend,
+            disable_custom_all_reduce=self.disable_custom_all_reduce)
+        if parallel_config.data_parallel_size != 1:
+            raise ValueError("data parallelism inside one engine is not supported: world_size must "
+                             "equal tensor_parallel_size x pipeline_parallel_size; run one engine per replica")
+        scheduler_config = SchedulerConfig(
+            max_num_batched_tokens=self.max_num_batched_tokens, max_num_seqs=self.max_num_seqs,
+            max_model_len=model_config.max_model_len,
+            enable_chunked_prefill=self.enable_chunked_prefill,
+            async_scheduling=self.async_scheduling, policy=self.scheduling_policy,
+            long_prefill_token_threshold=self.long_prefill_token_threshold)
+        compilation_config = CompilationConfig(use_hip_graph=not self.enforce_eager,
+                                               capture_sizes=self.hip_graph_sizes,
+                                               max_capture_size=self.max_capture_size)
+        kvt = KVTransferConfig(**self.kv_transfer_config) if self.kv_transfer_config else None
+        return VllmConfig(model_config=model_config, cache_config=cache_config,
+                          parallel_config=parallel_config, scheduler_config=scheduler_config,
+                          device_config=device_config, compilation_config=compilation_config,
+                          observability_config=ObservabilityConfig(), kv_transfer_config=kvt)
+
+
+AsyncEngineArgs = EngineArgs

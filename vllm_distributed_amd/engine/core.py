@@ -1,0 +1,190 @@
+"""Engine core: scheduler + executor loop.
+
+``step()`` = schedule -> execute on all workers -> fold sampled tokens back
+into the scheduler.  When the executor allows several batches in flight
+(pipeline parallelism: one per stage; async scheduling: two - reference
+``src/launch.py:298-302``) ``step()`` keeps a queue of futures from the
+non-blocking ``execute_model`` path (reference ``src/launch.py:380-381``) and
+only blocks on the oldest one when nothing new can be scheduled.
+"""
+from __future__ import annotations
+
+import time
+from collections import deque
+from typing import Deque, Dict, Iterable, List, Optional, Tuple, Type
+
+from ..config import VllmConfig
+from ..executor.abstract import Executor
+from ..logger import init_logger
+from ..utils import cdiv
+from .request import Request, RequestStatus
+from .scheduler import EngineCoreOutput, Scheduler, SchedulerStats
+from .types import KVCacheConfig, ModelRunnerOutput, SchedulerOutput
+
+logger = init_logger(__name__)
+
+
+class EngineDeadError(RuntimeError):
+    pass
+
+
+class StepTimer:
+    """Rolling per-step breakdown: schedule / execute (RPC + forward + sample) / update."""
+
+    def __init__(self) -> None:
+        self.n = 0
+        self.tot = {"schedule": 0.0, "execute": 0.0, "update": 0.0,
+                    "worker_prepare": 0.0, "worker_forward": 0.0, "worker_sample": 0.0}
+
+    def add(self, **kw: float) -> None:
+        self.n += 1
+        for k, v in kw.items():
+            self.tot[k] = self.tot.get(k, 0.0) + v
+
+    def summary(self) -> Dict[str, float]:
+        n = max(self.n, 1)
+        d = {k + "_ms": 1e3 * v / n for k, v in self.tot.items()}
+        d["steps"] = self.n
+        d["rpc_overhead_ms"] = d["execute_ms"] - d["worker_prepare_ms"] - d["worker_forward_ms"] - d["worker_sample_ms"]
+        return d
+
+
+class EngineCore:
+    def __init__(self, vllm_config: VllmConfig, executor_class: Optional[Type[Executor]] = None):
+        self.vllm_config = vllm_config
+        executor_class = executor_class or Executor.get_class(vllm_config)
+        t0 = time.time()
+        self.executor = executor_class(vllm_config)
+        self.dead = False
+        self.executor.register_failure_callback(self._on_executor_failure)
+        num_blocks = self._initialize_kv_caches()
+        pp = vllm_config.parallel_config.pipeline_parallel_size
+        kv_connector = None
+        if vllm_config.kv_transfer_config is not None:
+            from ..executor.kv_transfer import make_scheduler_connector
+            kv_connector = make_scheduler_connector(vllm_config)
+        self.scheduler = Scheduler(vllm_config.scheduler_config, vllm_config.cache_config, num_blocks,
+                                   include_new_token_ids=pp > 1, kv_connector=kv_connector)
+        self.max_concurrent = max(1, self.executor.max_concurrent_batches)
+        self.batch_queue: Deque[Tuple[object, SchedulerOutput]] = deque()
+        self.timer = StepTimer()
+        logger.info("engine core ready in %.1fs (%d KV blocks, %d batches in flight)",
+                    time.time() - t0, num_blocks, self.max_concurrent)
+
+    # ----------------------------------------------------------------- setup
+    def _initialize_kv_caches(self) -> int:
+        cc = self.vllm_config.cache_config
+        specs = self.executor.get_kv_cache_specs()
+        avail = self.executor.determine_available_memory()
+        if cc.num_gpu_blocks_override is not None:
+            num_blocks = int(cc.num_gpu_blocks_override)
+        else:
+            num_blocks = min(int(a // s.bytes_per_block) for a, s in zip(avail, specs))
+            # no point holding more than every sequence at full length
+            cap = self.vllm_config.scheduler_config.max_num_seqs * cdiv(
+                self.vllm_config.model_config.max_model_len, cc.block_size)
+            num_blocks = min(num_blocks, cap)
+        need = cdiv(self.vllm_config.model_config.max_model_len, cc.block_size)
+        if num_blocks < need:
+            raise RuntimeError(
+                f"KV cache too small: {num_blocks} blocks of {cc.block_size} tokens, but one "
+                f"sequence of max_model_len={self.vllm_config.model_config.max_model_len} needs {need}; "
+                f"lower --max-model-len or raise --gpu-memory-utilization")
+        cc.num_gpu_blocks = num_blocks
+        self.executor.initialize_from_config([KVCacheConfig(num_blocks=num_blocks)] * len(specs))
+        return num_blocks
+
+    def _on_executor_failure(self) -> None:
+        logger.error("executor reported a failure: engine is dead")
+        self.dead = True
+
+    # -------------------------------------------------------------- requests
+    def add_request(self, request: Request) -> None:
+        self._check_alive()
+        self.scheduler.add_request(request)
+
+    def abort_requests(self, request_ids: Iterable[str]) -> List[str]:
+        return self.scheduler.abort_requests(request_ids)
+
+    def finish_requests(self, request_ids: Iterable[str], status: RequestStatus) -> None:
+        self.scheduler.finish_requests(request_ids, status)
+
+    def has_unfinished_requests(self) -> bool:
+        return self.scheduler.has_unfinished_requests() or bool(self.batch_queue)
+
+    def _check_alive(self) -> None:
+        if self.dead or self.executor.is_failed:
+            raise EngineDeadError("the executor failed; the engine cannot continue")
+
+    # ------------------------------------------------------------------ step
+    def step(self) -> List[EngineCoreOutput]:
+        self._check_alive()
+        if self.max_concurrent > 1:
+            return self._step_with_batch_queue()
+        if not self.scheduler.has_requests():
+            return []
+        t0 = time.perf_counter()
+        so = self.scheduler.schedule()
+        t1 = time.perf_counter()
+        if so.is_empty and not so.finished_req_ids and not so.preempted_req_ids:
+            return []
+        out = self.executor.execute_model(so)
+        t2 = time.perf_counter()
+        res = self.scheduler.update_from_output(so, out)
+        t3 = time.perf_counter()
+        self._record(t1 - t0, t2 - t1, t3 - t2, out)
+        return res
+
+    def _record(self, ts: float, te: float, tu: float, out: Optional[ModelRunnerOutput]) -> None:
+        wt = (out.timing if out is not None else None) or {}
+        self.timer.add(schedule=ts, execute=te, update=tu, worker_prepare=wt.get("prepare", 0.0),
+                       worker_forward=wt.get("forward", 0.0), worker_sample=wt.get("sample", 0.0))
+
+    def _step_with_batch_queue(self) -> List[EngineCoreOutput]:
+        """Fill the pipeline before draining it: schedule a new batch whenever
+        a slot is free and something is schedulable; otherwise wait for the
+        oldest in-flight batch."""
+        if len(self.batch_queue) < self.max_concurrent and self.scheduler.has_requests():
+            t0 = time.perf_counter()
+            so = self.scheduler.schedule()
+            t1 = time.perf_counter()
+            if not so.is_empty or so.finished_req_ids or so.preempted_req_ids:
+                fut = self.executor.execute_model(so, non_block=True)
+                self.batch_queue.append((fut, so))
+                self.timer.add(schedule=t1 - t0)
+                if len(self.batch_queue) < self.max_concurrent and not so.is_empty:
+                    return []            # try to put another batch in flight first
+        if not self.batch_queue:
+            return []
+        fut, so = self.batch_queue.popleft()
+        t0 = time.perf_counter()
+        out = fut.result()
+        t1 = time.perf_counter()
+        res = self.scheduler.update_from_output(so, out)
+        self.timer.tot["execute"] += t1 - t0
+        return res
+
+    # ----------------------------------------------------------------- admin
+    def stats(self) -> SchedulerStats:
+        return self.scheduler.make_stats()
+
+    def profile(self, is_start: bool = True) -> None:
+        self.executor.profile(is_start)
+
+    def reset_prefix_cache(self) -> bool:
+        return self.scheduler.reset_prefix_cache()
+
+    def sleep(self, level: int = 1) -> None:
+        self.executor.sleep(level)
+
+    def wake_up(self, tags=None) -> None:
+        self.executor.wake_up(tags)
+
+    def check_health(self) -> None:
+        self._check_alive()
+        self.executor.check_health()
+
+    def shutdown(self) -> None:
+        ex = getattr(self, "executor", None)
+        if ex is not None:
+            ex.shutdown()

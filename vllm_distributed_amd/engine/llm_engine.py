@@ -1,0 +1,184 @@
+"""Synchronous engine front-end and the offline ``LLM`` class.
+
+``LLMEngine`` = tokenizer + ``EngineCore`` + incremental detokenisation.
+It is what the benchmark and the offline API drive directly; the HTTP server
+wraps it in ``AsyncLLM``.
+"""
+from __future__ import annotations
+
+import itertools
+import time
+from typing import Dict, Iterable, List, Optional, Sequence, Type, Union
+
+from ..config import VllmConfig
+from ..executor.abstract import Executor
+from ..logger import init_logger
+from ..outputs import CompletionOutput, RequestOutput
+from ..sampling_params import SamplingParams
+from ..tokenizer import get_tokenizer
+from .arg_utils import EngineArgs
+from .core import EngineCore
+from .detokenizer import IncrementalDetokenizer
+from .request import Request, RequestStatus
+from .scheduler import EngineCoreOutput
+
+logger = init_logger(__name__)
+
+
+class _ReqState:
+    __slots__ = ("request", "detok", "prompt", "cumulative_logprob", "logprobs", "finish_reason",
+                 "stop_reason")
+
+    def __init__(self, request: Request, detok: Optional[IncrementalDetokenizer], prompt: Optional[str]):
+        self.request = request
+        self.detok = detok
+        self.prompt = prompt
+        self.cumulative_logprob: Optional[float] = None
+        self.logprobs: Optional[List[Dict[int, float]]] = None
+        self.finish_reason: Optional[str] = None
+        self.stop_reason = None
+
+
+class LLMEngine:
+    def __init__(self, vllm_config: VllmConfig, executor_class: Optional[Type[Executor]] = None,
+                 tokenizer=None):
+        self.vllm_config = vllm_config
+        self.model_config = vllm_config.model_config
+        self.tokenizer = tokenizer or get_tokenizer(self.model_config)
+        self.core = EngineCore(vllm_config, executor_class)
+        self.states: Dict[str, _ReqState] = {}
+        self._counter = itertools.count()
+        eos = self.model_config.hf_config.get("eos_token_id")
+        self.eos_token_id = eos[0] if isinstance(eos, list) else eos
+        if getattr(self.tokenizer, "eos_token_id", None) is not None:
+            self.eos_token_id = self.tokenizer.eos_token_id
+
+    @classmethod
+    def from_engine_args(cls, engine_args: EngineArgs) -> "LLMEngine":
+        return cls(engine_args.create_engine_config())
+
+    # -------------------------------------------------------------- requests
+    def add_request(self, request_id: Optional[str], prompt: Union[str, Sequence[int], dict],
+                    params: Optional[SamplingParams] = None, arrival_time: Optional[float] = None,
+                    priority: int = 0) -> str:
+        params = params or SamplingParams()
+        if request_id is None:
+            request_id = f"req-{next(self._counter)}"
+        text: Optional[str] = None
+        if isinstance(prompt, dict):
+            text = prompt.get("prompt")
+            ids = prompt.get("prompt_token_ids")
+            if ids is None:
+                ids = self.tokenizer.encode(text)
+        elif isinstance(prompt, str):
+            text, ids = prompt, self.tokenizer.encode(prompt)
+        else:
+            ids = list(prompt)
+        ids = list(ids)
+        max_len = self.model_config.max_model_len
+        if params.max_tokens is None:
+            params = params.clone()
+            params.max_tokens = max(1, max_len - len(ids))
+        vocab = self.model_config.vocab_size
+        if any(t < 0 or t >= vocab for t in ids):
+            raise ValueError("prompt contains token ids outside the model vocabulary")
+        req = Request(request_id, ids, params, self.eos_token_id, arrival_time, priority, text)
+        detok = IncrementalDetokenizer(self.tokenizer, ids, params) if params.detokenize else None
+        self.core.add_request(req)
+        self.states[request_id] = _ReqState(req, detok, text)
+        return request_id
+
+    def abort_request(self, request_ids: Union[str, Iterable[str]]) -> None:
+        if isinstance(request_ids, str):
+            request_ids = [request_ids]
+        request_ids = list(request_ids)
+        self.core.abort_requests(request_ids)
+        for rid in request_ids:
+            self.states.pop(rid, None)
+
+    def has_unfinished_requests(self) -> bool:
+        return self.core.has_unfinished_requests()
+
+    def get_num_unfinished_requests(self) -> int:
+        return self.core.scheduler.get_num_unfinished_requests()
+
+    # ------------------------------------------------------------------ step
+    def step(self) -> List[RequestOutput]:
+        return self._process(self.core.step())
+
+    def _process(self, core_outputs: List[EngineCoreOutput]) -> List[RequestOutput]:
+        outs: List[RequestOutput] = []
+        stop_hits: List[str] = []
+        for co in core_outputs:
+            st = self.states.get(co.request_id)
+            if st is None:
+                continue
+            req = st.request
+            finish_reason, stop_reason = co.finish_reason, co.stop_reason
+            if st.detok is not None:
+                hit = st.detok.append(co.new_token_ids)
+                if hit is not None and finish_reason is None:
+                    finish_reason, stop_reason = "stop", hit
+                    stop_hits.append(co.request_id)
+            if co.logprobs:
+                st.logprobs = (st.logprobs or []) + co.logprobs
+                for tok, lp in zip(co.new_token_ids, co.logprobs):
+                    if lp is not None and tok in lp:
+                        st.cumulative_logprob = (st.cumulative_logprob or 0.0) + lp[tok]
+            finished = finish_reason is not None
+            new_text = st.detok.take_delta(finished) if st.detok is not None else ""
+            comp = CompletionOutput(index=0, text=st.detok.text if st.detok is not None else "",
+                                    token_ids=list(req.output_token_ids),
+                                    cumulative_logprob=st.cumulative_logprob, logprobs=st.logprobs,
+                                    finish_reason=finish_reason, stop_reason=stop_reason)
+            outs.append(RequestOutput(request_id=co.request_id, prompt=st.prompt,
+                                      prompt_token_ids=req.prompt_token_ids, outputs=[comp],
+                                      finished=finished, metrics=req.metrics,
+                                      new_token_ids=list(co.new_token_ids), new_text=new_text))
+            if finished:
+                if req.metrics.finished_time is None:
+                    req.metrics.finished_time = time.time()
+                self.states.pop(co.request_id, None)
+        if stop_hits:
+            self.core.finish_requests(stop_hits, RequestStatus.FINISHED_STOPPED)
+        return outs
+
+    def shutdown(self) -> None:
+        self.core.shutdown()
+
+
+class LLM:
+    """Offline batch generation: ``LLM(model=...).generate(prompts, sampling_params)``."""
+
+    def __init__(self, model: str = "llama-tiny", **kwargs):
+        self.engine = LLMEngine.from_engine_args(EngineArgs(model=model, **kwargs))
+
+    def get_tokenizer(self):
+        return self.engine.tokenizer
+
+    def generate(self, prompts: Union[str, Sequence[Union[str, Sequence[int], dict]]],
+                 sampling_params: Union[None, SamplingParams, Sequence[SamplingParams]] = None,
+                 ) -> List[RequestOutput]:
+        if isinstance(prompts, (str, dict)) or (prompts and isinstance(prompts[0], int)):
+            prompts = [prompts]  # type: ignore[list-item]
+        n = len(prompts)
+        if sampling_params is None or isinstance(sampling_params, SamplingParams):
+            sps = [sampling_params or SamplingParams()] * n
+        else:
+            sps = list(sampling_params)
+        ids = [self.engine.add_request(None, p, sp) for p, sp in zip(prompts, sps)]
+        final: Dict[str, RequestOutput] = {}
+        while self.engine.has_unfinished_requests():
+            for out in self.engine.step():
+                if out.finished:
+                    final[out.request_id] = out
+        return [final[i] for i in ids]
+
+    def chat(self, messages: List[dict], sampling_params: Optional[SamplingParams] = None,
+             tools=None) -> List[RequestOutput]:
+        prompt = self.engine.tokenizer.apply_chat_template(messages, tokenize=False,
+                                                           add_generation_prompt=True, tools=tools)
+        return self.generate([prompt], sampling_params)
+
+    def shutdown(self) -> None:
+        self.engine.shutdown()

@@ -1,0 +1,346 @@
+"""Continuous-batching scheduler with chunked prefill and preemption.
+
+Every step hands out a token budget (``max_num_batched_tokens``): running
+requests first (decodes need one token; a partially prefilled prompt takes as
+much of its remainder as fits), then waiting requests in FCFS or priority
+order.  There is no separate prefill/decode phase - a step is just "request ->
+number of tokens to run".  When KV blocks run out the most recently admitted
+running request is preempted (blocks freed, recomputed later).
+
+A request's ``num_computed_tokens`` is advanced when it is *scheduled*, so with
+several batches in flight (pipeline parallelism / async scheduling,
+``max_concurrent_batches`` in reference ``src/launch.py:298-302``) a request
+whose next token is still being computed is simply not schedulable until
+``update_from_output`` appends that token.
+"""
+from __future__ import annotations
+
+import time
+from collections import deque
+from dataclasses import dataclass, field
+from typing import Deque, Dict, Iterable, List, Optional, Set, Tuple
+
+from ..config import CacheConfig, SchedulerConfig
+from ..logger import init_logger
+from .kv_cache_manager import KVCacheManager
+from .request import Request, RequestStatus
+from .types import (CachedRequestData, ModelRunnerOutput, NewRequestData, SchedulerOutput)
+
+logger = init_logger(__name__)
+
+
+@dataclass
+class EngineCoreOutput:
+    request_id: str
+    new_token_ids: List[int]
+    finish_reason: Optional[str] = None
+    stop_reason: Optional[object] = None
+    logprobs: Optional[List[Dict[int, float]]] = None
+    num_cached_tokens: int = 0
+
+
+@dataclass
+class SchedulerStats:
+    num_running: int = 0
+    num_waiting: int = 0
+    kv_cache_usage: float = 0.0
+    prefix_cache_queries: int = 0
+    prefix_cache_hits: int = 0
+    num_preemptions: int = 0
+
+
+class Scheduler:
+    def __init__(self, scheduler_config: SchedulerConfig, cache_config: CacheConfig,
+                 num_blocks: int, include_new_token_ids: bool = True,
+                 kv_connector=None):
+        self.config = scheduler_config
+        self.cache_config = cache_config
+        self.max_num_seqs = scheduler_config.max_num_seqs
+        self.max_num_batched_tokens = scheduler_config.max_num_batched_tokens
+        self.max_model_len = scheduler_config.max_model_len
+        self.kv = KVCacheManager(num_blocks, cache_config.block_size, self.max_model_len,
+                                 cache_config.enable_prefix_caching)
+        self.requests: Dict[str, Request] = {}
+        self.waiting: Deque[Request] = deque()
+        self.running: List[Request] = []
+        # ids the workers still hold state for and must drop on the next step
+        self._finished_since_last: Set[str] = set()
+        self._preempted_since_last: Set[str] = set()
+        # requests the workers already have cached state for
+        self._known_to_workers: Set[str] = set()
+        self._pending_new_tokens: Dict[str, List[int]] = {}
+        self.include_new_token_ids = include_new_token_ids
+        self.kv_connector = kv_connector
+        self.step_id = 0
+        self.num_preemptions = 0
+
+    # ---------------------------------------------------------------- intake
+    def add_request(self, request: Request) -> None:
+        if request.request_id in self.requests:
+            raise ValueError(f"duplicate request id {request.request_id}")
+        if request.num_prompt_tokens == 0:
+            raise ValueError("empty prompt")
+        if request.num_prompt_tokens >= self.max_model_len:
+            raise ValueError(f"prompt ({request.num_prompt_tokens} tokens) does not fit "
+                             f"max_model_len ({self.max_model_len})")
+        self.requests[request.request_id] = request
+        self._enqueue_waiting(request)
+
+    def _enqueue_waiting(self, request: Request, front: bool = False) -> None:
+        if self.config.policy == "priority":
+            items = list(self.waiting)
+            items.append(request)
+            items.sort(key=lambda r: (r.priority, r.arrival_time))
+            self.waiting = deque(items)
+        elif front:
+            self.waiting.appendleft(request)
+        else:
+            self.waiting.append(request)
+
+    def abort_requests(self, request_ids: Iterable[str]) -> List[str]:
+        aborted = []
+        for rid in list(request_ids):
+            req = self.requests.get(rid)
+            if req is None or req.finished:
+                continue
+            if req.status == RequestStatus.RUNNING:
+                self.running.remove(req)
+            else:
+                try:
+                    self.waiting.remove(req)
+                except ValueError:
+                    pass
+            req.status = RequestStatus.FINISHED_ABORTED
+            self._free_request(req)
+            aborted.append(rid)
+        return aborted
+
+    def has_unfinished_requests(self) -> bool:
+        return bool(self.waiting or self.running)
+
+    def has_requests(self) -> bool:
+        return self.has_unfinished_requests() or bool(self._finished_since_last)
+
+    def get_num_unfinished_requests(self) -> int:
+        return len(self.waiting) + len(self.running)
+
+    # -------------------------------------------------------------- schedule
+    def schedule(self) -> SchedulerOutput:
+        budget = self.max_num_batched_tokens
+        num_scheduled: Dict[str, int] = {}
+        new_reqs: List[NewRequestData] = []
+        cached = CachedRequestData()
+        preempted: List[Request] = []
+        now = time.time()
+
+        # 1. running requests
+        for req in list(self.running):
+            if budget <= 0:
+                break
+            if req.status != RequestStatus.RUNNING:
+                continue             # preempted earlier in this loop
+            n = req.num_tokens - req.num_computed_tokens
+            if n <= 0:               # its next token is still in flight
+                continue
+            n = min(n, budget)
+            if self.config.long_prefill_token_threshold > 0:
+                n = min(n, self.config.long_prefill_token_threshold)
+            n = min(n, self.max_model_len - req.num_computed_tokens)
+            if n <= 0:
+                continue
+            new_blocks = self.kv.allocate_slots(req, n)
+            while new_blocks is None:
+                victim = self._pick_victim(exclude_scheduled=num_scheduled)
+                if victim is None:
+                    break
+                self._preempt(victim)
+                preempted.append(victim)
+                if victim is req:
+                    break
+                new_blocks = self.kv.allocate_slots(req, n)
+            if new_blocks is None or req.status != RequestStatus.RUNNING:
+                continue
+            self._add_cached(cached, req, new_blocks)
+            num_scheduled[req.request_id] = n
+            req.num_computed_tokens += n
+            budget -= n
+
+        # 2. waiting requests (not while we are under memory pressure)
+        if not preempted:
+            while self.waiting and budget > 0 and len(self.running) < self.max_num_seqs:
+                req = self.waiting[0]
+                computed_blocks, num_cached = ([], 0)
+                if req.num_computed_tokens == 0:
+                    computed_blocks, num_cached = self.kv.get_computed_blocks(req)
+                n = req.num_tokens - num_cached
+                if not self.config.enable_chunked_prefill and n > budget:
+                    break
+                n = min(n, budget)
+                if self.config.long_prefill_token_threshold > 0:
+                    n = min(n, self.config.long_prefill_token_threshold)
+                if n <= 0:
+                    break
+                blocks = self.kv.allocate_slots(req, n, computed_blocks)
+                if blocks is None:
+                    break
+                self.waiting.popleft()
+                resumed = req.status == RequestStatus.PREEMPTED
+                req.status = RequestStatus.RUNNING
+                self.running.append(req)
+                if req.metrics.first_scheduled_time is None:
+                    req.metrics.first_scheduled_time = now
+                if req.num_cached_tokens < 0:
+                    req.num_cached_tokens = num_cached
+                    req.metrics.num_cached_tokens = num_cached
+                req.num_computed_tokens = num_cached
+                # workers dropped all state for finished/preempted requests, so
+                # (re)introduce it as new, carrying any tokens already generated
+                new_reqs.append(NewRequestData(
+                    req_id=req.request_id, prompt_token_ids=req.prompt_token_ids,
+                    sampling_params=req.sampling_params, block_ids=blocks,
+                    num_computed_tokens=num_cached,
+                    output_token_ids=list(req.output_token_ids) if resumed else []))
+                self._known_to_workers.add(req.request_id)
+                self._pending_new_tokens.pop(req.request_id, None)
+                num_scheduled[req.request_id] = n
+                req.num_computed_tokens += n
+                budget -= n
+
+        total = sum(num_scheduled.values())
+        out = SchedulerOutput(
+            step_id=self.step_id, scheduled_new_reqs=new_reqs, scheduled_cached_reqs=cached,
+            num_scheduled_tokens=num_scheduled, total_num_scheduled_tokens=total,
+            finished_req_ids=self._finished_since_last,
+            preempted_req_ids=self._preempted_since_last)
+        self._finished_since_last = set()
+        self._preempted_since_last = set()
+        if self.kv_connector is not None:
+            out.kv_connector_metadata = self.kv_connector.build_connector_meta(out)
+        self.step_id += 1
+        return out
+
+    def _add_cached(self, cached: CachedRequestData, req: Request, new_blocks: List[int]) -> None:
+        """Record a delta for an already-known request.  The list is sparse:
+        workers advance computed-token counts themselves, and TP ranks append
+        the tokens they sampled, so a request with no new block and no token
+        to forward needs no entry."""
+        if not new_blocks and req.request_id not in self._pending_new_tokens:
+            return
+        cached.req_ids.append(req.request_id)
+        cached.new_block_ids.append(new_blocks)
+        cached.num_computed_tokens.append(req.num_computed_tokens)
+        toks = self._pending_new_tokens.pop(req.request_id, None) if self.include_new_token_ids else None
+        cached.new_token_ids.append(toks or [])
+
+    def _pick_victim(self, exclude_scheduled: Dict[str, int]) -> Optional[Request]:
+        """Lowest-priority running request that is not already part of this
+        step's batch (its blocks are about to be written)."""
+        candidates = [r for r in self.running if r.request_id not in exclude_scheduled]
+        if not candidates:
+            return None
+        if self.config.policy == "priority":
+            return max(candidates, key=lambda r: (r.priority, r.arrival_time))
+        return candidates[-1]
+
+    def _preempt(self, req: Request) -> None:
+        self.running.remove(req)
+        self.kv.free(req)
+        req.status = RequestStatus.PREEMPTED
+        req.num_computed_tokens = 0
+        req.num_preemptions += 1
+        self.num_preemptions += 1
+        if req.request_id in self._known_to_workers:
+            self._known_to_workers.discard(req.request_id)
+            self._preempted_since_last.add(req.request_id)
+        self._pending_new_tokens.pop(req.request_id, None)
+        self._enqueue_waiting(req, front=True)
+
+    # ------------------------------------------------------------ post-step
+    def update_from_output(self, scheduler_output: SchedulerOutput,
+                           runner_output: ModelRunnerOutput) -> List[EngineCoreOutput]:
+        outputs: List[EngineCoreOutput] = []
+        sampled = dict(zip(runner_output.req_ids, runner_output.sampled_token_ids))
+        lps = dict(zip(runner_output.req_ids, runner_output.logprobs)) if runner_output.logprobs else {}
+        now = time.time()
+        for rid, n_sched in scheduler_output.num_scheduled_tokens.items():
+            req = self.requests.get(rid)
+            if req is None or req.finished or req.status != RequestStatus.RUNNING:
+                continue             # aborted / preempted while in flight
+            new_tokens = sampled.get(rid) or []
+            accepted: List[int] = []
+            for tok in new_tokens:
+                req.append_output_token(tok)
+                accepted.append(tok)
+                if self._check_stop(req, tok):
+                    break
+            # blocks that are now full and fully known can be shared
+            self.kv.cache_blocks(req, req.num_computed_tokens)
+            if accepted:
+                if req.metrics.first_token_time is None:
+                    req.metrics.first_token_time = now
+                req.metrics.num_generation_tokens = req.num_output_tokens
+                if self.include_new_token_ids and not req.finished:
+                    self._pending_new_tokens.setdefault(rid, []).extend(accepted)
+                req_lps = lps.get(rid)
+                outputs.append(EngineCoreOutput(
+                    request_id=rid, new_token_ids=accepted,
+                    finish_reason=req.status.finish_reason, stop_reason=req.stop_reason,
+                    logprobs=req_lps[:len(accepted)] if req_lps else None,
+                    num_cached_tokens=max(req.num_cached_tokens, 0)))
+            if req.finished:
+                req.metrics.finished_time = now
+                self.running.remove(req)
+                self._free_request(req)
+        return outputs
+
+    def _check_stop(self, req: Request, tok: int) -> bool:
+        sp = req.sampling_params
+        n_out = req.num_output_tokens
+        if n_out >= sp.min_tokens:
+            if not sp.ignore_eos and req.eos_token_id is not None and tok == req.eos_token_id:
+                req.status = RequestStatus.FINISHED_STOPPED
+                return True
+            if tok in sp.stop_token_ids:
+                req.status = RequestStatus.FINISHED_STOPPED
+                req.stop_reason = tok
+                return True
+        if (req.max_tokens is not None and n_out >= req.max_tokens) or \
+                req.num_tokens >= self.max_model_len:
+            req.status = RequestStatus.FINISHED_LENGTH
+            return True
+        return False
+
+    def finish_requests(self, request_ids: Iterable[str], status: RequestStatus) -> None:
+        """Front-end initiated finish (stop string matched, client went away)."""
+        for rid in request_ids:
+            req = self.requests.get(rid)
+            if req is None or req.finished:
+                continue
+            if req.status == RequestStatus.RUNNING:
+                self.running.remove(req)
+            else:
+                try:
+                    self.waiting.remove(req)
+                except ValueError:
+                    pass
+            req.status = status
+            self._free_request(req)
+
+    def _free_request(self, req: Request) -> None:
+        self.kv.free(req)
+        if req.request_id in self._known_to_workers:
+            self._known_to_workers.discard(req.request_id)
+            self._finished_since_last.add(req.request_id)
+        self._pending_new_tokens.pop(req.request_id, None)
+        self.requests.pop(req.request_id, None)
+
+    # ----------------------------------------------------------------- stats
+    def make_stats(self) -> SchedulerStats:
+        return SchedulerStats(num_running=len(self.running), num_waiting=len(self.waiting),
+                              kv_cache_usage=self.kv.usage,
+                              prefix_cache_queries=self.kv.prefix_queries,
+                              prefix_cache_hits=self.kv.prefix_hits,
+                              num_preemptions=self.num_preemptions)
+
+    def reset_prefix_cache(self) -> bool:
+        return self.kv.reset_prefix_cache()

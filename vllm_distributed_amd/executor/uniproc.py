@@ -1,0 +1,41 @@
+"""Single worker in the engine's own process (TP=PP=1)."""
+from __future__ import annotations
+
+import concurrent.futures
+from typing import Any, Callable, List, Optional, Union
+
+from ..utils import get_distributed_init_method, get_ip, get_open_port, run_method
+from ..worker.worker_base import WorkerWrapperBase
+from .abstract import Executor
+
+
+class UniProcExecutor(Executor):
+    def _init_executor(self) -> None:
+        assert self.parallel_config.world_size == 1, "UniProcExecutor runs exactly one worker"
+        self.driver = WorkerWrapperBase(self.vllm_config, rpc_rank=0)
+        kwargs = dict(vllm_config=self.vllm_config, local_rank=0, rank=0,
+                      distributed_init_method=None, is_driver_worker=True)
+        self.collective_rpc("init_worker", args=([kwargs],))
+        self.collective_rpc("init_device")
+        self.collective_rpc("load_model")
+
+    def collective_rpc(self, method: Union[str, Callable], timeout: Optional[float] = None,
+                       args: tuple = (), kwargs: Optional[dict] = None, non_block: bool = False,
+                       unique_reply_rank: Optional[int] = None) -> List[Any]:
+        if non_block:
+            fut: concurrent.futures.Future = concurrent.futures.Future()
+            try:
+                fut.set_result(run_method(self.driver, method, args, kwargs))
+            except BaseException as e:  # noqa: BLE001
+                fut.set_exception(e)
+            return [fut]
+        return [run_method(self.driver, method, args, kwargs)]
+
+    def shutdown(self) -> None:
+        drv = getattr(self, "driver", None)
+        if drv is not None and drv.worker is not None:
+            try:
+                drv.worker.shutdown()
+            except Exception:
+                pass
+            drv.worker = None

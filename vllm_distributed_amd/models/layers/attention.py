@@ -1,0 +1,124 @@
+"""Attention layer over the paged KV cache, plus the per-step forward context.
+
+The model runner publishes one ``AttentionMetadata`` per step; every layer's
+``Attention.forward`` reads it.  A batch is ordered decode-first: the first
+``num_decodes`` sequences contribute one query token each and go to the
+split-KV decode kernel; the rest (prompt chunks, possibly continuing a cached
+prefix) go to the varlen prefill kernel.  Both read K/V through block tables.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+
+
+@dataclass
+class AttentionMetadata:
+    num_decodes: int                 # sequences with q_len == 1, at the front
+    num_decode_tokens: int           # == num_decodes
+    num_prefills: int
+    num_prefill_tokens: int
+    slot_mapping: torch.Tensor       # [T] int32 (cache slot per token, -1 = skip)
+    block_table: torch.Tensor        # [B, max_blocks] int32
+    seq_lens: torch.Tensor           # [B] int32 (context length incl. this step)
+    query_start_loc: torch.Tensor    # [B+1] int32
+    max_query_len: int
+    max_seq_len: int
+    # prefill-only views (sequence index rebased to the prefill part)
+    prefill_query_start_loc: Optional[torch.Tensor] = None
+    max_prefill_query_len: int = 0
+    max_decode_seq_len: int = 0
+    decode_workspace: Optional[torch.Tensor] = None
+
+
+class ForwardContext:
+    attn_metadata: Optional[AttentionMetadata] = None
+    positions: Optional[torch.Tensor] = None
+
+
+_CTX = ForwardContext()
+
+
+def set_forward_context(attn_metadata: Optional[AttentionMetadata],
+                        positions: Optional[torch.Tensor] = None) -> None:
+    _CTX.attn_metadata = attn_metadata
+    _CTX.positions = positions
+
+
+def get_forward_context() -> ForwardContext:
+    return _CTX
+
+
+class Attention(nn.Module):
+    """Owns one layer's slice of the KV cache (bound by the model runner)."""
+
+    def __init__(self, num_heads: int, head_dim: int, num_kv_heads: int, scale: float,
+                 layer_idx: int):
+        super().__init__()
+        self.num_heads, self.head_dim, self.num_kv_heads = num_heads, head_dim, num_kv_heads
+        self.scale = scale
+        self.layer_idx = layer_idx
+        self.k_cache: Optional[torch.Tensor] = None
+        self.v_cache: Optional[torch.Tensor] = None
+
+    def bind_kv_cache(self, k_cache: torch.Tensor, v_cache: torch.Tensor) -> None:
+        self.k_cache, self.v_cache = k_cache, v_cache
+
+    def forward_cached(self, q: torch.Tensor) -> torch.Tensor:
+        """``q[T, Hq*D]`` (already rotated; this step's K/V already in the cache)."""
+        md = _CTX.attn_metadata
+        t = q.shape[0]
+        qv = q.view(t, self.num_heads, self.head_dim)
+        if md is None:               # memory-profiling pass: no cache bound
+            return q
+        out = torch.empty((t, self.num_heads, self.head_dim), dtype=q.dtype, device=q.device)
+        nd = md.num_decode_tokens
+        if nd > 0:
+            ops.paged_attention_decode(
+                qv[:nd], self.k_cache, self.v_cache, md.block_table[:md.num_decodes],
+                md.seq_lens[:md.num_decodes], self.scale, md.max_decode_seq_len,
+                out=out[:nd], workspace=md.decode_workspace)
+        if md.num_prefills > 0:
+            ops.paged_attention(
+                qv[nd:], self.k_cache, self.v_cache, md.block_table[md.num_decodes:],
+                md.prefill_query_start_loc, md.seq_lens[md.num_decodes:], self.scale,
+                md.max_prefill_query_len, md.max_seq_len, out=out[nd:])
+        return out.view(t, self.num_heads * self.head_dim)
+
+    def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+        """Unfused path: write k/v (``[T, Hkv*D]``) to the cache, then attend."""
+        md = _CTX.attn_metadata
+        if md is not None:
+            t = k.shape[0]
+            ops.reshape_and_cache(k.reshape(t, self.num_kv_heads, self.head_dim),
+                                  v.reshape(t, self.num_kv_heads, self.head_dim),
+                                  self.k_cache, self.v_cache, md.slot_mapping)
+        return self.forward_cached(q)
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, hidden_size: int, eps: float, dtype: torch.dtype):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size, dtype=dtype), requires_grad=False)
+        self.eps = eps
+
+    def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None):
+        if residual is None:
+            return ops.rms_norm(x, self.weight, self.eps)
+        return ops.fused_add_rms_norm(x, residual, self.weight, self.eps)
+
+
+class LayerNorm(nn.Module):
+    def __init__(self, hidden_size: int, eps: float, dtype: torch.dtype, bias: bool = True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size, dtype=dtype), requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(hidden_size, dtype=dtype), requires_grad=False) if bias else None
+        self.eps = eps
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.layer_norm(x, self.weight, self.bias, self.eps)

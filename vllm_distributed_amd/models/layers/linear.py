@@ -1,0 +1,207 @@
+"""Tensor-parallel linear layers and embeddings.
+
+Column-parallel layers shard the output dimension (no communication); the
+row-parallel layer that follows shards the input dimension and all-reduces its
+partial sums - two all-reduces per transformer layer.  Weights are stored
+``[out, in]`` and each rank loads only its slice (``weight_loader``).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import ops
+from ...parallel.state import (get_tensor_model_parallel_rank,
+                               get_tensor_model_parallel_world_size,
+                               tensor_model_parallel_all_gather,
+                               tensor_model_parallel_all_reduce)
+
+
+def _param(*shape: int, dtype: torch.dtype) -> nn.Parameter:
+    return nn.Parameter(torch.empty(*shape, dtype=dtype), requires_grad=False)
+
+
+def divide(a: int, b: int) -> int:
+    assert a % b == 0, f"{a} is not divisible by {b}"
+    return a // b
+
+
+class ReplicatedLinear(nn.Module):
+    def __init__(self, in_features: int, out_features: int, bias: bool, dtype: torch.dtype):
+        super().__init__()
+        self.weight = _param(out_features, in_features, dtype=dtype)
+        self.bias = _param(out_features, dtype=dtype) if bias else None
+        self.weight.weight_loader = self._load      # type: ignore[attr-defined]
+        if self.bias is not None:
+            self.bias.weight_loader = self._load    # type: ignore[attr-defined]
+
+    @staticmethod
+    def _load(param: nn.Parameter, w: torch.Tensor, shard_id=None) -> None:
+        assert param.shape == w.shape, (param.shape, w.shape)
+        param.data.copy_(w)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return F.linear(x, self.weight, self.bias)
+
+
+class ColumnParallelLinear(nn.Module):
+    """``y = x W^T`` with ``W`` split along ``out``.  ``output_sizes`` lists the
+    logical sub-matrices fused into this layer (e.g. gate and up), each sharded
+    independently so a rank's slice stays ``[gate_i | up_i]``."""
+
+    def __init__(self, in_features: int, output_sizes: Sequence[int], bias: bool,
+                 dtype: torch.dtype, gather_output: bool = False):
+        super().__init__()
+        self.tp = get_tensor_model_parallel_world_size()
+        self.tp_rank = get_tensor_model_parallel_rank()
+        self.output_sizes = list(output_sizes)
+        self.shard_sizes = [divide(s, self.tp) for s in self.output_sizes]
+        self.gather_output = gather_output
+        out_local = sum(self.shard_sizes)
+        self.weight = _param(out_local, in_features, dtype=dtype)
+        self.bias = _param(out_local, dtype=dtype) if bias else None
+        self.weight.weight_loader = self.weight_loader      # type: ignore[attr-defined]
+        if self.bias is not None:
+            self.bias.weight_loader = self.weight_loader    # type: ignore[attr-defined]
+
+    def weight_loader(self, param: nn.Parameter, w: torch.Tensor, shard_id: Optional[int] = None) -> None:
+        """``shard_id`` = index into ``output_sizes``; None = the full fused matrix."""
+        if shard_id is None:
+            assert w.shape[0] == sum(self.output_sizes), (w.shape, self.output_sizes)
+            off = 0
+            for i, s in enumerate(self.output_sizes):
+                self.weight_loader(param, w.narrow(0, off, s), i)
+                off += s
+            return
+        size = self.shard_sizes[shard_id]
+        dst_off = sum(self.shard_sizes[:shard_id])
+        src = w.narrow(0, self.tp_rank * size, size)
+        param.data.narrow(0, dst_off, size).copy_(src)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        y = F.linear(x, self.weight, self.bias)
+        if self.gather_output and self.tp > 1:
+            y = tensor_model_parallel_all_gather(y, dim=-1)
+        return y
+
+
+class QKVParallelLinear(nn.Module):
+    """Fused q/k/v projection.  Query heads are split across ranks; KV heads
+    are split when there are at least ``tp`` of them, else replicated."""
+
+    def __init__(self, hidden_size: int, head_dim: int, num_heads: int, num_kv_heads: int,
+                 bias: bool, dtype: torch.dtype):
+        super().__init__()
+        self.tp = get_tensor_model_parallel_world_size()
+        self.tp_rank = get_tensor_model_parallel_rank()
+        self.head_dim = head_dim
+        self.total_heads, self.total_kv_heads = num_heads, num_kv_heads
+        self.num_heads = divide(num_heads, self.tp)
+        if num_kv_heads >= self.tp:
+            self.num_kv_heads = divide(num_kv_heads, self.tp)
+            self.kv_replicas = 1
+        else:
+            self.num_kv_heads = 1
+            self.kv_replicas = divide(self.tp, num_kv_heads)
+        self.q_size = self.num_heads * head_dim
+        self.kv_size = self.num_kv_heads * head_dim
+        out_local = self.q_size + 2 * self.kv_size
+        self.weight = _param(out_local, hidden_size, dtype=dtype)
+        self.bias = _param(out_local, dtype=dtype) if bias else None
+        self.weight.weight_loader = self.weight_loader      # type: ignore[attr-defined]
+        if self.bias is not None:
+            self.bias.weight_loader = self.weight_loader    # type: ignore[attr-defined]
+
+    def weight_loader(self, param: nn.Parameter, w: torch.Tensor, shard_id: Optional[str] = None) -> None:
+        if shard_id is None:      # full fused [q | k | v]
+            qs, ks = self.total_heads * self.head_dim, self.total_kv_heads * self.head_dim
+            self.weight_loader(param, w.narrow(0, 0, qs), "q")
+            self.weight_loader(param, w.narrow(0, qs, ks), "k")
+            self.weight_loader(param, w.narrow(0, qs + ks, ks), "v")
+            return
+        if shard_id == "q":
+            size, dst, src_idx = self.q_size, 0, self.tp_rank
+        else:
+            size = self.kv_size
+            dst = self.q_size + (0 if shard_id == "k" else self.kv_size)
+            src_idx = self.tp_rank // self.kv_replicas
+        param.data.narrow(0, dst, size).copy_(w.narrow(0, src_idx * size, size))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return F.linear(x, self.weight, self.bias)
+
+
+class RowParallelLinear(nn.Module):
+    def __init__(self, in_features: int, out_features: int, bias: bool, dtype: torch.dtype,
+                 reduce_results: bool = True):
+        super().__init__()
+        self.tp = get_tensor_model_parallel_world_size()
+        self.tp_rank = get_tensor_model_parallel_rank()
+        self.in_local = divide(in_features, self.tp)
+        self.reduce_results = reduce_results
+        self.weight = _param(out_features, self.in_local, dtype=dtype)
+        self.bias = _param(out_features, dtype=dtype) if bias else None
+        self.weight.weight_loader = self.weight_loader      # type: ignore[attr-defined]
+        if self.bias is not None:
+            self.bias.weight_loader = ReplicatedLinear._load    # type: ignore[attr-defined]
+
+    def weight_loader(self, param: nn.Parameter, w: torch.Tensor, shard_id=None) -> None:
+        param.data.copy_(w.narrow(1, self.tp_rank * self.in_local, self.in_local))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        # bias is added once (rank 0) so the all-reduce does not multiply it
+        y = F.linear(x, self.weight, self.bias if self.tp_rank == 0 else None)
+        if self.reduce_results and self.tp > 1:
+            y = tensor_model_parallel_all_reduce(y)
+        return y
+
+
+def pad_vocab(vocab_size: int, tp: int, multiple: int = 64) -> int:
+    m = multiple * tp
+    return (vocab_size + m - 1) // m * m
+
+
+class VocabParallelEmbedding(nn.Module):
+    def __init__(self, vocab_size: int, hidden_size: int, dtype: torch.dtype):
+        super().__init__()
+        self.tp = get_tensor_model_parallel_world_size()
+        self.tp_rank = get_tensor_model_parallel_rank()
+        self.vocab_size = vocab_size
+        self.padded_vocab = pad_vocab(vocab_size, self.tp)
+        self.rows = self.padded_vocab // self.tp
+        self.vocab_start = self.tp_rank * self.rows
+        self.weight = _param(self.rows, hidden_size, dtype=dtype)
+        self.weight.weight_loader = self.weight_loader      # type: ignore[attr-defined]
+
+    def weight_loader(self, param: nn.Parameter, w: torch.Tensor, shard_id=None) -> None:
+        start = self.vocab_start
+        end = min(start + self.rows, w.shape[0])
+        n = max(0, end - start)
+        if n > 0:
+            param.data[:n].copy_(w[start:end])
+        if n < self.rows:
+            param.data[n:].zero_()
+
+    def forward(self, ids: torch.Tensor) -> torch.Tensor:
+        out = ops.embedding(ids, self.weight, self.vocab_start, masked=self.tp > 1)
+        if self.tp > 1:
+            out = tensor_model_parallel_all_reduce(out)
+        return out
+
+
+class ParallelLMHead(VocabParallelEmbedding):
+    """Vocab-sharded output projection; ``logits`` all-gathers so every rank of
+    the TP group samples from the same full-vocab row."""
+
+    def __init__(self, vocab_size: int, hidden_size: int, dtype: torch.dtype, bias: bool = False):
+        super().__init__(vocab_size, hidden_size, dtype)
+        self.bias = _param(self.rows, dtype=dtype) if bias else None
+
+    def logits(self, hidden: torch.Tensor) -> torch.Tensor:
+        y = F.linear(hidden, self.weight, self.bias)
+        if self.tp > 1:
+            y = tensor_model_parallel_all_gather(y, dim=-1)
+        return y[..., :self.vocab_size]

@@ -1,0 +1,209 @@
+"""Llama-family decoder (Llama-2/3, Mistral, Qwen2, Qwen3 dense).
+
+Per layer: fused add+RMSNorm -> fused QKV GEMM -> fused rotary + KV-cache
+write -> paged attention -> O GEMM (+all-reduce) -> fused add+RMSNorm ->
+gate/up GEMM -> SiLU*mul -> down GEMM (+all-reduce).  A pipeline stage owns a
+contiguous slice of layers; the first stage embeds, the last applies the final
+norm and the LM head, and ``(hidden, residual)`` crosses stage boundaries.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..config import VllmConfig
+from ..parallel.state import get_pp_group
+from .layers.attention import Attention, RMSNorm, get_forward_context
+from .layers.linear import (ColumnParallelLinear, ParallelLMHead, QKVParallelLinear,
+                            RowParallelLinear, VocabParallelEmbedding)
+from .utils import IntermediateTensors, get_pp_layer_range
+
+
+class LlamaMLP(nn.Module):
+    def __init__(self, hidden: int, inter: int, dtype: torch.dtype, bias: bool = False):
+        super().__init__()
+        self.gate_up_proj = ColumnParallelLinear(hidden, [inter, inter], bias, dtype)
+        self.down_proj = RowParallelLinear(inter, hidden, bias, dtype)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.down_proj(ops.silu_and_mul(self.gate_up_proj(x)))
+
+
+class LlamaAttention(nn.Module):
+    def __init__(self, cfg: dict, layer_idx: int, dtype: torch.dtype, cos_sin: torch.Tensor):
+        super().__init__()
+        hidden = cfg["hidden_size"]
+        heads = cfg["num_attention_heads"]
+        kv_heads = cfg.get("num_key_value_heads") or heads
+        self.head_dim = cfg.get("head_dim") or hidden // heads
+        bias = bool(cfg.get("attention_bias", False)) or cfg.get("model_type") == "qwen2"
+        self.qkv_proj = QKVParallelLinear(hidden, self.head_dim, heads, kv_heads, bias, dtype)
+        self.o_proj = RowParallelLinear(heads * self.head_dim, hidden,
+                                        bool(cfg.get("attention_bias", False)), dtype)
+        self.num_heads = self.qkv_proj.num_heads
+        self.num_kv_heads = self.qkv_proj.num_kv_heads
+        self.q_size, self.kv_size = self.qkv_proj.q_size, self.qkv_proj.kv_size
+        self.cos_sin = cos_sin
+        self.qk_norm = cfg.get("model_type") in ("qwen3", "qwen3_moe")
+        if self.qk_norm:
+            eps = cfg.get("rms_norm_eps", 1e-6)
+            self.q_norm = RMSNorm(self.head_dim, eps, dtype)
+            self.k_norm = RMSNorm(self.head_dim, eps, dtype)
+        self.attn = Attention(self.num_heads, self.head_dim, self.num_kv_heads,
+                              self.head_dim ** -0.5, layer_idx)
+
+    def forward(self, positions: torch.Tensor, hidden: torch.Tensor) -> torch.Tensor:
+        qkv = self.qkv_proj(hidden)
+        md = get_forward_context().attn_metadata
+        if self.qk_norm:
+            t = qkv.shape[0]
+            q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+            q = self.q_norm(q.reshape(t * self.num_heads, self.head_dim)).view(t, self.q_size)
+            k = self.k_norm(k.reshape(t * self.num_kv_heads, self.head_dim)).view(t, self.kv_size)
+            ops.rotary_embedding(positions, q, k, self.cos_sin, self.head_dim)
+            out = self.attn(q, k, v)
+        elif md is None:
+            q = qkv[:, :self.q_size]
+            out = self.attn.forward_cached(q)
+        else:
+            q = ops.rope_and_cache(positions, qkv, self.cos_sin, self.attn.k_cache,
+                                   self.attn.v_cache, md.slot_mapping, self.num_heads,
+                                   self.num_kv_heads, self.head_dim)
+            out = self.attn.forward_cached(q)
+        return self.o_proj(out)
+
+
+class LlamaDecoderLayer(nn.Module):
+    def __init__(self, cfg: dict, layer_idx: int, dtype: torch.dtype, cos_sin: torch.Tensor):
+        super().__init__()
+        eps = cfg.get("rms_norm_eps", 1e-5)
+        self.self_attn = LlamaAttention(cfg, layer_idx, dtype, cos_sin)
+        self.mlp = self._make_mlp(cfg, dtype)
+        self.input_layernorm = RMSNorm(cfg["hidden_size"], eps, dtype)
+        self.post_attention_layernorm = RMSNorm(cfg["hidden_size"], eps, dtype)
+
+    def _make_mlp(self, cfg: dict, dtype: torch.dtype) -> nn.Module:
+        return LlamaMLP(cfg["hidden_size"], cfg["intermediate_size"], dtype,
+                        bool(cfg.get("mlp_bias", False)))
+
+    def forward(self, positions: torch.Tensor, hidden: torch.Tensor,
+                residual: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+        if residual is None:
+            residual = hidden
+            hidden = self.input_layernorm(hidden)
+        else:
+            hidden, residual = self.input_layernorm(hidden, residual)
+        hidden = self.self_attn(positions, hidden)
+        hidden, residual = self.post_attention_layernorm(hidden, residual)
+        hidden = self.mlp(hidden)
+        return hidden, residual
+
+
+class LlamaForCausalLM(nn.Module):
+    layer_cls = LlamaDecoderLayer
+    # checkpoint name fragment -> (fused param fragment, shard id)
+    stacked_params = [
+        (".q_proj", ".qkv_proj", "q"), (".k_proj", ".qkv_proj", "k"), (".v_proj", ".qkv_proj", "v"),
+        (".gate_proj", ".gate_up_proj", 0), (".up_proj", ".gate_up_proj", 1),
+    ]
+
+    def __init__(self, vllm_config: VllmConfig):
+        super().__init__()
+        mc = vllm_config.model_config
+        cfg = mc.hf_config
+        dtype = mc.torch_dtype
+        self.cfg = cfg
+        pp = get_pp_group()
+        self.is_first, self.is_last = pp.is_first_rank, pp.is_last_rank
+        n_layers = cfg["num_hidden_layers"]
+        self.start_layer, self.end_layer = get_pp_layer_range(
+            n_layers, pp.rank_in_group, pp.world_size, vllm_config.parallel_config.pp_layer_partition)
+        head_dim = cfg.get("head_dim") or cfg["hidden_size"] // cfg["num_attention_heads"]
+        cos_sin = ops.build_cos_sin_cache(head_dim, mc.max_model_len, cfg.get("rope_theta", 10000.0),
+                                          cfg.get("rope_scaling"))
+        self.register_buffer("cos_sin_cache", cos_sin, persistent=False)
+        tie = bool(cfg.get("tie_word_embeddings", False))
+        if self.is_first or (tie and self.is_last):
+            self.embed_tokens = VocabParallelEmbedding(cfg["vocab_size"], cfg["hidden_size"], dtype)
+        self.layers = nn.ModuleDict({
+            str(i): self.layer_cls(cfg, i, dtype, self.cos_sin_cache)
+            for i in range(self.start_layer, self.end_layer)})
+        if self.is_last:
+            self.norm = RMSNorm(cfg["hidden_size"], cfg.get("rms_norm_eps", 1e-5), dtype)
+            if tie:
+                self.lm_head = None
+            else:
+                self.lm_head = ParallelLMHead(cfg["vocab_size"], cfg["hidden_size"], dtype)
+        self.tie = tie
+
+    def rebind_buffers(self) -> None:
+        """After ``.to(device)`` the layers must see the moved cos/sin table."""
+        for layer in self.layers.values():
+            layer.self_attn.cos_sin = self.cos_sin_cache
+
+    def attention_layers(self) -> List[Attention]:
+        return [layer.self_attn.attn for layer in self.layers.values()]
+
+    def forward(self, input_ids: Optional[torch.Tensor], positions: torch.Tensor,
+                intermediate: Optional[IntermediateTensors] = None):
+        if self.is_first:
+            hidden = self.embed_tokens(input_ids)
+            residual = None
+        else:
+            hidden, residual = intermediate.hidden, intermediate.residual
+        for layer in self.layers.values():
+            hidden, residual = layer(positions, hidden, residual)
+        if not self.is_last:
+            return IntermediateTensors(hidden, residual)
+        hidden, _ = self.norm(hidden, residual)
+        return hidden
+
+    def compute_logits(self, hidden: torch.Tensor) -> torch.Tensor:
+        if self.lm_head is not None:
+            return self.lm_head.logits(hidden)
+        w = self.embed_tokens
+        y = torch.nn.functional.linear(hidden, w.weight)
+        if w.tp > 1:
+            from ..parallel.state import tensor_model_parallel_all_gather
+            y = tensor_model_parallel_all_gather(y, dim=-1)
+        return y[..., :w.vocab_size]
+
+    # ------------------------------------------------------------- weights
+    def _owns_layer(self, name: str) -> bool:
+        if ".layers." not in name:
+            return True
+        idx = int(name.split(".layers.")[1].split(".")[0])
+        return self.start_layer <= idx < self.end_layer
+
+    def map_weight_name(self, name: str) -> Optional[str]:
+        if name.startswith("model."):
+            name = name[len("model."):]
+        if "rotary_emb.inv_freq" in name:
+            return None
+        return name
+
+    def load_weights(self, weights: Iterable[Tuple[str, torch.Tensor]]) -> List[str]:
+        params: Dict[str, nn.Parameter] = dict(self.named_parameters())
+        loaded: List[str] = []
+        for name, w in weights:
+            name = self.map_weight_name(name)
+            if name is None or not self._owns_layer(name):
+                continue
+            target, shard = name, None
+            for frag, fused, sid in self.stacked_params:
+                if frag in name:
+                    target, shard = name.replace(frag, fused), sid
+                    break
+            p = params.get(target)
+            if p is None:
+                continue             # e.g. lm_head on a non-last stage
+            loader = getattr(p, "weight_loader", None)
+            if loader is None:
+                p.data.copy_(w)
+            else:
+                loader(p, w, shard)
+            loaded.append(name)
+        return loaded

@@ -1,0 +1,229 @@
+"""Model construction and weight loading.
+
+``load_model`` builds the architecture for this rank's (TP, PP) coordinates
+directly on the target device and fills it from one of:
+
+* safetensors shards in a local directory / the HF hub cache (each rank copies
+  only the slices it owns; reached through ``collective_rpc("load_model")`` in
+  the reference, ``src/launch.py:292``);
+* deterministic random weights (``load_format=dummy``): every *checkpoint*
+  tensor is generated whole from a seed derived from its name and then sharded
+  by the same ``weight_loader`` path, so TP/PP shards of a dummy model are
+  exactly the shards of one fixed full model;
+* AWQ 4-bit checkpoints (the reference's documented model is AWQ,
+  ``.env.server:11``): ``qweight/qzeros/scales`` triples are dequantised to the
+  compute dtype at load time.
+"""
+from __future__ import annotations
+
+import glob
+import hashlib
+import json
+import os
+import re
+from typing import Callable, Dict, Iterable, Iterator, List, Optional, Tuple
+
+import torch
+
+from ..config import ModelConfig, VllmConfig, resolve_model_path
+from ..logger import init_logger
+from .registry import get_model_class
+
+logger = init_logger(__name__)
+
+
+# ------------------------------------------------------------ dummy weights
+def _seed_for(name: str, base_seed: int) -> int:
+    h = hashlib.blake2b(f"{base_seed}:{name}".encode(), digest_size=8).digest()
+    return int.from_bytes(h, "little") & ((1 << 62) - 1)
+
+
+def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
+    """Checkpoint tensor names and shapes for the supported architectures."""
+    c = mc.hf_config
+    arch = mc.architecture
+    h = c["hidden_size"]
+    L = c.get("num_hidden_layers", 0)
+    shapes: Dict[str, Tuple[int, ...]] = {}
+    if arch == "OPTForCausalLM":
+        proj = c.get("word_embed_proj_dim", h)
+        ffn = c["ffn_dim"]
+        p = "model.decoder."
+        shapes[p + "embed_tokens.weight"] = (c["vocab_size"], proj)
+        shapes[p + "embed_positions.weight"] = (c["max_position_embeddings"] + 2, h)
+        if proj != h:
+            shapes[p + "project_in.weight"] = (h, proj)
+            shapes[p + "project_out.weight"] = (proj, h)
+        if c.get("do_layer_norm_before", True):
+            shapes[p + "final_layer_norm.weight"] = (h,)
+            shapes[p + "final_layer_norm.bias"] = (h,)
+        for i in range(L):
+            q = f"{p}layers.{i}."
+            for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                shapes[q + f"self_attn.{n}.weight"] = (h, h)
+                shapes[q + f"self_attn.{n}.bias"] = (h,)
+            shapes[q + "fc1.weight"], shapes[q + "fc1.bias"] = (ffn, h), (ffn,)
+            shapes[q + "fc2.weight"], shapes[q + "fc2.bias"] = (h, ffn), (h,)
+            for n in ("self_attn_layer_norm", "final_layer_norm"):
+                shapes[q + n + ".weight"] = (h,)
+                shapes[q + n + ".bias"] = (h,)
+        return shapes
+    heads = c["num_attention_heads"]
+    kvh = c.get("num_key_value_heads") or heads
+    hd = c.get("head_dim") or h // heads
+    inter = c.get("intermediate_size", 0)
+    moe = arch == "Qwen3MoeForCausalLM"
+    qkv_bias = bool(c.get("attention_bias", False)) or c.get("model_type") == "qwen2"
+    shapes["model.embed_tokens.weight"] = (c["vocab_size"], h)
+    shapes["model.norm.weight"] = (h,)
+    if not c.get("tie_word_embeddings", False):
+        shapes["lm_head.weight"] = (c["vocab_size"], h)
+    for i in range(L):
+        q = f"model.layers.{i}."
+        shapes[q + "self_attn.q_proj.weight"] = (heads * hd, h)
+        shapes[q + "self_attn.k_proj.weight"] = (kvh * hd, h)
+        shapes[q + "self_attn.v_proj.weight"] = (kvh * hd, h)
+        shapes[q + "self_attn.o_proj.weight"] = (h, heads * hd)
+        if qkv_bias:
+            shapes[q + "self_attn.q_proj.bias"] = (heads * hd,)
+            shapes[q + "self_attn.k_proj.bias"] = (kvh * hd,)
+            shapes[q + "self_attn.v_proj.bias"] = (kvh * hd,)
+        if c.get("model_type") in ("qwen3", "qwen3_moe"):
+            shapes[q + "self_attn.q_norm.weight"] = (hd,)
+            shapes[q + "self_attn.k_norm.weight"] = (hd,)
+        shapes[q + "input_layernorm.weight"] = (h,)
+        shapes[q + "post_attention_layernorm.weight"] = (h,)
+        step = c.get("decoder_sparse_step", 1)
+        sparse = moe and c.get("num_experts", 0) > 0 and i not in c.get("mlp_only_layers", []) \
+            and (i + 1) % step == 0
+        if sparse:
+            mi = c["moe_intermediate_size"]
+            shapes[q + "mlp.gate.weight"] = (c["num_experts"], h)
+            for e in range(c["num_experts"]):
+                shapes[q + f"mlp.experts.{e}.gate_proj.weight"] = (mi, h)
+                shapes[q + f"mlp.experts.{e}.up_proj.weight"] = (mi, h)
+                shapes[q + f"mlp.experts.{e}.down_proj.weight"] = (h, mi)
+        else:
+            shapes[q + "mlp.gate_proj.weight"] = (inter, h)
+            shapes[q + "mlp.up_proj.weight"] = (inter, h)
+            shapes[q + "mlp.down_proj.weight"] = (h, inter)
+    return shapes
+
+
+def dummy_weights_iterator(mc: ModelConfig, device: torch.device,
+                           want: Optional[Callable[[str], bool]] = None,
+                           ) -> Iterator[Tuple[str, torch.Tensor]]:
+    dtype = mc.torch_dtype
+    gen = torch.Generator(device=device)
+    for name, shape in hf_weight_shapes(mc).items():
+        if want is not None and not want(name):
+            continue
+        gen.manual_seed(_seed_for(name, mc.seed))
+        if re.search(r"(layernorm|layer_norm|norm)\.weight$", name):
+            w = 1.0 + 0.05 * (torch.rand(shape, generator=gen, device=device, dtype=torch.float32) - 0.5)
+            w = w.to(dtype)
+        elif name.endswith(".bias"):
+            w = (0.02 * (torch.rand(shape, generator=gen, device=device, dtype=torch.float32) - 0.5)).to(dtype)
+        else:
+            fan_in = shape[-1]
+            scale = (3.0 / fan_in) ** 0.5      # unit-variance-preserving uniform
+            if "embed" in name:
+                scale = 0.05
+            w = torch.empty(shape, device=device, dtype=dtype)
+            w.uniform_(-scale, scale, generator=gen)
+        yield name, w
+
+
+# ------------------------------------------------------------- safetensors
+_AWQ_ORDER = [0, 4, 1, 5, 2, 6, 3, 7]
+
+
+def awq_dequantize(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
+                   dtype: torch.dtype) -> torch.Tensor:
+    """AWQ GEMM-format 4-bit -> ``[out, in]`` dense.  ``qweight[in, out/8]`` int32
+    packs 8 nibbles per word in the order 0,4,1,5,2,6,3,7; ``qzeros[in/g, out/8]``
+    likewise; ``scales[in/g, out]``."""
+    shifts = torch.tensor([4 * _AWQ_ORDER.index(i) for i in range(8)], dtype=torch.int32,
+                          device=qweight.device)
+
+    def unpack(x: torch.Tensor) -> torch.Tensor:
+        u = (x.unsqueeze(-1) >> shifts) & 0xF           # [..., out/8, 8]
+        return u.reshape(x.shape[0], -1)
+    w = unpack(qweight).to(torch.float32)               # [in, out]
+    z = unpack(qzeros).to(torch.float32)                # [in/g, out]
+    g = w.shape[0] // scales.shape[0]
+    z = z.repeat_interleave(g, dim=0)
+    s = scales.to(torch.float32).repeat_interleave(g, dim=0)
+    return ((w - z) * s).t().contiguous().to(dtype)
+
+
+def safetensors_weights_iterator(path: str, dtype: torch.dtype,
+                                 want: Optional[Callable[[str], bool]] = None,
+                                 ) -> Iterator[Tuple[str, torch.Tensor]]:
+    from safetensors import safe_open
+    files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+    if not files:
+        raise FileNotFoundError(f"no *.safetensors under {path}")
+    index = os.path.join(path, "model.safetensors.index.json")
+    if os.path.isfile(index):
+        with open(index) as f:
+            wanted_files = sorted(set(json.load(f)["weight_map"].values()))
+        files = [os.path.join(path, w) for w in wanted_files if os.path.isfile(os.path.join(path, w))]
+    for fn in files:
+        with safe_open(fn, framework="pt", device="cpu") as f:
+            keys = list(f.keys())
+            awq_done = set()
+            for k in keys:
+                if k.endswith((".qzeros", ".scales")):
+                    continue
+                if k.endswith(".qweight"):
+                    base = k[:-len(".qweight")]
+                    name = base + ".weight"
+                    if want is not None and not want(name):
+                        continue
+                    yield name, awq_dequantize(f.get_tensor(k), f.get_tensor(base + ".qzeros"),
+                                               f.get_tensor(base + ".scales"), dtype)
+                    awq_done.add(base)
+                    continue
+                if want is not None and not want(k):
+                    continue
+                yield k, f.get_tensor(k)
+
+
+# ------------------------------------------------------------------- entry
+def load_model(vllm_config: VllmConfig, device: torch.device) -> torch.nn.Module:
+    mc = vllm_config.model_config
+    cls = get_model_class(mc.architecture)
+    with torch.device(device):
+        model = cls(vllm_config)
+    model.rebind_buffers()
+    model.eval()
+
+    def want(name: str) -> bool:
+        mapped = model.map_weight_name(name)
+        return mapped is not None and model._owns_layer(mapped)
+
+    path = resolve_model_path(mc.model)
+    if mc.load_format == "dummy" or path is None:
+        if mc.load_format not in ("dummy", "auto"):
+            raise FileNotFoundError(f"no weights for {mc.model!r}")
+        it: Iterable[Tuple[str, torch.Tensor]] = dummy_weights_iterator(mc, device, want)
+    else:
+        it = safetensors_weights_iterator(path, mc.torch_dtype, want)
+    with torch.no_grad():
+        loaded = model.load_weights(it)
+    logger.info("loaded %d checkpoint tensors for %s (layers %d-%d, format=%s)", len(loaded),
+                mc.model, getattr(model, "start_layer", 0), getattr(model, "end_layer", 0),
+                mc.load_format if path is None else "safetensors")
+    return model
+
+
+def save_dummy_checkpoint(mc: ModelConfig, out_dir: str) -> None:
+    """Write the deterministic dummy weights as a safetensors checkpoint (tests
+    use it to check that the file loader and the dummy loader agree)."""
+    from safetensors.torch import save_file
+    os.makedirs(out_dir, exist_ok=True)
+    tensors = {n: w.contiguous() for n, w in dummy_weights_iterator(mc, torch.device("cpu"))}
+    save_file(tensors, os.path.join(out_dir, "model.safetensors"))
+    with open(os.path.join(out_dir, "config.json"), "w") as f:
+        json.dump(mc.hf_config, f)

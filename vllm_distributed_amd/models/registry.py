@@ -1,0 +1,31 @@
+"""Architecture name -> model class."""
+from __future__ import annotations
+
+import importlib
+from typing import Dict, Tuple, Type
+
+_MODELS: Dict[str, Tuple[str, str]] = {
+    "LlamaForCausalLM": ("llama", "LlamaForCausalLM"),
+    "MistralForCausalLM": ("llama", "LlamaForCausalLM"),
+    "Qwen2ForCausalLM": ("llama", "LlamaForCausalLM"),
+    "Qwen3ForCausalLM": ("llama", "LlamaForCausalLM"),
+    "Qwen3MoeForCausalLM": ("qwen3_moe", "Qwen3MoeForCausalLM"),
+    "OPTForCausalLM": ("opt", "OPTForCausalLM"),
+}
+
+
+def register_model(arch: str, module: str, cls: str) -> None:
+    _MODELS[arch] = (module, cls)
+
+
+def get_model_class(arch: str) -> Type:
+    if arch not in _MODELS:
+        raise ValueError(f"unsupported architecture {arch!r}; supported: {sorted(_MODELS)}")
+    mod, cls = _MODELS[arch]
+    if "." not in mod:
+        mod = f"{__package__}.{mod}"
+    return getattr(importlib.import_module(mod), cls)
+
+
+def supported_architectures():
+    return sorted(_MODELS)

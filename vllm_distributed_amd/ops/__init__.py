@@ -1,0 +1,143 @@
+"""Op dispatch: hand-written gfx950 HIP kernels on GPU, PyTorch reference on CPU.
+
+``VDAMD_OPS_BACKEND`` = ``auto`` (default: HIP for CUDA tensors, torch for CPU
+tensors), ``hip`` (fail if the extension is missing) or ``torch`` (reference
+everywhere).  On a GPU box a missing extension is an error, not a silent
+fallback: numbers measured on the reference path would be meaningless.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from .. import envs
+from . import torch_ref
+
+_hip = None
+_hip_error: Optional[BaseException] = None
+
+
+def _load_hip():
+    global _hip, _hip_error
+    if _hip is not None or _hip_error is not None:
+        return _hip
+    try:
+        from . import hip as hip_mod
+        hip_mod.load()
+        _hip = hip_mod
+    except BaseException as e:  # noqa: BLE001
+        _hip_error = e
+    return _hip
+
+
+def hip_available() -> bool:
+    return _load_hip() is not None
+
+
+def _use_hip(t: torch.Tensor) -> bool:
+    if not t.is_cuda:
+        return False
+    backend = envs.VDAMD_OPS_BACKEND
+    if backend == "torch":
+        return False
+    if _load_hip() is None:
+        raise RuntimeError(
+            "HIP kernel library is not available on a GPU tensor path "
+            f"({_hip_error!r}); build it with `python -m vllm_distributed_amd.build` "
+            "or set VDAMD_OPS_BACKEND=torch to use the slow reference ops")
+    return True
+
+
+def rms_norm(x, weight, eps):
+    if _use_hip(x):
+        return _hip.rms_norm(x, weight, eps)
+    return torch_ref.rms_norm(x, weight, eps)
+
+
+def fused_add_rms_norm(x, residual, weight, eps) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Returns ``(normed, new_residual)``; the HIP path updates both in place."""
+    if _use_hip(x):
+        return _hip.fused_add_rms_norm(x, residual, weight, eps)
+    return torch_ref.fused_add_rms_norm(x, residual, weight, eps)
+
+
+def layer_norm(x, weight, bias, eps):
+    if _use_hip(x):
+        return _hip.layer_norm(x, weight, bias, eps)
+    return torch_ref.layer_norm(x, weight, bias, eps)
+
+
+def silu_and_mul(x):
+    if _use_hip(x):
+        return _hip.silu_and_mul(x)
+    return torch_ref.silu_and_mul(x)
+
+
+def rotary_embedding(positions, q, k, cos_sin_cache, head_dim):
+    if _use_hip(q):
+        return _hip.rotary_embedding(positions, q, k, cos_sin_cache, head_dim)
+    return torch_ref.rotary_embedding(positions, q, k, cos_sin_cache, head_dim)
+
+
+def reshape_and_cache(k, v, k_cache, v_cache, slot_mapping):
+    if _use_hip(k):
+        return _hip.reshape_and_cache(k, v, k_cache, v_cache, slot_mapping)
+    return torch_ref.reshape_and_cache(k, v, k_cache, v_cache, slot_mapping)
+
+
+def rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping,
+                   num_heads, num_kv_heads, head_dim):
+    if _use_hip(qkv):
+        return _hip.rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping,
+                                   num_heads, num_kv_heads, head_dim)
+    return torch_ref.rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping,
+                                    num_heads, num_kv_heads, head_dim)
+
+
+def paged_attention(q, k_cache, v_cache, block_table, query_start_loc, seq_lens, scale,
+                    max_query_len: int = 0, max_seq_len: int = 0, out=None):
+    if _use_hip(q) and _hip.supports_head_dim(q.shape[-1]):
+        return _hip.paged_attention_prefill(q, k_cache, v_cache, block_table, query_start_loc,
+                                            seq_lens, scale, max_query_len, max_seq_len, out)
+    res = torch_ref.paged_attention(q, k_cache, v_cache, block_table, query_start_loc,
+                                    seq_lens, scale)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
+def paged_attention_decode(q, k_cache, v_cache, block_table, seq_lens, scale,
+                           max_seq_len: int = 0, out=None, workspace=None):
+    if _use_hip(q) and _hip.supports_head_dim(q.shape[-1]):
+        return _hip.paged_attention_decode(q, k_cache, v_cache, block_table, seq_lens, scale,
+                                           max_seq_len, out, workspace)
+    res = torch_ref.paged_attention_decode(q, k_cache, v_cache, block_table, seq_lens, scale)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
+def sample(logits, temperature, top_k, top_p, min_p, uniform):
+    if _use_hip(logits):
+        return _hip.sample(logits, temperature, top_k, top_p, min_p, uniform)
+    return torch_ref.sample(logits, temperature, top_k, top_p, min_p, uniform)
+
+
+def argmax(logits):
+    if _use_hip(logits):
+        return _hip.argmax(logits)
+    return logits.argmax(-1)
+
+
+def embedding(ids, weight, vocab_start=0, masked=False):
+    if _use_hip(weight):
+        return _hip.embedding(ids, weight, vocab_start)
+    return torch_ref.embedding(ids, weight, vocab_start, masked)
+
+
+apply_penalties = torch_ref.apply_penalties
+compute_logprobs = torch_ref.compute_logprobs
+build_cos_sin_cache = torch_ref.build_cos_sin_cache

@@ -1,0 +1,229 @@
+"""Plain-PyTorch implementations of every op in ``ops``.
+
+They define the semantics (the HIP kernels are tested against these in fp32)
+and are the execution path on CPU.  KV-cache layouts are the ones the CDNA4
+kernels consume as MFMA operands straight from global memory:
+
+* ``k_cache[num_blocks, num_kv_heads, block_size, head_dim]``  - a key row is
+  contiguous in ``head_dim`` (the QK^T reduction axis);
+* ``v_cache[num_blocks, num_kv_heads, head_dim, block_size]``  - transposed: a
+  ``head_dim`` row is contiguous in keys (the PV reduction axis).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------- norms
+def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    xf = x.float()
+    y = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    return (y * weight.float()).to(x.dtype)
+
+
+def fused_add_rms_norm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor,
+                       eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``r = x + residual``; returns ``(rms_norm(r), r)`` (r rounded to x.dtype
+    before the norm, as the fused kernel stores it)."""
+    r = (x.float() + residual.float()).to(x.dtype)
+    return rms_norm(r, weight, eps), r
+
+
+def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+               eps: float) -> torch.Tensor:
+    return F.layer_norm(x.float(), (x.shape[-1],), weight.float(),
+                        None if bias is None else bias.float(), eps).to(x.dtype)
+
+
+# -------------------------------------------------------------- activation
+def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
+    d = x.shape[-1] // 2
+    return (F.silu(x[..., :d].float()) * x[..., d:].float()).to(x.dtype)
+
+
+# ------------------------------------------------------------------ rotary
+def build_cos_sin_cache(head_dim: int, max_pos: int, theta: float,
+                        rope_scaling: Optional[dict] = None,
+                        rotary_dim: Optional[int] = None) -> torch.Tensor:
+    """``[max_pos, rotary_dim]`` fp32: cos in the first half, sin in the second."""
+    rd = rotary_dim or head_dim
+    inv_freq = 1.0 / (theta ** (torch.arange(0, rd, 2, dtype=torch.float64) / rd))
+    if rope_scaling:
+        rtype = rope_scaling.get("rope_type", rope_scaling.get("type"))
+        if rtype == "llama3":
+            factor = rope_scaling.get("factor", 8.0)
+            lo = rope_scaling.get("low_freq_factor", 1.0)
+            hi = rope_scaling.get("high_freq_factor", 4.0)
+            old = rope_scaling.get("original_max_position_embeddings", 8192)
+            wavelen = 2 * math.pi / inv_freq
+            smooth = ((old / wavelen) - lo) / (hi - lo)
+            scaled = torch.where(wavelen > old / lo, inv_freq / factor,
+                                 torch.where(wavelen < old / hi, inv_freq,
+                                             (1 - smooth) * inv_freq / factor + smooth * inv_freq))
+            inv_freq = scaled
+        elif rtype == "linear":
+            inv_freq = inv_freq / rope_scaling.get("factor", 1.0)
+    t = torch.arange(max_pos, dtype=torch.float64)
+    freqs = torch.outer(t, inv_freq)
+    return torch.cat([freqs.cos(), freqs.sin()], dim=-1).float()
+
+
+def rotary_embedding(positions: torch.Tensor, q: torch.Tensor, k: torch.Tensor,
+                     cos_sin_cache: torch.Tensor, head_dim: int) -> None:
+    """NeoX-style rotation in place on ``q[T, Hq*D]`` and ``k[T, Hkv*D]``."""
+    rd = cos_sin_cache.shape[-1]
+    cs = cos_sin_cache.index_select(0, positions.long())
+    cos, sin = cs[:, :rd // 2].unsqueeze(1), cs[:, rd // 2:].unsqueeze(1)
+    for t in (q, k):
+        v = t.view(t.shape[0], -1, head_dim)
+        x1 = v[..., :rd // 2].float()
+        x2 = v[..., rd // 2:rd].float()
+        o1 = x1 * cos - x2 * sin
+        o2 = x2 * cos + x1 * sin
+        v[..., :rd // 2] = o1.to(t.dtype)
+        v[..., rd // 2:rd] = o2.to(t.dtype)
+
+
+# ---------------------------------------------------------------- KV cache
+def reshape_and_cache(k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor,
+                      v_cache: torch.Tensor, slot_mapping: torch.Tensor) -> None:
+    """Scatter ``k,v[T, Hkv, D]`` into the paged caches; slot < 0 is skipped."""
+    bs = k_cache.shape[2]
+    valid = slot_mapping >= 0
+    slots = slot_mapping[valid].long()
+    blk, off = slots // bs, slots % bs
+    k_cache[blk, :, off, :] = k[valid].to(k_cache.dtype)
+    v_cache[blk, :, :, off] = v[valid].to(v_cache.dtype)
+
+
+def rope_and_cache(positions: torch.Tensor, qkv: torch.Tensor, cos_sin_cache: torch.Tensor,
+                   k_cache: torch.Tensor, v_cache: torch.Tensor, slot_mapping: torch.Tensor,
+                   num_heads: int, num_kv_heads: int, head_dim: int) -> torch.Tensor:
+    """Rotate q and k inside the packed ``qkv[T, (Hq+2Hkv)*D]``, write k/v to
+    the cache, return the rotated ``q[T, Hq*D]`` (a view of qkv)."""
+    qs, ks = num_heads * head_dim, num_kv_heads * head_dim
+    q, k, v = qkv[:, :qs], qkv[:, qs:qs + ks], qkv[:, qs + ks:]
+    rotary_embedding(positions, q, k, cos_sin_cache, head_dim)
+    reshape_and_cache(k.reshape(-1, num_kv_heads, head_dim), v.reshape(-1, num_kv_heads, head_dim),
+                      k_cache, v_cache, slot_mapping)
+    return q
+
+
+def _gather_kv(k_cache, v_cache, block_table_row, seq_len):
+    bs = k_cache.shape[2]
+    nb = (seq_len + bs - 1) // bs
+    blocks = block_table_row[:nb].long()
+    k = k_cache[blocks]                       # [nb, H, bs, D]
+    v = v_cache[blocks]                       # [nb, H, D, bs]
+    k = k.permute(1, 0, 2, 3).reshape(k.shape[1], nb * bs, -1)[:, :seq_len]
+    v = v.permute(1, 0, 3, 2).reshape(v.shape[1], nb * bs, -1)[:, :seq_len]
+    return k, v                               # [H, S, D]
+
+
+def paged_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                    block_table: torch.Tensor, query_start_loc: torch.Tensor,
+                    seq_lens: torch.Tensor, scale: float) -> torch.Tensor:
+    """Causal attention of each sequence's query chunk against its paged KV
+    (which already contains the chunk).  ``q[T, Hq, D]``; sequence ``i`` owns
+    query rows ``query_start_loc[i]:query_start_loc[i+1]`` which are the last
+    ``q_len`` positions of its ``seq_lens[i]`` tokens."""
+    out = torch.empty_like(q)
+    hq = q.shape[1]
+    hkv = k_cache.shape[1]
+    g = hq // hkv
+    qsl = query_start_loc.tolist()
+    sls = seq_lens.tolist()
+    for i, sl in enumerate(sls):
+        s, e = qsl[i], qsl[i + 1]
+        ql = e - s
+        if ql == 0:
+            continue
+        k, v = _gather_kv(k_cache, v_cache, block_table[i], sl)
+        k = k.float().repeat_interleave(g, dim=0)
+        v = v.float().repeat_interleave(g, dim=0)
+        qi = q[s:e].float().transpose(0, 1)                     # [Hq, ql, D]
+        scores = torch.matmul(qi, k.transpose(1, 2)) * scale    # [Hq, ql, sl]
+        qpos = torch.arange(sl - ql, sl, device=q.device).unsqueeze(1)
+        kpos = torch.arange(sl, device=q.device).unsqueeze(0)
+        scores = scores.masked_fill(kpos > qpos, float("-inf"))
+        out[s:e] = torch.matmul(torch.softmax(scores, -1), v).transpose(0, 1).to(q.dtype)
+    return out
+
+
+def paged_attention_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                           block_table: torch.Tensor, seq_lens: torch.Tensor,
+                           scale: float) -> torch.Tensor:
+    b = q.shape[0]
+    qsl = torch.arange(b + 1, device=q.device, dtype=torch.int32)
+    return paged_attention(q, k_cache, v_cache, block_table, qsl, seq_lens, scale)
+
+
+# ---------------------------------------------------------------- sampling
+def apply_penalties(logits: torch.Tensor, token_counts: torch.Tensor, prompt_mask: torch.Tensor,
+                    presence: torch.Tensor, frequency: torch.Tensor,
+                    repetition: torch.Tensor) -> torch.Tensor:
+    """``token_counts[B,V]`` = occurrences in the output so far;
+    ``prompt_mask[B,V]`` = token appears in the prompt."""
+    seen = (token_counts > 0) | prompt_mask
+    rep = repetition.unsqueeze(1)
+    logits = torch.where(seen, torch.where(logits > 0, logits / rep, logits * rep), logits)
+    logits = logits - frequency.unsqueeze(1) * token_counts
+    logits = logits - presence.unsqueeze(1) * (token_counts > 0)
+    return logits
+
+
+def sample(logits: torch.Tensor, temperature: torch.Tensor, top_k: torch.Tensor,
+           top_p: torch.Tensor, min_p: torch.Tensor, uniform: torch.Tensor) -> torch.Tensor:
+    """One token per row.  ``temperature == 0`` rows are argmax.  ``uniform[B]``
+    in (0,1) drives inverse-CDF sampling over the *descending-sorted* filtered
+    distribution, so an identical ``uniform`` gives identical tokens on every
+    implementation."""
+    logits = logits.float()
+    greedy = temperature == 0
+    t = torch.where(greedy, torch.ones_like(temperature), temperature)
+    probs = torch.softmax(logits / t.unsqueeze(1), dim=-1)
+    sp, si = probs.sort(dim=-1, descending=True, stable=True)
+    v = logits.shape[-1]
+    ranks = torch.arange(v, device=logits.device).unsqueeze(0)
+    k = torch.where(top_k <= 0, torch.full_like(top_k, v), top_k).unsqueeze(1)
+    keep = ranks < k
+    cum = sp.cumsum(-1)
+    keep &= (cum - sp) < top_p.unsqueeze(1)          # keep until mass reaches top_p
+    keep &= sp >= (min_p.unsqueeze(1) * sp[:, :1])
+    keep[:, 0] = True
+    sp = torch.where(keep, sp, torch.zeros_like(sp))
+    total = sp.sum(-1, keepdim=True)
+    cdf = sp.cumsum(-1)
+    target = uniform.unsqueeze(1).to(cdf.dtype) * total
+    idx = (cdf < target).sum(-1).clamp(max=v - 1)
+    # guard: never pick a filtered-out entry because of rounding at the tail
+    n_keep = keep.sum(-1)
+    idx = torch.minimum(idx, n_keep - 1)
+    sampled = si.gather(1, idx.unsqueeze(1)).squeeze(1)
+    return torch.where(greedy, logits.argmax(-1), sampled)
+
+
+def compute_logprobs(logits: torch.Tensor, token_ids: torch.Tensor, num_top: int):
+    lp = torch.log_softmax(logits.float(), dim=-1)
+    chosen = lp.gather(1, token_ids.unsqueeze(1).long()).squeeze(1)
+    if num_top > 0:
+        tv, ti = lp.topk(num_top, dim=-1)
+    else:
+        tv = ti = None
+    return chosen, tv, ti
+
+
+def embedding(ids: torch.Tensor, weight: torch.Tensor, vocab_start: int = 0,
+              masked: bool = False) -> torch.Tensor:
+    """Vocab-parallel gather: ids outside ``[vocab_start, vocab_start+rows)``
+    produce zero rows (summed across ranks afterwards)."""
+    local = ids.long() - vocab_start
+    mask = (local >= 0) & (local < weight.shape[0])
+    out = F.embedding(torch.where(mask, local, torch.zeros_like(local)), weight)
+    if masked or vocab_start != 0:
+        out = out * mask.unsqueeze(-1).to(out.dtype)
+    return out

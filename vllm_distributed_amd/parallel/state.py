@@ -1,0 +1,315 @@
+"""Process groups for the data plane.
+
+Rank layout is ``[DP][PP][TP]`` with TP fastest (reference
+``src/launch.py:215,234,278``: ``rank = pp_rank * TP + tp_rank``).  A TP group
+is the consecutive ranks of one pipeline stage; a PP group strides by TP.
+
+Collectives go through ``GroupCoordinator`` so the model code never sees which
+transport carries them: gloo on CPU, RCCL over xGMI on GPU (through
+``torch.distributed`` or the direct ctypes binding in ``rccl.py``), and the
+peer-mapped direct all-reduce in ``custom_all_reduce.py`` for small messages.
+A group of size 1 short-circuits every call.
+
+The rendezvous is a ``tcp://head:port`` store address generated on the head
+and shipped to every worker in its ``init_worker`` kwargs
+(reference ``src/launch.py:94,279-288``).
+"""
+from __future__ import annotations
+
+import os
+from datetime import timedelta
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .. import envs
+from ..logger import init_logger
+
+logger = init_logger(__name__)
+
+
+class CollectiveOrderChecker:
+    """Debug aid: every collective bumps a per-group sequence number and tags
+    it with an op code; ``verify`` all-gathers (seq, op, numel) over the CPU
+    group and raises when ranks disagree - mis-ordered collectives are the
+    "data race" of this design."""
+
+    def __init__(self) -> None:
+        self.seq = 0
+        self.log: List[Tuple[int, str, int]] = []
+
+    def record(self, op: str, numel: int) -> None:
+        self.seq += 1
+        self.log.append((self.seq, op, numel))
+        if len(self.log) > 4096:
+            del self.log[:2048]
+
+    def verify(self, group: "GroupCoordinator") -> None:
+        if group.world_size == 1 or group.cpu_group is None:
+            return
+        mine = self.log[-1] if self.log else (0, "", 0)
+        gathered: List[Any] = [None] * group.world_size
+        dist.all_gather_object(gathered, mine, group=group.cpu_group)
+        if any(g != gathered[0] for g in gathered):
+            raise RuntimeError(f"collective order mismatch in group {group.name}: {gathered}")
+
+
+class GroupCoordinator:
+    def __init__(self, name: str, ranks: Sequence[int], global_rank: int,
+                 device_group: Optional[Any], cpu_group: Optional[Any],
+                 device: torch.device):
+        self.name = name
+        self.ranks = list(ranks)
+        self.world_size = len(self.ranks)
+        self.rank = global_rank
+        self.rank_in_group = self.ranks.index(global_rank)
+        self.device_group = device_group
+        self.cpu_group = cpu_group
+        self.device = device
+        self.checker = CollectiveOrderChecker() if envs.VDAMD_CHECK_COLLECTIVE_ORDER else None
+        # optional accelerated paths, attached by the worker on GPU
+        self.rccl = None              # parallel.rccl.RcclCommunicator
+        self.custom_ar = None         # parallel.custom_all_reduce.CustomAllReduce
+
+    # ---------------------------------------------------------------- helpers
+    @property
+    def first_rank(self) -> int:
+        return self.ranks[0]
+
+    @property
+    def last_rank(self) -> int:
+        return self.ranks[-1]
+
+    @property
+    def is_first_rank(self) -> bool:
+        return self.rank_in_group == 0
+
+    @property
+    def is_last_rank(self) -> bool:
+        return self.rank_in_group == self.world_size - 1
+
+    @property
+    def next_rank(self) -> int:
+        return self.ranks[(self.rank_in_group + 1) % self.world_size]
+
+    @property
+    def prev_rank(self) -> int:
+        return self.ranks[(self.rank_in_group - 1) % self.world_size]
+
+    def _note(self, op: str, t: torch.Tensor) -> None:
+        if self.checker is not None:
+            self.checker.record(op, t.numel())
+            self.checker.verify(self)
+
+    # ------------------------------------------------------------ collectives
+    def all_reduce(self, x: torch.Tensor) -> torch.Tensor:
+        """Sum over the group.  May return a new tensor (direct all-reduce) or
+        ``x`` reduced in place."""
+        if self.world_size == 1:
+            return x
+        self._note("all_reduce", x)
+        if self.custom_ar is not None:
+            out = self.custom_ar.maybe_all_reduce(x)
+            if out is not None:
+                return out
+        if self.rccl is not None:
+            self.rccl.all_reduce(x)
+            return x
+        dist.all_reduce(x, group=self.device_group)
+        return x
+
+    def all_gather(self, x: torch.Tensor, dim: int = -1) -> torch.Tensor:
+        if self.world_size == 1:
+            return x
+        self._note("all_gather", x)
+        if dim < 0:
+            dim += x.dim()
+        x = x.contiguous()
+        out = torch.empty((self.world_size,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        if self.rccl is not None:
+            self.rccl.all_gather(out, x)
+        else:
+            dist.all_gather_into_tensor(out, x, group=self.device_group)
+        if dim == 0:
+            return out.reshape((self.world_size * x.shape[0],) + tuple(x.shape[1:]))
+        out = out.movedim(0, dim)
+        shape = list(x.shape)
+        shape[dim] *= self.world_size
+        return out.reshape(shape)
+
+    def broadcast(self, x: torch.Tensor, src: int = 0) -> torch.Tensor:
+        """``src`` is a rank *within the group*."""
+        if self.world_size == 1:
+            return x
+        self._note("broadcast", x)
+        if self.rccl is not None:
+            self.rccl.broadcast(x, src)
+        else:
+            dist.broadcast(x, src=self.ranks[src], group=self.device_group)
+        return x
+
+    def send(self, x: torch.Tensor, dst: Optional[int] = None) -> None:
+        """Point-to-point to a rank within the group (default: next)."""
+        dst = (self.rank_in_group + 1) % self.world_size if dst is None else dst
+        self._note("send", x)
+        if self.rccl is not None:
+            self.rccl.send(x.contiguous(), dst)
+        else:
+            dist.send(x.contiguous(), dst=self.ranks[dst], group=self.device_group)
+
+    def recv(self, shape: Sequence[int], dtype: torch.dtype, src: Optional[int] = None) -> torch.Tensor:
+        src = (self.rank_in_group - 1) % self.world_size if src is None else src
+        x = torch.empty(tuple(shape), dtype=dtype, device=self.device)
+        self._note("recv", x)
+        if self.rccl is not None:
+            self.rccl.recv(x, src)
+        else:
+            dist.recv(x, src=self.ranks[src], group=self.device_group)
+        return x
+
+    def broadcast_object(self, obj: Any = None, src: int = 0) -> Any:
+        if self.world_size == 1:
+            return obj
+        box = [obj]
+        dist.broadcast_object_list(box, src=self.ranks[src], group=self.cpu_group)
+        return box[0]
+
+    def all_gather_object(self, obj: Any) -> List[Any]:
+        if self.world_size == 1:
+            return [obj]
+        out: List[Any] = [None] * self.world_size
+        dist.all_gather_object(out, obj, group=self.cpu_group)
+        return out
+
+    def barrier(self) -> None:
+        if self.world_size > 1:
+            dist.barrier(group=self.cpu_group)
+
+
+# ------------------------------------------------------------------ globals
+_WORLD: Optional[GroupCoordinator] = None
+_TP: Optional[GroupCoordinator] = None
+_PP: Optional[GroupCoordinator] = None
+_OWNS_PROCESS_GROUP = False
+
+
+def _single(name: str, device: torch.device) -> GroupCoordinator:
+    return GroupCoordinator(name, [0], 0, None, None, device)
+
+
+def init_distributed_environment(world_size: int, rank: int, init_method: Optional[str],
+                                 local_rank: int, backend: str, device: torch.device,
+                                 timeout_s: float = 1800.0) -> None:
+    """Join the world.  ``backend`` is ``nccl`` (= RCCL on ROCm) or ``gloo``."""
+    global _WORLD, _OWNS_PROCESS_GROUP
+    if world_size == 1:
+        _WORLD = _single("world", device)
+        return
+    if not dist.is_initialized():
+        kwargs: Dict[str, Any] = dict(backend=backend, world_size=world_size, rank=rank,
+                                      timeout=timedelta(seconds=timeout_s))
+        if init_method is not None and init_method != "env://":
+            kwargs["init_method"] = init_method
+        if backend == "nccl":
+            kwargs["device_id"] = device
+        dist.init_process_group(**kwargs)
+        _OWNS_PROCESS_GROUP = True
+    ranks = list(range(world_size))
+    cpu_group = dist.new_group(ranks, backend="gloo")
+    _WORLD = GroupCoordinator("world", ranks, rank, dist.group.WORLD, cpu_group, device)
+
+
+def initialize_model_parallel(tp_size: int, pp_size: int) -> None:
+    """Build TP and PP groups.  Every rank must call this with the same sizes
+    (``new_group`` is collective over the world)."""
+    global _TP, _PP
+    world = get_world_group()
+    ws, rank, device = world.world_size, world.rank, world.device
+    if ws == 1:
+        _TP, _PP = _single("tp", device), _single("pp", device)
+        return
+    assert ws % (tp_size * pp_size) == 0, (ws, tp_size, pp_size)
+    dp_size = ws // (tp_size * pp_size)
+    backend = dist.get_backend()
+    _TP = _PP = None
+    for dp in range(dp_size):
+        for pp in range(pp_size):
+            base = (dp * pp_size + pp) * tp_size
+            ranks = list(range(base, base + tp_size))
+            dev = dist.new_group(ranks, backend=backend) if tp_size > 1 else None
+            cpu = dist.new_group(ranks, backend="gloo") if tp_size > 1 else None
+            if rank in ranks:
+                _TP = GroupCoordinator("tp", ranks, rank, dev, cpu, device)
+    for dp in range(dp_size):
+        for tp in range(tp_size):
+            ranks = [(dp * pp_size + pp) * tp_size + tp for pp in range(pp_size)]
+            dev = dist.new_group(ranks, backend=backend) if pp_size > 1 else None
+            cpu = dist.new_group(ranks, backend="gloo") if pp_size > 1 else None
+            if rank in ranks:
+                _PP = GroupCoordinator("pp", ranks, rank, dev, cpu, device)
+    assert _TP is not None and _PP is not None
+
+
+def get_world_group() -> GroupCoordinator:
+    assert _WORLD is not None, "distributed environment is not initialised"
+    return _WORLD
+
+
+def get_tp_group() -> GroupCoordinator:
+    assert _TP is not None, "model parallel groups are not initialised"
+    return _TP
+
+
+def get_pp_group() -> GroupCoordinator:
+    assert _PP is not None, "model parallel groups are not initialised"
+    return _PP
+
+
+def model_parallel_is_initialized() -> bool:
+    return _TP is not None and _PP is not None
+
+
+def get_tensor_model_parallel_world_size() -> int:
+    return _TP.world_size if _TP is not None else 1
+
+
+def get_tensor_model_parallel_rank() -> int:
+    return _TP.rank_in_group if _TP is not None else 0
+
+
+def tensor_model_parallel_all_reduce(x: torch.Tensor) -> torch.Tensor:
+    return x if _TP is None else _TP.all_reduce(x)
+
+
+def tensor_model_parallel_all_gather(x: torch.Tensor, dim: int = -1) -> torch.Tensor:
+    return x if _TP is None else _TP.all_gather(x, dim)
+
+
+def ensure_single_process_groups(device: Optional[torch.device] = None) -> None:
+    """World/TP/PP of size 1 for single-process use (tests, TP=PP=1)."""
+    global _WORLD, _TP, _PP
+    device = device or torch.device("cpu")
+    if _WORLD is None:
+        _WORLD = _single("world", device)
+    if _TP is None:
+        _TP = _single("tp", device)
+    if _PP is None:
+        _PP = _single("pp", device)
+
+
+def destroy_model_parallel() -> None:
+    global _WORLD, _TP, _PP, _OWNS_PROCESS_GROUP
+    for g in (_TP, _PP):
+        if g is not None:
+            if g.custom_ar is not None:
+                g.custom_ar.close()
+            if g.rccl is not None:
+                g.rccl.close()
+    _TP = _PP = _WORLD = None
+    if _OWNS_PROCESS_GROUP and dist.is_initialized():
+        try:
+            dist.destroy_process_group()
+        except Exception:  # pragma: no cover
+            pass
+    _OWNS_PROCESS_GROUP = False

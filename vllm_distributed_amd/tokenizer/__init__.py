@@ -1,0 +1,112 @@
+"""Tokenizers: a HuggingFace tokenizer when its files are available locally,
+otherwise a self-contained byte-level tokenizer (the GPU box has no network,
+so benchmark/test configurations must not depend on the hub)."""
+from __future__ import annotations
+
+import json
+import os
+from typing import Any, Dict, List, Optional, Sequence
+
+from ..config import ModelConfig, resolve_model_path
+from ..logger import init_logger
+
+logger = init_logger(__name__)
+
+DEFAULT_CHAT_TEMPLATE = (
+    "{% for message in messages %}"
+    "<|{{ message['role'] }}|>\n{{ message['content'] }}\n"
+    "{% endfor %}"
+    "{% if add_generation_prompt %}<|assistant|>\n{% endif %}")
+
+
+class ByteTokenizer:
+    """ids 0..255 = bytes, then specials; ids beyond decode to nothing, so any
+    model vocabulary can be driven with synthetic prompts."""
+
+    def __init__(self, vocab_size: int, bos_token_id: Optional[int] = None,
+                 eos_token_id: Optional[int] = None):
+        self.vocab_size = vocab_size
+        self.bos_token_id = bos_token_id
+        self.eos_token_id = eos_token_id
+        self.chat_template = DEFAULT_CHAT_TEMPLATE
+        self.is_fast = True
+        self.all_special_ids = [i for i in (bos_token_id, eos_token_id) if i is not None]
+
+    def encode(self, text: str, add_special_tokens: bool = True) -> List[int]:
+        ids = [b % self.vocab_size for b in text.encode("utf-8")]
+        if add_special_tokens and self.bos_token_id is not None:
+            ids = [self.bos_token_id] + ids
+        return ids
+
+    def decode(self, ids: Sequence[int], skip_special_tokens: bool = True) -> str:
+        special = set(self.all_special_ids) if skip_special_tokens else set()
+        bs = bytes(i for i in ids if i < 256 and i not in special)
+        return bs.decode("utf-8", errors="replace")
+
+    def convert_ids_to_tokens(self, ids: Sequence[int]) -> List[str]:
+        return [chr(i) if i < 256 else f"<{i}>" for i in ids]
+
+    def apply_chat_template(self, messages: List[Dict[str, Any]], tokenize: bool = False,
+                            add_generation_prompt: bool = True, tools=None, **kw) -> Any:
+        text = render_chat_template(self.chat_template, messages, add_generation_prompt, tools)
+        return self.encode(text) if tokenize else text
+
+    def __len__(self) -> int:
+        return self.vocab_size
+
+
+def render_chat_template(template: str, messages, add_generation_prompt: bool = True,
+                         tools=None, **extra) -> str:
+    import jinja2
+    env = jinja2.Environment(trim_blocks=True, lstrip_blocks=True)
+    env.globals["raise_exception"] = lambda m: (_ for _ in ()).throw(ValueError(m))
+    env.filters["tojson"] = lambda v, **k: json.dumps(v, ensure_ascii=False)
+    return env.from_string(template).render(messages=messages, tools=tools,
+                                            add_generation_prompt=add_generation_prompt, **extra)
+
+
+class HFTokenizer:
+    def __init__(self, path: str, trust_remote_code: bool = False):
+        from transformers import AutoTokenizer
+        self.tok = AutoTokenizer.from_pretrained(path, trust_remote_code=trust_remote_code,
+                                                 local_files_only=True)
+        self.vocab_size = len(self.tok)
+        self.bos_token_id = self.tok.bos_token_id
+        self.eos_token_id = self.tok.eos_token_id
+        self.chat_template = getattr(self.tok, "chat_template", None) or DEFAULT_CHAT_TEMPLATE
+        self.all_special_ids = list(self.tok.all_special_ids)
+
+    def encode(self, text: str, add_special_tokens: bool = True) -> List[int]:
+        return self.tok.encode(text, add_special_tokens=add_special_tokens)
+
+    def decode(self, ids: Sequence[int], skip_special_tokens: bool = True) -> str:
+        return self.tok.decode(list(ids), skip_special_tokens=skip_special_tokens)
+
+    def convert_ids_to_tokens(self, ids: Sequence[int]) -> List[str]:
+        return self.tok.convert_ids_to_tokens(list(ids))
+
+    def apply_chat_template(self, messages, tokenize: bool = False, add_generation_prompt: bool = True,
+                            tools=None, **kw) -> Any:
+        if getattr(self.tok, "chat_template", None):
+            return self.tok.apply_chat_template(messages, tokenize=tokenize, tools=tools,
+                                                add_generation_prompt=add_generation_prompt, **kw)
+        text = render_chat_template(self.chat_template, messages, add_generation_prompt, tools)
+        return self.encode(text) if tokenize else text
+
+    def __len__(self) -> int:
+        return self.vocab_size
+
+
+def get_tokenizer(mc: ModelConfig):
+    path = resolve_model_path(mc.tokenizer or mc.model)
+    if path is not None and any(os.path.isfile(os.path.join(path, f)) for f in
+                                ("tokenizer.json", "tokenizer.model", "vocab.json", "tokenizer_config.json")):
+        try:
+            return HFTokenizer(path, mc.trust_remote_code)
+        except Exception as e:  # noqa: BLE001
+            logger.warning("could not load tokenizer from %s (%r); using the byte tokenizer", path, e)
+    c = mc.hf_config
+    eos = c.get("eos_token_id")
+    if isinstance(eos, list):
+        eos = eos[0]
+    return ByteTokenizer(mc.vocab_size, c.get("bos_token_id"), eos)

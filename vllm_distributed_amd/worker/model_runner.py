@@ -1,0 +1,474 @@
+"""Model runner: turns a ``SchedulerOutput`` into device inputs, runs the model
+(eagerly or by replaying a captured hipGraph), samples, and reports tokens.
+
+Batch order is decode-first (all ``q_len == 1`` sequences, then prompt chunks)
+so the two attention kernels each see a contiguous slice.  Pure-decode steps
+whose padded batch size has a captured graph are replayed from static buffers:
+one graph launch instead of ~10 kernel launches per layer.
+"""
+from __future__ import annotations
+
+import time
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import envs, ops
+from ..config import VllmConfig
+from ..engine.types import KVCacheSpec, ModelRunnerOutput, SchedulerOutput
+from ..logger import init_logger
+from ..models.layers.attention import AttentionMetadata, set_forward_context
+from ..models.loader import load_model
+from ..models.utils import IntermediateTensors
+from ..parallel.state import get_pp_group, get_tp_group
+from ..utils import cdiv
+from .input_batch import InputBatch
+
+logger = init_logger(__name__)
+
+
+class DecodeGraph:
+    """A captured decode step for one padded batch size."""
+
+    def __init__(self, batch_size: int):
+        self.batch_size = batch_size
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.output: Optional[Any] = None
+
+
+class ModelRunner:
+    def __init__(self, vllm_config: VllmConfig, device: torch.device):
+        self.vllm_config = vllm_config
+        self.model_config = vllm_config.model_config
+        self.cache_config = vllm_config.cache_config
+        self.scheduler_config = vllm_config.scheduler_config
+        self.parallel_config = vllm_config.parallel_config
+        self.device = device
+        self.is_gpu = device.type == "cuda"
+        self.block_size = self.cache_config.block_size
+        self.max_model_len = self.model_config.max_model_len
+        self.max_num_reqs = self.scheduler_config.max_num_seqs
+        self.max_num_tokens = self.scheduler_config.max_num_batched_tokens
+        self.model: Optional[torch.nn.Module] = None
+        self.batch = InputBatch(self.max_num_reqs, self.max_model_len, self.block_size,
+                                self.model_config.vocab_size, self.model_config.seed)
+        self.kv_caches: List[Tuple[torch.Tensor, torch.Tensor]] = []
+        self.graphs: Dict[int, DecodeGraph] = {}
+        self.graph_sizes: List[int] = []
+        self.graph_pool = None
+        self._static: Dict[str, torch.Tensor] = {}
+        self.decode_workspace: Optional[torch.Tensor] = None
+        self.step_count = 0
+        self.report_on_all_ranks = False
+        self.timing_enabled = vllm_config.observability_config.collect_step_timing
+
+    # ------------------------------------------------------------------ setup
+    def load_model(self) -> None:
+        t0 = time.time()
+        self.model = load_model(self.vllm_config, self.device)
+        self.pp = get_pp_group()
+        self.tp = get_tp_group()
+        logger.info("model loaded in %.1fs", time.time() - t0)
+
+    def get_kv_cache_spec(self) -> KVCacheSpec:
+        layers = self.model.attention_layers()
+        a = layers[0]
+        return KVCacheSpec(num_layers=len(layers), num_kv_heads=a.num_kv_heads, head_dim=a.head_dim,
+                           block_size=self.block_size, dtype_bytes=self.model_config.dtype_bytes)
+
+    @torch.inference_mode()
+    def profile_run(self) -> None:
+        """Forward of the largest token batch with no KV cache bound, to expose
+        peak activation memory to the caller's measurement."""
+        t = min(self.max_num_tokens, self.max_model_len)
+        ids = torch.zeros(t, dtype=torch.int32, device=self.device)
+        pos = torch.arange(t, dtype=torch.int32, device=self.device)
+        set_forward_context(None, pos)
+        inter = None
+        if not self.pp.is_first_rank:
+            h = self.model_config.hidden_size
+            z = torch.zeros(t, h, dtype=self.model_config.torch_dtype, device=self.device)
+            inter = IntermediateTensors(z, z.clone())
+        out = self.model(ids, pos, inter)
+        if self.pp.is_last_rank:
+            n = min(self.max_num_reqs, t)
+            self.model.compute_logits(out[:n])
+        if self.is_gpu:
+            torch.cuda.synchronize()
+
+    def initialize_kv_cache(self, num_blocks: int) -> None:
+        spec = self.get_kv_cache_spec()
+        dtype = self.model_config.torch_dtype
+        self.num_blocks = num_blocks
+        self.kv_caches = []
+        for attn in self.model.attention_layers():
+            k = torch.zeros(num_blocks, spec.num_kv_heads, self.block_size, spec.head_dim,
+                            dtype=dtype, device=self.device)
+            v = torch.zeros(num_blocks, spec.num_kv_heads, spec.head_dim, self.block_size,
+                            dtype=dtype, device=self.device)
+            attn.bind_kv_cache(k, v)
+            self.kv_caches.append((k, v))
+        logger.info("KV cache: %d blocks x %d tokens (%.2f GiB)", num_blocks, self.block_size,
+                    num_blocks * spec.bytes_per_block / 2**30)
+
+    # ------------------------------------------------------------ state sync
+    def _update_states(self, so: SchedulerOutput) -> None:
+        b = self.batch
+        for rid in so.finished_req_ids:
+            b.remove_request(rid)
+        for rid in so.preempted_req_ids:
+            b.remove_request(rid)
+        for nr in so.scheduled_new_reqs:
+            b.add_request(nr.req_id, nr.prompt_token_ids, nr.output_token_ids, nr.sampling_params,
+                          nr.block_ids, nr.num_computed_tokens)
+        c = so.scheduled_cached_reqs
+        samples_here = self.pp.is_last_rank
+        for i, rid in enumerate(c.req_ids):
+            row = b.row_of.get(rid)
+            if row is None:
+                continue
+            b.append_blocks(row, c.new_block_ids[i])
+            toks = c.new_token_ids[i] if c.new_token_ids else None
+            if toks and not samples_here:
+                # stages that do not sample learn new tokens from the scheduler
+                b.append_tokens(row, toks)
+
+    # --------------------------------------------------------- input building
+    def _prepare_inputs(self, so: SchedulerOutput):
+        b = self.batch
+        req_ids = list(so.num_scheduled_tokens.keys())
+        n_sched = np.fromiter(so.num_scheduled_tokens.values(), dtype=np.int32, count=len(req_ids))
+        rows = np.fromiter((b.row_of[r] for r in req_ids), dtype=np.int64, count=len(req_ids))
+        # decode-first, stable
+        is_prefill = n_sched != 1
+        if is_prefill.any():
+            order = np.argsort(is_prefill, kind="stable")
+            rows, n_sched = rows[order], n_sched[order]
+            req_ids = [req_ids[i] for i in order.tolist()]
+            num_decodes = int((~is_prefill).sum())
+        else:
+            num_decodes = len(req_ids)
+        nreq = len(req_ids)
+        starts = b.num_computed[rows]
+        seq_lens = (starts + n_sched).astype(np.int32)
+        qsl = np.zeros(nreq + 1, dtype=np.int32)
+        np.cumsum(n_sched, out=qsl[1:])
+        total = int(qsl[-1])
+        if num_decodes == nreq:
+            positions = starts.astype(np.int32)
+            tok_rows = rows
+        else:
+            req_idx = np.repeat(np.arange(nreq), n_sched)
+            positions = (starts[req_idx] + (np.arange(total, dtype=np.int32) - qsl[req_idx])).astype(np.int32)
+            tok_rows = rows[req_idx]
+        input_ids = b.token_ids[tok_rows, positions]
+        blk = b.block_table[tok_rows, positions // self.block_size]
+        slot_mapping = (blk * self.block_size + positions % self.block_size).astype(np.int32)
+        max_blocks = int(cdiv(int(seq_lens.max()), self.block_size))
+        # which requests reach the end of their known tokens -> sample
+        sample_mask = seq_lens >= b.num_tokens[rows]
+        return dict(req_ids=req_ids, rows=rows, n_sched=n_sched, num_decodes=num_decodes,
+                    seq_lens=seq_lens, qsl=qsl, total=total, positions=positions,
+                    input_ids=input_ids, slot_mapping=slot_mapping, max_blocks=max_blocks,
+                    sample_mask=sample_mask)
+
+    def _to_dev(self, arr: np.ndarray, dtype=torch.int32) -> torch.Tensor:
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        if t.dtype != dtype:
+            t = t.to(dtype)
+        if self.is_gpu:
+            return t.pin_memory().to(self.device, non_blocking=True)
+        return t
+
+    def _build_metadata(self, p: dict) -> Tuple[AttentionMetadata, torch.Tensor, torch.Tensor]:
+        b = self.batch
+        nd, nreq = p["num_decodes"], len(p["req_ids"])
+        block_table = self._to_dev(b.block_table[p["rows"], :p["max_blocks"]])
+        seq_lens = self._to_dev(p["seq_lens"])
+        qsl = self._to_dev(p["qsl"])
+        slot = self._to_dev(p["slot_mapping"])
+        n_sched = p["n_sched"]
+        md = AttentionMetadata(
+            num_decodes=nd, num_decode_tokens=nd, num_prefills=nreq - nd,
+            num_prefill_tokens=p["total"] - nd, slot_mapping=slot, block_table=block_table,
+            seq_lens=seq_lens, query_start_loc=qsl,
+            max_query_len=int(n_sched.max()), max_seq_len=int(p["seq_lens"].max()),
+            max_decode_seq_len=int(p["seq_lens"][:nd].max()) if nd else 0,
+            decode_workspace=self.decode_workspace)
+        if nreq > nd:
+            pq = p["qsl"][nd:] - p["qsl"][nd]
+            md.prefill_query_start_loc = self._to_dev(pq)
+            md.max_prefill_query_len = int(n_sched[nd:].max())
+        input_ids = self._to_dev(p["input_ids"])
+        positions = self._to_dev(p["positions"])
+        return md, input_ids, positions
+
+    # ------------------------------------------------------------ execution
+    @torch.inference_mode()
+    def execute_model(self, so: SchedulerOutput) -> Optional[ModelRunnerOutput]:
+        t0 = time.perf_counter()
+        self._update_states(so)
+        self.step_count += 1
+        if so.total_num_scheduled_tokens == 0:
+            return ModelRunnerOutput(step_id=so.step_id) if self._is_output_rank() else None
+        p = self._prepare_inputs(so)
+        nreq, nd, total = len(p["req_ids"]), p["num_decodes"], p["total"]
+        t1 = time.perf_counter()
+
+        graph = None
+        if self.graphs and nd == nreq:
+            graph = self._pick_graph(nreq, p["max_blocks"])
+        if graph is not None:
+            hidden = self._run_graph(graph, p)
+        else:
+            md, input_ids, positions = self._build_metadata(p)
+            hidden = self._run_eager(md, input_ids, positions, total)
+
+        # advance computed-token counts (the scheduler did the same when it scheduled)
+        self.batch.num_computed[p["rows"]] += p["n_sched"]
+
+        if not self.pp.is_last_rank:
+            return None
+        t2 = time.perf_counter()
+        sample_mask = p["sample_mask"]
+        out_tokens: List[List[int]] = [[] for _ in range(nreq)]
+        logprobs_out = None
+        if sample_mask.any():
+            sel = np.nonzero(sample_mask)[0]
+            last_idx = p["qsl"][1:][sel] - 1
+            if len(sel) == total:        # every token is a sampling position (pure decode)
+                hs = hidden[:total]
+            else:
+                hs = hidden.index_select(0, self._to_dev(last_idx, torch.int64))
+            logits = self.model.compute_logits(hs)
+            rows_sel = p["rows"][sel]
+            tokens, logprobs_sel = self._sample(logits, rows_sel)
+            tok_list = tokens.tolist()
+            b = self.batch
+            # remember what we sampled: TP ranks all compute the same token
+            n_known = b.num_tokens[rows_sel]
+            b.token_ids[rows_sel, n_known] = tokens
+            b.num_tokens[rows_sel] = n_known + 1
+            for j, i in enumerate(sel.tolist()):
+                out_tokens[i] = [tok_list[j]]
+            if logprobs_sel is not None:
+                logprobs_out = [None] * nreq
+                for j, i in enumerate(sel.tolist()):
+                    logprobs_out[i] = logprobs_sel[j]
+        if not self._is_output_rank():
+            return None
+        t3 = time.perf_counter()
+        timing = {"prepare": t1 - t0, "forward": t2 - t1, "sample": t3 - t2} if self.timing_enabled else None
+        return ModelRunnerOutput(step_id=so.step_id, req_ids=p["req_ids"],
+                                 sampled_token_ids=out_tokens, logprobs=logprobs_out, timing=timing)
+
+    def _is_output_rank(self) -> bool:
+        return self.pp.is_last_rank and (self.tp.rank_in_group == 0 or self.report_on_all_ranks)
+
+    def _run_eager(self, md: AttentionMetadata, input_ids: torch.Tensor, positions: torch.Tensor,
+                   total: int):
+        inter = None
+        if not self.pp.is_first_rank:
+            inter = self._recv_intermediate(total)
+        set_forward_context(md, positions)
+        out = self.model(input_ids, positions, inter)
+        set_forward_context(None)
+        if not self.pp.is_last_rank:
+            self._send_intermediate(out)
+            return None
+        return out
+
+    def _recv_intermediate(self, total: int) -> IntermediateTensors:
+        h = self.model_config.hidden_size
+        dtype = self.model_config.torch_dtype
+        hidden = self.pp.recv((total, h), dtype)
+        residual = None
+        if self._pp_sends_residual():
+            residual = self.pp.recv((total, h), dtype)
+        return IntermediateTensors(hidden, residual)
+
+    def _send_intermediate(self, out: IntermediateTensors) -> None:
+        self.pp.send(out.hidden)
+        if self._pp_sends_residual():
+            self.pp.send(out.residual)
+
+    def _pp_sends_residual(self) -> bool:
+        return self.model_config.architecture != "OPTForCausalLM"
+
+    # -------------------------------------------------------------- sampling
+    def _sample(self, logits: torch.Tensor, rows: np.ndarray):
+        b = self.batch
+        temps = b.temperature[rows]
+        need_lp = int(b.num_logprobs[rows].max()) if len(rows) else -1
+        if b.has_penalty[rows].any():
+            logits = self._apply_penalties(logits.float(), rows)
+        if not temps.any():
+            tokens = ops.argmax(logits)
+        else:
+            uniform = b.draw_uniform(rows)
+            tokens = ops.sample(
+                logits, self._to_dev(temps, torch.float32), self._to_dev(b.top_k[rows], torch.int32),
+                self._to_dev(b.top_p[rows], torch.float32), self._to_dev(b.min_p[rows], torch.float32),
+                self._to_dev(uniform, torch.float32))
+        logprobs = None
+        if need_lp >= 0:
+            chosen, tv, ti = ops.compute_logprobs(logits, tokens, max(need_lp, 0))
+            chosen = chosen.tolist()
+            tv_l = tv.tolist() if tv is not None else None
+            ti_l = ti.tolist() if ti is not None else None
+            tk = tokens.tolist()
+            logprobs = []
+            for j, r in enumerate(rows.tolist()):
+                k = int(b.num_logprobs[r])
+                if k < 0:
+                    logprobs.append(None)
+                    continue
+                d = {tk[j]: chosen[j]}
+                for t_id, t_lp in zip((ti_l[j][:k] if ti_l else []), (tv_l[j][:k] if tv_l else [])):
+                    d.setdefault(t_id, t_lp)
+                logprobs.append([d])
+        tokens_np = tokens.to("cpu", torch.int32).numpy() if tokens.is_cuda else tokens.to(torch.int32).numpy()
+        return tokens_np, logprobs
+
+    def _apply_penalties(self, logits: torch.Tensor, rows: np.ndarray) -> torch.Tensor:
+        b = self.batch
+        v = logits.shape[-1]
+        counts = np.zeros((len(rows), v), dtype=np.float32)
+        prompt_mask = np.zeros((len(rows), v), dtype=bool)
+        for j, r in enumerate(rows.tolist()):
+            if not b.has_penalty[r]:
+                continue
+            npt, nt = int(b.num_prompt_tokens[r]), int(b.num_tokens[r])
+            out_t = b.token_ids[r, npt:nt]
+            out_t = out_t[out_t < v]
+            np.add.at(counts[j], out_t, 1.0)
+            pt = b.token_ids[r, :npt]
+            prompt_mask[j, pt[pt < v]] = True
+        dev = logits.device
+        return ops.apply_penalties(
+            logits, torch.from_numpy(counts).to(dev), torch.from_numpy(prompt_mask).to(dev),
+            torch.from_numpy(b.presence[rows]).to(dev), torch.from_numpy(b.frequency[rows]).to(dev),
+            torch.from_numpy(b.repetition[rows]).to(dev))
+
+    # ---------------------------------------------------------- hipGraph path
+    def _pick_graph(self, nreq: int, max_blocks: int) -> Optional[DecodeGraph]:
+        if max_blocks > self._static["block_table"].shape[1]:
+            return None
+        for s in self.graph_sizes:
+            if s >= nreq:
+                return self.graphs[s]
+        return None
+
+    def _alloc_static(self, max_bs: int) -> None:
+        dev = self.device
+        mb = self.batch.max_blocks
+        self._static = {
+            "input_ids": torch.zeros(max_bs, dtype=torch.int32, device=dev),
+            "positions": torch.zeros(max_bs, dtype=torch.int32, device=dev),
+            "slot_mapping": torch.full((max_bs,), -1, dtype=torch.int32, device=dev),
+            "seq_lens": torch.zeros(max_bs, dtype=torch.int32, device=dev),
+            "block_table": torch.zeros(max_bs, mb, dtype=torch.int32, device=dev),
+            "qsl": torch.arange(max_bs + 1, dtype=torch.int32, device=dev),
+        }
+        if self.is_gpu:
+            # pinned staging so one H2D per tensor per step
+            self._stage = {k: torch.zeros_like(v, device="cpu").pin_memory()
+                           for k, v in self._static.items() if k != "qsl"}
+
+    def _static_metadata(self, bs: int, max_seq_len: int) -> AttentionMetadata:
+        s = self._static
+        return AttentionMetadata(
+            num_decodes=bs, num_decode_tokens=bs, num_prefills=0, num_prefill_tokens=0,
+            slot_mapping=s["slot_mapping"][:bs], block_table=s["block_table"][:bs],
+            seq_lens=s["seq_lens"][:bs], query_start_loc=s["qsl"][:bs + 1],
+            max_query_len=1, max_seq_len=max_seq_len, max_decode_seq_len=max_seq_len,
+            decode_workspace=self.decode_workspace)
+
+    @torch.inference_mode()
+    def capture_graphs(self) -> None:
+        cc = self.vllm_config.compilation_config
+        if not (self.is_gpu and cc.use_hip_graph and envs.VDAMD_USE_HIP_GRAPH):
+            return
+        if self.pp.world_size > 1:
+            logger.info("hipGraph decode capture is disabled with pipeline parallelism")
+            return
+        sizes = [s for s in cc.sizes(self.max_num_reqs) if s <= self.max_num_reqs]
+        if not sizes:
+            return
+        t0 = time.time()
+        self._alloc_static(max(sizes))
+        self._ensure_decode_workspace(max(sizes))
+        try:
+            for bs in sorted(sizes, reverse=True):
+                self._capture_one(bs)
+        except Exception as e:  # capture is an optimisation: fall back to eager
+            logger.warning("hipGraph capture failed (%r): running decode eagerly", e)
+            self.graphs.clear()
+            self.graph_sizes = []
+            torch.cuda.synchronize()
+            return
+        self.graph_sizes = sorted(self.graphs)
+        logger.info("captured %d decode graphs (%s) in %.1fs", len(self.graphs),
+                    self.graph_sizes, time.time() - t0)
+
+    def _ensure_decode_workspace(self, max_bs: int) -> None:
+        if not self.is_gpu or not ops.hip_available():
+            return
+        from ..ops import hip
+        attn = self.model.attention_layers()[0]
+        n = hip.decode_workspace_floats(max(max_bs, self.max_num_reqs), attn.num_heads, attn.head_dim)
+        self.decode_workspace = torch.empty(n, dtype=torch.float32, device=self.device)
+
+    def _capture_one(self, bs: int) -> None:
+        s = self._static
+        md = self._static_metadata(bs, self.max_model_len)
+        ids, pos = s["input_ids"][:bs], s["positions"][:bs]
+        # warm up on a side stream (allocator + lazy init), then capture
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            for _ in range(2):
+                set_forward_context(md, pos)
+                self.model(ids, pos, None)
+        torch.cuda.current_stream().wait_stream(stream)
+        torch.cuda.synchronize()
+        g = DecodeGraph(bs)
+        g.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g.graph, pool=self.graph_pool):
+            set_forward_context(md, pos)
+            g.output = self.model(ids, pos, None)
+        set_forward_context(None)
+        if self.graph_pool is None:
+            self.graph_pool = g.graph.pool()
+        self.graphs[bs] = g
+
+    def _run_graph(self, g: DecodeGraph, p: dict):
+        s, st = self._static, self._stage
+        n, bs = len(p["req_ids"]), g.batch_size
+        mb = p["max_blocks"]
+        st["input_ids"][:n] = torch.from_numpy(p["input_ids"])
+        st["positions"][:n] = torch.from_numpy(p["positions"])
+        st["slot_mapping"][:n] = torch.from_numpy(p["slot_mapping"])
+        st["seq_lens"][:n] = torch.from_numpy(p["seq_lens"])
+        st["block_table"][:n, :mb] = torch.from_numpy(self.batch.block_table[p["rows"], :mb])
+        if n < bs:      # padding rows: no cache write, zero-length attention
+            st["slot_mapping"][n:bs] = -1
+            st["seq_lens"][n:bs] = 0
+            st["input_ids"][n:bs] = 0
+            st["positions"][n:bs] = 0
+        for k in ("input_ids", "positions", "slot_mapping", "seq_lens"):
+            s[k][:bs].copy_(st[k][:bs], non_blocking=True)
+        s["block_table"][:n, :mb].copy_(st["block_table"][:n, :mb], non_blocking=True)
+        g.graph.replay()
+        return g.output
+
+    # ----------------------------------------------------------------- warmup
+    @torch.inference_mode()
+    def warm_up(self) -> None:
+        """Run one tiny prefill + decode through the real kernels so lazy
+        initialisation (hipBLASLt heuristics, RCCL channels) is off the
+        request path, then capture decode graphs."""
+        if self.decode_workspace is None:
+            self._ensure_decode_workspace(self.max_num_reqs)
+        self.capture_graphs()

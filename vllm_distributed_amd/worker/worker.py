@@ -1,0 +1,199 @@
+"""Per-GPU worker: binds a device, joins the process groups, owns the model
+runner.  Methods are invoked by name through the executor's
+``collective_rpc`` (reference ``src/launch.py:290-292,330,387`` and the
+additional calls the engine issues: ``get_kv_cache_spec``,
+``determine_available_memory``, ``initialize_from_config``,
+``compile_or_warm_up_model``, ``execute_dummy_batch``, ``profile``,
+``sleep``/``wake_up``, ``save_sharded_state``).
+"""
+from __future__ import annotations
+
+import gc
+import os
+import sys
+import time
+from typing import Any, Dict, List, Optional
+
+import torch
+
+from .. import envs
+from ..config import VllmConfig
+from ..engine.types import KVCacheConfig, KVCacheSpec, ModelRunnerOutput, SchedulerOutput
+from ..logger import init_logger
+from ..parallel import state as pstate
+from .model_runner import ModelRunner
+
+logger = init_logger(__name__)
+
+
+class Worker:
+    def __init__(self, vllm_config: VllmConfig, local_rank: int, rank: int,
+                 distributed_init_method: Optional[str], is_driver_worker: bool = False):
+        self.vllm_config = vllm_config
+        self.parallel_config = vllm_config.parallel_config
+        self.local_rank = local_rank
+        self.rank = rank
+        self.distributed_init_method = distributed_init_method
+        self.is_driver_worker = is_driver_worker
+        self.device: Optional[torch.device] = None
+        self.model_runner: Optional[ModelRunner] = None
+        self._profiler = None
+        self._fault = self._parse_fault()
+        self._steps = 0
+        self._sleeping = False
+
+    # ------------------------------------------------------------------ init
+    def _parse_fault(self) -> Optional[int]:
+        """Test-only fault hook: ``VDAMD_FAULT_DIE_AT=rank:step``."""
+        spec = envs.VDAMD_FAULT_DIE_AT
+        if not spec:
+            return None
+        try:
+            r, s = spec.split(":")
+            return int(s) if int(r) == self.rank else None
+        except ValueError:
+            return None
+
+    def init_device(self) -> None:
+        dev_type = self.vllm_config.device_config.device
+        if dev_type == "cuda":
+            # one process per GPU; local_rank indexes the *visible* devices
+            torch.cuda.set_device(self.local_rank)
+            self.device = torch.device(f"cuda:{self.local_rank}")
+            backend = "nccl"      # RCCL on ROCm
+            gc.collect()
+            torch.cuda.empty_cache()
+            self.init_free, self.init_total = torch.cuda.mem_get_info()
+        else:
+            self.device = torch.device("cpu")
+            backend = "gloo"
+            torch.set_num_threads(max(1, min(8, (os.cpu_count() or 2) // max(1, self.parallel_config.world_size))))
+        pc = self.parallel_config
+        pstate.init_distributed_environment(pc.world_size, self.rank, self.distributed_init_method,
+                                            self.local_rank, backend, self.device)
+        pstate.initialize_model_parallel(pc.tensor_parallel_size, pc.pipeline_parallel_size)
+        if dev_type == "cuda" and pc.world_size > 1:
+            self._attach_fast_collectives()
+        torch.manual_seed(self.vllm_config.model_config.seed)
+        self.model_runner = ModelRunner(self.vllm_config, self.device)
+
+    def _attach_fast_collectives(self) -> None:
+        """Direct RCCL binding and the peer-mapped all-reduce, each verified
+        against ``torch.distributed`` before it is trusted."""
+        from ..parallel.accel import attach_accelerated_collectives
+        try:
+            attach_accelerated_collectives(self.parallel_config)
+        except Exception as e:  # never fatal: torch.distributed carries the traffic
+            logger.warning("accelerated collectives unavailable (%r); using torch.distributed", e)
+
+    def load_model(self) -> None:
+        self.model_runner.load_model()
+
+    # --------------------------------------------------------------- KV cache
+    def get_kv_cache_spec(self) -> KVCacheSpec:
+        return self.model_runner.get_kv_cache_spec()
+
+    def determine_available_memory(self) -> int:
+        """Bytes this worker can give to the KV cache."""
+        cc = self.vllm_config.cache_config
+        if self.device.type != "cuda":
+            return int(cc.cpu_kv_bytes)
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        self.model_runner.profile_run()
+        torch.cuda.synchronize()
+        peak = torch.cuda.max_memory_allocated()
+        free, total = torch.cuda.mem_get_info()
+        non_torch = max(0, (total - free) - torch.cuda.memory_reserved())
+        torch.cuda.empty_cache()
+        budget = int(total * cc.gpu_memory_utilization)
+        # head-room for hipGraph pools, RCCL channels and the direct all-reduce staging
+        reserve = 2 << 30
+        avail = budget - peak - non_torch - reserve
+        logger.info("memory: total %.1f GiB, peak torch %.1f GiB, non-torch %.1f GiB -> KV %.1f GiB",
+                    total / 2**30, peak / 2**30, non_torch / 2**30, max(avail, 0) / 2**30)
+        return max(int(avail), 0)
+
+    def initialize_from_config(self, kv_cache_config: KVCacheConfig) -> None:
+        self.model_runner.initialize_kv_cache(kv_cache_config.num_blocks)
+
+    def compile_or_warm_up_model(self) -> None:
+        self.model_runner.warm_up()
+
+    # ---------------------------------------------------------------- execute
+    def execute_model(self, scheduler_output: SchedulerOutput) -> Optional[ModelRunnerOutput]:
+        self._steps += 1
+        if self._fault is not None and self._steps >= self._fault:
+            logger.error("fault injection: rank %d exiting at step %d", self.rank, self._steps)
+            os._exit(17)
+        return self.model_runner.execute_model(scheduler_output)
+
+    def execute_dummy_batch(self) -> None:
+        self.model_runner.profile_run()
+
+    def check_health(self) -> bool:
+        return True
+
+    def get_stats(self) -> Dict[str, Any]:
+        d: Dict[str, Any] = {"rank": self.rank, "steps": self._steps}
+        if self.device is not None and self.device.type == "cuda":
+            free, total = torch.cuda.mem_get_info()
+            d.update(mem_free=free, mem_total=total, mem_torch=torch.cuda.memory_allocated())
+        return d
+
+    # ------------------------------------------------------------- profiling
+    def profile(self, is_start: bool = True) -> None:
+        """Start/stop a ``torch.profiler`` trace on this worker; the trace is
+        written under ``VDAMD_PROFILE_DIR``."""
+        if is_start:
+            if self._profiler is not None:
+                return
+            acts = [torch.profiler.ProfilerActivity.CPU]
+            if self.device.type == "cuda":
+                acts.append(torch.profiler.ProfilerActivity.CUDA)
+            out = envs.VDAMD_PROFILE_DIR
+            os.makedirs(out, exist_ok=True)
+            self._profiler = torch.profiler.profile(
+                activities=acts,
+                on_trace_ready=torch.profiler.tensorboard_trace_handler(out, f"rank{self.rank}"))
+            self._profiler.start()
+        elif self._profiler is not None:
+            self._profiler.stop()
+            self._profiler = None
+
+    # --------------------------------------------------------- sleep / wake
+    def sleep(self, level: int = 1) -> None:
+        """Release the KV cache (level 1) so the GPU can be lent out."""
+        if self._sleeping:
+            return
+        for attn in self.model_runner.model.attention_layers():
+            attn.k_cache = attn.v_cache = None
+        self.model_runner.kv_caches = []
+        self.model_runner.graphs.clear()
+        self.model_runner.graph_sizes = []
+        gc.collect()
+        if self.device.type == "cuda":
+            torch.cuda.empty_cache()
+        self._sleeping = True
+
+    def wake_up(self, tags: Optional[List[str]] = None) -> None:
+        if not self._sleeping:
+            return
+        self.model_runner.initialize_kv_cache(self.model_runner.num_blocks)
+        self.model_runner.warm_up()
+        self._sleeping = False
+
+    def save_sharded_state(self, path: str, pattern: Optional[str] = None,
+                           max_size: Optional[int] = None) -> None:
+        from safetensors.torch import save_file
+        os.makedirs(path, exist_ok=True)
+        sd = {k: v.detach().to("cpu").contiguous() for k, v in self.model_runner.model.state_dict().items()}
+        save_file(sd, os.path.join(path, (pattern or "model-rank-{rank}.safetensors").format(rank=self.rank)))
+
+    def add_lora(self, *a, **k) -> bool:
+        raise NotImplementedError("LoRA adapters are not supported")
+
+    def shutdown(self) -> None:
+        self.model_runner = None
+        pstate.destroy_model_parallel()
+        gc.collect()
