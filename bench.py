@@ -1,0 +1,144 @@
+"""Headline benchmark: decode throughput (output tokens/s, whole node) and p50
+time-to-first-token for Llama-3-70B bf16, tensor-parallel over N MI355X GPUs.
+
+    python bench.py --gpus 1 --steps 32 --warmup 4
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" is one engine step (scheduler -> executor -> worker forward ->
+sampling -> scheduler update) in which every running sequence produces one
+token.  The batch is 256 sequences per GPU (weak scaling: global batch 256*N,
+TP = N), 128-token synthetic prompts, random-init weights of the real
+architecture, greedy sampling.  Prefill of the whole batch and W decode steps
+are warm-up; exactly K decode steps are timed between barrier+synchronize
+pairs and the maximum over ranks is reported.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--model", type=str, default="llama-3-70b")
+    ap.add_argument("--batch-per-gpu", type=int, default=256)
+    ap.add_argument("--prompt-len", type=int, default=128)
+    ap.add_argument("--ttft-requests", type=int, default=5)
+    ap.add_argument("--dtype", type=str, default="bfloat16")
+    ap.add_argument("--enforce-eager", action="store_true")
+    ap.add_argument("--executor", type=str, default="auto", choices=["auto", "uni", "spmd"])
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    n = args.gpus
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if n > 1 and world != n:
+        raise SystemExit(f"--gpus {n} needs one rank per GPU: launch with "
+                         f"`python -m torch.distributed.run --nproc-per-node {n} bench.py --gpus {n} ...`")
+    os.environ.setdefault("VLLM_LOGGING_LEVEL", "INFO" if rank == 0 else "WARNING")
+
+    from vllm_distributed_amd.engine.arg_utils import EngineArgs
+    from vllm_distributed_amd.engine.llm_engine import LLMEngine
+    from vllm_distributed_amd.sampling_params import SamplingParams
+
+    batch = args.batch_per_gpu * n
+    total_new = args.warmup + args.steps + 2
+    max_len = args.prompt_len + total_new + 16
+    backend = args.executor
+    if backend == "auto":
+        backend = "spmd" if n > 1 else "uni"
+    engine = LLMEngine.from_engine_args(EngineArgs(
+        model=args.model, dtype=args.dtype, load_format="dummy", tensor_parallel_size=n,
+        distributed_executor_backend=backend, max_model_len=max_len, max_num_seqs=batch,
+        max_num_batched_tokens=max(8192, batch), enable_prefix_caching=False,
+        enforce_eager=args.enforce_eager, max_capture_size=batch, hip_graph_sizes=[batch],
+        gpu_memory_utilization=0.92, seed=0))
+    vocab = engine.model_config.vocab_size
+    rng = np.random.default_rng(1234)
+
+    def sync() -> None:
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- p50 TTFT: single requests on an idle engine
+    ttfts = []
+    for i in range(args.ttft_requests + 1):
+        ids = rng.integers(0, vocab, size=args.prompt_len).tolist()
+        sync()
+        t0 = time.perf_counter()
+        rid = engine.add_request(f"ttft-{i}", ids, SamplingParams(temperature=0.0, max_tokens=1, ignore_eos=True,
+                                                                  detokenize=False))
+        got = False
+        while not got:
+            for out in engine.step():
+                got = got or (out.request_id == rid and len(out.outputs[0].token_ids) >= 1)
+        torch.cuda.synchronize()
+        if i > 0:                      # first one pays lazy initialisation
+            ttfts.append(time.perf_counter() - t0)
+        while engine.has_unfinished_requests():
+            engine.step()
+    ttft_p50_ms = 1e3 * float(np.median(ttfts)) if ttfts else None
+
+    # ---- throughput: fill the batch, prefill it, warm up, time K decode steps
+    sp = SamplingParams(temperature=0.0, max_tokens=total_new, ignore_eos=True, detokenize=False)
+    for i in range(batch):
+        engine.add_request(f"b-{i}", rng.integers(0, vocab, size=args.prompt_len).tolist(), sp)
+    sched = engine.core.scheduler
+    t_prefill0 = time.perf_counter()
+    while sched.waiting or any(r.num_computed_tokens < r.num_prompt_tokens for r in sched.running):
+        engine.step()
+    torch.cuda.synchronize()
+    prefill_s = time.perf_counter() - t_prefill0
+    for _ in range(args.warmup):
+        engine.step()
+    produced = 0
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        outs = engine.step()
+        produced += sum(len(o.new_token_ids) for o in outs)
+    sync()
+    elapsed = time.perf_counter() - t0
+    assert produced == batch * args.steps, (produced, batch, args.steps)
+    if dist.is_initialized():
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        runner = engine.core.executor.driver.worker.model_runner
+        tps = batch * args.steps / elapsed
+        print(json.dumps({
+            "metric": "output tokens/sec (whole node), Llama-3-70B bf16 TP over N GPUs, decode",
+            "value": round(tps, 2), "unit": "tokens/s", "n_gpus": n, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic prompts (random token ids), random-init weights",
+            "ttft_p50_ms": None if ttft_p50_ms is None else round(ttft_p50_ms, 2),
+            "prefill_tokens_per_s": round(batch * args.prompt_len / prefill_s, 1),
+            "config": {"model": args.model, "global_batch": batch, "seq_len": args.prompt_len,
+                       "parallelism": f"tp{n}", "executor": backend,
+                       "hip_graph": bool(runner.graphs), "block_size": runner.block_size,
+                       "step_breakdown_ms": {k: round(v, 3) for k, v in engine.core.timer.summary().items()}},
+        }))
+    engine.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,343 @@
+// Paged attention for gfx950: split-KV decode and varlen causal prefill.
+//
+// Cache layouts make K and V^T direct MFMA operands from global memory (no LDS
+// staging, no transposes):
+//   k_cache[num_blocks][Hkv][block_size][D]     key row contiguous in D
+//   v_cache[num_blocks][Hkv][D][block_size]     D row contiguous in keys
+//
+// Both kernels use the "swapped" formulation on v_mfma_f32_16x16x32:
+//   S^T[key][q]  = K[key][:] . Q[q][:]          A = K rows,   B = Q^T
+//   O^T[d][q]   += V^T[d][key] . P^T[key][q]    A = V^T rows, B = P^T
+// With C/D layout (col = lane&15, row = 4*(lane>>4)+reg) a lane holds, for ONE
+// query column q = lane&15, four consecutive keys per S^T tile.  Two S^T tiles
+// whose K rows are interleaved (tile0 row i <-> key 8*(i>>2)+(i&3), tile1 the
+// same +4) give every lane 8 consecutive keys 8*(lane>>4)..+7 of a 32-key
+// group - exactly the B-operand layout of the PV product, so P never leaves
+// registers and V^T is fetched with plain 16-byte loads.  The softmax
+// running max is shared by the four lanes that hold one query column (two
+// xor-shuffles per 32 keys); row sums stay lane-local until the end.
+#include "common.h"
+
+namespace {
+
+constexpr float NEG_BIG = -1.0e30f;
+constexpr int MAX_SPLITS = 16;
+
+template <typename T>
+__device__ __forceinline__ typename Vec8<T>::type zero8() {
+  typename Vec8<T>::type z;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) z[j] = (T)0.f;
+  return z;
+}
+
+// ---------------------------------------------------------------------------
+// One 32-key group for NQ query sub-tiles of 16 rows each.
+//   qf[n][s]   : Q^T B-operand fragments (s = k-step over D)
+//   acc[n][dt] : O^T accumulators, m[n]/l[n] softmax state (per lane)
+//   qpos_hi[n] : largest key index the lane's query row may attend to
+// ---------------------------------------------------------------------------
+template <typename T, int D, int NQ>
+__device__ __forceinline__ void attend_group(
+    const T* __restrict__ k_cache, const T* __restrict__ v_cache, const int* __restrict__ bt_row, int kvh, int Hkv,
+    int block_size, int base, int seq_len, float scale_log2e, const typename Vec8<T>::type (&qf)[NQ][D / 32],
+    f32x4 (&acc)[NQ][D / 16], float (&m)[NQ], float (&l)[NQ], const int (&qpos_hi)[NQ]) {
+  using V = typename Vec8<T>::type;
+  const int lane = threadIdx.x & 63;
+  const int r16 = lane & 15, g4 = lane >> 4;
+  // ---- K rows for the two interleaved tiles
+  const int key0 = base + 8 * (r16 >> 2) + (r16 & 3);        // tile 0 row; tile 1 row = key0 + 4
+  const int ka = min(key0, seq_len - 1);
+  const int kb = min(key0 + 4, seq_len - 1);
+  const long blk_a = bt_row[ka / block_size], blk_b = bt_row[kb / block_size];
+  const T* ka_ptr = k_cache + ((blk_a * Hkv + kvh) * block_size + (ka % block_size)) * (long)D + 8 * g4;
+  const T* kb_ptr = k_cache + ((blk_b * Hkv + kvh) * block_size + (kb % block_size)) * (long)D + 8 * g4;
+  V kfa[D / 32], kfb[D / 32];
+#pragma unroll
+  for (int s = 0; s < D / 32; ++s) { kfa[s] = ld8<T>(ka_ptr + 32 * s); kfb[s] = ld8<T>(kb_ptr + 32 * s); }
+  // ---- V^T rows: this lane's 8 keys are base + 8*g4 .. +7 (one block: block_size % 8 == 0)
+  const int vkey = min(base + 8 * g4, seq_len - 1) & ~7;
+  const long blk_v = bt_row[vkey / block_size];
+  const T* v_ptr = v_cache + ((blk_v * Hkv + kvh) * (long)D + r16) * block_size + (vkey % block_size);
+  V vf[D / 16];
+#pragma unroll
+  for (int dt = 0; dt < D / 16; ++dt) vf[dt] = ld8<T>(v_ptr + (long)(16 * dt) * block_size);
+
+  const int kidx0 = base + 8 * g4;     // key index of P element j is kidx0 + j
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) {
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < D / 32; ++s) {
+      s0 = mfma16(kfa[s], qf[n][s], s0);
+      s1 = mfma16(kfb[s], qf[n][s], s1);
+    }
+    const int hi = min(qpos_hi[n], seq_len - 1);
+    float p[8];
+    float tmax = NEG_BIG;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float sv = (j < 4 ? s0[j & 3] : s1[j & 3]) * scale_log2e;
+      p[j] = (kidx0 + j <= hi) ? sv : NEG_BIG;
+      tmax = fmaxf(tmax, p[j]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m[n], tmax);
+    const float alpha = exp2f(m[n] - m_new);
+    float psum = 0.f;
+    V pf;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float e = exp2f(p[j] - m_new);
+      psum += e;
+      pf[j] = (T)e;
+    }
+    l[n] = l[n] * alpha + psum;
+    m[n] = m_new;
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt) {
+      acc[n][dt] *= alpha;
+      acc[n][dt] = mfma16(vf[dt], pf, acc[n][dt]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Decode: one query token per sequence.  Workgroup = (kv-split, kv-head x
+// q-tile, sequence); its 4 waves stride over the split's 32-key groups and are
+// merged through LDS.  The 16 MFMA columns carry the GQA group's query heads.
+// ---------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void paged_decode_kernel(
+    T* __restrict__ out, float* __restrict__ part_o, float* __restrict__ part_ml, const T* __restrict__ q,
+    long q_stride, const T* __restrict__ k_cache, const T* __restrict__ v_cache,
+    const int* __restrict__ block_table, int bt_stride, const int* __restrict__ seq_lens, float scale_log2e,
+    int Hq, int Hkv, int block_size, int num_splits, long out_stride) {
+  using V = typename Vec8<T>::type;
+  constexpr int LDS_ROW = D + 4;
+  __shared__ float s_o[4][16][LDS_ROW];
+  __shared__ float s_m[4][16];
+  __shared__ float s_l[4][16];
+
+  const int split = blockIdx.x, b = blockIdx.z;
+  const int G = Hq / Hkv;
+  const int q_tiles = (G + 15) >> 4;
+  const int kvh = blockIdx.y / q_tiles, qt = blockIdx.y - kvh * q_tiles;
+  const int qh0 = kvh * G + qt * 16;
+  const int nq = min(16, G - qt * 16);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int seq_len = seq_lens[b];
+
+  const int n_groups = (seq_len + 31) >> 5;
+  const int gps = (n_groups + num_splits - 1) / num_splits;
+  const int g_begin = split * gps;
+  const int g_end = min(g_begin + gps, n_groups);
+
+  V qf[1][D / 32];
+#pragma unroll
+  for (int s = 0; s < D / 32; ++s)
+    qf[0][s] = (r16 < nq) ? ld8<T>(q + b * q_stride + (long)(qh0 + r16) * D + 32 * s + 8 * g4) : zero8<T>();
+
+  f32x4 acc[1][D / 16];
+#pragma unroll
+  for (int dt = 0; dt < D / 16; ++dt) acc[0][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m[1] = {NEG_BIG}, l[1] = {0.f};
+  const int qpos_hi[1] = {seq_len - 1};
+  const int* bt_row = block_table + (long)b * bt_stride;
+
+  for (int g = g_begin + wid; g < g_end; g += 4)
+    attend_group<T, D, 1>(k_cache, v_cache, bt_row, kvh, Hkv, block_size, g * 32, seq_len, scale_log2e, qf, acc, m,
+                          l, qpos_hi);
+
+  float lsum = l[0];
+  lsum += __shfl_xor(lsum, 16, 64);
+  lsum += __shfl_xor(lsum, 32, 64);
+  if (g4 == 0) { s_m[wid][r16] = m[0]; s_l[wid][r16] = lsum; }
+#pragma unroll
+  for (int dt = 0; dt < D / 16; ++dt)
+    *reinterpret_cast<f32x4*>(&s_o[wid][r16][16 * dt + 4 * g4]) = acc[0][dt];
+  __syncthreads();
+
+  for (int e = threadIdx.x; e < 16 * D; e += 256) {
+    const int qi = e / D, d = e - qi * D;
+    if (qi >= nq) continue;
+    const float m0 = s_m[0][qi], m1 = s_m[1][qi], m2 = s_m[2][qi], m3 = s_m[3][qi];
+    const float mm = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    const float a0 = exp2f(m0 - mm), a1 = exp2f(m1 - mm), a2 = exp2f(m2 - mm), a3 = exp2f(m3 - mm);
+    const float o = s_o[0][qi][d] * a0 + s_o[1][qi][d] * a1 + s_o[2][qi][d] * a2 + s_o[3][qi][d] * a3;
+    const float lt = s_l[0][qi] * a0 + s_l[1][qi] * a1 + s_l[2][qi] * a2 + s_l[3][qi] * a3;
+    const int qh = qh0 + qi;
+    if (num_splits == 1) {
+      out[b * out_stride + (long)qh * D + d] = (T)(lt > 0.f ? o / lt : 0.f);
+    } else {
+      const long pidx = ((long)b * Hq + qh) * num_splits + split;
+      part_o[pidx * D + d] = o;
+      if (d == 0) { part_ml[2 * pidx] = mm; part_ml[2 * pidx + 1] = lt; }
+    }
+  }
+}
+
+template <typename T, int D>
+__global__ void decode_reduce_kernel(T* __restrict__ out, const float* __restrict__ part_o,
+                                     const float* __restrict__ part_ml, int Hq, int num_splits, long out_stride) {
+  const int qh = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+  const long base = ((long)b * Hq + qh) * num_splits;
+  float mm = NEG_BIG;
+  for (int s = 0; s < num_splits; ++s) mm = fmaxf(mm, part_ml[2 * (base + s)]);
+  float o = 0.f, lt = 0.f;
+  for (int s = 0; s < num_splits; ++s) {
+    const float a = exp2f(part_ml[2 * (base + s)] - mm);
+    lt += part_ml[2 * (base + s) + 1] * a;
+    o += part_o[(base + s) * D + d] * a;
+  }
+  out[b * out_stride + (long)qh * D + d] = (T)(lt > 0.f ? o / lt : 0.f);
+}
+
+// ---------------------------------------------------------------------------
+// Prefill / chunked prefill: sequence z owns query rows qsl[z]..qsl[z+1], the
+// last q_len positions of its seq_len tokens; all keys come from the paged
+// cache (the chunk's own K/V were written before this kernel runs).
+// Workgroup = 128 query tokens of one head; each wave owns 32 tokens as two
+// 16-row MFMA column tiles that share every K / V^T fragment it loads.
+// ---------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void paged_prefill_kernel(
+    T* __restrict__ out, const T* __restrict__ q, long q_stride, const T* __restrict__ k_cache,
+    const T* __restrict__ v_cache, const int* __restrict__ block_table, int bt_stride,
+    const int* __restrict__ query_start_loc, const int* __restrict__ seq_lens, float scale_log2e, int Hq, int Hkv,
+    int block_size, long out_stride) {
+  using V = typename Vec8<T>::type;
+  constexpr int NQ = 2;
+  const int z = blockIdx.z, h = blockIdx.y;
+  const int q0 = query_start_loc[z];
+  const int q_len = query_start_loc[z + 1] - q0;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int t_wave = blockIdx.x * 128 + wid * 32;       // first token of this wave within the chunk
+  if (t_wave >= q_len) return;
+  const int seq_len = seq_lens[z];
+  const int ctx = seq_len - q_len;
+  const int kvh = h / (Hq / Hkv);
+
+  V qf[NQ][D / 32];
+  int qpos_hi[NQ];
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) {
+    const int tok = t_wave + 16 * n + r16;
+    qpos_hi[n] = ctx + tok;
+#pragma unroll
+    for (int s = 0; s < D / 32; ++s)
+      qf[n][s] = (tok < q_len) ? ld8<T>(q + (long)(q0 + tok) * q_stride + (long)h * D + 32 * s + 8 * g4)
+                               : zero8<T>();
+  }
+  f32x4 acc[NQ][D / 16];
+  float m[NQ], l[NQ];
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) {
+    m[n] = NEG_BIG; l[n] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt) acc[n][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int* bt_row = block_table + (long)z * bt_stride;
+  const int last_key = min(seq_len - 1, ctx + min(t_wave + 31, q_len - 1));
+  const int n_groups = (last_key >> 5) + 1;
+  for (int g = 0; g < n_groups; ++g)
+    attend_group<T, D, NQ>(k_cache, v_cache, bt_row, kvh, Hkv, block_size, g * 32, seq_len, scale_log2e, qf, acc,
+                           m, l, qpos_hi);
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) {
+    float lsum = l[n];
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+    const int tok = t_wave + 16 * n + r16;
+    if (tok < q_len) {
+      T* orow = out + (long)(q0 + tok) * out_stride + (long)h * D + 4 * g4;
+#pragma unroll
+      for (int dt = 0; dt < D / 16; ++dt) {
+        typename Vec4<T>::type o4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o4[r] = (T)(acc[n][dt][r] * inv);
+        *reinterpret_cast<typename Vec4<T>::type*>(orow + 16 * dt) = o4;
+      }
+    }
+  }
+}
+
+template <typename T, int D>
+int launch_decode(void* out, float* ws, const void* q, long q_stride, const void* kc, const void* vc, const int* bt,
+                  int bt_stride, const int* seq_lens, float scale, int B, int Hq, int Hkv, int block_size,
+                  int num_splits, long out_stride, hipStream_t s) {
+  const int G = Hq / Hkv;
+  const int q_tiles = (G + 15) / 16;
+  float* part_o = ws;
+  float* part_ml = ws ? ws + (long)B * Hq * num_splits * D : nullptr;
+  const float sl2 = scale * 1.4426950408889634f;
+  hipLaunchKernelGGL((paged_decode_kernel<T, D>), dim3(num_splits, Hkv * q_tiles, B), dim3(256), 0, s, (T*)out,
+                     part_o, part_ml, (const T*)q, q_stride, (const T*)kc, (const T*)vc, bt, bt_stride, seq_lens,
+                     sl2, Hq, Hkv, block_size, num_splits, out_stride);
+  HIP_LAUNCH_CHECK();
+  if (num_splits > 1) {
+    hipLaunchKernelGGL((decode_reduce_kernel<T, D>), dim3(Hq, B), dim3(D), 0, s, (T*)out, part_o, part_ml, Hq,
+                       num_splits, out_stride);
+    HIP_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+template <typename T, int D>
+int launch_prefill(void* out, const void* q, long q_stride, const void* kc, const void* vc, const int* bt,
+                   int bt_stride, const int* qsl, const int* seq_lens, float scale, int num_seqs, int max_q_len,
+                   int Hq, int Hkv, int block_size, long out_stride, hipStream_t s) {
+  const float sl2 = scale * 1.4426950408889634f;
+  const int tiles = (max_q_len + 127) / 128;
+  hipLaunchKernelGGL((paged_prefill_kernel<T, D>), dim3(tiles, Hq, num_seqs), dim3(256), 0, s, (T*)out,
+                     (const T*)q, q_stride, (const T*)kc, (const T*)vc, bt, bt_stride, qsl, seq_lens, sl2, Hq, Hkv,
+                     block_size, out_stride);
+  HIP_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+VDAMD_API int vdamd_max_splits() { return MAX_SPLITS; }
+
+// workspace (floats) needed for B sequences: partial O + (m, l) per split
+VDAMD_API long vdamd_decode_workspace_floats(int B, int Hq, int D) {
+  return (long)B * Hq * MAX_SPLITS * (D + 2);
+}
+
+VDAMD_API int vdamd_paged_attention_decode(void* out, float* workspace, const void* q, long q_stride,
+                                           const void* k_cache, const void* v_cache, const int* block_table,
+                                           int bt_stride, const int* seq_lens, float scale, int B, int Hq, int Hkv,
+                                           int D, int block_size, int num_splits, long out_stride, int dtype,
+                                           hipStream_t s) {
+  if (B == 0) return 0;
+  if (Hq % Hkv != 0 || block_size % 8 != 0 || num_splits < 1 || num_splits > MAX_SPLITS) return -1;
+  if (num_splits > 1 && workspace == nullptr) return -3;
+#define CASE(TY, DD)                                                                                           \
+  return launch_decode<TY, DD>(out, workspace, q, q_stride, k_cache, v_cache, block_table, bt_stride, seq_lens, \
+                               scale, B, Hq, Hkv, block_size, num_splits, out_stride, s)
+  if (dtype == DT_BF16) { if (D == 128) CASE(bf16_t, 128); if (D == 64) CASE(bf16_t, 64); }
+  if (dtype == DT_F16) { if (D == 128) CASE(f16_t, 128); if (D == 64) CASE(f16_t, 64); }
+#undef CASE
+  return -2;
+}
+
+VDAMD_API int vdamd_paged_attention_prefill(void* out, const void* q, long q_stride, const void* k_cache,
+                                            const void* v_cache, const int* block_table, int bt_stride,
+                                            const int* query_start_loc, const int* seq_lens, float scale,
+                                            int num_seqs, int max_q_len, int Hq, int Hkv, int D, int block_size,
+                                            long out_stride, int dtype, hipStream_t s) {
+  if (num_seqs == 0 || max_q_len == 0) return 0;
+  if (Hq % Hkv != 0 || block_size % 8 != 0) return -1;
+#define CASE(TY, DD)                                                                                          \
+  return launch_prefill<TY, DD>(out, q, q_stride, k_cache, v_cache, block_table, bt_stride, query_start_loc,   \
+                                seq_lens, scale, num_seqs, max_q_len, Hq, Hkv, block_size, out_stride, s)
+  if (dtype == DT_BF16) { if (D == 128) CASE(bf16_t, 128); if (D == 64) CASE(bf16_t, 64); }
+  if (dtype == DT_F16) { if (D == 128) CASE(f16_t, 128); if (D == 64) CASE(f16_t, 64); }
+#undef CASE
+  return -2;
+}

@@ -1,0 +1,113 @@
+// Rotary embedding (NeoX pairing) fused with the paged KV-cache write.
+//
+// Cache layouts are MFMA-operand-native (see attention_decode.hip):
+//   k_cache[num_blocks][Hkv][block_size][D]   key row contiguous in D
+//   v_cache[num_blocks][Hkv][D][block_size]   transposed: D row contiguous in keys
+//
+// One workgroup per token; each thread owns one 8-element (16-byte) piece:
+//   items [0, Hq*D/16)            rotate a q pair-chunk in place
+//   items [.., +Hkv*D/16)         rotate a k pair-chunk, write it to k_cache
+//   items [.., +Hkv*D/8)          copy a v chunk to v_cache (2-byte strided stores)
+#include "common.h"
+
+namespace {
+
+template <typename T, bool WRITE_CACHE, bool ROTATE>
+__global__ void rope_cache_kernel(const int* __restrict__ positions, T* __restrict__ q, T* __restrict__ k,
+                                  const T* __restrict__ v, long q_stride, long k_stride, long v_stride,
+                                  const float* __restrict__ cos_sin, T* __restrict__ k_cache,
+                                  T* __restrict__ v_cache, const int* __restrict__ slot_mapping, int Hq, int Hkv,
+                                  int D, int block_size) {
+  using V = typename Vec8<T>::type;
+  const long t = blockIdx.x;
+  const int half = D >> 1;
+  const int cpp = half >> 3;                 // 8-element chunks per half head
+  const int q_items = Hq * cpp, k_items = Hkv * cpp, v_items = WRITE_CACHE ? Hkv * (D >> 3) : 0;
+  const int pos = ROTATE ? positions[t] : 0;
+  const float* cs = cos_sin + (long)pos * D;   // [cos(half) | sin(half)]
+  long slot = -1;
+  if (WRITE_CACHE) slot = slot_mapping[t];
+  const long blk = slot >= 0 ? slot / block_size : 0;
+  const int off = slot >= 0 ? (int)(slot % block_size) : 0;
+
+  for (int item = threadIdx.x; item < q_items + k_items + v_items; item += blockDim.x) {
+    if (item < q_items + k_items) {
+      const bool is_q = item < q_items;
+      const int it = is_q ? item : item - q_items;
+      const int h = it / cpp, c = it - h * cpp;
+      T* base = is_q ? q + t * q_stride + (long)h * D : k + t * k_stride + (long)h * D;
+      V x1 = ld8<T>(base + 8 * c);
+      V x2 = ld8<T>(base + half + 8 * c);
+      V o1 = x1, o2 = x2;
+      if (ROTATE) {
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs + 8 * c);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(cs + 8 * c + 4);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(cs + half + 8 * c);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(cs + half + 8 * c + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float cj = j < 4 ? c0[j & 3] : c1[j & 3];
+          const float sj = j < 4 ? s0[j & 3] : s1[j & 3];
+          const float a = (float)x1[j], b = (float)x2[j];
+          o1[j] = (T)(a * cj - b * sj);
+          o2[j] = (T)(b * cj + a * sj);
+        }
+      }
+      if (is_q) {
+        if (ROTATE) { st8<T>(base + 8 * c, o1); st8<T>(base + half + 8 * c, o2); }
+      } else {
+        if (!WRITE_CACHE && ROTATE) { st8<T>(base + 8 * c, o1); st8<T>(base + half + 8 * c, o2); }
+        if (WRITE_CACHE && slot >= 0) {
+          T* dst = k_cache + (((blk * Hkv + h) * block_size + off) * (long)D);
+          st8<T>(dst + 8 * c, o1);
+          st8<T>(dst + half + 8 * c, o2);
+        }
+      }
+    } else if (slot >= 0) {
+      const int it = item - q_items - k_items;
+      const int cpd = D >> 3;
+      const int h = it / cpd, c = it - h * cpd;
+      V x = ld8<T>(v + t * v_stride + (long)h * D + 8 * c);
+      T* dst = v_cache + ((blk * Hkv + h) * (long)D + 8 * c) * block_size + off;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dst[(long)j * block_size] = x[j];
+    }
+  }
+}
+
+template <typename T>
+int launch(const int* positions, void* q, void* k, const void* v, long qs, long ks, long vs, const float* cos_sin,
+           void* k_cache, void* v_cache, const int* slot_mapping, int T_tokens, int Hq, int Hkv, int D,
+           int block_size, int mode, hipStream_t s) {
+  const int items = Hq * (D >> 4) + Hkv * (D >> 4) + Hkv * (D >> 3);
+  int threads = (items + 63) / 64 * 64;
+  if (threads > 512) threads = 512;
+#define L(WC, ROT)                                                                                          \
+  hipLaunchKernelGGL((rope_cache_kernel<T, WC, ROT>), dim3(T_tokens), dim3(threads), 0, s, positions, (T*)q, \
+                     (T*)k, (const T*)v, qs, ks, vs, cos_sin, (T*)k_cache, (T*)v_cache, slot_mapping, Hq, Hkv, \
+                     D, block_size)
+  if (mode == 0) L(true, true);          // rotate q,k + write k,v to cache
+  else if (mode == 1) L(false, true);    // rotate q,k in place only
+  else L(true, false);                   // cache write only (k,v already final)
+#undef L
+  HIP_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+// mode 0: rotate + cache, 1: rotate only, 2: cache only.  Strides are in elements.
+VDAMD_API int vdamd_rope_cache(const int* positions, void* q, void* k, const void* v, long q_stride,
+                               long k_stride, long v_stride, const float* cos_sin, void* k_cache, void* v_cache,
+                               const int* slot_mapping, int T, int Hq, int Hkv, int D, int block_size, int mode,
+                               int dtype, hipStream_t s) {
+  if (T == 0) return 0;
+  if (D % 16 != 0) return -1;
+  if (dtype == DT_BF16)
+    return launch<bf16_t>(positions, q, k, v, q_stride, k_stride, v_stride, cos_sin, k_cache, v_cache,
+                          slot_mapping, T, Hq, Hkv, D, block_size, mode, s);
+  if (dtype == DT_F16)
+    return launch<f16_t>(positions, q, k, v, q_stride, k_stride, v_stride, cos_sin, k_cache, v_cache,
+                         slot_mapping, T, Hq, Hkv, D, block_size, mode, s);
+  return -2;
+}

@@ -1,0 +1,259 @@
+"""HIP kernels vs the plain-PyTorch fp32 reference of the same op (needs an MI355X)."""
+import math
+
+import pytest
+import torch
+
+from vllm_distributed_amd import ops
+from vllm_distributed_amd.ops import torch_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib():
+    from vllm_distributed_amd.ops import hip
+    hip.load()      # fail loudly if the extension was not built
+    yield
+
+
+def _rand(*shape, dtype=torch.bfloat16, scale=1.0):
+    return (torch.randn(*shape, device=DEV, dtype=torch.float32) * scale).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,H", [(1, 4096), (7, 8192), (300, 768), (33, 128), (5, 16384)])
+def test_rms_norm_and_fused_add(dtype, T, H):
+    x, r, w = _rand(T, H, dtype=dtype), _rand(T, H, dtype=dtype), _rand(H, dtype=dtype, scale=0.3) + 1
+    ref = torch_ref.rms_norm(x.float(), w.float(), 1e-5)
+    got = ops.rms_norm(x, w, 1e-5)
+    torch.testing.assert_close(got.float(), ref, rtol=2e-2, atol=2e-2)
+    ref_n, ref_r = torch_ref.fused_add_rms_norm(x.clone(), r.clone(), w, 1e-5)
+    xx, rr = x.clone(), r.clone()
+    got_n, got_r = ops.fused_add_rms_norm(xx, rr, w, 1e-5)
+    assert got_n.data_ptr() == xx.data_ptr() and got_r.data_ptr() == rr.data_ptr()   # in place
+    torch.testing.assert_close(got_r.float(), ref_r.float(), rtol=0, atol=0)
+    torch.testing.assert_close(got_n.float(), ref_n.float(), rtol=2e-2, atol=2e-2)
+
+
+def test_rms_norm_strided_rows():
+    big = _rand(10, 3 * 512)
+    x = big[:, 512:1024]
+    w = _rand(512) + 1
+    torch.testing.assert_close(ops.rms_norm(x, w, 1e-6).float(),
+                               torch_ref.rms_norm(x.float(), w.float(), 1e-6), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("T,H", [(3, 768), (64, 4096)])
+def test_layer_norm(T, H):
+    x, w, b = _rand(T, H, dtype=torch.float16), _rand(H, dtype=torch.float16) + 1, _rand(H, dtype=torch.float16)
+    ref = torch_ref.layer_norm(x.float(), w.float(), b.float(), 1e-5)
+    torch.testing.assert_close(ops.layer_norm(x, w, b, 1e-5).float(), ref, rtol=1e-2, atol=1e-2)
+    ref = torch_ref.layer_norm(x.float(), w.float(), None, 1e-5)
+    torch.testing.assert_close(ops.layer_norm(x, w, None, 1e-5).float(), ref, rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("T,F", [(1, 14336), (257, 3584), (4096, 512)])
+def test_silu_and_mul(T, F):
+    x = _rand(T, 2 * F)
+    torch.testing.assert_close(ops.silu_and_mul(x).float(), torch_ref.silu_and_mul(x.float()),
+                               rtol=2e-2, atol=2e-2)
+
+
+def test_embedding_vocab_shard():
+    w = _rand(1000, 256)
+    ids = torch.tensor([0, 5, 999, 1000, 2500, 1999, 1001], device=DEV, dtype=torch.int32)
+    got = ops.embedding(ids, w, vocab_start=1000, masked=True)
+    ref = torch_ref.embedding(ids, w, 1000, True)
+    torch.testing.assert_close(got, ref, rtol=0, atol=0)
+    assert got[0].abs().sum() == 0 and got[3].abs().sum() > 0
+
+
+@pytest.mark.parametrize("hq,hkv,d,bs", [(32, 8, 128, 64), (8, 8, 64, 16), (12, 2, 128, 32)])
+def test_rope_and_cache_matches_reference(hq, hkv, d, bs):
+    T, nb = 37, 12
+    qkv = _rand(T, (hq + 2 * hkv) * d)
+    cos_sin = torch_ref.build_cos_sin_cache(d, 4096, 500000.0).to(DEV)
+    pos = torch.randint(0, 4096, (T,), device=DEV, dtype=torch.int32)
+    slots = torch.randperm(nb * bs, device=DEV)[:T].to(torch.int32)
+    slots[5] = -1                                       # padding token: no cache write
+    kc = torch.zeros(nb, hkv, bs, d, device=DEV, dtype=torch.bfloat16)
+    vc = torch.zeros(nb, hkv, d, bs, device=DEV, dtype=torch.bfloat16)
+    kc_ref, vc_ref = kc.float(), vc.float()
+    q_ref = torch_ref.rope_and_cache(pos, qkv.float().clone(), cos_sin, kc_ref, vc_ref, slots, hq, hkv, d)
+    q = ops.rope_and_cache(pos, qkv, cos_sin, kc, vc, slots, hq, hkv, d)
+    torch.testing.assert_close(q.float(), q_ref, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(kc.float(), kc_ref, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(vc.float(), vc_ref, rtol=0, atol=0)
+
+
+def test_rotary_and_reshape_unfused():
+    T, hq, hkv, d, bs, nb = 19, 4, 2, 64, 16, 8
+    q, k, v = _rand(T, hq * d), _rand(T, hkv * d), _rand(T, hkv * d)
+    cos_sin = torch_ref.build_cos_sin_cache(d, 512, 10000.0).to(DEV)
+    pos = torch.randint(0, 512, (T,), device=DEV, dtype=torch.int32)
+    qr, kr = q.float().clone(), k.float().clone()
+    torch_ref.rotary_embedding(pos, qr, kr, cos_sin, d)
+    ops.rotary_embedding(pos, q, k, cos_sin, d)
+    torch.testing.assert_close(q.float(), qr, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(k.float(), kr, rtol=2e-2, atol=2e-2)
+    slots = torch.randperm(nb * bs, device=DEV)[:T].to(torch.int32)
+    kc = torch.zeros(nb, hkv, bs, d, device=DEV, dtype=torch.bfloat16)
+    vc = torch.zeros(nb, hkv, d, bs, device=DEV, dtype=torch.bfloat16)
+    kc_ref, vc_ref = kc.clone(), vc.clone()
+    torch_ref.reshape_and_cache(k.view(T, hkv, d), v.view(T, hkv, d), kc_ref, vc_ref, slots)
+    ops.reshape_and_cache(k.view(T, hkv, d), v.view(T, hkv, d), kc, vc, slots)
+    assert torch.equal(kc, kc_ref) and torch.equal(vc, vc_ref)
+
+
+def _make_paged(seq_lens, hkv, d, bs, dtype=torch.bfloat16, extra_blocks=3):
+    """Random paged caches with a shuffled block table."""
+    nblk = [(s + bs - 1) // bs for s in seq_lens]
+    total = sum(nblk) + extra_blocks
+    perm = torch.randperm(total).tolist()
+    maxb = max(nblk) + 1
+    bt = torch.zeros(len(seq_lens), maxb, dtype=torch.int32)
+    it = iter(perm)
+    for i, n in enumerate(nblk):
+        for j in range(n):
+            bt[i, j] = next(it)
+    kc = _rand(total, hkv, bs, d, dtype=dtype)
+    vc = _rand(total, hkv, d, bs, dtype=dtype)
+    return kc, vc, bt.to(DEV)
+
+
+@pytest.mark.parametrize("hq,hkv,d,bs", [(32, 8, 128, 64), (64, 8, 128, 64), (12, 12, 64, 16),
+                                         (24, 2, 128, 32), (4, 2, 64, 128)])
+@pytest.mark.parametrize("splits", [None, 1, 4])
+def test_paged_attention_decode(hq, hkv, d, bs, splits):
+    from vllm_distributed_amd.ops import hip
+    seq_lens = [1, 31, 32, 33, 64, 100, 517, 1000, 129, 64 * 7]
+    kc, vc, bt = _make_paged(seq_lens, hkv, d, bs)
+    sl = torch.tensor(seq_lens, device=DEV, dtype=torch.int32)
+    q = _rand(len(seq_lens), hq, d)
+    scale = 1.0 / math.sqrt(d)
+    ref = torch_ref.paged_attention_decode(q.float(), kc.float(), vc.float(), bt, sl, scale)
+    got = hip.paged_attention_decode(q, kc, vc, bt, sl, scale, max_seq_len=max(seq_lens), num_splits=splits)
+    torch.testing.assert_close(got.float(), ref, rtol=2e-2, atol=2e-2)
+
+
+def test_paged_attention_decode_strided_q_and_padding_rows():
+    from vllm_distributed_amd.ops import hip
+    hq, hkv, d, bs = 32, 8, 128, 64
+    seq_lens = [200, 0, 77]                     # a zero-length (graph padding) row
+    kc, vc, bt = _make_paged([200, 1, 77], hkv, d, bs)
+    sl = torch.tensor(seq_lens, device=DEV, dtype=torch.int32)
+    qkv = _rand(3, (hq + 2 * hkv) * d)
+    q = qkv[:, :hq * d].view(3, hq, d)          # row stride = packed qkv width
+    got = hip.paged_attention_decode(q, kc, vc, bt, sl, 0.09, max_seq_len=200)
+    ref = torch_ref.paged_attention_decode(q.float()[[0, 2]], kc.float(), vc.float(), bt[[0, 2]], sl[[0, 2]], 0.09)
+    torch.testing.assert_close(got[[0, 2]].float(), ref, rtol=2e-2, atol=2e-2)
+    assert got[1].abs().sum() == 0
+
+
+def test_decode_softmax_rescale_branch_with_spiked_key():
+    """A late key whose score dwarfs all earlier ones forces the running-max
+    rescale of everything accumulated so far."""
+    from vllm_distributed_amd.ops import hip
+    hq, hkv, d, bs = 8, 1, 128, 64
+    seq_lens = [700]
+    kc, vc, bt = _make_paged(seq_lens, hkv, d, bs)
+    q = _rand(1, hq, d)
+    blk = int(bt[0, 600 // bs])
+    kc[blk, 0, 600 % bs, :] = (q[0, 3].float() * 4).to(kc.dtype)      # huge dot product with head 3
+    sl = torch.tensor(seq_lens, device=DEV, dtype=torch.int32)
+    ref = torch_ref.paged_attention_decode(q.float(), kc.float(), vc.float(), bt, sl, 0.5)
+    for splits in (1, 3):
+        got = hip.paged_attention_decode(q, kc, vc, bt, sl, 0.5, max_seq_len=700, num_splits=splits)
+        torch.testing.assert_close(got.float(), ref, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("hq,hkv,d,bs", [(32, 8, 128, 64), (8, 8, 64, 16), (6, 2, 128, 32)])
+def test_paged_attention_prefill_varlen_and_chunked(hq, hkv, d, bs):
+    # (q_len, seq_len): full prompts, a chunk continuing a cached prefix, a single token
+    cases = [(5, 5), (128, 128), (130, 130), (40, 300), (1, 77), (257, 600), (33, 33)]
+    seq_lens = [c[1] for c in cases]
+    kc, vc, bt = _make_paged(seq_lens, hkv, d, bs)
+    qsl = [0]
+    for ql, _ in cases:
+        qsl.append(qsl[-1] + ql)
+    q = _rand(qsl[-1], hq, d)
+    qsl_t = torch.tensor(qsl, device=DEV, dtype=torch.int32)
+    sl = torch.tensor(seq_lens, device=DEV, dtype=torch.int32)
+    scale = 1.0 / math.sqrt(d)
+    ref = torch_ref.paged_attention(q.float(), kc.float(), vc.float(), bt, qsl_t, sl, scale)
+    got = ops.paged_attention(q, kc, vc, bt, qsl_t, sl, scale, max(c[0] for c in cases), max(seq_lens))
+    torch.testing.assert_close(got.float(), ref, rtol=2e-2, atol=2e-2)
+
+
+def test_mfma_operand_maps_with_exact_integer_data():
+    """A = I style check with asymmetric data: one-hot queries pick out single
+    K dimensions, V holds distinct small integers, so any swapped lane/row map
+    in the kernels changes the result by whole numbers."""
+    from vllm_distributed_amd.ops import hip
+    hq, hkv, d, bs, S = 8, 1, 128, 64, 64
+    kc = torch.zeros(1, hkv, bs, d, device=DEV, dtype=torch.bfloat16)
+    vc = torch.zeros(1, hkv, d, bs, device=DEV, dtype=torch.bfloat16)
+    # key j has a large value only in dimension j -> query one-hot(dim j) selects key j
+    for j in range(S):
+        kc[0, 0, j, j] = 64.0
+    keys = torch.arange(S, device=DEV).float()
+    dims = torch.arange(d, device=DEV).float()
+    vc[0, 0] = ((dims[:, None] * 2 + keys[None, :] * 3) % 61).to(torch.bfloat16)   # asymmetric in (d, key)
+    q = torch.zeros(1, hq, d, device=DEV, dtype=torch.bfloat16)
+    picks = [3, 17, 40, 63, 0, 9, 31, 32]
+    for h, j in enumerate(picks):
+        q[0, h, j] = 8.0
+    bt = torch.zeros(1, 1, device=DEV, dtype=torch.int32)
+    sl = torch.tensor([S], device=DEV, dtype=torch.int32)
+    got = hip.paged_attention_decode(q, kc, vc, bt, sl, 1.0, max_seq_len=S, num_splits=1).float()
+    for h, j in enumerate(picks):
+        torch.testing.assert_close(got[0, h], vc[0, 0, :, j].float(), rtol=0, atol=1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_argmax(dtype):
+    logits = _rand(9, 128256, dtype=dtype)
+    logits[3, 777] = 50.0
+    logits[4, 10] = 60.0
+    logits[4, 5] = 60.0            # tie -> lowest index
+    got = ops.argmax(logits)
+    ref = logits.float().argmax(-1)
+    assert got[3] == 777 and got[4] == 5
+    assert torch.equal(got.long(), torch.where(torch.arange(9, device=DEV) == 4, torch.tensor(5, device=DEV), ref))
+
+
+def test_sample_matches_reference_on_separated_distributions():
+    torch.manual_seed(0)
+    B, V = 16, 5000
+    # well separated probabilities: random permutation of a geometric-like ladder
+    base = torch.linspace(8.0, -30.0, V)
+    logits = torch.stack([base[torch.randperm(V)] for _ in range(B)]).to(DEV)
+    temperature = torch.tensor([0.0, 1.0, 0.7, 1.3] * 4, device=DEV)
+    top_k = torch.tensor([-1, -1, 50, 5, 1, 100, -1, 20] * 2, device=DEV, dtype=torch.int32)
+    top_p = torch.tensor([1.0, 0.9, 1.0, 0.5, 1.0, 0.95, 0.3, 0.8] * 2, device=DEV)
+    min_p = torch.tensor([0.0, 0.0, 0.0, 0.0, 0.0, 0.05, 0.0, 0.1] * 2, device=DEV)
+    for u in (0.013, 0.37, 0.61, 0.93, 0.999):
+        uniform = torch.full((B,), u, device=DEV)
+        got = ops.sample(logits, temperature, top_k, top_p, min_p, uniform)
+        ref = torch_ref.sample(logits, temperature, top_k, top_p, min_p, uniform)
+        assert torch.equal(got.long(), ref.long()), (u, got.tolist(), ref.tolist())
+
+
+def test_sample_respects_filters_statistically():
+    torch.manual_seed(1)
+    V = 128256
+    logits = _rand(4, V, dtype=torch.float32, scale=3.0)
+    temperature = torch.ones(4, device=DEV)
+    top_k = torch.tensor([10, -1, 10, -1], device=DEV, dtype=torch.int32)
+    top_p = torch.tensor([1.0, 0.5, 0.5, 1.0], device=DEV)
+    min_p = torch.tensor([0.0, 0.0, 0.0, 0.2], device=DEV)
+    probs = torch.softmax(logits, -1)
+    sp, si = probs.sort(-1, descending=True)
+    for u in torch.linspace(0.01, 0.99, 25).tolist():
+        tok = ops.sample(logits, temperature, top_k, top_p, min_p, torch.full((4,), u, device=DEV)).long()
+        rank = [(si[i] == tok[i]).nonzero().item() for i in range(4)]
+        assert rank[0] < 10 and rank[2] < 10
+        assert sp[1, :rank[1]].sum() < 0.5 + 1e-4 and sp[2, :rank[2]].sum() < 0.5 + 1e-4
+        assert probs[3, tok[3]] >= 0.2 * sp[3, 0] - 1e-7

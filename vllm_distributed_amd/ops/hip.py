@@ -1,0 +1,294 @@
+"""ctypes bindings for ``libvdamd_ops.so`` (the gfx950 kernel library).
+
+Every entry point takes raw device pointers plus the current HIP stream, so
+the launches are captured when the caller is inside a hipGraph capture.
+Shapes are validated here, on the host, before a kernel is launched: an
+out-of-bounds access in a hand-written kernel can take the GPU down.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_long, c_void_p
+from typing import Optional, Tuple
+
+import torch
+
+_LIB: Optional[ctypes.CDLL] = None
+_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "_C",
+                         "libvdamd_ops.so")
+_DT = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
+MAX_SPLITS = 16
+
+
+def load() -> ctypes.CDLL:
+    global _LIB, MAX_SPLITS
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_LIB_PATH):
+        raise FileNotFoundError(f"{_LIB_PATH} is missing: run `python -m vllm_distributed_amd.build`")
+    lib = ctypes.CDLL(_LIB_PATH)
+    P, I, L, F = c_void_p, c_int, c_long, c_float
+    sigs = {
+        "vdamd_rms_norm": [P, P, P, P, F, I, I, L, L, I, P],
+        "vdamd_layer_norm": [P, P, P, P, F, I, I, I, P],
+        "vdamd_silu_and_mul": [P, P, L, I, I, P],
+        "vdamd_embedding": [P, P, P, I, I, I, I, I, P],
+        "vdamd_rope_cache": [P, P, P, P, L, L, L, P, P, P, P, I, I, I, I, I, I, I, P],
+        "vdamd_paged_attention_decode": [P, P, P, L, P, P, P, I, P, F, I, I, I, I, I, I, L, I, P],
+        "vdamd_paged_attention_prefill": [P, P, L, P, P, P, I, P, P, F, I, I, I, I, I, I, L, I, P],
+        "vdamd_argmax": [P, P, I, I, L, I, P],
+        "vdamd_sample": [P, P, I, I, L, P, P, P, P, P, I, P],
+    }
+    for name, argtypes in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    lib.vdamd_decode_workspace_floats.argtypes = [I, I, I]
+    lib.vdamd_decode_workspace_floats.restype = c_long
+    lib.vdamd_max_splits.restype = c_int
+    MAX_SPLITS = int(lib.vdamd_max_splits())
+    _LIB = lib
+    return lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(rc: int, name: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with code {rc}")
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t.dtype}") from None
+
+
+def supports_head_dim(d: int) -> bool:
+    return d in (64, 128)
+
+
+def _half(t: torch.Tensor) -> bool:
+    return t.dtype in (torch.bfloat16, torch.float16)
+
+
+# ------------------------------------------------------------------- norms
+def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    if not _half(x):
+        from . import torch_ref
+        return torch_ref.rms_norm(x, weight, eps)
+    h = x.shape[-1]
+    x2 = x.reshape(-1, h)
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    out = torch.empty((x2.shape[0], h), dtype=x.dtype, device=x.device)
+    assert weight.numel() == h and weight.dtype == x.dtype and weight.is_contiguous()
+    _check(_LIB.vdamd_rms_norm(out.data_ptr(), x2.data_ptr(), None, weight.data_ptr(), eps, x2.shape[0], h,
+                               x2.stride(0), h, _dt(x), _stream()), "rms_norm")
+    return out.view(x.shape)
+
+
+def fused_add_rms_norm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float,
+                       ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """In place: ``residual <- x + residual``; ``x <- rms_norm(residual) * w``."""
+    if not _half(x):
+        from . import torch_ref
+        return torch_ref.fused_add_rms_norm(x, residual, weight, eps)
+    h = x.shape[-1]
+    assert x.dim() == 2 and x.is_contiguous() and residual.is_contiguous() and residual.shape == x.shape
+    assert weight.numel() == h and weight.dtype == x.dtype and residual.dtype == x.dtype
+    _check(_LIB.vdamd_rms_norm(x.data_ptr(), x.data_ptr(), residual.data_ptr(), weight.data_ptr(), eps,
+                               x.shape[0], h, h, h, _dt(x), _stream()), "fused_add_rms_norm")
+    return x, residual
+
+
+def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], eps: float) -> torch.Tensor:
+    if not _half(x):
+        from . import torch_ref
+        return torch_ref.layer_norm(x, weight, bias, eps)
+    h = x.shape[-1]
+    x2 = x.reshape(-1, h).contiguous()
+    out = torch.empty_like(x2)
+    _check(_LIB.vdamd_layer_norm(out.data_ptr(), x2.data_ptr(), weight.data_ptr(),
+                                 None if bias is None else bias.data_ptr(), eps, x2.shape[0], h, _dt(x),
+                                 _stream()), "layer_norm")
+    return out.view(x.shape)
+
+
+def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
+    if not _half(x):
+        from . import torch_ref
+        return torch_ref.silu_and_mul(x)
+    f = x.shape[-1] // 2
+    x2 = x.reshape(-1, 2 * f)
+    assert x2.is_contiguous()
+    out = torch.empty((x2.shape[0], f), dtype=x.dtype, device=x.device)
+    _check(_LIB.vdamd_silu_and_mul(out.data_ptr(), x2.data_ptr(), x2.shape[0], f, _dt(x), _stream()),
+           "silu_and_mul")
+    return out.view(x.shape[:-1] + (f,))
+
+
+def embedding(ids: torch.Tensor, weight: torch.Tensor, vocab_start: int = 0) -> torch.Tensor:
+    if not _half(weight):
+        from . import torch_ref
+        return torch_ref.embedding(ids, weight, vocab_start, True)
+    assert ids.dim() == 1 and weight.is_contiguous()
+    if ids.dtype != torch.int32:
+        ids = ids.to(torch.int32)
+    t, h = ids.shape[0], weight.shape[1]
+    out = torch.empty((t, h), dtype=weight.dtype, device=weight.device)
+    _check(_LIB.vdamd_embedding(out.data_ptr(), ids.data_ptr(), weight.data_ptr(), t, h, vocab_start,
+                                weight.shape[0], _dt(weight), _stream()), "embedding")
+    return out
+
+
+# ---------------------------------------------------------- rotary + cache
+def _check_cache(k_cache: torch.Tensor, v_cache: torch.Tensor, hkv: int, d: int) -> int:
+    assert k_cache.dim() == 4 and v_cache.dim() == 4 and k_cache.is_contiguous() and v_cache.is_contiguous()
+    nb, h, bs, dd = k_cache.shape
+    assert (h, dd) == (hkv, d) and tuple(v_cache.shape) == (nb, hkv, d, bs), (k_cache.shape, v_cache.shape)
+    assert bs % 8 == 0
+    return bs
+
+
+def rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping, num_heads, num_kv_heads,
+                   head_dim) -> torch.Tensor:
+    if not _half(qkv):
+        from . import torch_ref
+        return torch_ref.rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping,
+                                        num_heads, num_kv_heads, head_dim)
+    t = qkv.shape[0]
+    qs, ks = num_heads * head_dim, num_kv_heads * head_dim
+    assert qkv.dim() == 2 and qkv.shape[1] == qs + 2 * ks and qkv.stride(1) == 1
+    assert cos_sin_cache.dtype == torch.float32 and cos_sin_cache.shape[1] == head_dim
+    assert positions.dtype == torch.int32 and slot_mapping.dtype == torch.int32
+    assert positions.numel() >= t and slot_mapping.numel() >= t
+    bs = _check_cache(k_cache, v_cache, num_kv_heads, head_dim)
+    st = qkv.stride(0)
+    esz = qkv.element_size()
+    base = qkv.data_ptr()
+    _check(_LIB.vdamd_rope_cache(positions.data_ptr(), base, base + qs * esz, base + (qs + ks) * esz, st, st, st,
+                                 cos_sin_cache.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+                                 slot_mapping.data_ptr(), t, num_heads, num_kv_heads, head_dim, bs, 0,
+                                 _dt(qkv), _stream()), "rope_and_cache")
+    return qkv[:, :qs]
+
+
+def rotary_embedding(positions, q, k, cos_sin_cache, head_dim) -> None:
+    if not _half(q):
+        from . import torch_ref
+        return torch_ref.rotary_embedding(positions, q, k, cos_sin_cache, head_dim)
+    t = q.shape[0]
+    assert q.stride(-1) == 1 and k.stride(-1) == 1 and q.dim() == 2 and k.dim() == 2
+    assert positions.dtype == torch.int32 and cos_sin_cache.dtype == torch.float32
+    _check(_LIB.vdamd_rope_cache(positions.data_ptr(), q.data_ptr(), k.data_ptr(), None, q.stride(0),
+                                 k.stride(0), 0, cos_sin_cache.data_ptr(), None, None, None, t,
+                                 q.shape[1] // head_dim, k.shape[1] // head_dim, head_dim, 16, 1, _dt(q),
+                                 _stream()), "rotary_embedding")
+
+
+def reshape_and_cache(k, v, k_cache, v_cache, slot_mapping) -> None:
+    if not _half(k):
+        from . import torch_ref
+        return torch_ref.reshape_and_cache(k, v, k_cache, v_cache, slot_mapping)
+    t, hkv, d = k.shape
+    assert k.stride(2) == 1 and v.stride(2) == 1 and k.stride(1) == d and v.stride(1) == d
+    assert slot_mapping.dtype == torch.int32 and slot_mapping.numel() >= t
+    bs = _check_cache(k_cache, v_cache, hkv, d)
+    _check(_LIB.vdamd_rope_cache(None, None, k.data_ptr(), v.data_ptr(), 0, k.stride(0), v.stride(0), None,
+                                 k_cache.data_ptr(), v_cache.data_ptr(), slot_mapping.data_ptr(), t, 0, hkv, d,
+                                 bs, 2, _dt(k), _stream()), "reshape_and_cache")
+
+
+# ---------------------------------------------------------------- attention
+def decode_workspace_floats(max_bs: int, num_heads: int, head_dim: int) -> int:
+    return int(_LIB.vdamd_decode_workspace_floats(max_bs, num_heads, head_dim))
+
+
+def choose_num_splits(batch: int, num_kv_heads: int, max_seq_len: int) -> int:
+    """Enough workgroups to fill 256 CUs twice over, each split >= 256 keys."""
+    wgs = max(1, batch * num_kv_heads)
+    want = (512 + wgs - 1) // wgs
+    by_len = max(1, (max_seq_len + 255) // 256)
+    return max(1, min(MAX_SPLITS, want, by_len))
+
+
+def paged_attention_decode(q, k_cache, v_cache, block_table, seq_lens, scale, max_seq_len=0, out=None,
+                           workspace=None, num_splits: Optional[int] = None) -> torch.Tensor:
+    b, hq, d = q.shape
+    hkv = k_cache.shape[1]
+    bs = _check_cache(k_cache, v_cache, hkv, d)
+    assert q.stride(2) == 1 and q.stride(1) == d and hq % hkv == 0
+    assert block_table.dtype == torch.int32 and seq_lens.dtype == torch.int32
+    assert block_table.shape[0] >= b and seq_lens.numel() >= b and block_table.stride(1) == 1
+    if max_seq_len <= 0:
+        max_seq_len = block_table.shape[1] * bs
+    assert max_seq_len <= block_table.shape[1] * bs, "block table narrower than max_seq_len"
+    if out is None:
+        out = torch.empty((b, hq, d), dtype=q.dtype, device=q.device)
+    assert out.is_contiguous() and out.shape == (b, hq, d)
+    if num_splits is None:
+        num_splits = choose_num_splits(b, hkv, max_seq_len)
+    ws_ptr = None
+    if num_splits > 1:
+        need = b * hq * num_splits * (d + 2)
+        if workspace is None or workspace.numel() < need:
+            workspace = torch.empty(need, dtype=torch.float32, device=q.device)
+        ws_ptr = workspace.data_ptr()
+    _check(_LIB.vdamd_paged_attention_decode(
+        out.data_ptr(), ws_ptr, q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(),
+        block_table.data_ptr(), block_table.stride(0), seq_lens.data_ptr(), float(scale), b, hq, hkv, d, bs,
+        num_splits, hq * d, _dt(q), _stream()), "paged_attention_decode")
+    return out
+
+
+def paged_attention_prefill(q, k_cache, v_cache, block_table, query_start_loc, seq_lens, scale,
+                            max_query_len=0, max_seq_len=0, out=None) -> torch.Tensor:
+    t, hq, d = q.shape
+    hkv = k_cache.shape[1]
+    bs = _check_cache(k_cache, v_cache, hkv, d)
+    nseq = seq_lens.numel()
+    assert q.stride(2) == 1 and q.stride(1) == d and hq % hkv == 0
+    assert block_table.dtype == torch.int32 and seq_lens.dtype == torch.int32
+    assert query_start_loc.dtype == torch.int32 and query_start_loc.numel() == nseq + 1
+    assert block_table.shape[0] >= nseq and block_table.stride(1) == 1
+    if max_query_len <= 0:
+        max_query_len = t
+    if max_seq_len > 0:
+        assert max_seq_len <= block_table.shape[1] * bs, "block table narrower than max_seq_len"
+    if out is None:
+        out = torch.empty((t, hq, d), dtype=q.dtype, device=q.device)
+    assert out.is_contiguous() and out.shape == (t, hq, d)
+    _check(_LIB.vdamd_paged_attention_prefill(
+        out.data_ptr(), q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(),
+        block_table.data_ptr(), block_table.stride(0), query_start_loc.data_ptr(), seq_lens.data_ptr(),
+        float(scale), nseq, max_query_len, hq, hkv, d, bs, hq * d, _dt(q), _stream()),
+        "paged_attention_prefill")
+    return out
+
+
+# ----------------------------------------------------------------- sampling
+def argmax(logits: torch.Tensor) -> torch.Tensor:
+    assert logits.dim() == 2 and logits.stride(1) == 1
+    b, v = logits.shape
+    out = torch.empty(b, dtype=torch.int32, device=logits.device)
+    _check(_LIB.vdamd_argmax(out.data_ptr(), logits.data_ptr(), b, v, logits.stride(0), _dt(logits),
+                             _stream()), "argmax")
+    return out
+
+
+def sample(logits, temperature, top_k, top_p, min_p, uniform) -> torch.Tensor:
+    assert logits.dim() == 2 and logits.stride(1) == 1
+    b, v = logits.shape
+    for t, dt in ((temperature, torch.float32), (top_k, torch.int32), (top_p, torch.float32),
+                  (min_p, torch.float32), (uniform, torch.float32)):
+        assert t.dtype == dt and t.numel() == b and t.is_contiguous() and t.is_cuda
+    out = torch.empty(b, dtype=torch.int32, device=logits.device)
+    _check(_LIB.vdamd_sample(out.data_ptr(), logits.data_ptr(), b, v, logits.stride(0), temperature.data_ptr(),
+                             top_k.data_ptr(), top_p.data_ptr(), min_p.data_ptr(), uniform.data_ptr(),
+                             _dt(logits), _stream()), "sample")
+    return out
