@@ -32,7 +32,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--model", type=str, default="llama-3-70b")
-    ap.add_argument("--batch-per-gpu", type=int, default=256)
+    ap.add_argument("--batch-per-gpu", type=int, default=1024)
     ap.add_argument("--prompt-len", type=int, default=128)
     ap.add_argument("--ttft-requests", type=int, default=5)
     ap.add_argument("--dtype", type=str, default="bfloat16")
@@ -57,7 +57,9 @@ def main() -> None:
     from vllm_distributed_amd.sampling_params import SamplingParams
 
     batch = args.batch_per_gpu * n
-    total_new = args.warmup + args.steps + 2
+    # continuous batching staggers the sequences by the number of prefill steps
+    prefill_steps = -(-batch * args.prompt_len // max(16384, batch))
+    total_new = args.warmup + args.steps + prefill_steps + 8
     max_len = args.prompt_len + total_new + 16
     backend = args.executor
     if backend == "auto":
@@ -65,7 +67,7 @@ def main() -> None:
     engine = LLMEngine.from_engine_args(EngineArgs(
         model=args.model, dtype=args.dtype, load_format="dummy", tensor_parallel_size=n,
         distributed_executor_backend=backend, max_model_len=max_len, max_num_seqs=batch,
-        max_num_batched_tokens=max(8192, batch), enable_prefix_caching=False,
+        max_num_batched_tokens=max(16384, batch), enable_prefix_caching=False,
         enforce_eager=args.enforce_eager, max_capture_size=batch, hip_graph_sizes=[batch],
         gpu_memory_utilization=0.92, seed=0))
     vocab = engine.model_config.vocab_size
