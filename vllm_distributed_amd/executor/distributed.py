@@ -1,0 +1,427 @@
+"""Head-side distributed executor.
+
+Replaces a Ray / multiprocessing executor with one that (a) spawns a worker
+process per head-local GPU, (b) accepts TCP connections from
+``launch.py remote <head_ip>`` processes on other machines and turns each into
+a worker, and (c) fans every engine->worker call out over the control-plane
+RPC.  Behavioural contract of the reference's ``CustomExecutor``
+(reference ``src/launch.py:60-388``); what is different on purpose:
+
+* connections are authenticated (HMAC handshake) before any pickle is read;
+* the per-call payload is pickled **once** and the same bytes go to every
+  worker (the reference pickles per worker, ``:371``);
+* ``timeout`` is enforced (the reference accepts and ignores it, ``:354,383``);
+* non-reply ranks return nothing and nothing is unpickled for them
+  (the reference unpickles ``None`` and swallows the error, ``:367-378,536-537``);
+* placement is a pure, deterministic function (``placement.py``) that is
+  re-evaluated as nodes register instead of dropping a stage;
+* local workers are *spawned*, never forked: the head must stay free of any
+  GPU context, and a forked HIP runtime is undefined behaviour.
+
+Tensors never travel over this channel - only pickled scheduler metadata and
+sampled token ids.  The data plane (RCCL / gloo) rendezvouses through the
+``tcp://`` address generated here and shipped in ``init_worker`` kwargs.
+"""
+from __future__ import annotations
+
+import asyncio
+import concurrent.futures
+import multiprocessing
+import os
+import sys
+import threading
+import time
+import traceback
+import weakref
+from typing import Any, Callable, Dict, List, Optional, Tuple, Union
+
+import cloudpickle
+
+from .. import envs
+from ..engine.types import ModelRunnerOutput, SchedulerOutput
+from ..logger import init_logger
+from ..rpc import (AuthenticationError, ConnectionTransport, RpcPeer, StreamTransport,
+                   prepare_peer_readloop, server_handshake)
+from ..utils import (current_platform, get_distributed_init_method, get_ip, get_open_port,
+                     hip_device_count_stateless)
+from .abstract import Executor
+from .kv_transfer import KVOutputAggregator
+from .placement import (Assignment, NodeInfo, PlacementError, max_concurrent_batches,
+                        output_rank, plan_placement)
+
+logger = init_logger(__name__)
+
+
+class _RemoteWorkerSlot:
+    """One registered remote worker process (one TCP connection)."""
+
+    def __init__(self, peer: RpcPeer, node_id: str, ip: str, local_rank: int, create_worker: Any):
+        self.peer, self.node_id, self.ip = peer, node_id, ip
+        self.local_rank = local_rank
+        self.create_worker = create_worker
+        self.used = False
+
+
+class DistributedExecutor(Executor):
+    uses_ray = False
+    # worker-specific: never copied from the head (reference src/launch.py:64-69)
+    WORKER_SPECIFIC_ENV_VARS = {"VLLM_HOST_IP", "VLLM_HOST_PORT", "LOCAL_RANK", "RANK",
+                                "CUDA_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES",
+                                "VLLM_HEAD_LOCAL_DEVICES"}
+    # non-framework variables that are copied (reference src/launch.py:72)
+    ADDITIONAL_ENV_VARS = {"HF_TOKEN", "HUGGING_FACE_HUB_TOKEN", "HF_HOME", "HUGGINGFACE_HUB_CACHE"}
+    exit_on_failure = False     # launch.py sets this for the serving process
+
+    # ------------------------------------------------------------------ init
+    def _init_executor(self) -> None:
+        self._finalizer = weakref.finalize(self, DistributedExecutor._cleanup, weakref.ref(self))
+        self.shutdown_event = threading.Event()
+        pc = self.parallel_config
+        self.world_size = pc.world_size
+        tp, pp = pc.tensor_parallel_size, pc.pipeline_parallel_size
+        assert self.world_size == tp * pp, (
+            f"world_size ({self.world_size}) must be equal to the tensor_parallel_size ({tp}) x "
+            f"pipeline_parallel_size ({pp})")
+        self.port = envs.VLLM_SERVER_PORT
+        self.secret = envs.VLLM_RPC_SECRET
+        if not self.secret:
+            logger.warning("VLLM_RPC_SECRET is not set: the worker-registration port accepts any "
+                           "peer that speaks the protocol; set the same secret on head and workers")
+        self._slots: Dict[str, List[_RemoteWorkerSlot]] = {}     # node_id -> registered slots
+        self._node_expected: Dict[str, int] = {}
+        self._local_procs: List[multiprocessing.Process] = []
+        self._peers: List[Optional[RpcPeer]] = [None] * self.world_size
+        self.workers: List[Any] = [None] * self.world_size
+        self.assignments: List[Assignment] = []
+        self._nodes_changed: Optional[asyncio.Event] = None
+        self._server: Optional[asyncio.AbstractServer] = None
+
+        loop_ready: "concurrent.futures.Future[asyncio.AbstractEventLoop]" = concurrent.futures.Future()
+        workers_ready: "concurrent.futures.Future[None]" = concurrent.futures.Future()
+
+        def rpc_thread() -> None:
+            loop = asyncio.new_event_loop()
+            asyncio.set_event_loop(loop)
+            loop_ready.set_result(loop)
+            try:
+                loop.run_until_complete(self._serve(workers_ready))
+            except BaseException as e:  # noqa: BLE001
+                if not workers_ready.done():
+                    workers_ready.set_exception(e)
+            finally:
+                try:
+                    loop.run_until_complete(loop.shutdown_asyncgens())
+                except Exception:
+                    pass
+
+        self._thread = threading.Thread(target=rpc_thread, name="executor-rpc", daemon=True)
+        self._thread.start()
+        self.loop = loop_ready.result()
+        workers_ready.result()          # blocks until every rank has a worker process
+
+        init_method = self._distributed_init_method()
+        all_kwargs = []
+        for a in self.assignments:
+            all_kwargs.append(dict(
+                vllm_config=None,              # each wrapper already holds it
+                local_rank=-1,                 # the wrapper substitutes its own (reference :281-282)
+                rank=a.rank, distributed_init_method=init_method,
+                is_driver_worker=(a.rank % tp == 0)))
+        self.collective_rpc("init_worker", args=(all_kwargs,))
+        self.collective_rpc("init_device")
+        self.collective_rpc("load_model")
+        self.has_connector = self.vllm_config.kv_transfer_config is not None
+        self.kv_output_aggregator = KVOutputAggregator(self.world_size)
+        hb = envs.VLLM_HEARTBEAT_SECONDS
+        if hb > 0:
+            threading.Thread(target=self._heartbeat, args=(hb,), daemon=True, name="executor-hb").start()
+
+    def _distributed_init_method(self) -> str:
+        a0 = self.assignments[0]
+        if a0.node_id is None:
+            ip = get_ip()
+            # same-host split groups rendezvous over loopback-reachable address
+            return get_distributed_init_method(ip, get_open_port())
+        slot = next(s for s in self._slots[a0.node_id] if s.local_rank == a0.local_rank)
+        fut = asyncio.run_coroutine_threadsafe(slot.peer.get_param("open_port", timeout=30), self.loop)
+        return get_distributed_init_method(slot.ip, int(fut.result()))
+
+    # ------------------------------------------------------------ rpc thread
+    async def _serve(self, workers_ready: "concurrent.futures.Future[None]") -> None:
+        self._nodes_changed = asyncio.Event()
+        self._server = await asyncio.start_server(self._handle_client, envs.VLLM_RPC_BIND, self.port)
+        logger.info("worker registration server listening on %s:%d", envs.VLLM_RPC_BIND, self.port)
+        try:
+            await self._spawn_and_listen_for_workers()
+            workers_ready.set_result(None)
+        except BaseException as e:  # noqa: BLE001
+            workers_ready.set_exception(e)
+            raise
+        async with self._server:
+            await self._server.serve_forever()
+
+    async def _handle_client(self, reader: asyncio.StreamReader, writer: asyncio.StreamWriter) -> None:
+        addr = writer.get_extra_info("peername")
+        ip = addr[0] if addr else "?"
+        logger.info("connection from %s", addr)
+        transport = StreamTransport(reader, writer)
+        slot: Optional[_RemoteWorkerSlot] = None
+        try:
+            await server_handshake(transport, self.secret)
+            peer, read_loop = await prepare_peer_readloop(asyncio.get_running_loop(), transport,
+                                                          "head", f"worker@{ip}")
+            loop_task = asyncio.get_running_loop().create_task(read_loop())
+            available = int(await peer.get_param("available_devices", timeout=30))
+            local_rank = int(await peer.get_param("local_rank", timeout=30))
+            node_id = str(await peer.get_param("node_id", timeout=30))
+            create_worker = await peer.get_param("create_worker", timeout=30)
+            slot = _RemoteWorkerSlot(peer, node_id, ip, local_rank, create_worker)
+            self._slots.setdefault(node_id, []).append(slot)
+            self._node_expected[node_id] = available
+            # a node is offered for placement once all its GPU processes are in
+            if len(self._slots[node_id]) == available:
+                logger.info("remote node %s (%s) registered with %d device(s)", node_id, ip, available)
+                self._nodes_changed.set()
+            await loop_task
+        except AuthenticationError as e:
+            logger.error("rejected connection from %s: %s", addr, e)
+        except (ConnectionError, asyncio.IncompleteReadError, OSError) as e:
+            logger.info("connection %s closed: %r", addr, e)
+        except Exception:
+            logger.error("error handling client %s\n%s", addr, traceback.format_exc())
+        finally:
+            try:
+                writer.close()
+            except Exception:
+                pass
+            if slot is not None:
+                if slot.used:
+                    # a worker that held a rank is gone: the executor cannot continue
+                    self._fail(f"worker {slot.node_id}/{slot.local_rank} at {ip} disconnected")
+                else:
+                    # never assigned: forget it, it may reconnect (reference src/launch.py:138-139)
+                    lst = self._slots.get(slot.node_id, [])
+                    if slot in lst:
+                        lst.remove(slot)
+                    self._nodes_changed.set()
+
+    def _head_local_devices(self) -> int:
+        n = hip_device_count_stateless() if current_platform.is_rocm() else 1
+        if self.device_config.device == "cpu":
+            n = 1
+        cap = envs.VLLM_HEAD_LOCAL_DEVICES
+        return n if cap < 0 else min(n, cap)
+
+    def _registered_nodes(self) -> List[NodeInfo]:
+        head_ips = {get_ip(), "127.0.0.1", "::1"}
+        nodes = []
+        for nid, slots in self._slots.items():
+            if len(slots) != self._node_expected.get(nid, -1):
+                continue
+            free = tuple(s.local_rank for s in slots if not s.used)
+            nodes.append(NodeInfo(nid, free, same_host=slots[0].ip in head_ips))
+        return nodes
+
+    def _worker_environ(self) -> Dict[str, str]:
+        names = (set(envs.environment_variables) | self.ADDITIONAL_ENV_VARS) - self.WORKER_SPECIFIC_ENV_VARS
+        return {n: os.environ[n] for n in names if n in os.environ}
+
+    async def _spawn_and_listen_for_workers(self) -> None:
+        pc = self.parallel_config
+        tp, pp = pc.tensor_parallel_size, pc.pipeline_parallel_size
+        local = self._head_local_devices()
+        deadline = None
+        if envs.VLLM_WORKER_REGISTRATION_TIMEOUT > 0:
+            deadline = time.monotonic() + envs.VLLM_WORKER_REGISTRATION_TIMEOUT
+        while True:
+            try:
+                plan = plan_placement(tp, pp, local, self._registered_nodes())
+                break
+            except PlacementError as e:
+                logger.info("waiting for workers: %s", e)
+                self._nodes_changed.clear()
+                wait = None if deadline is None else max(0.0, deadline - time.monotonic())
+                try:
+                    await asyncio.wait_for(self._nodes_changed.wait(), wait)
+                except asyncio.TimeoutError:
+                    raise PlacementError(f"timed out waiting for workers: {e}") from None
+        self.assignments = plan
+        env = self._worker_environ()
+        cfg_blob = cloudpickle.dumps(self.vllm_config)
+        tasks = []
+        for a in plan:
+            if a.node_id is None:
+                tasks.append(asyncio.ensure_future(self._spawn_local_worker(a)))
+            else:
+                slot = next(s for s in self._slots[a.node_id] if s.local_rank == a.local_rank and not s.used)
+                slot.used = True
+                self._peers[a.rank] = slot.peer
+                tasks.append(asyncio.ensure_future(
+                    slot.create_worker(cfg_blob, a.rank, env, timeout=envs.VLLM_RPC_TIMEOUT)))
+        run_workers = await asyncio.gather(*tasks)     # rank order == plan order
+        for a, rw in zip(plan, run_workers):
+            self.workers[a.rank] = rw
+        where = ", ".join(f"{a.rank}:{a.node_id or 'head'}/{a.local_rank}" for a in plan)
+        logger.info("placed %d rank(s): %s", len(plan), where)
+
+    async def _spawn_local_worker(self, a: Assignment) -> Any:
+        from ..launch import worker_main
+        ctx = multiprocessing.get_context("spawn")
+        parent_conn, child_conn = ctx.Pipe()
+        proc = ctx.Process(target=worker_main, args=(child_conn,),
+                           kwargs=dict(vllm_config_blob=cloudpickle.dumps(self.vllm_config),
+                                       rank=a.rank, local_rank=a.local_rank),
+                           daemon=True, name=f"worker-{a.rank}")
+        proc.start()
+        child_conn.close()
+        self._local_procs.append(proc)
+        transport = ConnectionTransport(parent_conn)
+        loop = asyncio.get_running_loop()
+        peer, read_loop = await prepare_peer_readloop(loop, transport, "head", f"local-worker-{a.rank}")
+        self._peers[a.rank] = peer
+
+        async def worker_read_loop() -> None:
+            try:
+                await read_loop()
+            except BaseException as e:  # noqa: BLE001
+                logger.info("local worker %d read loop exited: %r", a.rank, e)
+            finally:
+                transport.close()
+                if proc.is_alive():
+                    proc.terminate()
+                if not self.shutdown_event.is_set():
+                    self._fail(f"local worker rank {a.rank} exited")
+
+        loop.create_task(worker_read_loop())
+        return await peer.get_param("run_worker", timeout=envs.VLLM_RPC_TIMEOUT)
+
+    # --------------------------------------------------------------- failure
+    def _fail(self, why: str) -> None:
+        if self.is_failed or self.shutdown_event.is_set():
+            return
+        logger.error("executor failed: %s", why)
+        self.is_failed = True
+        cb = self.failure_callback
+        if cb is not None:
+            try:
+                cb()
+            except Exception:
+                traceback.print_exc()
+        if self.exit_on_failure:
+            logger.error("executor failed, shutting down")
+            os._exit(1)
+
+    def _heartbeat(self, period: float) -> None:
+        while not self.shutdown_event.wait(period):
+            if self.is_failed:
+                return
+            try:
+                self.collective_rpc("check_health", timeout=max(10.0, period))
+            except Exception as e:  # noqa: BLE001
+                self._fail(f"heartbeat failed: {e!r}")
+                return
+
+    # ------------------------------------------------------------ runtime API
+    @property
+    def max_concurrent_batches(self) -> int:
+        return max_concurrent_batches(self.parallel_config.pipeline_parallel_size,
+                                      self.scheduler_config.async_scheduling)
+
+    @property
+    def output_rank(self) -> int:
+        return output_rank(self.world_size, self.parallel_config.tensor_parallel_size)
+
+    def execute_model(self, scheduler_output: SchedulerOutput, non_block: bool = False,
+                      ) -> Union[ModelRunnerOutput, "concurrent.futures.Future[ModelRunnerOutput]"]:
+        timeout = envs.VLLM_EXECUTE_MODEL_TIMEOUT_SECONDS
+        if not self.has_connector:
+            (output,) = self.collective_rpc("execute_model", args=(scheduler_output,),
+                                            unique_reply_rank=self.output_rank, non_block=non_block,
+                                            timeout=timeout)
+            return output
+        outputs = self.collective_rpc("execute_model", args=(scheduler_output,), non_block=non_block,
+                                      timeout=timeout)
+        if non_block:
+            return self.kv_output_aggregator.async_aggregate(outputs, self.output_rank)
+        return self.kv_output_aggregator.aggregate(outputs, self.output_rank)
+
+    def collective_rpc(self, method: Union[str, Callable], timeout: Optional[float] = None,
+                       args: tuple = (), kwargs: Optional[dict] = None, non_block: bool = False,
+                       unique_reply_rank: Optional[int] = None) -> List[Any]:
+        if self.is_failed:
+            raise RuntimeError("Executor failed.")
+        if timeout is None:
+            timeout = envs.VLLM_RPC_TIMEOUT
+        if callable(method) and not isinstance(method, (str, bytes)):
+            method = cloudpickle.dumps(method)
+        payload = cloudpickle.dumps((method, unique_reply_rank, list(args), kwargs))   # once
+        reply_ranks = list(range(self.world_size)) if unique_reply_rank is None else [unique_reply_rank]
+
+        async def call(rank: int, want_reply: bool) -> Any:
+            ret = await self.workers[rank](payload, timeout=timeout)
+            if not want_reply:
+                return None
+            return cloudpickle.loads(ret) if ret is not None else None
+
+        futures: List[concurrent.futures.Future] = []
+        for rank in range(self.world_size):
+            fut = asyncio.run_coroutine_threadsafe(call(rank, rank in reply_ranks), self.loop)
+            if rank in reply_ranks:
+                futures.append(fut)
+            else:
+                fut.add_done_callback(self._log_background_error)
+        if non_block:
+            return futures
+        try:
+            return [f.result() for f in futures]
+        except Exception:
+            if self.is_failed:
+                raise RuntimeError("Executor failed.") from None
+            raise
+
+    def _log_background_error(self, fut: "concurrent.futures.Future") -> None:
+        if fut.cancelled():
+            return
+        e = fut.exception()
+        if e is not None and not self.shutdown_event.is_set():
+            logger.error("worker call failed on a non-reply rank: %r", e)
+
+    def check_health(self) -> None:
+        self.collective_rpc("check_health", timeout=10)
+
+    # --------------------------------------------------------------- shutdown
+    def shutdown(self) -> None:
+        if getattr(self, "shutdown_event", None) is None or self.shutdown_event.is_set():
+            return
+        self.shutdown_event.set()
+        loop = getattr(self, "loop", None)
+
+        def stop() -> None:
+            for p in self._peers:
+                if p is not None:
+                    p.kill("executor shutdown")
+            if self._server is not None:
+                self._server.close()
+            for t in asyncio.all_tasks(loop):
+                t.cancel()
+
+        if loop is not None and loop.is_running():
+            try:
+                loop.call_soon_threadsafe(stop)
+            except RuntimeError:
+                pass
+        for p in self._local_procs:
+            p.join(timeout=3)
+            if p.is_alive():
+                p.terminate()
+        self._local_procs.clear()
+
+    @staticmethod
+    def _cleanup(ref: "weakref.ReferenceType[DistributedExecutor]") -> None:
+        self = ref()
+        if self is not None:
+            self.shutdown()
+
+
+# the reference's class name, for configs that name it
+CustomExecutor = DistributedExecutor

@@ -1,1 +1,209 @@
-"""placeholder; replaced below"""
+"""Entry point: ``launch.py serve <model> [engine/server flags]`` on the head,
+``launch.py remote <head_ip>`` on every worker node.
+
+Same two roles and the same deployment workflow as the reference
+(reference ``src/launch.py:668-675`` role dispatch; ``:510-541`` worker RPC
+endpoint; ``:543-632`` remote node supervisor and worker; ``:635-665`` local
+worker main; ``:589-594`` GC ticker).
+"""
+from __future__ import annotations
+
+import asyncio
+import concurrent.futures
+import gc
+import multiprocessing
+import multiprocessing.connection
+import os
+import sys
+import time
+import traceback
+import uuid
+from typing import Any, Dict, Optional
+
+import cloudpickle
+
+from . import envs
+from .logger import init_logger
+from .rpc import (ConnectionTransport, RpcPeer, StreamTransport, client_handshake,
+                  prepare_peer_readloop)
+from .utils import current_platform, get_open_port, hip_device_count_stateless, run_method
+
+logger = init_logger(__name__)
+
+
+# --------------------------------------------------------------------------
+# worker-side RPC endpoint
+# --------------------------------------------------------------------------
+def set_peer_run_worker(peer: RpcPeer, wrapper: Any, rank: int, local_rank: int):
+    """Publish ``run_worker(pickled)`` on ``peer``.
+
+    The payload is ``(method, unique_reply_rank, args, kwargs)``; ``method`` is a
+    name or a pickled callable.  Calls execute strictly in arrival order on one
+    dedicated thread (the data-plane collectives deadlock otherwise) while the
+    event loop stays free to answer health checks.  Only the reply rank ships
+    a result back; the work is done on every rank.
+    """
+    executor = concurrent.futures.ThreadPoolExecutor(1, thread_name_prefix=f"worker-{rank}")
+
+    def _run(pickled: bytes) -> Optional[bytes]:
+        method, unique_reply_rank, args, kwargs = cloudpickle.loads(pickled)
+        try:
+            result = run_method(wrapper, method, args or [], kwargs or {})
+        except Exception as e:
+            logger.error("error while running method %r on rank %d: %s\n%s",
+                         method if isinstance(method, str) else "<callable>", rank, e,
+                         traceback.format_exc())
+            raise
+        if unique_reply_rank is not None and unique_reply_rank != rank:
+            return None
+        return cloudpickle.dumps(result)
+
+    async def run_worker(pickled: bytes):
+        return await asyncio.get_running_loop().run_in_executor(executor, _run, pickled)
+
+    peer.params["run_worker"] = run_worker
+    return run_worker
+
+
+def gc_runner_loop(loop: asyncio.AbstractEventLoop, period: float = 10.0) -> None:
+    """Collect garbage periodically so dropped RPC proxies are finalised on the
+    peer and unpickled step payloads are returned to the OS."""
+    def tick() -> None:
+        gc.collect()
+        loop.call_later(period, tick)
+    loop.call_later(period, tick)
+
+
+# --------------------------------------------------------------------------
+# worker spawned by the head for one of its own GPUs
+# --------------------------------------------------------------------------
+async def worker_async_main(transport, vllm_config, rank: int, local_rank: int) -> None:
+    from .worker.worker_base import WorkerWrapper
+    loop = asyncio.get_running_loop()
+    peer, read_loop = await prepare_peer_readloop(loop, transport, f"worker-{rank}", "head")
+    peer.params["print"] = print
+    peer.params["local_rank"] = local_rank
+    wrapper = WorkerWrapper(vllm_config=vllm_config, rpc_rank=rank, local_rank=local_rank)
+    set_peer_run_worker(peer, wrapper, rank, local_rank)
+    try:
+        await read_loop()
+    except BaseException:  # noqa: BLE001
+        pass
+    finally:
+        os._exit(0)        # the pipe is gone: nothing to clean up that the OS will not
+
+
+def worker_main(conn: multiprocessing.connection.Connection, vllm_config_blob: bytes, rank: int,
+                local_rank: int) -> None:
+    vllm_config = cloudpickle.loads(vllm_config_blob)
+    transport = ConnectionTransport(conn)
+    loop = asyncio.new_event_loop()
+    asyncio.set_event_loop(loop)
+    gc_runner_loop(loop)
+    loop.run_until_complete(worker_async_main(transport, vllm_config, rank, local_rank))
+    loop.close()
+
+
+# --------------------------------------------------------------------------
+# worker node: ``launch.py remote <head_ip>``
+# --------------------------------------------------------------------------
+async def remote_worker_async_main(server_ip: str, available_devices: int, local_rank: int,
+                                   node_id: str, port: Optional[int] = None) -> None:
+    from .worker.worker_base import WorkerWrapper
+    loop = asyncio.get_running_loop()
+    port = port or envs.VLLM_SERVER_PORT
+    wrapper: Optional[Any] = None
+    while True:
+        try:
+            reader, writer = await asyncio.open_connection(server_ip, port)
+            transport = StreamTransport(reader, writer)
+            await client_handshake(transport, envs.VLLM_RPC_SECRET)
+            peer, read_loop = await prepare_peer_readloop(loop, transport, f"{node_id}/{local_rank}", "head")
+            peer.params["print"] = print
+            peer.params["available_devices"] = available_devices
+            peer.params["local_rank"] = local_rank
+            peer.params["node_id"] = node_id
+            peer.params["open_port"] = get_open_port
+
+            async def create_worker(vllm_config_blob: bytes, rank: int, environ: Dict[str, str]):
+                nonlocal wrapper
+                if wrapper is not None:
+                    raise RuntimeError("Worker already created.")
+                os.environ.update(environ)
+                vllm_config = cloudpickle.loads(vllm_config_blob)
+                wrapper = WorkerWrapper(vllm_config=vllm_config, rpc_rank=rank, local_rank=local_rank)
+                return set_peer_run_worker(peer, wrapper, rank, local_rank)
+
+            peer.params["create_worker"] = create_worker
+            logger.info("registered with head %s:%d as %s/%d", server_ip, port, node_id, local_rank)
+            await read_loop()
+        except BaseException as e:  # noqa: BLE001
+            if isinstance(e, (KeyboardInterrupt, SystemExit)):
+                raise
+            # retry for as long as no worker has been created; once one exists
+            # the whole node must tear down and restart (reference :576-586)
+            if wrapper is not None:
+                logger.error("running worker lost its head connection (%r), shutting down", e)
+                os._exit(1)
+            logger.info("connection to %s:%d failed (%r); retrying in %.0fs", server_ip, port, e,
+                        envs.VLLM_REMOTE_RETRY_SECONDS)
+            await asyncio.sleep(envs.VLLM_REMOTE_RETRY_SECONDS)
+
+
+def remote_worker_main(server_ip: str, available_devices: int, local_rank: int, node_id: str,
+                       port: Optional[int] = None) -> None:
+    loop = asyncio.new_event_loop()
+    asyncio.set_event_loop(loop)
+    gc_runner_loop(loop)
+    loop.run_until_complete(remote_worker_async_main(server_ip, available_devices, local_rank, node_id, port))
+    loop.close()
+
+
+def remote_main(server_ip: str, port: Optional[int] = None, num_devices: Optional[int] = None,
+                device_offset: int = 0) -> None:
+    """One process per local GPU; if any of them exits the node is torn down
+    with a non-zero status so the supervisor (docker ``restart:
+    unless-stopped``) brings it back (reference ``src/launch.py:608-632``)."""
+    if num_devices is None:
+        num_devices = hip_device_count_stateless() if current_platform.is_rocm() else 1
+        num_devices = max(1, num_devices - device_offset)
+    node_id = f"{os.uname().nodename}-{uuid.uuid4().hex[:8]}"
+    ctx = multiprocessing.get_context("spawn")
+    workers = []
+    for i in range(num_devices):
+        p = ctx.Process(target=remote_worker_main,
+                        args=(server_ip, num_devices, device_offset + i, node_id, port), daemon=True)
+        p.start()
+        workers.append(p)
+    multiprocessing.connection.wait([p.sentinel for p in workers])
+    logger.error("a worker exited, shutting down node")
+    for p in workers:
+        p.terminate()
+    for p in workers:
+        p.join()
+    sys.exit(1)
+
+
+# --------------------------------------------------------------------------
+# role dispatch
+# --------------------------------------------------------------------------
+def main(argv: Optional[list] = None) -> None:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if argv and argv[0] == "remote":
+        import argparse
+        ap = argparse.ArgumentParser(prog="launch.py remote")
+        ap.add_argument("server_ip")
+        ap.add_argument("--port", type=int, default=None)
+        ap.add_argument("--num-devices", type=int, default=None,
+                        help="GPUs this node offers (default: all visible)")
+        ap.add_argument("--device-offset", type=int, default=0,
+                        help="first local GPU index to offer (head and workers sharing one host)")
+        a = ap.parse_args(argv[1:])
+        remote_main(a.server_ip, a.port, a.num_devices, a.device_offset)
+        return
+    from .entrypoints.cli import head_main
+    head_main(argv)
+
+
+if __name__ == "__main__":
+    main()

@@ -126,14 +126,19 @@ class GroupCoordinator:
         if dim < 0:
             dim += x.dim()
         x = x.contiguous()
-        out = torch.empty((self.world_size,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        if x.dim() == 0:
+            x = x.reshape(1)
+        # [world * n0, ...]: ranks concatenated along dim 0 (the layout both
+        # RCCL and gloo produce), then moved to the requested dim
+        flat = torch.empty((self.world_size * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype,
+                           device=x.device)
         if self.rccl is not None:
-            self.rccl.all_gather(out, x)
+            self.rccl.all_gather(flat, x)
         else:
-            dist.all_gather_into_tensor(out, x, group=self.device_group)
+            dist.all_gather_into_tensor(flat, x, group=self.device_group)
         if dim == 0:
-            return out.reshape((self.world_size * x.shape[0],) + tuple(x.shape[1:]))
-        out = out.movedim(0, dim)
+            return flat
+        out = flat.view((self.world_size,) + tuple(x.shape)).movedim(0, dim)
         shape = list(x.shape)
         shape[dim] *= self.world_size
         return out.reshape(shape)
