@@ -1,0 +1,104 @@
+"""OpenAI-compatible server on a tiny CPU model: endpoints, SSE streaming, auth, tool parsing."""
+import asyncio
+import json
+
+import httpx
+import pytest
+
+from vllm_distributed_amd.entrypoints.cli import build_parser
+from vllm_distributed_amd.entrypoints.openai import api_server
+from vllm_distributed_amd.entrypoints.openai.tool_parsers import ToolParserManager
+from vllm_distributed_amd.parallel import state as pstate
+
+
+def test_tool_parsers():
+    tools = [{"type": "function", "function": {"name": "get_weather", "parameters": {
+        "type": "object", "properties": {"city": {"type": "string"}, "days": {"type": "integer"},
+                                         "opts": {"type": "object"}}}}}]
+    p = ToolParserManager.get_tool_parser("qwen3_coder")()
+    text = ("Let me check.\n<tool_call>\n<function=get_weather>\n<parameter=city>\nParis\n</parameter>\n"
+            "<parameter=days>\n3\n</parameter>\n<parameter=opts>\n{\"units\": \"C\"}\n</parameter>\n"
+            "</function>\n</tool_call>")
+    content, calls = p.extract(text, tools)
+    assert content == "Let me check." and len(calls) == 1
+    assert calls[0]["function"]["name"] == "get_weather"
+    assert json.loads(calls[0]["function"]["arguments"]) == {"city": "Paris", "days": 3, "opts": {"units": "C"}}
+    assert p.extract("no tools here", tools) == ("no tools here", [])
+    h = ToolParserManager.get_tool_parser("hermes")()
+    c, calls = h.extract('<tool_call>{"name": "f", "arguments": {"x": 1}}</tool_call>', None)
+    assert c is None and json.loads(calls[0]["function"]["arguments"]) == {"x": 1}
+    l3 = ToolParserManager.get_tool_parser("llama3_json")()
+    c, calls = l3.extract('{"name": "f", "parameters": {"y": [1, 2]}}', None)
+    assert calls[0]["function"]["name"] == "f"
+    with pytest.raises(KeyError):
+        ToolParserManager.get_tool_parser("nope")
+
+
+def test_cli_parses_reference_command_line():
+    # the documented head command (.env.server) must parse
+    argv = ("serve koushd/Qwen3-Coder-480B-A35B-Instruct-AWQ -tp 2 -pp 2 --max-model-len 262144 "
+            "--served-model-name qwen3 --enable-auto-tool-choice --tool-call-parser qwen3_coder "
+            "--host 0.0.0.0 --port 8000 --api-key token-abc123").split()
+    a = build_parser().parse_args(argv)
+    assert a.model_tag.startswith("koushd/") and a.tensor_parallel_size == 2 and a.pipeline_parallel_size == 2
+    assert a.max_model_len == 262144 and a.served_model_name == ["qwen3"] and a.port == 8000
+    assert a.enable_auto_tool_choice and a.tool_call_parser == "qwen3_coder" and a.api_key == "token-abc123"
+    a = build_parser().parse_args(["serve", "m", "--max_model_len=64"])
+    assert a.max_model_len == 64
+
+
+def test_server_endpoints_end_to_end():
+    pstate.destroy_model_parallel()
+    args = build_parser().parse_args(
+        "serve llama-tiny --device cpu --dtype float32 --max-model-len 256 --block-size 16 "
+        "--num-gpu-blocks-override 128 --served-model-name tiny --api-key sekret "
+        "--enable-auto-tool-choice --tool-call-parser hermes --port 0".split())
+    args.model = args.model_tag
+
+    async def main():
+        async with api_server.build_async_engine_client(args) as engine:
+            app = api_server.build_app(args)
+            await api_server.init_app_state(engine, await engine.get_vllm_config(), app.state, args)
+            transport = httpx.ASGITransport(app=app)
+            hdr = {"Authorization": "Bearer sekret"}
+            async with httpx.AsyncClient(transport=transport, base_url="http://t") as c:
+                assert (await c.get("/health")).status_code == 200
+                assert (await c.get("/version")).json()["version"]
+                assert (await c.get("/v1/models")).status_code == 401          # key required
+                m = (await c.get("/v1/models", headers=hdr)).json()
+                assert m["data"][0]["id"] == "tiny"
+                r = await c.post("/v1/completions", headers=hdr, json={
+                    "model": "tiny", "prompt": "hello", "max_tokens": 5, "temperature": 0, "logprobs": 1})
+                assert r.status_code == 200, r.text
+                body = r.json()
+                assert body["usage"]["completion_tokens"] == 5 and body["choices"][0]["finish_reason"] == "length"
+                assert len(body["choices"][0]["logprobs"]["token_logprobs"]) == 5
+                r2 = await c.post("/v1/completions", headers=hdr, json={
+                    "prompt": [1, 2, 3, 4], "max_tokens": 4, "temperature": 0, "stream": True,
+                    "stream_options": {"include_usage": True}})
+                lines = [l for l in r2.text.split("\n\n") if l.startswith("data: ")]
+                assert lines[-1] == "data: [DONE]"
+                usage = json.loads(lines[-2][6:])["usage"]
+                assert usage["completion_tokens"] == 4
+                r3 = await c.post("/v1/chat/completions", headers=hdr, json={
+                    "messages": [{"role": "user", "content": "hi"}], "max_tokens": 6, "temperature": 0})
+                assert r3.status_code == 200, r3.text
+                assert r3.json()["choices"][0]["message"]["role"] == "assistant"
+                assert r3.json()["usage"]["completion_tokens"] == 6
+                r4 = await c.post("/v1/chat/completions", headers=hdr, json={
+                    "messages": [{"role": "user", "content": "hi"}], "max_tokens": 4, "stream": True, "seed": 3})
+                chunks = [json.loads(l[6:]) for l in r4.text.split("\n\n")
+                          if l.startswith("data: ") and l != "data: [DONE]"]
+                assert chunks[0]["choices"][0]["delta"]["role"] == "assistant"
+                assert chunks[-1]["choices"][0]["finish_reason"] == "length"
+                assert (await c.post("/v1/completions", headers=hdr,
+                                     json={"model": "other", "prompt": "x"})).status_code == 404
+                t = (await c.post("/tokenize", json={"prompt": "abc"})).json()
+                assert t["count"] == len(t["tokens"])
+                d = (await c.post("/detokenize", json={"tokens": t["tokens"]})).json()
+                assert "abc" in d["prompt"]
+                met = (await c.get("/metrics")).text
+                assert "vllm:generation_tokens_total" in met and "vllm:time_to_first_token_seconds" in met
+                assert (await c.post("/reset_prefix_cache")).status_code == 200
+    asyncio.run(main())
+    pstate.destroy_model_parallel()

@@ -1,0 +1,571 @@
+"""OpenAI-compatible HTTP server.
+
+Bring-up order follows the reference's ``run_server`` (reference
+``src/launch.py:413-457``): bind the listening socket first, import a
+tool-parser plugin, load the uvicorn log config, build the engine client,
+build the app, initialise app state, serve; close the socket after shutdown.
+
+Endpoints: ``/health`` ``/ping`` ``/version`` ``/v1/models``
+``/v1/completions`` ``/v1/chat/completions`` (SSE streaming, tool calls)
+``/tokenize`` ``/detokenize`` ``/metrics`` ``/get_tokenizer_info``
+``/start_profile`` ``/stop_profile`` ``/reset_prefix_cache`` ``/sleep``
+``/wake_up``.  ``--api-key`` (or ``VLLM_API_KEY``) enforces a bearer token on
+``/v1/*``.
+"""
+from __future__ import annotations
+
+import argparse
+import asyncio
+import json
+import socket
+import time
+import uuid
+from contextlib import asynccontextmanager
+from typing import Any, AsyncIterator, Dict, List, Optional, Tuple, Union
+
+from fastapi import FastAPI, Request
+from fastapi.responses import JSONResponse, Response, StreamingResponse
+from pydantic import BaseModel, ConfigDict, Field
+
+from ... import envs
+from ...engine.arg_utils import EngineArgs
+from ...engine.async_llm import AsyncLLM
+from ...engine.core import EngineDeadError
+from ...logger import init_logger
+from ...sampling_params import SamplingParams
+from ...version import __version__
+from .tool_parsers import ToolParserManager
+
+logger = init_logger("entrypoints.openai.api_server")
+
+
+# ------------------------------------------------------------------ protocol
+class _Base(BaseModel):
+    model_config = ConfigDict(extra="allow")
+
+
+class StreamOptions(_Base):
+    include_usage: Optional[bool] = False
+
+
+class CompletionRequest(_Base):
+    model: Optional[str] = None
+    prompt: Union[str, List[str], List[int], List[List[int]]]
+    max_tokens: Optional[int] = 16
+    temperature: Optional[float] = 1.0
+    top_p: Optional[float] = 1.0
+    top_k: Optional[int] = -1
+    min_p: Optional[float] = 0.0
+    n: int = 1
+    stream: bool = False
+    stream_options: Optional[StreamOptions] = None
+    stop: Union[None, str, List[str]] = None
+    stop_token_ids: Optional[List[int]] = None
+    seed: Optional[int] = None
+    logprobs: Optional[int] = None
+    echo: bool = False
+    presence_penalty: Optional[float] = 0.0
+    frequency_penalty: Optional[float] = 0.0
+    repetition_penalty: Optional[float] = 1.0
+    ignore_eos: bool = False
+    min_tokens: int = 0
+    skip_special_tokens: bool = True
+    priority: int = 0
+
+
+class ChatMessage(_Base):
+    role: str
+    content: Union[None, str, List[Dict[str, Any]]] = None
+    tool_calls: Optional[List[Dict[str, Any]]] = None
+    tool_call_id: Optional[str] = None
+    name: Optional[str] = None
+
+
+class ChatCompletionRequest(_Base):
+    model: Optional[str] = None
+    messages: List[ChatMessage]
+    max_tokens: Optional[int] = None
+    max_completion_tokens: Optional[int] = None
+    temperature: Optional[float] = 1.0
+    top_p: Optional[float] = 1.0
+    top_k: Optional[int] = -1
+    min_p: Optional[float] = 0.0
+    n: int = 1
+    stream: bool = False
+    stream_options: Optional[StreamOptions] = None
+    stop: Union[None, str, List[str]] = None
+    stop_token_ids: Optional[List[int]] = None
+    seed: Optional[int] = None
+    logprobs: Optional[bool] = False
+    top_logprobs: Optional[int] = None
+    presence_penalty: Optional[float] = 0.0
+    frequency_penalty: Optional[float] = 0.0
+    repetition_penalty: Optional[float] = 1.0
+    tools: Optional[List[Dict[str, Any]]] = None
+    tool_choice: Union[None, str, Dict[str, Any]] = "auto"
+    ignore_eos: bool = False
+    min_tokens: int = 0
+    skip_special_tokens: bool = True
+    add_generation_prompt: bool = True
+    chat_template: Optional[str] = None
+    chat_template_kwargs: Optional[Dict[str, Any]] = None
+    priority: int = 0
+
+
+class TokenizeRequest(_Base):
+    model: Optional[str] = None
+    prompt: Optional[str] = None
+    messages: Optional[List[ChatMessage]] = None
+    add_special_tokens: bool = True
+    add_generation_prompt: bool = True
+
+
+class DetokenizeRequest(_Base):
+    model: Optional[str] = None
+    tokens: List[int]
+
+
+def _error(message: str, status: int = 400, etype: str = "BadRequestError") -> JSONResponse:
+    return JSONResponse({"object": "error", "message": message, "type": etype, "param": None,
+                         "code": status}, status_code=status)
+
+
+# ------------------------------------------------------------- server set-up
+def setup_server(args: argparse.Namespace) -> Tuple[str, socket.socket]:
+    """Bind the HTTP socket before the (slow) engine start so a port conflict
+    fails immediately."""
+    host = args.host or "0.0.0.0"
+    family = socket.AF_INET6 if ":" in host else socket.AF_INET
+    sock = socket.socket(family=family, type=socket.SOCK_STREAM)
+    sock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    sock.bind((host, args.port))
+    scheme = "https" if getattr(args, "ssl_certfile", None) else "http"
+    return f"{scheme}://{host}:{sock.getsockname()[1]}", sock
+
+
+def load_log_config(path: Optional[str]) -> Optional[dict]:
+    if not path:
+        return None
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception as e:  # noqa: BLE001
+        logger.warning("failed to load log config %s: %r", path, e)
+        return None
+
+
+@asynccontextmanager
+async def build_async_engine_client(args: argparse.Namespace, client_config: Optional[dict] = None,
+                                    ) -> AsyncIterator[AsyncLLM]:
+    """Engine client with the distributed executor injected whenever more than
+    one rank is needed (reference ``src/launch.py:391-410``)."""
+    engine_args = EngineArgs.from_cli_args(args)
+    if engine_args.distributed_executor_backend in (None, "external_launcher") and \
+            engine_args.tensor_parallel_size * engine_args.pipeline_parallel_size > 1:
+        engine_args.distributed_executor_backend = "distributed"
+    loop = asyncio.get_running_loop()
+    engine = await loop.run_in_executor(None, AsyncLLM.from_engine_args, engine_args)
+    try:
+        yield engine
+    finally:
+        engine.shutdown()
+
+
+def build_app(args: argparse.Namespace) -> FastAPI:
+    app = FastAPI(title="vllm-distributed-amd", version=__version__)
+    api_key = getattr(args, "api_key", None) or envs.VLLM_API_KEY
+
+    if api_key:
+        @app.middleware("http")
+        async def auth(request: Request, call_next):
+            if request.method != "OPTIONS" and request.url.path.startswith("/v1"):
+                if request.headers.get("Authorization") != "Bearer " + api_key:
+                    return JSONResponse({"error": "Unauthorized"}, status_code=401)
+            return await call_next(request)
+
+    _register_routes(app)
+    return app
+
+
+def maybe_register_tokenizer_info_endpoint(args: argparse.Namespace) -> None:
+    """Kept for bring-up parity; the endpoint is always registered and gated at
+    request time by ``--enable-tokenizer-info-endpoint``."""
+    return None
+
+
+async def init_app_state(engine: AsyncLLM, vllm_config, state, args: argparse.Namespace) -> None:
+    state.engine = engine
+    state.args = args
+    state.served_names = vllm_config.model_config.served_model_name
+    state.max_model_len = vllm_config.model_config.max_model_len
+    state.tool_parser = None
+    name = getattr(args, "tool_call_parser", None)
+    if getattr(args, "enable_auto_tool_choice", False) and name:
+        state.tool_parser = ToolParserManager.get_tool_parser(name)(engine.tokenizer)
+    state.chat_template = None
+    ct = getattr(args, "chat_template", None)
+    if ct:
+        try:
+            with open(ct) as f:
+                state.chat_template = f.read()
+        except OSError:
+            state.chat_template = ct
+    state.start_time = time.time()
+
+
+# -------------------------------------------------------------------- routes
+def _sampling_params(req, default_max: Optional[int], max_model_len: int, logprobs: Optional[int],
+                     ) -> SamplingParams:
+    max_tokens = getattr(req, "max_completion_tokens", None) or req.max_tokens or default_max
+    return SamplingParams(
+        temperature=req.temperature if req.temperature is not None else 1.0,
+        top_p=req.top_p if req.top_p is not None else 1.0, top_k=req.top_k or -1,
+        min_p=req.min_p or 0.0, presence_penalty=req.presence_penalty or 0.0,
+        frequency_penalty=req.frequency_penalty or 0.0, repetition_penalty=req.repetition_penalty or 1.0,
+        seed=req.seed, max_tokens=max_tokens, min_tokens=req.min_tokens, stop=req.stop,
+        stop_token_ids=req.stop_token_ids, ignore_eos=req.ignore_eos, logprobs=logprobs,
+        skip_special_tokens=req.skip_special_tokens)
+
+
+def _usage(n_prompt: int, n_out: int) -> dict:
+    return {"prompt_tokens": n_prompt, "completion_tokens": n_out, "total_tokens": n_prompt + n_out}
+
+
+def _sse(obj: Any) -> str:
+    return "data: " + (obj if isinstance(obj, str) else json.dumps(obj, ensure_ascii=False)) + "\n\n"
+
+
+def _messages_to_dicts(messages: List[ChatMessage]) -> List[dict]:
+    out = []
+    for m in messages:
+        d = m.model_dump(exclude_none=True)
+        c = d.get("content")
+        if isinstance(c, list):     # content parts -> text
+            d["content"] = "".join(p.get("text", "") for p in c if isinstance(p, dict))
+        out.append(d)
+    return out
+
+
+def _register_routes(app: FastAPI) -> None:
+    @app.get("/health")
+    async def health(request: Request):
+        try:
+            await request.app.state.engine.check_health()
+            return Response(status_code=200)
+        except EngineDeadError:
+            return Response(status_code=503)
+
+    @app.get("/ping")
+    @app.post("/ping")
+    async def ping(request: Request):
+        return await health(request)
+
+    @app.get("/version")
+    async def version():
+        return {"version": __version__}
+
+    @app.get("/v1/models")
+    async def models(request: Request):
+        st = request.app.state
+        return {"object": "list", "data": [
+            {"id": n, "object": "model", "created": int(st.start_time), "owned_by": "vllm-distributed-amd",
+             "root": st.served_names[0], "max_model_len": st.max_model_len} for n in st.served_names]}
+
+    @app.get("/metrics")
+    async def metrics(request: Request):
+        return Response(request.app.state.engine.metrics.render(), media_type="text/plain; version=0.0.4")
+
+    @app.post("/tokenize")
+    async def tokenize(req: TokenizeRequest, request: Request):
+        tok = request.app.state.engine.tokenizer
+        if req.messages is not None:
+            text = tok.apply_chat_template(_messages_to_dicts(req.messages), tokenize=False,
+                                           add_generation_prompt=req.add_generation_prompt)
+            ids = tok.encode(text, add_special_tokens=False)
+        else:
+            ids = tok.encode(req.prompt or "", add_special_tokens=req.add_special_tokens)
+        return {"tokens": ids, "count": len(ids), "max_model_len": request.app.state.max_model_len}
+
+    @app.post("/detokenize")
+    async def detokenize(req: DetokenizeRequest, request: Request):
+        return {"prompt": request.app.state.engine.tokenizer.decode(req.tokens, skip_special_tokens=False)}
+
+    @app.get("/get_tokenizer_info")
+    async def tokenizer_info(request: Request):
+        if not getattr(request.app.state.args, "enable_tokenizer_info_endpoint", False):
+            return _error("tokenizer info endpoint is disabled", 404, "NotFoundError")
+        tok = request.app.state.engine.tokenizer
+        return {"tokenizer_class": type(tok).__name__, "vocab_size": len(tok),
+                "chat_template": getattr(tok, "chat_template", None),
+                "bos_token_id": tok.bos_token_id, "eos_token_id": tok.eos_token_id}
+
+    @app.post("/start_profile")
+    async def start_profile(request: Request):
+        await request.app.state.engine.start_profile()
+        return Response(status_code=200)
+
+    @app.post("/stop_profile")
+    async def stop_profile(request: Request):
+        await request.app.state.engine.stop_profile()
+        return Response(status_code=200)
+
+    @app.post("/reset_prefix_cache")
+    async def reset_prefix_cache(request: Request):
+        ok = await request.app.state.engine.reset_prefix_cache()
+        return Response(status_code=200 if ok else 409)
+
+    @app.post("/sleep")
+    async def sleep(request: Request, level: int = 1):
+        await request.app.state.engine.sleep(level)
+        return Response(status_code=200)
+
+    @app.post("/wake_up")
+    async def wake_up(request: Request):
+        await request.app.state.engine.wake_up()
+        return Response(status_code=200)
+
+    def _check_model(st, name: Optional[str]) -> Optional[JSONResponse]:
+        if name and name not in st.served_names:
+            return _error(f"The model `{name}` does not exist.", 404, "NotFoundError")
+        return None
+
+    # ------------------------------------------------------- /v1/completions
+    @app.post("/v1/completions")
+    async def completions(req: CompletionRequest, request: Request):
+        st = request.app.state
+        engine: AsyncLLM = st.engine
+        err = _check_model(st, req.model)
+        if err:
+            return err
+        if req.n != 1:
+            return _error("n > 1 is not supported")
+        p = req.prompt
+        if isinstance(p, str):
+            prompts: List[Any] = [p]
+        elif p and isinstance(p[0], int):
+            prompts = [list(p)]
+        else:
+            prompts = list(p)
+        if not prompts:
+            return _error("empty prompt")
+        model = req.model or st.served_names[0]
+        rid = "cmpl-" + uuid.uuid4().hex
+        created = int(time.time())
+        try:
+            sp = _sampling_params(req, 16, st.max_model_len, req.logprobs)
+        except ValueError as e:
+            return _error(str(e))
+        gens = [engine.generate(pr, sp.clone(), f"{rid}-{i}", req.priority) for i, pr in enumerate(prompts)]
+
+        def lp_block(out, start: int) -> Optional[dict]:
+            lps = out.outputs[0].logprobs
+            if req.logprobs is None or not lps:
+                return None
+            tok = engine.tokenizer
+            ids = out.outputs[0].token_ids[start:]
+            sel = lps[start:]
+            return {"tokens": tok.convert_ids_to_tokens(ids),
+                    "token_logprobs": [d.get(t) for t, d in zip(ids, sel)],
+                    "top_logprobs": [{tok.decode([k]): v for k, v in d.items()} for d in sel],
+                    "text_offset": []}
+
+        if req.stream:
+            async def stream() -> AsyncIterator[str]:
+                n_prompt = n_out = 0
+                try:
+                    for i, g in enumerate(gens):
+                        sent = 0
+                        async for out in g:
+                            if await request.is_disconnected():
+                                return
+                            c = out.outputs[0]
+                            text = out.new_text
+                            if req.echo and sent == 0:
+                                text = (out.prompt or "") + text
+                            if text or out.finished:
+                                yield _sse({"id": rid, "object": "text_completion", "created": created,
+                                            "model": model, "choices": [{
+                                                "index": i, "text": text, "logprobs": lp_block(out, sent),
+                                                "finish_reason": c.finish_reason, "stop_reason": c.stop_reason}]})
+                            sent = len(c.token_ids)
+                            if out.finished:
+                                n_prompt += len(out.prompt_token_ids)
+                                n_out += len(c.token_ids)
+                    if req.stream_options and req.stream_options.include_usage:
+                        yield _sse({"id": rid, "object": "text_completion", "created": created, "model": model,
+                                    "choices": [], "usage": _usage(n_prompt, n_out)})
+                except Exception as e:  # noqa: BLE001
+                    yield _sse({"error": {"message": str(e), "type": type(e).__name__}})
+                yield _sse("[DONE]")
+            return StreamingResponse(stream(), media_type="text/event-stream")
+
+        async def collect(g):
+            last = None
+            async for out in g:
+                last = out
+            return last
+        try:
+            finals = await asyncio.gather(*[collect(g) for g in gens])
+        except ValueError as e:
+            return _error(str(e))
+        except EngineDeadError as e:
+            return _error(str(e), 500, "InternalServerError")
+        choices = []
+        n_prompt = n_out = 0
+        for i, out in enumerate(finals):
+            c = out.outputs[0]
+            text = ((out.prompt or "") if req.echo else "") + c.text
+            choices.append({"index": i, "text": text, "logprobs": lp_block(out, 0),
+                            "finish_reason": c.finish_reason, "stop_reason": c.stop_reason})
+            n_prompt += len(out.prompt_token_ids)
+            n_out += len(c.token_ids)
+        return {"id": rid, "object": "text_completion", "created": created, "model": model,
+                "choices": choices, "usage": _usage(n_prompt, n_out)}
+
+    # -------------------------------------------------- /v1/chat/completions
+    @app.post("/v1/chat/completions")
+    async def chat_completions(req: ChatCompletionRequest, request: Request):
+        st = request.app.state
+        engine: AsyncLLM = st.engine
+        err = _check_model(st, req.model)
+        if err:
+            return err
+        if req.n != 1:
+            return _error("n > 1 is not supported")
+        tok = engine.tokenizer
+        messages = _messages_to_dicts(req.messages)
+        tools = req.tools if req.tool_choice != "none" else None
+        try:
+            kwargs = dict(req.chat_template_kwargs or {})
+            template = req.chat_template or st.chat_template
+            if template:
+                from ...tokenizer import render_chat_template
+                prompt = render_chat_template(template, messages, req.add_generation_prompt, tools, **kwargs)
+            else:
+                prompt = tok.apply_chat_template(messages, tokenize=False, tools=tools,
+                                                 add_generation_prompt=req.add_generation_prompt, **kwargs)
+        except Exception as e:  # noqa: BLE001
+            return _error(f"chat template error: {e}")
+        prompt_ids = tok.encode(prompt, add_special_tokens=False)
+        n_lp = (req.top_logprobs or 0) if req.logprobs else None
+        try:
+            sp = _sampling_params(req, None, st.max_model_len, n_lp)
+        except ValueError as e:
+            return _error(str(e))
+        model = req.model or st.served_names[0]
+        rid = "chatcmpl-" + uuid.uuid4().hex
+        created = int(time.time())
+        parser = st.tool_parser if tools else None
+        gen = engine.generate({"prompt": prompt, "prompt_token_ids": prompt_ids}, sp, rid, req.priority)
+
+        def lp_content(out, start: int) -> Optional[dict]:
+            lps = out.outputs[0].logprobs
+            if not req.logprobs or not lps:
+                return None
+            ids = out.outputs[0].token_ids[start:]
+            items = []
+            for t, d in zip(ids, lps[start:]):
+                items.append({"token": tok.decode([t]), "logprob": d.get(t), "bytes": None,
+                              "top_logprobs": [{"token": tok.decode([k]), "logprob": v, "bytes": None}
+                                               for k, v in d.items()]})
+            return {"content": items}
+
+        if req.stream:
+            async def stream() -> AsyncIterator[str]:
+                def chunk(delta: dict, finish=None, lp=None) -> str:
+                    return _sse({"id": rid, "object": "chat.completion.chunk", "created": created,
+                                 "model": model, "choices": [{"index": 0, "delta": delta, "logprobs": lp,
+                                                              "finish_reason": finish}]})
+                yield chunk({"role": "assistant", "content": ""})
+                sent = 0
+                final = None
+                held = ""
+                try:
+                    async for out in gen:
+                        if await request.is_disconnected():
+                            return
+                        final = out
+                        text = out.new_text
+                        if parser is not None:
+                            # tool-call syntax must be parsed as a whole: hold text once a call starts
+                            held += text
+                            if "<tool_call>" in held or held.lstrip().startswith(("{", "<|python_tag|>")):
+                                text = ""
+                            else:
+                                text, held = held, ""
+                        if text:
+                            yield chunk({"content": text}, lp=lp_content(out, sent))
+                        sent = len(out.outputs[0].token_ids)
+                    c = final.outputs[0]
+                    finish = c.finish_reason
+                    if parser is not None and held:
+                        content, calls = parser.extract(held, tools)
+                        if calls:
+                            if content:
+                                yield chunk({"content": content})
+                            yield chunk({"tool_calls": [dict(tc, index=i) for i, tc in enumerate(calls)]})
+                            finish = "tool_calls"
+                        else:
+                            yield chunk({"content": held})
+                    yield chunk({}, finish=finish)
+                    if req.stream_options and req.stream_options.include_usage:
+                        yield _sse({"id": rid, "object": "chat.completion.chunk", "created": created,
+                                    "model": model, "choices": [],
+                                    "usage": _usage(len(prompt_ids), len(c.token_ids))})
+                except Exception as e:  # noqa: BLE001
+                    yield _sse({"error": {"message": str(e), "type": type(e).__name__}})
+                yield _sse("[DONE]")
+            return StreamingResponse(stream(), media_type="text/event-stream")
+
+        final = None
+        try:
+            async for out in gen:
+                final = out
+        except ValueError as e:
+            return _error(str(e))
+        except EngineDeadError as e:
+            return _error(str(e), 500, "InternalServerError")
+        c = final.outputs[0]
+        message: Dict[str, Any] = {"role": "assistant", "content": c.text}
+        finish = c.finish_reason
+        if parser is not None:
+            content, calls = parser.extract(c.text, tools)
+            if calls:
+                message = {"role": "assistant", "content": content, "tool_calls": calls}
+                finish = "tool_calls"
+        return {"id": rid, "object": "chat.completion", "created": created, "model": model,
+                "choices": [{"index": 0, "message": message, "logprobs": lp_content(final, 0),
+                             "finish_reason": finish, "stop_reason": c.stop_reason}],
+                "usage": _usage(len(prompt_ids), len(c.token_ids))}
+
+
+# ------------------------------------------------------------------- run
+async def run_server(args: argparse.Namespace, client_config: Optional[dict] = None, **uvicorn_kwargs) -> None:
+    from ..launcher import serve_http
+    listen_address, sock = setup_server(args)
+    plugin = getattr(args, "tool_parser_plugin", None)
+    if plugin and len(plugin) > 3:
+        ToolParserManager.import_tool_parser(plugin)
+    server_index = client_config.get("client_index", 0) if client_config else 0
+    log_config = load_log_config(getattr(args, "log_config_file", None))
+    if log_config is not None:
+        uvicorn_kwargs["log_config"] = log_config
+    async with build_async_engine_client(args, client_config) as engine_client:
+        maybe_register_tokenizer_info_endpoint(args)
+        app = build_app(args)
+        vllm_config = await engine_client.get_vllm_config()
+        await init_app_state(engine_client, vllm_config, app.state, args)
+        logger.info("Starting API server %d on %s", server_index, listen_address)
+        shutdown_task = await serve_http(
+            app, sock=sock, enable_ssl_refresh=getattr(args, "enable_ssl_refresh", False),
+            host=args.host, port=args.port, log_level=getattr(args, "uvicorn_log_level", "info"),
+            access_log=not getattr(args, "disable_uvicorn_access_log", False),
+            timeout_keep_alive=envs.VLLM_HTTP_TIMEOUT_KEEP_ALIVE,
+            ssl_keyfile=getattr(args, "ssl_keyfile", None), ssl_certfile=getattr(args, "ssl_certfile", None),
+            ssl_ca_certs=getattr(args, "ssl_ca_certs", None),
+            ssl_cert_reqs=getattr(args, "ssl_cert_reqs", 0), **uvicorn_kwargs)
+        try:
+            await shutdown_task
+        finally:
+            pass
+    sock.close()
