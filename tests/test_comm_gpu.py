@@ -1,0 +1,106 @@
+"""Data-plane communication on a real GPU: the ctypes RCCL binding (single rank
+- RCCL refuses several ranks on one device) and the peer-mapped direct
+all-reduce between several processes sharing GPU 0 over hipIpc handles."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from vllm_distributed_amd.utils import get_open_port
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CAR_SCRIPT = r"""
+import json, os, sys
+sys.path.insert(0, {root!r})
+import torch
+from vllm_distributed_amd.parallel import state as pstate
+from vllm_distributed_amd.parallel.custom_all_reduce import CustomAllReduce
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dev = torch.device("cuda:0")
+pstate.init_distributed_environment(world, rank, "tcp://127.0.0.1:" + os.environ["MASTER_PORT"], 0, "gloo", dev)
+pstate.initialize_model_parallel(world, 1)
+g = pstate.get_tp_group()
+car = CustomAllReduce(g, max_bytes=4 << 20)
+ok = True
+worst = 0.0
+for it in range(6):
+    for n, mode in ((8, 1), (4096, 1), (8192 * 7, 1), (8192 * 7, 2), (1 << 20, 2), (2 << 20, 0), (1000 * 8, 0)):
+        for dtype in (torch.bfloat16, torch.float16):
+            torch.manual_seed(1000 * it + n + rank)
+            x = torch.randn(n, device=dev).to(dtype)
+            out = car.all_reduce(x, mode)
+            torch.cuda.synchronize()
+            parts = g.all_gather_object(x.float().cpu())
+            ref = sum(parts).to(dtype).float()
+            err = (out.float().cpu() - ref).abs().max().item()
+            worst = max(worst, err)
+            tol = 0.05 * world
+            if not err <= tol:
+                ok = False
+            bits = g.all_gather_object(out.cpu().view(torch.int16).sum().item())
+            if len(set(bits)) != 1:       # every rank must hold identical bits
+                ok = False
+# graph capture + replay
+x = torch.ones(4096, device=dev, dtype=torch.bfloat16) * (rank + 1)
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    car.all_reduce(x)
+torch.cuda.synchronize()
+gr = torch.cuda.CUDAGraph()
+with torch.cuda.graph(gr):
+    y = car.all_reduce(x)
+for _ in range(3):
+    gr.replay()
+torch.cuda.synchronize()
+ok = ok and bool((y.float() == sum(range(1, world + 1))).all().item())
+ok = ok and not car.timed_out()
+print("RESULT " + json.dumps(dict(ok=ok, worst=worst)), flush=True)
+g.barrier()
+car.close()
+"""
+
+
+def test_rccl_binding_single_rank_and_graph_capture():
+    from vllm_distributed_amd.parallel.rccl import RcclCommunicator
+    torch.cuda.set_device(0)
+    comm = RcclCommunicator(rank=0, world_size=1)
+    x = torch.randn(1 << 16, device="cuda", dtype=torch.bfloat16)
+    ref = x.clone()
+    comm.all_reduce(x)
+    out = torch.empty_like(x)
+    comm.all_gather(out, x)
+    comm.broadcast(x, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref) and torch.equal(out, ref)
+    g = torch.cuda.CUDAGraph()
+    y = torch.full((1024,), 3.0, device="cuda", dtype=torch.bfloat16)
+    with torch.cuda.graph(g):
+        comm.all_reduce(y)
+    g.replay()
+    torch.cuda.synchronize()
+    assert bool((y == 3.0).all())
+    comm.close()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_direct_all_reduce_between_processes_sharing_one_gpu(world):
+    port = get_open_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_PORT=str(port),
+                   VLLM_LOGGING_LEVEL="WARNING", GLOO_SOCKET_IFNAME="lo")
+        procs.append(subprocess.Popen([sys.executable, "-c", CAR_SCRIPT.format(root=ROOT)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    results = []
+    for p in procs:
+        so, _ = p.communicate(timeout=110)
+        assert p.returncode == 0, so[-3000:]
+        line = [l for l in so.splitlines() if l.startswith("RESULT ")][-1]
+        results.append(json.loads(line[7:]))
+    assert all(r["ok"] for r in results), results

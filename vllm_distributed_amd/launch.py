@@ -95,6 +95,7 @@ async def worker_async_main(transport, vllm_config, rank: int, local_rank: int) 
 
 def worker_main(conn: multiprocessing.connection.Connection, vllm_config_blob: bytes, rank: int,
                 local_rank: int) -> None:
+    _die_with_parent()
     vllm_config = cloudpickle.loads(vllm_config_blob)
     transport = ConnectionTransport(conn)
     loop = asyncio.new_event_loop()
@@ -150,8 +151,20 @@ async def remote_worker_async_main(server_ip: str, available_devices: int, local
             await asyncio.sleep(envs.VLLM_REMOTE_RETRY_SECONDS)
 
 
+def _die_with_parent() -> None:
+    """Ask the kernel to SIGTERM this process when its parent dies, so killing a
+    node supervisor never leaves orphaned GPU workers registering with the head."""
+    try:
+        import ctypes
+        import signal
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM)   # PR_SET_PDEATHSIG
+    except Exception:  # noqa: BLE001
+        pass
+
+
 def remote_worker_main(server_ip: str, available_devices: int, local_rank: int, node_id: str,
                        port: Optional[int] = None) -> None:
+    _die_with_parent()
     loop = asyncio.new_event_loop()
     asyncio.set_event_loop(loop)
     gc_runner_loop(loop)
@@ -175,6 +188,15 @@ def remote_main(server_ip: str, port: Optional[int] = None, num_devices: Optiona
                         args=(server_ip, num_devices, device_offset + i, node_id, port), daemon=True)
         p.start()
         workers.append(p)
+    import signal
+
+    def on_term(signum, frame):
+        for p in workers:
+            p.terminate()
+        os._exit(1)
+
+    signal.signal(signal.SIGTERM, on_term)
+    signal.signal(signal.SIGINT, on_term)
     multiprocessing.connection.wait([p.sentinel for p in workers])
     logger.error("a worker exited, shutting down node")
     for p in workers:
