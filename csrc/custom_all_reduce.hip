@@ -22,7 +22,7 @@ namespace {
 constexpr int CAR_MAX_RANKS = 8;
 constexpr int CAR_MAX_BLOCKS = 64;
 constexpr int CAR_THREADS = 512;
-constexpr long CAR_SPIN_LIMIT = 200L * 1000 * 1000;   // ~ seconds of polling
+constexpr long CAR_SPIN_LIMIT = 4L * 1000 * 1000;     // a few seconds of uncached polling
 
 struct Signal {
   alignas(128) uint32_t epoch[CAR_MAX_BLOCKS];

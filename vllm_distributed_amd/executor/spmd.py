@@ -58,6 +58,13 @@ class SpmdExecutor(Executor):
             return [fut]
         return [result]
 
+    def determine_available_memory(self) -> List[int]:
+        """Every rank runs its own scheduler, so all must size the KV cache
+        identically: take the minimum over ranks."""
+        (mine,) = self.collective_rpc("determine_available_memory")
+        from ..parallel.state import get_world_group
+        return [min(get_world_group().all_gather_object(int(mine)))]
+
     def shutdown(self) -> None:
         drv = getattr(self, "driver", None)
         if drv is not None and drv.worker is not None:

@@ -205,3 +205,25 @@ class ParallelLMHead(VocabParallelEmbedding):
         if self.tp > 1:
             y = tensor_model_parallel_all_gather(y, dim=-1)
         return y[..., :self.vocab_size]
+
+    def greedy_tokens(self, hidden: torch.Tensor) -> torch.Tensor:
+        """Vocab-parallel argmax: each rank reduces its own shard to one
+        ``(max, index)`` pair per row and only those pairs are all-gathered -
+        ``8 * B`` bytes per rank instead of a ``[B, vocab]`` logits gather.
+        Ties resolve to the lowest token id, like a full-row argmax."""
+        y = F.linear(hidden, self.weight, self.bias)
+        valid = max(0, min(self.rows, self.vocab_size - self.vocab_start))
+        if valid == 0:
+            val = torch.full((y.shape[0],), float("-inf"), dtype=torch.float32, device=y.device)
+            idx = torch.zeros(y.shape[0], dtype=torch.int64, device=y.device)
+        else:
+            idx = ops.argmax(y[:, :valid]).long()
+            val = y[:, :valid].gather(1, idx.unsqueeze(1)).squeeze(1).float()
+        if self.tp == 1:
+            return idx.to(torch.int32)
+        pack = torch.stack([val, (idx + self.vocab_start).float()], dim=1)      # ids < 2^24: exact in fp32
+        g = tensor_model_parallel_all_gather(pack, dim=0).view(self.tp, -1, 2)
+        vals, ids = g[..., 0], g[..., 1]
+        best = vals.max(dim=0, keepdim=True).values
+        ids = torch.where(vals == best, ids, torch.full_like(ids, float(1 << 30)))
+        return ids.min(dim=0).values.to(torch.int32)

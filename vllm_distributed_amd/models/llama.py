@@ -171,6 +171,11 @@ class LlamaForCausalLM(nn.Module):
             y = tensor_model_parallel_all_gather(y, dim=-1)
         return y[..., :w.vocab_size]
 
+    def compute_greedy_tokens(self, hidden: torch.Tensor) -> torch.Tensor:
+        if self.lm_head is not None:
+            return self.lm_head.greedy_tokens(hidden)
+        return ops.argmax(self.compute_logits(hidden))
+
     # ------------------------------------------------------------- weights
     def _owns_layer(self, name: str) -> bool:
         if ".layers." not in name:

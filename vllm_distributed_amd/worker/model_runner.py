@@ -241,9 +241,8 @@ class ModelRunner:
                 hs = hidden[:total]
             else:
                 hs = hidden.index_select(0, self._to_dev(last_idx, torch.int64))
-            logits = self.model.compute_logits(hs)
             rows_sel = p["rows"][sel]
-            tokens, logprobs_sel = self._sample(logits, rows_sel)
+            tokens, logprobs_sel = self._sample(hs, rows_sel)
             tok_list = tokens.tolist()
             b = self.batch
             # remember what we sampled: TP ranks all compute the same token
@@ -297,10 +296,16 @@ class ModelRunner:
         return self.model_config.architecture != "OPTForCausalLM"
 
     # -------------------------------------------------------------- sampling
-    def _sample(self, logits: torch.Tensor, rows: np.ndarray):
+    def _sample(self, hidden: torch.Tensor, rows: np.ndarray):
         b = self.batch
         temps = b.temperature[rows]
         need_lp = int(b.num_logprobs[rows].max()) if len(rows) else -1
+        if (self.tp.world_size > 1 and need_lp < 0 and not temps.any() and not b.has_penalty[rows].any()
+                and hasattr(self.model, "compute_greedy_tokens")):
+            # all-greedy batch under TP: argmax per vocabulary shard, gather only the winners
+            tokens = self.model.compute_greedy_tokens(hidden)
+            return tokens.to("cpu", torch.int32).numpy(), None
+        logits = self.model.compute_logits(hidden)
         if b.has_penalty[rows].any():
             logits = self._apply_penalties(logits.float(), rows)
         if not temps.any():
@@ -392,6 +397,11 @@ class ModelRunner:
             return
         if self.pp.world_size > 1:
             logger.info("hipGraph decode capture is disabled with pipeline parallelism")
+            return
+        if self.tp.world_size > 1 and self.tp.rccl is None:
+            # torch.distributed collectives keep host-side work objects; only the
+            # direct RCCL binding is a pure stream enqueue that a capture can record
+            logger.info("hipGraph decode capture needs the direct RCCL communicator: running eagerly")
             return
         sizes = [s for s in cc.sizes(self.max_num_reqs) if s <= self.max_num_reqs]
         if not sizes:

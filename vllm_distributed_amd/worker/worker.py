@@ -69,6 +69,7 @@ class Worker:
             backend = "gloo"
             torch.set_num_threads(max(1, min(8, (os.cpu_count() or 2) // max(1, self.parallel_config.world_size))))
         pc = self.parallel_config
+        self._default_loopback_interfaces()
         pstate.init_distributed_environment(pc.world_size, self.rank, self.distributed_init_method,
                                             self.local_rank, backend, self.device)
         pstate.initialize_model_parallel(pc.tensor_parallel_size, pc.pipeline_parallel_size)
@@ -76,6 +77,17 @@ class Worker:
             self._attach_fast_collectives()
         torch.manual_seed(self.vllm_config.model_config.seed)
         self.model_runner = ModelRunner(self.vllm_config, self.device)
+
+    def _default_loopback_interfaces(self) -> None:
+        """Single-host rendezvous over 127.0.0.1: pin gloo / RCCL bootstrap sockets
+        to ``lo`` unless the operator chose an interface (a container hostname
+        that does not resolve otherwise breaks gloo's address discovery)."""
+        addr = self.distributed_init_method or ""
+        if addr in ("", "env://"):
+            addr = os.environ.get("MASTER_ADDR", "")
+        if any(x in addr for x in ("127.0.0.1", "localhost", "[::1]")):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
 
     def _attach_fast_collectives(self) -> None:
         """Direct RCCL binding and the peer-mapped all-reduce, each verified
