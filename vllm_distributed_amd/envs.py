@@ -76,6 +76,10 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     # Enable the peer-mapped direct all-reduce for small messages.
     "VDAMD_CUSTOM_ALL_REDUCE": _bool("VDAMD_CUSTOM_ALL_REDUCE", True),
     "VDAMD_CUSTOM_ALL_REDUCE_MAX_BYTES": _int("VDAMD_CUSTOM_ALL_REDUCE_MAX_BYTES", 8 << 20),
+    # Micro-batch overlap of TP all-reduces with compute in decode:
+    # "auto" (TP>1 and batch >= MIN_BATCH), "0" (off), "force" (also at TP=1; tests).
+    "VDAMD_TP_OVERLAP": _str("VDAMD_TP_OVERLAP", "auto"),
+    "VDAMD_TP_OVERLAP_MIN_BATCH": _int("VDAMD_TP_OVERLAP_MIN_BATCH", 512),
     # Capture decode steps in hipGraphs.
     "VDAMD_USE_HIP_GRAPH": _bool("VDAMD_USE_HIP_GRAPH", True),
     # Assert identical collective sequence numbers on all ranks (debug).

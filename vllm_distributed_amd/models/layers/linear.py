@@ -151,10 +151,12 @@ class RowParallelLinear(nn.Module):
     def weight_loader(self, param: nn.Parameter, w: torch.Tensor, shard_id=None) -> None:
         param.data.copy_(w.narrow(1, self.tp_rank * self.in_local, self.in_local))
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, reduce: bool = True) -> torch.Tensor:
+        """``reduce=False`` returns this rank's partial sums; the caller owns the
+        all-reduce (used to overlap it with another micro-batch's compute)."""
         # bias is added once (rank 0) so the all-reduce does not multiply it
         y = F.linear(x, self.weight, self.bias if self.tp_rank == 0 else None)
-        if self.reduce_results and self.tp > 1:
+        if reduce and self.reduce_results and self.tp > 1:
             y = tensor_model_parallel_all_reduce(y)
         return y
 

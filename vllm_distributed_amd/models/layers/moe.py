@@ -71,7 +71,7 @@ class FusedMoE(nn.Module):
             w = w.narrow(1, self.tp_rank * self.inter_local, self.inter_local)
         param.data[e].copy_(w)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, reduce: bool = True) -> torch.Tensor:
         logits = self.gate(x).float()
         probs = torch.softmax(logits, dim=-1)
         topw, topi = probs.topk(self.top_k, dim=-1)
@@ -98,6 +98,6 @@ class FusedMoE(nn.Module):
             h = F.linear(x.index_select(0, rows), self.w13[e])
             h = F.linear(ops.silu_and_mul(h), self.w2[e])
             out.index_add_(0, rows, h * wts[seg].unsqueeze(1))
-        if self.tp > 1:
+        if reduce and self.tp > 1:
             out = tensor_model_parallel_all_reduce(out)
         return out

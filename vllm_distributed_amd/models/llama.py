@@ -28,8 +28,8 @@ class LlamaMLP(nn.Module):
         self.gate_up_proj = ColumnParallelLinear(hidden, [inter, inter], bias, dtype)
         self.down_proj = RowParallelLinear(inter, hidden, bias, dtype)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.down_proj(ops.silu_and_mul(self.gate_up_proj(x)))
+    def forward(self, x: torch.Tensor, reduce: bool = True) -> torch.Tensor:
+        return self.down_proj(ops.silu_and_mul(self.gate_up_proj(x)), reduce)
 
 
 class LlamaAttention(nn.Module):
@@ -55,7 +55,7 @@ class LlamaAttention(nn.Module):
         self.attn = Attention(self.num_heads, self.head_dim, self.num_kv_heads,
                               self.head_dim ** -0.5, layer_idx)
 
-    def forward(self, positions: torch.Tensor, hidden: torch.Tensor) -> torch.Tensor:
+    def forward(self, positions: torch.Tensor, hidden: torch.Tensor, reduce: bool = True) -> torch.Tensor:
         qkv = self.qkv_proj(hidden)
         md = get_forward_context().attn_metadata
         if self.qk_norm:
@@ -73,7 +73,7 @@ class LlamaAttention(nn.Module):
                                    self.attn.v_cache, md.slot_mapping, self.num_heads,
                                    self.num_kv_heads, self.head_dim)
             out = self.attn.forward_cached(q)
-        return self.o_proj(out)
+        return self.o_proj(out, reduce)
 
 
 class LlamaDecoderLayer(nn.Module):
@@ -88,6 +88,20 @@ class LlamaDecoderLayer(nn.Module):
     def _make_mlp(self, cfg: dict, dtype: torch.dtype) -> nn.Module:
         return LlamaMLP(cfg["hidden_size"], cfg["intermediate_size"], dtype,
                         bool(cfg.get("mlp_bias", False)))
+
+    # the layer split in two at its all-reduces, for micro-batch overlap
+    def attn_phase(self, positions: torch.Tensor, hidden: torch.Tensor,
+                   residual: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+        if residual is None:
+            residual = hidden
+            hidden = self.input_layernorm(hidden)
+        else:
+            hidden, residual = self.input_layernorm(hidden, residual)
+        return self.self_attn(positions, hidden, reduce=False), residual
+
+    def mlp_phase(self, hidden: torch.Tensor, residual: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        hidden, residual = self.post_attention_layernorm(hidden, residual)
+        return self.mlp(hidden, reduce=False), residual
 
     def forward(self, positions: torch.Tensor, hidden: torch.Tensor,
                 residual: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -159,6 +173,54 @@ class LlamaForCausalLM(nn.Module):
         if not self.is_last:
             return IntermediateTensors(hidden, residual)
         hidden, _ = self.norm(hidden, residual)
+        return hidden
+
+    def forward_overlapped(self, input_ids: torch.Tensor, positions: torch.Tensor, metadatas, bounds,
+                           comm_stream) -> torch.Tensor:
+        """Decode forward with the batch cut into micro-batches whose tensor-
+        parallel all-reduces run on ``comm_stream`` while the compute stream
+        works on the other micro-batch: per layer
+        ``attn(A) | attn(B)+AR(A) | mlp(A)+AR(B) | mlp(B)+AR(A) | ...``.
+        xGMI all-reduces of large activations cost about as much as the layer's
+        GEMMs, so hiding them is worth up to ~2x at TP=8.  ``metadatas[i]`` /
+        ``bounds[i] = (start, end)`` describe micro-batch ``i``.  Single pipeline
+        stage only."""
+        from ..parallel.state import get_tp_group
+        from .layers.attention import set_forward_context
+        tp = get_tp_group()
+        main = torch.cuda.current_stream()
+        hidden = self.embed_tokens(input_ids)
+        n = len(bounds)
+        h = [hidden[s:e] for s, e in bounds]
+        pos = [positions[s:e] for s, e in bounds]
+        res: List[Optional[torch.Tensor]] = [None] * n
+        ready: List[Optional[torch.cuda.Event]] = [None] * n
+
+        def all_reduce_async(i: int, part: torch.Tensor) -> None:
+            produced = torch.cuda.Event()
+            produced.record(main)
+            comm_stream.wait_event(produced)
+            with torch.cuda.stream(comm_stream):
+                tp.all_reduce_(part)
+                done = torch.cuda.Event()
+                done.record(comm_stream)
+            h[i], ready[i] = part, done
+
+        for layer in self.layers.values():
+            for i in range(n):
+                if ready[i] is not None:
+                    main.wait_event(ready[i])
+                set_forward_context(metadatas[i], pos[i])
+                part, res[i] = layer.attn_phase(pos[i], h[i], res[i])
+                all_reduce_async(i, part)
+            for i in range(n):
+                main.wait_event(ready[i])
+                part, res[i] = layer.mlp_phase(h[i], res[i])
+                all_reduce_async(i, part)
+        for i in range(n):
+            main.wait_event(ready[i])
+        set_forward_context(None)
+        hidden, _ = self.norm(torch.cat(h), torch.cat(res))
         return hidden
 
     def compute_logits(self, hidden: torch.Tensor) -> torch.Tensor:

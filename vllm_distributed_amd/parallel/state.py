@@ -119,6 +119,17 @@ class GroupCoordinator:
         dist.all_reduce(x, group=self.device_group)
         return x
 
+    def all_reduce_(self, x: torch.Tensor) -> torch.Tensor:
+        """Strictly in-place sum on the current stream (RCCL / gloo only)."""
+        if self.world_size == 1:
+            return x
+        self._note("all_reduce", x)
+        if self.rccl is not None:
+            self.rccl.all_reduce(x)
+        else:
+            dist.all_reduce(x, group=self.device_group)
+        return x
+
     def all_gather(self, x: torch.Tensor, dim: int = -1) -> torch.Tensor:
         if self.world_size == 1:
             return x

@@ -61,6 +61,7 @@ class ModelRunner:
         self.decode_workspace: Optional[torch.Tensor] = None
         self.step_count = 0
         self.report_on_all_ranks = False
+        self.comm_stream = None
         self.timing_enabled = vllm_config.observability_config.collect_step_timing
 
     # ------------------------------------------------------------------ setup
@@ -69,6 +70,10 @@ class ModelRunner:
         self.model = load_model(self.vllm_config, self.device)
         self.pp = get_pp_group()
         self.tp = get_tp_group()
+        mode = envs.VDAMD_TP_OVERLAP
+        if (self.is_gpu and self.pp.world_size == 1 and hasattr(self.model, "forward_overlapped")
+                and (mode == "force" or (mode == "auto" and self.tp.world_size > 1))):
+            self.comm_stream = torch.cuda.Stream(priority=-1)
         logger.info("model loaded in %.1fs", time.time() - t0)
 
     def get_kv_cache_spec(self) -> KVCacheSpec:
@@ -262,11 +267,42 @@ class ModelRunner:
         return ModelRunnerOutput(step_id=so.step_id, req_ids=p["req_ids"],
                                  sampled_token_ids=out_tokens, logprobs=logprobs_out, timing=timing)
 
+    def _overlap_bounds(self, nreq: int):
+        """Micro-batch row ranges for all-reduce/compute overlap, or None."""
+        if self.comm_stream is None or nreq < 2:
+            return None
+        if envs.VDAMD_TP_OVERLAP != "force" and nreq < envs.VDAMD_TP_OVERLAP_MIN_BATCH:
+            return None
+        half = (nreq // 2 + 7) // 8 * 8 if nreq >= 32 else nreq // 2
+        return [(0, half), (half, nreq)]
+
+    @staticmethod
+    def _slice_decode_metadata(md: AttentionMetadata, s: int, e: int) -> AttentionMetadata:
+        n = e - s
+        return AttentionMetadata(
+            num_decodes=n, num_decode_tokens=n, num_prefills=0, num_prefill_tokens=0,
+            slot_mapping=md.slot_mapping[s:e], block_table=md.block_table[s:e], seq_lens=md.seq_lens[s:e],
+            query_start_loc=md.query_start_loc[:n + 1], max_query_len=1, max_seq_len=md.max_seq_len,
+            max_decode_seq_len=md.max_decode_seq_len, decode_workspace=md.decode_workspace)
+
+    def _forward_decode(self, md: AttentionMetadata, input_ids: torch.Tensor, positions: torch.Tensor):
+        """Pure-decode forward on a single pipeline stage, overlapped when enabled."""
+        bounds = self._overlap_bounds(md.num_decodes)
+        if bounds is None:
+            set_forward_context(md, positions)
+            out = self.model(input_ids, positions, None)
+            set_forward_context(None)
+            return out
+        mds = [self._slice_decode_metadata(md, s, e) for s, e in bounds]
+        return self.model.forward_overlapped(input_ids, positions, mds, bounds, self.comm_stream)
+
     def _is_output_rank(self) -> bool:
         return self.pp.is_last_rank and (self.tp.rank_in_group == 0 or self.report_on_all_ranks)
 
     def _run_eager(self, md: AttentionMetadata, input_ids: torch.Tensor, positions: torch.Tensor,
                    total: int):
+        if md.num_prefills == 0 and self.pp.world_size == 1 and self.comm_stream is not None:
+            return self._forward_decode(md, input_ids, positions)
         inter = None
         if not self.pp.is_first_rank:
             inter = self._recv_intermediate(total)
@@ -439,15 +475,13 @@ class ModelRunner:
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):
             for _ in range(2):
-                set_forward_context(md, pos)
-                self.model(ids, pos, None)
+                self._forward_decode(md, ids, pos)
         torch.cuda.current_stream().wait_stream(stream)
         torch.cuda.synchronize()
         g = DecodeGraph(bs)
         g.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g.graph, pool=self.graph_pool):
-            set_forward_context(md, pos)
-            g.output = self.model(ids, pos, None)
+            g.output = self._forward_decode(md, ids, pos)
         set_forward_context(None)
         if self.graph_pool is None:
             self.graph_pool = g.graph.pool()
