@@ -38,6 +38,8 @@ def main() -> None:
     ap.add_argument("--dtype", type=str, default="bfloat16")
     ap.add_argument("--enforce-eager", action="store_true")
     ap.add_argument("--executor", type=str, default="auto", choices=["auto", "uni", "spmd"])
+    ap.add_argument("--device", type=str, default="cuda", choices=["cuda", "cpu"],
+                    help="cpu = gloo rehearsal of the multi-rank path with a tiny model (not a measurement)")
     args = ap.parse_args()
 
     import numpy as np
@@ -65,7 +67,7 @@ def main() -> None:
     if backend == "auto":
         backend = "spmd" if n > 1 else "uni"
     engine = LLMEngine.from_engine_args(EngineArgs(
-        model=args.model, dtype=args.dtype, load_format="dummy", tensor_parallel_size=n,
+        model=args.model, dtype=args.dtype, load_format="dummy", tensor_parallel_size=n, device=args.device,
         distributed_executor_backend=backend, max_model_len=max_len, max_num_seqs=batch,
         max_num_batched_tokens=max(16384, batch), enable_prefix_caching=False,
         enforce_eager=args.enforce_eager, max_capture_size=batch, hip_graph_sizes=[batch],
@@ -73,10 +75,13 @@ def main() -> None:
     vocab = engine.model_config.vocab_size
     rng = np.random.default_rng(1234)
 
+    on_gpu = args.device == "cuda"
+
     def sync() -> None:
         if dist.is_initialized():
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     # ---- p50 TTFT: single requests on an idle engine
     ttfts = []
@@ -90,7 +95,8 @@ def main() -> None:
         while not got:
             for out in engine.step():
                 got = got or (out.request_id == rid and len(out.outputs[0].token_ids) >= 1)
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         if i > 0:                      # first one pays lazy initialisation
             ttfts.append(time.perf_counter() - t0)
         while engine.has_unfinished_requests():
@@ -105,7 +111,8 @@ def main() -> None:
     t_prefill0 = time.perf_counter()
     while sched.waiting or any(r.num_computed_tokens < r.num_prompt_tokens for r in sched.running):
         engine.step()
-    torch.cuda.synchronize()
+    if on_gpu:
+        torch.cuda.synchronize()
     prefill_s = time.perf_counter() - t_prefill0
     for _ in range(args.warmup):
         engine.step()
@@ -119,7 +126,7 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     assert produced == batch * args.steps, (produced, batch, args.steps)
     if dist.is_initialized():
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -130,7 +137,7 @@ def main() -> None:
             "metric": "output tokens/sec (whole node), Llama-3-70B bf16 TP over N GPUs, decode",
             "value": round(tps, 2), "unit": "tokens/s", "n_gpus": n, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"bfloat16": "bf16", "float16": "fp16", "float32": "fp32"}[args.dtype],
             "data": "synthetic prompts (random token ids), random-init weights",
             "ttft_p50_ms": None if ttft_p50_ms is None else round(ttft_p50_ms, 2),
             "prefill_tokens_per_s": round(batch * args.prompt_len / prefill_s, 1),

@@ -104,3 +104,43 @@ def test_direct_all_reduce_between_processes_sharing_one_gpu(world):
         line = [l for l in so.splitlines() if l.startswith("RESULT ")][-1]
         results.append(json.loads(line[7:]))
     assert all(r["ok"] for r in results), results
+
+
+NCCL_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from vllm_distributed_amd.parallel import state as pstate
+from vllm_distributed_amd.worker.worker import Worker
+os.environ["MASTER_ADDR"] = "127.0.0.1"
+os.environ["MASTER_PORT"] = os.environ["PORT"]
+Worker._default_loopback_interfaces(type("W", (), dict(distributed_init_method="env://"))())
+torch.cuda.set_device(0)
+dev = torch.device("cuda:0")
+# exactly the calls a TP worker makes, on a world of one rank
+pstate.init_distributed_environment(1, 0, "env://", 0, "nccl", dev, force=True)
+w = pstate.get_world_group()
+assert w.cpu_group is not None and dist.get_backend() == "nccl"
+g = dist.new_group([0], backend="nccl")
+x = torch.arange(1024, device=dev, dtype=torch.bfloat16)
+dist.all_reduce(x, group=g)
+out = torch.empty(1024, device=dev, dtype=torch.bfloat16)
+dist.all_gather_into_tensor(out, x, group=g)
+assert torch.equal(out, x)
+assert w.all_gather_object(7) == [7]
+w.barrier()
+t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+pstate.destroy_model_parallel()
+print("RESULT ok", flush=True)
+"""
+
+
+def test_nccl_process_group_bringup_calls_on_one_rank():
+    """The torch.distributed call sequence of a GPU worker (env:// rendezvous on
+    loopback, nccl + gloo groups, device_id binding) on a one-rank world."""
+    env = dict(os.environ, PORT=str(get_open_port()), VLLM_LOGGING_LEVEL="WARNING")
+    env.pop("GLOO_SOCKET_IFNAME", None)
+    p = subprocess.run([sys.executable, "-c", NCCL_SCRIPT.format(root=ROOT)], env=env, capture_output=True,
+                       text=True, timeout=110)
+    assert p.returncode == 0 and "RESULT ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]

@@ -58,3 +58,22 @@ def test_spmd_tp2_matches_single_process_on_every_rank():
     ref = _run(1)[0]
     got = _run(2)
     assert got[0] == ref and got[1] == ref
+
+
+@pytest.mark.slow
+def test_bench_script_multi_rank_rehearsal_on_cpu():
+    """bench.py exactly as the driver launches it for N=2 (torch.distributed.run,
+    one rank per device), on gloo with a tiny model: one JSON line from rank 0."""
+    port = get_open_port()
+    env = dict(os.environ, VLLM_LOGGING_LEVEL="ERROR", GLOO_SOCKET_IFNAME="lo", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--device", "cpu", "--model", "llama-tiny",
+           "--dtype", "float32", "--batch-per-gpu", "4", "--prompt-len", "12", "--ttft-requests", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["config"]["global_batch"] == 8
+    assert j["config"]["parallelism"] == "tp2" and j["value"] > 0

@@ -216,10 +216,11 @@ def _single(name: str, device: torch.device) -> GroupCoordinator:
 
 def init_distributed_environment(world_size: int, rank: int, init_method: Optional[str],
                                  local_rank: int, backend: str, device: torch.device,
-                                 timeout_s: float = 1800.0) -> None:
-    """Join the world.  ``backend`` is ``nccl`` (= RCCL on ROCm) or ``gloo``."""
+                                 timeout_s: float = 1800.0, force: bool = False) -> None:
+    """Join the world.  ``backend`` is ``nccl`` (= RCCL on ROCm) or ``gloo``.
+    A world of one skips process-group creation unless ``force`` is set."""
     global _WORLD, _OWNS_PROCESS_GROUP
-    if world_size == 1:
+    if world_size == 1 and not force:
         _WORLD = _single("world", device)
         return
     if not dist.is_initialized():

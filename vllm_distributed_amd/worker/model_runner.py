@@ -452,6 +452,9 @@ class ModelRunner:
             logger.warning("hipGraph capture failed (%r): running decode eagerly", e)
             self.graphs.clear()
             self.graph_sizes = []
+            if self.tp.rccl is not None:
+                # a communicator that was mid-capture cannot be trusted afterwards
+                self.tp.rccl = None
             torch.cuda.synchronize()
             return
         self.graph_sizes = sorted(self.graphs)
@@ -480,7 +483,9 @@ class ModelRunner:
         torch.cuda.synchronize()
         g = DecodeGraph(bs)
         g.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g.graph, pool=self.graph_pool):
+        # thread_local: API calls on other threads (RCCL watchdog, HTTP loop) must not
+        # invalidate this capture
+        with torch.cuda.graph(g.graph, pool=self.graph_pool, capture_error_mode="thread_local"):
             g.output = self._forward_decode(md, ids, pos)
         set_forward_context(None)
         if self.graph_pool is None:
