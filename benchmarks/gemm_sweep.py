@@ -24,7 +24,8 @@ def bench(m, n, k, iters=20):
 tp = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 H, FF, V = 8192, 28672, 128256
 shapes = {"qkv": (10240 // tp, H), "o": (H, H // tp), "gate_up": (2 * FF // tp, H), "down": (H, FF // tp)}
-for m in (256, 512, 1024, 2048, 4096, 8192):
+ms = [int(a) for a in sys.argv[2].split(",")] if len(sys.argv) > 2 else [256, 512, 1024, 2048, 4096, 8192]
+for m in ms:
     tot_us, tot_fl = 0.0, 0.0
     line = []
     for name, (n, k) in shapes.items():

@@ -266,6 +266,190 @@ __global__ __launch_bounds__(256) void paged_prefill_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Prefill, LDS-staged (D = 128): workgroup = 128 query tokens of one head,
+// 4 waves x 32 query columns on v_mfma_f32_32x32x16.  K (64 keys x 256 B) and
+// V^T (128 rows x 128 B) tiles are staged through double-buffered LDS with
+// register prefetch of the next tile (global loads issued before the MFMA
+// phase, LDS writes after it, one barrier per tile) and XOR-swizzled 16-byte
+// chunks so every ds_read_b128 is bank-conflict free.
+//
+// Swapped products again: S^T[key][q] = K.Q^T, O^T[d][q] += V^T.P^T.  The K
+// rows fed to the MFMA are permuted (bits 2 and 3 of the row index swapped) so
+// that accumulator registers 8s..8s+7 of a lane are 8 *consecutive* keys
+// 16s + 8*(lane>>5) + j - the natural B-operand layout of the PV product.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
+    T* __restrict__ out, const T* __restrict__ q, long q_stride, const T* __restrict__ k_cache,
+    const T* __restrict__ v_cache, const int* __restrict__ block_table, int bt_stride,
+    const int* __restrict__ query_start_loc, const int* __restrict__ seq_lens, float scale_log2e, int Hq, int Hkv,
+    int block_size, long out_stride) {
+  using V = typename Vec8<T>::type;
+  constexpr int D = 128, KT = 64, TILE_BYTES = KT * D * 2;
+  __shared__ __attribute__((aligned(16))) char smem[2][2][TILE_BYTES];     // [buffer][K | V^T]
+
+  const int z = blockIdx.z, head = blockIdx.y;
+  const int q0 = query_start_loc[z];
+  const int q_len = query_start_loc[z + 1] - q0;
+  // heaviest (latest, longest causal span) query tiles are dispatched first
+  const int t_blk = (int)(gridDim.x - 1 - blockIdx.x) * 128;
+  if (t_blk >= q_len) return;                       // uniform for the workgroup
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l32 = lane & 31, h = lane >> 5;
+  const int seq_len = seq_lens[z];
+  const int ctx = seq_len - q_len;
+  const int kvh = head / (Hq / Hkv);
+  const int t_wave = t_blk + wid * 32;
+  const int tok = t_wave + l32;
+  const bool wave_active = t_wave < q_len;
+  const int* bt_row = block_table + (long)z * bt_stride;
+
+  // Q^T B-operand fragments: 8 k-steps of 16 dims
+  V qf[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+    qf[s] = (tok < q_len) ? ld8<T>(q + (long)(q0 + tok) * q_stride + (long)head * D + 16 * s + 8 * h) : zero8<T>();
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+  float m_run = NEG_BIG, l_run = 0.f;
+  const int q_hi = min(ctx + tok, seq_len - 1);                    // last key this lane's query sees
+  const int wave_last_key = min(seq_len - 1, ctx + min(t_wave + 31, q_len - 1));
+  const int n_tiles = (min(seq_len - 1, ctx + min(t_blk + 127, q_len - 1)) >> 6) + 1;
+
+  // per-thread staging coordinates: 4 K chunks + 4 V^T chunks of 16 bytes
+  V stage_k[4], stage_v[4];
+  auto load_tile = [&](int tile) {
+    const int base = tile * KT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c >> 4, cc = c & 15;
+      const int key = min(base + row, seq_len - 1);
+      const long blk = bt_row[key / block_size];
+      stage_k[i] = ld8<T>(k_cache + ((blk * Hkv + kvh) * block_size + (key % block_size)) * (long)D + 8 * cc);
+      const int d = c >> 3, kc = c & 7;
+      const int vkey = min(base + 8 * kc, seq_len - 1) & ~7;
+      const long blkv = bt_row[vkey / block_size];
+      stage_v[i] = ld8<T>(v_cache + ((blkv * Hkv + kvh) * (long)D + d) * block_size + (vkey % block_size));
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c >> 4, cc = c & 15;
+      *reinterpret_cast<V*>(&smem[buf][0][row * 256 + ((cc ^ (row & 15)) << 4)]) = stage_k[i];
+      const int d = c >> 3, kc = c & 7;
+      *reinterpret_cast<V*>(&smem[buf][1][d * 128 + ((kc ^ ((d >> 1) & 7)) << 4)]) = stage_v[i];
+    }
+  };
+
+  // MFMA row rho of a 32-key sub-tile reads LDS key row kappa(rho): bits 2 and 3 swapped
+  const int kappa = (l32 & ~12) | ((l32 & 4) << 1) | ((l32 & 8) >> 1);
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int t = 0; t < n_tiles; ++t) {
+    const int buf = t & 1;
+    const bool more = t + 1 < n_tiles;
+    if (more) load_tile(t + 1);
+    const int base = t * KT;
+    if (wave_active && base <= wave_last_key) {
+      const char* ks = smem[buf][0];
+      const char* vs = smem[buf][1];
+      f32x16 sc[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[u][r] = 0.f;
+        const int row = 32 * u + kappa;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const int chunk = 2 * s + h;
+          const V a = *reinterpret_cast<const V*>(ks + row * 256 + ((chunk ^ (row & 15)) << 4));
+          sc[u] = mfma32(a, qf[s], sc[u]);
+        }
+      }
+      // scale + causal mask (only tiles that straddle the diagonal need the compare)
+      const bool need_mask = base + KT - 1 > min(ctx + t_wave, seq_len - 1);
+      float tmax = NEG_BIG;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = sc[u][r] * scale_log2e;
+          if (need_mask) {
+            const int key = base + 32 * u + 16 * (r >> 3) + 8 * h + (r & 7);
+            v = key <= q_hi ? v : NEG_BIG;
+          }
+          sc[u][r] = v;
+          tmax = fmaxf(tmax, v);
+        }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = exp2f(m_run - m_new);
+      float psum = 0.f;
+      V pf[4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = exp2f(sc[u][r] - m_new);
+          psum += e;
+          pf[2 * u + (r >> 3)][r & 7] = (T)e;
+        }
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+      const bool rescale = __any(alpha != 1.f);     // the running max rarely moves after the first tiles
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        if (rescale) acc[dt] *= alpha;
+        const int d = 32 * dt + l32;
+#pragma unroll
+        for (int ks4 = 0; ks4 < 4; ++ks4) {
+          const int kc = 2 * ks4 + h;
+          const V a = *reinterpret_cast<const V*>(vs + d * 128 + ((kc ^ ((d >> 1) & 7)) << 4));
+          acc[dt] = mfma32(a, pf[ks4], acc[dt]);
+        }
+      }
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (tok < q_len) {
+    float lsum = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+    T* orow = out + (long)(q0 + tok) * out_stride + (long)head * D + 4 * h;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        typename Vec4<T>::type o4;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) o4[b] = (T)(acc[dt][4 * g + b] * inv);
+        *reinterpret_cast<typename Vec4<T>::type*>(orow + 32 * dt + 8 * g) = o4;
+      }
+  } else {
+    (void)__shfl_xor(l_run, 32, 64);
+  }
+}
+
 template <typename T, int D>
 int launch_decode(void* out, float* ws, const void* q, long q_stride, const void* kc, const void* vc, const int* bt,
                   int bt_stride, const int* seq_lens, float scale, int B, int Hq, int Hkv, int block_size,
@@ -293,6 +477,15 @@ int launch_prefill(void* out, const void* q, long q_stride, const void* kc, cons
                    int Hq, int Hkv, int block_size, long out_stride, hipStream_t s) {
   const float sl2 = scale * 1.4426950408889634f;
   const int tiles = (max_q_len + 127) / 128;
+  if constexpr (D == 128) {
+    if (max_q_len > 32) {      // longer chunks: LDS-staged 32x32 MFMA kernel
+      hipLaunchKernelGGL((paged_prefill_lds_kernel<T>), dim3(tiles, Hq, num_seqs), dim3(256), 0, s, (T*)out,
+                         (const T*)q, q_stride, (const T*)kc, (const T*)vc, bt, bt_stride, qsl, seq_lens, sl2, Hq,
+                         Hkv, block_size, out_stride);
+      HIP_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   hipLaunchKernelGGL((paged_prefill_kernel<T, D>), dim3(tiles, Hq, num_seqs), dim3(256), 0, s, (T*)out,
                      (const T*)q, q_stride, (const T*)kc, (const T*)vc, bt, bt_stride, qsl, seq_lens, sl2, Hq, Hkv,
                      block_size, out_stride);
