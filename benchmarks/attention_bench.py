@@ -37,7 +37,7 @@ def decode(b, ctx, hq, hkv, d=128, bs=64):
     bt = torch.randperm(b * nb, device=dev).to(torch.int32).view(b, nb)
     sl = torch.full((b,), ctx, device=dev, dtype=torch.int32)
     q = torch.randn(b, hq, d, device=dev).to(torch.bfloat16)
-    ws = torch.empty(hip.decode_workspace_floats(b, hq, d), device=dev)
+    ws = torch.empty(hip.decode_workspace_floats(b, hq, d, hkv, ctx), device=dev)
     out = torch.empty_like(q)
     us = timeit(lambda: hip.paged_attention_decode(q, k, v, bt, sl, d ** -0.5, ctx, out, ws))
     bytes_ = b * ctx * hkv * d * 2 * 2

@@ -21,7 +21,7 @@
 namespace {
 
 constexpr float NEG_BIG = -1.0e30f;
-constexpr int MAX_SPLITS = 16;
+constexpr int MAX_SPLITS = 64;
 
 template <typename T>
 __device__ __forceinline__ typename Vec8<T>::type zero8() {

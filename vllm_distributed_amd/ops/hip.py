@@ -205,8 +205,12 @@ def reshape_and_cache(k, v, k_cache, v_cache, slot_mapping) -> None:
 
 
 # ---------------------------------------------------------------- attention
-def decode_workspace_floats(max_bs: int, num_heads: int, head_dim: int) -> int:
-    return int(_LIB.vdamd_decode_workspace_floats(max_bs, num_heads, head_dim))
+def decode_workspace_floats(max_bs: int, num_heads: int, head_dim: int, num_kv_heads: int = 1,
+                            max_seq_len: int = 1 << 30) -> int:
+    """Floats of split-KV scratch that cover every batch size up to ``max_bs``
+    (splits shrink as the batch grows, so this is far below max_bs * MAX_SPLITS)."""
+    worst = max(b * choose_num_splits(b, num_kv_heads, max_seq_len) for b in range(1, max(1, max_bs) + 1))
+    return worst * num_heads * (head_dim + 2)
 
 
 def choose_num_splits(batch: int, num_kv_heads: int, max_seq_len: int) -> int:

@@ -466,7 +466,8 @@ class ModelRunner:
             return
         from ..ops import hip
         attn = self.model.attention_layers()[0]
-        n = hip.decode_workspace_floats(max(max_bs, self.max_num_reqs), attn.num_heads, attn.head_dim)
+        n = hip.decode_workspace_floats(max(max_bs, self.max_num_reqs), attn.num_heads, attn.head_dim,
+                                        attn.num_kv_heads, self.max_model_len)
         self.decode_workspace = torch.empty(n, dtype=torch.float32, device=self.device)
 
     def _capture_one(self, bs: int) -> None:
