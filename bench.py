@@ -38,6 +38,8 @@ def main() -> None:
     ap.add_argument("--dtype", type=str, default="bfloat16")
     ap.add_argument("--enforce-eager", action="store_true")
     ap.add_argument("--executor", type=str, default="auto", choices=["auto", "uni", "spmd"])
+    ap.add_argument("--sync-scheduling", action="store_true",
+                    help="schedule each step only after the previous step's tokens reached the host")
     ap.add_argument("--device", type=str, default="cuda", choices=["cuda", "cpu"],
                     help="cpu = gloo rehearsal of the multi-rank path with a tiny model (not a measurement)")
     args = ap.parse_args()
@@ -61,7 +63,7 @@ def main() -> None:
     batch = args.batch_per_gpu * n
     # continuous batching staggers the sequences by the number of prefill steps
     prefill_steps = -(-batch * args.prompt_len // max(16384, batch))
-    total_new = args.warmup + args.steps + prefill_steps + 8
+    total_new = args.warmup + args.steps + prefill_steps + 10
     max_len = args.prompt_len + total_new + 16
     backend = args.executor
     if backend == "auto":
@@ -71,7 +73,7 @@ def main() -> None:
         distributed_executor_backend=backend, max_model_len=max_len, max_num_seqs=batch,
         max_num_batched_tokens=max(16384, batch), enable_prefix_caching=False,
         enforce_eager=args.enforce_eager, max_capture_size=batch, hip_graph_sizes=[batch],
-        gpu_memory_utilization=0.92, seed=0))
+        gpu_memory_utilization=0.92, seed=0, async_scheduling=not args.sync_scheduling))
     vocab = engine.model_config.vocab_size
     rng = np.random.default_rng(1234)
 
@@ -114,6 +116,8 @@ def main() -> None:
     if on_gpu:
         torch.cuda.synchronize()
     prefill_s = time.perf_counter() - t_prefill0
+    if not args.sync_scheduling:
+        engine.step()          # fill the one-step-ahead pipeline: from here every call returns one full step
     for _ in range(args.warmup):
         engine.step()
     produced = 0
@@ -143,6 +147,7 @@ def main() -> None:
             "prefill_tokens_per_s": round(batch * args.prompt_len / prefill_s, 1),
             "config": {"model": args.model, "global_batch": batch, "seq_len": args.prompt_len,
                        "parallelism": f"tp{n}", "executor": backend,
+                       "async_scheduling": not args.sync_scheduling,
                        "hip_graph": bool(runner.graphs), "block_size": runner.block_size,
                        "step_breakdown_ms": {k: round(v, 3) for k, v in engine.core.timer.summary().items()}},
         }))

@@ -113,8 +113,9 @@ def _reference(model):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("model,tp,pp", [("opt-tiny", 1, 2), ("llama-tiny", 2, 1), ("llama-tiny", 1, 2)])
-def test_head_plus_remote_worker_matches_single_process(monkeypatch, model, tp, pp):
+@pytest.mark.parametrize("model,tp,pp,async_sched", [("opt-tiny", 1, 2, False), ("llama-tiny", 2, 1, False),
+                                                     ("llama-tiny", 1, 2, False), ("llama-tiny", 2, 1, True)])
+def test_head_plus_remote_worker_matches_single_process(monkeypatch, model, tp, pp, async_sched):
     """OPT greedy with head + 1 worker on localhost is the plumbing configuration;
     the TP=2 case assembles one TP group from the head's device and a same-host worker."""
     ref = _reference(model)
@@ -127,10 +128,11 @@ def test_head_plus_remote_worker_matches_single_process(monkeypatch, model, tp, 
         eng = LLMEngine.from_engine_args(EngineArgs(
             model=model, device="cpu", dtype="float32", max_model_len=128, block_size=16,
             num_gpu_blocks_override=64, max_num_seqs=8, tensor_parallel_size=tp,
-            pipeline_parallel_size=pp, distributed_executor_backend="distributed"))
+            pipeline_parallel_size=pp, distributed_executor_backend="distributed",
+            async_scheduling=async_sched))
         ex = eng.core.executor
         assert [a.node_id is None for a in ex.assignments] == [True, False]
-        assert ex.max_concurrent_batches == pp
+        assert ex.max_concurrent_batches == (2 if async_sched else pp)
         ex.check_health()
         got = _generate(eng)
         assert got == ref

@@ -118,3 +118,46 @@ def test_sampling_seeded_and_stop_conditions():
     lp = llm.generate(p, SamplingParams(temperature=0, max_tokens=3, ignore_eos=True, logprobs=2))[0]
     assert len(lp.outputs[0].logprobs) == 3 and lp.outputs[0].cumulative_logprob < 0
     llm.shutdown()
+
+
+def _run_tokens(prompts, sps, **kw):
+    pstate.destroy_model_parallel()
+    llm = LLM(model="llama-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,
+              enable_prefix_caching=False, **kw)
+    outs = llm.generate(prompts, sps)
+    steps = llm.engine.core.timer.n
+    sched = llm.engine.core.scheduler
+    assert not sched.running and not sched.waiting and sched.kv.num_free_blocks == sched.kv.pool.num_blocks
+    llm.shutdown()
+    pstate.destroy_model_parallel()
+    return [(o.outputs[0].token_ids, o.outputs[0].finish_reason) for o in outs], steps
+
+
+def test_async_scheduling_matches_sync_including_stops_and_sampling():
+    """One step is always scheduled ahead of the sampled tokens (device-resident
+    inputs, placeholder accounting); results must be identical to the
+    synchronous engine for greedy, seeded sampling, EOS/stop-token stops,
+    max_tokens limits and penalties."""
+    prompts = [[5, 9, 200, 17, 3], list(range(10, 60)), [7], list(range(100, 131)), [42, 43]]
+    base, _ = _run_tokens(prompts, SamplingParams(temperature=0.0, max_tokens=20, ignore_eos=True),
+                          num_gpu_blocks_override=64)
+    stop_tok = base[1][0][6]
+    sps = [SamplingParams(temperature=0.0, max_tokens=20, ignore_eos=True),
+           SamplingParams(temperature=0.0, max_tokens=20, ignore_eos=True, stop_token_ids=[stop_tok]),
+           SamplingParams(temperature=0.9, top_p=0.8, seed=11, max_tokens=1, ignore_eos=True),
+           SamplingParams(temperature=0.7, top_k=20, seed=5, max_tokens=13, ignore_eos=True,
+                          repetition_penalty=1.3, presence_penalty=0.5),
+           SamplingParams(temperature=0.0, max_tokens=2, ignore_eos=True)]
+    ref, _ = _run_tokens(prompts, sps, num_gpu_blocks_override=64)
+    got, _ = _run_tokens(prompts, sps, num_gpu_blocks_override=64, async_scheduling=True)
+    assert got == ref
+    assert ref[1][1] == "stop" and ref[0][1] == "length" and len(ref[2][0]) == 1 and len(ref[4][0]) == 2
+
+
+def test_async_scheduling_with_preemption_and_chunked_prefill():
+    prompts = [list(range(2, 40)), list(range(100, 140)), list(range(200, 230))]
+    sp = SamplingParams(temperature=0.0, max_tokens=40, ignore_eos=True)
+    ref, _ = _run_tokens(prompts, sp, num_gpu_blocks_override=64)
+    got, _ = _run_tokens(prompts, sp, num_gpu_blocks_override=11, async_scheduling=True,
+                         max_num_batched_tokens=24)
+    assert got == ref

@@ -21,7 +21,8 @@ tp = int(os.environ.get("WORLD_SIZE", "1"))
 eng = LLMEngine.from_engine_args(EngineArgs(
     model="llama-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,
     num_gpu_blocks_override=64, max_num_seqs=8, tensor_parallel_size=tp,
-    distributed_executor_backend="spmd" if tp > 1 else "uni"))
+    distributed_executor_backend="spmd" if tp > 1 else "uni",
+    async_scheduling=os.environ.get("ASYNC") == "1"))
 sp = SamplingParams(temperature=0.8, top_p=0.9, seed=7, max_tokens=8, ignore_eos=True)
 g = SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True)
 ids = [eng.add_request(None, p, s) for p, s in (([5, 9, 200, 17], g), (list(range(10, 50)), sp), ([7, 7], g))]
@@ -35,13 +36,13 @@ eng.shutdown()
 """
 
 
-def _run(world):
+def _run(world, async_sched=False):
     port = get_open_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VLLM_LOGGING_LEVEL="WARNING",
-                   GLOO_SOCKET_IFNAME="lo", OMP_NUM_THREADS="2")
+                   GLOO_SOCKET_IFNAME="lo", OMP_NUM_THREADS="2", ASYNC="1" if async_sched else "0")
         procs.append(subprocess.Popen([sys.executable, "-c", SCRIPT.format(root=ROOT)], env=env,
                                       stdout=subprocess.PIPE, text=True))
     outs = []
@@ -57,6 +58,8 @@ def _run(world):
 def test_spmd_tp2_matches_single_process_on_every_rank():
     ref = _run(1)[0]
     got = _run(2)
+    assert got[0] == ref and got[1] == ref
+    got = _run(2, async_sched=True)        # one step scheduled ahead on every rank
     assert got[0] == ref and got[1] == ref
 
 

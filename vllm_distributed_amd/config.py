@@ -323,6 +323,10 @@ class VllmConfig:
         if mc.num_attention_heads % pc.tensor_parallel_size != 0:
             raise ValueError(f"num_attention_heads ({mc.num_attention_heads}) must be divisible "
                              f"by tensor_parallel_size ({pc.tensor_parallel_size})")
+        if self.scheduler_config.async_scheduling and pc.pipeline_parallel_size > 1:
+            logger.warning("async scheduling needs the sampled tokens on the first pipeline stage; "
+                           "disabled with pipeline_parallel_size > 1")
+            self.scheduler_config.async_scheduling = False
         if pc.pipeline_parallel_size > mc.num_hidden_layers:
             raise ValueError("pipeline_parallel_size exceeds the number of layers")
 

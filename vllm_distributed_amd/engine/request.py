@@ -31,7 +31,7 @@ class Request:
     __slots__ = ("request_id", "prompt_token_ids", "sampling_params", "eos_token_id",
                  "arrival_time", "priority", "status", "output_token_ids", "all_token_ids",
                  "num_computed_tokens", "num_cached_tokens", "stop_reason", "metrics",
-                 "block_hashes", "num_preemptions", "max_tokens", "prompt")
+                 "block_hashes", "num_preemptions", "max_tokens", "prompt", "num_output_placeholders")
 
     def __init__(self, request_id: str, prompt_token_ids: List[int],
                  sampling_params: SamplingParams, eos_token_id: Optional[int] = None,
@@ -52,6 +52,8 @@ class Request:
         self.stop_reason: Optional[object] = None
         self.block_hashes: List[int] = []
         self.num_preemptions = 0
+        # tokens scheduled to be sampled whose values are not known yet (async scheduling)
+        self.num_output_placeholders = 0
         self.max_tokens = sampling_params.max_tokens
         self.metrics = RequestMetrics(arrival_time=self.arrival_time,
                                       num_prompt_tokens=len(prompt_token_ids))

@@ -58,6 +58,9 @@ class Scheduler:
         self.max_num_seqs = scheduler_config.max_num_seqs
         self.max_num_batched_tokens = scheduler_config.max_num_batched_tokens
         self.max_model_len = scheduler_config.max_model_len
+        # async scheduling: step n+1 is scheduled before step n's tokens are known;
+        # a request that will sample carries a placeholder for the unknown token
+        self.async_scheduling = bool(scheduler_config.async_scheduling)
         self.kv = KVCacheManager(num_blocks, cache_config.block_size, self.max_model_len,
                                  cache_config.enable_prefix_caching)
         self.requests: Dict[str, Request] = {}
@@ -139,9 +142,11 @@ class Scheduler:
                 break
             if req.status != RequestStatus.RUNNING:
                 continue             # preempted earlier in this loop
-            n = req.num_tokens - req.num_computed_tokens
+            n = req.num_tokens + req.num_output_placeholders - req.num_computed_tokens
             if n <= 0:               # its next token is still in flight
                 continue
+            if req.num_output_placeholders and not self._may_run_ahead(req):
+                continue             # would overshoot max_tokens / max_model_len: wait for the token
             n = min(n, budget)
             if self.config.long_prefill_token_threshold > 0:
                 n = min(n, self.config.long_prefill_token_threshold)
@@ -163,6 +168,7 @@ class Scheduler:
             self._add_cached(cached, req, new_blocks)
             num_scheduled[req.request_id] = n
             req.num_computed_tokens += n
+            self._note_sampling(req)
             budget -= n
 
         # 2. waiting requests (not while we are under memory pressure)
@@ -204,6 +210,7 @@ class Scheduler:
                 self._pending_new_tokens.pop(req.request_id, None)
                 num_scheduled[req.request_id] = n
                 req.num_computed_tokens += n
+                self._note_sampling(req)
                 budget -= n
 
         total = sum(num_scheduled.values())
@@ -218,6 +225,19 @@ class Scheduler:
             out.kv_connector_metadata = self.kv_connector.build_connector_meta(out)
         self.step_id += 1
         return out
+
+    def _note_sampling(self, req: Request) -> None:
+        """Async mode: if this step runs the request's last known position it will
+        sample a token; account for it so the next step can be scheduled now."""
+        if self.async_scheduling and \
+                req.num_computed_tokens >= req.num_tokens + req.num_output_placeholders:
+            req.num_output_placeholders += 1
+
+    def _may_run_ahead(self, req: Request) -> bool:
+        n_out = req.num_output_tokens + req.num_output_placeholders
+        if req.max_tokens is not None and n_out >= req.max_tokens:
+            return False
+        return req.num_tokens + req.num_output_placeholders < self.max_model_len
 
     def _add_cached(self, cached: CachedRequestData, req: Request, new_blocks: List[int]) -> None:
         """Record a delta for an already-known request.  The list is sparse:
@@ -247,6 +267,7 @@ class Scheduler:
         self.kv.free(req)
         req.status = RequestStatus.PREEMPTED
         req.num_computed_tokens = 0
+        req.num_output_placeholders = 0
         req.num_preemptions += 1
         self.num_preemptions += 1
         if req.request_id in self._known_to_workers:
@@ -267,6 +288,8 @@ class Scheduler:
             if req is None or req.finished or req.status != RequestStatus.RUNNING:
                 continue             # aborted / preempted while in flight
             new_tokens = sampled.get(rid) or []
+            if new_tokens and req.num_output_placeholders:
+                req.num_output_placeholders = max(0, req.num_output_placeholders - len(new_tokens))
             accepted: List[int] = []
             for tok in new_tokens:
                 req.append_output_token(tok)

@@ -20,6 +20,23 @@ logger = init_logger(__name__)
 FailureCallback = Callable[[], None]
 
 
+class LazyFuture:
+    """Future-like wrapper for in-process executors: the worker has launched the
+    step on the device; ``result()`` waits for it (``obj.get()``) on first use."""
+
+    def __init__(self, obj: Any):
+        self._obj = obj
+
+    def result(self, timeout: Optional[float] = None) -> Any:
+        obj = self._obj
+        if hasattr(obj, "get"):
+            self._obj = obj = obj.get()
+        return obj
+
+    def done(self) -> bool:
+        return not hasattr(self._obj, "get")
+
+
 class Executor:
     uses_ray: bool = False
 
@@ -64,7 +81,8 @@ class Executor:
 
     @property
     def max_concurrent_batches(self) -> int:
-        return 1
+        # async scheduling keeps one step in flight while the next is scheduled
+        return 2 if self.scheduler_config.async_scheduling else 1
 
     @property
     def output_rank(self) -> int:

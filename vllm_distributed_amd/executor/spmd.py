@@ -18,7 +18,7 @@ from typing import Any, Callable, List, Optional, Union
 
 from ..utils import run_method
 from ..worker.worker_base import WorkerWrapperBase
-from .abstract import Executor
+from .abstract import Executor, LazyFuture
 
 
 class SpmdExecutor(Executor):
@@ -52,11 +52,10 @@ class SpmdExecutor(Executor):
         if method == "load_model":
             # every rank needs the sampled tokens to keep its own scheduler in step
             self.driver.worker.model_runner.report_on_all_ranks = True
+            self.driver.worker.model_runner.defer_output = self.scheduler_config.async_scheduling
         if non_block:
-            fut: concurrent.futures.Future = concurrent.futures.Future()
-            fut.set_result(result)
-            return [fut]
-        return [result]
+            return [LazyFuture(result)]
+        return [result.get() if hasattr(result, "get") else result]
 
     def determine_available_memory(self) -> List[int]:
         """Every rank runs its own scheduler, so all must size the KV cache

@@ -6,7 +6,7 @@ from typing import Any, Callable, List, Optional, Union
 
 from ..utils import get_distributed_init_method, get_ip, get_open_port, run_method
 from ..worker.worker_base import WorkerWrapperBase
-from .abstract import Executor
+from .abstract import Executor, LazyFuture
 
 
 class UniProcExecutor(Executor):
@@ -22,14 +22,12 @@ class UniProcExecutor(Executor):
     def collective_rpc(self, method: Union[str, Callable], timeout: Optional[float] = None,
                        args: tuple = (), kwargs: Optional[dict] = None, non_block: bool = False,
                        unique_reply_rank: Optional[int] = None) -> List[Any]:
+        result = run_method(self.driver, method, args, kwargs)
+        if method == "load_model":
+            self.driver.worker.model_runner.defer_output = self.scheduler_config.async_scheduling
         if non_block:
-            fut: concurrent.futures.Future = concurrent.futures.Future()
-            try:
-                fut.set_result(run_method(self.driver, method, args, kwargs))
-            except BaseException as e:  # noqa: BLE001
-                fut.set_exception(e)
-            return [fut]
-        return [run_method(self.driver, method, args, kwargs)]
+            return [LazyFuture(result)]
+        return [result.get() if hasattr(result, "get") else result]
 
     def shutdown(self) -> None:
         drv = getattr(self, "driver", None)

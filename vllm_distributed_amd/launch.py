@@ -54,6 +54,8 @@ def set_peer_run_worker(peer: RpcPeer, wrapper: Any, rank: int, local_rank: int)
                          method if isinstance(method, str) else "<callable>", rank, e,
                          traceback.format_exc())
             raise
+        if hasattr(result, "get"):          # a lazily resolved step result
+            result = result.get()
         if unique_reply_rank is not None and unique_reply_rank != rank:
             return None
         return cloudpickle.dumps(result)

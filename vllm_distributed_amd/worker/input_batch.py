@@ -27,7 +27,10 @@ class InputBatch:
         n = max_num_reqs
         # calloc-backed: rows that are never used never become resident
         self.token_ids = np.zeros((n, max_model_len), dtype=np.int32)
-        self.num_tokens = np.zeros(n, dtype=np.int32)         # tokens known (prompt + outputs)
+        self.num_tokens = np.zeros(n, dtype=np.int32)         # positions assigned (prompt + outputs)
+        # tokens whose *values* are on the host; lags num_tokens by the samples still in flight
+        self.num_known = np.zeros(n, dtype=np.int32)
+        self.row_gen = np.zeros(n, dtype=np.int64)             # bumped whenever a row changes owner
         self.num_prompt_tokens = np.zeros(n, dtype=np.int32)
         self.num_computed = np.zeros(n, dtype=np.int32)
         self.block_table = np.zeros((n, self.max_blocks), dtype=np.int32)
@@ -65,6 +68,8 @@ class InputBatch:
         if n_o:
             self.token_ids[row, n_p:n_p + n_o] = output_token_ids
         self.num_tokens[row] = n_p + n_o
+        self.num_known[row] = n_p + n_o
+        self.row_gen[row] += 1
         self.num_prompt_tokens[row] = n_p
         self.num_computed[row] = num_computed
         nb = len(block_ids)
@@ -99,6 +104,8 @@ class InputBatch:
         self.params[row] = None
         self.generators[row] = None
         self.num_tokens[row] = 0
+        self.num_known[row] = 0
+        self.row_gen[row] += 1
         self.num_computed[row] = 0
         self.num_blocks[row] = 0
         self._free_rows.append(row)
@@ -114,6 +121,7 @@ class InputBatch:
         n = int(self.num_tokens[row])
         self.token_ids[row, n:n + len(token_ids)] = token_ids
         self.num_tokens[row] = n + len(token_ids)
+        self.num_known[row] = n + len(token_ids)
 
     def draw_uniform(self, rows: np.ndarray) -> np.ndarray:
         """One U(0,1) per row from the row's own generator (0.5 for greedy rows)."""

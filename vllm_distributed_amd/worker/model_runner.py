@@ -28,6 +28,68 @@ from .input_batch import InputBatch
 logger = init_logger(__name__)
 
 
+class PendingSample:
+    """Tokens sampled on the device whose values have not reached the host yet."""
+
+    __slots__ = ("runner", "step_id", "req_ids", "nreq", "sel", "rows", "gens", "pos", "tokens",
+                 "event", "logprobs", "timing", "t_launch", "_result")
+
+    def __init__(self, runner: "ModelRunner", step_id: int, req_ids: List[str], sel: Optional[np.ndarray],
+                 rows: Optional[np.ndarray], pos: Optional[np.ndarray], tokens: Optional[torch.Tensor],
+                 event: Optional["torch.cuda.Event"], logprobs, timing: Optional[Dict[str, float]]):
+        self.runner, self.step_id, self.req_ids, self.nreq = runner, step_id, req_ids, len(req_ids)
+        self.sel, self.rows, self.pos, self.tokens, self.event = sel, rows, pos, tokens, event
+        self.gens = runner.batch.row_gen[rows].copy() if rows is not None else None
+        self.logprobs, self.timing = logprobs, timing
+        self.t_launch = time.perf_counter()
+        self._result: Optional[ModelRunnerOutput] = None
+
+    def get(self) -> ModelRunnerOutput:
+        """Wait for the device, publish the token values into the persistent
+        batch (unless the row changed owner meanwhile) and build the output."""
+        if self._result is not None:
+            return self._result
+        out_tokens: List[List[int]] = [[] for _ in range(self.nreq)]
+        logprobs_out = None
+        if self.sel is not None:
+            if self.event is not None:
+                self.event.synchronize()
+            toks = self.tokens.numpy()
+            b = self.runner.batch
+            ok = b.row_gen[self.rows] == self.gens
+            rows, pos = self.rows[ok], self.pos[ok]
+            b.token_ids[rows, pos] = toks[ok]
+            b.num_known[rows] = np.maximum(b.num_known[rows], pos + 1)
+            tok_list = toks.tolist()
+            for j, i in enumerate(self.sel.tolist()):
+                out_tokens[i] = [tok_list[j]]
+            if self.logprobs is not None:
+                logprobs_out = [None] * self.nreq
+                for j, i in enumerate(self.sel.tolist()):
+                    logprobs_out[i] = self.logprobs[j]
+        timing = self.timing
+        if timing is not None:
+            timing["sample"] = timing.get("sample", 0.0) + (time.perf_counter() - self.t_launch)
+        self._result = ModelRunnerOutput(step_id=self.step_id, req_ids=self.req_ids,
+                                         sampled_token_ids=out_tokens, logprobs=logprobs_out, timing=timing)
+        try:
+            self.runner._pending.remove(self)
+        except ValueError:
+            pass
+        return self._result
+
+
+class _Discard:
+    """Resolves a pending sample for its side effects on a non-output rank."""
+
+    def __init__(self, pending: PendingSample):
+        self.pending = pending
+
+    def get(self) -> None:
+        self.pending.get()
+        return None
+
+
 class DecodeGraph:
     """A captured decode step for one padded batch size."""
 
@@ -62,6 +124,9 @@ class ModelRunner:
         self.step_count = 0
         self.report_on_all_ranks = False
         self.comm_stream = None
+        self.sampled_dev: Optional[torch.Tensor] = None      # last sampled token per batch row (device)
+        self._pending: List[PendingSample] = []
+        self.defer_output = False        # set by in-process executors under async scheduling
         self.timing_enabled = vllm_config.observability_config.collect_step_timing
 
     # ------------------------------------------------------------------ setup
@@ -168,6 +233,7 @@ class ModelRunner:
             positions = (starts[req_idx] + (np.arange(total, dtype=np.int32) - qsl[req_idx])).astype(np.int32)
             tok_rows = rows[req_idx]
         input_ids = b.token_ids[tok_rows, positions]
+        unknown = positions >= b.num_known[tok_rows]      # values still on the device only
         blk = b.block_table[tok_rows, positions // self.block_size]
         slot_mapping = (blk * self.block_size + positions % self.block_size).astype(np.int32)
         max_blocks = int(cdiv(int(seq_lens.max()), self.block_size))
@@ -176,7 +242,8 @@ class ModelRunner:
         return dict(req_ids=req_ids, rows=rows, n_sched=n_sched, num_decodes=num_decodes,
                     seq_lens=seq_lens, qsl=qsl, total=total, positions=positions,
                     input_ids=input_ids, slot_mapping=slot_mapping, max_blocks=max_blocks,
-                    sample_mask=sample_mask)
+                    sample_mask=sample_mask, unknown=unknown if unknown.any() else None,
+                    tok_rows=tok_rows)
 
     def _to_dev(self, arr: np.ndarray, dtype=torch.int32) -> torch.Tensor:
         t = torch.from_numpy(np.ascontiguousarray(arr))
@@ -206,8 +273,19 @@ class ModelRunner:
             md.prefill_query_start_loc = self._to_dev(pq)
             md.max_prefill_query_len = int(n_sched[nd:].max())
         input_ids = self._to_dev(p["input_ids"])
+        self._patch_unknown_inputs(input_ids, p)
         positions = self._to_dev(p["positions"])
         return md, input_ids, positions
+
+    def _patch_unknown_inputs(self, input_ids: torch.Tensor, p: dict) -> None:
+        """Input tokens sampled by a step whose result has not been read back yet
+        come straight from the device-side copy of the last sampled tokens."""
+        unknown = p["unknown"]
+        if unknown is None:
+            return
+        where = np.nonzero(unknown)[0]
+        rows = self._to_dev(p["tok_rows"][where], torch.int64)
+        input_ids.index_copy_(0, self._to_dev(where, torch.int64), self.sampled_dev.index_select(0, rows))
 
     # ------------------------------------------------------------ execution
     @torch.inference_mode()
@@ -216,7 +294,7 @@ class ModelRunner:
         self._update_states(so)
         self.step_count += 1
         if so.total_num_scheduled_tokens == 0:
-            return ModelRunnerOutput(step_id=so.step_id) if self._is_output_rank() else None
+            return ModelRunnerOutput(step_id=so.step_id) if self._is_output_rank() else None   # nothing to wait for
         p = self._prepare_inputs(so)
         nreq, nd, total = len(p["req_ids"]), p["num_decodes"], p["total"]
         t1 = time.perf_counter()
@@ -237,8 +315,7 @@ class ModelRunner:
             return None
         t2 = time.perf_counter()
         sample_mask = p["sample_mask"]
-        out_tokens: List[List[int]] = [[] for _ in range(nreq)]
-        logprobs_out = None
+        sel = rows_sel = pos_sel = host_tokens = event = logprobs_sel = None
         if sample_mask.any():
             sel = np.nonzero(sample_mask)[0]
             last_idx = p["qsl"][1:][sel] - 1
@@ -248,24 +325,29 @@ class ModelRunner:
                 hs = hidden.index_select(0, self._to_dev(last_idx, torch.int64))
             rows_sel = p["rows"][sel]
             tokens, logprobs_sel = self._sample(hs, rows_sel)
-            tok_list = tokens.tolist()
             b = self.batch
-            # remember what we sampled: TP ranks all compute the same token
-            n_known = b.num_tokens[rows_sel]
-            b.token_ids[rows_sel, n_known] = tokens
-            b.num_tokens[rows_sel] = n_known + 1
-            for j, i in enumerate(sel.tolist()):
-                out_tokens[i] = [tok_list[j]]
-            if logprobs_sel is not None:
-                logprobs_out = [None] * nreq
-                for j, i in enumerate(sel.tolist()):
-                    logprobs_out[i] = logprobs_sel[j]
-        if not self._is_output_rank():
-            return None
+            if self.sampled_dev is None:
+                self.sampled_dev = torch.zeros(self.max_num_reqs, dtype=torch.int32, device=self.device)
+            # every TP rank samples the same token; keep it on the device for the next step
+            self.sampled_dev.index_copy_(0, self._to_dev(rows_sel, torch.int64), tokens)
+            pos_sel = b.num_tokens[rows_sel].copy()
+            b.num_tokens[rows_sel] = pos_sel + 1
+            if self.is_gpu:
+                host_tokens = torch.empty(len(sel), dtype=torch.int32, pin_memory=True)
+                host_tokens.copy_(tokens, non_blocking=True)
+                event = torch.cuda.Event()
+                event.record()
+            else:
+                host_tokens = tokens
         t3 = time.perf_counter()
         timing = {"prepare": t1 - t0, "forward": t2 - t1, "sample": t3 - t2} if self.timing_enabled else None
-        return ModelRunnerOutput(step_id=so.step_id, req_ids=p["req_ids"],
-                                 sampled_token_ids=out_tokens, logprobs=logprobs_out, timing=timing)
+        pending = PendingSample(self, so.step_id, p["req_ids"], sel, rows_sel, pos_sel, host_tokens, event,
+                                logprobs_sel, timing)
+        self._pending.append(pending)
+        if self.defer_output:
+            return pending if self._is_output_rank() else _Discard(pending)
+        out = pending.get()
+        return out if self._is_output_rank() else None
 
     def _overlap_bounds(self, nreq: int):
         """Micro-batch row ranges for all-reduce/compute overlap, or None."""
@@ -339,10 +421,11 @@ class ModelRunner:
         if (self.tp.world_size > 1 and need_lp < 0 and not temps.any() and not b.has_penalty[rows].any()
                 and hasattr(self.model, "compute_greedy_tokens")):
             # all-greedy batch under TP: argmax per vocabulary shard, gather only the winners
-            tokens = self.model.compute_greedy_tokens(hidden)
-            return tokens.to("cpu", torch.int32).numpy(), None
+            return self.model.compute_greedy_tokens(hidden).to(torch.int32), None
         logits = self.model.compute_logits(hidden)
         if b.has_penalty[rows].any():
+            for pend in list(self._pending):      # penalties count every token generated so far
+                pend.get()
             logits = self._apply_penalties(logits.float(), rows)
         if not temps.any():
             tokens = ops.argmax(logits)
@@ -369,8 +452,7 @@ class ModelRunner:
                 for t_id, t_lp in zip((ti_l[j][:k] if ti_l else []), (tv_l[j][:k] if tv_l else [])):
                     d.setdefault(t_id, t_lp)
                 logprobs.append([d])
-        tokens_np = tokens.to("cpu", torch.int32).numpy() if tokens.is_cuda else tokens.to(torch.int32).numpy()
-        return tokens_np, logprobs
+        return tokens.to(torch.int32), logprobs
 
     def _apply_penalties(self, logits: torch.Tensor, rows: np.ndarray) -> torch.Tensor:
         b = self.batch
@@ -510,6 +592,7 @@ class ModelRunner:
         for k in ("input_ids", "positions", "slot_mapping", "seq_lens"):
             s[k][:bs].copy_(st[k][:bs], non_blocking=True)
         s["block_table"][:n, :mb].copy_(st["block_table"][:n, :mb], non_blocking=True)
+        self._patch_unknown_inputs(s["input_ids"], p)
         g.graph.replay()
         return g.output
 
