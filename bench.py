@@ -7,7 +7,7 @@ time-to-first-token for Llama-3-70B bf16, tensor-parallel over N MI355X GPUs.
 
 One "step" is one engine step (scheduler -> executor -> worker forward ->
 sampling -> scheduler update) in which every running sequence produces one
-token.  The batch is 256 sequences per GPU (weak scaling: global batch 256*N,
+token.  The batch is 2048 sequences per GPU (weak scaling: global batch 2048*N,
 TP = N), 128-token synthetic prompts, random-init weights of the real
 architecture, greedy sampling.  Prefill of the whole batch and W decode steps
 are warm-up; exactly K decode steps are timed between barrier+synchronize
@@ -32,7 +32,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--model", type=str, default="llama-3-70b")
-    ap.add_argument("--batch-per-gpu", type=int, default=1024)
+    ap.add_argument("--batch-per-gpu", type=int, default=2048)
     ap.add_argument("--prompt-len", type=int, default=128)
     ap.add_argument("--ttft-requests", type=int, default=5)
     ap.add_argument("--dtype", type=str, default="bfloat16")

@@ -45,7 +45,8 @@ class StepTimer:
         n = max(self.n, 1)
         d = {k + "_ms": 1e3 * v / n for k, v in self.tot.items()}
         d["steps"] = self.n
-        d["rpc_overhead_ms"] = d["execute_ms"] - d["worker_prepare_ms"] - d["worker_forward_ms"] - d["worker_sample_ms"]
+        d["rpc_overhead_ms"] = max(0.0, d["execute_ms"] + d.get("launch_ms", 0.0) - d["worker_prepare_ms"]
+                                   - d["worker_forward_ms"] - d["worker_sample_ms"])
         return d
 
 
@@ -151,7 +152,7 @@ class EngineCore:
             if not so.is_empty or so.finished_req_ids or so.preempted_req_ids:
                 fut = self.executor.execute_model(so, non_block=True)
                 self.batch_queue.append((fut, so))
-                self.timer.add(schedule=t1 - t0)
+                self.timer.add(schedule=t1 - t0, launch=time.perf_counter() - t1)
                 if len(self.batch_queue) < self.max_concurrent and not so.is_empty:
                     return []            # try to put another batch in flight first
         if not self.batch_queue:
@@ -161,7 +162,13 @@ class EngineCore:
         out = fut.result()
         t1 = time.perf_counter()
         res = self.scheduler.update_from_output(so, out)
-        self.timer.tot["execute"] += t1 - t0
+        t2 = time.perf_counter()
+        wt = (out.timing if out is not None else None) or {}
+        tot = self.timer.tot
+        tot["execute"] += t1 - t0           # time blocked waiting for the oldest in-flight step
+        tot["update"] += t2 - t1
+        for k in ("prepare", "forward", "sample"):
+            tot["worker_" + k] += wt.get(k, 0.0)
         return res
 
     # ----------------------------------------------------------------- admin
