@@ -127,14 +127,15 @@ class LLMEngine:
                         st.cumulative_logprob = (st.cumulative_logprob or 0.0) + lp[tok]
             finished = finish_reason is not None
             new_text = st.detok.take_delta(finished) if st.detok is not None else ""
+            # the live list while the request runs (no per-step copy); a snapshot once it is final
             comp = CompletionOutput(index=0, text=st.detok.text if st.detok is not None else "",
-                                    token_ids=list(req.output_token_ids),
+                                    token_ids=list(req.output_token_ids) if finished else req.output_token_ids,
                                     cumulative_logprob=st.cumulative_logprob, logprobs=st.logprobs,
                                     finish_reason=finish_reason, stop_reason=stop_reason)
             outs.append(RequestOutput(request_id=co.request_id, prompt=st.prompt,
                                       prompt_token_ids=req.prompt_token_ids, outputs=[comp],
                                       finished=finished, metrics=req.metrics,
-                                      new_token_ids=list(co.new_token_ids), new_text=new_text))
+                                      new_token_ids=co.new_token_ids, new_text=new_text))
             if finished:
                 if req.metrics.finished_time is None:
                     req.metrics.finished_time = time.time()

@@ -29,6 +29,9 @@ from .types import (CachedRequestData, ModelRunnerOutput, NewRequestData, Schedu
 logger = init_logger(__name__)
 
 
+_NO_BLOCKS: List[int] = []
+
+
 @dataclass
 class EngineCoreOutput:
     request_id: str
@@ -135,6 +138,7 @@ class Scheduler:
         cached = CachedRequestData()
         preempted: List[Request] = []
         now = time.time()
+        req_blocks, block_size = self.kv.req_blocks, self.kv.block_size
 
         # 1. running requests
         for req in list(self.running):
@@ -153,7 +157,11 @@ class Scheduler:
             n = min(n, self.max_model_len - req.num_computed_tokens)
             if n <= 0:
                 continue
-            new_blocks = self.kv.allocate_slots(req, n)
+            held = req_blocks.get(req.request_id)
+            if held is not None and req.num_computed_tokens + n <= len(held) * block_size:
+                new_blocks = _NO_BLOCKS          # the common decode step: room left in the last block
+            else:
+                new_blocks = self.kv.allocate_slots(req, n)
             while new_blocks is None:
                 victim = self._pick_victim(exclude_scheduled=num_scheduled)
                 if victim is None:
@@ -279,41 +287,72 @@ class Scheduler:
     # ------------------------------------------------------------ post-step
     def update_from_output(self, scheduler_output: SchedulerOutput,
                            runner_output: ModelRunnerOutput) -> List[EngineCoreOutput]:
+        """Fold one step's sampled tokens into the requests.  This loop runs once
+        per running request per step, so the common case (one token, no stop)
+        is kept free of helper calls."""
         outputs: List[EngineCoreOutput] = []
-        sampled = dict(zip(runner_output.req_ids, runner_output.sampled_token_ids))
-        lps = dict(zip(runner_output.req_ids, runner_output.logprobs)) if runner_output.logprobs else {}
+        if runner_output is None:
+            return outputs
+        lps = dict(zip(runner_output.req_ids, runner_output.logprobs)) if runner_output.logprobs else None
         now = time.time()
-        for rid, n_sched in scheduler_output.num_scheduled_tokens.items():
-            req = self.requests.get(rid)
-            if req is None or req.finished or req.status != RequestStatus.RUNNING:
-                continue             # aborted / preempted while in flight
-            new_tokens = sampled.get(rid) or []
-            if new_tokens and req.num_output_placeholders:
+        requests = self.requests
+        scheduled = scheduler_output.num_scheduled_tokens
+        caching = self.kv.enable_caching
+        fwd_tokens = self.include_new_token_ids
+        running_state = RequestStatus.RUNNING
+        max_len = self.max_model_len
+        any_finished = False
+        for rid, new_tokens in zip(runner_output.req_ids, runner_output.sampled_token_ids):
+            req = requests.get(rid)
+            if req is None or req.status != running_state or rid not in scheduled:
+                continue             # aborted / preempted / finished while in flight
+            if caching:              # blocks that are now full and fully known can be shared
+                self.kv.cache_blocks(req, req.num_computed_tokens)
+            if not new_tokens:
+                continue             # partial prefill: nothing sampled
+            if req.num_output_placeholders:
                 req.num_output_placeholders = max(0, req.num_output_placeholders - len(new_tokens))
-            accepted: List[int] = []
-            for tok in new_tokens:
-                req.append_output_token(tok)
-                accepted.append(tok)
-                if self._check_stop(req, tok):
+            sp = req.sampling_params
+            out_ids, all_ids = req.output_token_ids, req.all_token_ids
+            accepted = new_tokens
+            for i, tok in enumerate(new_tokens):
+                out_ids.append(tok)
+                all_ids.append(tok)
+                n_out = len(out_ids)
+                stop = False
+                if n_out >= sp.min_tokens:
+                    if (not sp.ignore_eos and tok == req.eos_token_id and req.eos_token_id is not None):
+                        req.status = RequestStatus.FINISHED_STOPPED
+                        stop = True
+                    elif sp.stop_token_ids and tok in sp.stop_token_ids:
+                        req.status = RequestStatus.FINISHED_STOPPED
+                        req.stop_reason = tok
+                        stop = True
+                if not stop and ((req.max_tokens is not None and n_out >= req.max_tokens)
+                                 or len(all_ids) >= max_len):
+                    req.status = RequestStatus.FINISHED_LENGTH
+                    stop = True
+                if stop:
+                    accepted = new_tokens[:i + 1]
                     break
-            # blocks that are now full and fully known can be shared
-            self.kv.cache_blocks(req, req.num_computed_tokens)
-            if accepted:
-                if req.metrics.first_token_time is None:
-                    req.metrics.first_token_time = now
-                req.metrics.num_generation_tokens = req.num_output_tokens
-                if self.include_new_token_ids and not req.finished:
-                    self._pending_new_tokens.setdefault(rid, []).extend(accepted)
-                req_lps = lps.get(rid)
-                outputs.append(EngineCoreOutput(
-                    request_id=rid, new_token_ids=accepted,
-                    finish_reason=req.status.finish_reason, stop_reason=req.stop_reason,
-                    logprobs=req_lps[:len(accepted)] if req_lps else None,
-                    num_cached_tokens=max(req.num_cached_tokens, 0)))
-            if req.finished:
-                req.metrics.finished_time = now
-                self.running.remove(req)
+            m = req.metrics
+            if m.first_token_time is None:
+                m.first_token_time = now
+            m.num_generation_tokens = len(out_ids)
+            finished = req.status != running_state
+            if fwd_tokens and not finished:
+                self._pending_new_tokens.setdefault(rid, []).extend(accepted)
+            req_lps = lps.get(rid) if lps else None
+            outputs.append(EngineCoreOutput(
+                rid, accepted, req.status.finish_reason if finished else None, req.stop_reason,
+                req_lps[:len(accepted)] if req_lps else None,
+                req.num_cached_tokens if req.num_cached_tokens > 0 else 0))
+            if finished:
+                m.finished_time = now
+                any_finished = True
                 self._free_request(req)
+        if any_finished:             # one pass instead of a list.remove per request
+            self.running = [r for r in self.running if r.status == running_state]
         return outputs
 
     def _check_stop(self, req: Request, tok: int) -> bool:
