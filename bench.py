@@ -40,6 +40,7 @@ def main() -> None:
     ap.add_argument("--executor", type=str, default="auto", choices=["auto", "uni", "spmd"])
     ap.add_argument("--sync-scheduling", action="store_true",
                     help="schedule each step only after the previous step's tokens reached the host")
+    ap.add_argument("--gpu-memory-utilization", type=float, default=0.92)
     ap.add_argument("--device", type=str, default="cuda", choices=["cuda", "cpu"],
                     help="cpu = gloo rehearsal of the multi-rank path with a tiny model (not a measurement)")
     args = ap.parse_args()
@@ -73,7 +74,7 @@ def main() -> None:
         distributed_executor_backend=backend, max_model_len=max_len, max_num_seqs=batch,
         max_num_batched_tokens=max(16384, batch), enable_prefix_caching=False,
         enforce_eager=args.enforce_eager, max_capture_size=batch, hip_graph_sizes=[batch],
-        gpu_memory_utilization=0.92, seed=0, async_scheduling=not args.sync_scheduling))
+        gpu_memory_utilization=args.gpu_memory_utilization, seed=0, async_scheduling=not args.sync_scheduling))
     vocab = engine.model_config.vocab_size
     rng = np.random.default_rng(1234)
 
@@ -130,18 +131,21 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     assert produced == batch * args.steps, (produced, batch, args.steps)
     if dist.is_initialized():
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cuda" if on_gpu and dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if rank == 0:
         runner = engine.core.executor.driver.worker.model_runner
         tps = batch * args.steps / elapsed
+        dt = {"bfloat16": "bf16", "float16": "fp16", "float32": "fp32"}[args.dtype]
+        pretty = {"llama-3-70b": "Llama-3-70B", "llama-3-8b": "Llama-3-8B"}.get(args.model, args.model)
         print(json.dumps({
-            "metric": "output tokens/sec (whole node), Llama-3-70B bf16 TP over N GPUs, decode",
+            "metric": f"output tokens/sec (whole node), {pretty} {dt} TP over N GPUs, decode",
             "value": round(tps, 2), "unit": "tokens/s", "n_gpus": n, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"bfloat16": "bf16", "float16": "fp16", "float32": "fp32"}[args.dtype],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dt,
             "data": "synthetic prompts (random token ids), random-init weights",
             "ttft_p50_ms": None if ttft_p50_ms is None else round(ttft_p50_ms, 2),
             "prefill_tokens_per_s": round(batch * args.prompt_len / prefill_s, 1),

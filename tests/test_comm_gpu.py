@@ -144,3 +144,59 @@ def test_nccl_process_group_bringup_calls_on_one_rank():
     p = subprocess.run([sys.executable, "-c", NCCL_SCRIPT.format(root=ROOT)], env=env, capture_output=True,
                        text=True, timeout=110)
     assert p.returncode == 0 and "RESULT ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
+SPMD_SCRIPT = r"""
+import json, os, sys
+sys.path.insert(0, {root!r})
+from vllm_distributed_amd import SamplingParams
+from vllm_distributed_amd.engine.arg_utils import EngineArgs
+from vllm_distributed_amd.engine.llm_engine import LLMEngine
+tp = int(os.environ.get("WORLD_SIZE", "1"))
+eng = LLMEngine.from_engine_args(EngineArgs(
+    model="llama-tiny", device="cuda", dtype="bfloat16", max_model_len=256, num_gpu_blocks_override=64,
+    max_num_seqs=8, tensor_parallel_size=tp, distributed_executor_backend="spmd" if tp > 1 else "uni",
+    async_scheduling=os.environ.get("ASYNC") == "1", gpu_memory_utilization=0.2))
+g = SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True)
+ids = [eng.add_request(None, p, g) for p in ([5, 9, 200, 17], list(range(10, 90)), [7, 7])]
+final = {{}}
+while eng.has_unfinished_requests():
+    for o in eng.step():
+        if o.finished:
+            final[o.request_id] = o.outputs[0].token_ids
+from vllm_distributed_amd.parallel import state as pstate
+print("RESULT " + json.dumps(dict(tokens=[final[i] for i in ids],
+                                  direct_ar=pstate.get_tp_group().custom_ar is not None)), flush=True)
+eng.shutdown()
+"""
+
+
+def _run_spmd_shared(world, async_sched):
+    port = get_open_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), VLLM_LOGGING_LEVEL="WARNING", GLOO_SOCKET_IFNAME="lo",
+                   VDAMD_SHARE_DEVICE="1", ASYNC="1" if async_sched else "0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", SPMD_SCRIPT.format(root=ROOT)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        so, _ = p.communicate(timeout=110)
+        assert p.returncode == 0, so[-3000:]
+        line = [l for l in so.splitlines() if l.startswith("RESULT ")][-1]
+        outs.append(json.loads(line[len("RESULT "):]))
+    return outs
+
+
+def test_spmd_tensor_parallel_ranks_sharing_one_gpu_match_single_rank():
+    """The multi-rank GPU path end to end (SPMD executor, sharded HIP-kernel
+    model, peer-mapped all-reduce, vocab-parallel argmax) with ranks mapped
+    onto one device.  bf16 partial sums are reduced in a different order than
+    the unsharded GEMM, so the first tokens (largest margins) are compared."""
+    ref = _run_spmd_shared(1, False)[0]["tokens"]
+    for async_sched in (False, True):
+        got = _run_spmd_shared(2, async_sched)
+        assert got[0]["tokens"] == got[1]["tokens"]
+        assert got[0]["direct_ar"] and got[1]["direct_ar"]
+        assert [t[:2] for t in got[0]["tokens"]] == [t[:2] for t in ref]

@@ -80,6 +80,10 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     # "auto" (TP>1 and batch >= MIN_BATCH), "0" (off), "force" (also at TP=1; tests).
     "VDAMD_TP_OVERLAP": _str("VDAMD_TP_OVERLAP", "auto"),
     "VDAMD_TP_OVERLAP_MIN_BATCH": _int("VDAMD_TP_OVERLAP_MIN_BATCH", 512),
+    # Rehearsal of multi-rank GPU paths on fewer devices than ranks: ranks are
+    # mapped round-robin onto the visible devices and torch.distributed runs on
+    # gloo with host staging (RCCL refuses two ranks on one device).
+    "VDAMD_SHARE_DEVICE": _bool("VDAMD_SHARE_DEVICE", False),
     # Capture decode steps in hipGraphs.
     "VDAMD_USE_HIP_GRAPH": _bool("VDAMD_USE_HIP_GRAPH", True),
     # Assert identical collective sequence numbers on all ranks (debug).

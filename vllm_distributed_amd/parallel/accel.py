@@ -28,7 +28,7 @@ def _verify_all_reduce(group: GroupCoordinator, fn) -> bool:
         x = torch.arange(4096, dtype=torch.float32, device=group.device) * (group.rank_in_group + 1)
         x = x.to(torch.bfloat16)
         ref = x.clone()
-        dist.all_reduce(ref, group=group.device_group)
+        group._td_all_reduce(ref)
         out = fn(x.clone())
         torch.cuda.synchronize()
         return out is not None and torch.allclose(out.float(), ref.float(), rtol=2e-2, atol=1e-1)
@@ -43,7 +43,7 @@ def attach_accelerated_collectives(pc: ParallelConfig) -> None:
         if group.world_size == 1:
             continue
         # ---- direct RCCL binding (graph-capturable plain kernel enqueues)
-        if backend in ("auto", "rccl"):
+        if backend in ("auto", "rccl") and not group.staged:
             comm = None
             try:
                 from .rccl import RcclCommunicator

@@ -71,6 +71,10 @@ class GroupCoordinator:
         # optional accelerated paths, attached by the worker on GPU
         self.rccl = None              # parallel.rccl.RcclCommunicator
         self.custom_ar = None         # parallel.custom_all_reduce.CustomAllReduce
+        # gloo carrying GPU tensors: stage through the host (gloo itself only
+        # implements a few collectives for device tensors)
+        self.staged = (device.type == "cuda" and device_group is not None
+                       and dist.get_backend(device_group) == "gloo")
 
     # ---------------------------------------------------------------- helpers
     @property
@@ -102,6 +106,31 @@ class GroupCoordinator:
             self.checker.record(op, t.numel())
             self.checker.verify(self)
 
+    # torch.distributed calls, host-staged when gloo carries device tensors
+    def _td_all_reduce(self, x: torch.Tensor) -> None:
+        if self.staged and x.is_cuda:
+            h = x.cpu()
+            dist.all_reduce(h, group=self.device_group)
+            x.copy_(h)
+        else:
+            dist.all_reduce(x, group=self.device_group)
+
+    def _td_all_gather(self, flat: torch.Tensor, x: torch.Tensor) -> None:
+        if self.staged and x.is_cuda:
+            h = torch.empty(flat.shape, dtype=flat.dtype)
+            dist.all_gather_into_tensor(h, x.cpu(), group=self.device_group)
+            flat.copy_(h)
+        else:
+            dist.all_gather_into_tensor(flat, x, group=self.device_group)
+
+    def _td_broadcast(self, x: torch.Tensor, src_global: int) -> None:
+        if self.staged and x.is_cuda:
+            h = x.cpu()
+            dist.broadcast(h, src=src_global, group=self.device_group)
+            x.copy_(h)
+        else:
+            dist.broadcast(x, src=src_global, group=self.device_group)
+
     # ------------------------------------------------------------ collectives
     def all_reduce(self, x: torch.Tensor) -> torch.Tensor:
         """Sum over the group.  May return a new tensor (direct all-reduce) or
@@ -116,7 +145,7 @@ class GroupCoordinator:
         if self.rccl is not None:
             self.rccl.all_reduce(x)
             return x
-        dist.all_reduce(x, group=self.device_group)
+        self._td_all_reduce(x)
         return x
 
     def all_reduce_(self, x: torch.Tensor) -> torch.Tensor:
@@ -127,7 +156,7 @@ class GroupCoordinator:
         if self.rccl is not None:
             self.rccl.all_reduce(x)
         else:
-            dist.all_reduce(x, group=self.device_group)
+            self._td_all_reduce(x)
         return x
 
     def all_gather(self, x: torch.Tensor, dim: int = -1) -> torch.Tensor:
@@ -146,7 +175,7 @@ class GroupCoordinator:
         if self.rccl is not None:
             self.rccl.all_gather(flat, x)
         else:
-            dist.all_gather_into_tensor(flat, x, group=self.device_group)
+            self._td_all_gather(flat, x)
         if dim == 0:
             return flat
         out = flat.view((self.world_size,) + tuple(x.shape)).movedim(0, dim)
@@ -162,7 +191,7 @@ class GroupCoordinator:
         if self.rccl is not None:
             self.rccl.broadcast(x, src)
         else:
-            dist.broadcast(x, src=self.ranks[src], group=self.device_group)
+            self._td_broadcast(x, self.ranks[src])
         return x
 
     def send(self, x: torch.Tensor, dst: Optional[int] = None) -> None:
@@ -172,7 +201,8 @@ class GroupCoordinator:
         if self.rccl is not None:
             self.rccl.send(x.contiguous(), dst)
         else:
-            dist.send(x.contiguous(), dst=self.ranks[dst], group=self.device_group)
+            x = x.cpu() if self.staged else x.contiguous()
+            dist.send(x, dst=self.ranks[dst], group=self.device_group)
 
     def recv(self, shape: Sequence[int], dtype: torch.dtype, src: Optional[int] = None) -> torch.Tensor:
         src = (self.rank_in_group - 1) % self.world_size if src is None else src
@@ -180,6 +210,10 @@ class GroupCoordinator:
         self._note("recv", x)
         if self.rccl is not None:
             self.rccl.recv(x, src)
+        elif self.staged and x.is_cuda:
+            h = torch.empty(x.shape, dtype=dtype)
+            dist.recv(h, src=self.ranks[src], group=self.device_group)
+            x.copy_(h)
         else:
             dist.recv(x, src=self.ranks[src], group=self.device_group)
         return x

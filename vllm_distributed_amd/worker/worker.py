@@ -58,9 +58,11 @@ class Worker:
         dev_type = self.vllm_config.device_config.device
         if dev_type == "cuda":
             # one process per GPU; local_rank indexes the *visible* devices
-            torch.cuda.set_device(self.local_rank)
-            self.device = torch.device(f"cuda:{self.local_rank}")
-            backend = "nccl"      # RCCL on ROCm
+            index, backend = self.local_rank, "nccl"      # RCCL on ROCm
+            if envs.VDAMD_SHARE_DEVICE:
+                index, backend = self.local_rank % torch.cuda.device_count(), "gloo"
+            torch.cuda.set_device(index)
+            self.device = torch.device(f"cuda:{index}")
             gc.collect()
             torch.cuda.empty_cache()
             self.init_free, self.init_total = torch.cuda.mem_get_info()
