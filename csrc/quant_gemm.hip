@@ -1,0 +1,281 @@
+// Weight-only 4-bit (W4A16) linear layers for gfx950.
+//
+// Weights live in an MFMA-operand-native layout produced once at load time
+// (ops/quant.py: pack_w4): for output tile nt (16 rows) and K block kb (128
+// columns) the 1 KiB tile qw[nt][kb][lane][4] holds, for lane = c + 16*g, the
+// four words of row n = 16*nt + c covering k = 128*kb + 32*g + 8*s + e
+// (s = word, e = 0..7).  Element e sits in nibble (e>>1) + 4*(e&1), so
+// (w >> 4*i) & 0x000F000F isolates elements (2i, 2i+1) in the two halves of a
+// dword and OR-ing the exponent of 128.0 (bf16) / 1024.0 (fp16) turns them into
+// a packed pair holding OFF + q exactly - one shift and one and-or per two
+// weights, no integer->float conversion.  A wave's 16-byte-per-lane load of a
+// tile is one fully coalesced 1 KiB read and is directly the A operand of four
+// 16x16x32 MFMAs.
+//
+// Zero points and scales are applied to the fp32 group sums, not per weight:
+//   y[m][n] = sum_g s[n][g] * ( P_g[n][m] - (OFF + z[n][g]) * X_g[m] )
+// with P_g = sum_{k in g} (OFF + q[n][k]) x[m][k]  (MFMA) and
+//      X_g = sum_{k in g} x[m][k]                  (one MFMA against ones).
+// sz[nt][group][16][2] holds (s, OFF + z) per row in the activation dtype.
+#include "common.h"
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct W4Magic;
+template <> struct W4Magic<bf16_t> { static constexpr uint32_t OR = 0x43004300u; static constexpr float OFF = 128.f; };
+template <> struct W4Magic<f16_t> { static constexpr uint32_t OR = 0x64006400u; static constexpr float OFF = 1024.f; };
+
+template <typename T>
+__device__ __forceinline__ typename Vec8<T>::type w4_unpack(uint32_t w) {
+  union { uint32_t u[4]; typename Vec8<T>::type v; } r;
+  r.u[0] = (w & 0x000F000Fu) | W4Magic<T>::OR;
+  r.u[1] = ((w >> 4) & 0x000F000Fu) | W4Magic<T>::OR;
+  r.u[2] = ((w >> 8) & 0x000F000Fu) | W4Magic<T>::OR;
+  r.u[3] = ((w >> 12) & 0x000F000Fu) | W4Magic<T>::OR;
+  return r.v;
+}
+
+constexpr int W4_NTW = 4;          // output tiles (16 rows each) per wave
+constexpr int W4_WAVES = 4;        // waves per workgroup; they split the K range
+
+// grid = (ceil(N/64), ksplit, ceil(M / (16*MT))), block = 256.
+template <typename T, int MT>
+__global__ __launch_bounds__(256) void w4a16_gemm_kernel(
+    const T* __restrict__ x, long x_stride, const uint32_t* __restrict__ qw, const T* __restrict__ sz,
+    T* __restrict__ out, long out_stride, float* __restrict__ partial, int M, int N, int K,
+    int kb_per_group, int ksplit) {
+  using V8 = typename Vec8<T>::type;
+  constexpr bool PREFETCH_X = MT <= 2;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int KB = K >> 7, ntiles = N >> 4, NG = KB / kb_per_group;
+  const int nt0 = blockIdx.x * W4_NTW;
+  const int ks = blockIdx.y;
+  const int kb_lo = (int)((long)KB * ks / ksplit), kb_hi = (int)((long)KB * (ks + 1) / ksplit);
+  const int span = kb_hi - kb_lo;
+  const int w_lo = kb_lo + span * wid / W4_WAVES, w_hi = kb_lo + span * (wid + 1) / W4_WAVES;
+  const int m0 = blockIdx.z * (16 * MT);
+
+  // tiles past the end are computed on a clamped index and discarded
+  int ntc[W4_NTW];
+#pragma unroll
+  for (int t = 0; t < W4_NTW; ++t) ntc[t] = min(nt0 + t, ntiles - 1);
+  const T* xrow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = min(m0 + 16 * mt + c, M - 1);
+    xrow[mt] = x + (long)row * x_stride + 32 * g;
+  }
+
+  f32x4 acc[W4_NTW][MT];
+#pragma unroll
+  for (int t = 0; t < W4_NTW; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  V8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (T)1.0f;
+
+  auto load_w = [&](int kb, u32x4 (&w)[W4_NTW], V8 (&s)[W4_NTW]) {
+#pragma unroll
+    for (int t = 0; t < W4_NTW; ++t) {
+      w[t] = *reinterpret_cast<const u32x4*>(qw + (((size_t)ntc[t] * KB + kb) << 8) + lane * 4);
+      s[t] = ld8(sz + ((((size_t)ntc[t] * NG + kb / kb_per_group) * 16 + 4 * g) << 1));
+    }
+  };
+  auto load_x = [&](int kb, V8 (&bx)[MT][4]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bx[mt][s] = ld8(xrow[mt] + (kb << 7) + 8 * s);
+  };
+
+  u32x4 wc[W4_NTW], wn[W4_NTW];
+  V8 sc[W4_NTW], sn[W4_NTW];
+  V8 bxc[MT][4], bxn[MT][4];
+  if (w_lo < w_hi) {
+    load_w(w_lo, wc, sc);
+    load_x(w_lo, bxc);
+  }
+  for (int kb = w_lo; kb < w_hi; ++kb) {
+    const bool more = kb + 1 < w_hi;
+    if (more) {
+      load_w(kb + 1, wn, sn);
+      if (PREFETCH_X) load_x(kb + 1, bxn);
+    }
+    f32x4 xs[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      xs[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) xs[mt] = mfma16(ones, bxc[mt][s], xs[mt]);
+    }
+#pragma unroll
+    for (int t = 0; t < W4_NTW; ++t) {
+      f32x4 p[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) p[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const V8 a = w4_unpack<T>(wc[t][s]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) p[mt] = mfma16(a, bxc[mt][s], p[mt]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s_r = (float)sc[t][2 * r], z_r = (float)sc[t][2 * r + 1];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[t][mt][r] += s_r * (p[mt][r] - z_r * xs[mt][r]);
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int t = 0; t < W4_NTW; ++t) { wc[t] = wn[t]; sc[t] = sn[t]; }
+      if (PREFETCH_X) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) bxc[mt][s] = bxn[mt][s];
+      } else {
+        load_x(kb + 1, bxc);
+      }
+    }
+  }
+
+  // cross-wave reduction: wave w ends up owning tile w
+  __shared__ float red[W4_WAVES - 1][W4_NTW][MT * 4][64];
+#pragma unroll
+  for (int t = 0; t < W4_NTW; ++t) {
+    if (t == wid) continue;
+    const int slot = ((wid - t + W4_WAVES) % W4_WAVES) - 1;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[slot][t][mt * 4 + r][lane] = acc[t][mt][r];
+  }
+  __syncthreads();
+  f32x4 res[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    res[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < W4_NTW; ++t)
+      if (t == wid) res[mt] = acc[t][mt];
+#pragma unroll
+    for (int slot = 0; slot < W4_WAVES - 1; ++slot)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) res[mt][r] += red[slot][wid][mt * 4 + r][lane];
+  }
+  const int nt = nt0 + wid;
+  if (nt >= ntiles) return;
+  const int n = 16 * nt + 4 * g;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + 16 * mt + c;
+    if (m >= M) continue;
+    if (ksplit == 1) {
+      typename Vec4<T>::type o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (T)res[mt][r];
+      *reinterpret_cast<typename Vec4<T>::type*>(out + (long)m * out_stride + n) = o;
+    } else {
+      *reinterpret_cast<f32x4*>(partial + ((size_t)ks * M + m) * N + n) = res[mt];
+    }
+  }
+}
+
+// out[m][n] = sum_ks partial[ks][m][n]; one thread per 4 outputs
+template <typename T>
+__global__ void w4a16_reduce_kernel(T* __restrict__ out, long out_stride, const float* __restrict__ partial,
+                                    int M, int N, int ksplit) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n4 = N >> 2;
+  if (idx >= (long)M * n4) return;
+  const int m = (int)(idx / n4), n = (int)(idx % n4) * 4;
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < ksplit; ++k) s += *reinterpret_cast<const f32x4*>(partial + ((size_t)k * M + m) * N + n);
+  typename Vec4<T>::type o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = (T)s[r];
+  *reinterpret_cast<typename Vec4<T>::type*>(out + (long)m * out_stride + n) = o;
+}
+
+// native 4-bit -> dense [N][K]; one workgroup per 16x128 tile, thread = (row, word)
+template <typename T>
+__global__ __launch_bounds__(256) void w4_dequant_kernel(T* __restrict__ out, const uint32_t* __restrict__ qw,
+                                                         const T* __restrict__ sz, int N, int K,
+                                                         int kb_per_group) {
+  const int KB = K >> 7, NG = KB / kb_per_group;
+  const int tile = blockIdx.x;
+  const int nt = tile / KB, kb = tile % KB;
+  const int kk = threadIdx.x & 15, row = threadIdx.x >> 4;      // word along K, row in tile
+  const int lane = row + 16 * (kk >> 2), word = kk & 3;
+  const uint32_t w = qw[((size_t)tile << 8) + lane * 4 + word];
+  const T* szp = sz + ((((size_t)nt * NG + kb / kb_per_group) * 16 + row) << 1);
+  const float s = (float)szp[0], z = (float)szp[1] - W4Magic<T>::OFF;
+  typename Vec8<T>::type o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[2 * i] = (T)(((float)((w >> (4 * i)) & 0xF) - z) * s);
+    o[2 * i + 1] = (T)(((float)((w >> (16 + 4 * i)) & 0xF) - z) * s);
+  }
+  st8(out + (size_t)(16 * nt + row) * K + (kb << 7) + 8 * kk, o);
+}
+
+template <typename T>
+static int launch_w4a16(void* out, long out_stride, const void* x, long x_stride, const void* qw,
+                        const void* sz, void* partial, int M, int N, int K, int G, int ksplit,
+                        hipStream_t st) {
+  const int mt = min(4, (M + 15) / 16);
+  dim3 grid((N / 16 + W4_NTW - 1) / W4_NTW, ksplit, (M + 16 * mt - 1) / (16 * mt));
+#define W4_LAUNCH(MT_)                                                                                   \
+  w4a16_gemm_kernel<T, MT_><<<grid, 256, 0, st>>>((const T*)x, x_stride, (const uint32_t*)qw,           \
+                                                   (const T*)sz, (T*)out, out_stride, (float*)partial,  \
+                                                   M, N, K, G / 128, ksplit)
+  switch (mt) {
+    case 1: W4_LAUNCH(1); break;
+    case 2: W4_LAUNCH(2); break;
+    case 3: W4_LAUNCH(3); break;
+    default: W4_LAUNCH(4); break;
+  }
+#undef W4_LAUNCH
+  HIP_LAUNCH_CHECK();
+  if (ksplit > 1) {
+    const long n = (long)M * (N / 4);
+    w4a16_reduce_kernel<T><<<(unsigned)((n + 255) / 256), 256, 0, st>>>((T*)out, out_stride,
+                                                                        (const float*)partial, M, N, ksplit);
+    HIP_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// y[M][N] = x[M][K] . dequant(qw, sz)^T.  Requires K % 128 == 0, N % 16 == 0,
+// G % 128 == 0, K % G == 0, 1 <= ksplit <= K/128; `partial` holds ksplit*M*N
+// floats when ksplit > 1.
+VDAMD_API int vdamd_w4a16_gemm(void* out, long out_stride, const void* x, long x_stride, const void* qw,
+                               const void* sz, void* partial, int M, int N, int K, int G, int ksplit,
+                               int dtype, void* stream) {
+  if (M <= 0) return 0;
+  if (K % 128 || N % 16 || G % 128 || K % G || ksplit < 1 || ksplit > K / 128) return -1;
+  if (ksplit > 1 && partial == nullptr) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) return launch_w4a16<bf16_t>(out, out_stride, x, x_stride, qw, sz, partial, M, N, K, G, ksplit, st);
+  if (dtype == DT_F16) return launch_w4a16<f16_t>(out, out_stride, x, x_stride, qw, sz, partial, M, N, K, G, ksplit, st);
+  return -3;
+}
+
+VDAMD_API int vdamd_w4_dequant(void* out, const void* qw, const void* sz, int N, int K, int G, int dtype,
+                               void* stream) {
+  if (K % 128 || N % 16 || G % 128 || K % G) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned tiles = (unsigned)((N / 16) * (K / 128));
+  if (dtype == DT_BF16)
+    w4_dequant_kernel<bf16_t><<<tiles, 256, 0, st>>>((bf16_t*)out, (const uint32_t*)qw, (const bf16_t*)sz, N, K, G / 128);
+  else if (dtype == DT_F16)
+    w4_dequant_kernel<f16_t><<<tiles, 256, 0, st>>>((f16_t*)out, (const uint32_t*)qw, (const f16_t*)sz, N, K, G / 128);
+  else
+    return -3;
+  HIP_LAUNCH_CHECK();
+  return 0;
+}

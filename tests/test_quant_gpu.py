@@ -1,0 +1,91 @@
+"""W4A16 kernels (csrc/quant_gemm.hip) against the fp32 definition of the
+packed layout (ops/quant.py), and an AWQ model end to end on the GPU."""
+import pytest
+import torch
+
+from vllm_distributed_amd import ops
+from vllm_distributed_amd.ops import quant
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _packed(n, k, g, dtype, seed=0):
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    q = torch.randint(0, 16, (n, k), generator=gen, dtype=torch.uint8)
+    z = torch.randint(0, 16, (n, k // g), generator=gen).float()
+    s = (0.5 + torch.rand((n, k // g), generator=gen)) * 0.01
+    qw, sz = quant.pack_w4(q, z, s, dtype)
+    return qw.to(DEV), sz.to(DEV)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n,k,g", [(256, 512, 128), (1040, 1024, 128), (1280, 8192, 128), (512, 1024, 256)])
+@pytest.mark.parametrize("m", [1, 7, 16, 33, 64, 130, 256])
+def test_w4a16_gemm_matches_definition(dtype, n, k, g, m):
+    qw, sz = _packed(n, k, g, dtype, seed=n + k + m)
+    x = torch.randn(m, k, device=DEV, dtype=dtype)
+    ops.hip_available()
+    from vllm_distributed_amd.ops import hip
+    y = hip.w4a16_gemm(x, qw, sz)
+    torch.cuda.synchronize()
+    w = quant.w4_dequant(qw, sz)                         # fp32, exact (q - z) * s
+    ref = x.float() @ w.t()
+    scale = ref.abs().max().item()
+    # fp32 accumulation; only the output rounding to 16-bit separates the two
+    tol = scale * (2 ** -7 if dtype == torch.bfloat16 else 2 ** -9)
+    assert (y.float() - ref).abs().max().item() <= tol
+    # exact zero beyond M must not be touched: output has exactly m rows
+    assert y.shape == (m, n)
+
+
+def test_w4a16_gemm_strided_rows_and_forced_splits():
+    from vllm_distributed_amd.ops import hip
+    ops.hip_available()
+    qw, sz = _packed(512, 2048, 128, torch.bfloat16)
+    big = torch.randn(20, 4096, device=DEV, dtype=torch.bfloat16)
+    x = big[:, 1024:3072]                                # row stride 4096, 16-byte aligned offset
+    y = hip.w4a16_gemm(x, qw, sz)
+    ref = x.float() @ quant.w4_dequant(qw, sz).t()
+    assert (y.float() - ref).abs().max().item() <= ref.abs().max().item() * 2 ** -7
+    assert hip.w4_choose_ksplit(16, 512, 2048) > 1 and hip.w4_choose_ksplit(16, 65536, 2048) == 1
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_w4_dequant_and_large_batch_path(dtype):
+    from vllm_distributed_amd.ops import hip
+    ops.hip_available()
+    qw, sz = _packed(768, 1024, 128, dtype)
+    w = hip.w4_dequant(qw, sz)
+    ref = quant.w4_dequant(qw, sz)
+    assert torch.equal(w.float(), ref.to(dtype).float())
+    x = torch.randn(hip.W4_MAX_FUSED_M + 44, 1024, device=DEV, dtype=dtype)
+    bias = torch.randn(768, device=DEV, dtype=dtype)
+    y = ops.w4a16_linear(x, qw, sz, bias)
+    want = x.float() @ ref.t() + bias.float()
+    assert (y.float() - want).abs().max().item() <= want.abs().max().item() * 2 ** -6
+
+
+def test_awq_model_on_gpu_matches_dequantised_model():
+    """Packed 4-bit execution against the same checkpoint dequantised to
+    bf16 at load: the two differ only by bf16 rounding of the weights, so the
+    prompt logits must agree closely and greedy decoding must start the same."""
+    from vllm_distributed_amd import LLM, SamplingParams
+    from vllm_distributed_amd.parallel import state as pstate
+    outs = {}
+    for q in ("awq", "awq-dequant"):
+        llm = LLM(model="llama-tiny", dtype="bfloat16", max_model_len=256, num_gpu_blocks_override=64,
+                  max_num_seqs=8, quantization=q, gpu_memory_utilization=0.3)
+        model = llm.engine.core.executor.driver.worker.model_runner.model
+        layer = next(iter(model.layers.values()))
+        assert (layer.self_attn.qkv_proj.qw is not None) == (q == "awq")
+        o = llm.generate([[5, 9, 200, 17], list(range(10, 90))],
+                         SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True, logprobs=3))
+        outs[q] = o
+        llm.shutdown()
+        pstate.destroy_model_parallel()
+    for a, b in zip(outs["awq"], outs["awq-dequant"]):
+        assert a.outputs[0].token_ids[:2] == b.outputs[0].token_ids[:2]
+        la, lb = a.outputs[0].logprobs[0], b.outputs[0].logprobs[0]
+        t = a.outputs[0].token_ids[0]
+        assert abs(la[t] - lb[t]) < 0.05

@@ -96,7 +96,8 @@ class ModelConfig:
     seed: int = 0
     max_model_len: Optional[int] = None
     load_format: str = "auto"          # auto|safetensors|dummy
-    quantization: Optional[str] = None  # None|awq
+    # None | awq (4-bit weights stay packed, W4A16 kernels) | awq-dequant (dense at load)
+    quantization: Optional[str] = None
     trust_remote_code: bool = False
     revision: Optional[str] = None
     hf_overrides: Dict[str, Any] = field(default_factory=dict)
@@ -177,6 +178,11 @@ class ModelConfig:
     @property
     def vocab_size(self) -> int:
         return int(self.hf_config["vocab_size"])
+
+    @property
+    def quant_group_size(self) -> int:
+        q = self.hf_config.get("quantization_config") or {}
+        return int(q.get("group_size", q.get("q_group_size", 128)))
 
     @property
     def torch_dtype(self):

@@ -7,7 +7,9 @@ partial sums - two all-reduces per transformer layer.  Weights are stored
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence
+import contextlib
+from dataclasses import dataclass
+from typing import Iterator, List, Optional, Sequence
 
 import torch
 import torch.nn as nn
@@ -24,19 +26,120 @@ def _param(*shape: int, dtype: torch.dtype) -> nn.Parameter:
     return nn.Parameter(torch.empty(*shape, dtype=dtype), requires_grad=False)
 
 
+# ------------------------------------------------------------ quantisation
+@dataclass(frozen=True)
+class QuantSpec:
+    """Weight-only quantisation of the decoder's linear layers.  ``awq``: 4-bit
+    asymmetric, ``group_size`` input columns per (scale, zero) pair, checkpoint
+    tensors ``qweight [in, out/8]``, ``qzeros [in/g, out/8]``, ``scales [in/g, out]``."""
+    method: str = "awq"
+    group_size: int = 128
+    pack: int = 8
+
+
+_ACTIVE_QUANT: Optional[QuantSpec] = None
+
+
+@contextlib.contextmanager
+def quantized_linears(spec: Optional[QuantSpec]) -> Iterator[None]:
+    """Linear layers constructed inside this context are built quantised."""
+    global _ACTIVE_QUANT
+    prev, _ACTIVE_QUANT = _ACTIVE_QUANT, spec
+    try:
+        yield
+    finally:
+        _ACTIVE_QUANT = prev
+
+
+def active_quant() -> Optional[QuantSpec]:
+    return _ACTIVE_QUANT
+
+
+def _tag(p: nn.Parameter, out_dim: int, pack: int = 1, in_div: int = 1) -> nn.Parameter:
+    """Sharding metadata read by the weight loaders: which dim is the output
+    dim, how many logical output columns one stored column packs, and by how
+    much the input dim is divided (quantisation groups)."""
+    p.out_dim, p.pack, p.in_div = out_dim, pack, in_div      # type: ignore[attr-defined]
+    return p
+
+
+def _meta(p: nn.Parameter):
+    return getattr(p, "out_dim", 0), getattr(p, "pack", 1), getattr(p, "in_div", 1)
+
+
+def w4_layout_ok(in_local: int, out_local: int, group: int) -> bool:
+    return in_local % 128 == 0 and out_local % 16 == 0 and group % 128 == 0 and in_local % group == 0
+
+
+def awq_to_native(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor, dtype: torch.dtype):
+    """AWQ shard tensors -> ``(qw, sz)`` in the kernel layout (``ops.quant.pack_w4``)."""
+    from ...ops import quant
+    q = quant.awq_unpack(qweight).t().contiguous()
+    z = quant.awq_unpack(qzeros).t().contiguous()
+    return quant.pack_w4(q, z, scales.t().contiguous(), dtype)
+
+
+class _LinearBase(nn.Module):
+    """Dense ``weight [out, in]`` or, under ``quantized_linears``, the AWQ
+    checkpoint triple which ``finalize_weights`` repacks once loading is done."""
+
+    def _alloc(self, in_local: int, out_local: int, bias: bool, dtype: torch.dtype,
+               quant: Optional[bool] = None) -> None:
+        spec = _ACTIVE_QUANT if quant is not False else None
+        self.quant = spec
+        self.in_local, self.out_local, self.dtype = in_local, out_local, dtype
+        self.register_buffer("qw", None)
+        self.register_buffer("sz", None)
+        if spec is None:
+            self.weight = _tag(_param(out_local, in_local, dtype=dtype), 0)
+        else:
+            g = spec.group_size
+            assert in_local % g == 0 and out_local % spec.pack == 0, \
+                f"quantised shard [{out_local} x {in_local}] does not align with groups of {g}"
+            self.qweight = _tag(_param(in_local, out_local // spec.pack, dtype=torch.int32), 1, spec.pack, 1)
+            self.qzeros = _tag(_param(in_local // g, out_local // spec.pack, dtype=torch.int32), 1, spec.pack, g)
+            self.scales = _tag(_param(in_local // g, out_local, dtype=dtype), 1, 1, g)
+        self.bias = _tag(_param(out_local, dtype=dtype), 0) if bias else None
+
+    def _set_loaders(self, loader, bias_loader=None) -> None:
+        for name in ("weight", "qweight", "qzeros", "scales"):
+            p = getattr(self, name, None)
+            if isinstance(p, nn.Parameter):
+                p.weight_loader = loader                         # type: ignore[attr-defined]
+        if self.bias is not None:
+            self.bias.weight_loader = bias_loader or loader      # type: ignore[attr-defined]
+
+    def finalize_weights(self) -> None:
+        if self.quant is None or self.qw is not None:
+            return
+        qweight, qzeros, scales = self.qweight.data, self.qzeros.data, self.scales.data
+        del self.qweight, self.qzeros, self.scales
+        if w4_layout_ok(self.in_local, self.out_local, self.quant.group_size):
+            qw, sz = awq_to_native(qweight, qzeros, scales, self.dtype)
+            self.qw, self.sz = qw, sz
+            ops.w4_reserve_scratch(qw.shape[0] * 16 * qw.shape[1] * 128, qw.device, self.dtype)
+        else:      # shapes the 4-bit kernel does not tile: dense fallback
+            from ..loader import awq_dequantize
+            self.quant = None
+            self.weight = nn.Parameter(awq_dequantize(qweight, qzeros, scales, self.dtype), requires_grad=False)
+
+    def _matmul(self, x: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+        if self.qw is not None:
+            return ops.w4a16_linear(x, self.qw, self.sz, bias)
+        return F.linear(x, self.weight, bias)
+
+
 def divide(a: int, b: int) -> int:
     assert a % b == 0, f"{a} is not divisible by {b}"
     return a // b
 
 
-class ReplicatedLinear(nn.Module):
-    def __init__(self, in_features: int, out_features: int, bias: bool, dtype: torch.dtype):
+class ReplicatedLinear(_LinearBase):
+    def __init__(self, in_features: int, out_features: int, bias: bool, dtype: torch.dtype,
+                 quant: Optional[bool] = None):
         super().__init__()
-        self.weight = _param(out_features, in_features, dtype=dtype)
-        self.bias = _param(out_features, dtype=dtype) if bias else None
-        self.weight.weight_loader = self._load      # type: ignore[attr-defined]
-        if self.bias is not None:
-            self.bias.weight_loader = self._load    # type: ignore[attr-defined]
+        self._alloc(in_features, out_features, bias, dtype, quant)
+        self._set_loaders(self._load)
 
     @staticmethod
     def _load(param: nn.Parameter, w: torch.Tensor, shard_id=None) -> None:
@@ -44,10 +147,10 @@ class ReplicatedLinear(nn.Module):
         param.data.copy_(w)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return F.linear(x, self.weight, self.bias)
+        return self._matmul(x, self.bias)
 
 
-class ColumnParallelLinear(nn.Module):
+class ColumnParallelLinear(_LinearBase):
     """``y = x W^T`` with ``W`` split along ``out``.  ``output_sizes`` lists the
     logical sub-matrices fused into this layer (e.g. gate and up), each sharded
     independently so a rank's slice stays ``[gate_i | up_i]``."""
@@ -60,35 +163,32 @@ class ColumnParallelLinear(nn.Module):
         self.output_sizes = list(output_sizes)
         self.shard_sizes = [divide(s, self.tp) for s in self.output_sizes]
         self.gather_output = gather_output
-        out_local = sum(self.shard_sizes)
-        self.weight = _param(out_local, in_features, dtype=dtype)
-        self.bias = _param(out_local, dtype=dtype) if bias else None
-        self.weight.weight_loader = self.weight_loader      # type: ignore[attr-defined]
-        if self.bias is not None:
-            self.bias.weight_loader = self.weight_loader    # type: ignore[attr-defined]
+        self._alloc(in_features, sum(self.shard_sizes), bias, dtype)
+        self._set_loaders(self.weight_loader)
 
     def weight_loader(self, param: nn.Parameter, w: torch.Tensor, shard_id: Optional[int] = None) -> None:
         """``shard_id`` = index into ``output_sizes``; None = the full fused matrix."""
+        od, pack, _ = _meta(param)
         if shard_id is None:
-            assert w.shape[0] == sum(self.output_sizes), (w.shape, self.output_sizes)
+            assert w.shape[od] * pack == sum(self.output_sizes), (w.shape, self.output_sizes)
             off = 0
             for i, s in enumerate(self.output_sizes):
-                self.weight_loader(param, w.narrow(0, off, s), i)
+                self.weight_loader(param, w.narrow(od, off // pack, s // pack), i)
                 off += s
             return
-        size = self.shard_sizes[shard_id]
-        dst_off = sum(self.shard_sizes[:shard_id])
-        src = w.narrow(0, self.tp_rank * size, size)
-        param.data.narrow(0, dst_off, size).copy_(src)
+        size = self.shard_sizes[shard_id] // pack
+        dst_off = sum(self.shard_sizes[:shard_id]) // pack
+        src = w.narrow(od, self.tp_rank * size, size)
+        param.data.narrow(od, dst_off, size).copy_(src)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        y = F.linear(x, self.weight, self.bias)
+        y = self._matmul(x, self.bias)
         if self.gather_output and self.tp > 1:
             y = tensor_model_parallel_all_gather(y, dim=-1)
         return y
 
 
-class QKVParallelLinear(nn.Module):
+class QKVParallelLinear(_LinearBase):
     """Fused q/k/v projection.  Query heads are split across ranks; KV heads
     are split when there are at least ``tp`` of them, else replicated."""
 
@@ -108,19 +208,16 @@ class QKVParallelLinear(nn.Module):
             self.kv_replicas = divide(self.tp, num_kv_heads)
         self.q_size = self.num_heads * head_dim
         self.kv_size = self.num_kv_heads * head_dim
-        out_local = self.q_size + 2 * self.kv_size
-        self.weight = _param(out_local, hidden_size, dtype=dtype)
-        self.bias = _param(out_local, dtype=dtype) if bias else None
-        self.weight.weight_loader = self.weight_loader      # type: ignore[attr-defined]
-        if self.bias is not None:
-            self.bias.weight_loader = self.weight_loader    # type: ignore[attr-defined]
+        self._alloc(hidden_size, self.q_size + 2 * self.kv_size, bias, dtype)
+        self._set_loaders(self.weight_loader)
 
     def weight_loader(self, param: nn.Parameter, w: torch.Tensor, shard_id: Optional[str] = None) -> None:
+        od, pack, _ = _meta(param)
         if shard_id is None:      # full fused [q | k | v]
-            qs, ks = self.total_heads * self.head_dim, self.total_kv_heads * self.head_dim
-            self.weight_loader(param, w.narrow(0, 0, qs), "q")
-            self.weight_loader(param, w.narrow(0, qs, ks), "k")
-            self.weight_loader(param, w.narrow(0, qs + ks, ks), "v")
+            qs, ks = self.total_heads * self.head_dim // pack, self.total_kv_heads * self.head_dim // pack
+            self.weight_loader(param, w.narrow(od, 0, qs), "q")
+            self.weight_loader(param, w.narrow(od, qs, ks), "k")
+            self.weight_loader(param, w.narrow(od, qs + ks, ks), "v")
             return
         if shard_id == "q":
             size, dst, src_idx = self.q_size, 0, self.tp_rank
@@ -128,34 +225,33 @@ class QKVParallelLinear(nn.Module):
             size = self.kv_size
             dst = self.q_size + (0 if shard_id == "k" else self.kv_size)
             src_idx = self.tp_rank // self.kv_replicas
-        param.data.narrow(0, dst, size).copy_(w.narrow(0, src_idx * size, size))
+        size, dst = size // pack, dst // pack
+        param.data.narrow(od, dst, size).copy_(w.narrow(od, src_idx * size, size))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return F.linear(x, self.weight, self.bias)
+        return self._matmul(x, self.bias)
 
 
-class RowParallelLinear(nn.Module):
+class RowParallelLinear(_LinearBase):
     def __init__(self, in_features: int, out_features: int, bias: bool, dtype: torch.dtype,
                  reduce_results: bool = True):
         super().__init__()
         self.tp = get_tensor_model_parallel_world_size()
         self.tp_rank = get_tensor_model_parallel_rank()
-        self.in_local = divide(in_features, self.tp)
         self.reduce_results = reduce_results
-        self.weight = _param(out_features, self.in_local, dtype=dtype)
-        self.bias = _param(out_features, dtype=dtype) if bias else None
-        self.weight.weight_loader = self.weight_loader      # type: ignore[attr-defined]
-        if self.bias is not None:
-            self.bias.weight_loader = ReplicatedLinear._load    # type: ignore[attr-defined]
+        self._alloc(divide(in_features, self.tp), out_features, bias, dtype)
+        self._set_loaders(self.weight_loader, ReplicatedLinear._load)
 
     def weight_loader(self, param: nn.Parameter, w: torch.Tensor, shard_id=None) -> None:
-        param.data.copy_(w.narrow(1, self.tp_rank * self.in_local, self.in_local))
+        od, _, in_div = _meta(param)
+        n = self.in_local // in_div
+        param.data.copy_(w.narrow(1 - od, self.tp_rank * n, n))
 
     def forward(self, x: torch.Tensor, reduce: bool = True) -> torch.Tensor:
         """``reduce=False`` returns this rank's partial sums; the caller owns the
         all-reduce (used to overlap it with another micro-batch's compute)."""
         # bias is added once (rank 0) so the all-reduce does not multiply it
-        y = F.linear(x, self.weight, self.bias if self.tp_rank == 0 else None)
+        y = self._matmul(x, self.bias if self.tp_rank == 0 else None)
         if reduce and self.reduce_results and self.tp > 1:
             y = tensor_model_parallel_all_reduce(y)
         return y

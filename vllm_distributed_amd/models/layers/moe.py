@@ -22,7 +22,7 @@ from ... import ops
 from ...parallel.state import (get_tensor_model_parallel_rank,
                                get_tensor_model_parallel_world_size,
                                tensor_model_parallel_all_reduce)
-from .linear import ReplicatedLinear, divide
+from .linear import ReplicatedLinear, active_quant, awq_to_native, divide, w4_layout_ok
 
 
 class FusedMoE(nn.Module):
@@ -41,13 +41,35 @@ class FusedMoE(nn.Module):
             self.local_experts, self.expert_start = num_experts, 0
             self.inter_local = divide(inter, self.tp)
         self.inter = inter
-        self.gate = ReplicatedLinear(hidden, num_experts, False, dtype)
-        self.w13 = nn.Parameter(torch.empty(self.local_experts, 2 * self.inter_local, hidden,
-                                            dtype=dtype), requires_grad=False)
-        self.w2 = nn.Parameter(torch.empty(self.local_experts, hidden, self.inter_local,
-                                           dtype=dtype), requires_grad=False)
-        self.w13.weight_loader = self._load_w13     # type: ignore[attr-defined]
-        self.w2.weight_loader = self._load_w2       # type: ignore[attr-defined]
+        self.hidden, self.dtype = hidden, dtype
+        self.gate = ReplicatedLinear(hidden, num_experts, False, dtype, quant=False)   # router stays dense
+        self.quant = active_quant()
+        E, I = self.local_experts, self.inter_local
+        self.register_buffer("qw13", None)
+        self.register_buffer("sz13", None)
+        self.register_buffer("qw2", None)
+        self.register_buffer("sz2", None)
+
+        def param(*shape, dt=dtype, out_dim=0, pack=1, in_div=1, loader=None):
+            p = nn.Parameter(torch.empty(*shape, dtype=dt), requires_grad=False)
+            p.out_dim, p.pack, p.in_div, p.weight_loader = out_dim, pack, in_div, loader
+            return p
+        if self.quant is None:
+            self.w13 = param(E, 2 * I, hidden, loader=self._load_w13)
+            self.w2 = param(E, hidden, I, loader=self._load_w2)
+        else:
+            g, pk = self.quant.group_size, self.quant.pack
+            assert hidden % g == 0 and I % g == 0, \
+                f"expert shard [{I} x {hidden}] does not align with quantisation groups of {g}"
+            i32 = torch.int32
+            self.w13_qweight = param(E, hidden, 2 * I // pk, dt=i32, out_dim=1, pack=pk, loader=self._load_w13)
+            self.w13_qzeros = param(E, hidden // g, 2 * I // pk, dt=i32, out_dim=1, pack=pk, in_div=g,
+                                    loader=self._load_w13)
+            self.w13_scales = param(E, hidden // g, 2 * I, out_dim=1, in_div=g, loader=self._load_w13)
+            self.w2_qweight = param(E, I, hidden // pk, dt=i32, out_dim=1, pack=pk, loader=self._load_w2)
+            self.w2_qzeros = param(E, I // g, hidden // pk, dt=i32, out_dim=1, pack=pk, in_div=g,
+                                   loader=self._load_w2)
+            self.w2_scales = param(E, I // g, hidden, out_dim=1, in_div=g, loader=self._load_w2)
 
     def _local_index(self, expert_id: int) -> Optional[int]:
         e = expert_id - self.expert_start
@@ -58,9 +80,11 @@ class FusedMoE(nn.Module):
         e = self._local_index(expert_id)
         if e is None:
             return
+        od, pack = param.out_dim, param.pack
+        n = self.inter_local // pack
         if not self.expert_parallel:
-            w = w.narrow(0, self.tp_rank * self.inter_local, self.inter_local)
-        param.data[e].narrow(0, which * self.inter_local, self.inter_local).copy_(w)
+            w = w.narrow(od, self.tp_rank * n, n)
+        param.data[e].narrow(od, which * n, n).copy_(w)
 
     def _load_w2(self, param: nn.Parameter, w: torch.Tensor, shard_id) -> None:
         expert_id, _ = shard_id
@@ -68,8 +92,47 @@ class FusedMoE(nn.Module):
         if e is None:
             return
         if not self.expert_parallel:
-            w = w.narrow(1, self.tp_rank * self.inter_local, self.inter_local)
+            n = self.inter_local // param.in_div
+            w = w.narrow(1 - param.out_dim, self.tp_rank * n, n)
         param.data[e].copy_(w)
+
+    def finalize_weights(self) -> None:
+        """Repack the experts' AWQ shards into the 4-bit kernel layout (or
+        dequantise them when a shard shape does not tile)."""
+        if self.quant is None or self.qw13 is not None:
+            return
+        E, I, H, g = self.local_experts, self.inter_local, self.hidden, self.quant.group_size
+        native = w4_layout_ok(H, 2 * I, g) and w4_layout_ok(I, H, g)
+        parts = {"13": [], "2": []}
+        for key in ("13", "2"):
+            qweight = getattr(self, f"w{key}_qweight").data
+            qzeros = getattr(self, f"w{key}_qzeros").data
+            scales = getattr(self, f"w{key}_scales").data
+            for e in range(E):
+                if native:
+                    parts[key].append(awq_to_native(qweight[e], qzeros[e], scales[e], self.dtype))
+                else:
+                    from ..loader import awq_dequantize
+                    parts[key].append(awq_dequantize(qweight[e], qzeros[e], scales[e], self.dtype))
+            delattr(self, f"w{key}_qweight")
+            delattr(self, f"w{key}_qzeros")
+            delattr(self, f"w{key}_scales")
+        if native:
+            self.qw13 = torch.stack([p[0] for p in parts["13"]])
+            self.sz13 = torch.stack([p[1] for p in parts["13"]])
+            self.qw2 = torch.stack([p[0] for p in parts["2"]])
+            self.sz2 = torch.stack([p[1] for p in parts["2"]])
+            ops.w4_reserve_scratch(2 * I * H, self.qw13.device, self.dtype)
+        else:
+            self.quant = None
+            self.w13 = nn.Parameter(torch.stack(parts["13"]), requires_grad=False)
+            self.w2 = nn.Parameter(torch.stack(parts["2"]), requires_grad=False)
+
+    def _expert_mlp(self, e: int, x: torch.Tensor) -> torch.Tensor:
+        if self.qw13 is not None:
+            h = ops.w4a16_linear(x, self.qw13[e], self.sz13[e])
+            return ops.w4a16_linear(ops.silu_and_mul(h), self.qw2[e], self.sz2[e])
+        return F.linear(ops.silu_and_mul(F.linear(x, self.w13[e])), self.w2[e])
 
     def forward(self, x: torch.Tensor, reduce: bool = True) -> torch.Tensor:
         logits = self.gate(x).float()
@@ -95,8 +158,7 @@ class FusedMoE(nn.Module):
             if e is None:
                 continue
             rows = tok[seg]
-            h = F.linear(x.index_select(0, rows), self.w13[e])
-            h = F.linear(ops.silu_and_mul(h), self.w2[e])
+            h = self._expert_mlp(e, x.index_select(0, rows))
             out.index_add_(0, rows, h * wts[seg].unsqueeze(1))
         if reduce and self.tp > 1:
             out = tensor_model_parallel_all_reduce(out)

@@ -17,8 +17,8 @@ from .. import ops
 from ..config import VllmConfig
 from ..parallel.state import get_pp_group
 from .layers.attention import Attention, RMSNorm, get_forward_context
-from .layers.linear import (ColumnParallelLinear, ParallelLMHead, QKVParallelLinear,
-                            RowParallelLinear, VocabParallelEmbedding)
+from .layers.linear import (ColumnParallelLinear, ParallelLMHead, QKVParallelLinear, QuantSpec,
+                            RowParallelLinear, VocabParallelEmbedding, quantized_linears)
 from .utils import IntermediateTensors, get_pp_layer_range
 
 
@@ -142,9 +142,11 @@ class LlamaForCausalLM(nn.Module):
         tie = bool(cfg.get("tie_word_embeddings", False))
         if self.is_first or (tie and self.is_last):
             self.embed_tokens = VocabParallelEmbedding(cfg["vocab_size"], cfg["hidden_size"], dtype)
-        self.layers = nn.ModuleDict({
-            str(i): self.layer_cls(cfg, i, dtype, self.cos_sin_cache)
-            for i in range(self.start_layer, self.end_layer)})
+        spec = QuantSpec("awq", mc.quant_group_size) if mc.quantization == "awq" else None
+        with quantized_linears(spec):
+            self.layers = nn.ModuleDict({
+                str(i): self.layer_cls(cfg, i, dtype, self.cos_sin_cache)
+                for i in range(self.start_layer, self.end_layer)})
         if self.is_last:
             self.norm = RMSNorm(cfg["hidden_size"], cfg.get("rms_norm_eps", 1e-5), dtype)
             if tie:

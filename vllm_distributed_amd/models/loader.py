@@ -110,15 +110,36 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
     return shapes
 
 
+_QUANTIZED_LINEAR = re.compile(r"\.(q_proj|k_proj|v_proj|o_proj|gate_proj|up_proj|down_proj)\.weight$")
+
+
 def dummy_weights_iterator(mc: ModelConfig, device: torch.device,
                            want: Optional[Callable[[str], bool]] = None,
                            ) -> Iterator[Tuple[str, torch.Tensor]]:
+    """Deterministic random checkpoint.  With an AWQ model config the decoder's
+    linear layers come as random ``qweight/qzeros/scales`` triples instead of
+    dense matrices (the same tensors an AWQ checkpoint would hold)."""
     dtype = mc.torch_dtype
     gen = torch.Generator(device=device)
+    awq = mc.quantization in ("awq", "awq-dequant")
+    g = mc.quant_group_size
     for name, shape in hf_weight_shapes(mc).items():
         if want is not None and not want(name):
             continue
         gen.manual_seed(_seed_for(name, mc.seed))
+        if awq and _QUANTIZED_LINEAR.search(name) and shape[1] % g == 0 and shape[0] % 8 == 0:
+            out_f, in_f = shape
+            base = name[:-len(".weight")]
+            lo, hi = -(1 << 31), (1 << 31) - 1
+            yield base + ".qweight", torch.randint(lo, hi, (in_f, out_f // 8), generator=gen, device=device,
+                                                   dtype=torch.int64).to(torch.int32)
+            yield base + ".qzeros", torch.randint(lo, hi, (in_f // g, out_f // 8), generator=gen, device=device,
+                                                  dtype=torch.int64).to(torch.int32)
+            # (q - z) has std ~6.5: keep activations near unit variance
+            sc = (1.0 / in_f) ** 0.5 / 6.5
+            yield base + ".scales", (sc * (0.5 + torch.rand((in_f // g, out_f), generator=gen, device=device,
+                                                            dtype=torch.float32))).to(dtype)
+            continue
         if re.search(r"(layernorm|layer_norm|norm)\.weight$", name):
             w = 1.0 + 0.05 * (torch.rand(shape, generator=gen, device=device, dtype=torch.float32) - 0.5)
             w = w.to(dtype)
@@ -157,8 +178,28 @@ def awq_dequantize(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Te
     return ((w - z) * s).t().contiguous().to(dtype)
 
 
+def _dequantize_stream(weights: Iterable[Tuple[str, torch.Tensor]], dtype: torch.dtype,
+                       ) -> Iterator[Tuple[str, torch.Tensor]]:
+    """Turn ``qweight/qzeros/scales`` triples of a weight stream into dense
+    ``.weight`` tensors; everything else passes through."""
+    pending: Dict[str, Dict[str, torch.Tensor]] = {}
+    for name, w in weights:
+        for kind in ("qweight", "qzeros", "scales"):
+            if name.endswith("." + kind):
+                base = name[:-len(kind) - 1]
+                slot = pending.setdefault(base, {})
+                slot[kind] = w
+                if len(slot) == 3:
+                    del pending[base]
+                    yield base + ".weight", awq_dequantize(slot["qweight"], slot["qzeros"], slot["scales"], dtype)
+                break
+        else:
+            yield name, w
+
+
 def safetensors_weights_iterator(path: str, dtype: torch.dtype,
                                  want: Optional[Callable[[str], bool]] = None,
+                                 keep_quantized: bool = False,
                                  ) -> Iterator[Tuple[str, torch.Tensor]]:
     from safetensors import safe_open
     files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
@@ -174,6 +215,11 @@ def safetensors_weights_iterator(path: str, dtype: torch.dtype,
             keys = list(f.keys())
             awq_done = set()
             for k in keys:
+                if keep_quantized:
+                    if want is None or want(k):
+                        t = f.get_tensor(k)
+                        yield k, (t.to(dtype) if k.endswith(".scales") else t)
+                    continue
                 if k.endswith((".qzeros", ".scales")):
                     continue
                 if k.endswith(".qweight"):
@@ -208,10 +254,16 @@ def load_model(vllm_config: VllmConfig, device: torch.device) -> torch.nn.Module
         if mc.load_format not in ("dummy", "auto"):
             raise FileNotFoundError(f"no weights for {mc.model!r}")
         it: Iterable[Tuple[str, torch.Tensor]] = dummy_weights_iterator(mc, device, want)
+        if mc.quantization == "awq-dequant":
+            it = _dequantize_stream(it, mc.torch_dtype)
     else:
-        it = safetensors_weights_iterator(path, mc.torch_dtype, want)
+        it = safetensors_weights_iterator(path, mc.torch_dtype, want, keep_quantized=mc.quantization == "awq")
     with torch.no_grad():
         loaded = model.load_weights(it)
+        for m in model.modules():          # repack quantised shards into the kernel layout
+            fin = getattr(m, "finalize_weights", None)
+            if fin is not None:
+                fin()
     logger.info("loaded %d checkpoint tensors for %s (layers %d-%d, format=%s)", len(loaded),
                 mc.model, getattr(model, "start_layer", 0), getattr(model, "end_layer", 0),
                 mc.load_format if path is None else "safetensors")

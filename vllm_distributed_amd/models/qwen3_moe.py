@@ -34,7 +34,7 @@ class Qwen3MoeDecoderLayer(LlamaDecoderLayer):
 
 class Qwen3MoeForCausalLM(LlamaForCausalLM):
     layer_cls = Qwen3MoeDecoderLayer
-    _expert_re = re.compile(r"(.*\.mlp)\.experts\.(\d+)\.(gate_proj|up_proj|down_proj)\.weight$")
+    _expert_re = re.compile(r"(.*\.mlp)\.experts\.(\d+)\.(gate_proj|up_proj|down_proj)\.(weight|qweight|qzeros|scales)$")
 
     def __init__(self, vllm_config: VllmConfig):
         global _EP
@@ -52,12 +52,13 @@ class Qwen3MoeForCausalLM(LlamaForCausalLM):
                 continue
             if not self._owns_layer(mapped):
                 continue
-            prefix, eid, proj = m.group(1), int(m.group(2)), m.group(3)
+            prefix, eid, proj, kind = m.group(1), int(m.group(2)), m.group(3), m.group(4)
+            suffix = "" if kind == "weight" else "_" + kind
             if proj == "down_proj":
-                p = params[prefix + ".w2"]
+                p = params[prefix + ".w2" + suffix]
                 p.weight_loader(p, w, (eid, 0))
             else:
-                p = params[prefix + ".w13"]
+                p = params[prefix + ".w13" + suffix]
                 p.weight_loader(p, w, (eid, 0 if proj == "gate_proj" else 1))
             loaded.append(mapped)
         return loaded + super().load_weights(rest)

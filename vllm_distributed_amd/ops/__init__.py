@@ -138,6 +138,53 @@ def embedding(ids, weight, vocab_start=0, masked=False):
     return torch_ref.embedding(ids, weight, vocab_start, masked)
 
 
+_w4_scratch = {}
+
+
+def _scratch_key(device, dtype):
+    d = torch.device(device)
+    return (d.index if d.index is not None else torch.cuda.current_device(), dtype)
+
+
+def w4_reserve_scratch(numel: int, device, dtype) -> None:
+    """Size the dequantisation scratch for the largest quantised matrix up
+    front: captured hipGraphs keep its address, so it must never be
+    reallocated while serving."""
+    if torch.device(device).type != "cuda":
+        return
+    key = _scratch_key(device, dtype)
+    buf = _w4_scratch.get(key)
+    if buf is None or buf.numel() < numel:
+        _w4_scratch[key] = torch.empty(numel, dtype=dtype, device=device)
+
+
+def w4a16_linear(x, qw, sz, bias=None):
+    """``y = x . dequant(qw, sz)^T (+ bias)`` for weights packed by
+    ``ops.quant.pack_w4``.  Small batches run the fused 4-bit MFMA kernel (the
+    weights cross HBM once, as 4-bit); large batches dequantise into a shared
+    scratch matrix and use the library GEMM, which is compute-bound there."""
+    from . import quant
+    shape = x.shape
+    x2 = x.reshape(-1, shape[-1])
+    if _use_hip(x2) and x2.dtype in (torch.bfloat16, torch.float16):
+        if x2.shape[0] <= _hip.W4_MAX_FUSED_M:
+            if x2.stride(1) != 1 or x2.stride(0) % 8 or x2.data_ptr() % 16:
+                x2 = x2.contiguous()
+            y = _hip.w4a16_gemm(x2, qw, sz)
+        else:
+            n, k = qw.shape[0] * 16, qw.shape[1] * 128
+            key = _scratch_key(x2.device, sz.dtype)
+            buf = _w4_scratch.get(key)
+            if buf is None or buf.numel() < n * k:
+                buf = _w4_scratch[key] = torch.empty(n * k, dtype=sz.dtype, device=x2.device)
+            y = torch.nn.functional.linear(x2, _hip.w4_dequant(qw, sz, buf))
+    else:
+        y = torch.nn.functional.linear(x2, quant.w4_dequant(qw, sz, x2.dtype))
+    if bias is not None:
+        y = y + bias
+    return y.view(shape[:-1] + (y.shape[-1],))
+
+
 apply_penalties = torch_ref.apply_penalties
 compute_logprobs = torch_ref.compute_logprobs
 build_cos_sin_cache = torch_ref.build_cos_sin_cache

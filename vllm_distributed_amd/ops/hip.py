@@ -39,6 +39,8 @@ def load() -> ctypes.CDLL:
         "vdamd_paged_attention_prefill": [P, P, L, P, P, P, I, P, P, F, I, I, I, I, I, I, L, I, P],
         "vdamd_argmax": [P, P, I, I, L, I, P],
         "vdamd_sample": [P, P, I, I, L, P, P, P, P, P, I, P],
+        "vdamd_w4a16_gemm": [P, L, P, L, P, P, P, I, I, I, I, I, I, P],
+        "vdamd_w4_dequant": [P, P, P, I, I, I, I, P],
     }
     for name, argtypes in sigs.items():
         fn = getattr(lib, name)
@@ -295,4 +297,53 @@ def sample(logits, temperature, top_k, top_p, min_p, uniform) -> torch.Tensor:
     _check(_LIB.vdamd_sample(out.data_ptr(), logits.data_ptr(), b, v, logits.stride(0), temperature.data_ptr(),
                              top_k.data_ptr(), top_p.data_ptr(), min_p.data_ptr(), uniform.data_ptr(),
                              _dt(logits), _stream()), "sample")
+    return out
+
+
+# ------------------------------------------------------------ W4A16 linears
+W4_MAX_FUSED_M = int(os.environ.get("VDAMD_W4_MAX_FUSED_M", "256"))
+
+
+def _w4_dims(qw: torch.Tensor, sz: torch.Tensor) -> Tuple[int, int, int]:
+    assert qw.dim() == 4 and qw.shape[2:] == (64, 4) and qw.dtype == torch.int32 and qw.is_contiguous()
+    n, k = qw.shape[0] * 16, qw.shape[1] * 128
+    assert sz.dim() == 4 and sz.shape[0] == qw.shape[0] and sz.shape[2:] == (16, 2) and sz.is_contiguous()
+    g = k // sz.shape[1]
+    assert g * sz.shape[1] == k and g % 128 == 0, (k, sz.shape)
+    return n, k, g
+
+
+def w4_choose_ksplit(m: int, n: int, k: int) -> int:
+    """Workgroups cover 64 output rows x all of K; split K until ~3 workgroups
+    per CU exist, keeping at least two 128-column blocks per wave."""
+    mt = min(4, (m + 15) // 16)
+    base = ((n // 16 + 3) // 4) * ((m + 16 * mt - 1) // (16 * mt))
+    want = (768 + base - 1) // base
+    return max(1, min(want, (k // 128) // 8))
+
+
+def w4_dequant(qw: torch.Tensor, sz: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    n, k, g = _w4_dims(qw, sz)
+    if out is None:
+        out = torch.empty((n, k), dtype=sz.dtype, device=qw.device)
+    assert out.is_contiguous() and out.numel() >= n * k and out.dtype == sz.dtype
+    _check(_LIB.vdamd_w4_dequant(out.data_ptr(), qw.data_ptr(), sz.data_ptr(), n, k, g, _dt(sz), _stream()),
+           "w4_dequant")
+    return out[:n * k].view(n, k) if out.dim() == 1 else out
+
+
+def w4a16_gemm(x: torch.Tensor, qw: torch.Tensor, sz: torch.Tensor) -> torch.Tensor:
+    """``x [M, K]`` (bf16/fp16, rows 16-byte aligned) times the packed weights."""
+    n, k, g = _w4_dims(qw, sz)
+    assert x.dim() == 2 and x.shape[1] == k and x.dtype == sz.dtype and x.stride(1) == 1
+    assert x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
+    m = x.shape[0]
+    out = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    if m == 0:
+        return out
+    ksplit = w4_choose_ksplit(m, n, k)
+    partial = torch.empty(ksplit * m * n, dtype=torch.float32, device=x.device) if ksplit > 1 else None
+    _check(_LIB.vdamd_w4a16_gemm(out.data_ptr(), n, x.data_ptr(), x.stride(0), qw.data_ptr(), sz.data_ptr(),
+                                 None if partial is None else partial.data_ptr(), m, n, k, g, ksplit,
+                                 _dt(x), _stream()), "w4a16_gemm")
     return out
