@@ -45,7 +45,7 @@ def main():
     assert ops.hip_available()
     from vllm_distributed_amd.ops import hip
     dev = "cuda"
-    print(f"{'shape':26s} {'M':>4s} {'w4 us':>9s} {'w4 GB/s':>9s} {'bf16 us':>9s} {'speedup':>8s} {'ksplit':>6s}")
+    print(f"{'shape':26s} {'M':>4s} {'v0 us':>9s} {'v1 us':>9s} {'best GB/s':>9s} {'bf16 us':>9s} {'speedup':>8s} {'auto':>5s}")
     for name, n, k in SHAPES:
         gen = torch.Generator(device=dev).manual_seed(0)
         # pack on the GPU in row chunks (the packer's int64 temporaries are 8x the weights)
@@ -57,11 +57,13 @@ def main():
         del q
         for m in (1, 16, 32, 64, 128, 256):
             x = torch.randn(m, k, device=dev, dtype=torch.bfloat16)
-            t4 = timeit(lambda: hip.w4a16_gemm(x, qw, sz), args.iters)
+            t0 = timeit(lambda: hip.w4a16_gemm(x, qw, sz, variant=0), args.iters)
+            t1 = timeit(lambda: hip.w4a16_gemm(x, qw, sz, variant=1), args.iters)
             tb = timeit(lambda: torch.nn.functional.linear(x, w), args.iters)
+            t4 = min(t0, t1)
             gbs = (n * k / 2) / (t4 * 1e-6) / 1e9
-            print(f"{name:26s} {m:4d} {t4:9.1f} {gbs:9.0f} {tb:9.1f} {tb / t4:8.2f} "
-                  f"{hip.w4_choose_ksplit(m, n, k):6d}", flush=True)
+            print(f"{name:26s} {m:4d} {t0:9.1f} {t1:9.1f} {gbs:9.0f} {tb:9.1f} {tb / t4:8.2f} "
+                  f"{hip.w4_choose_variant(m, n, k):5d}", flush=True)
         td = timeit(lambda: hip.w4_dequant(qw, sz, w), args.iters)
         print(f"{name:26s} dequant to bf16: {td:.1f} us ({n * k * 2.5 / (td * 1e-6) / 1e9:.0f} GB/s moved)")
         del qw, sz, w

@@ -185,6 +185,129 @@ __global__ __launch_bounds__(256) void w4a16_gemm_kernel(
   }
 }
 
+// Batches above one MFMA tile of rows: the four waves of a workgroup take
+// *different* output tiles (16 tiles = 256 rows per workgroup) and share each
+// 128-column block of x through LDS, so x crosses L2 once per 16 KiB of
+// weights instead of once per wave.  Rows of the LDS copy are padded to 272
+// bytes so the 16 lanes of a ds_read_b128 phase fall into distinct banks.
+// grid = (ceil(N/256), ksplit, ceil(M / (16*MT))), block = 256.
+constexpr int W4_XPAD = 136;
+
+template <typename T, int MT>
+__global__ __launch_bounds__(256) void w4a16_gemm_lds_kernel(
+    const T* __restrict__ x, long x_stride, const uint32_t* __restrict__ qw, const T* __restrict__ sz,
+    T* __restrict__ out, long out_stride, float* __restrict__ partial, int M, int N, int K,
+    int kb_per_group, int ksplit) {
+  using V8 = typename Vec8<T>::type;
+  __shared__ __attribute__((aligned(16))) T xl[2][MT * 16][W4_XPAD];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int KB = K >> 7, ntiles = N >> 4, NG = KB / kb_per_group;
+  const int nt0 = (blockIdx.x * W4_WAVES + wid) * W4_NTW;
+  const int ks = blockIdx.y;
+  const int kb_lo = (int)((long)KB * ks / ksplit), kb_hi = (int)((long)KB * (ks + 1) / ksplit);
+  const int m0 = blockIdx.z * (16 * MT);
+
+  int ntc[W4_NTW];
+#pragma unroll
+  for (int t = 0; t < W4_NTW; ++t) ntc[t] = min(nt0 + t, ntiles - 1);
+  // cooperative copy of x: thread -> (row xr of a 16-row pass, 16-byte column xc)
+  const int xr = threadIdx.x >> 4, xc = threadIdx.x & 15;
+  const T* xsrc[MT];
+#pragma unroll
+  for (int p = 0; p < MT; ++p) xsrc[p] = x + (long)min(m0 + 16 * p + xr, M - 1) * x_stride + 8 * xc;
+
+  f32x4 acc[W4_NTW][MT];
+#pragma unroll
+  for (int t = 0; t < W4_NTW; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  V8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (T)1.0f;
+
+  auto load_w = [&](int kb, u32x4 (&w)[W4_NTW], V8 (&s)[W4_NTW]) {
+#pragma unroll
+    for (int t = 0; t < W4_NTW; ++t) {
+      w[t] = *reinterpret_cast<const u32x4*>(qw + (((size_t)ntc[t] * KB + kb) << 8) + lane * 4);
+      s[t] = ld8(sz + ((((size_t)ntc[t] * NG + kb / kb_per_group) * 16 + 4 * g) << 1));
+    }
+  };
+  u32x4 wc[W4_NTW], wn[W4_NTW];
+  V8 sc[W4_NTW], sn[W4_NTW];
+  V8 xreg[MT];
+  if (kb_lo < kb_hi) {
+    load_w(kb_lo, wc, sc);
+#pragma unroll
+    for (int p = 0; p < MT; ++p) st8(&xl[0][16 * p + xr][8 * xc], ld8(xsrc[p] + (kb_lo << 7)));
+  }
+  __syncthreads();
+  for (int kb = kb_lo; kb < kb_hi; ++kb) {
+    const int buf = (kb - kb_lo) & 1;
+    const bool more = kb + 1 < kb_hi;
+    if (more) {
+      load_w(kb + 1, wn, sn);
+#pragma unroll
+      for (int p = 0; p < MT; ++p) xreg[p] = ld8(xsrc[p] + ((kb + 1) << 7));
+    }
+    V8 bx[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bx[mt][s] = ld8(&xl[buf][16 * mt + c][32 * g + 8 * s]);
+    f32x4 xs[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      xs[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) xs[mt] = mfma16(ones, bx[mt][s], xs[mt]);
+    }
+#pragma unroll
+    for (int t = 0; t < W4_NTW; ++t) {
+      f32x4 p[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) p[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const V8 a = w4_unpack<T>(wc[t][s]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) p[mt] = mfma16(a, bx[mt][s], p[mt]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s_r = (float)sc[t][2 * r], z_r = (float)sc[t][2 * r + 1];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[t][mt][r] += s_r * (p[mt][r] - z_r * xs[mt][r]);
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int t = 0; t < W4_NTW; ++t) { wc[t] = wn[t]; sc[t] = sn[t]; }
+#pragma unroll
+      for (int p = 0; p < MT; ++p) st8(&xl[buf ^ 1][16 * p + xr][8 * xc], xreg[p]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < W4_NTW; ++t) {
+    if (nt0 + t >= ntiles) continue;
+    const int n = 16 * (nt0 + t) + 4 * g;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m0 + 16 * mt + c;
+      if (m >= M) continue;
+      if (ksplit == 1) {
+        typename Vec4<T>::type o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (T)acc[t][mt][r];
+        *reinterpret_cast<typename Vec4<T>::type*>(out + (long)m * out_stride + n) = o;
+      } else {
+        *reinterpret_cast<f32x4*>(partial + ((size_t)ks * M + m) * N + n) = acc[t][mt];
+      }
+    }
+  }
+}
+
 // out[m][n] = sum_ks partial[ks][m][n]; one thread per 4 outputs
 template <typename T>
 __global__ void w4a16_reduce_kernel(T* __restrict__ out, long out_stride, const float* __restrict__ partial,
@@ -225,14 +348,20 @@ __global__ __launch_bounds__(256) void w4_dequant_kernel(T* __restrict__ out, co
 
 template <typename T>
 static int launch_w4a16(void* out, long out_stride, const void* x, long x_stride, const void* qw,
-                        const void* sz, void* partial, int M, int N, int K, int G, int ksplit,
+                        const void* sz, void* partial, int M, int N, int K, int G, int ksplit, int variant,
                         hipStream_t st) {
   const int mt = min(4, (M + 15) / 16);
-  dim3 grid((N / 16 + W4_NTW - 1) / W4_NTW, ksplit, (M + 16 * mt - 1) / (16 * mt));
+  const int tiles_per_wg = variant == 1 ? W4_NTW * W4_WAVES : W4_NTW;
+  dim3 grid((N / 16 + tiles_per_wg - 1) / tiles_per_wg, ksplit, (M + 16 * mt - 1) / (16 * mt));
 #define W4_LAUNCH(MT_)                                                                                   \
-  w4a16_gemm_kernel<T, MT_><<<grid, 256, 0, st>>>((const T*)x, x_stride, (const uint32_t*)qw,           \
-                                                   (const T*)sz, (T*)out, out_stride, (float*)partial,  \
-                                                   M, N, K, G / 128, ksplit)
+  if (variant == 1)                                                                                      \
+    w4a16_gemm_lds_kernel<T, MT_><<<grid, 256, 0, st>>>((const T*)x, x_stride, (const uint32_t*)qw,     \
+                                                     (const T*)sz, (T*)out, out_stride, (float*)partial, \
+                                                     M, N, K, G / 128, ksplit);                          \
+  else                                                                                                   \
+    w4a16_gemm_kernel<T, MT_><<<grid, 256, 0, st>>>((const T*)x, x_stride, (const uint32_t*)qw,         \
+                                                 (const T*)sz, (T*)out, out_stride, (float*)partial,     \
+                                                 M, N, K, G / 128, ksplit)
   switch (mt) {
     case 1: W4_LAUNCH(1); break;
     case 2: W4_LAUNCH(2); break;
@@ -252,16 +381,18 @@ static int launch_w4a16(void* out, long out_stride, const void* x, long x_stride
 
 // y[M][N] = x[M][K] . dequant(qw, sz)^T.  Requires K % 128 == 0, N % 16 == 0,
 // G % 128 == 0, K % G == 0, 1 <= ksplit <= K/128; `partial` holds ksplit*M*N
-// floats when ksplit > 1.
+// floats when ksplit > 1.  variant 0: waves split K (one 64-row tile group per
+// workgroup, x straight from L2); variant 1: waves split N and share x in LDS.
 VDAMD_API int vdamd_w4a16_gemm(void* out, long out_stride, const void* x, long x_stride, const void* qw,
                                const void* sz, void* partial, int M, int N, int K, int G, int ksplit,
-                               int dtype, void* stream) {
+                               int variant, int dtype, void* stream) {
   if (M <= 0) return 0;
   if (K % 128 || N % 16 || G % 128 || K % G || ksplit < 1 || ksplit > K / 128) return -1;
   if (ksplit > 1 && partial == nullptr) return -2;
+  if (variant != 0 && variant != 1) return -4;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DT_BF16) return launch_w4a16<bf16_t>(out, out_stride, x, x_stride, qw, sz, partial, M, N, K, G, ksplit, st);
-  if (dtype == DT_F16) return launch_w4a16<f16_t>(out, out_stride, x, x_stride, qw, sz, partial, M, N, K, G, ksplit, st);
+  if (dtype == DT_BF16) return launch_w4a16<bf16_t>(out, out_stride, x, x_stride, qw, sz, partial, M, N, K, G, ksplit, variant, st);
+  if (dtype == DT_F16) return launch_w4a16<f16_t>(out, out_stride, x, x_stride, qw, sz, partial, M, N, K, G, ksplit, variant, st);
   return -3;
 }
 

@@ -22,12 +22,13 @@ def _packed(n, k, g, dtype, seed=0):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("n,k,g", [(256, 512, 128), (1040, 1024, 128), (1280, 8192, 128), (512, 1024, 256)])
 @pytest.mark.parametrize("m", [1, 7, 16, 33, 64, 130, 256])
-def test_w4a16_gemm_matches_definition(dtype, n, k, g, m):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_w4a16_gemm_matches_definition(dtype, n, k, g, m, variant):
     qw, sz = _packed(n, k, g, dtype, seed=n + k + m)
     x = torch.randn(m, k, device=DEV, dtype=dtype)
     ops.hip_available()
     from vllm_distributed_amd.ops import hip
-    y = hip.w4a16_gemm(x, qw, sz)
+    y = hip.w4a16_gemm(x, qw, sz, variant=variant)
     torch.cuda.synchronize()
     w = quant.w4_dequant(qw, sz)                         # fp32, exact (q - z) * s
     ref = x.float() @ w.t()
@@ -45,9 +46,10 @@ def test_w4a16_gemm_strided_rows_and_forced_splits():
     qw, sz = _packed(512, 2048, 128, torch.bfloat16)
     big = torch.randn(20, 4096, device=DEV, dtype=torch.bfloat16)
     x = big[:, 1024:3072]                                # row stride 4096, 16-byte aligned offset
-    y = hip.w4a16_gemm(x, qw, sz)
     ref = x.float() @ quant.w4_dequant(qw, sz).t()
-    assert (y.float() - ref).abs().max().item() <= ref.abs().max().item() * 2 ** -7
+    for variant, ksplit in ((0, None), (1, None), (0, 1), (1, 1), (0, 2), (1, 4)):
+        y = hip.w4a16_gemm(x, qw, sz, variant=variant, ksplit=ksplit)
+        assert (y.float() - ref).abs().max().item() <= ref.abs().max().item() * 2 ** -7
     assert hip.w4_choose_ksplit(16, 512, 2048) > 1 and hip.w4_choose_ksplit(16, 65536, 2048) == 1
 
 

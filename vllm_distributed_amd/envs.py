@@ -84,6 +84,10 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     # mapped round-robin onto the visible devices and torch.distributed runs on
     # gloo with host staging (RCCL refuses two ranks on one device).
     "VDAMD_SHARE_DEVICE": _bool("VDAMD_SHARE_DEVICE", False),
+    # W4A16 linears: largest batch that runs the fused 4-bit GEMM (larger ones
+    # dequantise + library GEMM); kernel variant override (0/1) for experiments.
+    "VDAMD_W4_MAX_FUSED_M": _int("VDAMD_W4_MAX_FUSED_M", 256),
+    "VDAMD_W4_VARIANT": _str("VDAMD_W4_VARIANT", None),
     # Capture decode steps in hipGraphs.
     "VDAMD_USE_HIP_GRAPH": _bool("VDAMD_USE_HIP_GRAPH", True),
     # Assert identical collective sequence numbers on all ranks (debug).

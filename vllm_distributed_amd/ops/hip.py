@@ -39,7 +39,7 @@ def load() -> ctypes.CDLL:
         "vdamd_paged_attention_prefill": [P, P, L, P, P, P, I, P, P, F, I, I, I, I, I, I, L, I, P],
         "vdamd_argmax": [P, P, I, I, L, I, P],
         "vdamd_sample": [P, P, I, I, L, P, P, P, P, P, I, P],
-        "vdamd_w4a16_gemm": [P, L, P, L, P, P, P, I, I, I, I, I, I, P],
+        "vdamd_w4a16_gemm": [P, L, P, L, P, P, P, I, I, I, I, I, I, I, P],
         "vdamd_w4_dequant": [P, P, P, I, I, I, I, P],
     }
     for name, argtypes in sigs.items():
@@ -313,13 +313,30 @@ def _w4_dims(qw: torch.Tensor, sz: torch.Tensor) -> Tuple[int, int, int]:
     return n, k, g
 
 
-def w4_choose_ksplit(m: int, n: int, k: int) -> int:
-    """Workgroups cover 64 output rows x all of K; split K until ~3 workgroups
-    per CU exist, keeping at least two 128-column blocks per wave."""
+def w4_choose_variant(m: int, n: int, k: int) -> int:
+    """0: waves split K, x from L2 (finest tiling; best for one row tile);
+    1: waves split N and share x through LDS (batches above 16 rows, when
+    there are enough 256-row workgroups to go round)."""
+    override = os.environ.get("VDAMD_W4_VARIANT")
+    if override is not None:
+        return int(override)
+    if m <= 16:
+        return 0
+    wgs = ((n // 16 + 15) // 16) * max(1, (k // 128) // 4)
+    return 1 if wgs >= 128 else 0
+
+
+def w4_choose_ksplit(m: int, n: int, k: int, variant: int = 0) -> int:
+    """Split K until ~3 workgroups per CU exist (variant 0: 64 rows per
+    workgroup, at least two 128-column blocks per wave; variant 1: 256 rows
+    per workgroup, at least four blocks per workgroup)."""
     mt = min(4, (m + 15) // 16)
-    base = ((n // 16 + 3) // 4) * ((m + 16 * mt - 1) // (16 * mt))
-    want = (768 + base - 1) // base
-    return max(1, min(want, (k // 128) // 8))
+    mz = (m + 16 * mt - 1) // (16 * mt)
+    if variant == 1:
+        base = ((n // 16 + 15) // 16) * mz
+        return max(1, min((512 + base - 1) // base, (k // 128) // 4))
+    base = ((n // 16 + 3) // 4) * mz
+    return max(1, min((768 + base - 1) // base, (k // 128) // 8))
 
 
 def w4_dequant(qw: torch.Tensor, sz: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -332,7 +349,8 @@ def w4_dequant(qw: torch.Tensor, sz: torch.Tensor, out: Optional[torch.Tensor] =
     return out[:n * k].view(n, k) if out.dim() == 1 else out
 
 
-def w4a16_gemm(x: torch.Tensor, qw: torch.Tensor, sz: torch.Tensor) -> torch.Tensor:
+def w4a16_gemm(x: torch.Tensor, qw: torch.Tensor, sz: torch.Tensor, variant: Optional[int] = None,
+               ksplit: Optional[int] = None) -> torch.Tensor:
     """``x [M, K]`` (bf16/fp16, rows 16-byte aligned) times the packed weights."""
     n, k, g = _w4_dims(qw, sz)
     assert x.dim() == 2 and x.shape[1] == k and x.dtype == sz.dtype and x.stride(1) == 1
@@ -341,9 +359,13 @@ def w4a16_gemm(x: torch.Tensor, qw: torch.Tensor, sz: torch.Tensor) -> torch.Ten
     out = torch.empty((m, n), dtype=x.dtype, device=x.device)
     if m == 0:
         return out
-    ksplit = w4_choose_ksplit(m, n, k)
+    if variant is None:
+        variant = w4_choose_variant(m, n, k)
+    if ksplit is None:
+        ksplit = w4_choose_ksplit(m, n, k, variant)
+    assert 1 <= ksplit <= k // 128
     partial = torch.empty(ksplit * m * n, dtype=torch.float32, device=x.device) if ksplit > 1 else None
     _check(_LIB.vdamd_w4a16_gemm(out.data_ptr(), n, x.data_ptr(), x.stride(0), qw.data_ptr(), sz.data_ptr(),
                                  None if partial is None else partial.data_ptr(), m, n, k, g, ksplit,
-                                 _dt(x), _stream()), "w4a16_gemm")
+                                 variant, _dt(x), _stream()), "w4a16_gemm")
     return out
