@@ -259,7 +259,8 @@ def test_sample_respects_filters_statistically():
         assert probs[3, tok[3]] >= 0.2 * sp[3, 0] - 1e-7
 
 
-def test_microbatch_overlap_path_matches_plain_decode(monkeypatch):
+@pytest.mark.parametrize("sp", ["0", "force"])
+def test_microbatch_overlap_path_matches_plain_decode(monkeypatch, sp):
     """The two-stream micro-batch schedule (forced on at TP=1, where the
     all-reduce is an identity) must reproduce the plain forward: checks the
     stream / event choreography and the metadata slicing, eagerly and as a
@@ -269,6 +270,8 @@ def test_microbatch_overlap_path_matches_plain_decode(monkeypatch):
     from vllm_distributed_amd.models.layers.attention import AttentionMetadata
     from vllm_distributed_amd.parallel import state as pstate
     monkeypatch.setenv("VDAMD_TP_OVERLAP", "force")
+    # "force": the sequence-parallel variant (reduce-scatter / shard norm / all-gather chains)
+    monkeypatch.setenv("VDAMD_SEQUENCE_PARALLEL", sp)
     pstate.destroy_model_parallel()
     llm = LLM(model="llama-tiny", device="cuda", dtype="bfloat16", max_model_len=512, max_num_seqs=64,
               gpu_memory_utilization=0.3, enable_prefix_caching=False, enforce_eager=True,
@@ -302,7 +305,11 @@ def test_microbatch_overlap_path_matches_plain_decode(monkeypatch):
     with torch.inference_mode():
         stream = runner.comm_stream
         runner.comm_stream = None
+        monkeypatch.setenv("VDAMD_SEQUENCE_PARALLEL", "0")
         ref = runner._forward_decode(md, ids, posd).float().clone()
+        monkeypatch.setenv("VDAMD_SEQUENCE_PARALLEL", sp)
+        if sp == "force":        # plain (single-stream) sequence-parallel forward
+            torch.testing.assert_close(runner._forward_decode(md, ids, posd).float(), ref, rtol=3e-2, atol=3e-2)
         runner.comm_stream = stream
         assert runner._overlap_bounds(B) == [(0, 24), (24, 48)]
         for _ in range(3):

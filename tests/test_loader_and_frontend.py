@@ -159,3 +159,28 @@ def test_kv_manager_prefix_sharing_and_eviction():
     kv.free(big)
     d = Request("d", list(range(10)), SamplingParams())
     assert kv.get_computed_blocks(d)[1] == 0
+
+
+def test_sequence_parallel_forward_matches_replicated_forward(monkeypatch):
+    """The row-sharded residual stream (reduce-scatter / norm / all-gather) is
+    the same arithmetic as all-reduce + replicated norm; on one rank the
+    collectives are identities, so tokens must be identical."""
+    from vllm_distributed_amd.models.llama import LlamaForCausalLM
+    calls = {"n": 0}
+    orig = LlamaForCausalLM.forward_sequence_parallel
+
+    def counted(self, *a, **k):
+        calls["n"] += 1
+        return orig(self, *a, **k)
+    monkeypatch.setattr(LlamaForCausalLM, "forward_sequence_parallel", counted)
+    outs = {}
+    for mode in ("0", "force"):
+        monkeypatch.setenv("VDAMD_SEQUENCE_PARALLEL", mode)
+        llm = LLM(model="llama-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,
+                  num_gpu_blocks_override=64, max_num_seqs=8)
+        o = llm.generate([[5, 9, 200, 17], list(range(10, 50))],
+                         SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True))
+        outs[mode] = [x.outputs[0].token_ids for x in o]
+        llm.shutdown()
+        pstate.destroy_model_parallel()
+    assert calls["n"] > 0 and outs["0"] == outs["force"]

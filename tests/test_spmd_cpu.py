@@ -36,13 +36,14 @@ eng.shutdown()
 """
 
 
-def _run(world, async_sched=False):
+def _run(world, async_sched=False, sp="0"):
     port = get_open_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VLLM_LOGGING_LEVEL="WARNING",
-                   GLOO_SOCKET_IFNAME="lo", OMP_NUM_THREADS="2", ASYNC="1" if async_sched else "0")
+                   GLOO_SOCKET_IFNAME="lo", OMP_NUM_THREADS="2", ASYNC="1" if async_sched else "0",
+                   VDAMD_SEQUENCE_PARALLEL=sp)
         procs.append(subprocess.Popen([sys.executable, "-c", SCRIPT.format(root=ROOT)], env=env,
                                       stdout=subprocess.PIPE, text=True))
     outs = []
@@ -60,6 +61,9 @@ def test_spmd_tp2_matches_single_process_on_every_rank():
     got = _run(2)
     assert got[0] == ref and got[1] == ref
     got = _run(2, async_sched=True)        # one step scheduled ahead on every rank
+    assert got[0] == ref and got[1] == ref
+    # sequence-parallel residual stream wherever the token count divides by TP
+    got = _run(2, sp="force")
     assert got[0] == ref and got[1] == ref
 
 

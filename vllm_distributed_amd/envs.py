@@ -80,6 +80,11 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     # "auto" (TP>1 and batch >= MIN_BATCH), "0" (off), "force" (also at TP=1; tests).
     "VDAMD_TP_OVERLAP": _str("VDAMD_TP_OVERLAP", "auto"),
     "VDAMD_TP_OVERLAP_MIN_BATCH": _int("VDAMD_TP_OVERLAP_MIN_BATCH", 512),
+    # Sequence-parallel residual stream under TP (reduce-scatter -> norm on a
+    # 1/TP row shard -> all-gather instead of all-reduce -> replicated norm):
+    # "auto" (TP>1, single pipeline stage, >= MIN_TOKENS rows), "0", "force".
+    "VDAMD_SEQUENCE_PARALLEL": _str("VDAMD_SEQUENCE_PARALLEL", "auto"),
+    "VDAMD_SP_MIN_TOKENS": _int("VDAMD_SP_MIN_TOKENS", 512),
     # Rehearsal of multi-rank GPU paths on fewer devices than ranks: ranks are
     # mapped round-robin onto the visible devices and torch.distributed runs on
     # gloo with host staging (RCCL refuses two ranks on one device).

@@ -283,9 +283,11 @@ class VocabParallelEmbedding(nn.Module):
         if n < self.rows:
             param.data[n:].zero_()
 
-    def forward(self, ids: torch.Tensor) -> torch.Tensor:
+    def forward(self, ids: torch.Tensor, reduce: bool = True) -> torch.Tensor:
+        """``reduce=False`` returns this rank's partial rows (zero for ids of
+        other shards); the caller owns the reduction."""
         out = ops.embedding(ids, self.weight, self.vocab_start, masked=self.tp > 1)
-        if self.tp > 1:
+        if reduce and self.tp > 1:
             out = tensor_model_parallel_all_reduce(out)
         return out
 

@@ -13,9 +13,9 @@ from typing import Dict, Iterable, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import envs, ops
 from ..config import VllmConfig
-from ..parallel.state import get_pp_group
+from ..parallel.state import get_pp_group, get_tp_group
 from .layers.attention import Attention, RMSNorm, get_forward_context
 from .layers.linear import (ColumnParallelLinear, ParallelLMHead, QKVParallelLinear, QuantSpec,
                             RowParallelLinear, VocabParallelEmbedding, quantized_linears)
@@ -165,6 +165,8 @@ class LlamaForCausalLM(nn.Module):
 
     def forward(self, input_ids: Optional[torch.Tensor], positions: torch.Tensor,
                 intermediate: Optional[IntermediateTensors] = None):
+        if intermediate is None and self.sequence_parallel_ok(positions.shape[0]):
+            return self.forward_sequence_parallel(input_ids, positions)
         if self.is_first:
             hidden = self.embed_tokens(input_ids)
             residual = None
@@ -176,6 +178,93 @@ class LlamaForCausalLM(nn.Module):
             return IntermediateTensors(hidden, residual)
         hidden, _ = self.norm(hidden, residual)
         return hidden
+
+    # ---------------------------------------------------- sequence parallel
+    def sequence_parallel_ok(self, num_tokens: int) -> bool:
+        """Whether a batch of ``num_tokens`` rows runs with the residual stream
+        row-sharded over the TP group.  The all-reduce after each row-parallel
+        GEMM becomes reduce-scatter + all-gather (the same bytes on the wire)
+        and the add+RMSNorm between them touches ``1/TP`` of the rows, where
+        the replicated form makes every rank normalise all of them."""
+        mode = envs.VDAMD_SEQUENCE_PARALLEL
+        if mode == "0" or not (self.is_first and self.is_last):
+            return False
+        w = get_tp_group().world_size
+        if num_tokens % w:
+            return False
+        if mode == "force":
+            return True
+        return w > 1 and num_tokens >= envs.VDAMD_SP_MIN_TOKENS
+
+    def forward_sequence_parallel(self, input_ids: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
+        tp = get_tp_group()
+        layers = list(self.layers.values())
+        part = self.embed_tokens(input_ids, reduce=False)
+        # residual shard starts at zero so every step below is the same fused add+norm
+        res = torch.zeros((part.shape[0] // tp.world_size, part.shape[1]), dtype=part.dtype, device=part.device)
+        norm = layers[0].input_layernorm if layers else self.norm
+        for li, layer in enumerate(layers):
+            normed, res = norm(tp.reduce_scatter(part), res)
+            part = layer.self_attn(positions, tp.all_gather(normed, dim=0), reduce=False)
+            normed, res = layer.post_attention_layernorm(tp.reduce_scatter(part), res)
+            part = layer.mlp(tp.all_gather(normed, dim=0), reduce=False)
+            norm = layers[li + 1].input_layernorm if li + 1 < len(layers) else self.norm
+        hidden, _ = norm(tp.reduce_scatter(part), res)
+        return tp.all_gather(hidden, dim=0)
+
+    def forward_overlapped_sp(self, input_ids: torch.Tensor, positions: torch.Tensor, metadatas, bounds,
+                              comm_stream) -> torch.Tensor:
+        """``forward_overlapped`` with the sequence-parallel residual stream: the
+        communication stream runs reduce-scatter -> add+RMSNorm on the row
+        shard -> all-gather for one micro-batch while the compute stream runs
+        the other micro-batch's GEMMs.  Buffers the communication stream
+        writes are allocated on the compute stream and kept referenced until
+        the compute stream has waited for the chain that uses them."""
+        from .layers.attention import set_forward_context
+        tp = get_tp_group()
+        w = tp.world_size
+        main = torch.cuda.current_stream()
+        layers = list(self.layers.values())
+        n = len(bounds)
+        pos = [positions[s:e] for s, e in bounds]
+        part_all = self.embed_tokens(input_ids, reduce=False)
+        res = [torch.zeros(((e - s) // w, part_all.shape[1]), dtype=part_all.dtype, device=part_all.device)
+               for s, e in bounds]
+        h: List[Optional[torch.Tensor]] = [None] * n
+        ready: List[Optional[torch.cuda.Event]] = [None] * n
+        keep: List[Optional[tuple]] = [None] * n
+
+        def reduce_norm_gather_async(i: int, part: torch.Tensor, norm) -> None:
+            shard = torch.empty_like(res[i])
+            full = torch.empty_like(part)
+            produced = torch.cuda.Event()
+            produced.record(main)
+            comm_stream.wait_event(produced)
+            with torch.cuda.stream(comm_stream):
+                tp.reduce_scatter(part, out=shard)
+                normed, res[i] = norm(shard, res[i])
+                tp.all_gather_into(full, normed)
+                done = torch.cuda.Event()
+                done.record(comm_stream)
+            h[i], ready[i], keep[i] = full, done, (part, shard, normed)
+
+        first_norm = layers[0].input_layernorm if layers else self.norm
+        for i, (s, e) in enumerate(bounds):
+            reduce_norm_gather_async(i, part_all[s:e], first_norm)
+        for li, layer in enumerate(layers):
+            nxt = layers[li + 1].input_layernorm if li + 1 < len(layers) else self.norm
+            for i in range(n):
+                main.wait_event(ready[i])
+                set_forward_context(metadatas[i], pos[i])
+                reduce_norm_gather_async(i, layer.self_attn(pos[i], h[i], reduce=False),
+                                         layer.post_attention_layernorm)
+            for i in range(n):
+                main.wait_event(ready[i])
+                reduce_norm_gather_async(i, layer.mlp(h[i], reduce=False), nxt)
+        for i in range(n):
+            main.wait_event(ready[i])
+        set_forward_context(None)
+        return torch.cat(h)
 
     def forward_overlapped(self, input_ids: torch.Tensor, positions: torch.Tensor, metadatas, bounds,
                            comm_stream) -> torch.Tensor:

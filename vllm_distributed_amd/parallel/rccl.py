@@ -60,12 +60,13 @@ def load_rccl() -> ctypes.CDLL:
     lib.ncclCommInitRank.argtypes = [ctypes.POINTER(P), I, ncclUniqueId, I]
     lib.ncclAllReduce.argtypes = [P, P, Z, I, I, P, P]
     lib.ncclAllGather.argtypes = [P, P, Z, I, P, P]
+    lib.ncclReduceScatter.argtypes = [P, P, Z, I, I, P, P]
     lib.ncclBroadcast.argtypes = [P, P, Z, I, I, P, P]
     lib.ncclSend.argtypes = [P, Z, I, I, P, P]
     lib.ncclRecv.argtypes = [P, Z, I, I, P, P]
     lib.ncclCommDestroy.argtypes = [P]
-    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllReduce", "ncclAllGather", "ncclBroadcast",
-                 "ncclSend", "ncclRecv", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd"):
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllReduce", "ncclAllGather", "ncclReduceScatter",
+                 "ncclBroadcast", "ncclSend", "ncclRecv", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd"):
         getattr(lib, name).restype = I
     _lib = lib
     return lib
@@ -115,6 +116,12 @@ class RcclCommunicator:
         assert out.is_contiguous() and x.is_contiguous() and out.numel() == x.numel() * self.world_size
         _check(self.lib.ncclAllGather(x.data_ptr(), out.data_ptr(), x.numel(), _NCCL_DT[x.dtype], self.comm,
                                       self._stream()))
+
+    def reduce_scatter(self, out: torch.Tensor, x: torch.Tensor) -> None:
+        """``out`` = this rank's ``1/world`` slice (along dim 0) of the sum of ``x``."""
+        assert out.is_contiguous() and x.is_contiguous() and x.numel() == out.numel() * self.world_size
+        _check(self.lib.ncclReduceScatter(x.data_ptr(), out.data_ptr(), out.numel(), _NCCL_DT[x.dtype],
+                                          _NCCL_SUM, self.comm, self._stream()))
 
     def broadcast(self, x: torch.Tensor, src: int) -> None:
         assert x.is_contiguous()

@@ -183,6 +183,39 @@ class GroupCoordinator:
         shape[dim] *= self.world_size
         return out.reshape(shape)
 
+    def all_gather_into(self, out: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        """Concatenate every rank's ``x`` along dim 0 into the caller's ``out``."""
+        if self.world_size == 1:
+            out.copy_(x)
+            return out
+        self._note("all_gather", x)
+        if self.rccl is not None:
+            self.rccl.all_gather(out, x)
+        else:
+            self._td_all_gather(out, x)
+        return out
+
+    def reduce_scatter(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Sum over the group, keeping rows ``[r*n, (r+1)*n)`` of dim 0 on rank
+        ``r`` (``n = x.shape[0] / world``).  gloo has no reduce-scatter: there
+        the sum is an all-reduce and the slice is copied out."""
+        if self.world_size == 1:
+            return x
+        assert x.shape[0] % self.world_size == 0 and x.is_contiguous()
+        n = x.shape[0] // self.world_size
+        if out is None:
+            out = torch.empty((n,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        self._note("reduce_scatter", x)
+        if self.rccl is not None:
+            self.rccl.reduce_scatter(out, x)
+        elif dist.get_backend(self.device_group) == "nccl":
+            dist.reduce_scatter_tensor(out, x, group=self.device_group)
+        else:
+            full = x.clone()
+            self._td_all_reduce(full)
+            out.copy_(full[self.rank_in_group * n:(self.rank_in_group + 1) * n])
+        return out
+
     def broadcast(self, x: torch.Tensor, src: int = 0) -> torch.Tensor:
         """``src`` is a rank *within the group*."""
         if self.world_size == 1:

@@ -376,6 +376,9 @@ class ModelRunner:
             set_forward_context(None)
             return out
         mds = [self._slice_decode_metadata(md, s, e) for s, e in bounds]
+        sp_ok = getattr(self.model, "sequence_parallel_ok", None)
+        if sp_ok is not None and sp_ok(md.num_decodes) and all(sp_ok(e - s) for s, e in bounds):
+            return self.model.forward_overlapped_sp(input_ids, positions, mds, bounds, self.comm_stream)
         return self.model.forward_overlapped(input_ids, positions, mds, bounds, self.comm_stream)
 
     def _is_output_rank(self) -> bool:
