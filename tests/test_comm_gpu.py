@@ -76,8 +76,10 @@ def test_rccl_binding_single_rank_and_graph_capture():
     out = torch.empty_like(x)
     comm.all_gather(out, x)
     comm.broadcast(x, 0)
+    rs = torch.empty_like(x)
+    comm.reduce_scatter(rs, x)
     torch.cuda.synchronize()
-    assert torch.equal(x, ref) and torch.equal(out, ref)
+    assert torch.equal(x, ref) and torch.equal(out, ref) and torch.equal(rs, ref)
     g = torch.cuda.CUDAGraph()
     y = torch.full((1024,), 3.0, device="cuda", dtype=torch.bfloat16)
     with torch.cuda.graph(g):
@@ -171,13 +173,14 @@ eng.shutdown()
 """
 
 
-def _run_spmd_shared(world, async_sched):
+def _run_spmd_shared(world, async_sched, sp="0"):
     port = get_open_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), VLLM_LOGGING_LEVEL="WARNING", GLOO_SOCKET_IFNAME="lo",
-                   VDAMD_SHARE_DEVICE="1", ASYNC="1" if async_sched else "0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   VDAMD_SHARE_DEVICE="1", ASYNC="1" if async_sched else "0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   VDAMD_SEQUENCE_PARALLEL=sp)
         procs.append(subprocess.Popen([sys.executable, "-c", SPMD_SCRIPT.format(root=ROOT)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -195,8 +198,8 @@ def test_spmd_tensor_parallel_ranks_sharing_one_gpu_match_single_rank():
     onto one device.  bf16 partial sums are reduced in a different order than
     the unsharded GEMM, so the first tokens (largest margins) are compared."""
     ref = _run_spmd_shared(1, False)[0]["tokens"]
-    for async_sched in (False, True):
-        got = _run_spmd_shared(2, async_sched)
+    for async_sched, sp in ((False, "0"), (True, "0"), (False, "force")):
+        got = _run_spmd_shared(2, async_sched, sp)
         assert got[0]["tokens"] == got[1]["tokens"]
         assert got[0]["direct_ar"] and got[1]["direct_ar"]
         assert [t[:2] for t in got[0]["tokens"]] == [t[:2] for t in ref]

@@ -200,7 +200,10 @@ class GroupCoordinator:
         ``r`` (``n = x.shape[0] / world``).  gloo has no reduce-scatter: there
         the sum is an all-reduce and the slice is copied out."""
         if self.world_size == 1:
-            return x
+            if out is None:
+                return x
+            out.copy_(x)
+            return out
         assert x.shape[0] % self.world_size == 0 and x.is_contiguous()
         n = x.shape[0] // self.world_size
         if out is None:
