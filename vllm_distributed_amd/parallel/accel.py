@@ -23,15 +23,43 @@ def _all_agree(group: GroupCoordinator, ok: bool) -> bool:
     return all(flags)
 
 
-def _verify_all_reduce(group: GroupCoordinator, fn) -> bool:
+def _verify_all_reduce(group: GroupCoordinator, fn, sizes=(4096, 1 << 19, 3 << 20)) -> bool:
+    """Sums of several message sizes (they select different algorithms: the
+    direct all-reduce is one-shot up to 512 KiB and two-shot above) against
+    ``torch.distributed``."""
     try:
-        x = torch.arange(4096, dtype=torch.float32, device=group.device) * (group.rank_in_group + 1)
-        x = x.to(torch.bfloat16)
-        ref = x.clone()
-        group._td_all_reduce(ref)
-        out = fn(x.clone())
+        for n in sizes:
+            x = (torch.arange(n, dtype=torch.float32, device=group.device) % 251) * (group.rank_in_group + 1)
+            x = (x / 64).to(torch.bfloat16)
+            ref = x.clone()
+            group._td_all_reduce(ref)
+            out = fn(x.clone())
+            torch.cuda.synchronize()
+            if out is None or not torch.allclose(out.float(), ref.float(), rtol=2e-2, atol=1e-1):
+                return False
+        return True
+    except Exception as e:  # noqa: BLE001
+        logger.warning("collective self-check raised %r", e)
+        return False
+
+
+def _verify_gather_scatter(group: GroupCoordinator, comm) -> bool:
+    """all-gather and reduce-scatter of the direct binding against their definitions."""
+    try:
+        w, r = group.world_size, group.rank_in_group
+        x = torch.full((256, 64), float(r + 1), dtype=torch.bfloat16, device=group.device)
+        out = torch.empty((w * 256, 64), dtype=torch.bfloat16, device=group.device)
+        comm.all_gather(out, x)
+        want = torch.arange(1, w + 1, device=group.device, dtype=torch.float32).repeat_interleave(256)
+        y = (torch.arange(w * 128, device=group.device, dtype=torch.float32) % 16).view(-1, 1).expand(-1, 64)
+        y = (y * (r + 1)).to(torch.bfloat16).contiguous()
+        rs = torch.empty((128, 64), dtype=torch.bfloat16, device=group.device)
+        comm.reduce_scatter(rs, y)
         torch.cuda.synchronize()
-        return out is not None and torch.allclose(out.float(), ref.float(), rtol=2e-2, atol=1e-1)
+        scale = w * (w + 1) / 2
+        want_rs = (torch.arange(r * 128, (r + 1) * 128, device=group.device, dtype=torch.float32) % 16) * scale
+        return bool(torch.equal(out[:, 0].float(), want)
+                    and torch.allclose(rs[:, 0].float(), want_rs, rtol=2e-2, atol=1e-1))
     except Exception as e:  # noqa: BLE001
         logger.warning("collective self-check raised %r", e)
         return False
@@ -51,7 +79,7 @@ def attach_accelerated_collectives(pc: ParallelConfig) -> None:
             except Exception as e:  # noqa: BLE001
                 logger.warning("RCCL direct binding unavailable for %s: %r", group.name, e)
             ok = comm is not None and _verify_all_reduce(
-                group, lambda t: (comm.all_reduce(t), t)[1])
+                group, lambda t: (comm.all_reduce(t), t)[1]) and _verify_gather_scatter(group, comm)
             if _all_agree(group, ok):
                 group.rccl = comm
                 logger.info("%s group: direct RCCL communicator active", group.name)
@@ -66,7 +94,8 @@ def attach_accelerated_collectives(pc: ParallelConfig) -> None:
                 car = CustomAllReduce(group, max_bytes=envs.VDAMD_CUSTOM_ALL_REDUCE_MAX_BYTES)
             except Exception as e:  # noqa: BLE001
                 logger.warning("direct all-reduce unavailable: %r", e)
-            ok = car is not None and _verify_all_reduce(group, car.all_reduce)
+            ok = car is not None and _verify_all_reduce(
+                group, car.all_reduce, [n for n in (4096, 1 << 19, 3 << 20) if 2 * n <= car.max_bytes])
             if _all_agree(group, ok):
                 group.custom_ar = car
                 logger.info("tp group: direct (peer-mapped) all-reduce active")
