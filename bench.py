@@ -26,6 +26,36 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _fit_batch_per_gpu(args) -> int:
+    """Largest per-GPU batch (<= --batch-per-gpu) whose KV cache fits next to
+    the weights for the requested number of steps.  Sized for N=1, where one
+    GPU holds all the weights, and used at every N so the per-GPU work is the
+    same along the scaling curve."""
+    if args.device != "cuda":
+        return args.batch_per_gpu
+    import math
+
+    import torch
+
+    from vllm_distributed_amd.config import ModelConfig
+    from vllm_distributed_amd.models.loader import hf_weight_shapes
+    mc = ModelConfig(model=args.model, dtype=args.dtype, load_format="dummy")
+    esz = 2 if args.dtype != "float32" else 4
+    weights = sum(math.prod(s) for s in hf_weight_shapes(mc).values()) * esz
+    total = torch.cuda.get_device_properties(int(os.environ.get("LOCAL_RANK", "0"))).total_memory
+    kv_budget = total * args.gpu_memory_utilization - weights - (10 << 30)     # activations, graphs, reserve
+    per_token = 2 * mc.num_hidden_layers * mc.num_kv_heads * mc.head_dim * esz
+    block = 64
+    per = args.batch_per_gpu
+    while per > 64:
+        prefill_steps = -(-per * args.prompt_len // 16384)
+        tokens = args.prompt_len + prefill_steps + args.warmup + args.steps + 6
+        if per * (-(-tokens // block)) * block * per_token <= kv_budget:
+            break
+        per -= 64
+    return per
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -61,9 +91,12 @@ def main() -> None:
     from vllm_distributed_amd.engine.llm_engine import LLMEngine
     from vllm_distributed_amd.sampling_params import SamplingParams
 
-    batch = args.batch_per_gpu * n
+    # prefill budget scales with N so the batch is prefilled in the same number of steps at every N
+    prefill_budget = 16384 * n
+    per_gpu = _fit_batch_per_gpu(args)
+    batch = per_gpu * n
     # continuous batching staggers the sequences by the number of prefill steps
-    prefill_steps = -(-batch * args.prompt_len // max(16384, batch))
+    prefill_steps = -(-batch * args.prompt_len // max(prefill_budget, batch))
     total_new = args.warmup + args.steps + prefill_steps + 10
     max_len = args.prompt_len + total_new + 16
     backend = args.executor
@@ -72,11 +105,16 @@ def main() -> None:
     engine = LLMEngine.from_engine_args(EngineArgs(
         model=args.model, dtype=args.dtype, load_format="dummy", tensor_parallel_size=n, device=args.device,
         distributed_executor_backend=backend, max_model_len=max_len, max_num_seqs=batch,
-        max_num_batched_tokens=max(16384, batch), enable_prefix_caching=False,
+        max_num_batched_tokens=max(prefill_budget, batch), enable_prefix_caching=False,
         enforce_eager=args.enforce_eager, max_capture_size=batch, hip_graph_sizes=[batch],
         gpu_memory_utilization=args.gpu_memory_utilization, seed=0, async_scheduling=not args.sync_scheduling))
     vocab = engine.model_config.vocab_size
     rng = np.random.default_rng(1234)
+    # the KV cache the workers could actually allocate has the last word on the batch
+    blocks_per_seq = -(-(args.prompt_len + total_new) // engine.vllm_config.cache_config.block_size)
+    fit = engine.vllm_config.cache_config.num_gpu_blocks // blocks_per_seq
+    if fit < batch:
+        batch = max(8 * n, fit // (8 * n) * (8 * n))
 
     on_gpu = args.device == "cuda"
 

@@ -151,9 +151,9 @@ class ModelRunner:
     def profile_run(self) -> None:
         """Forward of the largest token batch with no KV cache bound, to expose
         peak activation memory to the caller's measurement."""
-        t = min(self.max_num_tokens, self.max_model_len)
+        t = self.max_num_tokens         # a step packs many sequences: not bounded by max_model_len
         ids = torch.zeros(t, dtype=torch.int32, device=self.device)
-        pos = torch.arange(t, dtype=torch.int32, device=self.device)
+        pos = torch.arange(t, dtype=torch.int32, device=self.device) % self.max_model_len
         set_forward_context(None, pos)
         inter = None
         if not self.pp.is_first_rank:
