@@ -327,3 +327,24 @@ def test_microbatch_overlap_path_matches_plain_decode(monkeypatch, sp):
             torch.testing.assert_close(out.float(), ref, rtol=3e-2, atol=3e-2)
     llm.shutdown()
     pstate.destroy_model_parallel()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,n,k", [(1, 256, 512), (7, 1040, 1024), (16, 1280, 8192), (33, 512, 2048),
+                                   (64, 2064, 1024), (100, 768, 3584), (128, 1024, 4096)])
+def test_skinny_gemm_matches_fp32_reference(dtype, m, n, k):
+    from vllm_distributed_amd.ops import hip
+    assert ops.hip_available()
+    x = _rand(m, k).to(dtype)
+    w = (_rand(n, k) * 0.05).to(dtype)
+    ref = x.float() @ w.float().t()
+    tol = ref.abs().max().item() * (2 ** -7 if dtype == torch.bfloat16 else 2 ** -9)
+    for ntw, ksplit in ((None, None), (1, 1), (2, 2), (4, 1), (1, 4)):
+        y = hip.skinny_gemm(x, w, ntw, ksplit)
+        assert y.shape == (m, n)
+        assert (y.float() - ref).abs().max().item() <= tol, (ntw, ksplit)
+    # strided views (a column slice of a fused activation, a row slice of a weight)
+    xb = _rand(m, 2 * k).to(dtype)
+    y = hip.skinny_gemm(xb[:, k:], w[16:])
+    ref = xb[:, k:].float() @ w[16:].float().t()
+    assert (y.float() - ref).abs().max().item() <= tol

@@ -89,6 +89,8 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     # mapped round-robin onto the visible devices and torch.distributed runs on
     # gloo with host staging (RCCL refuses two ranks on one device).
     "VDAMD_SHARE_DEVICE": _bool("VDAMD_SHARE_DEVICE", False),
+    # Short-batch weight-streaming GEMM for long-reduction shapes (0 = library GEMM only).
+    "VDAMD_SKINNY_GEMM": _bool("VDAMD_SKINNY_GEMM", True),
     # W4A16 linears: largest batch that runs the fused 4-bit GEMM (larger ones
     # dequantise + library GEMM); kernel variant override (0/1) for experiments.
     "VDAMD_W4_MAX_FUSED_M": _int("VDAMD_W4_MAX_FUSED_M", 256),

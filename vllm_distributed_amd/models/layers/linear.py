@@ -126,7 +126,7 @@ class _LinearBase(nn.Module):
     def _matmul(self, x: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
         if self.qw is not None:
             return ops.w4a16_linear(x, self.qw, self.sz, bias)
-        return F.linear(x, self.weight, bias)
+        return ops.linear(x, self.weight, bias)
 
 
 def divide(a: int, b: int) -> int:

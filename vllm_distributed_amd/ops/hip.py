@@ -41,6 +41,7 @@ def load() -> ctypes.CDLL:
         "vdamd_sample": [P, P, I, I, L, P, P, P, P, P, I, P],
         "vdamd_w4a16_gemm": [P, L, P, L, P, P, P, I, I, I, I, I, I, I, P],
         "vdamd_w4_dequant": [P, P, P, I, I, I, I, P],
+        "vdamd_skinny_gemm": [P, L, P, L, P, L, P, I, I, I, I, I, I, P],
     }
     for name, argtypes in sigs.items():
         fn = getattr(lib, name)
@@ -368,4 +369,59 @@ def w4a16_gemm(x: torch.Tensor, qw: torch.Tensor, sz: torch.Tensor, variant: Opt
     _check(_LIB.vdamd_w4a16_gemm(out.data_ptr(), n, x.data_ptr(), x.stride(0), qw.data_ptr(), sz.data_ptr(),
                                  None if partial is None else partial.data_ptr(), m, n, k, g, ksplit,
                                  variant, _dt(x), _stream()), "w4a16_gemm")
+    return out
+
+
+# ---------------------------------------------------------- skinny bf16 GEMM
+SKINNY_MAX_M = 128
+
+
+def skinny_supported(x: torch.Tensor, w: torch.Tensor) -> bool:
+    return (x.dim() == 2 and w.dim() == 2 and 0 < x.shape[0] <= SKINNY_MAX_M and x.dtype == w.dtype
+            and x.dtype in (torch.bfloat16, torch.float16) and x.shape[1] == w.shape[1]
+            and w.shape[1] % 128 == 0 and w.shape[0] % 16 == 0 and x.stride(1) == 1 and w.stride(1) == 1
+            and x.stride(0) % 8 == 0 and w.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
+            and w.data_ptr() % 16 == 0)
+
+
+def skinny_choose(m: int, n: int, k: int) -> Tuple[int, int]:
+    """``(ntw, ksplit)``: output tiles per wave and K split.  Fewer tiles per
+    wave when N alone cannot fill the chip; then K is split until there are
+    about two workgroups per CU, keeping >= 4 column blocks per workgroup.
+    Long-K shapes (the down projection) use the measured optimum."""
+    tiles = n // 16
+    if k >= 2 * n and k >= 8192:
+        ntw = 1 if m <= 32 else (4 if m <= 64 else 2)
+        wgs = (tiles + 4 * ntw - 1) // (4 * ntw)
+        return ntw, max(1, min(4 if m <= 32 else 8, (1024 + wgs - 1) // wgs, (k // 128) // 4))
+    ntw = 4 if m <= 64 else 2
+    while ntw > 1 and (tiles + 4 * ntw - 1) // (4 * ntw) < 512:
+        ntw //= 2
+    wgs = (tiles + 4 * ntw - 1) // (4 * ntw)
+    ksplit = max(1, min((512 + wgs - 1) // wgs, (k // 128) // 4))
+    return ntw, ksplit
+
+
+def skinny_profitable(m: int, n: int, k: int) -> bool:
+    """Where this kernel beats the library GEMM on MI355X (measured,
+    benchmarks/skinny_gemm_bench.py): long reductions into a narrow output,
+    for which the library's short-batch kernels reach only 2.3-4.8 TB/s."""
+    return m <= SKINNY_MAX_M and k >= 2 * n and k >= 8192
+
+
+def skinny_gemm(x: torch.Tensor, w: torch.Tensor, ntw: Optional[int] = None, ksplit: Optional[int] = None,
+                ) -> torch.Tensor:
+    """``x [M<=128, K] @ w [N, K]^T`` streaming ``w`` once at HBM speed."""
+    assert skinny_supported(x, w), (x.shape, x.stride(), w.shape, w.stride(), x.dtype)
+    m, k = x.shape
+    n = w.shape[0]
+    a, b = skinny_choose(m, n, k)
+    ntw = a if ntw is None else ntw
+    ksplit = b if ksplit is None else ksplit
+    assert 1 <= ksplit <= k // 128
+    out = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    partial = torch.empty(ksplit * m * n, dtype=torch.float32, device=x.device) if ksplit > 1 else None
+    _check(_LIB.vdamd_skinny_gemm(out.data_ptr(), n, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
+                                  None if partial is None else partial.data_ptr(), m, n, k, ksplit, ntw,
+                                  _dt(x), _stream()), "skinny_gemm")
     return out
