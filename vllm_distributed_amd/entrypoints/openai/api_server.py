@@ -382,12 +382,14 @@ def _register_routes(app: FastAPI) -> None:
                             text = out.new_text
                             if req.echo and sent == 0:
                                 text = (out.prompt or "") + text
-                            if text or out.finished:
+                            # one event per engine output that carries tokens, even while the
+                            # detokenizer holds their text back (incomplete UTF-8, stop-string tail)
+                            if text or out.finished or len(c.token_ids) > sent:
                                 yield _sse({"id": rid, "object": "text_completion", "created": created,
                                             "model": model, "choices": [{
                                                 "index": i, "text": text, "logprobs": lp_block(out, sent),
                                                 "finish_reason": c.finish_reason, "stop_reason": c.stop_reason}]})
-                            sent = len(c.token_ids)
+                                sent = len(c.token_ids)
                             if out.finished:
                                 n_prompt += len(out.prompt_token_ids)
                                 n_out += len(c.token_ids)
@@ -493,9 +495,9 @@ def _register_routes(app: FastAPI) -> None:
                                 text = ""
                             else:
                                 text, held = held, ""
-                        if text:
+                        if text or (parser is None and len(out.outputs[0].token_ids) > sent):
                             yield chunk({"content": text}, lp=lp_content(out, sent))
-                        sent = len(out.outputs[0].token_ids)
+                            sent = len(out.outputs[0].token_ids)
                     c = final.outputs[0]
                     finish = c.finish_reason
                     if parser is not None and held:
