@@ -55,7 +55,8 @@ async def run(args) -> dict:
     result = {"ttft": [], "itl": [], "tokens": 0}
     sem = asyncio.Semaphore(args.concurrency)
     timeout = aiohttp.ClientTimeout(total=args.timeout)
-    async with aiohttp.ClientSession(timeout=timeout) as session:
+    # aiohttp caps a session at 100 connections by default: lift it, or requests queue in the client
+    async with aiohttp.ClientSession(timeout=timeout, connector=aiohttp.TCPConnector(limit=0)) as session:
         async def guarded(i: int) -> None:
             prompt = [rng.randrange(3, args.vocab_size) for _ in range(args.input_len)]
             payload = {"model": args.model, "prompt": prompt, "max_tokens": args.output_len, "temperature": 0.0,

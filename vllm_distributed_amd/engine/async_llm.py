@@ -29,6 +29,39 @@ from .llm_engine import LLMEngine
 logger = init_logger(__name__)
 
 
+class OutputCollector:
+    """Hand-off of one request's outputs from the engine thread to its
+    consumer coroutine.  When the consumer lags (slow client, busy event
+    loop) successive outputs are merged into one - cumulative fields are
+    replaced, the deltas concatenated - so the event loop's work per step is
+    bounded by the number of consumers that are keeping up, not by the batch."""
+
+    __slots__ = ("_pending", "_event")
+
+    def __init__(self) -> None:
+        self._pending = None
+        self._event = asyncio.Event()
+
+    def put(self, item) -> None:
+        cur = self._pending
+        if cur is None or isinstance(item, BaseException) or isinstance(cur, BaseException):
+            if not isinstance(cur, BaseException):
+                self._pending = item
+        else:
+            item.new_token_ids = cur.new_token_ids + item.new_token_ids
+            item.new_text = cur.new_text + item.new_text
+            self._pending = item
+        self._event.set()
+
+    async def get(self):
+        while self._pending is None:
+            await self._event.wait()
+            self._event.clear()
+        item, self._pending = self._pending, None
+        self._event.clear()
+        return item
+
+
 class AsyncLLM:
     def __init__(self, vllm_config: VllmConfig, executor_class=None, log_stats: bool = True):
         self.vllm_config = vllm_config
@@ -36,7 +69,7 @@ class AsyncLLM:
         self.tokenizer = self.engine.tokenizer
         self.metrics = EngineMetrics(vllm_config.model_config.served_model_name[0])
         self._inbox: "queue.Queue[tuple]" = queue.Queue()
-        self._queues: Dict[str, asyncio.Queue] = {}
+        self._queues: Dict[str, OutputCollector] = {}
         self._loop: Optional[asyncio.AbstractEventLoop] = None
         self._counter = itertools.count()
         self._stop = threading.Event()
@@ -51,12 +84,21 @@ class AsyncLLM:
 
     # ------------------------------------------------------------ engine thread
     def _post(self, rid: str, item) -> None:
-        q = self._queues.get(rid)
+        self._post_many([(rid, item)])
+
+    def _deliver(self, items) -> None:        # runs on the event loop
+        for rid, item in items:
+            q = self._queues.get(rid)
+            if q is not None:
+                q.put(item)
+
+    def _post_many(self, items) -> None:
+        """One loop wake-up per engine step, however many requests produced output."""
         loop = self._loop
-        if q is None or loop is None:
+        if loop is None or not items:
             return
         try:
-            loop.call_soon_threadsafe(q.put_nowait, item)
+            loop.call_soon_threadsafe(self._deliver, items)
         except RuntimeError:        # loop closed
             pass
 
@@ -79,7 +121,7 @@ class AsyncLLM:
                 now = time.time()
                 for out in outs:
                     self.metrics.observe_output(out, now)
-                    self._post(out.request_id, out)
+                self._post_many([(out.request_id, out) for out in outs])
                 stats = eng.core.stats()
                 self.metrics.observe_scheduler(stats)
                 if self._log_stats and now - last_log > 10:
@@ -135,7 +177,7 @@ class AsyncLLM:
             raise EngineDeadError(f"engine is dead: {self._dead!r}")
         self._loop = asyncio.get_running_loop()
         rid = request_id or f"cmpl-{next(self._counter)}"
-        q: asyncio.Queue = asyncio.Queue()
+        q = OutputCollector()
         self._queues[rid] = q
         self._inbox.put(("add", rid, prompt, sampling_params, priority))
         finished = False

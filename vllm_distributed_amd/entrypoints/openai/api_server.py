@@ -374,9 +374,10 @@ def _register_routes(app: FastAPI) -> None:
                 n_prompt = n_out = 0
                 try:
                     for i, g in enumerate(gens):
-                        sent = 0
+                        sent = seen = 0
                         async for out in g:
-                            if await request.is_disconnected():
+                            seen += 1
+                            if seen % 16 == 0 and await request.is_disconnected():
                                 return
                             c = out.outputs[0]
                             text = out.new_text
@@ -483,8 +484,10 @@ def _register_routes(app: FastAPI) -> None:
                 final = None
                 held = ""
                 try:
+                    seen = 0
                     async for out in gen:
-                        if await request.is_disconnected():
+                        seen += 1
+                        if seen % 16 == 0 and await request.is_disconnected():
                             return
                         final = out
                         text = out.new_text
