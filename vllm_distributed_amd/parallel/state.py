@@ -25,6 +25,7 @@ import torch.distributed as dist
 
 from .. import envs
 from ..logger import init_logger
+from ..utils import tracing
 
 logger = init_logger(__name__)
 
@@ -102,6 +103,8 @@ class GroupCoordinator:
         return self.ranks[(self.rank_in_group - 1) % self.world_size]
 
     def _note(self, op: str, t: torch.Tensor) -> None:
+        if tracing.enabled():
+            tracing.mark(f"{self.name}.{op}[{t.numel() * t.element_size()}B]")
         if self.checker is not None:
             self.checker.record(op, t.numel())
             self.checker.verify(self)

@@ -18,6 +18,7 @@ from .. import envs, ops
 from ..config import VllmConfig
 from ..engine.types import KVCacheSpec, ModelRunnerOutput, SchedulerOutput
 from ..logger import init_logger
+from ..utils.tracing import trace_range
 from ..models.layers.attention import AttentionMetadata, set_forward_context
 from ..models.loader import load_model
 from ..models.utils import IntermediateTensors
@@ -291,22 +292,24 @@ class ModelRunner:
     @torch.inference_mode()
     def execute_model(self, so: SchedulerOutput) -> Optional[ModelRunnerOutput]:
         t0 = time.perf_counter()
-        self._update_states(so)
-        self.step_count += 1
-        if so.total_num_scheduled_tokens == 0:
-            return ModelRunnerOutput(step_id=so.step_id) if self._is_output_rank() else None   # nothing to wait for
-        p = self._prepare_inputs(so)
+        with trace_range("step.prepare"):
+            self._update_states(so)
+            self.step_count += 1
+            if so.total_num_scheduled_tokens == 0:
+                return ModelRunnerOutput(step_id=so.step_id) if self._is_output_rank() else None   # nothing to wait for
+            p = self._prepare_inputs(so)
         nreq, nd, total = len(p["req_ids"]), p["num_decodes"], p["total"]
         t1 = time.perf_counter()
 
         graph = None
         if self.graphs and nd == nreq:
             graph = self._pick_graph(nreq, p["max_blocks"])
-        if graph is not None:
-            hidden = self._run_graph(graph, p)
-        else:
-            md, input_ids, positions = self._build_metadata(p)
-            hidden = self._run_eager(md, input_ids, positions, total)
+        with trace_range("step.forward.graph" if graph is not None else "step.forward.eager"):
+            if graph is not None:
+                hidden = self._run_graph(graph, p)
+            else:
+                md, input_ids, positions = self._build_metadata(p)
+                hidden = self._run_eager(md, input_ids, positions, total)
 
         # advance computed-token counts (the scheduler did the same when it scheduled)
         self.batch.num_computed[p["rows"]] += p["n_sched"]
@@ -324,7 +327,8 @@ class ModelRunner:
             else:
                 hs = hidden.index_select(0, self._to_dev(last_idx, torch.int64))
             rows_sel = p["rows"][sel]
-            tokens, logprobs_sel = self._sample(hs, rows_sel)
+            with trace_range("step.sample"):
+                tokens, logprobs_sel = self._sample(hs, rows_sel)
             b = self.batch
             if self.sampled_dev is None:
                 self.sampled_dev = torch.zeros(self.max_num_reqs, dtype=torch.int32, device=self.device)
