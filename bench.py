@@ -71,6 +71,9 @@ def main() -> None:
     ap.add_argument("--sync-scheduling", action="store_true",
                     help="schedule each step only after the previous step's tokens reached the host")
     ap.add_argument("--gpu-memory-utilization", type=float, default=0.92)
+    ap.add_argument("--simulate-tp", type=int, default=1,
+                    help="one GPU stands in for one rank of a TP group of this size (per-rank compute proxy; "
+                         "collectives move no data and the result is NOT a benchmark number)")
     ap.add_argument("--device", type=str, default="cuda", choices=["cuda", "cpu"],
                     help="cpu = gloo rehearsal of the multi-rank path with a tiny model (not a measurement)")
     args = ap.parse_args()
@@ -80,6 +83,9 @@ def main() -> None:
     import torch.distributed as dist
 
     n = args.gpus
+    if args.simulate_tp > 1:
+        assert n == 1, "--simulate-tp runs on one GPU"
+        os.environ["VDAMD_SIMULATE_TP"] = str(args.simulate_tp)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if n > 1 and world != n:
@@ -92,9 +98,10 @@ def main() -> None:
     from vllm_distributed_amd.sampling_params import SamplingParams
 
     # prefill budget scales with N so the batch is prefilled in the same number of steps at every N
-    prefill_budget = 16384 * n
+    shards = n * args.simulate_tp
+    prefill_budget = 16384 * shards
     per_gpu = _fit_batch_per_gpu(args)
-    batch = per_gpu * n
+    batch = per_gpu * shards
     # continuous batching staggers the sequences by the number of prefill steps
     prefill_steps = -(-batch * args.prompt_len // max(prefill_budget, batch))
     total_new = args.warmup + args.steps + prefill_steps + 10
@@ -180,7 +187,9 @@ def main() -> None:
         dt = {"bfloat16": "bf16", "float16": "fp16", "float32": "fp32"}[args.dtype]
         pretty = {"llama-3-70b": "Llama-3-70B", "llama-3-8b": "Llama-3-8B"}.get(args.model, args.model)
         print(json.dumps({
-            "metric": f"output tokens/sec (whole node), {pretty} {dt} TP over N GPUs, decode",
+            "metric": (f"output tokens/sec (whole node), {pretty} {dt} TP over N GPUs, decode"
+                       if args.simulate_tp == 1 else
+                       f"NOT A BENCHMARK: per-rank compute proxy, one GPU simulating rank 0 of TP={args.simulate_tp}"),
             "value": round(tps, 2), "unit": "tokens/s", "n_gpus": n, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dt,

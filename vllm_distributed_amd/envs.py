@@ -85,6 +85,10 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     # "auto" (TP>1, single pipeline stage, >= MIN_TOKENS rows), "0", "force".
     "VDAMD_SEQUENCE_PARALLEL": _str("VDAMD_SEQUENCE_PARALLEL", "auto"),
     "VDAMD_SP_MIN_TOKENS": _int("VDAMD_SP_MIN_TOKENS", 512),
+    # Single-GPU stand-in for one rank of a TP group of this size: weights are
+    # sharded for rank 0, collectives only produce shapes.  Timing proxy only -
+    # the generated tokens are meaningless.
+    "VDAMD_SIMULATE_TP": _int("VDAMD_SIMULATE_TP", 1),
     # Rehearsal of multi-rank GPU paths on fewer devices than ranks: ranks are
     # mapped round-robin onto the visible devices and torch.distributed runs on
     # gloo with host staging (RCCL refuses two ranks on one device).

@@ -276,6 +276,50 @@ class GroupCoordinator:
             dist.barrier(group=self.cpu_group)
 
 
+class SimulatedShardGroup(GroupCoordinator):
+    """One rank standing in for a TP group of ``size`` ranks, for measuring a
+    rank's compute at a TP degree on a single GPU (``VDAMD_SIMULATE_TP``).
+    Layers shard their weights for rank 0 of ``size``; collectives move no
+    data between ranks and only produce tensors of the right shape
+    (all-reduce: identity; all-gather: ``size`` copies; reduce-scatter: the
+    first ``1/size`` rows), so outputs are *not* the model's outputs."""
+
+    def __init__(self, name: str, size: int, device: torch.device):
+        super().__init__(name, [0], 0, None, None, device)
+        self.world_size = size
+
+    def all_reduce(self, x: torch.Tensor) -> torch.Tensor:
+        return x
+
+    all_reduce_ = all_reduce
+
+    def all_gather(self, x: torch.Tensor, dim: int = -1) -> torch.Tensor:
+        return torch.cat([x] * self.world_size, dim=dim)
+
+    def all_gather_into(self, out: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        out.view((self.world_size,) + tuple(x.shape)).copy_(x.unsqueeze(0).expand((self.world_size,) + tuple(x.shape)))
+        return out
+
+    def reduce_scatter(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        n = x.shape[0] // self.world_size
+        if out is None:
+            return x[:n].clone()
+        out.copy_(x[:n])
+        return out
+
+    def broadcast(self, x: torch.Tensor, src: int = 0) -> torch.Tensor:
+        return x
+
+    def broadcast_object(self, obj: Any = None, src: int = 0) -> Any:
+        return obj
+
+    def all_gather_object(self, obj: Any) -> List[Any]:
+        return [obj] * self.world_size
+
+    def barrier(self) -> None:
+        return None
+
+
 # ------------------------------------------------------------------ globals
 _WORLD: Optional[GroupCoordinator] = None
 _TP: Optional[GroupCoordinator] = None
@@ -284,6 +328,9 @@ _OWNS_PROCESS_GROUP = False
 
 
 def _single(name: str, device: torch.device) -> GroupCoordinator:
+    sim = envs.VDAMD_SIMULATE_TP
+    if name == "tp" and sim > 1:
+        return SimulatedShardGroup(name, sim, device)
     return GroupCoordinator(name, [0], 0, None, None, device)
 
 

@@ -523,7 +523,7 @@ class ModelRunner:
         if self.pp.world_size > 1:
             logger.info("hipGraph decode capture is disabled with pipeline parallelism")
             return
-        if self.tp.world_size > 1 and self.tp.rccl is None:
+        if self.tp.world_size > 1 and self.tp.rccl is None and self.tp.device_group is not None:
             # torch.distributed collectives keep host-side work objects; only the
             # direct RCCL binding is a pure stream enqueue that a capture can record
             logger.info("hipGraph decode capture needs the direct RCCL communicator: running eagerly")
