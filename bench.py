@@ -67,6 +67,9 @@ def main() -> None:
     ap.add_argument("--ttft-requests", type=int, default=5)
     ap.add_argument("--dtype", type=str, default="bfloat16")
     ap.add_argument("--enforce-eager", action="store_true")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="capture the decode step in a hipGraph also for N>1 (default there: eager - at "
+                         "thousands of sequences per GPU the launches are hidden behind ~300 us kernels)")
     ap.add_argument("--executor", type=str, default="auto", choices=["auto", "uni", "spmd"])
     ap.add_argument("--sync-scheduling", action="store_true",
                     help="schedule each step only after the previous step's tokens reached the host")
@@ -113,7 +116,7 @@ def main() -> None:
         model=args.model, dtype=args.dtype, load_format="dummy", tensor_parallel_size=n, device=args.device,
         distributed_executor_backend=backend, max_model_len=max_len, max_num_seqs=batch,
         max_num_batched_tokens=max(prefill_budget, batch), enable_prefix_caching=False,
-        enforce_eager=args.enforce_eager, max_capture_size=batch, hip_graph_sizes=[batch],
+        enforce_eager=args.enforce_eager or (n > 1 and not args.hip_graph), max_capture_size=batch, hip_graph_sizes=[batch],
         gpu_memory_utilization=args.gpu_memory_utilization, seed=0, async_scheduling=not args.sync_scheduling))
     vocab = engine.model_config.vocab_size
     rng = np.random.default_rng(1234)

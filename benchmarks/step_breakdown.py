@@ -16,7 +16,11 @@ t0, t1 = int(step[0]["Start_Timestamp"]), int(step[-1]["End_Timestamp"])
 agg = collections.defaultdict(lambda: [0, 0])
 for r in step:
     n = r["Kernel_Name"]
-    n = n[:n.index("(")] if "(" in n and not n.startswith("Cijk") else n
+    if not n.startswith(("Cijk", "Custom_Cijk", "_Z")):
+        n = n.replace("void ", "").replace("(anonymous namespace)::", "")
+        for stop in ("<", "("):
+            if stop in n:
+                n = n[:n.index(stop)]
     n = n[:64]
     agg[n][0] += 1
     agg[n][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
