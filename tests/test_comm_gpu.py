@@ -203,3 +203,59 @@ def test_spmd_tensor_parallel_ranks_sharing_one_gpu_match_single_rank():
         assert got[0]["tokens"] == got[1]["tokens"]
         assert got[0]["direct_ar"] and got[1]["direct_ar"]
         assert [t[:2] for t in got[0]["tokens"]] == [t[:2] for t in ref]
+
+
+@pytest.mark.parametrize("tp,pp", [(1, 2), (2, 1)])
+def test_head_plus_remote_worker_sharing_one_gpu(monkeypatch, tp, pp):
+    """The distributed executor on the GPU: the head spawns rank 0, a `remote`
+    worker process registers over TCP and becomes rank 1 (second pipeline stage,
+    or the other half of the TP group); both are mapped onto the one device.
+    Exercises placement, the RPC fan-out, (hidden, residual) send/recv between
+    stages and sharded HIP-kernel execution under the real worker processes."""
+    from vllm_distributed_amd import SamplingParams
+    from vllm_distributed_amd.engine.arg_utils import EngineArgs
+    from vllm_distributed_amd.engine.llm_engine import LLMEngine
+    from vllm_distributed_amd.parallel import state as pstate
+
+    prompts = [[5, 9, 200, 17, 3, 3, 8], list(range(10, 90)), [7, 7, 7]]
+
+    def generate(engine):
+        sp = SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True)
+        ids = [engine.add_request(None, p, sp) for p in prompts]
+        final = {}
+        while engine.has_unfinished_requests():
+            for o in engine.step():
+                if o.finished:
+                    final[o.request_id] = o.outputs[0].token_ids
+        return [final[i] for i in ids]
+
+    common = dict(model="llama-tiny", device="cuda", dtype="bfloat16", max_model_len=256,
+                  num_gpu_blocks_override=64, max_num_seqs=8, gpu_memory_utilization=0.2)
+    pstate.destroy_model_parallel()
+    eng = LLMEngine.from_engine_args(EngineArgs(**common))
+    ref = generate(eng)
+    eng.shutdown()
+    pstate.destroy_model_parallel()
+
+    port = get_open_port()
+    env = dict(VLLM_SERVER_PORT=str(port), VLLM_RPC_SECRET="test-secret", VLLM_HOST_IP="127.0.0.1",
+               VLLM_LOGGING_LEVEL="WARNING", VLLM_REMOTE_RETRY_SECONDS="0.5", GLOO_SOCKET_IFNAME="lo",
+               PYTHONPATH=ROOT, VDAMD_SHARE_DEVICE="1", VLLM_HEAD_LOCAL_DEVICES="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    remote = subprocess.Popen([sys.executable, os.path.join(ROOT, "launch.py"), "remote", "127.0.0.1",
+                               "--num-devices", "1", "--device-offset", "1"], env=dict(os.environ, **env))
+    eng = None
+    try:
+        eng = LLMEngine.from_engine_args(EngineArgs(
+            tensor_parallel_size=tp, pipeline_parallel_size=pp, distributed_executor_backend="distributed",
+            **common))
+        assert [a.node_id is None for a in eng.core.executor.assignments] == [True, False]
+        got = generate(eng)
+        assert [t[:2] for t in got] == [t[:2] for t in ref]
+    finally:
+        if eng is not None:
+            eng.shutdown()
+        remote.terminate()
+        remote.wait(timeout=20)
