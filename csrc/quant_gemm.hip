@@ -188,10 +188,16 @@ __global__ __launch_bounds__(256) void w4a16_gemm_kernel(
 // Batches above one MFMA tile of rows: the four waves of a workgroup take
 // *different* output tiles (16 tiles = 256 rows per workgroup) and share each
 // 128-column block of x through LDS, so x crosses L2 once per 16 KiB of
-// weights instead of once per wave.  Rows of the LDS copy are padded to 272
-// bytes so the 16 lanes of a ds_read_b128 phase fall into distinct banks.
+// weights instead of once per wave.  The 16-byte slots of each 256-byte LDS row
+// are XOR-swizzled with the row index so that the 16-lane groups a
+// ds_read_b128 is served in ({0-3,12-15,20-27}, ...) hit distinct banks.
 // grid = (ceil(N/256), ksplit, ceil(M / (16*MT))), block = 256.
-constexpr int W4_XPAD = 136;
+constexpr int W4_XPAD = 128;
+// Row r XORs its slots with r after swapping bits 0 and 2: the two lane sets a
+// ds_read_b128 group mixes ({0-3,12-15} with g, {4-11} with g+1) read slots
+// that differ by 4 (slot = 4g + s), and rows whose swizzles differ by exactly 4
+// then always belong to the same set.
+__device__ __forceinline__ int w4_swz(int r) { return (r & 10) | ((r & 1) << 2) | ((r >> 2) & 1); }
 
 template <typename T, int MT>
 __global__ __launch_bounds__(256) void w4a16_gemm_lds_kernel(
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(256) void w4a16_gemm_lds_kernel(
   if (kb_lo < kb_hi) {
     load_w(kb_lo, wc, sc);
 #pragma unroll
-    for (int p = 0; p < MT; ++p) st8(&xl[0][16 * p + xr][8 * xc], ld8(xsrc[p] + (kb_lo << 7)));
+    for (int p = 0; p < MT; ++p) st8(&xl[0][16 * p + xr][8 * (xc ^ w4_swz(xr))], ld8(xsrc[p] + (kb_lo << 7)));
   }
   __syncthreads();
   for (int kb = kb_lo; kb < kb_hi; ++kb) {
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(256) void w4a16_gemm_lds_kernel(
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) bx[mt][s] = ld8(&xl[buf][16 * mt + c][32 * g + 8 * s]);
+      for (int s = 0; s < 4; ++s) bx[mt][s] = ld8(&xl[buf][16 * mt + c][8 * ((4 * g + s) ^ w4_swz(c))]);
     f32x4 xs[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(256) void w4a16_gemm_lds_kernel(
 #pragma unroll
       for (int t = 0; t < W4_NTW; ++t) { wc[t] = wn[t]; sc[t] = sn[t]; }
 #pragma unroll
-      for (int p = 0; p < MT; ++p) st8(&xl[buf ^ 1][16 * p + xr][8 * xc], xreg[p]);
+      for (int p = 0; p < MT; ++p) st8(&xl[buf ^ 1][16 * p + xr][8 * (xc ^ w4_swz(xr))], xreg[p]);
     }
     __syncthreads();
   }

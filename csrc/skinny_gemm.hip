@@ -8,13 +8,15 @@
 // MFMA step s: one instruction covers 64 contiguous bytes of each of 16 rows,
 // and the four steps of a block complete two 128-byte lines per row back to
 // back.  The four waves of a workgroup own different 16-row tiles and
-// share the x block through LDS (rows padded to 272 bytes: conflict-free
-// ds_read_b128).  Next block's W and x are in flight while the current one is
+// share the x block through LDS.  A ds_read_b128 is served in four groups of
+// 16 lanes that mix two values of g ({0-3,12-15,20-27}, ...), so padded rows
+// still collide; instead the 16-byte slot of a 256-byte row is XOR-ed with the
+// row index (slot ^ (row & 15)), which makes every group hit 16 distinct slots.  Next block's W and x are in flight while the current one is
 // multiplied.  K may be split over grid.y; partial sums are then reduced by a
 // second kernel.
 #include "common.h"
 
-constexpr int SG_XPAD = 136;
+constexpr int SG_XPAD = 128;   // 256-byte rows; 16-byte slots XOR-swizzled by the row (see below)
 constexpr int SG_WAVES = 4;
 
 // grid = (ceil(N / (64*NTW)), ksplit), block = 256.  Requires K % 128 == 0, N % 16 == 0, M <= 16*MT.
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(
   if (kb_lo < kb_hi) {
     load_w(kb_lo, ac);
 #pragma unroll
-    for (int p = 0; p < MT; ++p) st8(&xl[0][16 * p + xr][8 * xc], ld8(xsrc[p] + (kb_lo << 7)));
+    for (int p = 0; p < MT; ++p) st8(&xl[0][16 * p + xr][8 * (xc ^ xr)], ld8(xsrc[p] + (kb_lo << 7)));
   }
   __syncthreads();
   for (int kb = kb_lo; kb < kb_hi; ++kb) {
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(
     for (int s = 0; s < 4; ++s) {
       V8 b[MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) b[mt] = ld8(&xl[buf][16 * mt + c][32 * s + 8 * g]);
+      for (int mt = 0; mt < MT; ++mt) b[mt] = ld8(&xl[buf][16 * mt + c][8 * ((4 * s + g) ^ c)]);
 #pragma unroll
       for (int t = 0; t < NTW; ++t)
 #pragma unroll
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(
 #pragma unroll
         for (int s = 0; s < 4; ++s) ac[t][s] = an[t][s];
 #pragma unroll
-      for (int p = 0; p < MT; ++p) st8(&xl[buf ^ 1][16 * p + xr][8 * xc], xreg[p]);
+      for (int p = 0; p < MT; ++p) st8(&xl[buf ^ 1][16 * p + xr][8 * (xc ^ xr)], xreg[p]);
     }
     __syncthreads();
   }
