@@ -47,12 +47,16 @@ def test_cli_parses_reference_command_line():
     assert a.max_model_len == 64
 
 
-def test_server_endpoints_end_to_end():
+@pytest.mark.parametrize("frontend_mp", [True, False])
+def test_server_endpoints_end_to_end(frontend_mp):
+    """Every endpoint, with the engine core in its own process (the default) and
+    on a thread of the server process (--disable-frontend-multiprocessing)."""
     pstate.destroy_model_parallel()
     args = build_parser().parse_args(
-        "serve llama-tiny --device cpu --dtype float32 --max-model-len 256 --block-size 16 "
-        "--num-gpu-blocks-override 128 --served-model-name tiny --api-key sekret "
-        "--enable-auto-tool-choice --tool-call-parser hermes --port 0".split())
+        ("serve llama-tiny --device cpu --dtype float32 --max-model-len 256 --block-size 16 "
+         "--num-gpu-blocks-override 128 --served-model-name tiny --api-key sekret "
+         "--enable-auto-tool-choice --tool-call-parser hermes --port 0"
+         + ("" if frontend_mp else " --disable-frontend-multiprocessing")).split())
     args.model = args.model_tag
 
     async def main():

@@ -63,9 +63,10 @@ class OutputCollector:
 
 
 class AsyncLLM:
-    def __init__(self, vllm_config: VllmConfig, executor_class=None, log_stats: bool = True):
+    def __init__(self, vllm_config: VllmConfig, executor_class=None, log_stats: bool = True,
+                 multiprocess: bool = False):
         self.vllm_config = vllm_config
-        self.engine = LLMEngine(vllm_config, executor_class)
+        self.engine = LLMEngine(vllm_config, executor_class, multiprocess=multiprocess)
         self.tokenizer = self.engine.tokenizer
         self.metrics = EngineMetrics(vllm_config.model_config.served_model_name[0])
         self._inbox: "queue.Queue[tuple]" = queue.Queue()
@@ -79,8 +80,9 @@ class AsyncLLM:
         self._thread.start()
 
     @classmethod
-    def from_engine_args(cls, engine_args: EngineArgs) -> "AsyncLLM":
-        return cls(engine_args.create_engine_config(), log_stats=not engine_args.disable_log_stats)
+    def from_engine_args(cls, engine_args: EngineArgs, multiprocess: bool = False) -> "AsyncLLM":
+        return cls(engine_args.create_engine_config(), log_stats=not engine_args.disable_log_stats,
+                   multiprocess=multiprocess)
 
     # ------------------------------------------------------------ engine thread
     def _post(self, rid: str, item) -> None:

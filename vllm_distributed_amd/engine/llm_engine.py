@@ -41,11 +41,16 @@ class _ReqState:
 
 class LLMEngine:
     def __init__(self, vllm_config: VllmConfig, executor_class: Optional[Type[Executor]] = None,
-                 tokenizer=None):
+                 tokenizer=None, multiprocess: bool = False):
         self.vllm_config = vllm_config
         self.model_config = vllm_config.model_config
         self.tokenizer = tokenizer or get_tokenizer(self.model_config)
-        self.core = EngineCore(vllm_config, executor_class)
+        if multiprocess:        # scheduler + executor loop in a child process (engine/core_client.py)
+            from .core_client import MPEngineCoreClient
+            self.core = MPEngineCoreClient(vllm_config, executor_class)
+        else:
+            self.core = EngineCore(vllm_config, executor_class)
+        self.remote_core = multiprocess
         self.states: Dict[str, _ReqState] = {}
         self._counter = itertools.count()
         eos = self.model_config.hf_config.get("eos_token_id")
@@ -100,6 +105,8 @@ class LLMEngine:
         return self.core.has_unfinished_requests()
 
     def get_num_unfinished_requests(self) -> int:
+        if self.remote_core:
+            return self.core.get_num_unfinished_requests()
         return self.core.scheduler.get_num_unfinished_requests()
 
     # ------------------------------------------------------------------ step
@@ -115,6 +122,14 @@ class LLMEngine:
                 continue
             req = st.request
             finish_reason, stop_reason = co.finish_reason, co.stop_reason
+            if self.remote_core:        # the scheduler's Request lives in the core process: mirror it
+                for t in co.new_token_ids:
+                    req.append_output_token(t)
+                m = req.metrics
+                if co.new_token_ids and m.first_token_time is None:
+                    m.first_token_time = time.time()
+                m.num_generation_tokens = len(req.output_token_ids)
+                m.num_cached_tokens = co.num_cached_tokens
             if st.detok is not None:
                 hit = st.detok.append(co.new_token_ids)
                 if hit is not None and finish_reason is None:

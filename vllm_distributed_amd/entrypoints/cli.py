@@ -44,7 +44,7 @@ def add_server_args(p: argparse.ArgumentParser) -> None:
     g.add_argument("--chat-template", type=str, default=None)
     g.add_argument("--enable-tokenizer-info-endpoint", action="store_true")
     g.add_argument("--disable-frontend-multiprocessing", action="store_true",
-                   help="accepted for compatibility: the engine always runs on a thread of the server process")
+                   help="run the engine core on a thread of the API-server process instead of in its own process")
 
 
 def _serve_parser(sub) -> argparse.ArgumentParser:

@@ -164,7 +164,10 @@ async def build_async_engine_client(args: argparse.Namespace, client_config: Opt
             engine_args.tensor_parallel_size * engine_args.pipeline_parallel_size > 1:
         engine_args.distributed_executor_backend = "distributed"
     loop = asyncio.get_running_loop()
-    engine = await loop.run_in_executor(None, AsyncLLM.from_engine_args, engine_args)
+    # scheduler + executor in their own process unless --disable-frontend-multiprocessing
+    # (reference src/launch.py:408 passes the same flag through)
+    multiprocess = not getattr(args, "disable_frontend_multiprocessing", False)
+    engine = await loop.run_in_executor(None, lambda: AsyncLLM.from_engine_args(engine_args, multiprocess))
     try:
         yield engine
     finally:
