@@ -180,3 +180,54 @@ def test_worker_death_fails_fast_and_unused_worker_is_tolerated(monkeypatch):
             eng.shutdown()
         remote.terminate()
         remote.wait(timeout=10)
+
+
+@pytest.mark.slow
+def test_executor_contract_with_stub_workers(monkeypatch):
+    """TP=2 x PP=2 over the head's one device and a three-device worker node,
+    with a worker class that has no model: placement, rank order, the reply
+    rank, per-rank replies of ``collective_rpc``, callables by value,
+    ``non_block`` futures and the enforced timeout."""
+    import cloudpickle  # noqa: F401  (callables travel by value)
+    port = get_open_port()
+    tests_dir = os.path.join(ROOT, "tests")
+    env = _env(port, VLLM_HEAD_LOCAL_DEVICES="1", PYTHONPATH=ROOT + os.pathsep + tests_dir)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.syspath_prepend(tests_dir)
+    remote = subprocess.Popen([sys.executable, os.path.join(ROOT, "launch.py"), "remote", "127.0.0.1",
+                               "--num-devices", "3", "--device-offset", "1"], env=env)
+    eng = None
+    try:
+        eng = LLMEngine.from_engine_args(EngineArgs(
+            model="llama-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,
+            num_gpu_blocks_override=64, max_num_seqs=8, tensor_parallel_size=2, pipeline_parallel_size=2,
+            distributed_executor_backend="distributed", worker_cls="stub_worker.StubWorker"))
+        ex = eng.core.executor
+        who = ex.collective_rpc("whoami")
+        assert [w["rank"] for w in who] == [0, 1, 2, 3]
+        assert [w["driver"] for w in who] == [True, False, True, False]
+        assert len({w["pid"] for w in who}) == 4
+        assert ex.output_rank == 2 and ex.max_concurrent_batches == 2
+        # one TP group never spans nodes that are not the same host; every device used once
+        assert len({(a.node_id, a.local_rank) for a in ex.assignments}) == 4
+        assert ex.collective_rpc("nap", args=(0.0,), unique_reply_rank=3) == [3]
+        assert ex.collective_rpc(lambda w: w.rank * 10) == [0, 10, 20, 30]
+        futs = ex.collective_rpc("nap", args=(0.05,), non_block=True)
+        assert [f.result(timeout=10) for f in futs] == [0, 1, 2, 3]
+        with pytest.raises(Exception):
+            ex.collective_rpc("nap", args=(3.0,), timeout=0.3)
+        time.sleep(3.2)          # let the slow call drain before the next one (FIFO worker thread)
+        # tokens come from the reply rank (2): each step adds rank + 1 = 3
+        rid = eng.add_request(None, [5, 9, 100], SamplingParams(temperature=0.0, max_tokens=4, ignore_eos=True))
+        final = None
+        while eng.has_unfinished_requests():
+            for o in eng.step():
+                if o.request_id == rid and o.finished:
+                    final = o.outputs[0].token_ids
+        assert final == [103, 106, 109, 112]
+    finally:
+        if eng is not None:
+            eng.shutdown()
+        remote.terminate()
+        remote.wait(timeout=10)

@@ -221,6 +221,8 @@ class ParallelConfig:
     distributed_executor_backend: Any = None
     pp_layer_partition: Optional[str] = None
     disable_custom_all_reduce: bool = False
+    # dotted path of the worker class each wrapper instantiates (default: worker.worker.Worker)
+    worker_cls: Optional[str] = None
     world_size: int = field(init=False, default=1)
 
     def __post_init__(self) -> None:

@@ -36,6 +36,7 @@ class EngineArgs:
     enable_expert_parallel: bool = False
     distributed_executor_backend: Any = None
     disable_custom_all_reduce: bool = False
+    worker_cls: Optional[str] = None
     block_size: Optional[int] = None
     gpu_memory_utilization: float = 0.90
     num_gpu_blocks_override: Optional[int] = None
@@ -122,7 +123,7 @@ class EngineArgs:
             data_parallel_size=self.data_parallel_size,
             enable_expert_parallel=self.enable_expert_parallel,
             distributed_executor_backend=self.distributed_executor_backend,
-            disable_custom_all_reduce=self.disable_custom_all_reduce)
+            disable_custom_all_reduce=self.disable_custom_all_reduce, worker_cls=self.worker_cls)
         if parallel_config.data_parallel_size != 1:
             raise ValueError("data parallelism inside one engine is not supported: world_size must "
                              "equal tensor_parallel_size x pipeline_parallel_size; run one engine per replica")

@@ -29,12 +29,12 @@ class LazyFuture:
 
     def result(self, timeout: Optional[float] = None) -> Any:
         obj = self._obj
-        if hasattr(obj, "get"):
+        if getattr(obj, "lazy_step_result", False):
             self._obj = obj = obj.get()
         return obj
 
     def done(self) -> bool:
-        return not hasattr(self._obj, "get")
+        return not getattr(self._obj, "lazy_step_result", False)
 
 
 class Executor:
@@ -49,7 +49,14 @@ class Executor:
         self.device_config = vllm_config.device_config
         self.is_failed = False
         self.failure_callback: Optional[FailureCallback] = None
-        self._init_executor()
+        try:
+            self._init_executor()
+        except BaseException:
+            try:                      # do not leave worker processes / RPC threads behind
+                self.shutdown()
+            except Exception:  # noqa: BLE001
+                pass
+            raise
 
     # ------------------------------------------------------------- selection
     @staticmethod

@@ -126,7 +126,8 @@ class DistributedExecutor(Executor):
                 vllm_config=None,              # each wrapper already holds it
                 local_rank=-1,                 # the wrapper substitutes its own (reference :281-282)
                 rank=a.rank, distributed_init_method=init_method,
-                is_driver_worker=(a.rank % tp == 0)))
+                is_driver_worker=(a.rank % tp == 0),
+                **({"worker_cls": self.parallel_config.worker_cls} if self.parallel_config.worker_cls else {})))
         self.collective_rpc("init_worker", args=(all_kwargs,))
         self.collective_rpc("init_device")
         self.collective_rpc("load_model")
@@ -143,8 +144,12 @@ class DistributedExecutor(Executor):
             # same-host split groups rendezvous over loopback-reachable address
             return get_distributed_init_method(ip, get_open_port())
         slot = next(s for s in self._slots[a0.node_id] if s.local_rank == a0.local_rank)
-        fut = asyncio.run_coroutine_threadsafe(slot.peer.get_param("open_port", timeout=30), self.loop)
-        return get_distributed_init_method(slot.ip, int(fut.result()))
+
+        async def remote_port() -> int:      # the worker publishes a function: a fresh port per call
+            fn = await slot.peer.get_param("open_port", timeout=30)
+            return int(await fn(timeout=30))
+        fut = asyncio.run_coroutine_threadsafe(remote_port(), self.loop)
+        return get_distributed_init_method(slot.ip, fut.result())
 
     # ------------------------------------------------------------ rpc thread
     async def _serve(self, workers_ready: "concurrent.futures.Future[None]") -> None:

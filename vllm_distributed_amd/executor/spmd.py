@@ -37,6 +37,8 @@ class SpmdExecutor(Executor):
         kwargs = dict(vllm_config=self.vllm_config, local_rank=self.local_rank, rank=self.rank,
                       distributed_init_method="env://" if world > 1 and "MASTER_ADDR" in os.environ
                       else init_method, is_driver_worker=self.rank % pc.tensor_parallel_size == 0)
+        if self.parallel_config.worker_cls:
+            kwargs["worker_cls"] = self.parallel_config.worker_cls
         self.collective_rpc("init_worker", args=([kwargs],))
         self.collective_rpc("init_device")
         self.collective_rpc("load_model")
@@ -55,7 +57,7 @@ class SpmdExecutor(Executor):
             self.driver.worker.model_runner.defer_output = self.scheduler_config.async_scheduling
         if non_block:
             return [LazyFuture(result)]
-        return [result.get() if hasattr(result, "get") else result]
+        return [result.get() if getattr(result, "lazy_step_result", False) else result]
 
     def determine_available_memory(self) -> List[int]:
         """Every rank runs its own scheduler, so all must size the KV cache

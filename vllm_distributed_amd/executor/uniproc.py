@@ -15,6 +15,8 @@ class UniProcExecutor(Executor):
         self.driver = WorkerWrapperBase(self.vllm_config, rpc_rank=0)
         kwargs = dict(vllm_config=self.vllm_config, local_rank=0, rank=0,
                       distributed_init_method=None, is_driver_worker=True)
+        if self.parallel_config.worker_cls:
+            kwargs["worker_cls"] = self.parallel_config.worker_cls
         self.collective_rpc("init_worker", args=([kwargs],))
         self.collective_rpc("init_device")
         self.collective_rpc("load_model")
@@ -27,7 +29,7 @@ class UniProcExecutor(Executor):
             self.driver.worker.model_runner.defer_output = self.scheduler_config.async_scheduling
         if non_block:
             return [LazyFuture(result)]
-        return [result.get() if hasattr(result, "get") else result]
+        return [result.get() if getattr(result, "lazy_step_result", False) else result]
 
     def shutdown(self) -> None:
         drv = getattr(self, "driver", None)

@@ -54,7 +54,7 @@ def set_peer_run_worker(peer: RpcPeer, wrapper: Any, rank: int, local_rank: int)
                          method if isinstance(method, str) else "<callable>", rank, e,
                          traceback.format_exc())
             raise
-        if hasattr(result, "get"):          # a lazily resolved step result
+        if getattr(result, "lazy_step_result", False):      # resolved after the next step is queued
             result = result.get()
         if unique_reply_rank is not None and unique_reply_rank != rank:
             return None

@@ -32,6 +32,7 @@ logger = init_logger(__name__)
 class PendingSample:
     """Tokens sampled on the device whose values have not reached the host yet."""
 
+    lazy_step_result = True       # executors call .get() on results carrying this mark
     __slots__ = ("runner", "step_id", "req_ids", "nreq", "sel", "rows", "gens", "pos", "tokens",
                  "event", "logprobs", "timing", "t_launch", "_result")
 
@@ -82,6 +83,8 @@ class PendingSample:
 
 class _Discard:
     """Resolves a pending sample for its side effects on a non-output rank."""
+
+    lazy_step_result = True
 
     def __init__(self, pending: PendingSample):
         self.pending = pending
