@@ -182,6 +182,34 @@ def test_worker_death_fails_fast_and_unused_worker_is_tolerated(monkeypatch):
         remote.wait(timeout=10)
 
 
+def test_kv_output_aggregator_counts_every_rank():
+    import concurrent.futures
+    from vllm_distributed_amd.engine.types import ModelRunnerOutput
+    from vllm_distributed_amd.executor.kv_transfer import KVOutputAggregator
+    agg = KVOutputAggregator(world_size=3)
+
+    def out(tokens=None, sent=None, recv=None):
+        o = ModelRunnerOutput(step_id=0, req_ids=["a"] if tokens else [], sampled_token_ids=[tokens] if tokens else [])
+        o.finished_sending, o.finished_recving = sent, recv
+        return o
+    # a transfer is finished only when all three ranks have reported it
+    r = agg.aggregate([out(sent={"x"}), out([7], sent={"x"}), out()], output_rank=1)
+    assert r.sampled_token_ids == [[7]] and r.finished_sending is None
+    r = agg.aggregate([out(recv={"y"}), out([8], recv={"y"}), out(sent={"x"}, recv={"y"})], output_rank=1)
+    assert r.finished_sending == {"x"} and r.finished_recving == {"y"}
+    futs = [concurrent.futures.Future() for _ in range(3)]
+    res = agg.async_aggregate(futs, output_rank=2)
+    for i, f in enumerate(futs):
+        assert not res.done()
+        f.set_result(out([i], sent={"z"}))
+    assert res.result(timeout=1).sampled_token_ids == [[2]] and res.result().finished_sending == {"z"}
+    bad = [concurrent.futures.Future() for _ in range(2)]
+    res = KVOutputAggregator(2).async_aggregate(bad, 0)
+    bad[1].set_exception(RuntimeError("worker died"))
+    with pytest.raises(RuntimeError):
+        res.result(timeout=1)
+
+
 @pytest.mark.slow
 def test_executor_contract_with_stub_workers(monkeypatch):
     """TP=2 x PP=2 over the head's one device and a three-device worker node,
@@ -191,7 +219,8 @@ def test_executor_contract_with_stub_workers(monkeypatch):
     import cloudpickle  # noqa: F401  (callables travel by value)
     port = get_open_port()
     tests_dir = os.path.join(ROOT, "tests")
-    env = _env(port, VLLM_HEAD_LOCAL_DEVICES="1", PYTHONPATH=ROOT + os.pathsep + tests_dir)
+    env = _env(port, VLLM_HEAD_LOCAL_DEVICES="1", PYTHONPATH=ROOT + os.pathsep + tests_dir,
+               VLLM_HEARTBEAT_SECONDS="0.2")            # health checks interleave with everything below
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     monkeypatch.syspath_prepend(tests_dir)
@@ -202,8 +231,10 @@ def test_executor_contract_with_stub_workers(monkeypatch):
         eng = LLMEngine.from_engine_args(EngineArgs(
             model="llama-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,
             num_gpu_blocks_override=64, max_num_seqs=8, tensor_parallel_size=2, pipeline_parallel_size=2,
-            distributed_executor_backend="distributed", worker_cls="stub_worker.StubWorker"))
+            distributed_executor_backend="distributed", worker_cls="stub_worker.StubWorker",
+            kv_transfer_config={"kv_connector": "null", "kv_role": "kv_both"}))   # all ranks reply, aggregated
         ex = eng.core.executor
+        assert ex.has_connector
         who = ex.collective_rpc("whoami")
         assert [w["rank"] for w in who] == [0, 1, 2, 3]
         assert [w["driver"] for w in who] == [True, False, True, False]
