@@ -184,3 +184,65 @@ def test_sequence_parallel_forward_matches_replicated_forward(monkeypatch):
         llm.shutdown()
         pstate.destroy_model_parallel()
     assert calls["n"] > 0 and outs["0"] == outs["force"]
+
+
+def test_phi3_fused_checkpoint_equals_llama_checkpoint(tmp_path):
+    """A Phi-3 checkpoint is a Llama checkpoint with q/k/v and gate/up stored
+    fused: rewriting one into the other must not change a single token."""
+    import json
+    from safetensors.torch import load_file, save_file
+    from vllm_distributed_amd.config import ModelConfig
+    from vllm_distributed_amd.models.loader import save_dummy_checkpoint
+    mc = ModelConfig(model="llama-tiny", dtype="float32", load_format="dummy")
+    src = tmp_path / "llama"
+    save_dummy_checkpoint(mc, str(src))
+    sd = load_file(str(src / "model.safetensors"))
+    fused = {}
+    for name, w in sd.items():
+        if ".q_proj." in name:
+            k, v = sd[name.replace(".q_proj.", ".k_proj.")], sd[name.replace(".q_proj.", ".v_proj.")]
+            fused[name.replace(".q_proj.", ".qkv_proj.")] = torch.cat([w, k, v], 0)
+        elif ".gate_proj." in name:
+            fused[name.replace(".gate_proj.", ".gate_up_proj.")] = torch.cat(
+                [w, sd[name.replace(".gate_proj.", ".up_proj.")]], 0)
+        elif not any(t in name for t in (".k_proj.", ".v_proj.", ".up_proj.")):
+            fused[name] = w
+    dst = tmp_path / "phi3"
+    dst.mkdir()
+    save_file({k: v.contiguous() for k, v in fused.items()}, str(dst / "model.safetensors"))
+    cfg = dict(mc.hf_config, architectures=["Phi3ForCausalLM"], model_type="phi3")
+    (dst / "config.json").write_text(json.dumps(cfg))
+    outs = []
+    for path in (src, dst):
+        llm = LLM(model=str(path), device="cpu", dtype="float32", max_model_len=128, block_size=16,
+                  num_gpu_blocks_override=64, max_num_seqs=8)
+        o = llm.generate([[5, 9, 200, 17], list(range(10, 50))],
+                         SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True))
+        outs.append([x.outputs[0].token_ids for x in o])
+        llm.shutdown()
+        pstate.destroy_model_parallel()
+    assert outs[0] == outs[1]
+
+
+def test_mixtral_checkpoint_round_trip_and_quantised_experts(tmp_path):
+    from vllm_distributed_amd.config import ModelConfig
+    from vllm_distributed_amd.models.loader import save_dummy_checkpoint
+    outs = {}
+    mc = ModelConfig(model="mixtral-tiny", dtype="float32", load_format="dummy")
+    save_dummy_checkpoint(mc, str(tmp_path / "mixtral"))
+    for tag, kw in (("dummy", dict(model="mixtral-tiny")), ("file", dict(model=str(tmp_path / "mixtral"))),
+                    ("awq", dict(model="mixtral-tiny", quantization="awq")),
+                    ("awq-dequant", dict(model="mixtral-tiny", quantization="awq-dequant"))):
+        llm = LLM(device="cpu", dtype="float32", max_model_len=128, block_size=16, num_gpu_blocks_override=64,
+                  max_num_seqs=8, **kw)
+        model = llm.engine.core.executor.driver.worker.model_runner.model
+        moe = next(iter(model.layers.values())).mlp
+        assert type(moe).__name__ == "FusedMoE" and moe.num_experts == 4 and moe.top_k == 2
+        if tag == "awq":
+            assert moe.qw13 is not None
+        o = llm.generate([[5, 9, 200, 17], list(range(10, 50))],
+                         SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True))
+        outs[tag] = [x.outputs[0].token_ids for x in o]
+        llm.shutdown()
+        pstate.destroy_model_parallel()
+    assert outs["dummy"] == outs["file"] and outs["awq"] == outs["awq-dequant"]

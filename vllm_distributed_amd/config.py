@@ -35,6 +35,13 @@ _BUILTIN_ALIASES = {
     "llama-tiny": "llama-tiny.json",
     "opt-tiny": "opt-tiny.json",
     "qwen3-moe-tiny": "qwen3-moe-tiny.json",
+    "mixtral-tiny": "mixtral-tiny.json",
+    "phi3-tiny": "phi3-tiny.json",
+    "mistralai/mixtral-8x7b-instruct-v0.1": "mixtral-8x7b.json",
+    "mistralai/mixtral-8x7b-v0.1": "mixtral-8x7b.json",
+    "mixtral-8x7b": "mixtral-8x7b.json",
+    "microsoft/phi-3-mini-4k-instruct": "phi-3-mini-4k.json",
+    "phi-3-mini-4k": "phi-3-mini-4k.json",
     "qwen/qwen3-coder-480b-a35b-instruct": "qwen3-coder-480b-a35b.json",
     "koushd/qwen3-coder-480b-a35b-instruct-awq": "qwen3-coder-480b-a35b.json",
     "qwen/qwen3-8b": "qwen3-8b.json",
@@ -152,7 +159,8 @@ class ModelConfig:
         mt = self.hf_config.get("model_type", "llama")
         return {"llama": "LlamaForCausalLM", "opt": "OPTForCausalLM",
                 "qwen3_moe": "Qwen3MoeForCausalLM", "qwen2": "Qwen2ForCausalLM",
-                "qwen3": "Qwen3ForCausalLM", "mistral": "MistralForCausalLM"}.get(mt, mt)
+                "qwen3": "Qwen3ForCausalLM", "mistral": "MistralForCausalLM",
+                "mixtral": "MixtralForCausalLM", "phi3": "Phi3ForCausalLM"}.get(mt, mt)
 
     @property
     def hidden_size(self) -> int:

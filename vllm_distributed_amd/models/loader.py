@@ -73,6 +73,8 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
     hd = c.get("head_dim") or h // heads
     inter = c.get("intermediate_size", 0)
     moe = arch == "Qwen3MoeForCausalLM"
+    mixtral = arch == "MixtralForCausalLM"
+    phi3 = arch == "Phi3ForCausalLM"
     qkv_bias = bool(c.get("attention_bias", False)) or c.get("model_type") == "qwen2"
     shapes["model.embed_tokens.weight"] = (c["vocab_size"], h)
     shapes["model.norm.weight"] = (h,)
@@ -80,9 +82,12 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
         shapes["lm_head.weight"] = (c["vocab_size"], h)
     for i in range(L):
         q = f"model.layers.{i}."
-        shapes[q + "self_attn.q_proj.weight"] = (heads * hd, h)
-        shapes[q + "self_attn.k_proj.weight"] = (kvh * hd, h)
-        shapes[q + "self_attn.v_proj.weight"] = (kvh * hd, h)
+        if phi3:        # checkpoint stores [q | k | v] fused
+            shapes[q + "self_attn.qkv_proj.weight"] = ((heads + 2 * kvh) * hd, h)
+        else:
+            shapes[q + "self_attn.q_proj.weight"] = (heads * hd, h)
+            shapes[q + "self_attn.k_proj.weight"] = (kvh * hd, h)
+            shapes[q + "self_attn.v_proj.weight"] = (kvh * hd, h)
         shapes[q + "self_attn.o_proj.weight"] = (h, heads * hd)
         if qkv_bias:
             shapes[q + "self_attn.q_proj.bias"] = (heads * hd,)
@@ -103,6 +108,15 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
                 shapes[q + f"mlp.experts.{e}.gate_proj.weight"] = (mi, h)
                 shapes[q + f"mlp.experts.{e}.up_proj.weight"] = (mi, h)
                 shapes[q + f"mlp.experts.{e}.down_proj.weight"] = (h, mi)
+        elif mixtral:
+            shapes[q + "block_sparse_moe.gate.weight"] = (c["num_local_experts"], h)
+            for e in range(c["num_local_experts"]):
+                shapes[q + f"block_sparse_moe.experts.{e}.w1.weight"] = (inter, h)
+                shapes[q + f"block_sparse_moe.experts.{e}.w3.weight"] = (inter, h)
+                shapes[q + f"block_sparse_moe.experts.{e}.w2.weight"] = (h, inter)
+        elif phi3:      # [gate | up] fused
+            shapes[q + "mlp.gate_up_proj.weight"] = (2 * inter, h)
+            shapes[q + "mlp.down_proj.weight"] = (h, inter)
         else:
             shapes[q + "mlp.gate_proj.weight"] = (inter, h)
             shapes[q + "mlp.up_proj.weight"] = (inter, h)
@@ -110,7 +124,8 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
     return shapes
 
 
-_QUANTIZED_LINEAR = re.compile(r"\.(q_proj|k_proj|v_proj|o_proj|gate_proj|up_proj|down_proj)\.weight$")
+_QUANTIZED_LINEAR = re.compile(
+    r"\.(q_proj|k_proj|v_proj|qkv_proj|o_proj|gate_proj|up_proj|gate_up_proj|down_proj|w1|w2|w3)\.weight$")
 
 
 def dummy_weights_iterator(mc: ModelConfig, device: torch.device,

@@ -1,0 +1,58 @@
+"""Mixtral: Llama/Mistral attention with a sparse MoE MLP on every layer
+(``block_sparse_moe``: router ``gate``, experts ``w1`` = gate, ``w3`` = up,
+``w2`` = down; softmax over all experts, top-k, renormalised)."""
+from __future__ import annotations
+
+import re
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from ..config import VllmConfig
+from .layers.moe import FusedMoE
+from .llama import LlamaDecoderLayer, LlamaForCausalLM
+
+_EP = False
+
+
+class MixtralDecoderLayer(LlamaDecoderLayer):
+    def _make_mlp(self, cfg: dict, dtype: torch.dtype) -> nn.Module:
+        return FusedMoE(cfg["hidden_size"], cfg["intermediate_size"], cfg["num_local_experts"],
+                        cfg["num_experts_per_tok"], True, dtype, expert_parallel=_EP)
+
+
+class MixtralForCausalLM(LlamaForCausalLM):
+    layer_cls = MixtralDecoderLayer
+    _expert_re = re.compile(r"(.*\.mlp)\.experts\.(\d+)\.(w1|w2|w3)\.(weight|qweight|qzeros|scales)$")
+
+    def __init__(self, vllm_config: VllmConfig):
+        global _EP
+        _EP = vllm_config.parallel_config.enable_expert_parallel
+        super().__init__(vllm_config)
+
+    def map_weight_name(self, name: str) -> Optional[str]:
+        name = super().map_weight_name(name)
+        return None if name is None else name.replace(".block_sparse_moe.", ".mlp.")
+
+    def load_weights(self, weights: Iterable[Tuple[str, torch.Tensor]]) -> List[str]:
+        params: Dict[str, nn.Parameter] = dict(self.named_parameters())
+        rest, loaded = [], []
+        for name, w in weights:
+            mapped = self.map_weight_name(name)
+            m = self._expert_re.match(mapped) if mapped else None
+            if m is None:
+                rest.append((name, w))
+                continue
+            if not self._owns_layer(mapped):
+                continue
+            prefix, eid, proj, kind = m.group(1), int(m.group(2)), m.group(3), m.group(4)
+            suffix = "" if kind == "weight" else "_" + kind
+            if proj == "w2":
+                p = params[prefix + ".w2" + suffix]
+                p.weight_loader(p, w, (eid, 0))
+            else:
+                p = params[prefix + ".w13" + suffix]
+                p.weight_loader(p, w, (eid, 0 if proj == "w1" else 1))
+            loaded.append(mapped)
+        return loaded + super().load_weights(rest)

@@ -10,6 +10,9 @@ _MODELS: Dict[str, Tuple[str, str]] = {
     "Qwen2ForCausalLM": ("llama", "LlamaForCausalLM"),
     "Qwen3ForCausalLM": ("llama", "LlamaForCausalLM"),
     "Qwen3MoeForCausalLM": ("qwen3_moe", "Qwen3MoeForCausalLM"),
+    "MixtralForCausalLM": ("mixtral", "MixtralForCausalLM"),
+    # Phi-3 checkpoints store qkv and gate/up already fused: the fused loaders take them whole
+    "Phi3ForCausalLM": ("llama", "LlamaForCausalLM"),
     "OPTForCausalLM": ("opt", "OPTForCausalLM"),
 }
 
