@@ -203,16 +203,28 @@ template <typename T, int MT>
 __global__ __launch_bounds__(256) void w4a16_gemm_lds_kernel(
     const T* __restrict__ x, long x_stride, const uint32_t* __restrict__ qw, const T* __restrict__ sz,
     T* __restrict__ out, long out_stride, float* __restrict__ partial, int M, int N, int K,
-    int kb_per_group, int ksplit) {
+    int kb_per_group, int ksplit, const int* __restrict__ tiles, long qw_group_stride, long sz_group_stride) {
   using V8 = typename Vec8<T>::type;
   __shared__ __attribute__((aligned(16))) T xl[2][MT * 16][W4_XPAD];
+  int m0 = blockIdx.z * (16 * MT);
+  if (tiles != nullptr) {
+    // grouped mode (mixture-of-experts): blockIdx.z names a row tile
+    // (group, first row, rows) of the group-sorted x; rows == 0 marks padding
+    const int* d = tiles + 3 * blockIdx.z;
+    M = d[2];
+    if (M == 0) return;
+    qw += (size_t)d[0] * qw_group_stride;
+    sz += (size_t)d[0] * sz_group_stride;
+    x += (long)d[1] * x_stride;
+    out += (long)d[1] * out_stride;
+    m0 = 0;
+  }
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int KB = K >> 7, ntiles = N >> 4, NG = KB / kb_per_group;
   const int nt0 = (blockIdx.x * W4_WAVES + wid) * W4_NTW;
   const int ks = blockIdx.y;
   const int kb_lo = (int)((long)KB * ks / ksplit), kb_hi = (int)((long)KB * (ks + 1) / ksplit);
-  const int m0 = blockIdx.z * (16 * MT);
 
   int ntc[W4_NTW];
 #pragma unroll
@@ -363,7 +375,7 @@ static int launch_w4a16(void* out, long out_stride, const void* x, long x_stride
   if (variant == 1)                                                                                      \
     w4a16_gemm_lds_kernel<T, MT_><<<grid, 256, 0, st>>>((const T*)x, x_stride, (const uint32_t*)qw,     \
                                                      (const T*)sz, (T*)out, out_stride, (float*)partial, \
-                                                     M, N, K, G / 128, ksplit);                          \
+                                                     M, N, K, G / 128, ksplit, nullptr, 0, 0);           \
   else                                                                                                   \
     w4a16_gemm_kernel<T, MT_><<<grid, 256, 0, st>>>((const T*)x, x_stride, (const uint32_t*)qw,         \
                                                  (const T*)sz, (T*)out, out_stride, (float*)partial,     \
@@ -415,4 +427,43 @@ VDAMD_API int vdamd_w4_dequant(void* out, const void* qw, const void* sz, int N,
     return -3;
   HIP_LAUNCH_CHECK();
   return 0;
+}
+
+template <typename T>
+static int launch_w4_grouped(void* out, long os, const void* x, long xs, const void* qw, const void* sz, long qgs,
+                             long sgs, const int* tiles, int num_tiles, int tile_rows, int N, int K, int G,
+                             hipStream_t st) {
+  dim3 grid((N / 16 + W4_NTW * W4_WAVES - 1) / (W4_NTW * W4_WAVES), 1, num_tiles);
+#define W4G(MT_)                                                                                                \
+  w4a16_gemm_lds_kernel<T, MT_><<<grid, 256, 0, st>>>((const T*)x, xs, (const uint32_t*)qw, (const T*)sz, (T*)out, os, \
+                                                     nullptr, tile_rows, N, K, G / 128, 1, tiles, qgs, sgs)
+  switch (tile_rows / 16) {
+    case 1: W4G(1); break;
+    case 2: W4G(2); break;
+    case 3: W4G(3); break;
+    default: W4G(4); break;
+  }
+#undef W4G
+  HIP_LAUNCH_CHECK();
+  return 0;
+}
+
+// Grouped form for mixture-of-experts (see vdamd_skinny_gemm_grouped): group g's
+// packed weights start at qw + g * qw_group_stride words, sz + g * sz_group_stride
+// elements; tile_rows is 16, 32, 48 or 64.
+VDAMD_API int vdamd_w4a16_gemm_grouped(void* out, long out_stride, const void* x, long x_stride, const void* qw,
+                                       const void* sz, long qw_group_stride, long sz_group_stride,
+                                       const int* tiles, int num_tiles, int tile_rows, int N, int K, int G,
+                                       int dtype, void* stream) {
+  if (num_tiles <= 0) return 0;
+  if (tile_rows <= 0 || tile_rows > 64 || tile_rows % 16 || tiles == nullptr) return -1;
+  if (K % 128 || N % 16 || G % 128 || K % G) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16)
+    return launch_w4_grouped<bf16_t>(out, out_stride, x, x_stride, qw, sz, qw_group_stride, sz_group_stride, tiles,
+                                     num_tiles, tile_rows, N, K, G, st);
+  if (dtype == DT_F16)
+    return launch_w4_grouped<f16_t>(out, out_stride, x, x_stride, qw, sz, qw_group_stride, sz_group_stride, tiles,
+                                    num_tiles, tile_rows, N, K, G, st);
+  return -3;
 }

@@ -23,9 +23,20 @@ constexpr int SG_WAVES = 4;
 template <typename T, int MT, int NTW>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(
     const T* __restrict__ x, long x_stride, const T* __restrict__ w, long w_stride, T* __restrict__ out,
-    long out_stride, float* __restrict__ partial, int M, int N, int K, int ksplit) {
+    long out_stride, float* __restrict__ partial, int M, int N, int K, int ksplit,
+    const int* __restrict__ tiles, long w_group_stride) {
   using V8 = typename Vec8<T>::type;
   __shared__ __attribute__((aligned(16))) T xl[2][MT * 16][SG_XPAD];
+  if (tiles != nullptr) {
+    // grouped mode (mixture-of-experts): blockIdx.z names a row tile
+    // (group, first row, rows) of the group-sorted x; rows == 0 marks padding
+    const int* d = tiles + 3 * blockIdx.z;
+    M = d[2];
+    if (M == 0) return;
+    w += (size_t)d[0] * w_group_stride;
+    x += (long)d[1] * x_stride;
+    out += (long)d[1] * out_stride;
+  }
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int KB = K >> 7, ntiles = N >> 4;
@@ -128,26 +139,28 @@ __global__ void skinny_reduce_kernel(T* __restrict__ out, long out_stride, const
 
 template <typename T, int MT, int NTW>
 static void launch_one(const void* x, long xs, const void* w, long ws, void* out, long os, void* partial, int M,
-                       int N, int K, int ksplit, hipStream_t st) {
-  dim3 grid((N / 16 + SG_WAVES * NTW - 1) / (SG_WAVES * NTW), ksplit);
+                       int N, int K, int ksplit, hipStream_t st, const int* tiles = nullptr, int num_tiles = 1,
+                       long w_group_stride = 0) {
+  dim3 grid((N / 16 + SG_WAVES * NTW - 1) / (SG_WAVES * NTW), ksplit, num_tiles);
   skinny_gemm_kernel<T, MT, NTW><<<grid, 256, 0, st>>>((const T*)x, xs, (const T*)w, ws, (T*)out, os,
-                                                       (float*)partial, M, N, K, ksplit);
+                                                       (float*)partial, M, N, K, ksplit, tiles, w_group_stride);
 }
 
 template <typename T>
 static int launch_skinny(const void* x, long xs, const void* w, long ws, void* out, long os, void* partial, int M,
-                         int N, int K, int ksplit, int ntw, hipStream_t st) {
-  const int mt = (M + 15) / 16;
-#define SG_CASE(MT_)                                                                              \
-  if (ntw == 1) launch_one<T, MT_, 1>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st);       \
-  else if (ntw == 2) launch_one<T, MT_, 2>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st);  \
-  else launch_one<T, MT_, 4>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st)
+                         int N, int K, int ksplit, int ntw, hipStream_t st, const int* tiles = nullptr,
+                         int num_tiles = 1, long wgs = 0) {
+  const int mt = (M + 15) / 16;        // grouped mode: M is the row capacity of a tile
+#define SG_CASE(MT_)                                                                                            \
+  if (ntw == 1) launch_one<T, MT_, 1>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st, tiles, num_tiles, wgs);       \
+  else if (ntw == 2) launch_one<T, MT_, 2>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st, tiles, num_tiles, wgs);  \
+  else launch_one<T, MT_, 4>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st, tiles, num_tiles, wgs)
   if (mt <= 1) { SG_CASE(1); }
   else if (mt <= 2) { SG_CASE(2); }
   else if (mt <= 4) { SG_CASE(4); }
   else {       // 8 row tiles: at most two output tiles per wave fit the register file
-    if (ntw == 1) launch_one<T, 8, 1>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st);
-    else launch_one<T, 8, 2>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st);
+    if (ntw == 1) launch_one<T, 8, 1>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st, tiles, num_tiles, wgs);
+    else launch_one<T, 8, 2>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st, tiles, num_tiles, wgs);
   }
 #undef SG_CASE
   HIP_LAUNCH_CHECK();
@@ -174,5 +187,25 @@ VDAMD_API int vdamd_skinny_gemm(void* out, long out_stride, const void* x, long 
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16) return launch_skinny<bf16_t>(x, x_stride, w, w_stride, out, out_stride, partial, M, N, K, ksplit, ntw, st);
   if (dtype == DT_F16) return launch_skinny<f16_t>(x, x_stride, w, w_stride, out, out_stride, partial, M, N, K, ksplit, ntw, st);
+  return -3;
+}
+
+// Grouped form for mixture-of-experts: x rows are sorted by group (expert) and
+// cut into tiles of at most `tile_rows` rows; tiles[i] = (group, first row,
+// rows) on the device, rows == 0 for padding entries.  w[g] = w + g * w_group_stride.
+VDAMD_API int vdamd_skinny_gemm_grouped(void* out, long out_stride, const void* x, long x_stride, const void* w,
+                                        long w_stride, long w_group_stride, const int* tiles, int num_tiles,
+                                        int tile_rows, int N, int K, int ntw, int dtype, void* stream) {
+  if (num_tiles <= 0) return 0;
+  if (tile_rows <= 0 || tile_rows > 128 || tile_rows % 16 || K % 128 || N % 16 || tiles == nullptr) return -1;
+  if (ntw != 1 && ntw != 2 && ntw != 4) return -4;
+  if ((x_stride | w_stride) % 8 || out_stride % 4 || w_group_stride % 8) return -5;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16)
+    return launch_skinny<bf16_t>(x, x_stride, w, w_stride, out, out_stride, nullptr, tile_rows, N, K, 1, ntw, st, tiles,
+                                 num_tiles, w_group_stride);
+  if (dtype == DT_F16)
+    return launch_skinny<f16_t>(x, x_stride, w, w_stride, out, out_stride, nullptr, tile_rows, N, K, 1, ntw, st, tiles,
+                                num_tiles, w_group_stride);
   return -3;
 }

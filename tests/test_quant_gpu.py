@@ -91,3 +91,55 @@ def test_awq_model_on_gpu_matches_dequantised_model():
         la, lb = a.outputs[0].logprobs[0], b.outputs[0].logprobs[0]
         t = a.outputs[0].token_ids[0]
         assert abs(la[t] - lb[t]) < 0.05
+
+
+@pytest.mark.parametrize("quantized", [False, True])
+@pytest.mark.parametrize("tokens", [1, 7, 64, 300, 1100])
+def test_fused_moe_grouped_gemm_path_matches_per_expert_loop(quantized, tokens, monkeypatch):
+    """Experts as grouped HIP GEMMs over expert-sorted rows (device-side
+    routing tables) against the per-expert library-GEMM loop."""
+    from vllm_distributed_amd.models.layers.linear import QuantSpec, quantized_linears
+    from vllm_distributed_amd.models.layers.moe import FusedMoE
+    from vllm_distributed_amd.parallel import state as pstate
+    pstate.destroy_model_parallel()
+    pstate.ensure_single_process_groups(torch.device(DEV))
+    hidden, inter, experts, top_k = 512, 256, 16, 4
+    torch.manual_seed(tokens)
+    with torch.device(DEV), quantized_linears(QuantSpec("awq", 128) if quantized else None):
+        moe = FusedMoE(hidden, inter, experts, top_k, True, torch.bfloat16)
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    for name, p in moe.named_parameters():
+        if p.dtype == torch.int32:
+            p.data.copy_(torch.randint(-(1 << 31), (1 << 31) - 1, p.shape, device=DEV, generator=gen,
+                                       dtype=torch.int64).to(torch.int32))
+        elif "scales" in name:
+            p.data.copy_((0.002 + 0.002 * torch.rand(p.shape, device=DEV, generator=gen)).to(p.dtype))
+        else:
+            p.data.copy_((torch.randn(p.shape, device=DEV, generator=gen) * 0.05).to(p.dtype))
+    moe.finalize_weights()
+    assert (moe.qw13 is not None) == quantized
+    x = torch.randn(tokens, hidden, device=DEV, generator=gen).to(torch.bfloat16)
+    rows = moe._grouped_tile_rows(x)
+    assert rows in (16, 32, 64, 128) if tokens <= 300 else True
+    with torch.inference_mode():
+        monkeypatch.setattr(FusedMoE, "_grouped_tile_rows", lambda self, x: 0)
+        ref = moe(x).float()
+        for tile_rows in {16, 64, rows or 64}:
+            monkeypatch.setattr(FusedMoE, "_grouped_tile_rows", lambda self, x, r=tile_rows: r)
+            got = moe(x).float()
+            torch.cuda.synchronize()
+            err = (got - ref).abs().max().item()
+            assert err <= 0.03 * ref.abs().max().item() + 1e-3, (tile_rows, err)
+    # the routing tables are built without a host sync: the step can be captured
+    if tokens == 64:
+        monkeypatch.setattr(FusedMoE, "_grouped_tile_rows", lambda self, x: 32)
+        with torch.inference_mode():
+            moe(x)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                y = moe(x)
+            g.replay()
+            torch.cuda.synchronize()
+            assert (y.float() - ref).abs().max().item() <= 0.03 * ref.abs().max().item() + 1e-3
+    pstate.destroy_model_parallel()

@@ -134,6 +134,50 @@ class FusedMoE(nn.Module):
             return ops.w4a16_linear(ops.silu_and_mul(h), self.qw2[e], self.sz2[e])
         return F.linear(ops.silu_and_mul(F.linear(x, self.w13[e])), self.w2[e])
 
+    def _grouped_tile_rows(self, x: torch.Tensor) -> int:
+        """Row-tile size for the grouped HIP GEMMs, or 0 to use the per-expert
+        library GEMMs (large prefill batches, where each expert has hundreds of
+        rows and hipBLASLt is compute-efficient; that path syncs with the host,
+        so it is never taken while a hipGraph is being captured)."""
+        if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and ops.hip_available()):
+            return 0
+        if self.quant is None and (self.w13.shape[2] % 128 or self.w2.shape[2] % 128 or self.w13.shape[1] % 16):
+            return 0
+        cap = 64 if self.qw13 is not None else 128
+        avg = x.shape[0] * self.top_k / max(1, self.num_experts)
+        if avg > cap and not torch.cuda.is_current_stream_capturing():
+            return 0
+        for rows in (16, 32, 64, 128):
+            if avg <= rows or rows == cap:
+                return rows
+        return cap
+
+    def _forward_grouped(self, x: torch.Tensor, topw: torch.Tensor, topi: torch.Tensor, tile_rows: int,
+                         ) -> torch.Tensor:
+        """Experts as two grouped GEMMs over expert-sorted rows: no host sync,
+        every expert's weights stream from HBM once per step."""
+        t, k = topi.shape
+        order, tiles = ops.moe_align(topi, self.num_experts, tile_rows, self.expert_start,
+                                     self.local_experts if self.expert_parallel else -1)
+        xs = x.index_select(0, order // k)
+        if self.qw13 is not None:
+            h = ops.grouped_linear(xs, tiles, tile_rows, qw=self.qw13, sz=self.sz13)
+            a = ops.silu_and_mul(h)
+            y = ops.grouped_linear(a, tiles, tile_rows, qw=self.qw2, sz=self.sz2)
+        else:
+            h = ops.grouped_linear(xs, tiles, tile_rows, weight=self.w13)
+            a = ops.silu_and_mul(h)
+            y = ops.grouped_linear(a, tiles, tile_rows, weight=self.w2)
+        w_sorted = topw.reshape(-1)[order]
+        if self.expert_parallel:        # rows of experts held elsewhere were never written
+            local = (topi.reshape(-1)[order] >= self.expert_start) & \
+                    (topi.reshape(-1)[order] < self.expert_start + self.local_experts)
+            y = torch.where(local.unsqueeze(1), y, torch.zeros_like(y))
+        y = y * w_sorted.unsqueeze(1)
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(order.numel(), device=order.device)
+        return y.index_select(0, inv).view(t, k, -1).sum(dim=1)      # fixed order: deterministic
+
     def forward(self, x: torch.Tensor, reduce: bool = True) -> torch.Tensor:
         logits = self.gate(x).float()
         probs = torch.softmax(logits, dim=-1)
@@ -141,6 +185,12 @@ class FusedMoE(nn.Module):
         if self.renormalize:
             topw = topw / topw.sum(-1, keepdim=True)
         topw = topw.to(x.dtype)
+        tile_rows = self._grouped_tile_rows(x)
+        if tile_rows:
+            out = self._forward_grouped(x, topw, topi, tile_rows)
+            if reduce and self.tp > 1:
+                out = tensor_model_parallel_all_reduce(out)
+            return out
         out = torch.zeros_like(x)
         # group token-slots by expert: one sort, then contiguous segments
         flat_e = topi.reshape(-1)

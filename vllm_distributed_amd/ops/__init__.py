@@ -197,6 +197,47 @@ def w4a16_linear(x, qw, sz, bias=None):
     return y.view(shape[:-1] + (y.shape[-1],))
 
 
+def moe_align(topi, num_experts: int, tile_rows: int, expert_start: int = 0, local_experts: int = -1):
+    """Sort the ``T*k`` (token, expert) slots by expert and cut each expert's
+    run into row tiles, entirely on the device (no host sync, so a decode
+    step with experts stays hipGraph-capturable).
+
+    Returns ``(order, tiles)``: ``order [T*k]`` maps sorted position -> flat
+    slot ``t*k + j``; ``tiles [n, 3] int32`` = (local expert, first sorted row,
+    rows), ``n = T*k // tile_rows + E`` (an upper bound), rows = 0 for unused
+    entries and for experts this rank does not hold."""
+    flat = topi.reshape(-1)
+    tk = flat.numel()
+    order = flat.argsort(stable=True)
+    counts = torch.zeros(num_experts, dtype=torch.int64, device=flat.device)
+    counts.scatter_add_(0, flat, torch.ones_like(flat))
+    ends = counts.cumsum(0)
+    tpe = (counts + tile_rows - 1) // tile_rows
+    tends = tpe.cumsum(0)
+    n = tk // tile_rows + num_experts
+    j = torch.arange(n, device=flat.device)
+    e = torch.searchsorted(tends, j, right=True).clamp_(max=num_experts - 1)
+    within = j - (tends - tpe)[e]
+    row0 = (ends - counts)[e] + within * tile_rows
+    rows = (counts[e] - within * tile_rows).clamp_(min=0, max=tile_rows)
+    rows = torch.where(j < tends[-1], rows, torch.zeros_like(rows))
+    if local_experts >= 0:
+        local = (e >= expert_start) & (e < expert_start + local_experts)
+        rows = torch.where(local, rows, torch.zeros_like(rows))
+        e = (e - expert_start).clamp_(min=0, max=max(local_experts - 1, 0))
+    tiles = torch.stack([e, row0, rows], dim=1).to(torch.int32).contiguous()
+    return order, tiles
+
+
+def grouped_linear(x, tiles, tile_rows: int, weight=None, qw=None, sz=None):
+    """Row-grouped ``x @ W[g]^T`` (dense ``weight [G, N, K]`` or packed 4-bit
+    ``qw/sz``) for rows sorted by group - see ``moe_align``.  HIP only."""
+    assert _use_hip(x)
+    if qw is not None:
+        return _hip.grouped_w4a16_gemm(x, qw, sz, tiles, tile_rows)
+    return _hip.grouped_gemm(x, weight, tiles, tile_rows)
+
+
 apply_penalties = torch_ref.apply_penalties
 compute_logprobs = torch_ref.compute_logprobs
 build_cos_sin_cache = torch_ref.build_cos_sin_cache

@@ -42,6 +42,8 @@ def load() -> ctypes.CDLL:
         "vdamd_w4a16_gemm": [P, L, P, L, P, P, P, I, I, I, I, I, I, I, P],
         "vdamd_w4_dequant": [P, P, P, I, I, I, I, P],
         "vdamd_skinny_gemm": [P, L, P, L, P, L, P, I, I, I, I, I, I, P],
+        "vdamd_skinny_gemm_grouped": [P, L, P, L, P, L, L, P, I, I, I, I, I, I, P],
+        "vdamd_w4a16_gemm_grouped": [P, L, P, L, P, P, L, L, P, I, I, I, I, I, I, P],
     }
     for name, argtypes in sigs.items():
         fn = getattr(lib, name)
@@ -424,4 +426,46 @@ def skinny_gemm(x: torch.Tensor, w: torch.Tensor, ntw: Optional[int] = None, ksp
     _check(_LIB.vdamd_skinny_gemm(out.data_ptr(), n, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
                                   None if partial is None else partial.data_ptr(), m, n, k, ksplit, ntw,
                                   _dt(x), _stream()), "skinny_gemm")
+    return out
+
+
+# ------------------------------------------------- grouped GEMMs (MoE experts)
+def _check_tiles(tiles: torch.Tensor, x: torch.Tensor, tile_rows: int) -> int:
+    assert tiles.dtype == torch.int32 and tiles.dim() == 2 and tiles.shape[1] == 3 and tiles.is_contiguous()
+    assert tiles.device == x.device and tile_rows % 16 == 0
+    assert x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
+    return tiles.shape[0]
+
+
+def grouped_gemm(x: torch.Tensor, w: torch.Tensor, tiles: torch.Tensor, tile_rows: int,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``out[r] = x[r] @ w[g(r)]^T`` for group-sorted rows: ``w [G, N, K]``,
+    ``tiles [n, 3] int32`` = (group, first row, rows <= tile_rows; 0 = unused).
+    Every row covered by a tile must lie inside ``x``; rows outside all tiles
+    are left untouched in ``out``."""
+    nt = _check_tiles(tiles, x, tile_rows)
+    g, n, k = w.shape
+    assert w.is_contiguous() and w.dtype == x.dtype and x.shape[1] == k and 16 <= tile_rows <= 128
+    assert k % 128 == 0 and n % 16 == 0
+    if out is None:
+        out = torch.empty((x.shape[0], n), dtype=x.dtype, device=x.device)
+    ntw = 1 if tile_rows > 64 or n <= 4096 else 2
+    _check(_LIB.vdamd_skinny_gemm_grouped(out.data_ptr(), out.stride(0), x.data_ptr(), x.stride(0), w.data_ptr(), k,
+                                          n * k, tiles.data_ptr(), nt, tile_rows, n, k, ntw, _dt(x), _stream()),
+           "skinny_gemm_grouped")
+    return out
+
+
+def grouped_w4a16_gemm(x: torch.Tensor, qw: torch.Tensor, sz: torch.Tensor, tiles: torch.Tensor,
+                       tile_rows: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Grouped form of ``w4a16_gemm``: ``qw [G, N/16, K/128, 64, 4]``, ``sz [G, N/16, K/g, 16, 2]``."""
+    nt = _check_tiles(tiles, x, tile_rows)
+    assert qw.dim() == 5 and sz.dim() == 5 and qw.shape[0] == sz.shape[0] and tile_rows <= 64
+    n, k, grp = _w4_dims(qw[0], sz[0])
+    assert qw.is_contiguous() and sz.is_contiguous() and x.shape[1] == k and x.dtype == sz.dtype
+    if out is None:
+        out = torch.empty((x.shape[0], n), dtype=x.dtype, device=x.device)
+    _check(_LIB.vdamd_w4a16_gemm_grouped(out.data_ptr(), out.stride(0), x.data_ptr(), x.stride(0), qw.data_ptr(),
+                                         sz.data_ptr(), qw[0].numel(), sz[0].numel(), tiles.data_ptr(), nt,
+                                         tile_rows, n, k, grp, _dt(x), _stream()), "w4a16_gemm_grouped")
     return out
