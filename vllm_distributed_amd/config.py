@@ -72,6 +72,8 @@ def load_hf_config(model: str) -> Dict[str, Any]:
                 with open(path) as f:
                     return json.load(f)
     alias = _BUILTIN_ALIASES.get(model.lower())
+    if alias is None and os.path.isfile(os.path.join(_CONFIG_DIR, os.path.basename(model.lower()) + ".json")):
+        alias = os.path.basename(model.lower()) + ".json"       # any bundled config by its file name
     if alias is not None:
         with open(os.path.join(_CONFIG_DIR, alias)) as f:
             return json.load(f)
