@@ -42,13 +42,14 @@ def _fit_batch_per_gpu(args) -> int:
     mc = ModelConfig(model=args.model, dtype=args.dtype, load_format="dummy")
     esz = 2 if args.dtype != "float32" else 4
     weights = sum(math.prod(s) for s in hf_weight_shapes(mc).values()) * esz
-    total = torch.cuda.get_device_properties(int(os.environ.get("LOCAL_RANK", "0"))).total_memory
+    index = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+    total = torch.cuda.get_device_properties(index).total_memory
     kv_budget = total * args.gpu_memory_utilization - weights - (10 << 30)     # activations, graphs, reserve
     per_token = 2 * mc.num_hidden_layers * mc.num_kv_heads * mc.head_dim * esz
     block = 64
     per = args.batch_per_gpu
     while per > 64:
-        prefill_steps = -(-per * args.prompt_len // 16384)
+        prefill_steps = -(-per * args.prompt_len // args.prefill_budget_per_gpu)
         tokens = args.prompt_len + prefill_steps + args.warmup + args.steps + 6
         if per * (-(-tokens // block)) * block * per_token <= kv_budget:
             break
@@ -74,6 +75,10 @@ def main() -> None:
     ap.add_argument("--sync-scheduling", action="store_true",
                     help="schedule each step only after the previous step's tokens reached the host")
     ap.add_argument("--gpu-memory-utilization", type=float, default=0.92)
+    ap.add_argument("--prefill-budget-per-gpu", type=int, default=16384,
+                    help="tokens per prefill step and GPU (max_num_batched_tokens = this x N)")
+    ap.add_argument("--num-gpu-blocks-override", type=int, default=None,
+                    help="fixed KV-cache size in blocks (rehearsals with several ranks on one device)")
     ap.add_argument("--simulate-tp", type=int, default=1,
                     help="one GPU stands in for one rank of a TP group of this size (per-rank compute proxy; "
                          "collectives move no data and the result is NOT a benchmark number)")
@@ -102,7 +107,7 @@ def main() -> None:
 
     # prefill budget scales with N so the batch is prefilled in the same number of steps at every N
     shards = n * args.simulate_tp
-    prefill_budget = 16384 * shards
+    prefill_budget = args.prefill_budget_per_gpu * shards
     per_gpu = _fit_batch_per_gpu(args)
     batch = per_gpu * shards
     # continuous batching staggers the sequences by the number of prefill steps
@@ -117,7 +122,8 @@ def main() -> None:
         distributed_executor_backend=backend, max_model_len=max_len, max_num_seqs=batch,
         max_num_batched_tokens=max(prefill_budget, batch), enable_prefix_caching=False,
         enforce_eager=args.enforce_eager or (n > 1 and not args.hip_graph), max_capture_size=batch, hip_graph_sizes=[batch],
-        gpu_memory_utilization=args.gpu_memory_utilization, seed=0, async_scheduling=not args.sync_scheduling))
+        gpu_memory_utilization=args.gpu_memory_utilization,
+        num_gpu_blocks_override=args.num_gpu_blocks_override, seed=0, async_scheduling=not args.sync_scheduling))
     vocab = engine.model_config.vocab_size
     rng = np.random.default_rng(1234)
     # the KV cache the workers could actually allocate has the last word on the batch
