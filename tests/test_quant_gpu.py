@@ -120,7 +120,8 @@ def test_fused_moe_grouped_gemm_path_matches_per_expert_loop(quantized, tokens, 
     assert (moe.qw13 is not None) == quantized
     x = torch.randn(tokens, hidden, device=DEV, generator=gen).to(torch.bfloat16)
     rows = moe._grouped_tile_rows(x)
-    assert rows in (16, 32, 64, 128) if tokens <= 300 else True
+    avg = tokens * top_k / experts
+    assert rows == 0 if avg > (64 if quantized else 128) else rows in (16, 32, 64, 128)
     with torch.inference_mode():
         monkeypatch.setattr(FusedMoE, "_grouped_tile_rows", lambda self, x: 0)
         ref = moe(x).float()
