@@ -68,6 +68,8 @@ def main() -> None:
     ap.add_argument("--ttft-requests", type=int, default=5)
     ap.add_argument("--dtype", type=str, default="bfloat16")
     ap.add_argument("--enforce-eager", action="store_true")
+    ap.add_argument("--quantization", type=str, default=None, choices=[None, "fp8", "awq"],
+                    help="NOT the headline configuration (that is bf16): reduced-precision linears")
     ap.add_argument("--hip-graph", action="store_true",
                     help="capture the decode step in a hipGraph also for N>1 (default there: eager - at "
                          "thousands of sequences per GPU the launches are hidden behind ~300 us kernels)")
@@ -119,6 +121,7 @@ def main() -> None:
         backend = "spmd" if n > 1 else "uni"
     engine = LLMEngine.from_engine_args(EngineArgs(
         model=args.model, dtype=args.dtype, load_format="dummy", tensor_parallel_size=n, device=args.device,
+        quantization=args.quantization,
         distributed_executor_backend=backend, max_model_len=max_len, max_num_seqs=batch,
         max_num_batched_tokens=max(prefill_budget, batch), enable_prefix_caching=False,
         enforce_eager=args.enforce_eager or (n > 1 and not args.hip_graph), max_capture_size=batch, hip_graph_sizes=[batch],
@@ -194,6 +197,8 @@ def main() -> None:
         runner = engine.core.executor.driver.worker.model_runner
         tps = batch * args.steps / elapsed
         dt = {"bfloat16": "bf16", "float16": "fp16", "float32": "fp32"}[args.dtype]
+        if args.quantization:
+            dt = f"{args.quantization}-weights/{dt}"
         pretty = {"llama-3-70b": "Llama-3-70B", "llama-3-8b": "Llama-3-8B"}.get(args.model, args.model)
         print(json.dumps({
             "metric": (f"output tokens/sec (whole node), {pretty} {dt} TP over N GPUs, decode"

@@ -144,3 +144,61 @@ def test_fused_moe_grouped_gemm_path_matches_per_expert_loop(quantized, tokens, 
             torch.cuda.synchronize()
             assert (y.float() - ref).abs().max().item() <= 0.03 * ref.abs().max().item() + 1e-3
     pstate.destroy_model_parallel()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,k", [(1, 512), (7, 4096), (300, 8192), (16, 28672), (5, 1000)])
+def test_dynamic_fp8_quant_matches_torch_conversion(dtype, m, k):
+    from vllm_distributed_amd.ops import hip
+    assert ops.hip_available()
+    x = (torch.randn(m, k, device=DEV) * torch.rand(m, 1, device=DEV) * 5).to(dtype)
+    x[0, 0] = 0.0
+    xq, scale = hip.dynamic_fp8_quant(x)
+    assert xq.dtype == torch.float8_e4m3fn and scale.shape == (m, 1)
+    ref_scale = x.float().abs().amax(dim=1, keepdim=True).clamp_min(1e-12) / 448.0
+    torch.testing.assert_close(scale, ref_scale, rtol=1e-6, atol=0)
+    ref_q = (x.float() / ref_scale).clamp(-448, 448).to(torch.float8_e4m3fn)
+    # the hardware convert and torch both round to nearest even: bit-identical except where the
+    # reciprocal multiply (x * (1/s) vs x / s) lands on the other side of a tie - then one code apart
+    a, b = xq.view(torch.uint8).int(), ref_q.view(torch.uint8).int()
+    assert (a == b).float().mean().item() > 0.99
+    assert int((a - b).abs().max()) <= 1
+    err = (xq.float() * scale - x.float()).abs().amax(dim=1, keepdim=True)
+    assert bool((err <= ref_scale * 16.0 + 1e-6).all())          # half a step at the top binade (step 32)
+
+
+@pytest.mark.parametrize("m", [1, 16, 200, 2048])
+def test_fp8_linear_matches_dequantised_reference(m):
+    n, k = 1280, 4096
+    w = (torch.randn(n, k, device=DEV) * 0.03).to(torch.bfloat16)
+    x = torch.randn(m, k, device=DEV).to(torch.bfloat16)
+    bias = torch.randn(n, device=DEV).to(torch.bfloat16)
+    wq, ws = ops.fp8_quantize_weight(w)
+    y = ops.fp8_linear(x, wq, ws, bias)
+    from vllm_distributed_amd.ops import hip
+    xq, xs = hip.dynamic_fp8_quant(x)
+    ref = (xq.float() * xs) @ (wq.float() * ws.view(-1, 1)).t() + bias.float()
+    assert (y.float() - ref).abs().max().item() <= ref.abs().max().item() * 2 ** -7
+    dense = x.float() @ w.float().t() + bias.float()
+    rel = (y.float() - dense).norm() / dense.norm()
+    assert rel < 0.05, rel                    # the quantisation error itself: ~3 % for gaussian data
+
+
+def test_fp8_model_on_gpu_tracks_bf16_model():
+    from vllm_distributed_amd import LLM, SamplingParams
+    from vllm_distributed_amd.parallel import state as pstate
+    outs = {}
+    for q in (None, "fp8"):
+        pstate.destroy_model_parallel()
+        llm = LLM(model="llama-tiny", dtype="bfloat16", max_model_len=256, num_gpu_blocks_override=64,
+                  max_num_seqs=8, quantization=q, gpu_memory_utilization=0.3)
+        layer = next(iter(llm.engine.core.executor.driver.worker.model_runner.model.layers.values()))
+        assert (layer.mlp.down_proj.weight.dtype == torch.float8_e4m3fn) == (q == "fp8")
+        outs[q] = llm.generate([[5, 9, 200, 17], list(range(10, 90))],
+                               SamplingParams(temperature=0.0, max_tokens=4, ignore_eos=True, logprobs=8))
+        llm.shutdown()
+        pstate.destroy_model_parallel()
+    for a, b in zip(outs[None], outs["fp8"]):
+        t = a.outputs[0].token_ids[0]
+        lb = b.outputs[0].logprobs[0]
+        assert t in lb and abs(lb[t] - a.outputs[0].logprobs[0][t]) < 0.25

@@ -106,6 +106,7 @@ class ModelConfig:
     max_model_len: Optional[int] = None
     load_format: str = "auto"          # auto|safetensors|dummy
     # None | awq (4-bit weights stay packed, W4A16 kernels) | awq-dequant (dense at load)
+    # | fp8 (W8A8: weights quantised per channel at load, activations per token at run time)
     quantization: Optional[str] = None
     trust_remote_code: bool = False
     revision: Optional[str] = None

@@ -67,7 +67,7 @@ class EngineArgs:
         g.add_argument("--seed", type=int, default=0)
         g.add_argument("--max-model-len", type=int, default=None)
         g.add_argument("--load-format", type=str, default="auto", choices=["auto", "safetensors", "dummy"])
-        g.add_argument("--quantization", "-q", type=str, default=None, choices=[None, "awq", "awq-dequant"])
+        g.add_argument("--quantization", "-q", type=str, default=None, choices=[None, "awq", "awq-dequant", "fp8"])
         g.add_argument("--trust-remote-code", action="store_true")
         g.add_argument("--revision", type=str, default=None)
         g.add_argument("--hf-overrides", type=json.loads, default=None)

@@ -29,9 +29,11 @@ def _param(*shape: int, dtype: torch.dtype) -> nn.Parameter:
 # ------------------------------------------------------------ quantisation
 @dataclass(frozen=True)
 class QuantSpec:
-    """Weight-only quantisation of the decoder's linear layers.  ``awq``: 4-bit
+    """Quantisation of the decoder's linear layers.  ``awq``: weight-only 4-bit
     asymmetric, ``group_size`` input columns per (scale, zero) pair, checkpoint
-    tensors ``qweight [in, out/8]``, ``qzeros [in/g, out/8]``, ``scales [in/g, out]``."""
+    tensors ``qweight [in, out/8]``, ``qzeros [in/g, out/8]``, ``scales [in/g, out]``.
+    ``fp8``: W8A8 on the fp8 matrix cores - weights quantised per output channel
+    to OCP e4m3 once loaded, activations per token at run time."""
     method: str = "awq"
     group_size: int = 128
     pack: int = 8
@@ -90,7 +92,9 @@ class _LinearBase(nn.Module):
         self.in_local, self.out_local, self.dtype = in_local, out_local, dtype
         self.register_buffer("qw", None)
         self.register_buffer("sz", None)
-        if spec is None:
+        self.register_buffer("weight_scale", None)
+        if spec is None or spec.method == "fp8":
+            # fp8: loaded in the checkpoint dtype, quantised per output channel in finalize_weights
             self.weight = _tag(_param(out_local, in_local, dtype=dtype), 0)
         else:
             g = spec.group_size
@@ -110,7 +114,15 @@ class _LinearBase(nn.Module):
             self.bias.weight_loader = bias_loader or loader      # type: ignore[attr-defined]
 
     def finalize_weights(self) -> None:
-        if self.quant is None or self.qw is not None:
+        if self.quant is None or self.qw is not None or self.weight_scale is not None:
+            return
+        if self.quant.method == "fp8":
+            if self.in_local % 16 or self.out_local % 16:       # hipBLASLt fp8 alignment
+                self.quant = None
+                return
+            wq, scale = ops.fp8_quantize_weight(self.weight.data)
+            self.weight = nn.Parameter(wq, requires_grad=False)
+            self.weight_scale = scale
             return
         qweight, qzeros, scales = self.qweight.data, self.qzeros.data, self.scales.data
         del self.qweight, self.qzeros, self.scales
@@ -126,6 +138,8 @@ class _LinearBase(nn.Module):
     def _matmul(self, x: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
         if self.qw is not None:
             return ops.w4a16_linear(x, self.qw, self.sz, bias)
+        if self.weight_scale is not None:
+            return ops.fp8_linear(x, self.weight, self.weight_scale, bias)
         return ops.linear(x, self.weight, bias)
 
 

@@ -44,6 +44,8 @@ class FusedMoE(nn.Module):
         self.hidden, self.dtype = hidden, dtype
         self.gate = ReplicatedLinear(hidden, num_experts, False, dtype, quant=False)   # router stays dense
         self.quant = active_quant()
+        if self.quant is not None and self.quant.method != "awq":
+            self.quant = None           # fp8 covers the dense linears; experts stay in the model dtype
         E, I = self.local_experts, self.inter_local
         self.register_buffer("qw13", None)
         self.register_buffer("sz13", None)

@@ -142,7 +142,7 @@ class LlamaForCausalLM(nn.Module):
         tie = bool(cfg.get("tie_word_embeddings", False))
         if self.is_first or (tie and self.is_last):
             self.embed_tokens = VocabParallelEmbedding(cfg["vocab_size"], cfg["hidden_size"], dtype)
-        spec = QuantSpec("awq", mc.quant_group_size) if mc.quantization == "awq" else None
+        spec = {"awq": QuantSpec("awq", mc.quant_group_size), "fp8": QuantSpec("fp8")}.get(mc.quantization)
         with quantized_linears(spec):
             self.layers = nn.ModuleDict({
                 str(i): self.layer_cls(cfg, i, dtype, self.cos_sin_cache)

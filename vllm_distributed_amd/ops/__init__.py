@@ -150,6 +150,42 @@ def linear(x, weight, bias=None):
     return torch.nn.functional.linear(x, weight, bias)
 
 
+FP8_MAX = 448.0        # largest finite OCP e4m3 value
+
+
+def fp8_quantize_weight(w):
+    """Per-output-channel symmetric quantisation of ``w [N, K]`` to e4m3:
+    ``(wq float8_e4m3fn, scale [N] fp32)`` with ``w ~ wq * scale[:, None]``."""
+    wf = w.to(torch.float32)
+    scale = wf.abs().amax(dim=1).clamp_min(1e-12) / FP8_MAX
+    wq = (wf / scale.unsqueeze(1)).clamp_(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+    return wq, scale
+
+
+def fp8_linear(x, wq, w_scale, bias=None):
+    """W8A8 linear: activations quantised per token on the fly (HIP kernel),
+    weights per output channel, product on the fp8 matrix cores through
+    hipBLASLt (``torch._scaled_mm``, fp32 accumulation, row-wise scaling).
+    Off the GPU the same arithmetic is done in fp32 from the dequantised
+    operands."""
+    shape = x.shape
+    x2 = x.reshape(-1, shape[-1])
+    if _use_hip(x2) and x2.dtype in (torch.bfloat16, torch.float16) and x2.shape[0] > 0:
+        if x2.stride(1) != 1 or x2.stride(0) % 8 or x2.data_ptr() % 16:
+            x2 = x2.contiguous()
+        xq, xs = _hip.dynamic_fp8_quant(x2)
+        y = torch._scaled_mm(xq, wq.t(), scale_a=xs, scale_b=w_scale.view(1, -1), bias=bias, out_dtype=x2.dtype)
+    else:
+        xf = x2.to(torch.float32)
+        xs = xf.abs().amax(dim=1, keepdim=True).clamp_min(1e-12) / FP8_MAX
+        xq = (xf / xs).clamp_(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+        y = (xq.to(torch.float32) * xs) @ (wq.to(torch.float32) * w_scale.view(-1, 1)).t()
+        if bias is not None:
+            y = y + bias.to(torch.float32)
+        y = y.to(x.dtype)
+    return y.view(shape[:-1] + (y.shape[-1],))
+
+
 _w4_scratch = {}
 
 

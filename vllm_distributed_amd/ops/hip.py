@@ -42,6 +42,7 @@ def load() -> ctypes.CDLL:
         "vdamd_w4a16_gemm": [P, L, P, L, P, P, P, I, I, I, I, I, I, I, P],
         "vdamd_w4_dequant": [P, P, P, I, I, I, I, P],
         "vdamd_skinny_gemm": [P, L, P, L, P, L, P, I, I, I, I, I, I, P],
+        "vdamd_dynamic_fp8_quant": [P, P, P, I, I, L, I, P],
         "vdamd_skinny_gemm_grouped": [P, L, P, L, P, L, L, P, I, I, I, I, I, I, P],
         "vdamd_w4a16_gemm_grouped": [P, L, P, L, P, P, L, L, P, I, I, I, I, I, I, P],
     }
@@ -469,3 +470,16 @@ def grouped_w4a16_gemm(x: torch.Tensor, qw: torch.Tensor, sz: torch.Tensor, tile
                                          sz.data_ptr(), qw[0].numel(), sz[0].numel(), tiles.data_ptr(), nt,
                                          tile_rows, n, k, grp, _dt(x), _stream()), "w4a16_gemm_grouped")
     return out
+
+
+# ------------------------------------------------------------------ FP8 W8A8
+def dynamic_fp8_quant(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Per-token dynamic quantisation to OCP e4m3: ``(xq [M, K] float8_e4m3fn, scale [M, 1] fp32)``
+    with ``x ~ xq * scale``."""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
+    m, k = x.shape
+    out = torch.empty((m, k), dtype=torch.float8_e4m3fn, device=x.device)
+    scale = torch.empty((m, 1), dtype=torch.float32, device=x.device)
+    _check(_LIB.vdamd_dynamic_fp8_quant(out.data_ptr(), scale.data_ptr(), x.data_ptr(), m, k, x.stride(0),
+                                        _dt(x), _stream()), "dynamic_fp8_quant")
+    return out, scale
