@@ -77,6 +77,20 @@ def test_server_endpoints_end_to_end(frontend_mp):
                 body = r.json()
                 assert body["usage"]["completion_tokens"] == 5 and body["choices"][0]["finish_reason"] == "length"
                 assert len(body["choices"][0]["logprobs"]["token_logprobs"]) == 5
+                # n samples per prompt: one choice each, reproducible under a seed, prompt counted once
+                r = await c.post("/v1/completions", headers=hdr, json={
+                    "model": "tiny", "prompt": ["hello", "bye"], "max_tokens": 4, "temperature": 1.0, "seed": 3, "ignore_eos": True,
+                    "n": 3})
+                body = r.json()
+                assert r.status_code == 200 and [ch["index"] for ch in body["choices"]] == list(range(6))
+                assert body["usage"]["completion_tokens"] == 24
+                r2 = await c.post("/v1/completions", headers=hdr, json={
+                    "model": "tiny", "prompt": ["hello", "bye"], "max_tokens": 4, "temperature": 1.0, "seed": 3, "ignore_eos": True,
+                    "n": 3})
+                assert [ch["text"] for ch in r2.json()["choices"]] == [ch["text"] for ch in body["choices"]]
+                r = await c.post("/v1/chat/completions", headers=hdr, json={
+                    "model": "tiny", "messages": [{"role": "user", "content": "hi"}], "max_tokens": 3, "n": 2})
+                assert r.status_code == 200 and len(r.json()["choices"]) == 2
                 r2 = await c.post("/v1/completions", headers=hdr, json={
                     "prompt": [1, 2, 3, 4], "max_tokens": 4, "temperature": 0, "stream": True,
                     "stream_options": {"include_usage": True}})

@@ -143,6 +143,15 @@ def setup_server(args: argparse.Namespace) -> Tuple[str, socket.socket]:
     return f"{scheme}://{host}:{sock.getsockname()[1]}", sock
 
 
+def _nth_params(sp: SamplingParams, j: int) -> SamplingParams:
+    """Sampling parameters of the ``j``-th of ``n`` samples of one prompt."""
+    out = sp.clone()
+    out.n = 1
+    if out.seed is not None:
+        out.seed = out.seed + j
+    return out
+
+
 def load_log_config(path: Optional[str]) -> Optional[dict]:
     if not path:
         return None
@@ -340,8 +349,7 @@ def _register_routes(app: FastAPI) -> None:
         err = _check_model(st, req.model)
         if err:
             return err
-        if req.n != 1:
-            return _error("n > 1 is not supported")
+        n = max(1, int(req.n or 1))
         p = req.prompt
         if isinstance(p, str):
             prompts: List[Any] = [p]
@@ -358,7 +366,10 @@ def _register_routes(app: FastAPI) -> None:
             sp = _sampling_params(req, 16, st.max_model_len, req.logprobs)
         except ValueError as e:
             return _error(str(e))
-        gens = [engine.generate(pr, sp.clone(), f"{rid}-{i}", req.priority) for i, pr in enumerate(prompts)]
+        # n samples per prompt = n requests sharing the prompt (its KV blocks are shared through the
+        # prefix cache); a fixed seed is advanced per sample so the samples differ reproducibly
+        gens = [engine.generate(pr, _nth_params(sp, j), f"{rid}-{i}-{j}", req.priority)
+                for i, pr in enumerate(prompts) for j in range(n)]
 
         def lp_block(out, start: int) -> Optional[dict]:
             lps = out.outputs[0].logprobs
@@ -395,7 +406,8 @@ def _register_routes(app: FastAPI) -> None:
                                                 "finish_reason": c.finish_reason, "stop_reason": c.stop_reason}]})
                                 sent = len(c.token_ids)
                             if out.finished:
-                                n_prompt += len(out.prompt_token_ids)
+                                if i % n == 0:
+                                    n_prompt += len(out.prompt_token_ids)
                                 n_out += len(c.token_ids)
                     if req.stream_options and req.stream_options.include_usage:
                         yield _sse({"id": rid, "object": "text_completion", "created": created, "model": model,
@@ -423,7 +435,8 @@ def _register_routes(app: FastAPI) -> None:
             text = ((out.prompt or "") if req.echo else "") + c.text
             choices.append({"index": i, "text": text, "logprobs": lp_block(out, 0),
                             "finish_reason": c.finish_reason, "stop_reason": c.stop_reason})
-            n_prompt += len(out.prompt_token_ids)
+            if i % n == 0:
+                n_prompt += len(out.prompt_token_ids)
             n_out += len(c.token_ids)
         return {"id": rid, "object": "text_completion", "created": created, "model": model,
                 "choices": choices, "usage": _usage(n_prompt, n_out)}
@@ -436,8 +449,9 @@ def _register_routes(app: FastAPI) -> None:
         err = _check_model(st, req.model)
         if err:
             return err
-        if req.n != 1:
-            return _error("n > 1 is not supported")
+        n = max(1, int(req.n or 1))
+        if n != 1 and req.stream:
+            return _error("n > 1 is not supported with stream=true on this endpoint")
         tok = engine.tokenizer
         messages = _messages_to_dicts(req.messages)
         tools = req.tools if req.tool_choice != "none" else None
@@ -462,7 +476,9 @@ def _register_routes(app: FastAPI) -> None:
         rid = "chatcmpl-" + uuid.uuid4().hex
         created = int(time.time())
         parser = st.tool_parser if tools else None
-        gen = engine.generate({"prompt": prompt, "prompt_token_ids": prompt_ids}, sp, rid, req.priority)
+        gens = [engine.generate({"prompt": prompt, "prompt_token_ids": prompt_ids}, _nth_params(sp, j),
+                                rid if n == 1 else f"{rid}-{j}", req.priority) for j in range(n)]
+        gen = gens[0]
 
         def lp_content(out, start: int) -> Optional[dict]:
             lps = out.outputs[0].logprobs
@@ -525,26 +541,32 @@ def _register_routes(app: FastAPI) -> None:
                 yield _sse("[DONE]")
             return StreamingResponse(stream(), media_type="text/event-stream")
 
-        final = None
-        try:
-            async for out in gen:
+        async def last_of(g):
+            final = None
+            async for out in g:
                 final = out
+            return final
+        try:
+            finals = await asyncio.gather(*[last_of(g) for g in gens])
         except ValueError as e:
             return _error(str(e))
         except EngineDeadError as e:
             return _error(str(e), 500, "InternalServerError")
-        c = final.outputs[0]
-        message: Dict[str, Any] = {"role": "assistant", "content": c.text}
-        finish = c.finish_reason
-        if parser is not None:
-            content, calls = parser.extract(c.text, tools)
-            if calls:
-                message = {"role": "assistant", "content": content, "tool_calls": calls}
-                finish = "tool_calls"
+        choices, n_out = [], 0
+        for j, final in enumerate(finals):
+            c = final.outputs[0]
+            message: Dict[str, Any] = {"role": "assistant", "content": c.text}
+            finish = c.finish_reason
+            if parser is not None:
+                content, calls = parser.extract(c.text, tools)
+                if calls:
+                    message = {"role": "assistant", "content": content, "tool_calls": calls}
+                    finish = "tool_calls"
+            choices.append({"index": j, "message": message, "logprobs": lp_content(final, 0),
+                            "finish_reason": finish, "stop_reason": c.stop_reason})
+            n_out += len(c.token_ids)
         return {"id": rid, "object": "chat.completion", "created": created, "model": model,
-                "choices": [{"index": 0, "message": message, "logprobs": lp_content(final, 0),
-                             "finish_reason": finish, "stop_reason": c.stop_reason}],
-                "usage": _usage(len(prompt_ids), len(c.token_ids))}
+                "choices": choices, "usage": _usage(len(prompt_ids), n_out)}
 
 
 # ------------------------------------------------------------------- run
