@@ -1,6 +1,6 @@
 // Rotary embedding (NeoX pairing) fused with the paged KV-cache write.
 //
-// Cache layouts are MFMA-operand-native (see attention_decode.hip):
+// Cache layouts are MFMA-operand-native (see attention.hip):
 //   k_cache[num_blocks][Hkv][block_size][D]   key row contiguous in D
 //   v_cache[num_blocks][Hkv][D][block_size]   transposed: D row contiguous in keys
 //
