@@ -4,10 +4,12 @@
 //   k_cache[num_blocks][Hkv][block_size][D]   key row contiguous in D
 //   v_cache[num_blocks][Hkv][D][block_size]   transposed: D row contiguous in keys
 //
-// One workgroup per token; each thread owns one 8-element (16-byte) piece:
+// Each thread owns one 8-element (16-byte) piece of one token; a token has
 //   items [0, Hq*D/16)            rotate a q pair-chunk in place
 //   items [.., +Hkv*D/16)         rotate a k pair-chunk, write it to k_cache
 //   items [.., +Hkv*D/8)          copy a v chunk to v_cache (2-byte strided stores)
+// and (token, item) pairs are laid out flat over the grid, so a rank that holds
+// one KV head (TP=8: 88 items per token) still fills 256-thread workgroups.
 #include "common.h"
 
 namespace {
@@ -17,12 +19,16 @@ __global__ void rope_cache_kernel(const int* __restrict__ positions, T* __restri
                                   const T* __restrict__ v, long q_stride, long k_stride, long v_stride,
                                   const float* __restrict__ cos_sin, T* __restrict__ k_cache,
                                   T* __restrict__ v_cache, const int* __restrict__ slot_mapping, int Hq, int Hkv,
-                                  int D, int block_size) {
+                                  int D, int block_size, int T_tokens) {
   using V = typename Vec8<T>::type;
-  const long t = blockIdx.x;
   const int half = D >> 1;
   const int cpp = half >> 3;                 // 8-element chunks per half head
   const int q_items = Hq * cpp, k_items = Hkv * cpp, v_items = WRITE_CACHE ? Hkv * (D >> 3) : 0;
+  const int items = q_items + k_items + v_items;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long t = gid / items;
+  if (t >= T_tokens) return;
+  const int item = (int)(gid - t * items);
   const int pos = ROTATE ? positions[t] : 0;
   const float* cs = cos_sin + (long)pos * D;   // [cos(half) | sin(half)]
   long slot = -1;
@@ -30,7 +36,7 @@ __global__ void rope_cache_kernel(const int* __restrict__ positions, T* __restri
   const long blk = slot >= 0 ? slot / block_size : 0;
   const int off = slot >= 0 ? (int)(slot % block_size) : 0;
 
-  for (int item = threadIdx.x; item < q_items + k_items + v_items; item += blockDim.x) {
+  {
     if (item < q_items + k_items) {
       const bool is_q = item < q_items;
       const int it = is_q ? item : item - q_items;
@@ -79,13 +85,15 @@ template <typename T>
 int launch(const int* positions, void* q, void* k, const void* v, long qs, long ks, long vs, const float* cos_sin,
            void* k_cache, void* v_cache, const int* slot_mapping, int T_tokens, int Hq, int Hkv, int D,
            int block_size, int mode, hipStream_t s) {
-  const int items = Hq * (D >> 4) + Hkv * (D >> 4) + Hkv * (D >> 3);
-  int threads = (items + 63) / 64 * 64;
-  if (threads > 512) threads = 512;
+  // mode 0 and 2 write the cache (v items exist), mode 1 rotates only
+  const long items = Hq * (D >> 4) + Hkv * (D >> 4) + (mode == 1 ? 0 : Hkv * (D >> 3));
+  const long total = items * T_tokens;
+  const int threads = 256;
+  const unsigned blocks = (unsigned)((total + threads - 1) / threads);
 #define L(WC, ROT)                                                                                          \
-  hipLaunchKernelGGL((rope_cache_kernel<T, WC, ROT>), dim3(T_tokens), dim3(threads), 0, s, positions, (T*)q, \
+  hipLaunchKernelGGL((rope_cache_kernel<T, WC, ROT>), dim3(blocks), dim3(threads), 0, s, positions, (T*)q,  \
                      (T*)k, (const T*)v, qs, ks, vs, cos_sin, (T*)k_cache, (T*)v_cache, slot_mapping, Hq, Hkv, \
-                     D, block_size)
+                     D, block_size, T_tokens)
   if (mode == 0) L(true, true);          // rotate q,k + write k,v to cache
   else if (mode == 1) L(false, true);    // rotate q,k in place only
   else L(true, false);                   // cache write only (k,v already final)
