@@ -252,3 +252,19 @@ def test_handshake_over_tcp_accepts_and_rejects():
         await server.wait_closed()
         assert results == ["ok", "rejected"]
     run(main())
+
+
+def test_rpc_suite_is_clean_under_asyncio_debug_mode():
+    """The control-plane tests again with ``PYTHONASYNCIODEBUG=1`` (slow-callback
+    and never-awaited-coroutine detection) and warnings as errors for coroutine
+    misuse: cross-thread hand-offs must all go through the loop."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONASYNCIODEBUG="1", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-W", "error::RuntimeWarning", "-m", "pytest", "-q", "-x",
+                        os.path.join(root, "tests", "test_rpc.py"), "-k", "not asyncio_debug_mode",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "never awaited" not in r.stdout + r.stderr

@@ -71,6 +71,29 @@ def _build_lib(name: str, sources: List[str], headers: List[str], compiler: str,
     return lib
 
 
+def build_sanitized(verbose: bool = True) -> str:
+    """Debug preset: the kernel library with AddressSanitizer and UBSan on the
+    *host* side of every translation unit (argument checking, launch code, the
+    direct all-reduce's handle exchange).  Device code is built as usual - GPU
+    sanitizers are not available for gfx950 here.  Load the result with
+    ``VDAMD_OPS_LIB=<path> LD_PRELOAD=$(clang -print-file-name=libclang_rt.asan-x86_64.so)``."""
+    hip_src = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    flags = ["-O1", "-g", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wno-unused-result",
+             "-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined",
+             "-Xarch_host", "-fno-omit-frame-pointer"]
+    global OUT
+    saved, OUT = OUT, os.path.join(OUT, "debug")
+    try:
+        lib = _build_lib("libvdamd_ops_asan.so", hip_src, headers, _hipcc(), flags,
+                         ["-fsanitize=address", "-fsanitize=undefined", "-shared-libsan"], force=False)
+    finally:
+        OUT = saved
+    if verbose:
+        print("built", os.path.relpath(lib, ROOT))
+    return lib
+
+
 def build(force: bool = False, verbose: bool = True) -> List[str]:
     built = []
     hip_src = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
@@ -91,4 +114,7 @@ def build(force: bool = False, verbose: bool = True) -> List[str]:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--sanitize" in sys.argv:
+        build_sanitized()
+    else:
+        build(force="--force" in sys.argv)

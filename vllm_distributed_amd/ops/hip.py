@@ -15,8 +15,9 @@ from typing import Optional, Tuple
 import torch
 
 _LIB: Optional[ctypes.CDLL] = None
-_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "_C",
-                         "libvdamd_ops.so")
+# VDAMD_OPS_LIB selects another build of the library (the host-sanitizer preset of build.py)
+_LIB_PATH = os.environ.get("VDAMD_OPS_LIB") or os.path.join(
+    os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "_C", "libvdamd_ops.so")
 _DT = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
 MAX_SPLITS = 16
 
