@@ -129,7 +129,7 @@ __device__ __forceinline__ void attend_group(
 // merged through LDS.  The 16 MFMA columns carry the GQA group's query heads.
 // ---------------------------------------------------------------------------
 template <typename T, int D>
-__global__ __launch_bounds__(256) void paged_decode_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void paged_decode_kernel(
     T* __restrict__ out, float* __restrict__ part_o, float* __restrict__ part_ml, const T* __restrict__ q,
     long q_stride, const T* __restrict__ k_cache, const T* __restrict__ v_cache,
     const int* __restrict__ block_table, int bt_stride, const int* __restrict__ seq_lens, float scale_log2e,
