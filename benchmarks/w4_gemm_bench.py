@@ -41,6 +41,8 @@ def timeit(fn, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--format", choices=["int4", "fp4"], default="int4",
+                    help="int4: AWQ-style groups of 128; fp4: NVFP4 (E2M1, one scale per 16 columns)")
     args = ap.parse_args()
     assert ops.hip_available()
     from vllm_distributed_amd.ops import hip
@@ -52,19 +54,30 @@ def main():
         q = torch.randint(0, 16, (n, k), device=dev, generator=gen, dtype=torch.uint8)
         z = torch.randint(0, 16, (n, k // 128), device=dev, generator=gen).float()
         s = torch.rand((n, k // 128), device=dev, generator=gen) * 0.01 + 0.005
-        qw, sz = quant.pack_w4(q, z, s, torch.bfloat16)
-        w = hip.w4_dequant(qw, sz)
+        if args.format == "fp4":
+            packed = torch.randint(0, 256, (n, k // 2), device=dev, generator=gen, dtype=torch.int32).to(torch.uint8)
+            bs = (0.5 + torch.rand((n, k // 16), device=dev, generator=gen)).to(torch.float8_e4m3fn)
+            qw, sz = quant.pack_fp4(packed, bs)
+            alpha = torch.full((n,), 0.01, device=dev)
+            w = hip.fp4_dequant(qw, sz, alpha, torch.bfloat16)
+            gemm = lambda x, v: hip.fp4a16_gemm(x, qw, sz, alpha, variant=v)      # noqa: E731
+            dequant = lambda: hip.fp4_dequant(qw, sz, alpha, torch.bfloat16, w)  # noqa: E731
+        else:
+            qw, sz = quant.pack_w4(q, z, s, torch.bfloat16)
+            w = hip.w4_dequant(qw, sz)
+            gemm = lambda x, v: hip.w4a16_gemm(x, qw, sz, variant=v)             # noqa: E731
+            dequant = lambda: hip.w4_dequant(qw, sz, w)                          # noqa: E731
         del q
         for m in (1, 16, 32, 64, 128, 256):
             x = torch.randn(m, k, device=dev, dtype=torch.bfloat16)
-            t0 = timeit(lambda: hip.w4a16_gemm(x, qw, sz, variant=0), args.iters)
-            t1 = timeit(lambda: hip.w4a16_gemm(x, qw, sz, variant=1), args.iters)
+            t0 = timeit(lambda: gemm(x, 0), args.iters)
+            t1 = timeit(lambda: gemm(x, 1), args.iters)
             tb = timeit(lambda: torch.nn.functional.linear(x, w), args.iters)
             t4 = min(t0, t1)
             gbs = (n * k / 2) / (t4 * 1e-6) / 1e9
             print(f"{name:26s} {m:4d} {t0:9.1f} {t1:9.1f} {gbs:9.0f} {tb:9.1f} {tb / t4:8.2f} "
                   f"{hip.w4_choose_variant(m, n, k):5d}", flush=True)
-        td = timeit(lambda: hip.w4_dequant(qw, sz, w), args.iters)
+        td = timeit(dequant, args.iters)
         print(f"{name:26s} dequant to bf16: {td:.1f} us ({n * k * 2.5 / (td * 1e-6) / 1e9:.0f} GB/s moved)")
         del qw, sz, w
 

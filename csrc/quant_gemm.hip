@@ -17,9 +17,44 @@
 // with P_g = sum_{k in g} (OFF + q[n][k]) x[m][k]  (MFMA) and
 //      X_g = sum_{k in g} x[m][k]                  (one MFMA against ones).
 // sz[nt][group][16][2] holds (s, OFF + z) per row in the activation dtype.
+//
+// FMT = 1 is the 4-bit *floating point* form (NVFP4 checkpoints): E2M1 values,
+// one OCP e4m3 scale per 16 input columns, one fp32 multiplier per output row.
+// The tile layout is the same with element e in nibble e (the checkpoint's own
+// byte order), so gfx950's packed fp4 -> f32 conversion reads a word one byte
+// at a time.  That conversion only honours the exponent of its scale operand,
+// so the e4m3 block scale is a real multiply (v_pk_mul_f32) before the
+// round to bf16; lane (c, g) needs exactly two scales per tile - words 0,1 sit
+// in block 2g and words 2,3 in block 2g+1 - stored as one dword fs[nt][kb][lane]
+// holding the two scales as bf16 (e4m3 -> bf16 is exact), which become fp32
+// with a shift and a mask.  (Converting e4m3 bytes in the loop with
+// v_cvt_pk_f32_fp8 produced wrong products, non-deterministically, whenever two
+// workgroups shared a CU on MI355X; the integer route has no such dependence.)
+// Products accumulate straight into the output tile and the per-row multiplier
+// is applied in the epilogue.
 #include "common.h"
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+enum { W4_INT = 0, W4_FP4 = 1 };
+
+template <typename T>
+__device__ __forceinline__ typename Vec8<T>::type fp4_unpack(uint32_t w, float s) {
+  typename Vec8<T>::type r;
+  const f32x2 a = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 0) * s;
+  const f32x2 b = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 1) * s;
+  const f32x2 c = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 2) * s;
+  const f32x2 d = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 3) * s;
+  r[0] = (T)a[0]; r[1] = (T)a[1]; r[2] = (T)b[0]; r[3] = (T)b[1];
+  r[4] = (T)c[0]; r[5] = (T)c[1]; r[6] = (T)d[0]; r[7] = (T)d[1];
+  return r;
+}
+
+// two bf16 block scales in one dword -> fp32
+__device__ __forceinline__ float fp4_scale(uint32_t pair, int hi) {
+  return __uint_as_float(hi ? (pair & 0xffff0000u) : (pair << 16));
+}
 
 template <typename T> struct W4Magic;
 template <> struct W4Magic<bf16_t> { static constexpr uint32_t OR = 0x43004300u; static constexpr float OFF = 128.f; };
@@ -39,11 +74,11 @@ constexpr int W4_NTW = 4;          // output tiles (16 rows each) per wave
 constexpr int W4_WAVES = 4;        // waves per workgroup; they split the K range
 
 // grid = (ceil(N/64), ksplit, ceil(M / (16*MT))), block = 256.
-template <typename T, int MT>
+template <typename T, int MT, int FMT>
 __global__ __launch_bounds__(256) void w4a16_gemm_kernel(
     const T* __restrict__ x, long x_stride, const uint32_t* __restrict__ qw, const T* __restrict__ sz,
     T* __restrict__ out, long out_stride, float* __restrict__ partial, int M, int N, int K,
-    int kb_per_group, int ksplit) {
+    int kb_per_group, int ksplit, const float* __restrict__ alpha) {
   using V8 = typename Vec8<T>::type;
   constexpr bool PREFETCH_X = MT <= 2;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -77,11 +112,14 @@ __global__ __launch_bounds__(256) void w4a16_gemm_kernel(
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones[j] = (T)1.0f;
 
-  auto load_w = [&](int kb, u32x4 (&w)[W4_NTW], V8 (&s)[W4_NTW]) {
+  auto load_w = [&](int kb, u32x4 (&w)[W4_NTW], V8 (&s)[W4_NTW], uint32_t (&f)[W4_NTW]) {
 #pragma unroll
     for (int t = 0; t < W4_NTW; ++t) {
       w[t] = *reinterpret_cast<const u32x4*>(qw + (((size_t)ntc[t] * KB + kb) << 8) + lane * 4);
-      s[t] = ld8(sz + ((((size_t)ntc[t] * NG + kb / kb_per_group) * 16 + 4 * g) << 1));
+      if (FMT == W4_INT)
+        s[t] = ld8(sz + ((((size_t)ntc[t] * NG + kb / kb_per_group) * 16 + 4 * g) << 1));
+      else
+        f[t] = reinterpret_cast<const uint32_t*>(sz)[(((size_t)ntc[t] * KB + kb) << 6) + lane];
     }
   };
   auto load_x = [&](int kb, V8 (&bx)[MT][4]) {
@@ -93,26 +131,38 @@ __global__ __launch_bounds__(256) void w4a16_gemm_kernel(
 
   u32x4 wc[W4_NTW], wn[W4_NTW];
   V8 sc[W4_NTW], sn[W4_NTW];
+  uint32_t fc[W4_NTW], fn[W4_NTW];
   V8 bxc[MT][4], bxn[MT][4];
   if (w_lo < w_hi) {
-    load_w(w_lo, wc, sc);
+    load_w(w_lo, wc, sc, fc);
     load_x(w_lo, bxc);
   }
   for (int kb = w_lo; kb < w_hi; ++kb) {
     const bool more = kb + 1 < w_hi;
     if (more) {
-      load_w(kb + 1, wn, sn);
+      load_w(kb + 1, wn, sn, fn);
       if (PREFETCH_X) load_x(kb + 1, bxn);
     }
     f32x4 xs[MT];
+    if (FMT == W4_INT) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      xs[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int mt = 0; mt < MT; ++mt) {
+        xs[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < 4; ++s) xs[mt] = mfma16(ones, bxc[mt][s], xs[mt]);
+        for (int s = 0; s < 4; ++s) xs[mt] = mfma16(ones, bxc[mt][s], xs[mt]);
+      }
     }
 #pragma unroll
     for (int t = 0; t < W4_NTW; ++t) {
+      if (FMT == W4_FP4) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const V8 a = fp4_unpack<T>(wc[t][s], fp4_scale(fc[t], s >> 1));
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[t][mt] = mfma16(a, bxc[mt][s], acc[t][mt]);
+        }
+        continue;
+      }
       f32x4 p[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) p[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -131,7 +181,7 @@ __global__ __launch_bounds__(256) void w4a16_gemm_kernel(
     }
     if (more) {
 #pragma unroll
-      for (int t = 0; t < W4_NTW; ++t) { wc[t] = wn[t]; sc[t] = sn[t]; }
+      for (int t = 0; t < W4_NTW; ++t) { wc[t] = wn[t]; sc[t] = sn[t]; fc[t] = fn[t]; }
       if (PREFETCH_X) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -170,6 +220,11 @@ __global__ __launch_bounds__(256) void w4a16_gemm_kernel(
   const int nt = nt0 + wid;
   if (nt >= ntiles) return;
   const int n = 16 * nt + 4 * g;
+  if (FMT == W4_FP4 && alpha != nullptr) {
+    const f32x4 al = *reinterpret_cast<const f32x4*>(alpha + n);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) res[mt] *= al;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = m0 + 16 * mt + c;
@@ -199,11 +254,12 @@ constexpr int W4_XPAD = 128;
 // then always belong to the same set.
 __device__ __forceinline__ int w4_swz(int r) { return (r & 10) | ((r & 1) << 2) | ((r >> 2) & 1); }
 
-template <typename T, int MT>
+template <typename T, int MT, int FMT>
 __global__ __launch_bounds__(256) void w4a16_gemm_lds_kernel(
     const T* __restrict__ x, long x_stride, const uint32_t* __restrict__ qw, const T* __restrict__ sz,
     T* __restrict__ out, long out_stride, float* __restrict__ partial, int M, int N, int K,
-    int kb_per_group, int ksplit, const int* __restrict__ tiles, long qw_group_stride, long sz_group_stride) {
+    int kb_per_group, int ksplit, const int* __restrict__ tiles, long qw_group_stride, long sz_group_stride,
+    const float* __restrict__ alpha) {
   using V8 = typename Vec8<T>::type;
   __shared__ __attribute__((aligned(16))) T xl[2][MT * 16][W4_XPAD];
   int m0 = blockIdx.z * (16 * MT);
@@ -214,7 +270,8 @@ __global__ __launch_bounds__(256) void w4a16_gemm_lds_kernel(
     M = d[2];
     if (M == 0) return;
     qw += (size_t)d[0] * qw_group_stride;
-    sz += (size_t)d[0] * sz_group_stride;
+    sz += (size_t)d[0] * sz_group_stride;      // in elements of T (FMT 1: two per scale dword)
+    if (alpha != nullptr) alpha += (size_t)d[0] * N;
     x += (long)d[1] * x_stride;
     out += (long)d[1] * out_stride;
     m0 = 0;
@@ -244,18 +301,22 @@ __global__ __launch_bounds__(256) void w4a16_gemm_lds_kernel(
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones[j] = (T)1.0f;
 
-  auto load_w = [&](int kb, u32x4 (&w)[W4_NTW], V8 (&s)[W4_NTW]) {
+  auto load_w = [&](int kb, u32x4 (&w)[W4_NTW], V8 (&s)[W4_NTW], uint32_t (&f)[W4_NTW]) {
 #pragma unroll
     for (int t = 0; t < W4_NTW; ++t) {
       w[t] = *reinterpret_cast<const u32x4*>(qw + (((size_t)ntc[t] * KB + kb) << 8) + lane * 4);
-      s[t] = ld8(sz + ((((size_t)ntc[t] * NG + kb / kb_per_group) * 16 + 4 * g) << 1));
+      if (FMT == W4_INT)
+        s[t] = ld8(sz + ((((size_t)ntc[t] * NG + kb / kb_per_group) * 16 + 4 * g) << 1));
+      else
+        f[t] = reinterpret_cast<const uint32_t*>(sz)[(((size_t)ntc[t] * KB + kb) << 6) + lane];
     }
   };
   u32x4 wc[W4_NTW], wn[W4_NTW];
   V8 sc[W4_NTW], sn[W4_NTW];
+  uint32_t fc[W4_NTW], fn[W4_NTW];
   V8 xreg[MT];
   if (kb_lo < kb_hi) {
-    load_w(kb_lo, wc, sc);
+    load_w(kb_lo, wc, sc, fc);
 #pragma unroll
     for (int p = 0; p < MT; ++p) st8(&xl[0][16 * p + xr][8 * (xc ^ w4_swz(xr))], ld8(xsrc[p] + (kb_lo << 7)));
   }
@@ -264,7 +325,7 @@ __global__ __launch_bounds__(256) void w4a16_gemm_lds_kernel(
     const int buf = (kb - kb_lo) & 1;
     const bool more = kb + 1 < kb_hi;
     if (more) {
-      load_w(kb + 1, wn, sn);
+      load_w(kb + 1, wn, sn, fn);
 #pragma unroll
       for (int p = 0; p < MT; ++p) xreg[p] = ld8(xsrc[p] + ((kb + 1) << 7));
     }
@@ -274,14 +335,25 @@ __global__ __launch_bounds__(256) void w4a16_gemm_lds_kernel(
 #pragma unroll
       for (int s = 0; s < 4; ++s) bx[mt][s] = ld8(&xl[buf][16 * mt + c][8 * ((4 * g + s) ^ w4_swz(c))]);
     f32x4 xs[MT];
+    if (FMT == W4_INT) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      xs[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int mt = 0; mt < MT; ++mt) {
+        xs[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < 4; ++s) xs[mt] = mfma16(ones, bx[mt][s], xs[mt]);
+        for (int s = 0; s < 4; ++s) xs[mt] = mfma16(ones, bx[mt][s], xs[mt]);
+      }
     }
 #pragma unroll
     for (int t = 0; t < W4_NTW; ++t) {
+      if (FMT == W4_FP4) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const V8 a = fp4_unpack<T>(wc[t][s], fp4_scale(fc[t], s >> 1));
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[t][mt] = mfma16(a, bx[mt][s], acc[t][mt]);
+        }
+        continue;
+      }
       f32x4 p[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) p[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -300,7 +372,7 @@ __global__ __launch_bounds__(256) void w4a16_gemm_lds_kernel(
     }
     if (more) {
 #pragma unroll
-      for (int t = 0; t < W4_NTW; ++t) { wc[t] = wn[t]; sc[t] = sn[t]; }
+      for (int t = 0; t < W4_NTW; ++t) { wc[t] = wn[t]; sc[t] = sn[t]; fc[t] = fn[t]; }
 #pragma unroll
       for (int p = 0; p < MT; ++p) st8(&xl[buf ^ 1][16 * p + xr][8 * (xc ^ w4_swz(xr))], xreg[p]);
     }
@@ -310,6 +382,11 @@ __global__ __launch_bounds__(256) void w4a16_gemm_lds_kernel(
   for (int t = 0; t < W4_NTW; ++t) {
     if (nt0 + t >= ntiles) continue;
     const int n = 16 * (nt0 + t) + 4 * g;
+    if (FMT == W4_FP4 && alpha != nullptr) {
+      const f32x4 al = *reinterpret_cast<const f32x4*>(alpha + n);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[t][mt] *= al;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int m = m0 + 16 * mt + c;
@@ -364,22 +441,23 @@ __global__ __launch_bounds__(256) void w4_dequant_kernel(T* __restrict__ out, co
   st8(out + (size_t)(16 * nt + row) * K + (kb << 7) + 8 * kk, o);
 }
 
-template <typename T>
+template <typename T, int FMT>
 static int launch_w4a16(void* out, long out_stride, const void* x, long x_stride, const void* qw,
-                        const void* sz, void* partial, int M, int N, int K, int G, int ksplit, int variant,
-                        hipStream_t st) {
+                        const void* sz, const float* alpha, void* partial, int M, int N, int K, int G,
+                        int ksplit, int variant, hipStream_t st) {
   const int mt = min(4, (M + 15) / 16);
   const int tiles_per_wg = variant == 1 ? W4_NTW * W4_WAVES : W4_NTW;
   dim3 grid((N / 16 + tiles_per_wg - 1) / tiles_per_wg, ksplit, (M + 16 * mt - 1) / (16 * mt));
-#define W4_LAUNCH(MT_)                                                                                   \
-  if (variant == 1)                                                                                      \
-    w4a16_gemm_lds_kernel<T, MT_><<<grid, 256, 0, st>>>((const T*)x, x_stride, (const uint32_t*)qw,     \
-                                                     (const T*)sz, (T*)out, out_stride, (float*)partial, \
-                                                     M, N, K, G / 128, ksplit, nullptr, 0, 0);           \
-  else                                                                                                   \
-    w4a16_gemm_kernel<T, MT_><<<grid, 256, 0, st>>>((const T*)x, x_stride, (const uint32_t*)qw,         \
-                                                 (const T*)sz, (T*)out, out_stride, (float*)partial,     \
-                                                 M, N, K, G / 128, ksplit)
+#define W4_LAUNCH(MT_)                                                                                      \
+  if (variant == 1)                                                                                         \
+    w4a16_gemm_lds_kernel<T, MT_, FMT><<<grid, 256, 0, st>>>((const T*)x, x_stride, (const uint32_t*)qw,   \
+                                                          (const T*)sz, (T*)out, out_stride,                \
+                                                          (float*)partial, M, N, K, G / 128, ksplit,        \
+                                                          nullptr, 0, 0, alpha);                            \
+  else                                                                                                      \
+    w4a16_gemm_kernel<T, MT_, FMT><<<grid, 256, 0, st>>>((const T*)x, x_stride, (const uint32_t*)qw,       \
+                                                      (const T*)sz, (T*)out, out_stride, (float*)partial,  \
+                                                      M, N, K, G / 128, ksplit, alpha)
   switch (mt) {
     case 1: W4_LAUNCH(1); break;
     case 2: W4_LAUNCH(2); break;
@@ -397,6 +475,22 @@ static int launch_w4a16(void* out, long out_stride, const void* x, long x_stride
   return 0;
 }
 
+// fp4 tiles -> dense [N][K]; same thread mapping as w4_dequant_kernel
+template <typename T>
+__global__ __launch_bounds__(256) void fp4_dequant_kernel(T* __restrict__ out, const uint32_t* __restrict__ qw,
+                                                          const uint32_t* __restrict__ fs,
+                                                          const float* __restrict__ alpha, int N, int K) {
+  const int KB = K >> 7;
+  const int tile = blockIdx.x;
+  const int nt = tile / KB, kb = tile % KB;
+  const int kk = threadIdx.x & 15, row = threadIdx.x >> 4;
+  const int lane = row + 16 * (kk >> 2), word = kk & 3;
+  const uint32_t w = qw[((size_t)tile << 8) + lane * 4 + word];
+  float s = fp4_scale(fs[((size_t)tile << 6) + lane], word >> 1);
+  if (alpha != nullptr) s *= alpha[16 * nt + row];
+  st8(out + (size_t)(16 * nt + row) * K + (kb << 7) + 8 * kk, fp4_unpack<T>(w, s));
+}
+
 // y[M][N] = x[M][K] . dequant(qw, sz)^T.  Requires K % 128 == 0, N % 16 == 0,
 // G % 128 == 0, K % G == 0, 1 <= ksplit <= K/128; `partial` holds ksplit*M*N
 // floats when ksplit > 1.  variant 0: waves split K (one 64-row tile group per
@@ -409,9 +503,39 @@ VDAMD_API int vdamd_w4a16_gemm(void* out, long out_stride, const void* x, long x
   if (ksplit > 1 && partial == nullptr) return -2;
   if (variant != 0 && variant != 1) return -4;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DT_BF16) return launch_w4a16<bf16_t>(out, out_stride, x, x_stride, qw, sz, partial, M, N, K, G, ksplit, variant, st);
-  if (dtype == DT_F16) return launch_w4a16<f16_t>(out, out_stride, x, x_stride, qw, sz, partial, M, N, K, G, ksplit, variant, st);
+  if (dtype == DT_BF16) return launch_w4a16<bf16_t, W4_INT>(out, out_stride, x, x_stride, qw, sz, nullptr, partial, M, N, K, G, ksplit, variant, st);
+  if (dtype == DT_F16) return launch_w4a16<f16_t, W4_INT>(out, out_stride, x, x_stride, qw, sz, nullptr, partial, M, N, K, G, ksplit, variant, st);
   return -3;
+}
+
+// NVFP4 weights: qw as above with element e in nibble e, fs[N/16][K/128][64]
+// dwords of two bf16 block scales, alpha[N] fp32 per-row multipliers (may be null).
+VDAMD_API int vdamd_fp4a16_gemm(void* out, long out_stride, const void* x, long x_stride, const void* qw,
+                                const void* fs, const float* alpha, void* partial, int M, int N, int K,
+                                int ksplit, int variant, int dtype, void* stream) {
+  if (M <= 0) return 0;
+  if (K % 128 || N % 16 || ksplit < 1 || ksplit > K / 128) return -1;
+  if (ksplit > 1 && partial == nullptr) return -2;
+  if (variant != 0 && variant != 1) return -4;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) return launch_w4a16<bf16_t, W4_FP4>(out, out_stride, x, x_stride, qw, fs, alpha, partial, M, N, K, 128, ksplit, variant, st);
+  if (dtype == DT_F16) return launch_w4a16<f16_t, W4_FP4>(out, out_stride, x, x_stride, qw, fs, alpha, partial, M, N, K, 128, ksplit, variant, st);
+  return -3;
+}
+
+VDAMD_API int vdamd_fp4_dequant(void* out, const void* qw, const void* fs, const float* alpha, int N, int K,
+                                int dtype, void* stream) {
+  if (K % 128 || N % 16) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned tiles = (unsigned)((N / 16) * (K / 128));
+  if (dtype == DT_BF16)
+    fp4_dequant_kernel<bf16_t><<<tiles, 256, 0, st>>>((bf16_t*)out, (const uint32_t*)qw, (const uint32_t*)fs, alpha, N, K);
+  else if (dtype == DT_F16)
+    fp4_dequant_kernel<f16_t><<<tiles, 256, 0, st>>>((f16_t*)out, (const uint32_t*)qw, (const uint32_t*)fs, alpha, N, K);
+  else
+    return -3;
+  HIP_LAUNCH_CHECK();
+  return 0;
 }
 
 VDAMD_API int vdamd_w4_dequant(void* out, const void* qw, const void* sz, int N, int K, int G, int dtype,
@@ -429,14 +553,15 @@ VDAMD_API int vdamd_w4_dequant(void* out, const void* qw, const void* sz, int N,
   return 0;
 }
 
-template <typename T>
+template <typename T, int FMT>
 static int launch_w4_grouped(void* out, long os, const void* x, long xs, const void* qw, const void* sz, long qgs,
-                             long sgs, const int* tiles, int num_tiles, int tile_rows, int N, int K, int G,
-                             hipStream_t st) {
+                             long sgs, const float* alpha, const int* tiles, int num_tiles, int tile_rows, int N,
+                             int K, int G, hipStream_t st) {
   dim3 grid((N / 16 + W4_NTW * W4_WAVES - 1) / (W4_NTW * W4_WAVES), 1, num_tiles);
 #define W4G(MT_)                                                                                                \
-  w4a16_gemm_lds_kernel<T, MT_><<<grid, 256, 0, st>>>((const T*)x, xs, (const uint32_t*)qw, (const T*)sz, (T*)out, os, \
-                                                     nullptr, tile_rows, N, K, G / 128, 1, tiles, qgs, sgs)
+  w4a16_gemm_lds_kernel<T, MT_, FMT><<<grid, 256, 0, st>>>((const T*)x, xs, (const uint32_t*)qw, (const T*)sz,     \
+                                                          (T*)out, os, nullptr, tile_rows, N, K, G / 128, 1,   \
+                                                          tiles, qgs, sgs, alpha)
   switch (tile_rows / 16) {
     case 1: W4G(1); break;
     case 2: W4G(2); break;
@@ -460,10 +585,29 @@ VDAMD_API int vdamd_w4a16_gemm_grouped(void* out, long out_stride, const void* x
   if (K % 128 || N % 16 || G % 128 || K % G) return -1;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16)
-    return launch_w4_grouped<bf16_t>(out, out_stride, x, x_stride, qw, sz, qw_group_stride, sz_group_stride, tiles,
-                                     num_tiles, tile_rows, N, K, G, st);
+    return launch_w4_grouped<bf16_t, W4_INT>(out, out_stride, x, x_stride, qw, sz, qw_group_stride, sz_group_stride,
+                                             nullptr, tiles, num_tiles, tile_rows, N, K, G, st);
   if (dtype == DT_F16)
-    return launch_w4_grouped<f16_t>(out, out_stride, x, x_stride, qw, sz, qw_group_stride, sz_group_stride, tiles,
-                                    num_tiles, tile_rows, N, K, G, st);
+    return launch_w4_grouped<f16_t, W4_INT>(out, out_stride, x, x_stride, qw, sz, qw_group_stride, sz_group_stride,
+                                            nullptr, tiles, num_tiles, tile_rows, N, K, G, st);
+  return -3;
+}
+
+// fs_group_stride counts 16-bit halves (2 * N/16 * K/128 * 64 per group);
+// alpha is [groups][N] or null.
+VDAMD_API int vdamd_fp4a16_gemm_grouped(void* out, long out_stride, const void* x, long x_stride, const void* qw,
+                                        const void* fs, long qw_group_stride, long fs_group_stride,
+                                        const float* alpha, const int* tiles, int num_tiles, int tile_rows, int N,
+                                        int K, int dtype, void* stream) {
+  if (num_tiles <= 0) return 0;
+  if (tile_rows <= 0 || tile_rows > 64 || tile_rows % 16 || tiles == nullptr) return -1;
+  if (K % 128 || N % 16) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16)
+    return launch_w4_grouped<bf16_t, W4_FP4>(out, out_stride, x, x_stride, qw, fs, qw_group_stride, fs_group_stride,
+                                             alpha, tiles, num_tiles, tile_rows, N, K, 128, st);
+  if (dtype == DT_F16)
+    return launch_w4_grouped<f16_t, W4_FP4>(out, out_stride, x, x_stride, qw, fs, qw_group_stride, fs_group_stride,
+                                            alpha, tiles, num_tiles, tile_rows, N, K, 128, st);
   return -3;
 }

@@ -246,3 +246,62 @@ def test_mixtral_checkpoint_round_trip_and_quantised_experts(tmp_path):
         llm.shutdown()
         pstate.destroy_model_parallel()
     assert outs["dummy"] == outs["file"] and outs["awq"] == outs["awq-dequant"]
+
+
+def test_nvfp4_checkpoint_spellings_and_dense_equivalent(tmp_path):
+    """NVFP4 tensors (packed E2M1 bytes, e4m3 block scales, per-matrix global
+    scale) load from safetensors exactly as the dummy stream yields them, the
+    modelopt spelling of the same tensors is accepted, and the packed model
+    matches the dense model built from the dequantised definition."""
+    import json
+    from safetensors.torch import load_file, save_file
+    from vllm_distributed_amd.config import ModelConfig
+    from vllm_distributed_amd.models.layers.linear import nvfp4_dequantize
+    from vllm_distributed_amd.models.loader import save_dummy_checkpoint
+    mc = ModelConfig(model="llama-tiny", dtype="float32", load_format="dummy", quantization="nvfp4")
+    src = tmp_path / "ct"
+    save_dummy_checkpoint(mc, str(src))
+    cfg = dict(mc.hf_config, quantization_config={"quant_method": "compressed-tensors",
+                                                  "format": "nvfp4-pack-quantized"})
+    (src / "config.json").write_text(json.dumps(cfg))
+    assert ModelConfig(model=str(src), dtype="float32").quantization == "nvfp4"
+    sd = load_file(str(src / "model.safetensors"))
+    assert any(k.endswith(".weight_packed") for k in sd)
+    # modelopt spelling; dense equivalent
+    mo, dense = {}, {}
+    for k, v in sd.items():
+        if k.endswith(".weight_packed"):
+            base = k[:-len(".weight_packed")]
+            mo[base + ".weight"] = v
+            alpha = sd[base + ".weight_global_scale"].reciprocal()
+            dense[base + ".weight"] = nvfp4_dequantize(v, sd[base + ".weight_scale"],
+                                                       alpha.expand(v.shape[0]), torch.float32)
+        elif k.endswith(".weight_global_scale"):
+            mo[k[:-len("weight_global_scale")] + "weight_scale_2"] = v.reciprocal()
+            mo[k[:-len("weight_global_scale")] + "input_scale"] = torch.ones(1)
+        elif k.endswith(".weight_scale"):
+            mo[k] = v
+        else:
+            mo[k] = dense[k] = v
+    for tag, tensors, qc in (("mo", mo, {"quant_method": "modelopt", "quant_algo": "NVFP4"}), ("dense", dense, None)):
+        d = tmp_path / tag
+        d.mkdir()
+        save_file({k: v.contiguous() for k, v in tensors.items()}, str(d / "model.safetensors"))
+        c = dict(mc.hf_config)
+        if qc:
+            c["quantization_config"] = qc
+        (d / "config.json").write_text(json.dumps(c))
+    outs = {}
+    for tag, kw in (("dummy", dict(model="llama-tiny", quantization="nvfp4")), ("ct", dict(model=str(src))),
+                    ("mo", dict(model=str(tmp_path / "mo"))), ("dense", dict(model=str(tmp_path / "dense")))):
+        llm = LLM(device="cpu", dtype="float32", max_model_len=128, block_size=16, num_gpu_blocks_override=64,
+                  max_num_seqs=8, **kw)
+        model = llm.engine.core.executor.driver.worker.model_runner.model
+        layer = next(iter(model.layers.values()))
+        assert (layer.mlp.down_proj.alpha is not None) == (tag != "dense")
+        o = llm.generate([[5, 9, 200, 17], list(range(10, 50))],
+                         SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True))
+        outs[tag] = [x.outputs[0].token_ids for x in o]
+        llm.shutdown()
+        pstate.destroy_model_parallel()
+    assert outs["dummy"] == outs["ct"] == outs["mo"] == outs["dense"]

@@ -20,7 +20,8 @@ def _packed(n, k, g, dtype, seed=0):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("n,k,g", [(256, 512, 128), (1040, 1024, 128), (1280, 8192, 128), (512, 1024, 256)])
+@pytest.mark.parametrize("n,k,g", [(256, 512, 128), (1040, 1024, 128), (1280, 8192, 128), (512, 1024, 256),
+                                   (8192, 4096, 128)])     # the last: more workgroups than CUs
 @pytest.mark.parametrize("m", [1, 7, 16, 33, 64, 130, 256])
 @pytest.mark.parametrize("variant", [0, 1])
 def test_w4a16_gemm_matches_definition(dtype, n, k, g, m, variant):
@@ -202,3 +203,154 @@ def test_fp8_model_on_gpu_tracks_bf16_model():
         t = a.outputs[0].token_ids[0]
         lb = b.outputs[0].logprobs[0]
         assert t in lb and abs(lb[t] - a.outputs[0].logprobs[0][t]) < 0.25
+
+
+# ------------------------------------------------------------------ NVFP4
+def _fp4_packed(n, k, seed=0, alpha=True):
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    packed = torch.randint(0, 256, (n, k // 2), generator=gen, dtype=torch.int32).to(torch.uint8)
+    bs = (0.25 + 2.0 * torch.rand((n, k // 16), generator=gen)).to(torch.float8_e4m3fn)
+    qw, fs = quant.pack_fp4(packed, bs)
+    al = (0.002 + 0.01 * torch.rand(n, generator=gen)).float() if alpha else None
+    return qw.to(DEV), fs.to(DEV), None if al is None else al.to(DEV)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n,k", [(256, 512), (1040, 1024), (1280, 8192), (8192, 4096)])
+@pytest.mark.parametrize("m", [1, 7, 16, 33, 64, 130, 256])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_fp4a16_gemm_matches_definition(dtype, n, k, m, variant):
+    """E2M1 weights x e4m3 block scales x per-row fp32 scale against the fp32
+    definition of the layout (ops/quant.py: fp4_dequant)."""
+    from vllm_distributed_amd.ops import hip
+    ops.hip_available()
+    qw, fs, alpha = _fp4_packed(n, k, seed=n + k + m, alpha=(m % 2 == 1))
+    x = torch.randn(m, k, device=DEV, dtype=dtype)
+    y = hip.fp4a16_gemm(x, qw, fs, alpha, variant=variant)
+    torch.cuda.synchronize()
+    # the kernel rounds each (e2m1 * block scale) product to the activation dtype before the MFMA
+    w = quant.fp4_dequant(qw, fs, None).to(dtype).float()
+    ref = x.float() @ w.t()
+    if alpha is not None:
+        ref = ref * alpha.reshape(1, -1)
+    tol = ref.abs().max().item() * (2 ** -7 if dtype == torch.bfloat16 else 2 ** -9)
+    assert y.shape == (m, n)
+    assert (y.float() - ref).abs().max().item() <= tol
+
+
+def test_fp4_forced_splits_dequant_and_large_batch_path():
+    from vllm_distributed_amd.ops import hip
+    ops.hip_available()
+    qw, fs, alpha = _fp4_packed(512, 2048, seed=3)
+    big = torch.randn(20, 4096, device=DEV, dtype=torch.bfloat16)
+    x = big[:, 1024:3072]
+    wref = quant.fp4_dequant(qw, fs, None).to(torch.bfloat16).float()
+    ref = (x.float() @ wref.t()) * alpha.reshape(1, -1)
+    for variant, ksplit in ((0, None), (1, None), (0, 1), (1, 1), (0, 2), (1, 4)):
+        y = hip.fp4a16_gemm(x, qw, fs, alpha, variant=variant, ksplit=ksplit)
+        assert (y.float() - ref).abs().max().item() <= ref.abs().max().item() * 2 ** -7
+    # several workgroups per CU, repeatedly: results must not depend on what shares the CU
+    qw2, fs2, _ = _fp4_packed(8192, 4096, seed=9, alpha=False)
+    w2 = quant.fp4_dequant(qw2, fs2, None).to(torch.bfloat16).float()
+    for m in (48, 192):
+        x2 = torch.randn(m, 4096, device=DEV, dtype=torch.bfloat16)
+        ref2 = x2.float() @ w2.t()
+        for variant, ksplit in ((0, 4), (1, 1), (1, 4)):
+            for _ in range(3):
+                y = hip.fp4a16_gemm(x2, qw2, fs2, None, variant=variant, ksplit=ksplit)
+                assert (y.float() - ref2).abs().max().item() <= ref2.abs().max().item() * 2 ** -7
+    for dtype in (torch.bfloat16, torch.float16):
+        w = hip.fp4_dequant(qw, fs, alpha, dtype)
+        want = quant.fp4_dequant(qw, fs, alpha)
+        assert (w.float() - want).abs().max().item() <= want.abs().max().item() * 2 ** -8
+    xl = torch.randn(hip.W4_MAX_FUSED_M + 44, 2048, device=DEV, dtype=torch.bfloat16)
+    bias = torch.randn(512, device=DEV, dtype=torch.bfloat16)
+    y = ops.fp4_linear(xl, qw, fs, alpha, bias)
+    want = xl.float() @ quant.fp4_dequant(qw, fs, alpha).t() + bias.float()
+    assert (y.float() - want).abs().max().item() <= want.abs().max().item() * 2 ** -5
+
+
+def test_quantize_fp4_round_trip_on_gpu_kernel():
+    """Dense weights -> NVFP4 checkpoint tensors -> kernel: the product tracks
+    the dense product to fp4 accuracy."""
+    from vllm_distributed_amd.ops import hip
+    ops.hip_available()
+    torch.manual_seed(0)
+    w = torch.randn(256, 1024) * 0.03
+    packed, bs, g = quant.quantize_fp4(w)
+    qw, fs = quant.pack_fp4(packed, bs)
+    alpha = (1.0 / g).expand(256).contiguous()
+    x = torch.randn(8, 1024, device=DEV, dtype=torch.bfloat16)
+    y = hip.fp4a16_gemm(x, qw.to(DEV), fs.to(DEV), alpha.to(DEV))
+    ref = x.float() @ w.to(DEV).t()
+    rel = (y.float() - ref).norm() / ref.norm()
+    assert rel < 0.15, rel
+
+
+@pytest.mark.parametrize("tokens", [1, 64, 300])
+def test_fused_moe_nvfp4_grouped_matches_per_expert_loop(tokens, monkeypatch):
+    from vllm_distributed_amd.models.layers.linear import QuantSpec, quantized_linears
+    from vllm_distributed_amd.models.layers.moe import FusedMoE
+    from vllm_distributed_amd.parallel import state as pstate
+    pstate.destroy_model_parallel()
+    pstate.ensure_single_process_groups(torch.device(DEV))
+    hidden, inter, experts, top_k = 512, 256, 16, 4
+    with torch.device(DEV), quantized_linears(QuantSpec("nvfp4", 16, 1)):
+        moe = FusedMoE(hidden, inter, experts, top_k, True, torch.bfloat16)
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    for name, p in moe.named_parameters():
+        if p.dtype == torch.uint8:
+            p.data.copy_(torch.randint(0, 256, p.shape, device=DEV, generator=gen, dtype=torch.int32).to(torch.uint8))
+        elif p.dtype == torch.float8_e4m3fn:
+            p.data.copy_((0.5 + torch.rand(p.shape, device=DEV, generator=gen)).to(p.dtype))
+        elif "alpha" in name:
+            p.data.copy_(0.005 + 0.005 * torch.rand(p.shape, device=DEV, generator=gen))
+        else:
+            p.data.copy_((torch.randn(p.shape, device=DEV, generator=gen) * 0.05).to(p.dtype))
+    moe.finalize_weights()
+    assert moe.alpha13 is not None and moe.sz13.dtype == torch.int32
+    x = torch.randn(tokens, hidden, device=DEV, generator=gen).to(torch.bfloat16)
+    with torch.inference_mode():
+        monkeypatch.setattr(FusedMoE, "_grouped_tile_rows", lambda self, x: 0)
+        ref = moe(x).float()
+        for tile_rows in (16, 64):
+            monkeypatch.setattr(FusedMoE, "_grouped_tile_rows", lambda self, x, r=tile_rows: r)
+            got = moe(x).float()
+            torch.cuda.synchronize()
+            err = (got - ref).abs().max().item()
+            assert err <= 0.03 * ref.abs().max().item() + 1e-3, (tile_rows, err)
+    pstate.destroy_model_parallel()
+
+
+def test_nvfp4_model_on_gpu_matches_cpu_definition(tmp_path):
+    """Packed NVFP4 execution on the GPU against the same checkpoint file run
+    through the fp32 CPU definition of the format."""
+    import json
+    from vllm_distributed_amd import LLM, SamplingParams
+    from vllm_distributed_amd.config import ModelConfig
+    from vllm_distributed_amd.models.loader import save_dummy_checkpoint
+    from vllm_distributed_amd.parallel import state as pstate
+    mc = ModelConfig(model="llama-tiny", dtype="float32", load_format="dummy", quantization="nvfp4")
+    save_dummy_checkpoint(mc, str(tmp_path))
+    (tmp_path / "config.json").write_text(json.dumps(dict(
+        mc.hf_config, quantization_config={"quant_method": "compressed-tensors", "format": "nvfp4-pack-quantized"})))
+    outs = {}
+    for dev in ("cuda", "cpu"):
+        kw = dict(dtype="bfloat16", gpu_memory_utilization=0.3) if dev == "cuda" else dict(dtype="float32", device="cpu")
+        llm = LLM(model=str(tmp_path), max_model_len=256, num_gpu_blocks_override=64, max_num_seqs=8, **kw)
+        if dev == "cuda":
+            model = llm.engine.core.executor.driver.worker.model_runner.model
+            layer = next(iter(model.layers.values()))
+            assert layer.self_attn.qkv_proj.alpha is not None and layer.mlp.down_proj.sz.dtype == torch.int32
+        outs[dev] = llm.generate([[5, 9, 200, 17], list(range(10, 90))],
+                                 SamplingParams(temperature=0.0, max_tokens=2, ignore_eos=True, logprobs=20))
+        llm.shutdown()
+        pstate.destroy_model_parallel()
+    # random fp4 weights give a nearly flat distribution, so the argmax itself is
+    # not stable under bf16 rounding: compare the log-probabilities of the
+    # tokens both runs rank in their top 20
+    for a, b in zip(outs["cuda"], outs["cpu"]):
+        la, lb = a.outputs[0].logprobs[0], b.outputs[0].logprobs[0]
+        common = set(la) & set(lb)
+        assert len(common) >= 8, (sorted(la), sorted(lb))
+        assert max(abs(la[t] - lb[t]) for t in common) < 0.15

@@ -22,7 +22,7 @@ eng = LLMEngine.from_engine_args(EngineArgs(
     model="llama-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,
     num_gpu_blocks_override=64, max_num_seqs=8, tensor_parallel_size=tp,
     distributed_executor_backend="spmd" if tp > 1 else "uni",
-    async_scheduling=os.environ.get("ASYNC") == "1"))
+    async_scheduling=os.environ.get("ASYNC") == "1", quantization=os.environ.get("QUANT") or None))
 sp = SamplingParams(temperature=0.8, top_p=0.9, seed=7, max_tokens=8, ignore_eos=True)
 g = SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True)
 ids = [eng.add_request(None, p, s) for p, s in (([5, 9, 200, 17], g), (list(range(10, 50)), sp), ([7, 7], g))]
@@ -36,14 +36,14 @@ eng.shutdown()
 """
 
 
-def _run(world, async_sched=False, sp="0"):
+def _run(world, async_sched=False, sp="0", quant=""):
     port = get_open_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VLLM_LOGGING_LEVEL="WARNING",
                    GLOO_SOCKET_IFNAME="lo", OMP_NUM_THREADS="2", ASYNC="1" if async_sched else "0",
-                   VDAMD_SEQUENCE_PARALLEL=sp)
+                   VDAMD_SEQUENCE_PARALLEL=sp, QUANT=quant)
         procs.append(subprocess.Popen([sys.executable, "-c", SCRIPT.format(root=ROOT)], env=env,
                                       stdout=subprocess.PIPE, text=True))
     outs = []
@@ -64,6 +64,16 @@ def test_spmd_tp2_matches_single_process_on_every_rank():
     assert got[0] == ref and got[1] == ref
     # sequence-parallel residual stream wherever the token count divides by TP
     got = _run(2, sp="force")
+    assert got[0] == ref and got[1] == ref
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("quant", ["awq", "nvfp4"])
+def test_spmd_tp2_quantised_shards_match_single_process(quant):
+    """Packed 4-bit tensors (integer groups / fp4 blocks with per-matrix
+    scalars) are cut per rank before repacking: TP=2 reproduces TP=1."""
+    ref = _run(1, quant=quant)[0]
+    got = _run(2, quant=quant)
     assert got[0] == ref and got[1] == ref
 
 

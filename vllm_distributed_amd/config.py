@@ -107,6 +107,7 @@ class ModelConfig:
     load_format: str = "auto"          # auto|safetensors|dummy
     # None | awq (4-bit weights stay packed, W4A16 kernels) | awq-dequant (dense at load)
     # | fp8 (W8A8: weights quantised per channel at load, activations per token at run time)
+    # | nvfp4 (E2M1 weights with e4m3 scales per 16 columns stay packed; activations stay 16-bit)
     quantization: Optional[str] = None
     trust_remote_code: bool = False
     revision: Optional[str] = None
@@ -141,6 +142,8 @@ class ModelConfig:
             q = self.hf_config.get("quantization_config") or {}
             if q.get("quant_method") == "awq":
                 self.quantization = "awq"
+            elif "nvfp4" in str(q.get("format", "")).lower() or str(q.get("quant_algo", "")).upper() == "NVFP4":
+                self.quantization = "nvfp4"      # compressed-tensors / modelopt exports
         if self.load_format == "auto" and resolve_model_path(self.model) is None:
             logger.warning("no weights found for %s: using deterministic random init "
                            "(load_format=dummy)", self.model)

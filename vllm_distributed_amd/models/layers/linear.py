@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import contextlib
 from dataclasses import dataclass
-from typing import Iterator, List, Optional, Sequence
+from typing import Iterator, List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn as nn
@@ -33,7 +33,11 @@ class QuantSpec:
     asymmetric, ``group_size`` input columns per (scale, zero) pair, checkpoint
     tensors ``qweight [in, out/8]``, ``qzeros [in/g, out/8]``, ``scales [in/g, out]``.
     ``fp8``: W8A8 on the fp8 matrix cores - weights quantised per output channel
-    to OCP e4m3 once loaded, activations per token at run time."""
+    to OCP e4m3 once loaded, activations per token at run time.
+    ``nvfp4``: weight-only E2M1 with one e4m3 scale per 16 input columns and one
+    fp32 scale per checkpoint matrix: ``weight_packed [out, in/2] uint8``,
+    ``weight_scale [out, in/16] float8_e4m3fn``, ``weight_global_scale [1]``
+    (the reference image installs its fp4 kernels "for nvfp4", ``Dockerfile:5-6``)."""
     method: str = "awq"
     group_size: int = 128
     pack: int = 8
@@ -69,6 +73,51 @@ def _meta(p: nn.Parameter):
     return getattr(p, "out_dim", 0), getattr(p, "pack", 1), getattr(p, "in_div", 1)
 
 
+def _scalar_param(n: int) -> nn.Parameter:
+    """One fp32 value per output row, loaded from per-matrix scalars: each
+    fused sub-matrix (q, k, v / gate, up) fills its own rows."""
+    p = nn.Parameter(torch.ones(n, dtype=torch.float32), requires_grad=False)
+    p.per_shard_scalar = True                                  # type: ignore[attr-defined]
+    return _tag(p, 0)
+
+
+def _fill_scalar(dst: torch.Tensor, w: torch.Tensor) -> None:
+    dst.copy_(w.reshape(-1)[:1].to(torch.float32).expand(dst.shape))
+
+
+def nvfp4_rename(name: str, w: torch.Tensor) -> Optional[Tuple[str, torch.Tensor]]:
+    """Checkpoint tensor of an NVFP4 linear -> (parameter name, tensor), or None
+    for tensors this weight-only path does not use (activation scales).
+    compressed-tensors stores ``weight_global_scale`` as a divisor, modelopt
+    stores the multiplier ``weight_scale_2`` and keeps the bytes in ``weight``."""
+    base, _, kind = name.rpartition(".")
+    if kind in ("input_global_scale", "input_scale", "k_scale", "v_scale"):
+        return None
+    if kind == "weight_scale":
+        return base + ".weight_block_scale", w
+    if kind == "weight_global_scale":
+        return base + ".weight_alpha", w.to(torch.float32).reciprocal()
+    if kind == "weight_scale_2":
+        return base + ".weight_alpha", w.to(torch.float32)
+    if kind == "weight" and w.dtype == torch.uint8:
+        return base + ".weight_packed", w
+    return name, w
+
+
+def nvfp4_dequantize(packed: torch.Tensor, block_scale: torch.Tensor, alpha: torch.Tensor,
+                     dtype: torch.dtype) -> torch.Tensor:
+    """NVFP4 shard tensors -> dense ``[out, in]`` (shapes the 4-bit kernel does not tile)."""
+    from ...ops import quant
+    codes = torch.stack([packed & 0xF, packed >> 4], dim=-1).reshape(packed.shape[0], -1)
+    w = quant.fp4_lut(packed.device)[codes.long()]
+    w = w * block_scale.to(torch.float32).repeat_interleave(16, dim=1) * alpha.reshape(-1, 1)
+    return w.to(dtype)
+
+
+def fp4_layout_ok(in_local: int, out_local: int) -> bool:
+    return in_local % 128 == 0 and out_local % 16 == 0
+
+
 def w4_layout_ok(in_local: int, out_local: int, group: int) -> bool:
     return in_local % 128 == 0 and out_local % 16 == 0 and group % 128 == 0 and in_local % group == 0
 
@@ -93,7 +142,13 @@ class _LinearBase(nn.Module):
         self.register_buffer("qw", None)
         self.register_buffer("sz", None)
         self.register_buffer("weight_scale", None)
-        if spec is None or spec.method == "fp8":
+        self.register_buffer("alpha", None)
+        if spec is not None and spec.method == "nvfp4":
+            assert in_local % 16 == 0, f"NVFP4 shard [{out_local} x {in_local}] splits a 16-column block"
+            self.weight_packed = _tag(_param(out_local, in_local // 2, dtype=torch.uint8), 0, 1, 2)
+            self.weight_block_scale = _tag(_param(out_local, in_local // 16, dtype=torch.float8_e4m3fn), 0, 1, 16)
+            self.weight_alpha = _scalar_param(out_local)
+        elif spec is None or spec.method == "fp8":
             # fp8: loaded in the checkpoint dtype, quantised per output channel in finalize_weights
             self.weight = _tag(_param(out_local, in_local, dtype=dtype), 0)
         else:
@@ -106,7 +161,7 @@ class _LinearBase(nn.Module):
         self.bias = _tag(_param(out_local, dtype=dtype), 0) if bias else None
 
     def _set_loaders(self, loader, bias_loader=None) -> None:
-        for name in ("weight", "qweight", "qzeros", "scales"):
+        for name in ("weight", "qweight", "qzeros", "scales", "weight_packed", "weight_block_scale", "weight_alpha"):
             p = getattr(self, name, None)
             if isinstance(p, nn.Parameter):
                 p.weight_loader = loader                         # type: ignore[attr-defined]
@@ -124,6 +179,18 @@ class _LinearBase(nn.Module):
             self.weight = nn.Parameter(wq, requires_grad=False)
             self.weight_scale = scale
             return
+        if self.quant.method == "nvfp4":
+            packed, bs, alpha = self.weight_packed.data, self.weight_block_scale.data, self.weight_alpha.data
+            del self.weight_packed, self.weight_block_scale, self.weight_alpha
+            if fp4_layout_ok(self.in_local, self.out_local):
+                from ...ops import quant
+                self.qw, self.sz = quant.pack_fp4(packed, bs)
+                self.alpha = alpha.contiguous()
+                ops.w4_reserve_scratch(self.in_local * self.out_local, self.qw.device, self.dtype)
+            else:
+                self.quant = None
+                self.weight = nn.Parameter(nvfp4_dequantize(packed, bs, alpha, self.dtype), requires_grad=False)
+            return
         qweight, qzeros, scales = self.qweight.data, self.qzeros.data, self.scales.data
         del self.qweight, self.qzeros, self.scales
         if w4_layout_ok(self.in_local, self.out_local, self.quant.group_size):
@@ -137,6 +204,8 @@ class _LinearBase(nn.Module):
 
     def _matmul(self, x: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
         if self.qw is not None:
+            if self.alpha is not None:
+                return ops.fp4_linear(x, self.qw, self.sz, self.alpha, bias)
             return ops.w4a16_linear(x, self.qw, self.sz, bias)
         if self.weight_scale is not None:
             return ops.fp8_linear(x, self.weight, self.weight_scale, bias)
@@ -157,6 +226,8 @@ class ReplicatedLinear(_LinearBase):
 
     @staticmethod
     def _load(param: nn.Parameter, w: torch.Tensor, shard_id=None) -> None:
+        if getattr(param, "per_shard_scalar", False):
+            return _fill_scalar(param.data, w)
         assert param.shape == w.shape, (param.shape, w.shape)
         param.data.copy_(w)
 
@@ -183,6 +254,10 @@ class ColumnParallelLinear(_LinearBase):
     def weight_loader(self, param: nn.Parameter, w: torch.Tensor, shard_id: Optional[int] = None) -> None:
         """``shard_id`` = index into ``output_sizes``; None = the full fused matrix."""
         od, pack, _ = _meta(param)
+        if getattr(param, "per_shard_scalar", False):
+            if shard_id is None:
+                return _fill_scalar(param.data, w)
+            return _fill_scalar(param.data.narrow(0, sum(self.shard_sizes[:shard_id]), self.shard_sizes[shard_id]), w)
         if shard_id is None:
             assert w.shape[od] * pack == sum(self.output_sizes), (w.shape, self.output_sizes)
             off = 0
@@ -227,6 +302,12 @@ class QKVParallelLinear(_LinearBase):
 
     def weight_loader(self, param: nn.Parameter, w: torch.Tensor, shard_id: Optional[str] = None) -> None:
         od, pack, _ = _meta(param)
+        if getattr(param, "per_shard_scalar", False):
+            if shard_id is None:
+                return _fill_scalar(param.data, w)
+            size = self.q_size if shard_id == "q" else self.kv_size
+            dst = 0 if shard_id == "q" else self.q_size + (0 if shard_id == "k" else self.kv_size)
+            return _fill_scalar(param.data.narrow(0, dst, size), w)
         if shard_id is None:      # full fused [q | k | v]
             qs, ks = self.total_heads * self.head_dim // pack, self.total_kv_heads * self.head_dim // pack
             self.weight_loader(param, w.narrow(od, 0, qs), "q")
@@ -257,6 +338,8 @@ class RowParallelLinear(_LinearBase):
         self._set_loaders(self.weight_loader, ReplicatedLinear._load)
 
     def weight_loader(self, param: nn.Parameter, w: torch.Tensor, shard_id=None) -> None:
+        if getattr(param, "per_shard_scalar", False):
+            return _fill_scalar(param.data, w)
         od, _, in_div = _meta(param)
         n = self.in_local // in_div
         param.data.copy_(w.narrow(1 - od, self.tp_rank * n, n))

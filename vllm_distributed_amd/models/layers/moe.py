@@ -22,7 +22,8 @@ from ... import ops
 from ...parallel.state import (get_tensor_model_parallel_rank,
                                get_tensor_model_parallel_world_size,
                                tensor_model_parallel_all_reduce)
-from .linear import ReplicatedLinear, active_quant, awq_to_native, divide, w4_layout_ok
+from .linear import (ReplicatedLinear, _fill_scalar, active_quant, awq_to_native, divide, fp4_layout_ok,
+                     nvfp4_dequantize, w4_layout_ok)
 
 
 class FusedMoE(nn.Module):
@@ -44,13 +45,15 @@ class FusedMoE(nn.Module):
         self.hidden, self.dtype = hidden, dtype
         self.gate = ReplicatedLinear(hidden, num_experts, False, dtype, quant=False)   # router stays dense
         self.quant = active_quant()
-        if self.quant is not None and self.quant.method != "awq":
+        if self.quant is not None and self.quant.method not in ("awq", "nvfp4"):
             self.quant = None           # fp8 covers the dense linears; experts stay in the model dtype
         E, I = self.local_experts, self.inter_local
         self.register_buffer("qw13", None)
         self.register_buffer("sz13", None)
         self.register_buffer("qw2", None)
         self.register_buffer("sz2", None)
+        self.register_buffer("alpha13", None)
+        self.register_buffer("alpha2", None)
 
         def param(*shape, dt=dtype, out_dim=0, pack=1, in_div=1, loader=None):
             p = nn.Parameter(torch.empty(*shape, dtype=dt), requires_grad=False)
@@ -59,6 +62,16 @@ class FusedMoE(nn.Module):
         if self.quant is None:
             self.w13 = param(E, 2 * I, hidden, loader=self._load_w13)
             self.w2 = param(E, hidden, I, loader=self._load_w2)
+        elif self.quant.method == "nvfp4":
+            assert hidden % 16 == 0 and I % 16 == 0, f"NVFP4 expert shard [{I} x {hidden}] splits a 16-column block"
+            u8, f8, f32 = torch.uint8, torch.float8_e4m3fn, torch.float32
+            self.w13_weight_packed = param(E, 2 * I, hidden // 2, dt=u8, in_div=2, loader=self._load_w13)
+            self.w13_weight_block_scale = param(E, 2 * I, hidden // 16, dt=f8, in_div=16, loader=self._load_w13)
+            self.w13_weight_alpha = param(E, 2 * I, dt=f32, loader=self._load_w13)
+            self.w2_weight_packed = param(E, hidden, I // 2, dt=u8, in_div=2, loader=self._load_w2)
+            self.w2_weight_block_scale = param(E, hidden, I // 16, dt=f8, in_div=16, loader=self._load_w2)
+            self.w2_weight_alpha = param(E, hidden, dt=f32, loader=self._load_w2)
+            self.w13_weight_alpha.per_shard_scalar = self.w2_weight_alpha.per_shard_scalar = True
         else:
             g, pk = self.quant.group_size, self.quant.pack
             assert hidden % g == 0 and I % g == 0, \
@@ -84,6 +97,8 @@ class FusedMoE(nn.Module):
             return
         od, pack = param.out_dim, param.pack
         n = self.inter_local // pack
+        if getattr(param, "per_shard_scalar", False):
+            return _fill_scalar(param.data[e].narrow(0, which * n, n), w)
         if not self.expert_parallel:
             w = w.narrow(od, self.tp_rank * n, n)
         param.data[e].narrow(od, which * n, n).copy_(w)
@@ -93,6 +108,8 @@ class FusedMoE(nn.Module):
         e = self._local_index(expert_id)
         if e is None:
             return
+        if getattr(param, "per_shard_scalar", False):
+            return _fill_scalar(param.data[e], w)
         if not self.expert_parallel:
             n = self.inter_local // param.in_div
             w = w.narrow(1 - param.out_dim, self.tp_rank * n, n)
@@ -104,6 +121,8 @@ class FusedMoE(nn.Module):
         if self.quant is None or self.qw13 is not None:
             return
         E, I, H, g = self.local_experts, self.inter_local, self.hidden, self.quant.group_size
+        if self.quant.method == "nvfp4":
+            return self._finalize_nvfp4()
         native = w4_layout_ok(H, 2 * I, g) and w4_layout_ok(I, H, g)
         parts = {"13": [], "2": []}
         for key in ("13", "2"):
@@ -130,7 +149,35 @@ class FusedMoE(nn.Module):
             self.w13 = nn.Parameter(torch.stack(parts["13"]), requires_grad=False)
             self.w2 = nn.Parameter(torch.stack(parts["2"]), requires_grad=False)
 
+    def _finalize_nvfp4(self) -> None:
+        from ...ops import quant
+        E, I, H = self.local_experts, self.inter_local, self.hidden
+        native = fp4_layout_ok(H, 2 * I) and fp4_layout_ok(I, H)
+        out = {}
+        for key in ("13", "2"):
+            packed = getattr(self, f"w{key}_weight_packed").data
+            bs = getattr(self, f"w{key}_weight_block_scale").data
+            alpha = getattr(self, f"w{key}_weight_alpha").data
+            for name in ("weight_packed", "weight_block_scale", "weight_alpha"):
+                delattr(self, f"w{key}_{name}")
+            if native:
+                parts = [quant.pack_fp4(packed[e], bs[e]) for e in range(E)]
+                out[key] = (torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]), alpha.contiguous())
+            else:
+                out[key] = torch.stack([nvfp4_dequantize(packed[e], bs[e], alpha[e], self.dtype) for e in range(E)])
+        if native:
+            self.qw13, self.sz13, self.alpha13 = out["13"]
+            self.qw2, self.sz2, self.alpha2 = out["2"]
+            ops.w4_reserve_scratch(2 * I * H, self.qw13.device, self.dtype)
+        else:
+            self.quant = None
+            self.w13 = nn.Parameter(out["13"], requires_grad=False)
+            self.w2 = nn.Parameter(out["2"], requires_grad=False)
+
     def _expert_mlp(self, e: int, x: torch.Tensor) -> torch.Tensor:
+        if self.alpha13 is not None:
+            h = ops.fp4_linear(x, self.qw13[e], self.sz13[e], self.alpha13[e])
+            return ops.fp4_linear(ops.silu_and_mul(h), self.qw2[e], self.sz2[e], self.alpha2[e])
         if self.qw13 is not None:
             h = ops.w4a16_linear(x, self.qw13[e], self.sz13[e])
             return ops.w4a16_linear(ops.silu_and_mul(h), self.qw2[e], self.sz2[e])
@@ -163,9 +210,9 @@ class FusedMoE(nn.Module):
                                      self.local_experts if self.expert_parallel else -1)
         xs = x.index_select(0, order // k)
         if self.qw13 is not None:
-            h = ops.grouped_linear(xs, tiles, tile_rows, qw=self.qw13, sz=self.sz13)
+            h = ops.grouped_linear(xs, tiles, tile_rows, qw=self.qw13, sz=self.sz13, alpha=self.alpha13)
             a = ops.silu_and_mul(h)
-            y = ops.grouped_linear(a, tiles, tile_rows, qw=self.qw2, sz=self.sz2)
+            y = ops.grouped_linear(a, tiles, tile_rows, qw=self.qw2, sz=self.sz2, alpha=self.alpha2)
         else:
             h = ops.grouped_linear(xs, tiles, tile_rows, weight=self.w13)
             a = ops.silu_and_mul(h)

@@ -18,7 +18,7 @@ from ..config import VllmConfig
 from ..parallel.state import get_pp_group, get_tp_group
 from .layers.attention import Attention, RMSNorm, get_forward_context
 from .layers.linear import (ColumnParallelLinear, ParallelLMHead, QKVParallelLinear, QuantSpec,
-                            RowParallelLinear, VocabParallelEmbedding, quantized_linears)
+                            RowParallelLinear, VocabParallelEmbedding, nvfp4_rename, quantized_linears)
 from .utils import IntermediateTensors, get_pp_layer_range
 
 
@@ -142,7 +142,9 @@ class LlamaForCausalLM(nn.Module):
         tie = bool(cfg.get("tie_word_embeddings", False))
         if self.is_first or (tie and self.is_last):
             self.embed_tokens = VocabParallelEmbedding(cfg["vocab_size"], cfg["hidden_size"], dtype)
-        spec = {"awq": QuantSpec("awq", mc.quant_group_size), "fp8": QuantSpec("fp8")}.get(mc.quantization)
+        spec = {"awq": QuantSpec("awq", mc.quant_group_size), "fp8": QuantSpec("fp8"),
+                "nvfp4": QuantSpec("nvfp4", 16, 1)}.get(mc.quantization)
+        self.quant_method = spec.method if spec is not None else None
         with quantized_linears(spec):
             self.layers = nn.ModuleDict({
                 str(i): self.layer_cls(cfg, i, dtype, self.cos_sin_cache)
@@ -350,6 +352,11 @@ class LlamaForCausalLM(nn.Module):
             name = self.map_weight_name(name)
             if name is None or not self._owns_layer(name):
                 continue
+            if self.quant_method == "nvfp4":
+                renamed = nvfp4_rename(name, w)
+                if renamed is None:
+                    continue
+                name, w = renamed
             target, shard = name, None
             for frag, fused, sid in self.stacked_params:
                 if frag in name:

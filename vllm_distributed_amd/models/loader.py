@@ -11,8 +11,11 @@ directly on the target device and fills it from one of:
   by the same ``weight_loader`` path, so TP/PP shards of a dummy model are
   exactly the shards of one fixed full model;
 * AWQ 4-bit checkpoints (the reference's documented model is AWQ,
-  ``.env.server:11``): ``qweight/qzeros/scales`` triples are dequantised to the
-  compute dtype at load time.
+  ``.env.server:11``): ``qweight/qzeros/scales`` triples stay packed for the
+  W4A16 kernels (``quantization=awq``) or are dequantised to the compute dtype
+  at load time (``awq-dequant``);
+* NVFP4 checkpoints (``Dockerfile:5-6``): ``weight_packed / weight_scale /
+  weight_global_scale`` stay packed for the fp4 weight-only kernels.
 """
 from __future__ import annotations
 
@@ -137,6 +140,7 @@ def dummy_weights_iterator(mc: ModelConfig, device: torch.device,
     dtype = mc.torch_dtype
     gen = torch.Generator(device=device)
     awq = mc.quantization in ("awq", "awq-dequant")
+    nvfp4 = mc.quantization == "nvfp4"
     g = mc.quant_group_size
     for name, shape in hf_weight_shapes(mc).items():
         if want is not None and not want(name):
@@ -154,6 +158,18 @@ def dummy_weights_iterator(mc: ModelConfig, device: torch.device,
             sc = (1.0 / in_f) ** 0.5 / 6.5
             yield base + ".scales", (sc * (0.5 + torch.rand((in_f // g, out_f), generator=gen, device=device,
                                                             dtype=torch.float32))).to(dtype)
+            continue
+        if nvfp4 and _QUANTIZED_LINEAR.search(name) and shape[1] % 16 == 0:
+            out_f, in_f = shape
+            base = name[:-len(".weight")]
+            yield base + ".weight_packed", torch.randint(0, 256, (out_f, in_f // 2), generator=gen, device=device,
+                                                         dtype=torch.int32).to(torch.uint8)
+            bs = 32.0 + 64.0 * torch.rand((out_f, in_f // 16), generator=gen, device=device, dtype=torch.float32)
+            yield base + ".weight_scale", bs.to(torch.float8_e4m3fn)
+            # uniform E2M1 codes have std ~2.9 and the block scales average 64:
+            # the divisor keeps activations near unit variance
+            yield base + ".weight_global_scale", torch.full((1,), 64.0 * 2.93 * 1.05 * in_f ** 0.5,
+                                                            dtype=torch.float32, device=device)
             continue
         if re.search(r"(layernorm|layer_norm|norm)\.weight$", name):
             w = 1.0 + 0.05 * (torch.rand(shape, generator=gen, device=device, dtype=torch.float32) - 0.5)
@@ -272,7 +288,7 @@ def load_model(vllm_config: VllmConfig, device: torch.device) -> torch.nn.Module
         if mc.quantization == "awq-dequant":
             it = _dequantize_stream(it, mc.torch_dtype)
     else:
-        it = safetensors_weights_iterator(path, mc.torch_dtype, want, keep_quantized=mc.quantization == "awq")
+        it = safetensors_weights_iterator(path, mc.torch_dtype, want, keep_quantized=mc.quantization in ("awq", "nvfp4"))
     with torch.no_grad():
         loaded = model.load_weights(it)
         for m in model.modules():          # repack quantised shards into the kernel layout

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from ..config import VllmConfig
+from .layers.linear import nvfp4_rename
 from .layers.moe import FusedMoE
 from .llama import LlamaDecoderLayer, LlamaForCausalLM
 
@@ -24,7 +25,7 @@ class MixtralDecoderLayer(LlamaDecoderLayer):
 
 class MixtralForCausalLM(LlamaForCausalLM):
     layer_cls = MixtralDecoderLayer
-    _expert_re = re.compile(r"(.*\.mlp)\.experts\.(\d+)\.(w1|w2|w3)\.(weight|qweight|qzeros|scales)$")
+    _expert_re = re.compile(r"(.*\.mlp)\.experts\.(\d+)\.(w1|w2|w3)\.(weight|qweight|qzeros|scales|weight_packed|weight_scale|weight_global_scale|weight_scale_2|input_global_scale|input_scale)$")
 
     def __init__(self, vllm_config: VllmConfig):
         global _EP
@@ -47,6 +48,11 @@ class MixtralForCausalLM(LlamaForCausalLM):
             if not self._owns_layer(mapped):
                 continue
             prefix, eid, proj, kind = m.group(1), int(m.group(2)), m.group(3), m.group(4)
+            if self.quant_method == "nvfp4":
+                renamed = nvfp4_rename("." + kind, w)
+                if renamed is None:
+                    continue
+                kind, w = renamed[0][1:], renamed[1]
             suffix = "" if kind == "weight" else "_" + kind
             if proj == "w2":
                 p = params[prefix + ".w2" + suffix]

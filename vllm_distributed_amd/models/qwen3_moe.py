@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from ..config import VllmConfig
+from .layers.linear import nvfp4_rename
 from .layers.moe import FusedMoE
 from .llama import LlamaDecoderLayer, LlamaForCausalLM, LlamaMLP
 
@@ -34,7 +35,7 @@ class Qwen3MoeDecoderLayer(LlamaDecoderLayer):
 
 class Qwen3MoeForCausalLM(LlamaForCausalLM):
     layer_cls = Qwen3MoeDecoderLayer
-    _expert_re = re.compile(r"(.*\.mlp)\.experts\.(\d+)\.(gate_proj|up_proj|down_proj)\.(weight|qweight|qzeros|scales)$")
+    _expert_re = re.compile(r"(.*\.mlp)\.experts\.(\d+)\.(gate_proj|up_proj|down_proj)\.(weight|qweight|qzeros|scales|weight_packed|weight_scale|weight_global_scale|weight_scale_2|input_global_scale|input_scale)$")
 
     def __init__(self, vllm_config: VllmConfig):
         global _EP
@@ -53,6 +54,11 @@ class Qwen3MoeForCausalLM(LlamaForCausalLM):
             if not self._owns_layer(mapped):
                 continue
             prefix, eid, proj, kind = m.group(1), int(m.group(2)), m.group(3), m.group(4)
+            if self.quant_method == "nvfp4":
+                renamed = nvfp4_rename("." + kind, w)
+                if renamed is None:
+                    continue
+                kind, w = renamed[0][1:], renamed[1]
             suffix = "" if kind == "weight" else "_" + kind
             if proj == "down_proj":
                 p = params[prefix + ".w2" + suffix]

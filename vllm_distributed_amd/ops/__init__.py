@@ -233,6 +233,33 @@ def w4a16_linear(x, qw, sz, bias=None):
     return y.view(shape[:-1] + (y.shape[-1],))
 
 
+def fp4_linear(x, qw, fs, alpha=None, bias=None):
+    """``y = x . dequant(qw, fs, alpha)^T (+ bias)`` for NVFP4 weights packed by
+    ``ops.quant.pack_fp4`` (weight-only: activations stay bf16/fp16).  Same
+    split as ``w4a16_linear``: fused 4-bit kernel for small batches, dequantise
+    + library GEMM for large ones."""
+    from . import quant
+    shape = x.shape
+    x2 = x.reshape(-1, shape[-1])
+    if _use_hip(x2) and x2.dtype in (torch.bfloat16, torch.float16):
+        if x2.shape[0] <= _hip.W4_MAX_FUSED_M:
+            if x2.stride(1) != 1 or x2.stride(0) % 8 or x2.data_ptr() % 16:
+                x2 = x2.contiguous()
+            y = _hip.fp4a16_gemm(x2, qw, fs, alpha)
+        else:
+            n, k = qw.shape[0] * 16, qw.shape[1] * 128
+            key = _scratch_key(x2.device, x2.dtype)
+            buf = _w4_scratch.get(key)
+            if buf is None or buf.numel() < n * k:
+                buf = _w4_scratch[key] = torch.empty(n * k, dtype=x2.dtype, device=x2.device)
+            y = torch.nn.functional.linear(x2, _hip.fp4_dequant(qw, fs, alpha, x2.dtype, buf))
+    else:
+        y = torch.nn.functional.linear(x2, quant.fp4_dequant(qw, fs, alpha, x2.dtype))
+    if bias is not None:
+        y = y + bias
+    return y.view(shape[:-1] + (y.shape[-1],))
+
+
 def moe_align(topi, num_experts: int, tile_rows: int, expert_start: int = 0, local_experts: int = -1):
     """Sort the ``T*k`` (token, expert) slots by expert and cut each expert's
     run into row tiles, entirely on the device (no host sync, so a decode
@@ -265,11 +292,14 @@ def moe_align(topi, num_experts: int, tile_rows: int, expert_start: int = 0, loc
     return order, tiles
 
 
-def grouped_linear(x, tiles, tile_rows: int, weight=None, qw=None, sz=None):
-    """Row-grouped ``x @ W[g]^T`` (dense ``weight [G, N, K]`` or packed 4-bit
-    ``qw/sz``) for rows sorted by group - see ``moe_align``.  HIP only."""
+def grouped_linear(x, tiles, tile_rows: int, weight=None, qw=None, sz=None, alpha=None):
+    """Row-grouped ``x @ W[g]^T`` (dense ``weight [G, N, K]``, packed 4-bit
+    integer ``qw/sz``, or NVFP4 ``qw`` + int32 ``sz`` + ``alpha [G, N]``) for rows
+    sorted by group - see ``moe_align``.  HIP only."""
     assert _use_hip(x)
     if qw is not None:
+        if sz.dtype == torch.int32:
+            return _hip.grouped_fp4a16_gemm(x, qw, sz, alpha, tiles, tile_rows)
         return _hip.grouped_w4a16_gemm(x, qw, sz, tiles, tile_rows)
     return _hip.grouped_gemm(x, weight, tiles, tile_rows)
 

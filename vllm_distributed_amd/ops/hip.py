@@ -46,6 +46,9 @@ def load() -> ctypes.CDLL:
         "vdamd_dynamic_fp8_quant": [P, P, P, I, I, L, I, P],
         "vdamd_skinny_gemm_grouped": [P, L, P, L, P, L, L, P, I, I, I, I, I, I, P],
         "vdamd_w4a16_gemm_grouped": [P, L, P, L, P, P, L, L, P, I, I, I, I, I, I, P],
+        "vdamd_fp4a16_gemm": [P, L, P, L, P, P, P, P, I, I, I, I, I, I, P],
+        "vdamd_fp4_dequant": [P, P, P, P, I, I, I, P],
+        "vdamd_fp4a16_gemm_grouped": [P, L, P, L, P, P, L, L, P, P, I, I, I, I, I, P],
     }
     for name, argtypes in sigs.items():
         fn = getattr(lib, name)
@@ -376,6 +379,51 @@ def w4a16_gemm(x: torch.Tensor, qw: torch.Tensor, sz: torch.Tensor, variant: Opt
     return out
 
 
+# ------------------------------------------------------------ NVFP4 linears
+def _fp4_dims(qw: torch.Tensor, fs: torch.Tensor, alpha: Optional[torch.Tensor]) -> Tuple[int, int]:
+    assert qw.dim() == 4 and qw.shape[2:] == (64, 4) and qw.dtype == torch.int32 and qw.is_contiguous()
+    assert fs.shape == qw.shape[:2] + (64,) and fs.dtype == torch.int32 and fs.is_contiguous()
+    n, k = qw.shape[0] * 16, qw.shape[1] * 128
+    if alpha is not None:
+        assert alpha.dtype == torch.float32 and alpha.numel() == n and alpha.is_contiguous()
+    return n, k
+
+
+def fp4_dequant(qw: torch.Tensor, fs: torch.Tensor, alpha: Optional[torch.Tensor], dtype: torch.dtype,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    n, k = _fp4_dims(qw, fs, alpha)
+    if out is None:
+        out = torch.empty((n, k), dtype=dtype, device=qw.device)
+    assert out.is_contiguous() and out.numel() >= n * k and out.dtype == dtype
+    _check(_LIB.vdamd_fp4_dequant(out.data_ptr(), qw.data_ptr(), fs.data_ptr(),
+                                  None if alpha is None else alpha.data_ptr(), n, k, _DT[dtype], _stream()),
+           "fp4_dequant")
+    return out[:n * k].view(n, k) if out.dim() == 1 else out
+
+
+def fp4a16_gemm(x: torch.Tensor, qw: torch.Tensor, fs: torch.Tensor, alpha: Optional[torch.Tensor] = None,
+                variant: Optional[int] = None, ksplit: Optional[int] = None) -> torch.Tensor:
+    """``x [M, K]`` (bf16/fp16) times NVFP4 weights (``ops.quant.pack_fp4``), ``alpha [N]`` fp32 per-row scale."""
+    n, k = _fp4_dims(qw, fs, alpha)
+    assert x.dim() == 2 and x.shape[1] == k and _half(x) and x.stride(1) == 1
+    assert x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
+    m = x.shape[0]
+    out = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    if m == 0:
+        return out
+    if variant is None:
+        variant = w4_choose_variant(m, n, k)
+    if ksplit is None:
+        ksplit = w4_choose_ksplit(m, n, k, variant)
+    assert 1 <= ksplit <= k // 128
+    partial = torch.empty(ksplit * m * n, dtype=torch.float32, device=x.device) if ksplit > 1 else None
+    _check(_LIB.vdamd_fp4a16_gemm(out.data_ptr(), n, x.data_ptr(), x.stride(0), qw.data_ptr(), fs.data_ptr(),
+                                  None if alpha is None else alpha.data_ptr(),
+                                  None if partial is None else partial.data_ptr(), m, n, k, ksplit, variant,
+                                  _dt(x), _stream()), "fp4a16_gemm")
+    return out
+
+
 # ---------------------------------------------------------- skinny bf16 GEMM
 SKINNY_MAX_M = 128
 
@@ -470,6 +518,25 @@ def grouped_w4a16_gemm(x: torch.Tensor, qw: torch.Tensor, sz: torch.Tensor, tile
     _check(_LIB.vdamd_w4a16_gemm_grouped(out.data_ptr(), out.stride(0), x.data_ptr(), x.stride(0), qw.data_ptr(),
                                          sz.data_ptr(), qw[0].numel(), sz[0].numel(), tiles.data_ptr(), nt,
                                          tile_rows, n, k, grp, _dt(x), _stream()), "w4a16_gemm_grouped")
+    return out
+
+
+def grouped_fp4a16_gemm(x: torch.Tensor, qw: torch.Tensor, fs: torch.Tensor, alpha: Optional[torch.Tensor],
+                        tiles: torch.Tensor, tile_rows: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Grouped form of ``fp4a16_gemm``: ``qw [G, N/16, K/128, 64, 4]``, ``fs [G, N/16, K/128, 64]``,
+    ``alpha [G, N]`` or None."""
+    nt = _check_tiles(tiles, x, tile_rows)
+    assert qw.dim() == 5 and fs.dim() == 4 and qw.shape[0] == fs.shape[0] and tile_rows <= 64
+    n, k = _fp4_dims(qw[0], fs[0], None)
+    assert qw.is_contiguous() and fs.is_contiguous() and x.shape[1] == k and _half(x)
+    if alpha is not None:
+        assert alpha.shape == (qw.shape[0], n) and alpha.dtype == torch.float32 and alpha.is_contiguous()
+    if out is None:
+        out = torch.empty((x.shape[0], n), dtype=x.dtype, device=x.device)
+    _check(_LIB.vdamd_fp4a16_gemm_grouped(out.data_ptr(), out.stride(0), x.data_ptr(), x.stride(0), qw.data_ptr(),
+                                          fs.data_ptr(), qw[0].numel(), fs[0].numel() * 2,
+                                          None if alpha is None else alpha.data_ptr(), tiles.data_ptr(), nt,
+                                          tile_rows, n, k, _dt(x), _stream()), "fp4a16_gemm_grouped")
     return out
 
 

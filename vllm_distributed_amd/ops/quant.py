@@ -110,3 +110,78 @@ def quantize_w4(w: torch.Tensor, group: int = 128) -> Tuple[torch.Tensor, torch.
     z = (-lo / s).round().clamp(0, 15)
     q = (wg / s.unsqueeze(-1) + z.unsqueeze(-1)).round().clamp(0, 15)
     return q.reshape(n, k).to(torch.uint8), z, s
+
+
+# ------------------------------------------------------------------ NVFP4
+# E2M1 code -> value; code bit 3 is the sign (``Dockerfile:5-6`` of the
+# reference installs the fp4 kernels its documented deployments rely on).
+FP4_VALUES = [0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0]
+
+
+def fp4_lut(device=None) -> torch.Tensor:
+    v = torch.tensor(FP4_VALUES, dtype=torch.float32, device=device)
+    return torch.cat([v, -v])
+
+
+def pack_fp4(packed: torch.Tensor, block_scale: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """NVFP4 checkpoint tensors -> kernel layout.  ``packed [N, K/2] uint8``
+    holds element ``2i`` in the low nibble of byte ``i``; ``block_scale
+    [N, K/16]`` is ``float8_e4m3fn`` (one scale per 16 input columns).  Returns
+    ``qw [N/16, K/128, 64, 4] int32`` (same tiles as ``pack_w4``, element ``e`` in
+    nibble ``e``) and ``fs [N/16, K/128, 64] int32`` - lane ``c + 16 g`` holds the
+    scales of row ``c``, blocks ``8 kb + 2 g`` (low half) and ``8 kb + 2 g + 1``
+    (high half), as bf16 bit patterns (every e4m3 value is exact in bf16)."""
+    n, kh = packed.shape
+    k = kh * 2
+    assert packed.dtype == torch.uint8 and n % 16 == 0 and k % 128 == 0, (packed.dtype, n, k)
+    assert block_scale.shape == (n, k // 16), (block_scale.shape, n, k)
+    words = packed.contiguous().view(torch.int32).reshape(n // 16, 16, k // 128, 4, 4)      # nt c kb g w
+    qw = words.permute(0, 2, 3, 1, 4).reshape(n // 16, k // 128, 64, 4).contiguous()
+    sb = block_scale.to(torch.float32).to(torch.bfloat16).reshape(n // 16, 16, k // 128, 4, 2)   # nt c kb g j
+    fs = sb.permute(0, 2, 3, 1, 4).reshape(n // 16, k // 128, 64, 2).contiguous().view(torch.int32)
+    return qw, fs.reshape(n // 16, k // 128, 64)
+
+
+def unpack_fp4(qw: torch.Tensor, fs: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Inverse of ``pack_fp4``: ``(codes [N, K] uint8 in 0..15, block_scale [N, K/16] f32)``."""
+    nt, kb = qw.shape[0], qw.shape[1]
+    w = qw.reshape(nt, kb, 4, 16, 4).permute(0, 3, 1, 2, 4).contiguous()               # nt c kb g w
+    by = w.view(torch.uint8).reshape(nt * 16, kb * 64)                                # [N, K/2]
+    codes = torch.stack([by & 0xF, by >> 4], dim=-1).reshape(nt * 16, kb * 128)
+    sb = fs.contiguous().view(torch.bfloat16).reshape(nt, kb, 4, 16, 2).permute(0, 3, 1, 2, 4)
+    return codes, sb.reshape(nt * 16, kb * 8).to(torch.float32)
+
+
+def fp4_dequant(qw: torch.Tensor, fs: torch.Tensor, alpha: torch.Tensor = None,
+                dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """Dense ``[N, K]`` weights ``e2m1 * block_scale * alpha[row]`` (reference path)."""
+    codes, sc = unpack_fp4(qw, fs)
+    w = fp4_lut(qw.device)[codes.long()] * sc.repeat_interleave(16, dim=1)
+    if alpha is not None:
+        w = w * alpha.to(torch.float32).reshape(-1, 1)
+    return w.to(dtype)
+
+
+def fp4a16_gemm(x: torch.Tensor, qw: torch.Tensor, fs: torch.Tensor, alpha: torch.Tensor = None) -> torch.Tensor:
+    return (x.to(torch.float32) @ fp4_dequant(qw, fs, alpha).t()).to(x.dtype)
+
+
+def quantize_fp4(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Round-to-nearest NVFP4 quantisation of dense ``w [N, K]``:
+    ``(packed [N, K/2] uint8, block_scale [N, K/16] float8_e4m3fn, global_scale [1] f32)``
+    with ``w ~ e2m1 * block_scale / global_scale`` - the tensors (and the
+    divide-by-global-scale convention) of a compressed-tensors
+    ``nvfp4-pack-quantized`` checkpoint."""
+    n, k = w.shape
+    wf = w.to(torch.float32)
+    amax = wf.abs().max().clamp_min(1e-12)
+    gscale = (448.0 * 6.0 / amax).reshape(1)
+    blocks = wf.reshape(n, k // 16, 16)
+    bs = (blocks.abs().amax(-1) / 6.0 * gscale).clamp(max=448.0).to(torch.float8_e4m3fn)
+    eff = (bs.to(torch.float32) / gscale).clamp_min(1e-30).unsqueeze(-1)
+    lut = torch.tensor(FP4_VALUES, dtype=torch.float32, device=w.device)
+    mag = (blocks.abs() / eff).clamp(max=6.0)
+    code = (mag.unsqueeze(-1) - lut).abs().argmin(-1)
+    code = (code + 8 * (blocks < 0)).to(torch.uint8).reshape(n, k // 2, 2)
+    packed = code[..., 0] | (code[..., 1] << 4)
+    return packed.contiguous(), bs, gscale
