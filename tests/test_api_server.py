@@ -120,3 +120,40 @@ def test_server_endpoints_end_to_end(frontend_mp):
                 assert (await c.post("/reset_prefix_cache")).status_code == 200
     asyncio.run(main())
     pstate.destroy_model_parallel()
+
+
+def test_chat_and_complete_clients_stream_from_a_server():
+    """The terminal clients: model discovery, bearer token, SSE parsing for
+    both endpoints, conversation history in chat mode."""
+    import io
+    from vllm_distributed_amd.entrypoints import client
+    seen = []
+
+    def handler(request: httpx.Request) -> httpx.Response:
+        assert request.headers["authorization"] == "Bearer sekret"
+        if request.url.path == "/v1/models":
+            return httpx.Response(200, json={"data": [{"id": "tiny"}]})
+        body = json.loads(request.content)
+        seen.append((request.url.path, body))
+        assert body["model"] == "tiny" and body["stream"] is True
+        if request.url.path == "/v1/completions":
+            events = [{"choices": [{"index": 0, "text": t}]} for t in (" wor", "ld")]
+        else:
+            events = [{"choices": [{"index": 0, "delta": {"role": "assistant"}}]},
+                      {"choices": [{"index": 0, "delta": {"content": "hi "}}]},
+                      {"choices": [{"index": 0, "delta": {"content": "there"}, "finish_reason": "stop"}]}]
+        sse = "".join(f"data: {json.dumps(e)}\n\n" for e in events) + "data: [DONE]\n\n"
+        return httpx.Response(200, content=sse.encode(), headers={"content-type": "text/event-stream"})
+
+    transport = httpx.MockTransport(handler)
+    a = build_parser().parse_args("complete --url http://t/v1 --api-key sekret -q hello --max-tokens 7".split())
+    out = io.StringIO()
+    a.dispatch_function(a, transport=transport, out=out)
+    assert out.getvalue() == " world\n"
+    assert seen[-1][0] == "/v1/completions" and seen[-1][1]["prompt"] == "hello" and seen[-1][1]["max_tokens"] == 7
+    a = build_parser().parse_args(["chat", "--url", "http://t/v1", "--api-key", "sekret", "-q", "hey",
+                                   "--system-prompt", "be brief"])
+    out = io.StringIO()
+    a.dispatch_function(a, transport=transport, out=out)
+    assert out.getvalue() == "hi there\n"
+    assert [m["role"] for m in seen[-1][1]["messages"]] == ["system", "user"]

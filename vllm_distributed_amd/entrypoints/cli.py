@@ -2,8 +2,9 @@
 
 ``serve <model>`` starts the OpenAI server on top of the distributed executor
 (the only sub-command the reference effectively supports, reference
-``src/launch.py:460-507``); ``bench``, ``collect-env`` and ``run-batch`` cover
-the other sub-commands the reference's parser registers (``:465-471``).
+``src/launch.py:460-507``); ``chat``, ``complete``, ``bench``, ``collect-env``
+and ``run-batch`` cover the other sub-commands the reference's parser
+registers (``:465-471``).
 """
 from __future__ import annotations
 
@@ -173,6 +174,14 @@ def build_parser() -> argparse.ArgumentParser:
     pbe.add_argument("--output-len", type=int, default=64)
     EngineArgs.add_cli_args(pbe)
     pbe.set_defaults(dispatch_function=cmd_bench)
+    from . import client
+    pc = sub.add_parser("chat", help="interactive chat with a running server")
+    client.add_client_args(pc)
+    pc.add_argument("--system-prompt", type=str, default=None)
+    pc.set_defaults(dispatch_function=client.cmd_chat)
+    pco = sub.add_parser("complete", help="text completion against a running server")
+    client.add_client_args(pco)
+    pco.set_defaults(dispatch_function=client.cmd_complete)
     return parser
 
 
