@@ -329,6 +329,13 @@ class ObservabilityConfig:
 
 
 @dataclass
+class LoRAConfig:
+    """Adapter slots every worker keeps resident (``--enable-lora``)."""
+    max_loras: int = 1
+    max_lora_rank: int = 16
+
+
+@dataclass
 class VllmConfig:
     model_config: ModelConfig = field(default_factory=ModelConfig)
     cache_config: CacheConfig = field(default_factory=CacheConfig)
@@ -338,6 +345,7 @@ class VllmConfig:
     compilation_config: CompilationConfig = field(default_factory=CompilationConfig)
     observability_config: ObservabilityConfig = field(default_factory=ObservabilityConfig)
     kv_transfer_config: Optional[KVTransferConfig] = None
+    lora_config: Optional[LoRAConfig] = None
 
     def __post_init__(self) -> None:
         self.scheduler_config.max_model_len = self.model_config.max_model_len

@@ -13,7 +13,7 @@ import json
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional
 
-from ..config import (CacheConfig, CompilationConfig, DeviceConfig, KVTransferConfig, ModelConfig,
+from ..config import (CacheConfig, CompilationConfig, DeviceConfig, KVTransferConfig, LoRAConfig, ModelConfig,
                       ObservabilityConfig, ParallelConfig, SchedulerConfig, VllmConfig)
 
 
@@ -54,6 +54,9 @@ class EngineArgs:
     max_capture_size: int = 512
     kv_transfer_config: Optional[Dict[str, Any]] = None
     disable_log_stats: bool = False
+    enable_lora: bool = False
+    max_loras: int = 1
+    max_lora_rank: int = 16
 
     # ---------------------------------------------------------------- CLI
     @staticmethod
@@ -67,7 +70,7 @@ class EngineArgs:
         g.add_argument("--seed", type=int, default=0)
         g.add_argument("--max-model-len", type=int, default=None)
         g.add_argument("--load-format", type=str, default="auto", choices=["auto", "safetensors", "dummy"])
-        g.add_argument("--quantization", "-q", type=str, default=None, choices=[None, "awq", "awq-dequant", "fp8"])
+        g.add_argument("--quantization", "-q", type=str, default=None, choices=[None, "awq", "awq-dequant", "fp8", "nvfp4"])
         g.add_argument("--trust-remote-code", action="store_true")
         g.add_argument("--revision", type=str, default=None)
         g.add_argument("--hf-overrides", type=json.loads, default=None)
@@ -95,6 +98,9 @@ class EngineArgs:
         g.add_argument("--max-capture-size", type=int, default=512)
         g.add_argument("--kv-transfer-config", type=json.loads, default=None)
         g.add_argument("--disable-log-stats", action="store_true")
+        g.add_argument("--enable-lora", action="store_true", help="serve LoRA adapters next to the base model")
+        g.add_argument("--max-loras", type=int, default=1, help="adapters resident (and usable in one batch) at once")
+        g.add_argument("--max-lora-rank", type=int, default=16)
         return parser
 
     @classmethod
@@ -137,10 +143,12 @@ class EngineArgs:
                                                capture_sizes=self.hip_graph_sizes,
                                                max_capture_size=self.max_capture_size)
         kvt = KVTransferConfig(**self.kv_transfer_config) if self.kv_transfer_config else None
+        lora = LoRAConfig(self.max_loras, self.max_lora_rank) if self.enable_lora else None
         return VllmConfig(model_config=model_config, cache_config=cache_config,
                           parallel_config=parallel_config, scheduler_config=scheduler_config,
                           device_config=device_config, compilation_config=compilation_config,
-                          observability_config=ObservabilityConfig(), kv_transfer_config=kvt)
+                          observability_config=ObservabilityConfig(), kv_transfer_config=kvt,
+                          lora_config=lora)
 
 
 AsyncEngineArgs = EngineArgs

@@ -141,9 +141,9 @@ class AsyncLLM:
     def _handle(self, msg: tuple) -> None:
         kind = msg[0]
         if kind == "add":
-            _, rid, prompt, params, priority = msg
+            _, rid, prompt, params, priority, lora = msg
             try:
-                self.engine.add_request(rid, prompt, params, priority=priority)
+                self.engine.add_request(rid, prompt, params, priority=priority, lora_request=lora)
                 self.metrics.request_arrived()
             except BaseException as e:  # noqa: BLE001 - report to the caller, keep serving
                 self._post(rid, e)
@@ -173,7 +173,7 @@ class AsyncLLM:
         return self.tokenizer
 
     async def generate(self, prompt: Union[str, Sequence[int], dict], sampling_params: SamplingParams,
-                       request_id: Optional[str] = None, priority: int = 0,
+                       request_id: Optional[str] = None, priority: int = 0, lora_request=None,
                        ) -> AsyncIterator[RequestOutput]:
         if self.errored:
             raise EngineDeadError(f"engine is dead: {self._dead!r}")
@@ -181,7 +181,7 @@ class AsyncLLM:
         rid = request_id or f"cmpl-{next(self._counter)}"
         q = OutputCollector()
         self._queues[rid] = q
-        self._inbox.put(("add", rid, prompt, sampling_params, priority))
+        self._inbox.put(("add", rid, prompt, sampling_params, priority, lora_request))
         finished = False
         try:
             while True:
@@ -219,6 +219,18 @@ class AsyncLLM:
 
     async def reset_prefix_cache(self) -> bool:
         return await self._call(self.engine.core.reset_prefix_cache)
+
+    async def add_lora(self, lora_request) -> bool:
+        return await self._call(lambda: self.engine.core.add_lora(lora_request))
+
+    async def remove_lora(self, lora_id: int) -> bool:
+        return await self._call(lambda: self.engine.core.remove_lora(lora_id))
+
+    async def list_loras(self):
+        return await self._call(self.engine.core.list_loras)
+
+    async def pin_lora(self, lora_id: int) -> bool:
+        return await self._call(lambda: self.engine.core.pin_lora(lora_id))
 
     async def sleep(self, level: int = 1) -> None:
         await self._call(lambda: self.engine.core.sleep(level))

@@ -65,7 +65,8 @@ class EngineCore:
             from ..executor.kv_transfer import make_scheduler_connector
             kv_connector = make_scheduler_connector(vllm_config)
         self.scheduler = Scheduler(vllm_config.scheduler_config, vllm_config.cache_config, num_blocks,
-                                   include_new_token_ids=pp > 1, kv_connector=kv_connector)
+                                   include_new_token_ids=pp > 1, kv_connector=kv_connector,
+                                   max_loras=vllm_config.lora_config.max_loras if vllm_config.lora_config else 0)
         self.max_concurrent = max(1, self.executor.max_concurrent_batches)
         self.batch_queue: Deque[Tuple[object, SchedulerOutput]] = deque()
         self.timer = StepTimer()
@@ -180,6 +181,21 @@ class EngineCore:
 
     def reset_prefix_cache(self) -> bool:
         return self.scheduler.reset_prefix_cache()
+
+    def add_lora(self, lora_request) -> bool:
+        return self.executor.add_lora(lora_request)
+
+    def remove_lora(self, lora_id: int) -> bool:
+        for r in self.scheduler.requests.values():
+            if not r.finished and r.lora_request is not None and r.lora_request.lora_int_id == lora_id:
+                raise RuntimeError(f"LoRA adapter {lora_id} is in use by request {r.request_id}")
+        return self.executor.remove_lora(lora_id)
+
+    def list_loras(self):
+        return self.executor.list_loras()
+
+    def pin_lora(self, lora_id: int) -> bool:
+        return self.executor.pin_lora(lora_id)
 
     def sleep(self, level: int = 1) -> None:
         self.executor.sleep(level)

@@ -248,6 +248,18 @@ class MPEngineCoreClient:
     def reset_prefix_cache(self) -> bool:
         return bool(self._call("reset_prefix_cache"))
 
+    def add_lora(self, lora_request) -> bool:
+        return bool(self._call("add_lora", lora_request))
+
+    def remove_lora(self, lora_id: int) -> bool:
+        return bool(self._call("remove_lora", lora_id))
+
+    def list_loras(self):
+        return self._call("list_loras")
+
+    def pin_lora(self, lora_id: int) -> bool:
+        return bool(self._call("pin_lora", lora_id))
+
     def sleep(self, level: int = 1) -> None:
         self._call("sleep", level)
 

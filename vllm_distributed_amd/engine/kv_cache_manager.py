@@ -122,7 +122,9 @@ class KVCacheManager:
         toks = request.all_token_ids
         n_full = min(num_tokens, len(toks)) // bs
         hashes = request.block_hashes
-        parent = hashes[-1] if hashes else None
+        # KV produced under an adapter is only reusable under the same adapter
+        lora = getattr(request, "lora_request", None)
+        parent = hashes[-1] if hashes else (None if lora is None else hash(("lora", lora.lora_int_id)))
         for i in range(len(hashes), n_full):
             parent = hash_block_tokens(parent, toks[i * bs:(i + 1) * bs])
             hashes.append(parent)

@@ -65,7 +65,7 @@ class LLMEngine:
     # -------------------------------------------------------------- requests
     def add_request(self, request_id: Optional[str], prompt: Union[str, Sequence[int], dict],
                     params: Optional[SamplingParams] = None, arrival_time: Optional[float] = None,
-                    priority: int = 0) -> str:
+                    priority: int = 0, lora_request=None) -> str:
         params = params or SamplingParams()
         if request_id is None:
             request_id = f"req-{next(self._counter)}"
@@ -87,7 +87,7 @@ class LLMEngine:
         vocab = self.model_config.vocab_size
         if any(t < 0 or t >= vocab for t in ids):
             raise ValueError("prompt contains token ids outside the model vocabulary")
-        req = Request(request_id, ids, params, self.eos_token_id, arrival_time, priority, text)
+        req = Request(request_id, ids, params, self.eos_token_id, arrival_time, priority, text, lora_request)
         detok = IncrementalDetokenizer(self.tokenizer, ids, params) if params.detokenize else None
         self.core.add_request(req)
         self.states[request_id] = _ReqState(req, detok, text)
@@ -174,7 +174,7 @@ class LLM:
 
     def generate(self, prompts: Union[str, Sequence[Union[str, Sequence[int], dict]]],
                  sampling_params: Union[None, SamplingParams, Sequence[SamplingParams]] = None,
-                 ) -> List[RequestOutput]:
+                 lora_request=None) -> List[RequestOutput]:
         if isinstance(prompts, (str, dict)) or (prompts and isinstance(prompts[0], int)):
             prompts = [prompts]  # type: ignore[list-item]
         n = len(prompts)
@@ -182,7 +182,8 @@ class LLM:
             sps = [sampling_params or SamplingParams()] * n
         else:
             sps = list(sampling_params)
-        ids = [self.engine.add_request(None, p, sp) for p, sp in zip(prompts, sps)]
+        loras = lora_request if isinstance(lora_request, (list, tuple)) else [lora_request] * n
+        ids = [self.engine.add_request(None, p, sp, lora_request=lr) for p, sp, lr in zip(prompts, sps, loras)]
         final: Dict[str, RequestOutput] = {}
         while self.engine.has_unfinished_requests():
             for out in self.engine.step():

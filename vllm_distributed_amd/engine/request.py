@@ -31,13 +31,15 @@ class Request:
     __slots__ = ("request_id", "prompt_token_ids", "sampling_params", "eos_token_id",
                  "arrival_time", "priority", "status", "output_token_ids", "all_token_ids",
                  "num_computed_tokens", "num_cached_tokens", "stop_reason", "metrics",
-                 "block_hashes", "num_preemptions", "max_tokens", "prompt", "num_output_placeholders")
+                 "block_hashes", "num_preemptions", "max_tokens", "prompt", "num_output_placeholders",
+                 "lora_request")
 
     def __init__(self, request_id: str, prompt_token_ids: List[int],
                  sampling_params: SamplingParams, eos_token_id: Optional[int] = None,
                  arrival_time: Optional[float] = None, priority: int = 0,
-                 prompt: Optional[str] = None):
+                 prompt: Optional[str] = None, lora_request=None):
         self.request_id = request_id
+        self.lora_request = lora_request
         self.prompt_token_ids = list(prompt_token_ids)
         self.sampling_params = sampling_params
         self.eos_token_id = eos_token_id

@@ -55,7 +55,7 @@ class SchedulerStats:
 class Scheduler:
     def __init__(self, scheduler_config: SchedulerConfig, cache_config: CacheConfig,
                  num_blocks: int, include_new_token_ids: bool = True,
-                 kv_connector=None):
+                 kv_connector=None, max_loras: int = 0):
         self.config = scheduler_config
         self.cache_config = cache_config
         self.max_num_seqs = scheduler_config.max_num_seqs
@@ -77,6 +77,8 @@ class Scheduler:
         self._pending_new_tokens: Dict[str, List[int]] = {}
         self.include_new_token_ids = include_new_token_ids
         self.kv_connector = kv_connector
+        # distinct adapters one batch may use (= the workers' resident slots); 0 = LoRA off
+        self.max_loras = max_loras
         self.step_id = 0
         self.num_preemptions = 0
 
@@ -89,6 +91,8 @@ class Scheduler:
         if request.num_prompt_tokens >= self.max_model_len:
             raise ValueError(f"prompt ({request.num_prompt_tokens} tokens) does not fit "
                              f"max_model_len ({self.max_model_len})")
+        if request.lora_request is not None and self.max_loras <= 0:
+            raise ValueError("the engine was started without --enable-lora")
         self.requests[request.request_id] = request
         self._enqueue_waiting(request)
 
@@ -183,6 +187,10 @@ class Scheduler:
         if not preempted:
             while self.waiting and budget > 0 and len(self.running) < self.max_num_seqs:
                 req = self.waiting[0]
+                if req.lora_request is not None:
+                    active = {r.lora_request.lora_int_id for r in self.running if r.lora_request is not None}
+                    if req.lora_request.lora_int_id not in active and len(active) >= self.max_loras:
+                        break            # every adapter slot is busy with running requests
                 computed_blocks, num_cached = ([], 0)
                 if req.num_computed_tokens == 0:
                     computed_blocks, num_cached = self.kv.get_computed_blocks(req)
@@ -213,7 +221,8 @@ class Scheduler:
                     req_id=req.request_id, prompt_token_ids=req.prompt_token_ids,
                     sampling_params=req.sampling_params, block_ids=blocks,
                     num_computed_tokens=num_cached,
-                    output_token_ids=list(req.output_token_ids) if resumed else []))
+                    output_token_ids=list(req.output_token_ids) if resumed else [],
+                    lora_request=req.lora_request))
                 self._known_to_workers.add(req.request_id)
                 self._pending_new_tokens.pop(req.request_id, None)
                 num_scheduled[req.request_id] = n

@@ -25,6 +25,7 @@ class NewRequestData:
     num_computed_tokens: int        # > 0 on a prefix-cache hit
     # tokens generated before a preemption (recompute path) - part of the prompt now
     output_token_ids: List[int] = field(default_factory=list)
+    lora_request: Optional[Any] = None
 
 
 @dataclass

@@ -44,6 +44,8 @@ def add_server_args(p: argparse.ArgumentParser) -> None:
     g.add_argument("--tool-parser-plugin", type=str, default="")
     g.add_argument("--chat-template", type=str, default=None)
     g.add_argument("--enable-tokenizer-info-endpoint", action="store_true")
+    g.add_argument("--lora-modules", type=str, nargs="+", default=None, metavar="NAME=PATH",
+                   help="LoRA adapters served under their own model names (needs --enable-lora)")
     g.add_argument("--disable-frontend-multiprocessing", action="store_true",
                    help="run the engine core on a thread of the API-server process instead of in its own process")
 

@@ -17,6 +17,7 @@ from __future__ import annotations
 import argparse
 import asyncio
 import json
+import os
 import socket
 import time
 import uuid
@@ -205,6 +206,17 @@ def maybe_register_tokenizer_info_endpoint(args: argparse.Namespace) -> None:
     return None
 
 
+def _register_lora(state, name: str, path: str):
+    from ...lora import LoRARequest
+    if name in state.loras or name in state.served_names:
+        raise ValueError(f"model name {name!r} is already served")
+    if not os.path.isfile(os.path.join(path, "adapter_config.json")):
+        raise ValueError(f"{path!r} is not a LoRA adapter directory (no adapter_config.json)")
+    state.loras[name] = LoRARequest(name, state.next_lora_id, path)
+    state.next_lora_id += 1
+    return state.loras[name]
+
+
 async def init_app_state(engine: AsyncLLM, vllm_config, state, args: argparse.Namespace) -> None:
     state.engine = engine
     state.args = args
@@ -223,6 +235,14 @@ async def init_app_state(engine: AsyncLLM, vllm_config, state, args: argparse.Na
         except OSError:
             state.chat_template = ct
     state.start_time = time.time()
+    # served LoRA adapters: name -> LoRARequest (``--lora-modules name=path ...`` and /v1/load_lora_adapter)
+    state.loras = {}
+    state.next_lora_id = 1
+    for item in getattr(args, "lora_modules", None) or []:
+        name, _, path = item.partition("=")
+        if not name or not path:
+            raise ValueError(f"--lora-modules expects name=path, got {item!r}")
+        _register_lora(state, name, path)
 
 
 # -------------------------------------------------------------------- routes
@@ -281,7 +301,10 @@ def _register_routes(app: FastAPI) -> None:
         st = request.app.state
         return {"object": "list", "data": [
             {"id": n, "object": "model", "created": int(st.start_time), "owned_by": "vllm-distributed-amd",
-             "root": st.served_names[0], "max_model_len": st.max_model_len} for n in st.served_names]}
+             "root": st.served_names[0], "max_model_len": st.max_model_len} for n in st.served_names] + [
+            {"id": n, "object": "model", "created": int(st.start_time), "owned_by": "vllm-distributed-amd",
+             "root": lr.lora_path, "parent": st.served_names[0], "max_model_len": st.max_model_len}
+            for n, lr in st.loras.items()]}
 
     @app.get("/metrics")
     async def metrics(request: Request):
@@ -337,9 +360,40 @@ def _register_routes(app: FastAPI) -> None:
         return Response(status_code=200)
 
     def _check_model(st, name: Optional[str]) -> Optional[JSONResponse]:
-        if name and name not in st.served_names:
+        if name and name not in st.served_names and name not in st.loras:
             return _error(f"The model `{name}` does not exist.", 404, "NotFoundError")
         return None
+
+    @app.post("/v1/load_lora_adapter")
+    async def load_lora_adapter(request: Request):
+        st = request.app.state
+        body = await request.json()
+        name, path = body.get("lora_name"), body.get("lora_path")
+        if not name or not path:
+            return _error("lora_name and lora_path are required")
+        if getattr(st.args, "enable_lora", False) is False:
+            return _error("the server was started without --enable-lora")
+        try:
+            lr = _register_lora(st, name, path)
+            await st.engine.add_lora(lr)          # load now so a bad adapter fails here, not in a request
+        except Exception as e:  # noqa: BLE001
+            st.loras.pop(name, None)
+            return _error(str(e))
+        return Response(f"Success: LoRA adapter '{name}' added successfully.", status_code=200)
+
+    @app.post("/v1/unload_lora_adapter")
+    async def unload_lora_adapter(request: Request):
+        st = request.app.state
+        body = await request.json()
+        lr = st.loras.get(body.get("lora_name"))
+        if lr is None:
+            return _error(f"The lora adapter '{body.get('lora_name')}' cannot be found.", 404, "NotFoundError")
+        try:
+            await st.engine.remove_lora(lr.lora_int_id)
+        except Exception as e:  # noqa: BLE001
+            return _error(str(e))
+        del st.loras[lr.lora_name]
+        return Response(f"Success: LoRA adapter '{lr.lora_name}' removed successfully.", status_code=200)
 
     # ------------------------------------------------------- /v1/completions
     @app.post("/v1/completions")
@@ -368,7 +422,8 @@ def _register_routes(app: FastAPI) -> None:
             return _error(str(e))
         # n samples per prompt = n requests sharing the prompt (its KV blocks are shared through the
         # prefix cache); a fixed seed is advanced per sample so the samples differ reproducibly
-        gens = [engine.generate(pr, _nth_params(sp, j), f"{rid}-{i}-{j}", req.priority)
+        lora = st.loras.get(req.model) if req.model else None
+        gens = [engine.generate(pr, _nth_params(sp, j), f"{rid}-{i}-{j}", req.priority, lora)
                 for i, pr in enumerate(prompts) for j in range(n)]
 
         def lp_block(out, start: int) -> Optional[dict]:
@@ -477,7 +532,8 @@ def _register_routes(app: FastAPI) -> None:
         created = int(time.time())
         parser = st.tool_parser if tools else None
         gens = [engine.generate({"prompt": prompt, "prompt_token_ids": prompt_ids}, _nth_params(sp, j),
-                                rid if n == 1 else f"{rid}-{j}", req.priority) for j in range(n)]
+                                rid if n == 1 else f"{rid}-{j}", req.priority,
+                                st.loras.get(req.model) if req.model else None) for j in range(n)]
         gen = gens[0]
 
         def lp_content(out, start: int) -> Optional[dict]:

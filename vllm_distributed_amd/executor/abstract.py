@@ -127,6 +127,18 @@ class Executor:
     def profile(self, is_start: bool = True) -> None:
         self.collective_rpc("profile", args=(is_start,))
 
+    def add_lora(self, lora_request) -> bool:
+        return all(self.collective_rpc("add_lora", args=(lora_request,)))
+
+    def remove_lora(self, lora_id: int) -> bool:
+        return all(self.collective_rpc("remove_lora", args=(lora_id,)))
+
+    def list_loras(self) -> List[int]:
+        return sorted(set().union(*[set(x or ()) for x in self.collective_rpc("list_loras")]))
+
+    def pin_lora(self, lora_id: int) -> bool:
+        return all(self.collective_rpc("pin_lora", args=(lora_id,)))
+
     def sleep(self, level: int = 1) -> None:
         self.collective_rpc("sleep", kwargs=dict(level=level))
 

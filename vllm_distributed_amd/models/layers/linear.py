@@ -143,6 +143,7 @@ class _LinearBase(nn.Module):
         self.register_buffer("sz", None)
         self.register_buffer("weight_scale", None)
         self.register_buffer("alpha", None)
+        self.lora = None          # adapter slots, attached by lora.LoRAManager
         if spec is not None and spec.method == "nvfp4":
             assert in_local % 16 == 0, f"NVFP4 shard [{out_local} x {in_local}] splits a 16-column block"
             self.weight_packed = _tag(_param(out_local, in_local // 2, dtype=torch.uint8), 0, 1, 2)
@@ -203,6 +204,12 @@ class _LinearBase(nn.Module):
             self.weight = nn.Parameter(awq_dequantize(qweight, qzeros, scales, self.dtype), requires_grad=False)
 
     def _matmul(self, x: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+        y = self._base_matmul(x, bias)
+        if self.lora is not None:
+            y = self.lora.apply(x, y)
+        return y
+
+    def _base_matmul(self, x: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
         if self.qw is not None:
             if self.alpha is not None:
                 return ops.fp4_linear(x, self.qw, self.sz, self.alpha, bias)

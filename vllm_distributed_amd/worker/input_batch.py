@@ -44,6 +44,7 @@ class InputBatch:
         self.repetition = np.ones(n, dtype=np.float32)
         self.num_logprobs = np.full(n, -1, dtype=np.int32)
         self.has_penalty = np.zeros(n, dtype=bool)
+        self.lora_id = np.zeros(n, dtype=np.int32)              # 0 = base model
         self.req_ids: List[Optional[str]] = [None] * n
         self.row_of: Dict[str, int] = {}
         self.params: List[Optional[SamplingParams]] = [None] * n
@@ -55,7 +56,7 @@ class InputBatch:
         return len(self.row_of)
 
     def add_request(self, req_id: str, prompt_token_ids: List[int], output_token_ids: List[int],
-                    sp: SamplingParams, block_ids: List[int], num_computed: int) -> int:
+                    sp: SamplingParams, block_ids: List[int], num_computed: int, lora_id: int = 0) -> int:
         if req_id in self.row_of:
             self.remove_request(req_id)
         if not self._free_rows:
@@ -84,6 +85,7 @@ class InputBatch:
         self.repetition[row] = sp.repetition_penalty
         self.has_penalty[row] = sp.has_penalties
         self.num_logprobs[row] = -1 if sp.logprobs is None else sp.logprobs
+        self.lora_id[row] = lora_id
         self.req_ids[row] = req_id
         self.row_of[req_id] = row
         self.params[row] = sp
@@ -108,6 +110,7 @@ class InputBatch:
         self.row_gen[row] += 1
         self.num_computed[row] = 0
         self.num_blocks[row] = 0
+        self.lora_id[row] = 0
         self._free_rows.append(row)
 
     def append_blocks(self, row: int, block_ids: List[int]) -> None:

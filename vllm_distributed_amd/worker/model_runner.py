@@ -18,6 +18,7 @@ from .. import envs, ops
 from ..config import VllmConfig
 from ..engine.types import KVCacheSpec, ModelRunnerOutput, SchedulerOutput
 from ..logger import init_logger
+from ..lora import lora_active, set_lora_step
 from ..utils.tracing import trace_range
 from ..models.layers.attention import AttentionMetadata, set_forward_context
 from ..models.loader import load_model
@@ -128,6 +129,7 @@ class ModelRunner:
         self.step_count = 0
         self.report_on_all_ranks = False
         self.comm_stream = None
+        self.lora_manager = None
         self.sampled_dev: Optional[torch.Tensor] = None      # last sampled token per batch row (device)
         self._pending: List[PendingSample] = []
         self.defer_output = False        # set by in-process executors under async scheduling
@@ -143,6 +145,10 @@ class ModelRunner:
         if (self.is_gpu and self.pp.world_size == 1 and hasattr(self.model, "forward_overlapped")
                 and (mode == "force" or (mode == "auto" and self.tp.world_size > 1))):
             self.comm_stream = torch.cuda.Stream(priority=-1)
+        if self.vllm_config.lora_config is not None:
+            from ..lora import LoRAManager
+            self.lora_manager = LoRAManager(self.model, self.vllm_config.lora_config,
+                                            self.model_config.torch_dtype, self.device)
         logger.info("model loaded in %.1fs", time.time() - t0)
 
     def get_kv_cache_spec(self) -> KVCacheSpec:
@@ -194,8 +200,14 @@ class ModelRunner:
         for rid in so.preempted_req_ids:
             b.remove_request(rid)
         for nr in so.scheduled_new_reqs:
+            lora_id = 0
+            if nr.lora_request is not None:
+                if self.lora_manager is None:
+                    raise RuntimeError("request names a LoRA adapter but the engine runs without --enable-lora")
+                self.lora_manager.add_lora(nr.lora_request, protect=self.loras_in_batch())
+                lora_id = nr.lora_request.lora_int_id
             b.add_request(nr.req_id, nr.prompt_token_ids, nr.output_token_ids, nr.sampling_params,
-                          nr.block_ids, nr.num_computed_tokens)
+                          nr.block_ids, nr.num_computed_tokens, lora_id)
         c = so.scheduled_cached_reqs
         samples_here = self.pp.is_last_rank
         for i, rid in enumerate(c.req_ids):
@@ -207,6 +219,11 @@ class ModelRunner:
             if toks and not samples_here:
                 # stages that do not sample learn new tokens from the scheduler
                 b.append_tokens(row, toks)
+
+    def loras_in_batch(self):
+        b = self.batch
+        rows = list(b.row_of.values())
+        return set(int(i) for i in np.unique(b.lora_id[rows]) if i) if rows else set()
 
     # --------------------------------------------------------- input building
     def _prepare_inputs(self, so: SchedulerOutput):
@@ -304,15 +321,22 @@ class ModelRunner:
         nreq, nd, total = len(p["req_ids"]), p["num_decodes"], p["total"]
         t1 = time.perf_counter()
 
+        lora_step = None
+        if self.lora_manager is not None:
+            lora_step = self.lora_manager.make_step(self.batch.lora_id[p["tok_rows"]], self._to_dev)
         graph = None
-        if self.graphs and nd == nreq:
+        if self.graphs and nd == nreq and lora_step is None:       # captured graphs hold the base model only
             graph = self._pick_graph(nreq, p["max_blocks"])
         with trace_range("step.forward.graph" if graph is not None else "step.forward.eager"):
             if graph is not None:
                 hidden = self._run_graph(graph, p)
             else:
                 md, input_ids, positions = self._build_metadata(p)
-                hidden = self._run_eager(md, input_ids, positions, total)
+                set_lora_step(lora_step)
+                try:
+                    hidden = self._run_eager(md, input_ids, positions, total)
+                finally:
+                    set_lora_step(None)
 
         # advance computed-token counts (the scheduler did the same when it scheduled)
         self.batch.num_computed[p["rows"]] += p["n_sched"]
@@ -393,7 +417,8 @@ class ModelRunner:
 
     def _run_eager(self, md: AttentionMetadata, input_ids: torch.Tensor, positions: torch.Tensor,
                    total: int):
-        if md.num_prefills == 0 and self.pp.world_size == 1 and self.comm_stream is not None:
+        # adapter row indices refer to the whole batch: no micro-batch split while one is active
+        if md.num_prefills == 0 and self.pp.world_size == 1 and self.comm_stream is not None and not lora_active():
             return self._forward_decode(md, input_ids, positions)
         inter = None
         if not self.pp.is_first_rank:

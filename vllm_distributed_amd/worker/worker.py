@@ -204,8 +204,27 @@ class Worker:
         sd = {k: v.detach().to("cpu").contiguous() for k, v in self.model_runner.model.state_dict().items()}
         save_file(sd, os.path.join(path, (pattern or "model-rank-{rank}.safetensors").format(rank=self.rank)))
 
-    def add_lora(self, *a, **k) -> bool:
-        raise NotImplementedError("LoRA adapters are not supported")
+    # ------------------------------------------------------------------ LoRA
+    def _lora(self):
+        mgr = self.model_runner.lora_manager
+        if mgr is None:
+            raise RuntimeError("the engine was started without --enable-lora")
+        return mgr
+
+    def add_lora(self, lora_request) -> bool:
+        """Make the adapter resident now (requests naming it load it on demand otherwise)."""
+        self._lora().add_lora(lora_request, protect=self.model_runner.loras_in_batch())
+        return True
+
+    def remove_lora(self, lora_id: int) -> bool:
+        # the engine core refuses this while unfinished requests name the adapter
+        return self._lora().remove_lora(lora_id)
+
+    def list_loras(self):
+        return self._lora().list_loras()
+
+    def pin_lora(self, lora_id: int) -> bool:
+        return self._lora().pin_lora(lora_id)
 
     def shutdown(self) -> None:
         self.model_runner = None
