@@ -10,9 +10,9 @@
 // xGMI is point-to-point, so both shapes keep all 7 links of a GPU busy at
 // once instead of walking a ring.
 //
-// Cross-GPU ordering uses per-block flags in uncached (fine-grained) memory with
-// system-scope atomics; bulk data only ever crosses GPUs across a kernel
-// boundary.  Epochs are kept in device memory so a captured hipGraph replays
+// Cross-GPU ordering uses per-block flags with system-scope atomics; flags and
+// staging both live in uncached (fine-grained) memory, so data a peer wrote
+// before raising its flag is what a reader sees after observing the flag.  Epochs are kept in device memory so a captured hipGraph replays
 // correctly.  Every spin is bounded: a rank whose peer never arrives sets
 // `timeout_flag` and falls through rather than hanging the GPU.
 #include "common.h"
@@ -139,7 +139,12 @@ VDAMD_API void* vdamd_car_create(int rank, int world, size_t data_bytes, void* d
   if (world < 2 || world > CAR_MAX_RANKS || rank < 0 || rank >= world) return nullptr;
   Context* c = new Context();
   c->rank = rank; c->world = world; c->data_bytes = data_bytes; c->n_opened = 0;
-  if (hipMalloc((void**)&c->self_data, 2 * data_bytes) != hipSuccess) { delete c; return nullptr; }
+  // Uncached (fine-grained) like the flags: a peer's reduce-scatter result is read by this GPU's
+  // all-gather kernel inside one kernel pair, with only the in-kernel barrier between them, so the
+  // reader must never be served a line its L2 kept from the previous call on the same addresses.
+  if (hipExtMallocWithFlags((void**)&c->self_data, 2 * data_bytes, hipDeviceMallocUncached) != hipSuccess) {
+    delete c; return nullptr;
+  }
   if (hipExtMallocWithFlags((void**)&c->self_sig, sizeof(Signal), hipDeviceMallocUncached) != hipSuccess) {
     (void)hipFree(c->self_data); delete c; return nullptr;
   }
