@@ -17,7 +17,8 @@ eng = LLMEngine.from_engine_args(EngineArgs(
     model=model, load_format="dummy", max_model_len=256, max_num_seqs=batch, max_num_batched_tokens=16384,
     enable_prefix_caching=False, hip_graph_sizes=[batch], max_capture_size=batch, async_scheduling=True))
 rng = np.random.default_rng(0)
-sp = SamplingParams(temperature=0.0, max_tokens=100, ignore_eos=True, detokenize=False)
+detok = os.environ.get("DETOK") == "1"
+sp = SamplingParams(temperature=0.0, max_tokens=100, ignore_eos=True, detokenize=detok)
 for i in range(batch):
     eng.add_request(f"r{i}", rng.integers(0, 1000, size=64).tolist(), sp)
 sched = eng.core.scheduler
@@ -25,6 +26,14 @@ while sched.waiting or any(r.num_computed_tokens < r.num_prompt_tokens for r in 
     eng.step()
 for _ in range(3):
     eng.step()
+import time  # noqa: E402
+import torch  # noqa: E402
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    eng.step()
+torch.cuda.synchronize()
+print(f"batch {batch} detokenize={detok}: {(time.perf_counter() - t0) / 20 * 1e3:.2f} ms/step wall (unprofiled)")
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(20):

@@ -314,16 +314,26 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
     T* __restrict__ out, const T* __restrict__ q, long q_stride, const T* __restrict__ k_cache,
     const T* __restrict__ v_cache, const int* __restrict__ block_table, int bt_stride,
     const int* __restrict__ query_start_loc, const int* __restrict__ seq_lens, float scale_log2e, int Hq, int Hkv,
-    int block_size, long out_stride) {
+    int block_size, long out_stride, int q_tiles, int total_wgs, int xcd_remap) {
   using V = typename Vec8<T>::type;
   constexpr int D = 128, KT = 64, TILE_BYTES = KT * D * 2;
   __shared__ __attribute__((aligned(16))) char smem[2][2][TILE_BYTES];     // [buffer][K | V^T]
 
-  const int z = blockIdx.z, head = blockIdx.y;
+  // Workgroups are handed to the 8 XCDs round-robin by their linear id, and each
+  // XCD has its own L2.  Remapping id -> (id % 8) * (n / 8) + id / 8 gives every
+  // XCD one contiguous run of (sequence, head, query tile) triples, i.e. the query
+  // tiles and the GQA group of *one* KV head, so a K/V tile is fetched into one L2
+  // instead of eight.
+  int wg = blockIdx.x;
+  if (xcd_remap) {
+    wg = (wg & 7) * ((int)gridDim.x >> 3) + (wg >> 3);
+    if (wg >= total_wgs) return;
+  }
+  const int qt = wg % q_tiles, head = (wg / q_tiles) % Hq, z = wg / (q_tiles * Hq);
   const int q0 = query_start_loc[z];
   const int q_len = query_start_loc[z + 1] - q0;
   // heaviest (latest, longest causal span) query tiles are dispatched first
-  const int t_blk = (int)(gridDim.x - 1 - blockIdx.x) * 128;
+  const int t_blk = (q_tiles - 1 - qt) * 128;
   if (t_blk >= q_len) return;                       // uniform for the workgroup
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l32 = lane & 31, h = lane >> 5;
@@ -501,9 +511,16 @@ int launch_prefill(void* out, const void* q, long q_stride, const void* kc, cons
   const int tiles = (max_q_len + 127) / 128;
   if constexpr (D == 128) {
     if (max_q_len > 32) {      // longer chunks: LDS-staged 32x32 MFMA kernel
-      hipLaunchKernelGGL((paged_prefill_lds_kernel<T>), dim3(tiles, Hq, num_seqs), dim3(256), 0, s, (T*)out,
+      static const int remap = [] {
+        const char* e = getenv("VDAMD_PREFILL_XCD_REMAP");
+        return e == nullptr ? 1 : atoi(e);
+      }();
+      const long total = (long)tiles * Hq * num_seqs;
+      if (total > (1L << 30)) return -3;
+      const int grid = remap ? (int)((total + 7) / 8 * 8) : (int)total;
+      hipLaunchKernelGGL((paged_prefill_lds_kernel<T>), dim3(grid), dim3(256), 0, s, (T*)out,
                          (const T*)q, q_stride, (const T*)kc, (const T*)vc, bt, bt_stride, qsl, seq_lens, sl2, Hq,
-                         Hkv, block_size, out_stride);
+                         Hkv, block_size, out_stride, tiles, (int)total, remap);
       HIP_LAUNCH_CHECK();
       return 0;
     }
