@@ -223,6 +223,12 @@ class CacheConfig:
     # filled in by the engine after memory profiling
     num_gpu_blocks: Optional[int] = None
 
+    def __post_init__(self) -> None:
+        # the paged cache holds K/V in the model dtype; the attention kernels read it as MFMA operands
+        if self.cache_dtype not in ("auto", "bfloat16", "float16", "bf16", "fp16", "half"):
+            raise ValueError(f"kv cache dtype {self.cache_dtype!r} is not supported: the cache is kept in the "
+                             "model's 16-bit dtype (use 'auto')")
+
 
 @dataclass
 class ParallelConfig:
