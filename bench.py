@@ -68,7 +68,7 @@ def main() -> None:
     ap.add_argument("--ttft-requests", type=int, default=5)
     ap.add_argument("--dtype", type=str, default="bfloat16")
     ap.add_argument("--enforce-eager", action="store_true")
-    ap.add_argument("--quantization", type=str, default=None, choices=[None, "fp8", "awq"],
+    ap.add_argument("--quantization", type=str, default=None, choices=[None, "fp8", "awq", "nvfp4"],
                     help="NOT the headline configuration (that is bf16): reduced-precision linears")
     ap.add_argument("--hip-graph", action="store_true",
                     help="capture the decode step in a hipGraph also for N>1 (default there: eager - at "

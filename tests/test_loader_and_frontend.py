@@ -305,3 +305,34 @@ def test_nvfp4_checkpoint_spellings_and_dense_equivalent(tmp_path):
         llm.shutdown()
         pstate.destroy_model_parallel()
     assert outs["dummy"] == outs["ct"] == outs["mo"] == outs["dense"]
+
+
+@pytest.mark.parametrize("scaling", [
+    {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+     "original_max_position_embeddings": 8192},
+    {"rope_type": "linear", "factor": 4.0},
+    {"rope_type": "yarn", "factor": 4.0, "original_max_position_embeddings": 4096},
+    {"rope_type": "yarn", "factor": 8.0, "original_max_position_embeddings": 2048, "beta_fast": 16, "beta_slow": 2,
+     "attention_factor": 1.3},
+])
+def test_rope_scaling_tables_match_transformers(scaling):
+    """cos/sin tables against the rotary initialisers that ship with the
+    installed ``transformers`` (the definition checkpoints are trained with)."""
+    from transformers import LlamaConfig
+    from transformers.modeling_rope_utils import ROPE_INIT_FUNCTIONS
+    from vllm_distributed_amd.ops import build_cos_sin_cache
+    cfg = LlamaConfig(hidden_size=1024, num_attention_heads=8, max_position_embeddings=16384, rope_theta=500000.0,
+                      rope_scaling=dict(scaling))
+    inv_freq, attn = ROPE_INIT_FUNCTIONS[scaling["rope_type"]](cfg, "cpu")
+    pos = torch.tensor([0, 1, 17, 4095, 4096, 9000, 16383])
+    want = torch.outer(pos.double(), inv_freq.double())
+    want = torch.cat([want.cos(), want.sin()], dim=-1) * attn
+    got = build_cos_sin_cache(128, 16384, 500000.0, dict(scaling))[pos]
+    # transformers keeps inv_freq in fp32: at position 16383 that alone moves the angle by ~1e-3
+    assert torch.allclose(got.double(), want, atol=3e-3), (got.double() - want).abs().max()
+
+
+def test_unknown_rope_scaling_is_rejected():
+    from vllm_distributed_amd.ops import build_cos_sin_cache
+    with pytest.raises(ValueError, match="not supported"):
+        build_cos_sin_cache(128, 64, 10000.0, {"rope_type": "longrope", "factor": 2.0})

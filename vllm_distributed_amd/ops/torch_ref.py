@@ -67,6 +67,42 @@ def build_cos_sin_cache(head_dim: int, max_pos: int, theta: float,
             inv_freq = scaled
         elif rtype == "linear":
             inv_freq = inv_freq / rope_scaling.get("factor", 1.0)
+        elif rtype == "dynamic":
+            # NTK-aware base stretch, fixed for the configured context (the table is built once)
+            factor = rope_scaling.get("factor", 1.0)
+            old = rope_scaling.get("original_max_position_embeddings") or max_pos
+            if max_pos > old:
+                base = theta * ((factor * max_pos / old) - (factor - 1)) ** (rd / (rd - 2))
+                inv_freq = 1.0 / (base ** (torch.arange(0, rd, 2, dtype=torch.float64) / rd))
+        elif rtype == "yarn":
+            # interpolate the low-frequency dims by `factor`, keep the high-frequency
+            # ones, blend linearly in between; cos/sin carry the attention temperature
+            factor = float(rope_scaling.get("factor", 1.0))
+            old = rope_scaling.get("original_max_position_embeddings") or max_pos
+            beta_fast = float(rope_scaling.get("beta_fast") or 32)
+            beta_slow = float(rope_scaling.get("beta_slow") or 1)
+
+            def corr_dim(rot: float) -> float:
+                return rd * math.log(old / (rot * 2 * math.pi)) / (2 * math.log(theta))
+            low = max(math.floor(corr_dim(beta_fast)), 0)
+            high = min(math.ceil(corr_dim(beta_slow)), rd - 1)
+            if rope_scaling.get("truncate") is False:
+                low, high = max(corr_dim(beta_fast), 0), min(corr_dim(beta_slow), rd - 1)
+            ramp = ((torch.arange(rd // 2, dtype=torch.float64) - low) / max(high - low, 1e-3)).clamp(0, 1)
+            keep = 1.0 - ramp
+            inv_freq = inv_freq / factor * (1 - keep) + inv_freq * keep
+            mscale = rope_scaling.get("attention_factor")
+            if mscale is None:
+                ms, ms_all = rope_scaling.get("mscale"), rope_scaling.get("mscale_all_dim")
+
+                def get_mscale(scale: float, m: float = 1.0) -> float:
+                    return 1.0 if scale <= 1 else 0.1 * m * math.log(scale) + 1.0
+                mscale = get_mscale(factor, ms) / get_mscale(factor, ms_all) if ms and ms_all else get_mscale(factor)
+            t = torch.arange(max_pos, dtype=torch.float64)
+            freqs = torch.outer(t, inv_freq)
+            return (torch.cat([freqs.cos(), freqs.sin()], dim=-1) * float(mscale)).float()
+        elif rtype not in (None, "default"):
+            raise ValueError(f"rope scaling type {rtype!r} is not supported")
     t = torch.arange(max_pos, dtype=torch.float64)
     freqs = torch.outer(t, inv_freq)
     return torch.cat([freqs.cos(), freqs.sin()], dim=-1).float()
