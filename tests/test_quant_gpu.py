@@ -354,3 +354,37 @@ def test_nvfp4_model_on_gpu_matches_cpu_definition(tmp_path):
         common = set(la) & set(lb)
         assert len(common) >= 8, (sorted(la), sorted(lb))
         assert max(abs(la[t] - lb[t]) for t in common) < 0.15
+
+
+@pytest.mark.parametrize("method", ["awq", "nvfp4"])
+def test_dense_shadow_serves_large_batches(method, monkeypatch):
+    """VDAMD_W4_DENSE_SHADOW keeps a dequantised copy next to the 4-bit tiles:
+    large batches use it (same numbers as dequantise-per-call), small ones keep
+    the fused kernel."""
+    from vllm_distributed_amd.models.layers.linear import QuantSpec, ReplicatedLinear, quantized_linears
+    from vllm_distributed_amd.ops import hip
+    ops.hip_available()
+    outs = {}
+    for shadow in ("0", "1"):
+        monkeypatch.setenv("VDAMD_W4_DENSE_SHADOW", shadow)
+        spec = QuantSpec("awq", 128) if method == "awq" else QuantSpec("nvfp4", 16, 1)
+        with torch.device(DEV), quantized_linears(spec):
+            lin = ReplicatedLinear(1024, 512, False, torch.bfloat16)
+        gen = torch.Generator(device=DEV).manual_seed(3)
+        for name, p in lin.named_parameters():
+            if p.dtype == torch.int32:
+                p.data.copy_(torch.randint(-(1 << 31), (1 << 31) - 1, p.shape, device=DEV, generator=gen,
+                                           dtype=torch.int64).to(torch.int32))
+            elif p.dtype == torch.uint8:
+                p.data.copy_(torch.randint(0, 256, p.shape, device=DEV, generator=gen, dtype=torch.int32).to(torch.uint8))
+            elif p.dtype == torch.float8_e4m3fn:
+                p.data.copy_((0.5 + torch.rand(p.shape, device=DEV, generator=gen)).to(p.dtype))
+            else:
+                p.data.copy_((0.002 + 0.002 * torch.rand(p.shape, device=DEV, generator=gen)).to(p.dtype))
+        lin.finalize_weights()
+        assert (lin.dense_shadow is not None) == (shadow == "1")
+        xs = torch.randn(8, 1024, device=DEV, generator=gen).to(torch.bfloat16)
+        xl = torch.randn(hip.W4_MAX_FUSED_M + 64, 1024, device=DEV, generator=gen).to(torch.bfloat16)
+        outs[shadow] = (lin(xs).float(), lin(xl).float())
+    assert torch.equal(outs["0"][0], outs["1"][0])
+    assert (outs["0"][1] - outs["1"][1]).abs().max() <= 1e-6 * outs["0"][1].abs().max() + 1e-6

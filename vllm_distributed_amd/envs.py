@@ -99,6 +99,9 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     # dequantise + library GEMM); kernel variant override (0/1) for experiments.
     "VDAMD_W4_MAX_FUSED_M": _int("VDAMD_W4_MAX_FUSED_M", 256),
     "VDAMD_W4_VARIANT": _str("VDAMD_W4_VARIANT", None),
+    # 4-bit layers also keep a dequantised copy for batches above the fused
+    # kernels' range (4.5x the weight memory; no per-call dequantisation).
+    "VDAMD_W4_DENSE_SHADOW": _bool("VDAMD_W4_DENSE_SHADOW", False),
     # Capture decode steps in hipGraphs.
     "VDAMD_USE_HIP_GRAPH": _bool("VDAMD_USE_HIP_GRAPH", True),
     # Assert identical collective sequence numbers on all ranks (debug).

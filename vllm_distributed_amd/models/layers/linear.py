@@ -143,6 +143,7 @@ class _LinearBase(nn.Module):
         self.register_buffer("sz", None)
         self.register_buffer("weight_scale", None)
         self.register_buffer("alpha", None)
+        self.register_buffer("dense_shadow", None)
         self.lora = None          # adapter slots, attached by lora.LoRAManager
         if spec is not None and spec.method == "nvfp4":
             assert in_local % 16 == 0, f"NVFP4 shard [{out_local} x {in_local}] splits a 16-column block"
@@ -188,6 +189,7 @@ class _LinearBase(nn.Module):
                 self.qw, self.sz = quant.pack_fp4(packed, bs)
                 self.alpha = alpha.contiguous()
                 ops.w4_reserve_scratch(self.in_local * self.out_local, self.qw.device, self.dtype)
+                self._make_shadow()
             else:
                 self.quant = None
                 self.weight = nn.Parameter(nvfp4_dequantize(packed, bs, alpha, self.dtype), requires_grad=False)
@@ -198,6 +200,7 @@ class _LinearBase(nn.Module):
             qw, sz = awq_to_native(qweight, qzeros, scales, self.dtype)
             self.qw, self.sz = qw, sz
             ops.w4_reserve_scratch(qw.shape[0] * 16 * qw.shape[1] * 128, qw.device, self.dtype)
+            self._make_shadow()
         else:      # shapes the 4-bit kernel does not tile: dense fallback
             from ..loader import awq_dequantize
             self.quant = None
@@ -209,11 +212,26 @@ class _LinearBase(nn.Module):
             y = self.lora.apply(x, y)
         return y
 
+    def _make_shadow(self) -> None:
+        """With ``VDAMD_W4_DENSE_SHADOW=1`` a 4-bit layer also keeps its weights
+        dequantised: batches above the fused kernels' range then run the
+        library GEMM on the resident copy instead of dequantising on every
+        call.  4.5x the weight memory, which 288 GB of HBM can afford for
+        models up to ~70B parameters."""
+        from ... import envs
+        if not envs.VDAMD_W4_DENSE_SHADOW or self.qw is None or not self.qw.is_cuda or not ops.hip_available():
+            return
+        from ...ops import hip
+        if self.alpha is not None:
+            self.dense_shadow = hip.fp4_dequant(self.qw, self.sz, self.alpha, self.dtype)
+        else:
+            self.dense_shadow = hip.w4_dequant(self.qw, self.sz)
+
     def _base_matmul(self, x: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
         if self.qw is not None:
             if self.alpha is not None:
-                return ops.fp4_linear(x, self.qw, self.sz, self.alpha, bias)
-            return ops.w4a16_linear(x, self.qw, self.sz, bias)
+                return ops.fp4_linear(x, self.qw, self.sz, self.alpha, bias, self.dense_shadow)
+            return ops.w4a16_linear(x, self.qw, self.sz, bias, self.dense_shadow)
         if self.weight_scale is not None:
             return ops.fp8_linear(x, self.weight, self.weight_scale, bias)
         return ops.linear(x, self.weight, bias)

@@ -206,11 +206,13 @@ def w4_reserve_scratch(numel: int, device, dtype) -> None:
         _w4_scratch[key] = torch.empty(numel, dtype=dtype, device=device)
 
 
-def w4a16_linear(x, qw, sz, bias=None):
+def w4a16_linear(x, qw, sz, bias=None, dense=None):
     """``y = x . dequant(qw, sz)^T (+ bias)`` for weights packed by
     ``ops.quant.pack_w4``.  Small batches run the fused 4-bit MFMA kernel (the
     weights cross HBM once, as 4-bit); large batches dequantise into a shared
-    scratch matrix and use the library GEMM, which is compute-bound there."""
+    scratch matrix and use the library GEMM, which is compute-bound there
+    (``dense``: a resident dequantised copy to use instead, see
+    ``VDAMD_W4_DENSE_SHADOW``)."""
     from . import quant
     shape = x.shape
     x2 = x.reshape(-1, shape[-1])
@@ -219,6 +221,8 @@ def w4a16_linear(x, qw, sz, bias=None):
             if x2.stride(1) != 1 or x2.stride(0) % 8 or x2.data_ptr() % 16:
                 x2 = x2.contiguous()
             y = _hip.w4a16_gemm(x2, qw, sz)
+        elif dense is not None:
+            y = torch.nn.functional.linear(x2, dense)
         else:
             n, k = qw.shape[0] * 16, qw.shape[1] * 128
             key = _scratch_key(x2.device, sz.dtype)
@@ -233,7 +237,7 @@ def w4a16_linear(x, qw, sz, bias=None):
     return y.view(shape[:-1] + (y.shape[-1],))
 
 
-def fp4_linear(x, qw, fs, alpha=None, bias=None):
+def fp4_linear(x, qw, fs, alpha=None, bias=None, dense=None):
     """``y = x . dequant(qw, fs, alpha)^T (+ bias)`` for NVFP4 weights packed by
     ``ops.quant.pack_fp4`` (weight-only: activations stay bf16/fp16).  Same
     split as ``w4a16_linear``: fused 4-bit kernel for small batches, dequantise
@@ -246,6 +250,8 @@ def fp4_linear(x, qw, fs, alpha=None, bias=None):
             if x2.stride(1) != 1 or x2.stride(0) % 8 or x2.data_ptr() % 16:
                 x2 = x2.contiguous()
             y = _hip.fp4a16_gemm(x2, qw, fs, alpha)
+        elif dense is not None:
+            y = torch.nn.functional.linear(x2, dense)
         else:
             n, k = qw.shape[0] * 16, qw.shape[1] * 128
             key = _scratch_key(x2.device, x2.dtype)
