@@ -109,6 +109,14 @@ def test_server_endpoints_end_to_end(frontend_mp):
                           if l.startswith("data: ") and l != "data: [DONE]"]
                 assert chunks[0]["choices"][0]["delta"]["role"] == "assistant"
                 assert chunks[-1]["choices"][0]["finish_reason"] == "length"
+                r5 = await c.post("/v1/chat/completions", headers=hdr, json={
+                    "messages": [{"role": "user", "content": "hi"}], "max_tokens": 4, "stream": True, "seed": 3,
+                    "n": 3, "ignore_eos": True, "stream_options": {"include_usage": True}})
+                ev = [json.loads(l[6:]) for l in r5.text.split("\n\n") if l.startswith("data: ") and l != "data: [DONE]"]
+                per = {k: [e for e in ev if e["choices"] and e["choices"][0]["index"] == k] for k in range(3)}
+                assert all(per[k][0]["choices"][0]["delta"].get("role") == "assistant" for k in range(3))
+                assert all(per[k][-1]["choices"][0]["finish_reason"] == "length" for k in range(3))
+                assert ev[-1]["usage"]["completion_tokens"] == 12
                 assert (await c.post("/v1/completions", headers=hdr,
                                      json={"model": "other", "prompt": "x"})).status_code == 404
                 t = (await c.post("/tokenize", json={"prompt": "abc"})).json()

@@ -505,8 +505,6 @@ def _register_routes(app: FastAPI) -> None:
         if err:
             return err
         n = max(1, int(req.n or 1))
-        if n != 1 and req.stream:
-            return _error("n > 1 is not supported with stream=true on this endpoint")
         tok = engine.tokenizer
         messages = _messages_to_dicts(req.messages)
         tools = req.tools if req.tool_choice != "none" else None
@@ -549,49 +547,84 @@ def _register_routes(app: FastAPI) -> None:
             return {"content": items}
 
         if req.stream:
-            async def stream() -> AsyncIterator[str]:
-                def chunk(delta: dict, finish=None, lp=None) -> str:
-                    return _sse({"id": rid, "object": "chat.completion.chunk", "created": created,
-                                 "model": model, "choices": [{"index": 0, "delta": delta, "logprobs": lp,
-                                                              "finish_reason": finish}]})
-                yield chunk({"role": "assistant", "content": ""})
+            def chunk(index: int, delta: dict, finish=None, lp=None) -> str:
+                return _sse({"id": rid, "object": "chat.completion.chunk", "created": created,
+                             "model": model, "choices": [{"index": index, "delta": delta, "logprobs": lp,
+                                                          "finish_reason": finish}]})
+
+            async def choice_events(index: int, g, counts: List[int]) -> AsyncIterator[str]:
+                """SSE events of one sample; ``counts[index]`` ends up holding its token count."""
+                yield chunk(index, {"role": "assistant", "content": ""})
                 sent = 0
                 final = None
                 held = ""
-                try:
-                    seen = 0
-                    async for out in gen:
-                        seen += 1
-                        if seen % 16 == 0 and await request.is_disconnected():
-                            return
-                        final = out
-                        text = out.new_text
-                        if parser is not None:
-                            # tool-call syntax must be parsed as a whole: hold text once a call starts
-                            held += text
-                            if "<tool_call>" in held or held.lstrip().startswith(("{", "<|python_tag|>")):
-                                text = ""
-                            else:
-                                text, held = held, ""
-                        if text or (parser is None and len(out.outputs[0].token_ids) > sent):
-                            yield chunk({"content": text}, lp=lp_content(out, sent))
-                            sent = len(out.outputs[0].token_ids)
-                    c = final.outputs[0]
-                    finish = c.finish_reason
-                    if parser is not None and held:
-                        content, calls = parser.extract(held, tools)
-                        if calls:
-                            if content:
-                                yield chunk({"content": content})
-                            yield chunk({"tool_calls": [dict(tc, index=i) for i, tc in enumerate(calls)]})
-                            finish = "tool_calls"
+                seen = 0
+                async for out in g:
+                    seen += 1
+                    if seen % 16 == 0 and await request.is_disconnected():
+                        return
+                    final = out
+                    text = out.new_text
+                    if parser is not None:
+                        # tool-call syntax must be parsed as a whole: hold text once a call starts
+                        held += text
+                        if "<tool_call>" in held or held.lstrip().startswith(("{", "<|python_tag|>")):
+                            text = ""
                         else:
-                            yield chunk({"content": held})
-                    yield chunk({}, finish=finish)
+                            text, held = held, ""
+                    if text or (parser is None and len(out.outputs[0].token_ids) > sent):
+                        yield chunk(index, {"content": text}, lp=lp_content(out, sent))
+                        sent = len(out.outputs[0].token_ids)
+                c = final.outputs[0]
+                counts[index] = len(c.token_ids)
+                finish = c.finish_reason
+                if parser is not None and held:
+                    content, calls = parser.extract(held, tools)
+                    if calls:
+                        if content:
+                            yield chunk(index, {"content": content})
+                        yield chunk(index, {"tool_calls": [dict(tc, index=i) for i, tc in enumerate(calls)]})
+                        finish = "tool_calls"
+                    else:
+                        yield chunk(index, {"content": held})
+                yield chunk(index, {}, finish=finish)
+
+            async def stream() -> AsyncIterator[str]:
+                counts = [0] * n
+                try:
+                    if n == 1:
+                        async for ev in choice_events(0, gens[0], counts):
+                            yield ev
+                    else:
+                        # the n samples advance together: interleave their events as they arrive
+                        queue: asyncio.Queue = asyncio.Queue()
+
+                        async def pump(index: int, g) -> None:
+                            try:
+                                async for ev in choice_events(index, g, counts):
+                                    await queue.put(ev)
+                            except Exception as e:  # noqa: BLE001
+                                await queue.put(e)
+                            finally:
+                                await queue.put(None)
+                        tasks = [asyncio.ensure_future(pump(k, g)) for k, g in enumerate(gens)]
+                        try:
+                            live = n
+                            while live:
+                                ev = await queue.get()
+                                if ev is None:
+                                    live -= 1
+                                elif isinstance(ev, Exception):
+                                    raise ev
+                                else:
+                                    yield ev
+                        finally:
+                            for t in tasks:
+                                t.cancel()
                     if req.stream_options and req.stream_options.include_usage:
                         yield _sse({"id": rid, "object": "chat.completion.chunk", "created": created,
                                     "model": model, "choices": [],
-                                    "usage": _usage(len(prompt_ids), len(c.token_ids))})
+                                    "usage": _usage(len(prompt_ids), sum(counts))})
                 except Exception as e:  # noqa: BLE001
                     yield _sse({"error": {"message": str(e), "type": type(e).__name__}})
                 yield _sse("[DONE]")
