@@ -102,6 +102,9 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     # 4-bit layers also keep a dequantised copy for batches above the fused
     # kernels' range (4.5x the weight memory; no per-call dequantisation).
     "VDAMD_W4_DENSE_SHADOW": _bool("VDAMD_W4_DENSE_SHADOW", False),
+    # Time the library's candidate kernels for every decode GEMM shape at warm-up.
+    "VDAMD_TUNE_GEMM": _bool("VDAMD_TUNE_GEMM", False),
+    "VDAMD_TUNE_GEMM_FILE": _str("VDAMD_TUNE_GEMM_FILE", os.path.expanduser("~/.cache/vllm_distributed_amd/gemm_tuning.csv")),
     # Capture decode steps in hipGraphs.
     "VDAMD_USE_HIP_GRAPH": _bool("VDAMD_USE_HIP_GRAPH", True),
     # Assert identical collective sequence numbers on all ranks (debug).
