@@ -254,7 +254,10 @@ constexpr int W4_XPAD = 128;
 // then always belong to the same set.
 __device__ __forceinline__ int w4_swz(int r) { return (r & 10) | ((r & 1) << 2) | ((r >> 2) & 1); }
 
-template <typename T, int MT, int FMT>
+// NTW: output tiles per wave.  Up to 64 rows a wave keeps 4 tiles x MT <= 4 row
+// tiles; above that it keeps 2 tiles x MT <= 8, so every decoded 4-bit tile feeds
+// twice as many MFMAs (the decode, not HBM, bounds these kernels at that size).
+template <typename T, int MT, int FMT, int NTW>
 __global__ __launch_bounds__(256) void w4a16_gemm_lds_kernel(
     const T* __restrict__ x, long x_stride, const uint32_t* __restrict__ qw, const T* __restrict__ sz,
     T* __restrict__ out, long out_stride, float* __restrict__ partial, int M, int N, int K,
@@ -279,31 +282,31 @@ __global__ __launch_bounds__(256) void w4a16_gemm_lds_kernel(
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int KB = K >> 7, ntiles = N >> 4, NG = KB / kb_per_group;
-  const int nt0 = (blockIdx.x * W4_WAVES + wid) * W4_NTW;
+  const int nt0 = (blockIdx.x * W4_WAVES + wid) * NTW;
   const int ks = blockIdx.y;
   const int kb_lo = (int)((long)KB * ks / ksplit), kb_hi = (int)((long)KB * (ks + 1) / ksplit);
 
-  int ntc[W4_NTW];
+  int ntc[NTW];
 #pragma unroll
-  for (int t = 0; t < W4_NTW; ++t) ntc[t] = min(nt0 + t, ntiles - 1);
+  for (int t = 0; t < NTW; ++t) ntc[t] = min(nt0 + t, ntiles - 1);
   // cooperative copy of x: thread -> (row xr of a 16-row pass, 16-byte column xc)
   const int xr = threadIdx.x >> 4, xc = threadIdx.x & 15;
   const T* xsrc[MT];
 #pragma unroll
   for (int p = 0; p < MT; ++p) xsrc[p] = x + (long)min(m0 + 16 * p + xr, M - 1) * x_stride + 8 * xc;
 
-  f32x4 acc[W4_NTW][MT];
+  f32x4 acc[NTW][MT];
 #pragma unroll
-  for (int t = 0; t < W4_NTW; ++t)
+  for (int t = 0; t < NTW; ++t)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
   V8 ones;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones[j] = (T)1.0f;
 
-  auto load_w = [&](int kb, u32x4 (&w)[W4_NTW], V8 (&s)[W4_NTW], uint32_t (&f)[W4_NTW]) {
+  auto load_w = [&](int kb, u32x4 (&w)[NTW], V8 (&s)[NTW], uint32_t (&f)[NTW]) {
 #pragma unroll
-    for (int t = 0; t < W4_NTW; ++t) {
+    for (int t = 0; t < NTW; ++t) {
       w[t] = *reinterpret_cast<const u32x4*>(qw + (((size_t)ntc[t] * KB + kb) << 8) + lane * 4);
       if (FMT == W4_INT)
         s[t] = ld8(sz + ((((size_t)ntc[t] * NG + kb / kb_per_group) * 16 + 4 * g) << 1));
@@ -311,9 +314,9 @@ __global__ __launch_bounds__(256) void w4a16_gemm_lds_kernel(
         f[t] = reinterpret_cast<const uint32_t*>(sz)[(((size_t)ntc[t] * KB + kb) << 6) + lane];
     }
   };
-  u32x4 wc[W4_NTW], wn[W4_NTW];
-  V8 sc[W4_NTW], sn[W4_NTW];
-  uint32_t fc[W4_NTW], fn[W4_NTW];
+  u32x4 wc[NTW], wn[NTW];
+  V8 sc[NTW], sn[NTW];
+  uint32_t fc[NTW], fn[NTW];
   V8 xreg[MT];
   if (kb_lo < kb_hi) {
     load_w(kb_lo, wc, sc, fc);
@@ -329,57 +332,103 @@ __global__ __launch_bounds__(256) void w4a16_gemm_lds_kernel(
 #pragma unroll
       for (int p = 0; p < MT; ++p) xreg[p] = ld8(xsrc[p] + ((kb + 1) << 7));
     }
-    V8 bx[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) bx[mt][s] = ld8(&xl[buf][16 * mt + c][8 * ((4 * g + s) ^ w4_swz(c))]);
-    f32x4 xs[MT];
-    if (FMT == W4_INT) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        xs[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) xs[mt] = mfma16(ones, bx[mt][s], xs[mt]);
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < W4_NTW; ++t) {
-      if (FMT == W4_FP4) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const V8 a = fp4_unpack<T>(wc[t][s], fp4_scale(fc[t], s >> 1));
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[t][mt] = mfma16(a, bx[mt][s], acc[t][mt]);
+    if constexpr (MT <= 4) {
+      V8 bx[MT][4];
+  #pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+  #pragma unroll
+        for (int s = 0; s < 4; ++s) bx[mt][s] = ld8(&xl[buf][16 * mt + c][8 * ((4 * g + s) ^ w4_swz(c))]);
+      f32x4 xs[MT];
+      if (FMT == W4_INT) {
+  #pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          xs[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+          for (int s = 0; s < 4; ++s) xs[mt] = mfma16(ones, bx[mt][s], xs[mt]);
         }
-        continue;
       }
-      f32x4 p[MT];
+  #pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        if (FMT == W4_FP4) {
+  #pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const V8 a = fp4_unpack<T>(wc[t][s], fp4_scale(fc[t], s >> 1));
+  #pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[t][mt] = mfma16(a, bx[mt][s], acc[t][mt]);
+          }
+          continue;
+        }
+        f32x4 p[MT];
+  #pragma unroll
+        for (int mt = 0; mt < MT; ++mt) p[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const V8 a = w4_unpack<T>(wc[t][s]);
+  #pragma unroll
+          for (int mt = 0; mt < MT; ++mt) p[mt] = mfma16(a, bx[mt][s], p[mt]);
+        }
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float s_r = (float)sc[t][2 * r], z_r = (float)sc[t][2 * r + 1];
+  #pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[t][mt][r] += s_r * (p[mt][r] - z_r * xs[mt][r]);
+        }
+      }
+    } else {
+      // many row tiles: walk the four 32-column MFMA steps outermost so only one
+      // step's x fragments are live
+      f32x4 xs[MT], p[NTW][MT];
+      if (FMT == W4_INT) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) p[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MT; ++mt) {
+          xs[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) p[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const V8 a = w4_unpack<T>(wc[t][s]);
+        V8 bxs[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) p[mt] = mfma16(a, bx[mt][s], p[mt]);
+        for (int mt = 0; mt < MT; ++mt) bxs[mt] = ld8(&xl[buf][16 * mt + c][8 * ((4 * g + s) ^ w4_swz(c))]);
+        if (FMT == W4_INT) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) xs[mt] = mfma16(ones, bxs[mt], xs[mt]);
+        }
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+          if (FMT == W4_FP4) {
+            const V8 a = fp4_unpack<T>(wc[t][s], fp4_scale(fc[t], s >> 1));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[t][mt] = mfma16(a, bxs[mt], acc[t][mt]);
+          } else {
+            const V8 a = w4_unpack<T>(wc[t][s]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) p[t][mt] = mfma16(a, bxs[mt], p[t][mt]);
+          }
+        }
       }
+      if (FMT == W4_INT) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float s_r = (float)sc[t][2 * r], z_r = (float)sc[t][2 * r + 1];
+        for (int t = 0; t < NTW; ++t)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[t][mt][r] += s_r * (p[mt][r] - z_r * xs[mt][r]);
+          for (int r = 0; r < 4; ++r) {
+            const float s_r = (float)sc[t][2 * r], z_r = (float)sc[t][2 * r + 1];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[t][mt][r] += s_r * (p[t][mt][r] - z_r * xs[mt][r]);
+          }
       }
     }
     if (more) {
 #pragma unroll
-      for (int t = 0; t < W4_NTW; ++t) { wc[t] = wn[t]; sc[t] = sn[t]; fc[t] = fn[t]; }
+      for (int t = 0; t < NTW; ++t) { wc[t] = wn[t]; sc[t] = sn[t]; fc[t] = fn[t]; }
 #pragma unroll
       for (int p = 0; p < MT; ++p) st8(&xl[buf ^ 1][16 * p + xr][8 * (xc ^ w4_swz(xr))], xreg[p]);
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int t = 0; t < W4_NTW; ++t) {
+  for (int t = 0; t < NTW; ++t) {
     if (nt0 + t >= ntiles) continue;
     const int n = 16 * (nt0 + t) + 4 * g;
     if (FMT == W4_FP4 && alpha != nullptr) {
@@ -445,26 +494,44 @@ template <typename T, int FMT>
 static int launch_w4a16(void* out, long out_stride, const void* x, long x_stride, const void* qw,
                         const void* sz, const float* alpha, void* partial, int M, int N, int K, int G,
                         int ksplit, int variant, hipStream_t st) {
-  const int mt = min(4, (M + 15) / 16);
-  const int tiles_per_wg = variant == 1 ? W4_NTW * W4_WAVES : W4_NTW;
+  // variant 1 above 64 rows: chunks of <= 128 rows, 2 output tiles per wave
+  const bool wide = variant == 1 && M > 64;
+  const int chunks = wide ? (M + 127) / 128 : (M + 63) / 64;
+  const int mt = wide ? ((M + chunks - 1) / chunks + 15) / 16 : min(4, (M + 15) / 16);
+  const int ntw = wide ? 2 : W4_NTW;
+  const int tiles_per_wg = variant == 1 ? ntw * W4_WAVES : W4_NTW;
   dim3 grid((N / 16 + tiles_per_wg - 1) / tiles_per_wg, ksplit, (M + 16 * mt - 1) / (16 * mt));
+#define W4_LDS(MT_, NTW_)                                                                                    \
+  w4a16_gemm_lds_kernel<T, MT_, FMT, NTW_><<<grid, 256, 0, st>>>((const T*)x, x_stride, (const uint32_t*)qw, \
+                                                               (const T*)sz, (T*)out, out_stride,           \
+                                                               (float*)partial, M, N, K, G / 128, ksplit,   \
+                                                               nullptr, 0, 0, alpha)
 #define W4_LAUNCH(MT_)                                                                                      \
   if (variant == 1)                                                                                         \
-    w4a16_gemm_lds_kernel<T, MT_, FMT><<<grid, 256, 0, st>>>((const T*)x, x_stride, (const uint32_t*)qw,   \
-                                                          (const T*)sz, (T*)out, out_stride,                \
-                                                          (float*)partial, M, N, K, G / 128, ksplit,        \
-                                                          nullptr, 0, 0, alpha);                            \
+    W4_LDS(MT_, W4_NTW);                                                                                    \
   else                                                                                                      \
     w4a16_gemm_kernel<T, MT_, FMT><<<grid, 256, 0, st>>>((const T*)x, x_stride, (const uint32_t*)qw,       \
                                                       (const T*)sz, (T*)out, out_stride, (float*)partial,  \
                                                       M, N, K, G / 128, ksplit, alpha)
-  switch (mt) {
-    case 1: W4_LAUNCH(1); break;
-    case 2: W4_LAUNCH(2); break;
-    case 3: W4_LAUNCH(3); break;
-    default: W4_LAUNCH(4); break;
+  if (wide) {
+    switch (mt) {
+      case 3: W4_LDS(3, 2); break;      // 65..96 rows in two chunks cannot happen; kept for completeness
+      case 4: W4_LDS(4, 2); break;
+      case 5: W4_LDS(5, 2); break;
+      case 6: W4_LDS(6, 2); break;
+      case 7: W4_LDS(7, 2); break;
+      default: W4_LDS(8, 2); break;
+    }
+  } else {
+    switch (mt) {
+      case 1: W4_LAUNCH(1); break;
+      case 2: W4_LAUNCH(2); break;
+      case 3: W4_LAUNCH(3); break;
+      default: W4_LAUNCH(4); break;
+    }
   }
 #undef W4_LAUNCH
+#undef W4_LDS
   HIP_LAUNCH_CHECK();
   if (ksplit > 1) {
     const long n = (long)M * (N / 4);
@@ -559,7 +626,7 @@ static int launch_w4_grouped(void* out, long os, const void* x, long xs, const v
                              int K, int G, hipStream_t st) {
   dim3 grid((N / 16 + W4_NTW * W4_WAVES - 1) / (W4_NTW * W4_WAVES), 1, num_tiles);
 #define W4G(MT_)                                                                                                \
-  w4a16_gemm_lds_kernel<T, MT_, FMT><<<grid, 256, 0, st>>>((const T*)x, xs, (const uint32_t*)qw, (const T*)sz,     \
+  w4a16_gemm_lds_kernel<T, MT_, FMT, W4_NTW><<<grid, 256, 0, st>>>((const T*)x, xs, (const uint32_t*)qw, (const T*)sz, \
                                                           (T*)out, os, nullptr, tile_rows, N, K, G / 128, 1,   \
                                                           tiles, qgs, sgs, alpha)
   switch (tile_rows / 16) {

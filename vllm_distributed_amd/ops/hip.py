@@ -336,13 +336,17 @@ def w4_choose_variant(m: int, n: int, k: int) -> int:
 
 def w4_choose_ksplit(m: int, n: int, k: int, variant: int = 0) -> int:
     """Split K until ~3 workgroups per CU exist (variant 0: 64 rows per
-    workgroup, at least two 128-column blocks per wave; variant 1: 256 rows
-    per workgroup, at least four blocks per workgroup)."""
+    workgroup, at least two 128-column blocks per wave; variant 1: 256 output
+    rows per workgroup up to 64 batch rows, 128 above (row chunks of <= 128),
+    at least four blocks per workgroup)."""
+    if variant == 1:
+        if m > 64:
+            base = ((n // 16 + 7) // 8) * ((m + 127) // 128)
+        else:
+            base = (n // 16 + 15) // 16
+        return max(1, min((512 + base - 1) // base, (k // 128) // 4))
     mt = min(4, (m + 15) // 16)
     mz = (m + 16 * mt - 1) // (16 * mt)
-    if variant == 1:
-        base = ((n // 16 + 15) // 16) * mz
-        return max(1, min((512 + base - 1) // base, (k // 128) // 4))
     base = ((n // 16 + 3) // 4) * mz
     return max(1, min((768 + base - 1) // base, (k // 128) // 8))
 
