@@ -1,0 +1,219 @@
+// Mixture-of-experts routing in three kernels instead of ~30 framework ops:
+//
+//   moe_topk      router logits -> softmax -> top-k (weights renormalised on request)
+//   moe_align     counting sort of the T*k (token, expert) slots by expert and the
+//                 row-tile table the grouped GEMMs consume (csrc/skinny_gemm.hip,
+//                 csrc/quant_gemm.hip: tiles[n][3] = group, first row, rows)
+//   moe_combine   out[t] = sum_j w[t][j] * y[position of slot (t, j)]
+//
+// A decode step of a sparse model spends most of its time between GEMMs at small
+// batch (each framework op is a 5-8 us launch); with these the expert block of a
+// layer is eight launches: router GEMM, topk, align, row gather, two grouped
+// GEMMs, SiLU, combine.  Nothing here synchronises with the host, so the step
+// stays hipGraph-capturable.
+#include "common.h"
+
+namespace {
+
+constexpr int TOPK_MAX_VPL = 8;       // experts per lane: up to 512 experts
+constexpr int TOPK_MAX_K = 16;
+constexpr int ALIGN_MAX_E = 1024;
+constexpr int ALIGN_THREADS = 1024;
+
+template <typename T> __device__ __forceinline__ float to_f(T v) { return (float)v; }
+
+// one wave per token
+template <typename T>
+__global__ __launch_bounds__(256) void moe_topk_kernel(const T* __restrict__ logits, long stride,
+                                                       float* __restrict__ topw, int* __restrict__ topi, int tokens,
+                                                       int E, int k, int renorm) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int t = blockIdx.x * 4 + wid;
+  if (t >= tokens) return;
+  const T* row = logits + (long)t * stride;
+  float v[TOPK_MAX_VPL];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < TOPK_MAX_VPL; ++i) {
+    const int e = lane + 64 * i;
+    v[i] = e < E ? to_f(row[e]) : -INFINITY;
+    mx = fmaxf(mx, v[i]);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < TOPK_MAX_VPL; ++i) {
+    v[i] = (lane + 64 * i) < E ? __expf(v[i] - mx) : -1.f;      // probabilities are >= 0: -1 marks "taken / absent"
+    sum += fmaxf(v[i], 0.f);
+  }
+  sum = wave_sum(sum);
+  const float inv_sum = 1.f / sum;
+  float picked_w = 0.f;       // lane j keeps the j-th pick
+  int picked_i = 0;
+  float wsum = 0.f;
+  for (int j = 0; j < k; ++j) {
+    float best = -1.f;
+    int best_e = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < TOPK_MAX_VPL; ++i)
+      if (v[i] > best) { best = v[i]; best_e = lane + 64 * i; }      // ascending e within a lane: first maximum wins
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oe = __shfl_xor(best_e, o, 64);
+      if (ob > best || (ob == best && oe < best_e)) { best = ob; best_e = oe; }
+    }
+    // every lane now agrees on (best, best_e); ties went to the lowest expert id
+    if ((best_e & 63) == lane) {
+#pragma unroll
+      for (int i = 0; i < TOPK_MAX_VPL; ++i)
+        if (i == (best_e >> 6)) v[i] = -1.f;
+    }
+    if (lane == j) { picked_w = best * inv_sum; picked_i = best_e; }
+    wsum += best * inv_sum;
+  }
+  if (lane < k) {
+    topw[(long)t * k + lane] = renorm ? picked_w / wsum : picked_w;
+    topi[(long)t * k + lane] = picked_i;
+  }
+}
+
+// single workgroup; slots = tokens * k
+__global__ __launch_bounds__(ALIGN_THREADS) void moe_align_kernel(
+    const int* __restrict__ topi, int slots, int k, int E, int tile_rows, int expert_start, int local_experts,
+    int* __restrict__ src_row, int* __restrict__ inv, int* __restrict__ tiles, int max_tiles) {
+  __shared__ int counts[ALIGN_MAX_E], cursor[ALIGN_MAX_E], row0[ALIGN_MAX_E], tile0[ALIGN_MAX_E];
+  __shared__ int total_tiles;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < E; e += ALIGN_THREADS) { counts[e] = 0; cursor[e] = 0; }
+  __syncthreads();
+  for (int s = tid; s < slots; s += ALIGN_THREADS) atomicAdd(&counts[topi[s]], 1);
+  __syncthreads();
+  if (tid < 64) {
+    // exclusive scans of rows and of tiles per expert, one wave, 64 experts a round
+    int rbase = 0, tbase = 0;
+    for (int e0 = 0; e0 < E; e0 += 64) {
+      const int e = e0 + tid;
+      const int c = e < E ? counts[e] : 0;
+      const int tl = (c + tile_rows - 1) / tile_rows;
+      int rs = c, ts = tl;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int r2 = __shfl_up(rs, o, 64), t2 = __shfl_up(ts, o, 64);
+        if (tid >= o) { rs += r2; ts += t2; }
+      }
+      if (e < E) { row0[e] = rbase + rs - c; tile0[e] = tbase + ts - tl; }
+      rbase += __shfl(rs, 63, 64);
+      tbase += __shfl(ts, 63, 64);
+    }
+    if (tid == 0) total_tiles = tbase;
+  }
+  __syncthreads();
+  for (int s = tid; s < slots; s += ALIGN_THREADS) {
+    const int e = topi[s];
+    const int pos = row0[e] + atomicAdd(&cursor[e], 1);
+    inv[s] = pos;
+    src_row[pos] = s / k;
+  }
+  for (int e = tid; e < E; e += ALIGN_THREADS) {
+    const int c = counts[e];
+    const bool local = local_experts < 0 || (e >= expert_start && e < expert_start + local_experts);
+    const int le = local_experts < 0 ? e : min(max(e - expert_start, 0), max(local_experts - 1, 0));
+    int j = tile0[e];
+    for (int r = 0; r < c; r += tile_rows, ++j) {
+      if (j >= max_tiles) break;
+      tiles[3 * j + 0] = le;
+      tiles[3 * j + 1] = row0[e] + r;
+      tiles[3 * j + 2] = local ? min(tile_rows, c - r) : 0;
+    }
+  }
+  for (int j = total_tiles + tid; j < max_tiles; j += ALIGN_THREADS) {
+    tiles[3 * j + 0] = 0;
+    tiles[3 * j + 1] = 0;
+    tiles[3 * j + 2] = 0;
+  }
+}
+
+// one workgroup per token; y rows are in expert-sorted order
+template <typename T>
+__global__ __launch_bounds__(256) void moe_combine_kernel(T* __restrict__ out, long out_stride,
+                                                          const T* __restrict__ y, long y_stride,
+                                                          const float* __restrict__ topw, const int* __restrict__ topi,
+                                                          const int* __restrict__ inv, int k, int H, int expert_start,
+                                                          int local_experts) {
+  using V = typename Vec8<T>::type;
+  const int t = blockIdx.x;
+  __shared__ float w[TOPK_MAX_K];
+  __shared__ int pos[TOPK_MAX_K];
+  if (threadIdx.x < k) {
+    const int e = topi[(long)t * k + threadIdx.x];
+    const bool local = local_experts < 0 || (e >= expert_start && e < expert_start + local_experts);
+    w[threadIdx.x] = local ? topw[(long)t * k + threadIdx.x] : 0.f;
+    pos[threadIdx.x] = local ? inv[(long)t * k + threadIdx.x] : -1;
+  }
+  __syncthreads();
+  for (int h = threadIdx.x * 8; h < H; h += 256 * 8) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < k; ++j) {
+      if (pos[j] < 0) continue;          // an expert another rank holds: its row was never computed here
+      const V v = ld8<T>(y + (long)pos[j] * y_stride + h);
+      const float wj = w[j];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += wj * (float)v[i];
+    }
+    V o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (T)acc[i];
+    st8<T>(out + (long)t * out_stride + h, o);
+  }
+}
+
+}  // namespace
+
+VDAMD_API int vdamd_moe_topk(const void* logits, long stride, float* topw, int* topi, int tokens, int E, int k,
+                             int renorm, int dtype, hipStream_t s) {
+  if (tokens <= 0) return 0;
+  if (E < k || E > 64 * TOPK_MAX_VPL || k < 1 || k > TOPK_MAX_K) return -1;
+  const unsigned blocks = (unsigned)((tokens + 3) / 4);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL((moe_topk_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)logits, stride, topw,
+                       topi, tokens, E, k, renorm);
+  else if (dtype == DT_F16)
+    hipLaunchKernelGGL((moe_topk_kernel<f16_t>), dim3(blocks), dim3(256), 0, s, (const f16_t*)logits, stride, topw,
+                       topi, tokens, E, k, renorm);
+  else if (dtype == DT_F32)
+    hipLaunchKernelGGL((moe_topk_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)logits, stride, topw,
+                       topi, tokens, E, k, renorm);
+  else
+    return -2;
+  HIP_LAUNCH_CHECK();
+  return 0;
+}
+
+// tiles must hold max_tiles >= slots / tile_rows + E entries of 3 ints
+VDAMD_API int vdamd_moe_align(const int* topi, int slots, int k, int E, int tile_rows, int expert_start,
+                              int local_experts, int* src_row, int* inv, int* tiles, int max_tiles, hipStream_t s) {
+  if (slots <= 0) return 0;
+  if (E < 1 || E > ALIGN_MAX_E || tile_rows < 1 || k < 1 || max_tiles < slots / tile_rows + E) return -1;
+  hipLaunchKernelGGL(moe_align_kernel, dim3(1), dim3(ALIGN_THREADS), 0, s, topi, slots, k, E, tile_rows, expert_start,
+                     local_experts, src_row, inv, tiles, max_tiles);
+  HIP_LAUNCH_CHECK();
+  return 0;
+}
+
+VDAMD_API int vdamd_moe_combine(void* out, long out_stride, const void* y, long y_stride, const float* topw,
+                                const int* topi, const int* inv, int tokens, int k, int H, int expert_start,
+                                int local_experts, int dtype, hipStream_t s) {
+  if (tokens <= 0) return 0;
+  if (H % 8 || k < 1 || k > TOPK_MAX_K) return -1;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL((moe_combine_kernel<bf16_t>), dim3(tokens), dim3(256), 0, s, (bf16_t*)out, out_stride,
+                       (const bf16_t*)y, y_stride, topw, topi, inv, k, H, expert_start, local_experts);
+  else if (dtype == DT_F16)
+    hipLaunchKernelGGL((moe_combine_kernel<f16_t>), dim3(tokens), dim3(256), 0, s, (f16_t*)out, out_stride,
+                       (const f16_t*)y, y_stride, topw, topi, inv, k, H, expert_start, local_experts);
+  else
+    return -2;
+  HIP_LAUNCH_CHECK();
+  return 0;
+}

@@ -348,3 +348,72 @@ def test_skinny_gemm_matches_fp32_reference(dtype, m, n, k):
     y = hip.skinny_gemm(xb[:, k:], w[16:])
     ref = xb[:, k:].float() @ w[16:].float().t()
     assert (y.float() - ref).abs().max().item() <= tol
+
+
+# ------------------------------------------------------------- MoE routing
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("tokens,experts,k,renorm", [(1, 160, 8, True), (7, 8, 2, True), (300, 64, 4, False),
+                                                     (33, 512, 16, True), (5, 128, 1, False)])
+def test_moe_topk_matches_softmax_topk(dtype, tokens, experts, k, renorm):
+    from vllm_distributed_amd.ops import hip
+    ops.hip_available()
+    torch.manual_seed(tokens + experts)
+    logits = (torch.randn(tokens, experts, device=DEV) * 2).to(dtype)
+    topw, topi = hip.moe_topk(logits, k, renorm)
+    probs = torch.softmax(logits.float(), dim=-1)
+    rw, ri = probs.topk(k, dim=-1)
+    if renorm:
+        rw = rw / rw.sum(-1, keepdim=True)
+    # same experts (as sets: equal probabilities may order differently) and the same weights per expert
+    assert torch.equal(topi.long().sort(-1).values, ri.sort(-1).values)
+    got = torch.zeros_like(probs).scatter_(1, topi.long(), topw)
+    want = torch.zeros_like(probs).scatter_(1, ri, rw)
+    assert torch.allclose(got, want, atol=1e-6, rtol=1e-5)
+    # weights come out in descending order like torch.topk
+    assert (topw[:, :-1] >= topw[:, 1:]).all()
+
+
+@pytest.mark.parametrize("tokens,experts,k,tile_rows,ep", [(1, 160, 8, 16, None), (64, 16, 4, 16, None),
+                                                           (1000, 160, 8, 64, None), (300, 16, 4, 32, (4, 8)),
+                                                           (9000, 64, 8, 128, None)])
+def test_moe_align_and_combine(tokens, experts, k, tile_rows, ep):
+    """The slot sort is a permutation grouped by expert, the tile table covers
+    exactly the rows of each (local) expert, and combine is the weighted sum."""
+    from vllm_distributed_amd.ops import hip
+    ops.hip_available()
+    gen = torch.Generator(device=DEV).manual_seed(tokens)
+    probs = torch.rand(tokens, experts, device=DEV, generator=gen)
+    topw, topi = probs.topk(k, dim=-1)
+    topi = topi.to(torch.int32).contiguous()
+    topw = topw.float().contiguous()
+    start, local = ep if ep else (0, -1)
+    src_row, inv, tiles = hip.moe_align(topi, experts, tile_rows, start, local)
+    slots = tokens * k
+    flat = topi.reshape(-1).long()
+    assert torch.equal(inv.long().sort().values, torch.arange(slots, device=DEV))          # a permutation
+    assert torch.equal(src_row.long()[inv.long()], torch.arange(slots, device=DEV) // k)   # rows point at their token
+    sorted_experts = torch.empty(slots, dtype=torch.long, device=DEV)
+    sorted_experts[inv.long()] = flat
+    assert (sorted_experts[1:] >= sorted_experts[:-1]).all()                              # grouped by expert
+    t = tiles.cpu().tolist()
+    se = sorted_experts.cpu()
+    covered = torch.zeros(slots, dtype=torch.int32)
+    for g, r0, rows in t:
+        assert 0 <= rows <= tile_rows
+        if rows == 0:
+            continue
+        e = g + (start if ep else 0)
+        assert (se[r0:r0 + rows] == e).all()
+        covered[r0:r0 + rows] += 1
+    is_local = torch.ones(slots, dtype=torch.bool) if not ep else (se >= start) & (se < start + local)
+    assert torch.equal(covered, is_local.to(torch.int32))
+    # combine
+    h = 256
+    y = torch.randn(slots, h, device=DEV, generator=gen).to(torch.bfloat16)
+    out = hip.moe_combine(y, topw, topi, inv, start, local)
+    rows = y.float()[inv.long()].view(tokens, k, h)
+    w = topw.clone()
+    if ep:
+        w = torch.where((topi >= start) & (topi < start + local), w, torch.zeros_like(w))
+    want = (rows * w.unsqueeze(-1)).sum(1)
+    assert (out.float() - want).abs().max().item() <= 2 ** -7 * want.abs().max().item() + 1e-6

@@ -227,14 +227,38 @@ class FusedMoE(nn.Module):
         inv[order] = torch.arange(order.numel(), device=order.device)
         return y.index_select(0, inv).view(t, k, -1).sum(dim=1)      # fixed order: deterministic
 
+    def _experts_grouped(self, xs: torch.Tensor, tiles: torch.Tensor, tile_rows: int) -> torch.Tensor:
+        if self.qw13 is not None:
+            h = ops.grouped_linear(xs, tiles, tile_rows, qw=self.qw13, sz=self.sz13, alpha=self.alpha13)
+            return ops.grouped_linear(ops.silu_and_mul(h), tiles, tile_rows, qw=self.qw2, sz=self.sz2,
+                                      alpha=self.alpha2)
+        h = ops.grouped_linear(xs, tiles, tile_rows, weight=self.w13)
+        return ops.grouped_linear(ops.silu_and_mul(h), tiles, tile_rows, weight=self.w2)
+
+    def _forward_fused_routing(self, x: torch.Tensor, logits: torch.Tensor, tile_rows: int) -> torch.Tensor:
+        """Routing, expert GEMMs and the weighted sum in eight launches (router
+        GEMM included): top-k, slot sort + tile table and the combine are one HIP
+        kernel each."""
+        topw, topi = ops.moe_topk(logits, self.top_k, self.renormalize)
+        local = self.local_experts if self.expert_parallel else -1
+        src_row, inv, tiles = ops.moe_align_fused(topi, self.num_experts, tile_rows, self.expert_start, local)
+        y = self._experts_grouped(x.index_select(0, src_row), tiles, tile_rows)
+        return ops.moe_combine(y, topw, topi, inv, self.expert_start, local)
+
     def forward(self, x: torch.Tensor, reduce: bool = True) -> torch.Tensor:
-        logits = self.gate(x).float()
+        logits = self.gate(x)
+        tile_rows = self._grouped_tile_rows(x)
+        if tile_rows and x.dim() == 2 and ops.moe_route_fused_ok(logits, self.num_experts, self.top_k):
+            out = self._forward_fused_routing(x, logits, tile_rows)
+            if reduce and self.tp > 1:
+                out = tensor_model_parallel_all_reduce(out)
+            return out
+        logits = logits.float()
         probs = torch.softmax(logits, dim=-1)
         topw, topi = probs.topk(self.top_k, dim=-1)
         if self.renormalize:
             topw = topw / topw.sum(-1, keepdim=True)
         topw = topw.to(x.dtype)
-        tile_rows = self._grouped_tile_rows(x)
         if tile_rows:
             out = self._forward_grouped(x, topw, topi, tile_rows)
             if reduce and self.tp > 1:

@@ -267,6 +267,20 @@ def safetensors_weights_iterator(path: str, dtype: torch.dtype,
                 yield k, f.get_tensor(k)
 
 
+def _with_progress(items: Iterable, what: str, every: float = 20.0) -> Iterator:
+    """Pass ``items`` through, logging a count every ``every`` seconds (large
+    models take minutes to load; silence looks like a hang)."""
+    import time
+    t_last, n = time.monotonic(), 0
+    for x in items:
+        yield x
+        n += 1
+        now = time.monotonic()
+        if now - t_last >= every:
+            logger.info("loading: %d %s", n, what)
+            t_last = now
+
+
 # ------------------------------------------------------------------- entry
 def load_model(vllm_config: VllmConfig, device: torch.device) -> torch.nn.Module:
     mc = vllm_config.model_config
@@ -290,11 +304,10 @@ def load_model(vllm_config: VllmConfig, device: torch.device) -> torch.nn.Module
     else:
         it = safetensors_weights_iterator(path, mc.torch_dtype, want, keep_quantized=mc.quantization in ("awq", "nvfp4"))
     with torch.no_grad():
-        loaded = model.load_weights(it)
-        for m in model.modules():          # repack quantised shards into the kernel layout
-            fin = getattr(m, "finalize_weights", None)
-            if fin is not None:
-                fin()
+        loaded = model.load_weights(_with_progress(it, "checkpoint tensors read"))
+        mods = [m for m in model.modules() if getattr(m, "finalize_weights", None) is not None]
+        for m in _with_progress(mods, "modules finalised"):      # repack quantised shards into the kernel layout
+            m.finalize_weights()
     logger.info("loaded %d checkpoint tensors for %s (layers %d-%d, format=%s)", len(loaded),
                 mc.model, getattr(model, "start_layer", 0), getattr(model, "end_layer", 0),
                 mc.load_format if path is None else "safetensors")

@@ -298,6 +298,24 @@ def moe_align(topi, num_experts: int, tile_rows: int, expert_start: int = 0, loc
     return order, tiles
 
 
+def moe_route_fused_ok(logits, num_experts: int, top_k: int) -> bool:
+    """Whether the three-kernel HIP routing path (``csrc/moe_route.hip``) covers this router."""
+    return (_use_hip(logits) and logits.dim() == 2 and num_experts <= _hip.MOE_MAX_EXPERTS
+            and top_k <= _hip.MOE_MAX_TOPK and logits.dtype in (torch.bfloat16, torch.float16, torch.float32))
+
+
+def moe_topk(logits, k: int, renormalize: bool):
+    return _hip.moe_topk(logits, k, renormalize)
+
+
+def moe_align_fused(topi, num_experts: int, tile_rows: int, expert_start: int = 0, local_experts: int = -1):
+    return _hip.moe_align(topi, num_experts, tile_rows, expert_start, local_experts)
+
+
+def moe_combine(y, topw, topi, inv, expert_start: int = 0, local_experts: int = -1):
+    return _hip.moe_combine(y, topw, topi, inv, expert_start, local_experts)
+
+
 def grouped_linear(x, tiles, tile_rows: int, weight=None, qw=None, sz=None, alpha=None):
     """Row-grouped ``x @ W[g]^T`` (dense ``weight [G, N, K]``, packed 4-bit
     integer ``qw/sz``, or NVFP4 ``qw`` + int32 ``sz`` + ``alpha [G, N]``) for rows

@@ -46,6 +46,9 @@ def load() -> ctypes.CDLL:
         "vdamd_dynamic_fp8_quant": [P, P, P, I, I, L, I, P],
         "vdamd_skinny_gemm_grouped": [P, L, P, L, P, L, L, P, I, I, I, I, I, I, P],
         "vdamd_w4a16_gemm_grouped": [P, L, P, L, P, P, L, L, P, I, I, I, I, I, I, P],
+        "vdamd_moe_topk": [P, L, P, P, I, I, I, I, I, P],
+        "vdamd_moe_align": [P, I, I, I, I, I, I, P, P, P, I, P],
+        "vdamd_moe_combine": [P, L, P, L, P, P, P, I, I, I, I, I, I, P],
         "vdamd_fp4a16_gemm": [P, L, P, L, P, P, P, P, I, I, I, I, I, I, P],
         "vdamd_fp4_dequant": [P, P, P, P, I, I, I, P],
         "vdamd_fp4a16_gemm_grouped": [P, L, P, L, P, P, L, L, P, P, I, I, I, I, I, P],
@@ -541,6 +544,55 @@ def grouped_fp4a16_gemm(x: torch.Tensor, qw: torch.Tensor, fs: torch.Tensor, alp
                                           fs.data_ptr(), qw[0].numel(), fs[0].numel() * 2,
                                           None if alpha is None else alpha.data_ptr(), tiles.data_ptr(), nt,
                                           tile_rows, n, k, _dt(x), _stream()), "fp4a16_gemm_grouped")
+    return out
+
+
+# ------------------------------------------------------------- MoE routing
+MOE_MAX_EXPERTS = 512
+MOE_MAX_TOPK = 16
+
+
+def moe_topk(logits: torch.Tensor, k: int, renormalize: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    """softmax + top-k over router logits ``[T, E]``: ``(weights [T, k] fp32, experts [T, k] int32)``;
+    ties go to the lowest expert id."""
+    assert logits.dim() == 2 and logits.stride(1) == 1 and logits.dtype in _DT
+    t, e = logits.shape
+    assert k <= e <= MOE_MAX_EXPERTS and 1 <= k <= MOE_MAX_TOPK
+    topw = torch.empty((t, k), dtype=torch.float32, device=logits.device)
+    topi = torch.empty((t, k), dtype=torch.int32, device=logits.device)
+    _check(_LIB.vdamd_moe_topk(logits.data_ptr(), logits.stride(0), topw.data_ptr(), topi.data_ptr(), t, e, k,
+                               int(renormalize), _dt(logits), _stream()), "moe_topk")
+    return topw, topi
+
+
+def moe_align(topi: torch.Tensor, num_experts: int, tile_rows: int, expert_start: int = 0, local_experts: int = -1,
+              ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Sort the ``T*k`` slots by expert on the device: ``(src_row [T*k] = token of each sorted row,
+    inv [T*k] = sorted position of each slot, tiles [T*k // tile_rows + E, 3] int32)``.  Tiles of
+    experts outside ``[expert_start, expert_start + local_experts)`` have 0 rows."""
+    assert topi.dtype == torch.int32 and topi.dim() == 2 and topi.is_contiguous() and num_experts <= 1024
+    t, k = topi.shape
+    slots = t * k
+    n = slots // tile_rows + num_experts
+    src_row = torch.empty(slots, dtype=torch.int32, device=topi.device)
+    inv = torch.empty(slots, dtype=torch.int32, device=topi.device)
+    tiles = torch.empty((n, 3), dtype=torch.int32, device=topi.device)
+    _check(_LIB.vdamd_moe_align(topi.data_ptr(), slots, k, num_experts, tile_rows, expert_start, local_experts,
+                                src_row.data_ptr(), inv.data_ptr(), tiles.data_ptr(), n, _stream()), "moe_align")
+    return src_row, inv, tiles
+
+
+def moe_combine(y: torch.Tensor, topw: torch.Tensor, topi: torch.Tensor, inv: torch.Tensor, expert_start: int = 0,
+                local_experts: int = -1) -> torch.Tensor:
+    """``out[t] = sum_j topw[t, j] * y[inv[t*k + j]]`` in fp32 (slots of experts this rank does not hold are skipped)."""
+    t, k = topi.shape
+    h = y.shape[1]
+    assert _half(y) and y.stride(1) == 1 and y.stride(0) % 8 == 0 and h % 8 == 0 and y.data_ptr() % 16 == 0
+    assert topw.dtype == torch.float32 and topw.is_contiguous() and topi.is_contiguous() and inv.numel() == t * k
+    out = torch.empty((t, h), dtype=y.dtype, device=y.device)
+    _check(_LIB.vdamd_moe_combine(out.data_ptr(), h, y.data_ptr(), y.stride(0), topw.data_ptr(), topi.data_ptr(),
+                                  inv.data_ptr(), t, k, h, expert_start, local_experts, _dt(y), _stream()),
+           "moe_combine")
     return out
 
 
