@@ -134,7 +134,7 @@ __global__ __launch_bounds__(ALIGN_THREADS) void moe_align_kernel(
   }
 }
 
-// one workgroup per token; y rows are in expert-sorted order
+// grid (token, 2048-column slab); y rows are in expert-sorted order
 template <typename T>
 __global__ __launch_bounds__(256) void moe_combine_kernel(T* __restrict__ out, long out_stride,
                                                           const T* __restrict__ y, long y_stride,
@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(T* __restrict__ out, l
     pos[threadIdx.x] = local ? inv[(long)t * k + threadIdx.x] : -1;
   }
   __syncthreads();
-  for (int h = threadIdx.x * 8; h < H; h += 256 * 8) {
+  const int h = blockIdx.y * 2048 + threadIdx.x * 8;
+  if (h < H) {
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int j = 0; j < k; ++j) {
       if (pos[j] < 0) continue;          // an expert another rank holds: its row was never computed here
@@ -207,10 +208,10 @@ VDAMD_API int vdamd_moe_combine(void* out, long out_stride, const void* y, long 
   if (tokens <= 0) return 0;
   if (H % 8 || k < 1 || k > TOPK_MAX_K) return -1;
   if (dtype == DT_BF16)
-    hipLaunchKernelGGL((moe_combine_kernel<bf16_t>), dim3(tokens), dim3(256), 0, s, (bf16_t*)out, out_stride,
+    hipLaunchKernelGGL((moe_combine_kernel<bf16_t>), dim3(tokens, (H + 2047) / 2048), dim3(256), 0, s, (bf16_t*)out, out_stride,
                        (const bf16_t*)y, y_stride, topw, topi, inv, k, H, expert_start, local_experts);
   else if (dtype == DT_F16)
-    hipLaunchKernelGGL((moe_combine_kernel<f16_t>), dim3(tokens), dim3(256), 0, s, (f16_t*)out, out_stride,
+    hipLaunchKernelGGL((moe_combine_kernel<f16_t>), dim3(tokens, (H + 2047) / 2048), dim3(256), 0, s, (f16_t*)out, out_stride,
                        (const f16_t*)y, y_stride, topw, topi, inv, k, H, expert_start, local_experts);
   else
     return -2;

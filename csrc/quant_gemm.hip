@@ -78,9 +78,25 @@ template <typename T, int MT, int FMT>
 __global__ __launch_bounds__(256) void w4a16_gemm_kernel(
     const T* __restrict__ x, long x_stride, const uint32_t* __restrict__ qw, const T* __restrict__ sz,
     T* __restrict__ out, long out_stride, float* __restrict__ partial, int M, int N, int K,
-    int kb_per_group, int ksplit, const float* __restrict__ alpha) {
+    int kb_per_group, int ksplit, const float* __restrict__ alpha, const int* __restrict__ tiles,
+    long qw_group_stride, long sz_group_stride) {
   using V8 = typename Vec8<T>::type;
   constexpr bool PREFETCH_X = MT <= 2;
+  int m_base = blockIdx.z * (16 * MT);
+  if (tiles != nullptr) {
+    // grouped mode, as in w4a16_gemm_lds_kernel: blockIdx.z names a row tile of one group.
+    // With a handful of rows per expert this variant spreads each expert over 4x the
+    // workgroups of the LDS variant (64 instead of 256 output rows each).
+    const int* d = tiles + 3 * blockIdx.z;
+    M = d[2];
+    if (M == 0) return;
+    qw += (size_t)d[0] * qw_group_stride;
+    sz += (size_t)d[0] * sz_group_stride;
+    if (alpha != nullptr) alpha += (size_t)d[0] * N;
+    x += (long)d[1] * x_stride;
+    out += (long)d[1] * out_stride;
+    m_base = 0;
+  }
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int KB = K >> 7, ntiles = N >> 4, NG = KB / kb_per_group;
@@ -89,7 +105,7 @@ __global__ __launch_bounds__(256) void w4a16_gemm_kernel(
   const int kb_lo = (int)((long)KB * ks / ksplit), kb_hi = (int)((long)KB * (ks + 1) / ksplit);
   const int span = kb_hi - kb_lo;
   const int w_lo = kb_lo + span * wid / W4_WAVES, w_hi = kb_lo + span * (wid + 1) / W4_WAVES;
-  const int m0 = blockIdx.z * (16 * MT);
+  const int m0 = m_base;
 
   // tiles past the end are computed on a clamped index and discarded
   int ntc[W4_NTW];
@@ -512,7 +528,7 @@ static int launch_w4a16(void* out, long out_stride, const void* x, long x_stride
   else                                                                                                      \
     w4a16_gemm_kernel<T, MT_, FMT><<<grid, 256, 0, st>>>((const T*)x, x_stride, (const uint32_t*)qw,       \
                                                       (const T*)sz, (T*)out, out_stride, (float*)partial,  \
-                                                      M, N, K, G / 128, ksplit, alpha)
+                                                      M, N, K, G / 128, ksplit, alpha, nullptr, 0, 0)
   if (wide) {
     switch (mt) {
       case 3: W4_LDS(3, 2); break;      // 65..96 rows in two chunks cannot happen; kept for completeness
@@ -624,14 +640,23 @@ template <typename T, int FMT>
 static int launch_w4_grouped(void* out, long os, const void* x, long xs, const void* qw, const void* sz, long qgs,
                              long sgs, const float* alpha, const int* tiles, int num_tiles, int tile_rows, int N,
                              int K, int G, hipStream_t st) {
+  if (tile_rows <= 32) {
+    // few rows per group: 64 output rows per workgroup, the four waves split K
+    dim3 grid((N / 16 + W4_NTW - 1) / W4_NTW, 1, num_tiles);
+#define W4G0(MT_)                                                                                               \
+  w4a16_gemm_kernel<T, MT_, FMT><<<grid, 256, 0, st>>>((const T*)x, xs, (const uint32_t*)qw, (const T*)sz, (T*)out, \
+                                                    os, nullptr, tile_rows, N, K, G / 128, 1, alpha, tiles, qgs, sgs)
+    if (tile_rows <= 16) W4G0(1); else W4G0(2);
+#undef W4G0
+    HIP_LAUNCH_CHECK();
+    return 0;
+  }
   dim3 grid((N / 16 + W4_NTW * W4_WAVES - 1) / (W4_NTW * W4_WAVES), 1, num_tiles);
 #define W4G(MT_)                                                                                                \
   w4a16_gemm_lds_kernel<T, MT_, FMT, W4_NTW><<<grid, 256, 0, st>>>((const T*)x, xs, (const uint32_t*)qw, (const T*)sz, \
                                                           (T*)out, os, nullptr, tile_rows, N, K, G / 128, 1,   \
                                                           tiles, qgs, sgs, alpha)
   switch (tile_rows / 16) {
-    case 1: W4G(1); break;
-    case 2: W4G(2); break;
     case 3: W4G(3); break;
     default: W4G(4); break;
   }
