@@ -10,6 +10,10 @@
 //   items [.., +Hkv*D/8)          copy a v chunk to v_cache (2-byte strided stores)
 // and (token, item) pairs are laid out flat over the grid, so a rank that holds
 // one KV head (TP=8: 88 items per token) still fills 256-thread workgroups.
+//
+// Optional per-head RMSNorm of q and k before the rotation (Qwen3): the D/16
+// threads that share a head are consecutive, aligned lanes, so the sum of
+// squares is a few lane shuffles and the normalised values never leave fp32.
 #include "common.h"
 
 namespace {
@@ -19,7 +23,8 @@ __global__ void rope_cache_kernel(const int* __restrict__ positions, T* __restri
                                   const T* __restrict__ v, long q_stride, long k_stride, long v_stride,
                                   const float* __restrict__ cos_sin, T* __restrict__ k_cache,
                                   T* __restrict__ v_cache, const int* __restrict__ slot_mapping, int Hq, int Hkv,
-                                  int D, int block_size, int T_tokens) {
+                                  int D, int block_size, int T_tokens, const T* __restrict__ q_norm_w,
+                                  const T* __restrict__ k_norm_w, float norm_eps) {
   using V = typename Vec8<T>::type;
   const int half = D >> 1;
   const int cpp = half >> 3;                 // 8-element chunks per half head
@@ -45,6 +50,20 @@ __global__ void rope_cache_kernel(const int* __restrict__ positions, T* __restri
       V x1 = ld8<T>(base + 8 * c);
       V x2 = ld8<T>(base + half + 8 * c);
       V o1 = x1, o2 = x2;
+      float f1[8], f2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { f1[j] = (float)x1[j]; f2[j] = (float)x2[j]; }
+      const T* nw = is_q ? q_norm_w : k_norm_w;
+      if (ROTATE && nw != nullptr) {
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += f1[j] * f1[j] + f2[j] * f2[j];
+        for (int o = 1; o < cpp; o <<= 1) ss += __shfl_xor(ss, o, 64);      // the head's cpp lanes are aligned
+        const float r = rsqrtf(ss / (float)D + norm_eps);
+        const V w1 = ld8<T>(nw + 8 * c), w2 = ld8<T>(nw + half + 8 * c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { f1[j] *= r * (float)w1[j]; f2[j] *= r * (float)w2[j]; }
+      }
       if (ROTATE) {
         const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs + 8 * c);
         const f32x4 c1 = *reinterpret_cast<const f32x4*>(cs + 8 * c + 4);
@@ -54,7 +73,7 @@ __global__ void rope_cache_kernel(const int* __restrict__ positions, T* __restri
         for (int j = 0; j < 8; ++j) {
           const float cj = j < 4 ? c0[j & 3] : c1[j & 3];
           const float sj = j < 4 ? s0[j & 3] : s1[j & 3];
-          const float a = (float)x1[j], b = (float)x2[j];
+          const float a = f1[j], b = f2[j];
           o1[j] = (T)(a * cj - b * sj);
           o2[j] = (T)(b * cj + a * sj);
         }
@@ -84,7 +103,7 @@ __global__ void rope_cache_kernel(const int* __restrict__ positions, T* __restri
 template <typename T>
 int launch(const int* positions, void* q, void* k, const void* v, long qs, long ks, long vs, const float* cos_sin,
            void* k_cache, void* v_cache, const int* slot_mapping, int T_tokens, int Hq, int Hkv, int D,
-           int block_size, int mode, hipStream_t s) {
+           int block_size, int mode, const void* qnw, const void* knw, float eps, hipStream_t s) {
   // mode 0 and 2 write the cache (v items exist), mode 1 rotates only
   const long items = Hq * (D >> 4) + Hkv * (D >> 4) + (mode == 1 ? 0 : Hkv * (D >> 3));
   const long total = items * T_tokens;
@@ -93,7 +112,7 @@ int launch(const int* positions, void* q, void* k, const void* v, long qs, long 
 #define L(WC, ROT)                                                                                          \
   hipLaunchKernelGGL((rope_cache_kernel<T, WC, ROT>), dim3(blocks), dim3(threads), 0, s, positions, (T*)q,  \
                      (T*)k, (const T*)v, qs, ks, vs, cos_sin, (T*)k_cache, (T*)v_cache, slot_mapping, Hq, Hkv, \
-                     D, block_size, T_tokens)
+                     D, block_size, T_tokens, (const T*)qnw, (const T*)knw, eps)
   if (mode == 0) L(true, true);          // rotate q,k + write k,v to cache
   else if (mode == 1) L(false, true);    // rotate q,k in place only
   else L(true, false);                   // cache write only (k,v already final)
@@ -105,17 +124,22 @@ int launch(const int* positions, void* q, void* k, const void* v, long qs, long 
 }  // namespace
 
 // mode 0: rotate + cache, 1: rotate only, 2: cache only.  Strides are in elements.
+// q_norm_w / k_norm_w (D elements each, both or neither): RMSNorm each head before rotating.
 VDAMD_API int vdamd_rope_cache(const int* positions, void* q, void* k, const void* v, long q_stride,
                                long k_stride, long v_stride, const float* cos_sin, void* k_cache, void* v_cache,
                                const int* slot_mapping, int T, int Hq, int Hkv, int D, int block_size, int mode,
-                               int dtype, hipStream_t s) {
+                               const void* q_norm_w, const void* k_norm_w, float norm_eps, int dtype,
+                               hipStream_t s) {
   if (T == 0) return 0;
   if (D % 16 != 0) return -1;
+  if ((q_norm_w == nullptr) != (k_norm_w == nullptr)) return -1;
+  // the head's D/16 lanes must form an aligned power-of-two group for the shuffle reduction
+  if (q_norm_w != nullptr && (mode == 2 || ((D / 16) & (D / 16 - 1)) != 0 || D / 16 > 64)) return -1;
   if (dtype == DT_BF16)
     return launch<bf16_t>(positions, q, k, v, q_stride, k_stride, v_stride, cos_sin, k_cache, v_cache,
-                          slot_mapping, T, Hq, Hkv, D, block_size, mode, s);
+                          slot_mapping, T, Hq, Hkv, D, block_size, mode, q_norm_w, k_norm_w, norm_eps, s);
   if (dtype == DT_F16)
     return launch<f16_t>(positions, q, k, v, q_stride, k_stride, v_stride, cos_sin, k_cache, v_cache,
-                         slot_mapping, T, Hq, Hkv, D, block_size, mode, s);
+                         slot_mapping, T, Hq, Hkv, D, block_size, mode, q_norm_w, k_norm_w, norm_eps, s);
   return -2;
 }

@@ -88,6 +88,27 @@ def test_rope_and_cache_matches_reference(hq, hkv, d, bs):
     torch.testing.assert_close(vc.float(), vc_ref, rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("hq,hkv,d,bs", [(32, 8, 128, 64), (8, 8, 64, 16), (12, 1, 128, 32)])
+def test_rope_and_cache_with_per_head_rms_norm(hq, hkv, d, bs):
+    """Qwen3: q and k heads are RMS-normalised before the rotation, in the same kernel."""
+    T, nb = 41, 12
+    qkv = _rand(T, (hq + 2 * hkv) * d)
+    qw, kw = (1.0 + 0.2 * torch.randn(d, device=DEV)).to(torch.bfloat16), \
+        (1.0 + 0.2 * torch.randn(d, device=DEV)).to(torch.bfloat16)
+    cos_sin = torch_ref.build_cos_sin_cache(d, 4096, 1e6).to(DEV)
+    pos = torch.randint(0, 4096, (T,), device=DEV, dtype=torch.int32)
+    slots = torch.randperm(nb * bs, device=DEV)[:T].to(torch.int32)
+    kc = torch.zeros(nb, hkv, bs, d, device=DEV, dtype=torch.bfloat16)
+    vc = torch.zeros(nb, hkv, d, bs, device=DEV, dtype=torch.bfloat16)
+    kc_ref, vc_ref = kc.float(), vc.float()
+    q_ref = torch_ref.rope_and_cache(pos, qkv.float().clone(), cos_sin, kc_ref, vc_ref, slots, hq, hkv, d,
+                                     qw.float(), kw.float(), 1e-6)
+    q = ops.rope_and_cache(pos, qkv, cos_sin, kc, vc, slots, hq, hkv, d, qw, kw, 1e-6)
+    torch.testing.assert_close(q.float(), q_ref, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(kc.float(), kc_ref, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(vc.float(), vc_ref, rtol=0, atol=0)
+
+
 def test_rotary_and_reshape_unfused():
     T, hq, hkv, d, bs, nb = 19, 4, 2, 64, 16, 8
     q, k, v = _rand(T, hq * d), _rand(T, hkv * d), _rand(T, hkv * d)

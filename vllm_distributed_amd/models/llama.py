@@ -58,7 +58,13 @@ class LlamaAttention(nn.Module):
     def forward(self, positions: torch.Tensor, hidden: torch.Tensor, reduce: bool = True) -> torch.Tensor:
         qkv = self.qkv_proj(hidden)
         md = get_forward_context().attn_metadata
-        if self.qk_norm:
+        if self.qk_norm and md is not None and self.attn.k_cache is not None:
+            # per-head RMSNorm of q and k, rotation and the cache write in one kernel
+            q = ops.rope_and_cache(positions, qkv, self.cos_sin, self.attn.k_cache, self.attn.v_cache,
+                                   md.slot_mapping, self.num_heads, self.num_kv_heads, self.head_dim,
+                                   self.q_norm.weight, self.k_norm.weight, self.q_norm.eps)
+            out = self.attn.forward_cached(q)
+        elif self.qk_norm:
             t = qkv.shape[0]
             q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
             q = self.q_norm(q.reshape(t * self.num_heads, self.head_dim)).view(t, self.q_size)

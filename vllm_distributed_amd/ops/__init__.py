@@ -87,12 +87,12 @@ def reshape_and_cache(k, v, k_cache, v_cache, slot_mapping):
 
 
 def rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping,
-                   num_heads, num_kv_heads, head_dim):
+                   num_heads, num_kv_heads, head_dim, q_norm_weight=None, k_norm_weight=None, norm_eps=0.0):
     if _use_hip(qkv):
         return _hip.rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping,
-                                   num_heads, num_kv_heads, head_dim)
+                                   num_heads, num_kv_heads, head_dim, q_norm_weight, k_norm_weight, norm_eps)
     return torch_ref.rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping,
-                                    num_heads, num_kv_heads, head_dim)
+                                    num_heads, num_kv_heads, head_dim, q_norm_weight, k_norm_weight, norm_eps)
 
 
 def paged_attention(q, k_cache, v_cache, block_table, query_start_loc, seq_lens, scale,

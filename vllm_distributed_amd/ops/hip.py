@@ -35,7 +35,7 @@ def load() -> ctypes.CDLL:
         "vdamd_layer_norm": [P, P, P, P, F, I, I, I, P],
         "vdamd_silu_and_mul": [P, P, L, I, I, P],
         "vdamd_embedding": [P, P, P, I, I, I, I, I, P],
-        "vdamd_rope_cache": [P, P, P, P, L, L, L, P, P, P, P, I, I, I, I, I, I, I, P],
+        "vdamd_rope_cache": [P, P, P, P, L, L, L, P, P, P, P, I, I, I, I, I, I, P, P, F, I, P],
         "vdamd_paged_attention_decode": [P, P, P, L, P, P, P, I, P, F, I, I, I, I, I, I, L, I, P],
         "vdamd_paged_attention_prefill": [P, P, L, P, P, P, I, P, P, F, I, I, I, I, I, I, L, I, P],
         "vdamd_argmax": [P, P, I, I, L, I, P],
@@ -169,11 +169,15 @@ def _check_cache(k_cache: torch.Tensor, v_cache: torch.Tensor, hkv: int, d: int)
 
 
 def rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping, num_heads, num_kv_heads,
-                   head_dim) -> torch.Tensor:
+                   head_dim, q_norm_weight=None, k_norm_weight=None, norm_eps: float = 0.0) -> torch.Tensor:
+    """``q_norm_weight`` / ``k_norm_weight``: RMSNorm each q and k head before rotating (Qwen3)."""
     if not _half(qkv):
         from . import torch_ref
         return torch_ref.rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping,
-                                        num_heads, num_kv_heads, head_dim)
+                                        num_heads, num_kv_heads, head_dim, q_norm_weight, k_norm_weight, norm_eps)
+    if q_norm_weight is not None:
+        for w in (q_norm_weight, k_norm_weight):
+            assert w.dtype == qkv.dtype and w.numel() == head_dim and w.is_contiguous()
     t = qkv.shape[0]
     qs, ks = num_heads * head_dim, num_kv_heads * head_dim
     assert qkv.dim() == 2 and qkv.shape[1] == qs + 2 * ks and qkv.stride(1) == 1
@@ -187,6 +191,8 @@ def rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping
     _check(_LIB.vdamd_rope_cache(positions.data_ptr(), base, base + qs * esz, base + (qs + ks) * esz, st, st, st,
                                  cos_sin_cache.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
                                  slot_mapping.data_ptr(), t, num_heads, num_kv_heads, head_dim, bs, 0,
+                                 None if q_norm_weight is None else q_norm_weight.data_ptr(),
+                                 None if k_norm_weight is None else k_norm_weight.data_ptr(), norm_eps,
                                  _dt(qkv), _stream()), "rope_and_cache")
     return qkv[:, :qs]
 
@@ -200,8 +206,8 @@ def rotary_embedding(positions, q, k, cos_sin_cache, head_dim) -> None:
     assert positions.dtype == torch.int32 and cos_sin_cache.dtype == torch.float32
     _check(_LIB.vdamd_rope_cache(positions.data_ptr(), q.data_ptr(), k.data_ptr(), None, q.stride(0),
                                  k.stride(0), 0, cos_sin_cache.data_ptr(), None, None, None, t,
-                                 q.shape[1] // head_dim, k.shape[1] // head_dim, head_dim, 16, 1, _dt(q),
-                                 _stream()), "rotary_embedding")
+                                 q.shape[1] // head_dim, k.shape[1] // head_dim, head_dim, 16, 1, None, None, 0.0,
+                                 _dt(q), _stream()), "rotary_embedding")
 
 
 def reshape_and_cache(k, v, k_cache, v_cache, slot_mapping) -> None:
@@ -214,7 +220,7 @@ def reshape_and_cache(k, v, k_cache, v_cache, slot_mapping) -> None:
     bs = _check_cache(k_cache, v_cache, hkv, d)
     _check(_LIB.vdamd_rope_cache(None, None, k.data_ptr(), v.data_ptr(), 0, k.stride(0), v.stride(0), None,
                                  k_cache.data_ptr(), v_cache.data_ptr(), slot_mapping.data_ptr(), t, 0, hkv, d,
-                                 bs, 2, _dt(k), _stream()), "reshape_and_cache")
+                                 bs, 2, None, None, 0.0, _dt(k), _stream()), "reshape_and_cache")
 
 
 # ---------------------------------------------------------------- attention

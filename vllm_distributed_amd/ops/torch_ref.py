@@ -138,11 +138,18 @@ def reshape_and_cache(k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor,
 
 def rope_and_cache(positions: torch.Tensor, qkv: torch.Tensor, cos_sin_cache: torch.Tensor,
                    k_cache: torch.Tensor, v_cache: torch.Tensor, slot_mapping: torch.Tensor,
-                   num_heads: int, num_kv_heads: int, head_dim: int) -> torch.Tensor:
+                   num_heads: int, num_kv_heads: int, head_dim: int, q_norm_weight=None, k_norm_weight=None,
+                   norm_eps: float = 0.0) -> torch.Tensor:
     """Rotate q and k inside the packed ``qkv[T, (Hq+2Hkv)*D]``, write k/v to
-    the cache, return the rotated ``q[T, Hq*D]`` (a view of qkv)."""
+    the cache, return the rotated ``q[T, Hq*D]`` (a view of qkv).  With norm
+    weights each q and k head is RMS-normalised first."""
     qs, ks = num_heads * head_dim, num_kv_heads * head_dim
     q, k, v = qkv[:, :qs], qkv[:, qs:qs + ks], qkv[:, qs + ks:]
+    if q_norm_weight is not None:
+        for part, w in ((q, q_norm_weight), (k, k_norm_weight)):
+            h = part.reshape(part.shape[0], -1, head_dim).float()
+            h = h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + norm_eps) * w.float()
+            part.copy_(h.reshape(part.shape).to(part.dtype))
     rotary_embedding(positions, q, k, cos_sin_cache, head_dim)
     reshape_and_cache(k.reshape(-1, num_kv_heads, head_dim), v.reshape(-1, num_kv_heads, head_dim),
                       k_cache, v_cache, slot_mapping)
