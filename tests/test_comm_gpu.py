@@ -156,8 +156,9 @@ from vllm_distributed_amd.engine.arg_utils import EngineArgs
 from vllm_distributed_amd.engine.llm_engine import LLMEngine
 tp = int(os.environ.get("WORLD_SIZE", "1"))
 eng = LLMEngine.from_engine_args(EngineArgs(
-    model="llama-tiny", device="cuda", dtype="bfloat16", max_model_len=256, num_gpu_blocks_override=64,
-    max_num_seqs=8, tensor_parallel_size=tp, distributed_executor_backend="spmd" if tp > 1 else "uni",
+    model=os.environ.get("MODEL", "llama-tiny"), device="cuda", dtype="bfloat16", max_model_len=256,
+    num_gpu_blocks_override=64, max_num_seqs=8, tensor_parallel_size=tp,
+    distributed_executor_backend="spmd" if tp > 1 else "uni", enable_expert_parallel=os.environ.get("EP") == "1",
     async_scheduling=os.environ.get("ASYNC") == "1", gpu_memory_utilization=0.2,
     hf_overrides=json.loads(os.environ.get("OVERRIDES", "{{}}"))))
 g = SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True, logprobs=8)
@@ -175,14 +176,15 @@ eng.shutdown()
 """
 
 
-def _run_spmd_shared(world, async_sched, sp="0", overrides=None):
+def _run_spmd_shared(world, async_sched, sp="0", overrides=None, model="llama-tiny", ep=False):
     port = get_open_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), VLLM_LOGGING_LEVEL="WARNING", GLOO_SOCKET_IFNAME="lo",
                    VDAMD_SHARE_DEVICE="1", ASYNC="1" if async_sched else "0", HSA_ENABLE_IPC_MODE_LEGACY="0",
-                   VDAMD_SEQUENCE_PARALLEL=sp, OVERRIDES=json.dumps(overrides or {}))
+                   VDAMD_SEQUENCE_PARALLEL=sp, OVERRIDES=json.dumps(overrides or {}), MODEL=model,
+                   EP="1" if ep else "0")
         procs.append(subprocess.Popen([sys.executable, "-c", SPMD_SCRIPT.format(root=ROOT)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -278,3 +280,17 @@ def test_spmd_wide_tensor_parallel_sharing_one_gpu(world):
     for lp_ref, lp_tp, toks in zip(ref["first_lp"], got[0]["first_lp"], ref["tokens"]):
         top = str(toks[0])
         assert top in lp_tp and abs(lp_tp[top] - lp_ref[top]) < 0.1, (lp_ref, lp_tp)
+
+
+@pytest.mark.parametrize("ep", [False, True])
+def test_spmd_moe_tensor_and_expert_parallel_sharing_one_gpu(ep):
+    """A cut-down Qwen3-Coder (head_dim 128, 128-aligned experts: HIP routing kernels and grouped
+    expert GEMMs) at TP=2 with tensor-sharded and with expert-parallel experts, against one rank."""
+    ov = dict(hidden_size=512, num_attention_heads=4, num_key_value_heads=2, head_dim=128, moe_intermediate_size=256,
+              num_experts=16, num_experts_per_tok=4, num_hidden_layers=2, vocab_size=1024, max_position_embeddings=512)
+    ref = _run_spmd_shared(1, False, overrides=ov, model="qwen3-coder-480b-a35b")[0]
+    got = _run_spmd_shared(2, False, overrides=ov, model="qwen3-coder-480b-a35b", ep=ep)
+    assert got[0]["tokens"] == got[1]["tokens"]
+    for lp_ref, lp_tp, toks in zip(ref["first_lp"], got[0]["first_lp"], ref["tokens"]):
+        top = str(toks[0])
+        assert top in lp_tp and abs(lp_tp[top] - lp_ref[top]) < 0.15, (lp_ref, lp_tp)
