@@ -26,13 +26,14 @@ ap.add_argument("--prompt-len", type=int, default=128)
 ap.add_argument("--steps", type=int, default=32)
 ap.add_argument("--quantization", default="awq")
 ap.add_argument("--gpu-memory-utilization", type=float, default=0.96)
+ap.add_argument("--max-batched-tokens", type=int, default=4096)
 args = ap.parse_args()
 
 t0 = time.time()
 eng = LLMEngine.from_engine_args(EngineArgs(
     model="qwen3-coder-480b-a35b", load_format="dummy", quantization=args.quantization,
     hf_overrides={"num_hidden_layers": args.layers}, max_model_len=4096, max_num_seqs=max(args.batch, 8),
-    max_num_batched_tokens=4096, gpu_memory_utilization=args.gpu_memory_utilization, enable_prefix_caching=False,
+    max_num_batched_tokens=args.max_batched_tokens, gpu_memory_utilization=args.gpu_memory_utilization, enable_prefix_caching=False,
     hip_graph_sizes=[args.batch], max_capture_size=args.batch, async_scheduling=True))
 load_s = time.time() - t0
 print(f"engine ready in {load_s:.1f}s; torch allocated {torch.cuda.memory_allocated() / 2 ** 30:.1f} GiB, "

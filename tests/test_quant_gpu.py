@@ -122,7 +122,7 @@ def test_fused_moe_grouped_gemm_path_matches_per_expert_loop(quantized, tokens, 
     x = torch.randn(tokens, hidden, device=DEV, generator=gen).to(torch.bfloat16)
     rows = moe._grouped_tile_rows(x)
     avg = tokens * top_k / experts
-    assert rows == 0 if avg > (64 if quantized else 128) else rows in (16, 32, 64, 128)
+    assert rows == 0 if avg > (512 if quantized else 1024) else rows in (16, 32, 64, 128)
     with torch.inference_mode():
         monkeypatch.setattr(FusedMoE, "_grouped_tile_rows", lambda self, x: 0)
         ref = moe(x).float()

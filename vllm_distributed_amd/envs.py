@@ -105,6 +105,9 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     # Time the library's candidate kernels for every decode GEMM shape at warm-up.
     "VDAMD_TUNE_GEMM": _bool("VDAMD_TUNE_GEMM", False),
     "VDAMD_TUNE_GEMM_FILE": _str("VDAMD_TUNE_GEMM_FILE", os.path.expanduser("~/.cache/vllm_distributed_amd/gemm_tuning.csv")),
+    # MoE: average rows per expert (4-bit experts; twice that for 16-bit ones) up to which a step
+    # runs the grouped HIP GEMMs; above it each expert gets its own library GEMM.
+    "VDAMD_MOE_GROUPED_MAX_ROWS": _int("VDAMD_MOE_GROUPED_MAX_ROWS", 512),
     # Capture decode steps in hipGraphs.
     "VDAMD_USE_HIP_GRAPH": _bool("VDAMD_USE_HIP_GRAPH", True),
     # Assert identical collective sequence numbers on all ranks (debug).

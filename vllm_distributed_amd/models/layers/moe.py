@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ... import ops
+from ... import envs, ops
 from ...parallel.state import (get_tensor_model_parallel_rank,
                                get_tensor_model_parallel_world_size,
                                tensor_model_parallel_all_reduce)
@@ -194,7 +194,7 @@ class FusedMoE(nn.Module):
             return 0
         cap = 64 if self.qw13 is not None else 128
         avg = x.shape[0] * self.top_k / max(1, self.num_experts)
-        if avg > cap and not torch.cuda.is_current_stream_capturing():
+        if avg > envs.VDAMD_MOE_GROUPED_MAX_ROWS * cap / 64 and not torch.cuda.is_current_stream_capturing():
             return 0
         for rows in (16, 32, 64, 128):
             if avg <= rows or rows == cap:
