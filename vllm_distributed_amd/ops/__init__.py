@@ -35,6 +35,10 @@ def hip_available() -> bool:
     return _load_hip() is not None
 
 
+def hip_supports_head_dim(d: int) -> bool:
+    return hip_available() and _hip.supports_head_dim(d)
+
+
 def _use_hip(t: torch.Tensor) -> bool:
     if not t.is_cuda:
         return False

@@ -552,6 +552,10 @@ class ModelRunner:
         if self.pp.world_size > 1:
             logger.info("hipGraph decode capture is disabled with pipeline parallelism")
             return
+        if not ops.hip_supports_head_dim(self.model_config.head_dim):
+            logger.info("hipGraph decode capture needs the HIP attention kernels (head_dim 64 or 128): "
+                        "running eagerly")
+            return
         if self.tp.world_size > 1 and self.tp.rccl is None and self.tp.device_group is not None:
             # torch.distributed collectives keep host-side work objects; only the
             # direct RCCL binding is a pure stream enqueue that a capture can record
