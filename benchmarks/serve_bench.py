@@ -1,98 +1,10 @@
-"""HTTP serving benchmark against a running ``launch.py serve`` instance.
+"""HTTP serving benchmark (same as ``python launch.py bench serve``); see
+``vllm_distributed_amd/entrypoints/bench_serve.py``."""
+import os
+import sys
 
-Sends ``--num-prompts`` streaming ``/v1/completions`` requests with at most
-``--concurrency`` in flight, synthetic prompts of ``--input-len`` token ids,
-``--output-len`` new tokens each (``ignore_eos``), and reports the metrics the
-deployment is judged by: output tokens/s over the whole run, p50/p99 time to
-first token, p50 inter-token latency.
-
-    python benchmarks/serve_bench.py --base-url http://127.0.0.1:8000 --model llama-3-8b \
-        --num-prompts 256 --concurrency 64 --input-len 128 --output-len 64
-"""
-from __future__ import annotations
-
-import argparse
-import asyncio
-import json
-import random
-import time
-from typing import List, Optional
-
-
-async def _one(session, url: str, headers: dict, payload: dict, result: dict) -> None:
-    t0 = time.perf_counter()
-    first: Optional[float] = None
-    stamps: List[float] = []
-    ntok = 0
-    async with session.post(url, json=payload, headers=headers) as resp:
-        resp.raise_for_status()
-        async for raw in resp.content:
-            line = raw.decode().strip()
-            if not line.startswith("data:"):
-                continue
-            data = line[5:].strip()
-            if data == "[DONE]":
-                break
-            chunk = json.loads(data)
-            now = time.perf_counter()
-            if first is None:
-                first = now - t0
-            stamps.append(now)
-            usage = chunk.get("usage")
-            if usage:
-                ntok = usage.get("completion_tokens", ntok)
-    result["ttft"].append(first if first is not None else float("nan"))
-    result["tokens"] += ntok if ntok else len(stamps)
-    if len(stamps) > 1:
-        result["itl"].extend(b - a for a, b in zip(stamps, stamps[1:]))
-
-
-async def run(args) -> dict:
-    import aiohttp
-    rng = random.Random(args.seed)
-    headers = {"Authorization": f"Bearer {args.api_key}"} if args.api_key else {}
-    url = args.base_url.rstrip("/") + "/v1/completions"
-    result = {"ttft": [], "itl": [], "tokens": 0}
-    sem = asyncio.Semaphore(args.concurrency)
-    timeout = aiohttp.ClientTimeout(total=args.timeout)
-    # aiohttp caps a session at 100 connections by default: lift it, or requests queue in the client
-    async with aiohttp.ClientSession(timeout=timeout, connector=aiohttp.TCPConnector(limit=0)) as session:
-        async def guarded(i: int) -> None:
-            prompt = [rng.randrange(3, args.vocab_size) for _ in range(args.input_len)]
-            payload = {"model": args.model, "prompt": prompt, "max_tokens": args.output_len, "temperature": 0.0,
-                       "ignore_eos": True, "stream": True, "stream_options": {"include_usage": True}}
-            async with sem:
-                await _one(session, url, headers, payload, result)
-        t0 = time.perf_counter()
-        await asyncio.gather(*(guarded(i) for i in range(args.num_prompts)))
-        elapsed = time.perf_counter() - t0
-
-    def pct(xs: List[float], p: float) -> Optional[float]:
-        xs = sorted(x for x in xs if x == x)
-        return round(1e3 * xs[min(len(xs) - 1, int(p * len(xs)))], 2) if xs else None
-    return {"num_prompts": args.num_prompts, "concurrency": args.concurrency, "input_len": args.input_len,
-            "output_len": args.output_len, "elapsed_s": round(elapsed, 3),
-            "output_tokens_per_s": round(result["tokens"] / elapsed, 1),
-            "requests_per_s": round(args.num_prompts / elapsed, 2),
-            "ttft_p50_ms": pct(result["ttft"], 0.5), "ttft_p99_ms": pct(result["ttft"], 0.99),
-            "itl_p50_ms": pct(result["itl"], 0.5)}
-
-
-def main(argv=None) -> None:
-    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("--base-url", default="http://127.0.0.1:8000")
-    ap.add_argument("--model", required=True)
-    ap.add_argument("--api-key", default=None)
-    ap.add_argument("--num-prompts", type=int, default=64)
-    ap.add_argument("--concurrency", type=int, default=16)
-    ap.add_argument("--input-len", type=int, default=128)
-    ap.add_argument("--output-len", type=int, default=64)
-    ap.add_argument("--vocab-size", type=int, default=32000)
-    ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--timeout", type=float, default=1800.0)
-    args = ap.parse_args(argv)
-    print(json.dumps(asyncio.run(run(args))))
-
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vllm_distributed_amd.entrypoints.bench_serve import main  # noqa: E402
 
 if __name__ == "__main__":
     main()

@@ -165,3 +165,49 @@ def test_chat_and_complete_clients_stream_from_a_server():
     a.dispatch_function(a, transport=transport, out=out)
     assert out.getvalue() == "hi there\n"
     assert [m["role"] for m in seen[-1][1]["messages"]] == ["system", "user"]
+
+
+@pytest.mark.slow
+def test_real_socket_server_with_bench_serve_and_clients():
+    """`launch.py serve` on a real port (uvicorn, engine core in its own process),
+    driven by `launch.py bench serve` and the `complete` client."""
+    import os
+    import subprocess
+    import sys
+    import time
+    from vllm_distributed_amd.utils import get_open_port
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = get_open_port()
+    env = dict(os.environ, VLLM_LOGGING_LEVEL="WARNING", OMP_NUM_THREADS="2")
+    server = subprocess.Popen(
+        [sys.executable, os.path.join(root, "launch.py"), "serve", "llama-tiny", "--device", "cpu", "--dtype", "float32",
+         "--max-model-len", "256", "--block-size", "16", "--num-gpu-blocks-override", "256", "--host", "127.0.0.1",
+         "--port", str(port), "--served-model-name", "tiny", "--uvicorn-log-level", "warning"],
+        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        url = f"http://127.0.0.1:{port}"
+        deadline = time.time() + 120
+        while True:
+            try:
+                if httpx.get(url + "/health", timeout=2).status_code == 200:
+                    break
+            except httpx.HTTPError:
+                pass
+            assert server.poll() is None, server.stdout.read()[-3000:]
+            assert time.time() < deadline, "server did not come up"
+            time.sleep(0.5)
+        r = subprocess.run([sys.executable, os.path.join(root, "launch.py"), "bench", "serve", "--base-url", url,
+                            "--num-prompts", "8", "--concurrency", "4", "--input-len", "16", "--output-len", "8",
+                            "--vocab-size", "500"], env=env, capture_output=True, text=True, timeout=180)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert j["num_prompts"] == 8 and j["output_tokens_per_s"] > 0 and j["ttft_p50_ms"] > 0
+        r = subprocess.run([sys.executable, os.path.join(root, "launch.py"), "complete", "--url", url + "/v1",
+                            "-q", "hello", "--max-tokens", "5"], env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    finally:
+        server.terminate()
+        try:
+            server.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            server.kill()

@@ -129,7 +129,11 @@ def cmd_run_batch(args: argparse.Namespace) -> None:
 
 
 def cmd_bench(args: argparse.Namespace) -> None:
-    """Offline throughput / latency on synthetic prompts through the engine."""
+    """Offline throughput / latency on synthetic prompts through the engine, or the HTTP client benchmark."""
+    if args.bench_type == "serve":
+        from . import bench_serve
+        print(json.dumps(bench_serve.run_sync(args)))
+        return
     import numpy as np
     from ..engine.llm_engine import LLMEngine
     from ..sampling_params import SamplingParams
@@ -170,7 +174,10 @@ def build_parser() -> argparse.ArgumentParser:
     EngineArgs.add_cli_args(pb)
     pb.set_defaults(dispatch_function=cmd_run_batch)
     pbe = sub.add_parser("bench", help="offline benchmark on synthetic prompts")
-    pbe.add_argument("bench_type", choices=["throughput", "latency"], nargs="?", default="throughput")
+    pbe.add_argument("bench_type", choices=["throughput", "latency", "serve"], nargs="?", default="throughput",
+                     help="throughput / latency: offline through the engine; serve: HTTP client against --base-url")
+    from . import bench_serve
+    bench_serve.add_args(pbe)
     pbe.add_argument("--num-prompts", type=int, default=64)
     pbe.add_argument("--input-len", type=int, default=128)
     pbe.add_argument("--output-len", type=int, default=64)
