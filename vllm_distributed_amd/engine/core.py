@@ -29,7 +29,8 @@ class EngineDeadError(RuntimeError):
 
 
 class StepTimer:
-    """Rolling per-step breakdown: schedule / execute (RPC + forward + sample) / update."""
+    """Rolling per-step breakdown: schedule / execute (RPC + forward + sample) / update;
+    ``worker_comm`` (time inside collectives, part of forward) when it is being measured."""
 
     def __init__(self) -> None:
         self.n = 0
@@ -139,8 +140,9 @@ class EngineCore:
 
     def _record(self, ts: float, te: float, tu: float, out: Optional[ModelRunnerOutput]) -> None:
         wt = (out.timing if out is not None else None) or {}
+        extra = {"worker_comm": wt["comm"]} if "comm" in wt else {}      # only with VDAMD_TIME_COLLECTIVES
         self.timer.add(schedule=ts, execute=te, update=tu, worker_prepare=wt.get("prepare", 0.0),
-                       worker_forward=wt.get("forward", 0.0), worker_sample=wt.get("sample", 0.0))
+                       worker_forward=wt.get("forward", 0.0), worker_sample=wt.get("sample", 0.0), **extra)
 
     def _step_with_batch_queue(self) -> List[EngineCoreOutput]:
         """Fill the pipeline before draining it: schedule a new batch whenever
@@ -170,6 +172,8 @@ class EngineCore:
         tot["update"] += t2 - t1
         for k in ("prepare", "forward", "sample"):
             tot["worker_" + k] += wt.get(k, 0.0)
+        if "comm" in wt:
+            tot["worker_comm"] = tot.get("worker_comm", 0.0) + wt["comm"]
         return res
 
     # ----------------------------------------------------------------- admin

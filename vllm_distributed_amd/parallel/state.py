@@ -56,6 +56,54 @@ class CollectiveOrderChecker:
             raise RuntimeError(f"collective order mismatch in group {group.name}: {gathered}")
 
 
+class CommTimer:
+    """Time spent in collectives per step (``VDAMD_TIME_COLLECTIVES=1``): GPU
+    collectives are bracketed with events on the stream they run on, host
+    (gloo) collectives with the wall clock.  ``drain`` waits for the recorded
+    events, so this is a measurement mode, not something to leave on."""
+    enabled = False
+    _events: List[Tuple["torch.cuda.Event", "torch.cuda.Event"]] = []
+    _host_seconds = 0.0
+
+    @classmethod
+    def configure(cls) -> None:
+        cls.enabled = bool(envs.VDAMD_TIME_COLLECTIVES)
+
+    @classmethod
+    def drain(cls) -> float:
+        total = cls._host_seconds
+        cls._host_seconds = 0.0
+        events, cls._events = cls._events, []
+        if events:
+            events[-1][1].synchronize()
+            total += sum(a.elapsed_time(b) for a, b in events) * 1e-3
+        return total
+
+
+def _timed(fn):
+    """Collective wrapper feeding ``CommTimer`` (a no-op unless it is enabled)."""
+    import functools
+    import time as _time
+
+    @functools.wraps(fn)
+    def wrapper(self, x, *args, **kwargs):
+        if not CommTimer.enabled or self.world_size == 1:
+            return fn(self, x, *args, **kwargs)
+        on_gpu = isinstance(x, torch.Tensor) and x.is_cuda and not torch.cuda.is_current_stream_capturing()
+        if on_gpu:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = fn(self, x, *args, **kwargs)
+            b.record()
+            CommTimer._events.append((a, b))
+            return out
+        t0 = _time.perf_counter()
+        out = fn(self, x, *args, **kwargs)
+        CommTimer._host_seconds += _time.perf_counter() - t0
+        return out
+    return wrapper
+
+
 class GroupCoordinator:
     def __init__(self, name: str, ranks: Sequence[int], global_rank: int,
                  device_group: Optional[Any], cpu_group: Optional[Any],
@@ -256,6 +304,9 @@ class GroupCoordinator:
         else:
             dist.recv(x, src=self.ranks[src], group=self.device_group)
         return x
+
+    all_reduce, all_reduce_, all_gather = _timed(all_reduce), _timed(all_reduce_), _timed(all_gather)
+    reduce_scatter, broadcast, send = _timed(reduce_scatter), _timed(broadcast), _timed(send)
 
     def broadcast_object(self, obj: Any = None, src: int = 0) -> Any:
         if self.world_size == 1:

@@ -24,7 +24,7 @@ from ..utils.tracing import trace_range
 from ..models.layers.attention import AttentionMetadata, set_forward_context
 from ..models.loader import load_model
 from ..models.utils import IntermediateTensors
-from ..parallel.state import get_pp_group, get_tp_group
+from ..parallel.state import CommTimer, get_pp_group, get_tp_group
 from ..utils import cdiv
 from .input_batch import InputBatch
 
@@ -135,6 +135,7 @@ class ModelRunner:
         self._pending: List[PendingSample] = []
         self.defer_output = False        # set by in-process executors under async scheduling
         self.timing_enabled = vllm_config.observability_config.collect_step_timing
+        CommTimer.configure()
 
     # ------------------------------------------------------------------ setup
     def load_model(self) -> None:
@@ -373,6 +374,8 @@ class ModelRunner:
                 host_tokens = tokens
         t3 = time.perf_counter()
         timing = {"prepare": t1 - t0, "forward": t2 - t1, "sample": t3 - t2} if self.timing_enabled else None
+        if timing is not None and CommTimer.enabled:
+            timing["comm"] = CommTimer.drain()
         pending = PendingSample(self, so.step_id, p["req_ids"], sel, rows_sel, pos_sel, host_tokens, event,
                                 logprobs_sel, timing)
         self._pending.append(pending)
