@@ -102,6 +102,9 @@ def main() -> None:
         raise SystemExit(f"--gpus {n} needs one rank per GPU: launch with "
                          f"`python -m torch.distributed.run --nproc-per-node {n} bench.py --gpus {n} ...`")
     os.environ.setdefault("VLLM_LOGGING_LEVEL", "INFO" if rank == 0 else "WARNING")
+    if n > 1:
+        # report the time inside collectives next to the step time (event pairs, no extra syncs)
+        os.environ.setdefault("VDAMD_TIME_COLLECTIVES", "1")
 
     from vllm_distributed_amd.engine.arg_utils import EngineArgs
     from vllm_distributed_amd.engine.llm_engine import LLMEngine

@@ -108,7 +108,7 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     # MoE: average rows per expert (4-bit experts; twice that for 16-bit ones) up to which a step
     # runs the grouped HIP GEMMs; above it each expert gets its own library GEMM.
     "VDAMD_MOE_GROUPED_MAX_ROWS": _int("VDAMD_MOE_GROUPED_MAX_ROWS", 512),
-    # Measure the time spent in collectives per step (adds a sync per step; eager steps only).
+    # Measure the time spent in collectives per step (event pairs around each call; eager steps only).
     "VDAMD_TIME_COLLECTIVES": _bool("VDAMD_TIME_COLLECTIVES", False),
     # Capture decode steps in hipGraphs.
     "VDAMD_USE_HIP_GRAPH": _bool("VDAMD_USE_HIP_GRAPH", True),

@@ -59,8 +59,8 @@ class CollectiveOrderChecker:
 class CommTimer:
     """Time spent in collectives per step (``VDAMD_TIME_COLLECTIVES=1``): GPU
     collectives are bracketed with events on the stream they run on, host
-    (gloo) collectives with the wall clock.  ``drain`` waits for the recorded
-    events, so this is a measurement mode, not something to leave on."""
+    (gloo) collectives with the wall clock.  Collectives on a side stream that
+    overlap compute are counted at their own duration."""
     enabled = False
     _events: List[Tuple["torch.cuda.Event", "torch.cuda.Event"]] = []
     _host_seconds = 0.0
@@ -71,12 +71,20 @@ class CommTimer:
 
     @classmethod
     def drain(cls) -> float:
+        """Seconds spent in the collectives that have completed since the last
+        call.  Never waits: events still in flight are counted by a later call."""
         total = cls._host_seconds
         cls._host_seconds = 0.0
-        events, cls._events = cls._events, []
-        if events:
-            events[-1][1].synchronize()
-            total += sum(a.elapsed_time(b) for a, b in events) * 1e-3
+        try:
+            done = 0
+            for a, b in cls._events:
+                if not b.query():
+                    break
+                total += a.elapsed_time(b) * 1e-3
+                done += 1
+            del cls._events[:done]
+        except RuntimeError:      # a measurement must never take a step down
+            cls._events = []
         return total
 
 
