@@ -21,14 +21,23 @@ SHAPES = [("tp1 qkv", 10240, 8192), ("tp1 o", 8192, 8192), ("tp1 gate_up", 57344
           ("tp8 o", 8192, 1024), ("tp8 gate_up", 7168, 8192), ("tp8 down", 8192, 3584)]
 
 
+SHAPES_8B = [("8b qkv", 6144, 4096), ("8b o", 4096, 4096), ("8b gate_up", 28672, 4096), ("8b down", 4096, 14336)]
+
+
 def timeit(fn, ws, iters=30):
+    """Per-call time inside a captured graph (how decode steps run): no launch gaps."""
     for i in range(3):
         fn(ws[i % len(ws)])
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(iters):
+            fn(ws[i % len(ws)])
+    g.replay()
+    torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for i in range(iters):
-        fn(ws[i % len(ws)])
+    g.replay()
     b.record()
     torch.cuda.synchronize()
     return a.elapsed_time(b) / iters * 1e3
@@ -37,11 +46,12 @@ def timeit(fn, ws, iters=30):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sweep", action="store_true")
+    ap.add_argument("--shapes", choices=["70b", "8b"], default="70b")
     args = ap.parse_args()
     assert ops.hip_available()
     from vllm_distributed_amd.ops import hip
     print(f"{'shape':14s} {'M':>4s} {'skinny us':>10s} {'TB/s':>6s} {'lib us':>9s} {'TB/s':>6s} {'speedup':>8s}  choice")
-    for name, n, k in SHAPES:
+    for name, n, k in (SHAPES if args.shapes == "70b" else SHAPES_8B):
         nw = max(2, min(8, int(3e9 // (n * k * 2))))
         ws = [torch.randn(n, k, device="cuda", dtype=torch.bfloat16) * 0.02 for _ in range(nw)]
         for m in (1, 16, 32, 64, 128):

@@ -453,12 +453,17 @@ def skinny_choose(m: int, n: int, k: int) -> Tuple[int, int]:
     """``(ntw, ksplit)``: output tiles per wave and K split.  Fewer tiles per
     wave when N alone cannot fill the chip; then K is split until there are
     about two workgroups per CU, keeping >= 4 column blocks per workgroup.
-    Long-K shapes (the down projection) use the measured optimum."""
+    Long-K shapes (the down projection) and wide short-K ones (an 8B-class
+    gate_up) use the measured optimum."""
     tiles = n // 16
     if k >= 2 * n and k >= 8192:
+        if tiles <= 256:                      # e.g. 4096 x 14336: one tile per wave, 64 workgroups x 8
+            return 1, max(1, min(8, (k // 128) // 4))
         ntw = 1 if m <= 32 else (4 if m <= 64 else 2)
         wgs = (tiles + 4 * ntw - 1) // (4 * ntw)
         return ntw, max(1, min(4 if m <= 32 else 8, (1024 + wgs - 1) // wgs, (k // 128) // 4))
+    if m <= 16 and n >= 16384 and k <= 4096:
+        return 2, max(1, min(4, (k // 128) // 4))
     ntw = 4 if m <= 64 else 2
     while ntw > 1 and (tiles + 4 * ntw - 1) // (4 * ntw) < 512:
         ntw //= 2
@@ -468,10 +473,16 @@ def skinny_choose(m: int, n: int, k: int) -> Tuple[int, int]:
 
 
 def skinny_profitable(m: int, n: int, k: int) -> bool:
-    """Where this kernel beats the library GEMM on MI355X (measured,
-    benchmarks/skinny_gemm_bench.py): long reductions into a narrow output,
-    for which the library's short-batch kernels reach only 2.3-4.8 TB/s."""
-    return m <= SKINNY_MAX_M and k >= 2 * n and k >= 8192
+    """Where this kernel beats the library GEMM on MI355X (measured in captured
+    graphs, benchmarks/skinny_gemm_bench.py): long reductions into a narrow
+    output, for which the library's short-batch kernels reach only 1.6-4.8 TB/s
+    (from 24 rows up when the output is 4096 wide or less - below that the
+    two are level), and very wide outputs over a short reduction at <= 16 rows."""
+    if m > SKINNY_MAX_M:
+        return False
+    if k >= 2 * n and k >= 8192:
+        return m >= 24 or n > 4096
+    return m <= 16 and n >= 16384 and k <= 4096
 
 
 def skinny_gemm(x: torch.Tensor, w: torch.Tensor, ntw: Optional[int] = None, ksplit: Optional[int] = None,
