@@ -337,14 +337,14 @@ def w4_choose_variant(m: int, n: int, k: int) -> int:
     override = os.environ.get("VDAMD_W4_VARIANT")
     if override is not None:
         return int(override)
-    if m <= 16:
+    if m <= 16 or (m <= 32 and n < 32768):      # measured inside a captured graph on 70B / 480B projections
         return 0
     wgs = ((n // 16 + 15) // 16) * max(1, (k // 128) // 4)
     return 1 if wgs >= 128 else 0
 
 
 def w4_choose_ksplit(m: int, n: int, k: int, variant: int = 0) -> int:
-    """Split K until ~3 workgroups per CU exist (variant 0: 64 rows per
+    """Split K until ~2-3 workgroups per CU exist (variant 0: 64 rows per
     workgroup, at least two 128-column blocks per wave; variant 1: 256 output
     rows per workgroup up to 64 batch rows, 128 above (row chunks of <= 128),
     at least four blocks per workgroup)."""
@@ -357,7 +357,7 @@ def w4_choose_ksplit(m: int, n: int, k: int, variant: int = 0) -> int:
     mt = min(4, (m + 15) // 16)
     mz = (m + 16 * mt - 1) // (16 * mt)
     base = ((n // 16 + 3) // 4) * mz
-    return max(1, min((768 + base - 1) // base, (k // 128) // 8))
+    return max(1, min((512 + base - 1) // base, (k // 128) // 8))
 
 
 def w4_dequant(qw: torch.Tensor, sz: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
