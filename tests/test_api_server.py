@@ -119,6 +119,23 @@ def test_server_endpoints_end_to_end(frontend_mp):
                 assert ev[-1]["usage"]["completion_tokens"] == 12
                 assert (await c.post("/v1/completions", headers=hdr,
                                      json={"model": "other", "prompt": "x"})).status_code == 404
+                # logit edits travel with the request: a +100 bias pins every token, the allow list bounds them
+                r6 = await c.post("/v1/completions", headers=hdr, json={
+                    "prompt": "hello", "max_tokens": 4, "temperature": 0, "ignore_eos": True, "logprobs": 0,
+                    "logit_bias": {"65": 100}})
+                assert r6.status_code == 200, r6.text
+                assert r6.json()["choices"][0]["text"] == "AAAA"
+                r7 = await c.post("/v1/chat/completions", headers=hdr, json={
+                    "messages": [{"role": "user", "content": "hi"}], "max_tokens": 6, "temperature": 0,
+                    "ignore_eos": True, "allowed_token_ids": [66, 67], "bad_words": ["B"]})
+                assert r7.status_code == 200, r7.text
+                assert r7.json()["choices"][0]["message"]["content"] == "CCCCCC"
+                r8 = await c.post("/v1/completions", headers=hdr, json={
+                    "prompt": "x" * 50, "max_tokens": 2, "temperature": 0, "truncate_prompt_tokens": 8})
+                assert r8.status_code == 200 and r8.json()["usage"]["prompt_tokens"] == 8
+                bad = await c.post("/v1/completions", headers=hdr, json={
+                    "prompt": "x", "max_tokens": 2, "logit_bias": {"99999999": 5}})
+                assert bad.status_code == 400, bad.text
                 t = (await c.post("/tokenize", json={"prompt": "abc"})).json()
                 assert t["count"] == len(t["tokens"])
                 d = (await c.post("/detokenize", json={"tokens": t["tokens"]})).json()

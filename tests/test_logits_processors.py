@@ -1,0 +1,106 @@
+"""Per-request logit edits: logit_bias, allowed_token_ids, bad_words, min_tokens and
+prompt truncation, through the engine on CPU (llama-tiny, byte tokenizer) and over
+HTTP.  These mirror the OpenAI / vLLM request fields of the same names, which the
+reference serves through vLLM's sampler (reference src/launch.py:413-457 brings up
+that app unchanged)."""
+import pytest
+
+from vllm_distributed_amd import LLM, SamplingParams
+from vllm_distributed_amd.parallel import state as pstate
+
+KW = dict(model="llama-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,
+          num_gpu_blocks_override=64)
+
+
+@pytest.fixture(scope="module")
+def llm():
+    pstate.destroy_model_parallel()
+    m = LLM(**KW)
+    yield m
+    m.shutdown()
+    pstate.destroy_model_parallel()
+
+
+def _gen(llm, sp, prompt="hello world"):
+    return llm.generate([prompt], sp)[0]
+
+
+def test_sampling_params_validation():
+    sp = SamplingParams(logit_bias={"5": 500, 7: -3.5})
+    assert sp.logit_bias == {5: 100.0, 7: -3.5} and sp.has_logit_adjust
+    assert not SamplingParams().has_logit_adjust
+    assert not SamplingParams(min_tokens=3).has_logit_adjust        # nothing to ban until the engine fills the list
+    with pytest.raises(ValueError):
+        SamplingParams(logit_bias={"x": 1})
+    with pytest.raises(ValueError):
+        SamplingParams(allowed_token_ids=[])
+    with pytest.raises(ValueError):
+        SamplingParams(truncate_prompt_tokens=0)
+    with pytest.raises(ValueError):
+        SamplingParams(logit_bias={10 ** 9: 1.0}).check_vocab(256)
+
+
+def test_logit_bias_forces_and_forbids_tokens(llm):
+    base = _gen(llm, SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True)).outputs[0].token_ids
+    forced = _gen(llm, SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True, logit_bias={42: 100.0}))
+    assert forced.outputs[0].token_ids == [42] * 6
+    first = base[0]
+    avoided = _gen(llm, SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True, logit_bias={first: -100.0}))
+    assert avoided.outputs[0].token_ids[0] != first
+    # a biased request next to an unbiased one in the same batch leaves the other untouched
+    outs = llm.generate(["hello world", "hello world"],
+                        [SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True),
+                         SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True, logit_bias={42: 100.0})])
+    assert outs[0].outputs[0].token_ids == base and outs[1].outputs[0].token_ids == [42] * 6
+
+
+def test_allowed_token_ids_restrict_greedy_and_sampled_outputs(llm):
+    allowed = [3, 17, 99]
+    g = _gen(llm, SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True, allowed_token_ids=allowed))
+    assert set(g.outputs[0].token_ids) <= set(allowed)
+    s = _gen(llm, SamplingParams(temperature=1.5, seed=3, max_tokens=24, ignore_eos=True, allowed_token_ids=allowed))
+    assert set(s.outputs[0].token_ids) <= set(allowed) and len(s.outputs[0].token_ids) == 24
+    with pytest.raises(ValueError):
+        _gen(llm, SamplingParams(max_tokens=2, allowed_token_ids=[10 ** 7]))
+
+
+def test_bad_words_single_and_multi_token(llm):
+    sp0 = SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True)
+    base = _gen(llm, sp0).outputs[0].token_ids
+    # single token: the greedy first choice can never appear
+    one = _gen(llm, SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True, bad_words_token_ids=[[base[0]]]))
+    assert base[0] not in one.outputs[0].token_ids
+    # two tokens: the sequence (base[0], base[1]) is broken at its second token, the first stays
+    two = _gen(llm, SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True,
+                                   bad_words_token_ids=[[base[0], base[1]]]))
+    t = two.outputs[0].token_ids
+    assert t[0] == base[0] and t[1] != base[1]
+    assert all(not (a == base[0] and b == base[1]) for a, b in zip(t, t[1:]))
+    # the string form is tokenised by the engine (byte tokenizer: one token per byte)
+    word = bytes([base[0] % 256]).decode("latin-1")
+    if word.isascii() and word.strip():
+        s = _gen(llm, SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True, bad_words=[word]))
+        assert base[0] not in s.outputs[0].token_ids
+
+
+def test_min_tokens_holds_back_eos_and_stop_tokens(llm):
+    eos = llm.engine.eos_token_id
+    assert eos is not None
+    # EOS is made overwhelmingly likely: it may only appear once min_tokens outputs exist
+    o = _gen(llm, SamplingParams(temperature=0.0, max_tokens=10, min_tokens=4, logit_bias={eos: 100.0}))
+    ids = o.outputs[0].token_ids
+    assert len(ids) == 5 and eos not in ids[:4] and ids[4] == eos and o.outputs[0].finish_reason == "stop"
+    # same for a stop token id
+    o = _gen(llm, SamplingParams(temperature=0.0, max_tokens=10, min_tokens=3, stop_token_ids=[77],
+                                 ignore_eos=True, logit_bias={77: 100.0}))
+    ids = o.outputs[0].token_ids
+    assert len(ids) == 4 and 77 not in ids[:3] and ids[3] == 77
+
+
+def test_truncate_prompt_tokens_keeps_the_tail(llm):
+    long = "x" * 40 + "hello world"
+    sp = SamplingParams(temperature=0.0, max_tokens=5, ignore_eos=True)
+    want = llm.generate([{"prompt_token_ids": llm.engine.tokenizer.encode(long)[-11:]}], sp)[0]
+    got = _gen(llm, SamplingParams(temperature=0.0, max_tokens=5, ignore_eos=True, truncate_prompt_tokens=11), long)
+    assert len(got.prompt_token_ids) == 11
+    assert got.outputs[0].token_ids == want.outputs[0].token_ids

@@ -44,3 +44,29 @@ def test_model_family_on_gpu_tracks_cpu_reference(model, tmp_path):
             assert len(common) >= 8, (model, step, sorted(la), sorted(lb))
             # bf16 router logits can flip a near-tied expert choice on the MoE models: allow for it
             assert max(abs(la[t] - lb[t]) for t in common) < 0.3, (model, step)
+
+
+def test_logit_edits_on_gpu_with_graph_decode():
+    """logit_bias / allow list / bad words / min_tokens on bf16 device logits, in a batch
+    that mixes edited and plain requests while decode runs from a captured graph."""
+    pstate.destroy_model_parallel()
+    llm = LLM(model="llama-tiny", dtype="bfloat16", gpu_memory_utilization=0.3, max_model_len=256,
+              num_gpu_blocks_override=64, max_num_seqs=8)
+    eos = llm.engine.eos_token_id
+    greedy = dict(temperature=0.0, max_tokens=6, ignore_eos=True)
+    base = llm.generate([PROMPTS[0]], SamplingParams(**greedy))[0].outputs[0].token_ids
+    outs = llm.generate(
+        [PROMPTS[0]] * 5,
+        [SamplingParams(**greedy),
+         SamplingParams(**greedy, logit_bias={42: 100.0}),
+         SamplingParams(**greedy, allowed_token_ids=[3, 17, 99]),
+         SamplingParams(**greedy, bad_words_token_ids=[[base[0]]]),
+         SamplingParams(temperature=0.0, max_tokens=10, min_tokens=4, logit_bias={eos: 100.0})])
+    ids = [o.outputs[0].token_ids for o in outs]
+    assert ids[0] == base
+    assert ids[1] == [42] * 6
+    assert set(ids[2]) <= {3, 17, 99}
+    assert base[0] not in ids[3]
+    assert len(ids[4]) == 5 and eos not in ids[4][:4] and ids[4][4] == eos
+    llm.shutdown()
+    pstate.destroy_model_parallel()

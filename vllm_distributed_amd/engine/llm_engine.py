@@ -81,10 +81,14 @@ class LLMEngine:
             ids = list(prompt)
         ids = list(ids)
         max_len = self.model_config.max_model_len
+        params = params.clone()          # the fields filled below are per request
+        if params.truncate_prompt_tokens is not None:
+            ids = ids[-params.truncate_prompt_tokens:]
         if params.max_tokens is None:
-            params = params.clone()
             params.max_tokens = max(1, max_len - len(ids))
         vocab = self.model_config.vocab_size
+        self._resolve_token_lists(params)
+        params.check_vocab(vocab)
         if any(t < 0 or t >= vocab for t in ids):
             raise ValueError("prompt contains token ids outside the model vocabulary")
         req = Request(request_id, ids, params, self.eos_token_id, arrival_time, priority, text, lora_request)
@@ -92,6 +96,26 @@ class LLMEngine:
         self.core.add_request(req)
         self.states[request_id] = _ReqState(req, detok, text)
         return request_id
+
+    def _resolve_token_lists(self, params: SamplingParams) -> None:
+        """Fill the token-id forms of ``bad_words`` and of the tokens ``min_tokens`` holds back."""
+        if params.bad_words:
+            words = list(params.bad_words_token_ids or [])
+            for w in params.bad_words:
+                # a word reads differently at the start of a text and after a space: ban both spellings
+                for variant in (w.lstrip(), " " + w.lstrip()):
+                    try:
+                        t = list(self.tokenizer.encode(variant, add_special_tokens=False))
+                    except TypeError:
+                        t = list(self.tokenizer.encode(variant))
+                    if t and t not in words:
+                        words.append(t)
+            params.bad_words_token_ids = words
+        if params.min_tokens > 0:
+            ban = set(params.stop_token_ids)
+            if self.eos_token_id is not None:
+                ban.add(int(self.eos_token_id))
+            params.min_tokens_ban_ids = sorted(ban)
 
     def abort_request(self, request_ids: Union[str, Iterable[str]]) -> None:
         if isinstance(request_ids, str):

@@ -71,6 +71,10 @@ class CompletionRequest(_Base):
     ignore_eos: bool = False
     min_tokens: int = 0
     skip_special_tokens: bool = True
+    logit_bias: Optional[Dict[str, float]] = None
+    allowed_token_ids: Optional[List[int]] = None
+    bad_words: Optional[List[str]] = None
+    truncate_prompt_tokens: Optional[int] = None
     priority: int = 0
 
 
@@ -110,6 +114,10 @@ class ChatCompletionRequest(_Base):
     add_generation_prompt: bool = True
     chat_template: Optional[str] = None
     chat_template_kwargs: Optional[Dict[str, Any]] = None
+    logit_bias: Optional[Dict[str, float]] = None
+    allowed_token_ids: Optional[List[int]] = None
+    bad_words: Optional[List[str]] = None
+    truncate_prompt_tokens: Optional[int] = None
     priority: int = 0
 
 
@@ -256,7 +264,9 @@ def _sampling_params(req, default_max: Optional[int], max_model_len: int, logpro
         frequency_penalty=req.frequency_penalty or 0.0, repetition_penalty=req.repetition_penalty or 1.0,
         seed=req.seed, max_tokens=max_tokens, min_tokens=req.min_tokens, stop=req.stop,
         stop_token_ids=req.stop_token_ids, ignore_eos=req.ignore_eos, logprobs=logprobs,
-        skip_special_tokens=req.skip_special_tokens)
+        skip_special_tokens=req.skip_special_tokens, logit_bias=req.logit_bias,
+        allowed_token_ids=req.allowed_token_ids, bad_words=req.bad_words,
+        truncate_prompt_tokens=req.truncate_prompt_tokens)
 
 
 def _usage(n_prompt: int, n_out: int) -> dict:

@@ -2,7 +2,7 @@
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import List, Optional, Union
+from typing import Dict, List, Optional, Union
 
 
 @dataclass
@@ -25,6 +25,13 @@ class SamplingParams:
     skip_special_tokens: bool = True
     include_stop_str_in_output: bool = False
     detokenize: bool = True
+    logit_bias: Optional[Dict[int, float]] = None        # token id -> additive bias, clamped to [-100, 100]
+    allowed_token_ids: Optional[List[int]] = None        # every other token is masked out
+    bad_words: Optional[List[str]] = None                # never generated (tokenised by the engine front-end)
+    bad_words_token_ids: Optional[List[List[int]]] = None
+    truncate_prompt_tokens: Optional[int] = None         # keep only the last k prompt tokens
+    # filled by the engine: EOS + stop token ids, masked until ``min_tokens`` outputs exist
+    min_tokens_ban_ids: List[int] = field(default_factory=list)
 
     def __post_init__(self) -> None:
         if self.temperature < 0:
@@ -52,6 +59,27 @@ class SamplingParams:
         self.stop_token_ids = list(self.stop_token_ids or [])
         if self.temperature < 1e-5:      # greedy: the other knobs are no-ops
             self.temperature = 0.0
+        if self.logit_bias:
+            try:                         # JSON object keys arrive as strings
+                self.logit_bias = {int(k): min(100.0, max(-100.0, float(v))) for k, v in self.logit_bias.items()}
+            except (TypeError, ValueError) as e:
+                raise ValueError("logit_bias must map token ids to numbers") from e
+            if any(k < 0 for k in self.logit_bias):
+                raise ValueError("logit_bias token ids must be >= 0")
+        else:
+            self.logit_bias = None
+        if self.allowed_token_ids is not None:
+            self.allowed_token_ids = [int(t) for t in self.allowed_token_ids]
+            if not self.allowed_token_ids or min(self.allowed_token_ids) < 0:
+                raise ValueError("allowed_token_ids must be a non-empty list of token ids >= 0")
+        if isinstance(self.bad_words, str):
+            self.bad_words = [self.bad_words]
+        if self.bad_words_token_ids is not None:
+            self.bad_words_token_ids = [[int(t) for t in w] for w in self.bad_words_token_ids if len(w)]
+        if self.truncate_prompt_tokens is not None and self.truncate_prompt_tokens < 1:
+            raise ValueError("truncate_prompt_tokens must be >= 1")
+        if self.min_tokens < 0:
+            raise ValueError("min_tokens must be >= 0")
 
     @property
     def greedy(self) -> bool:
@@ -61,6 +89,20 @@ class SamplingParams:
     def has_penalties(self) -> bool:
         return (self.presence_penalty != 0.0 or self.frequency_penalty != 0.0
                 or self.repetition_penalty != 1.0)
+
+    @property
+    def has_logit_adjust(self) -> bool:
+        """True when logits must be edited before sampling (bias, allow / ban lists, min_tokens)."""
+        return bool(self.logit_bias or self.allowed_token_ids is not None or self.bad_words_token_ids
+                    or (self.min_tokens > 0 and self.min_tokens_ban_ids))
+
+    def check_vocab(self, vocab_size: int) -> None:
+        ids = list(self.logit_bias or ()) + list(self.allowed_token_ids or ())
+        for w in self.bad_words_token_ids or ():
+            ids.extend(w)
+        if any(t >= vocab_size for t in ids):
+            raise ValueError(f"a token id in logit_bias / allowed_token_ids / bad_words is outside the "
+                             f"vocabulary of {vocab_size}")
 
     def clone(self) -> "SamplingParams":
         import copy

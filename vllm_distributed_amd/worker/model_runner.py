@@ -457,8 +457,9 @@ class ModelRunner:
         b = self.batch
         temps = b.temperature[rows]
         need_lp = int(b.num_logprobs[rows].max()) if len(rows) else -1
+        adjust = bool(b.has_adjust[rows].any())
         if (self.tp.world_size > 1 and need_lp < 0 and not temps.any() and not b.has_penalty[rows].any()
-                and hasattr(self.model, "compute_greedy_tokens")):
+                and not adjust and hasattr(self.model, "compute_greedy_tokens")):
             # all-greedy batch under TP: argmax per vocabulary shard, gather only the winners
             return self.model.compute_greedy_tokens(hidden).to(torch.int32), None
         logits = self.model.compute_logits(hidden)
@@ -466,6 +467,8 @@ class ModelRunner:
             for pend in list(self._pending):      # penalties count every token generated so far
                 pend.get()
             logits = self._apply_penalties(logits.float(), rows)
+        if adjust:
+            logits = self._adjust_logits(logits.float(), rows)
         if not temps.any():
             tokens = ops.argmax(logits)
         else:
@@ -492,6 +495,60 @@ class ModelRunner:
                     d.setdefault(t_id, t_lp)
                 logprobs.append([d])
         return tokens.to(torch.int32), logprobs
+
+    def _adjust_logits(self, logits: torch.Tensor, rows: np.ndarray) -> torch.Tensor:
+        """Per-request logit edits, in the order bias -> allow list -> ban lists:
+        ``logit_bias`` adds, ``allowed_token_ids`` masks everything else,
+        ``bad_words`` bans a word's last token while the generated tail spells
+        the rest of it, and ``min_tokens`` bans EOS / stop tokens until enough
+        tokens exist.  The edits are gathered on the host into one sparse
+        update so the device sees two index kernels whatever the batch mix."""
+        b = self.batch
+        v = logits.shape[-1]
+        neg = float("-inf")
+        add_r, add_c, add_v = [], [], []
+        ban_r, ban_c = [], []
+        allow = []
+        synced = False
+        for j, r in enumerate(rows.tolist()):
+            if not b.has_adjust[r]:
+                continue
+            sp = b.params[r]
+            if sp.logit_bias:
+                for t, val in sp.logit_bias.items():
+                    if t < v:
+                        add_r.append(j); add_c.append(t); add_v.append(val)
+            if sp.allowed_token_ids is not None:
+                allow.append((j, [t for t in sp.allowed_token_ids if t < v]))
+            n_out = int(b.num_tokens[r]) - int(b.num_prompt_tokens[r])
+            if sp.min_tokens > 0 and n_out < sp.min_tokens:
+                for t in sp.min_tokens_ban_ids:
+                    if t < v:
+                        ban_r.append(j); ban_c.append(t)
+            if sp.bad_words_token_ids:
+                if not synced:                      # the tail must hold every token generated so far
+                    for pend in list(self._pending):
+                        pend.get()
+                    synced = True
+                nt = int(b.num_tokens[r])
+                npt = int(b.num_prompt_tokens[r])
+                for w in sp.bad_words_token_ids:
+                    k = len(w) - 1
+                    if w[-1] >= v or k > nt - npt:
+                        continue                    # the prefix has to come from generated tokens
+                    if k == 0 or b.token_ids[r, nt - k:nt].tolist() == list(w[:-1]):
+                        ban_r.append(j); ban_c.append(w[-1])
+        dev = logits.device
+        if add_r:
+            logits.index_put_((torch.tensor(add_r, device=dev), torch.tensor(add_c, device=dev)),
+                              torch.tensor(add_v, dtype=logits.dtype, device=dev), accumulate=True)
+        for j, ids in allow:
+            keep = logits[j, ids].clone()
+            logits[j].fill_(neg)
+            logits[j, ids] = keep
+        if ban_r:
+            logits[torch.tensor(ban_r, device=dev), torch.tensor(ban_c, device=dev)] = neg
+        return logits
 
     def _apply_penalties(self, logits: torch.Tensor, rows: np.ndarray) -> torch.Tensor:
         b = self.batch
