@@ -136,6 +136,17 @@ def test_server_endpoints_end_to_end(frontend_mp):
                 bad = await c.post("/v1/completions", headers=hdr, json={
                     "prompt": "x", "max_tokens": 2, "logit_bias": {"99999999": 5}})
                 assert bad.status_code == 400, bad.text
+                # echo + logprobs scores the prompt too (the evaluation-harness form); prompt_logprobs is vLLM's field
+                r9 = await c.post("/v1/completions", headers=hdr, json={
+                    "prompt": [1, 2, 3, 4, 5], "max_tokens": 1, "temperature": 0, "echo": True, "logprobs": 1})
+                lp = r9.json()["choices"][0]["logprobs"]
+                assert r9.status_code == 200 and len(lp["token_logprobs"]) == 6 and lp["token_logprobs"][0] is None
+                assert all(isinstance(v, float) for v in lp["token_logprobs"][1:])
+                r10 = await c.post("/v1/chat/completions", headers=hdr, json={
+                    "messages": [{"role": "user", "content": "hi"}], "max_tokens": 2, "prompt_logprobs": 0})
+                pl = r10.json()["prompt_logprobs"]
+                assert r10.status_code == 200 and pl[0] is None and len(pl) == r10.json()["usage"]["prompt_tokens"]
+                assert all(len(d) == 1 and "logprob" in next(iter(d.values())) for d in pl[1:])
                 t = (await c.post("/tokenize", json={"prompt": "abc"})).json()
                 assert t["count"] == len(t["tokens"])
                 d = (await c.post("/detokenize", json={"tokens": t["tokens"]})).json()

@@ -104,3 +104,40 @@ def test_truncate_prompt_tokens_keeps_the_tail(llm):
     got = _gen(llm, SamplingParams(temperature=0.0, max_tokens=5, ignore_eos=True, truncate_prompt_tokens=11), long)
     assert len(got.prompt_token_ids) == 11
     assert got.outputs[0].token_ids == want.outputs[0].token_ids
+
+
+def test_prompt_logprobs_match_a_full_forward_across_chunks_and_cache_hits():
+    """prompt_logprobs: every prompt token's log-probability given its prefix.  Checked against
+    one whole-prompt pass (a request that generates after the prompt and reports ``logprobs``
+    for the same tokens), with the prefill split into 16-token chunks and with the prompt
+    already sitting in the prefix cache (which must be bypassed, not trusted)."""
+    import math
+    pstate.destroy_model_parallel()
+    m = LLM(**dict(KW, max_num_batched_tokens=16, enable_chunked_prefill=True, enable_prefix_caching=True))
+    prompt = [(7 * i + 3) % 250 + 1 for i in range(45)]
+    # reference: feed the first token, force the rest through logit_bias one token at a time, read their logprobs
+    want = [None]
+    for i in range(1, len(prompt)):
+        o = m.generate([{"prompt_token_ids": prompt[:i]}],
+                       SamplingParams(temperature=0.0, max_tokens=1, ignore_eos=True, logprobs=3))[0]
+        lp = o.outputs[0].logprobs[0]
+        want.append(lp)
+    # the prompt is now fully cached: a prompt_logprobs request must still score every position
+    o = m.generate([{"prompt_token_ids": prompt}],
+                   SamplingParams(temperature=0.0, max_tokens=2, ignore_eos=True, prompt_logprobs=2))[0]
+    got = o.prompt_logprobs
+    assert got is not None and len(got) == len(prompt) and got[0] is None
+    for i in range(1, len(prompt)):
+        assert prompt[i] in got[i] and len(got[i]) in (2, 3)
+        top_ref = max(want[i], key=want[i].get)
+        assert top_ref in got[i] and math.isclose(got[i][top_ref], want[i][top_ref], abs_tol=1e-4)
+    # two requests, one with and one without, in the same batch
+    outs = m.generate([{"prompt_token_ids": prompt[:20]}, {"prompt_token_ids": prompt[:30]}],
+                      [SamplingParams(temperature=0.0, max_tokens=2, ignore_eos=True),
+                       SamplingParams(temperature=0.0, max_tokens=2, ignore_eos=True, prompt_logprobs=0)])
+    assert outs[0].prompt_logprobs is None
+    assert outs[1].prompt_logprobs[0] is None and len(outs[1].prompt_logprobs) == 30
+    for t, d, ref in zip(prompt[1:30], outs[1].prompt_logprobs[1:], got[1:30]):
+        assert math.isclose(d[t], ref[t], abs_tol=1e-4)
+    m.shutdown()
+    pstate.destroy_model_parallel()

@@ -70,3 +70,30 @@ def test_logit_edits_on_gpu_with_graph_decode():
     assert len(ids[4]) == 5 and eos not in ids[4][:4] and ids[4][4] == eos
     llm.shutdown()
     pstate.destroy_model_parallel()
+
+
+def test_prompt_logprobs_on_gpu_match_generation_logprobs():
+    """The prompt-scoring path (chunked logits over prefill hidden states) against the sampler's
+    logprobs for the same positions, on bf16 device tensors."""
+    pstate.destroy_model_parallel()
+    llm = LLM(model="llama-tiny", dtype="bfloat16", gpu_memory_utilization=0.3, max_model_len=256,
+              num_gpu_blocks_override=64, max_num_seqs=8, max_num_batched_tokens=16, enable_chunked_prefill=True)
+    prompt = PROMPTS[1][:40]
+    out = llm.generate([{"prompt_token_ids": prompt}],
+                       SamplingParams(temperature=0.0, max_tokens=1, ignore_eos=True, prompt_logprobs=0))[0]
+    got = out.prompt_logprobs
+    assert got[0] is None and len(got) == len(prompt)
+    for i in (1, 7, 16, 17, 33, 39):          # both sides of the 16-token chunk boundaries
+        o = llm.generate([{"prompt_token_ids": prompt[:i]}],
+                         SamplingParams(temperature=0.0, max_tokens=1, ignore_eos=True, logprobs=0,
+                                        allowed_token_ids=[prompt[i]]))[0]
+        # the allow list pins the sampled token; its logprob is renormalised, so compare against a free run's top
+        free = llm.generate([{"prompt_token_ids": prompt[:i]}],
+                            SamplingParams(temperature=0.0, max_tokens=1, ignore_eos=True, logprobs=5))[0]
+        top = free.outputs[0].logprobs[0]
+        assert o.outputs[0].token_ids == [prompt[i]]
+        if prompt[i] in top:
+            assert abs(top[prompt[i]] - got[i][prompt[i]]) < 0.05
+        assert got[i][prompt[i]] <= max(top.values()) + 0.05
+    llm.shutdown()
+    pstate.destroy_model_parallel()

@@ -27,7 +27,7 @@ logger = init_logger(__name__)
 
 class _ReqState:
     __slots__ = ("request", "detok", "prompt", "cumulative_logprob", "logprobs", "finish_reason",
-                 "stop_reason")
+                 "stop_reason", "prompt_logprobs")
 
     def __init__(self, request: Request, detok: Optional[IncrementalDetokenizer], prompt: Optional[str]):
         self.request = request
@@ -37,6 +37,7 @@ class _ReqState:
         self.logprobs: Optional[List[Dict[int, float]]] = None
         self.finish_reason: Optional[str] = None
         self.stop_reason = None
+        self.prompt_logprobs = None
 
 
 class LLMEngine:
@@ -164,6 +165,8 @@ class LLMEngine:
                 for tok, lp in zip(co.new_token_ids, co.logprobs):
                     if lp is not None and tok in lp:
                         st.cumulative_logprob = (st.cumulative_logprob or 0.0) + lp[tok]
+            if co.prompt_logprobs is not None:
+                st.prompt_logprobs = co.prompt_logprobs
             finished = finish_reason is not None
             new_text = st.detok.take_delta(finished) if st.detok is not None else ""
             # the live list while the request runs (no per-step copy); a snapshot once it is final
@@ -174,7 +177,8 @@ class LLMEngine:
             outs.append(RequestOutput(request_id=co.request_id, prompt=st.prompt,
                                       prompt_token_ids=req.prompt_token_ids, outputs=[comp],
                                       finished=finished, metrics=req.metrics,
-                                      new_token_ids=co.new_token_ids, new_text=new_text))
+                                      new_token_ids=co.new_token_ids, new_text=new_text,
+                                      prompt_logprobs=st.prompt_logprobs))
             if finished:
                 if req.metrics.finished_time is None:
                     req.metrics.finished_time = time.time()

@@ -32,7 +32,7 @@ class Request:
                  "arrival_time", "priority", "status", "output_token_ids", "all_token_ids",
                  "num_computed_tokens", "num_cached_tokens", "stop_reason", "metrics",
                  "block_hashes", "num_preemptions", "max_tokens", "prompt", "num_output_placeholders",
-                 "lora_request")
+                 "lora_request", "prompt_logprobs")
 
     def __init__(self, request_id: str, prompt_token_ids: List[int],
                  sampling_params: SamplingParams, eos_token_id: Optional[int] = None,
@@ -54,6 +54,8 @@ class Request:
         self.stop_reason: Optional[object] = None
         self.block_hashes: List[int] = []
         self.num_preemptions = 0
+        # position -> {token_id: logprob}, filled chunk by chunk; emitted once with the first output token
+        self.prompt_logprobs: Optional[dict] = {} if sampling_params.prompt_logprobs is not None else None
         # tokens scheduled to be sampled whose values are not known yet (async scheduling)
         self.num_output_placeholders = 0
         self.max_tokens = sampling_params.max_tokens

@@ -40,6 +40,8 @@ class EngineCoreOutput:
     stop_reason: Optional[object] = None
     logprobs: Optional[List[Dict[int, float]]] = None
     num_cached_tokens: int = 0
+    # with the first output token of a request that asked: one entry per prompt token (None for the first)
+    prompt_logprobs: Optional[List[Optional[Dict[int, float]]]] = None
 
 
 @dataclass
@@ -306,6 +308,12 @@ class Scheduler:
         now = time.time()
         requests = self.requests
         scheduled = scheduler_output.num_scheduled_tokens
+        if runner_output.prompt_logprobs:
+            for rid, (first, entries) in runner_output.prompt_logprobs.items():
+                req = requests.get(rid)
+                if req is not None and req.prompt_logprobs is not None:
+                    for j, d in enumerate(entries):
+                        req.prompt_logprobs.setdefault(first + j, d)
         caching = self.kv.enable_caching
         fwd_tokens = self.include_new_token_ids
         running_state = RequestStatus.RUNNING
@@ -356,6 +364,10 @@ class Scheduler:
                 rid, accepted, req.status.finish_reason if finished else None, req.stop_reason,
                 req_lps[:len(accepted)] if req_lps else None,
                 req.num_cached_tokens if req.num_cached_tokens > 0 else 0))
+            if req.prompt_logprobs is not None:
+                got = req.prompt_logprobs
+                outputs[-1].prompt_logprobs = [got.get(i) for i in range(req.num_prompt_tokens)]
+                req.prompt_logprobs = None            # sent once
             if finished:
                 m.finished_time = now
                 any_finished = True

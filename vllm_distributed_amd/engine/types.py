@@ -67,6 +67,9 @@ class ModelRunnerOutput:
     sampled_token_ids: List[List[int]] = field(default_factory=list)
     # optional: per request, per sampled token, {token_id: logprob}
     logprobs: Optional[List[Optional[List[Dict[int, float]]]]] = None
+    # optional: req_id -> (position of the first prompt token covered, [{token_id: logprob}, ...]) for the
+    # prompt tokens this step's prefill chunk predicted (requests with ``prompt_logprobs`` only)
+    prompt_logprobs: Optional[Dict[str, Any]] = None
     # KV-transfer completion sets (aggregated over workers by KVOutputAggregator)
     finished_sending: Optional[Set[str]] = None
     finished_recving: Optional[Set[str]] = None

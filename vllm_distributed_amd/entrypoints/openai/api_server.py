@@ -75,6 +75,7 @@ class CompletionRequest(_Base):
     allowed_token_ids: Optional[List[int]] = None
     bad_words: Optional[List[str]] = None
     truncate_prompt_tokens: Optional[int] = None
+    prompt_logprobs: Optional[int] = None
     priority: int = 0
 
 
@@ -118,6 +119,7 @@ class ChatCompletionRequest(_Base):
     allowed_token_ids: Optional[List[int]] = None
     bad_words: Optional[List[str]] = None
     truncate_prompt_tokens: Optional[int] = None
+    prompt_logprobs: Optional[int] = None
     priority: int = 0
 
 
@@ -266,7 +268,17 @@ def _sampling_params(req, default_max: Optional[int], max_model_len: int, logpro
         stop_token_ids=req.stop_token_ids, ignore_eos=req.ignore_eos, logprobs=logprobs,
         skip_special_tokens=req.skip_special_tokens, logit_bias=req.logit_bias,
         allowed_token_ids=req.allowed_token_ids, bad_words=req.bad_words,
-        truncate_prompt_tokens=req.truncate_prompt_tokens)
+        truncate_prompt_tokens=req.truncate_prompt_tokens,
+        prompt_logprobs=(req.prompt_logprobs if req.prompt_logprobs is not None else
+                         logprobs if getattr(req, "echo", False) and not req.stream else None))
+
+
+def _prompt_logprobs_json(tok, plps) -> Optional[list]:
+    """vLLM's response form: per prompt token ``{token id: {logprob, decoded_token}}`` (null for the first)."""
+    if plps is None:
+        return None
+    return [None if d is None else {str(t): {"logprob": lp, "decoded_token": tok.decode([t])} for t, lp in d.items()}
+            for d in plps]
 
 
 def _usage(n_prompt: int, n_out: int) -> dict:
@@ -436,13 +448,16 @@ def _register_routes(app: FastAPI) -> None:
         gens = [engine.generate(pr, _nth_params(sp, j), f"{rid}-{i}-{j}", req.priority, lora)
                 for i, pr in enumerate(prompts) for j in range(n)]
 
-        def lp_block(out, start: int) -> Optional[dict]:
+        def lp_block(out, start: int, with_prompt: bool = False) -> Optional[dict]:
             lps = out.outputs[0].logprobs
             if req.logprobs is None or not lps:
                 return None
             tok = engine.tokenizer
             ids = out.outputs[0].token_ids[start:]
             sel = lps[start:]
+            if with_prompt and out.prompt_logprobs:      # echo: the prompt tokens lead, the first has no score
+                ids = list(out.prompt_token_ids) + list(ids)
+                sel = [d or {} for d in out.prompt_logprobs] + list(sel)
             return {"tokens": tok.convert_ids_to_tokens(ids),
                     "token_logprobs": [d.get(t) for t, d in zip(ids, sel)],
                     "top_logprobs": [{tok.decode([k]): v for k, v in d.items()} for d in sel],
@@ -498,8 +513,10 @@ def _register_routes(app: FastAPI) -> None:
         for i, out in enumerate(finals):
             c = out.outputs[0]
             text = ((out.prompt or "") if req.echo else "") + c.text
-            choices.append({"index": i, "text": text, "logprobs": lp_block(out, 0),
+            choices.append({"index": i, "text": text, "logprobs": lp_block(out, 0, req.echo),
                             "finish_reason": c.finish_reason, "stop_reason": c.stop_reason})
+            if req.prompt_logprobs is not None:
+                choices[-1]["prompt_logprobs"] = _prompt_logprobs_json(engine.tokenizer, out.prompt_logprobs)
             if i % n == 0:
                 n_prompt += len(out.prompt_token_ids)
             n_out += len(c.token_ids)
@@ -664,8 +681,11 @@ def _register_routes(app: FastAPI) -> None:
             choices.append({"index": j, "message": message, "logprobs": lp_content(final, 0),
                             "finish_reason": finish, "stop_reason": c.stop_reason})
             n_out += len(c.token_ids)
-        return {"id": rid, "object": "chat.completion", "created": created, "model": model,
+        body = {"id": rid, "object": "chat.completion", "created": created, "model": model,
                 "choices": choices, "usage": _usage(len(prompt_ids), n_out)}
+        if req.prompt_logprobs is not None and finals:
+            body["prompt_logprobs"] = _prompt_logprobs_json(tok, finals[0].prompt_logprobs)
+        return body
 
 
 # ------------------------------------------------------------------- run

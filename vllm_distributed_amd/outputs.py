@@ -48,3 +48,5 @@ class RequestOutput:
     # tokens produced since the previous RequestOutput for this request
     new_token_ids: List[int] = field(default_factory=list)
     new_text: str = ""
+    # one {token_id: logprob} per prompt token (None for the first), when ``prompt_logprobs`` was requested
+    prompt_logprobs: Optional[List[Optional[Dict[int, float]]]] = None

@@ -22,6 +22,7 @@ class SamplingParams:
     stop_token_ids: Optional[List[int]] = None
     ignore_eos: bool = False
     logprobs: Optional[int] = None
+    prompt_logprobs: Optional[int] = None                # logprob of every prompt token (+ this many alternatives)
     skip_special_tokens: bool = True
     include_stop_str_in_output: bool = False
     detokenize: bool = True
@@ -78,6 +79,8 @@ class SamplingParams:
             self.bad_words_token_ids = [[int(t) for t in w] for w in self.bad_words_token_ids if len(w)]
         if self.truncate_prompt_tokens is not None and self.truncate_prompt_tokens < 1:
             raise ValueError("truncate_prompt_tokens must be >= 1")
+        if self.prompt_logprobs is not None and self.prompt_logprobs < 0:
+            raise ValueError("prompt_logprobs must be >= 0")
         if self.min_tokens < 0:
             raise ValueError("min_tokens must be >= 0")
 

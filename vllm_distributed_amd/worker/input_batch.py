@@ -44,6 +44,7 @@ class InputBatch:
         self.repetition = np.ones(n, dtype=np.float32)
         self.num_logprobs = np.full(n, -1, dtype=np.int32)
         self.has_penalty = np.zeros(n, dtype=bool)
+        self.num_prompt_logprobs = np.full(n, -1, dtype=np.int32)
         self.has_adjust = np.zeros(n, dtype=bool)             # logit bias / allow / ban lists / min_tokens
         self.lora_id = np.zeros(n, dtype=np.int32)              # 0 = base model
         self.req_ids: List[Optional[str]] = [None] * n
@@ -86,6 +87,7 @@ class InputBatch:
         self.repetition[row] = sp.repetition_penalty
         self.has_penalty[row] = sp.has_penalties
         self.has_adjust[row] = sp.has_logit_adjust
+        self.num_prompt_logprobs[row] = -1 if sp.prompt_logprobs is None else sp.prompt_logprobs
         self.num_logprobs[row] = -1 if sp.logprobs is None else sp.logprobs
         self.lora_id[row] = lora_id
         self.req_ids[row] = req_id
@@ -114,6 +116,7 @@ class InputBatch:
         self.num_blocks[row] = 0
         self.lora_id[row] = 0
         self.has_adjust[row] = False
+        self.num_prompt_logprobs[row] = -1
         self.has_penalty[row] = False
         self._free_rows.append(row)
 

@@ -36,7 +36,7 @@ class PendingSample:
 
     lazy_step_result = True       # executors call .get() on results carrying this mark
     __slots__ = ("runner", "step_id", "req_ids", "nreq", "sel", "rows", "gens", "pos", "tokens",
-                 "event", "logprobs", "timing", "t_launch", "_result")
+                 "event", "logprobs", "timing", "t_launch", "_result", "prompt_logprobs")
 
     def __init__(self, runner: "ModelRunner", step_id: int, req_ids: List[str], sel: Optional[np.ndarray],
                  rows: Optional[np.ndarray], pos: Optional[np.ndarray], tokens: Optional[torch.Tensor],
@@ -45,6 +45,7 @@ class PendingSample:
         self.sel, self.rows, self.pos, self.tokens, self.event = sel, rows, pos, tokens, event
         self.gens = runner.batch.row_gen[rows].copy() if rows is not None else None
         self.logprobs, self.timing = logprobs, timing
+        self.prompt_logprobs = None
         self.t_launch = time.perf_counter()
         self._result: Optional[ModelRunnerOutput] = None
 
@@ -75,7 +76,8 @@ class PendingSample:
         if timing is not None:
             timing["sample"] = timing.get("sample", 0.0) + (time.perf_counter() - self.t_launch)
         self._result = ModelRunnerOutput(step_id=self.step_id, req_ids=self.req_ids,
-                                         sampled_token_ids=out_tokens, logprobs=logprobs_out, timing=timing)
+                                         sampled_token_ids=out_tokens, logprobs=logprobs_out, timing=timing,
+                                         prompt_logprobs=self.prompt_logprobs)
         try:
             self.runner._pending.remove(self)
         except ValueError:
@@ -346,6 +348,9 @@ class ModelRunner:
         if not self.pp.is_last_rank:
             return None
         t2 = time.perf_counter()
+        prompt_lps = None
+        if nd < nreq and (self.batch.num_prompt_logprobs[p["rows"][nd:]] >= 0).any():
+            prompt_lps = self._prompt_logprobs(hidden, p)
         sample_mask = p["sample_mask"]
         sel = rows_sel = pos_sel = host_tokens = event = logprobs_sel = None
         if sample_mask.any():
@@ -378,6 +383,7 @@ class ModelRunner:
             timing["comm"] = CommTimer.drain()
         pending = PendingSample(self, so.step_id, p["req_ids"], sel, rows_sel, pos_sel, host_tokens, event,
                                 logprobs_sel, timing)
+        pending.prompt_logprobs = prompt_lps
         self._pending.append(pending)
         if self.defer_output:
             return pending if self._is_output_rank() else _Discard(pending)
@@ -495,6 +501,43 @@ class ModelRunner:
                     d.setdefault(t_id, t_lp)
                 logprobs.append([d])
         return tokens.to(torch.int32), logprobs
+
+    def _prompt_logprobs(self, hidden: torch.Tensor, p: dict) -> Optional[dict]:
+        """Log-probabilities of the prompt tokens this step's prefill chunks predict:
+        the hidden state at position i scores prompt token i + 1.  Logits are formed
+        1024 positions at a time so a long chunk never holds a full [tokens, vocab]
+        matrix.  Every TP rank runs the same slices (the logits gather is collective)."""
+        b = self.batch
+        rows, n_sched, seq_lens, qsl = p["rows"], p["n_sched"], p["seq_lens"], p["qsl"]
+        out = {}
+        for i in range(p["num_decodes"], len(rows)):
+            r = int(rows[i])
+            k = int(b.num_prompt_logprobs[r])
+            if k < 0:
+                continue
+            n, npt = int(n_sched[i]), int(b.num_prompt_tokens[r])
+            start = int(seq_lens[i]) - n
+            lo, hi = start, min(start + n, npt - 1)
+            if hi <= lo:
+                continue
+            off = int(qsl[i]) - start
+            entries: list = []
+            for c0 in range(lo, hi, 1024):
+                c1 = min(hi, c0 + 1024)
+                logits = self.model.compute_logits(hidden[off + c0:off + c1])
+                targets = b.token_ids[r, c0 + 1:c1 + 1]
+                chosen, tv, ti = ops.compute_logprobs(logits, self._to_dev(targets, torch.int64), k)
+                chosen = chosen.tolist()
+                tv_l = tv.tolist() if tv is not None else None
+                ti_l = ti.tolist() if ti is not None else None
+                for j, t in enumerate(targets.tolist()):
+                    d = {t: chosen[j]}
+                    if ti_l:
+                        for t_id, t_lp in zip(ti_l[j], tv_l[j]):
+                            d.setdefault(t_id, t_lp)
+                    entries.append(d)
+            out[p["req_ids"][i]] = (lo + 1, entries)
+        return out or None
 
     def _adjust_logits(self, logits: torch.Tensor, rows: np.ndarray) -> torch.Tensor:
         """Per-request logit edits, in the order bias -> allow list -> ban lists:
