@@ -239,3 +239,52 @@ def test_real_socket_server_with_bench_serve_and_clients():
             server.wait(timeout=30)
         except subprocess.TimeoutExpired:
             server.kill()
+
+
+def test_generation_config_supplies_defaults_and_extra_eos_ids(tmp_path):
+    """generation_config.json next to the weights: its sampling fields are the defaults for requests
+    that leave them unset, every id in its eos_token_id list ends a sequence, and
+    ``--generation-config vllm`` turns both off."""
+    from vllm_distributed_amd.config import ModelConfig
+    from vllm_distributed_amd.models.loader import save_dummy_checkpoint
+    mc = ModelConfig(model="llama-tiny", dtype="float32", load_format="dummy")
+    save_dummy_checkpoint(mc, str(tmp_path))
+    (tmp_path / "config.json").write_text(json.dumps(mc.hf_config))
+    (tmp_path / "generation_config.json").write_text(json.dumps(
+        {"do_sample": True, "temperature": 0.0, "top_k": 5, "max_new_tokens": 7, "eos_token_id": [2, 77]}))
+    mc2 = ModelConfig(model=str(tmp_path), dtype="float32")
+    assert mc2.default_sampling_params() == {"temperature": 0.0, "top_k": 5, "max_tokens": 7}
+    assert 77 in mc2.eos_token_ids()
+    assert ModelConfig(model=str(tmp_path), dtype="float32", generation_config="vllm").default_sampling_params() == {}
+
+    def serve(extra: str):
+        pstate.destroy_model_parallel()
+        args = build_parser().parse_args(
+            (f"serve {tmp_path} --device cpu --dtype float32 --max-model-len 128 --block-size 16 "
+             f"--num-gpu-blocks-override 64 --served-model-name tiny --port 0 "
+             f"--disable-frontend-multiprocessing{extra}").split())
+        args.model = args.model_tag
+
+        async def main():
+            async with api_server.build_async_engine_client(args) as engine:
+                app = api_server.build_app(args)
+                await api_server.init_app_state(engine, await engine.get_vllm_config(), app.state, args)
+                async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://t") as c:
+                    a = (await c.post("/v1/chat/completions", json={
+                        "messages": [{"role": "user", "content": "hi"}], "ignore_eos": True})).json()
+                    b = (await c.post("/v1/chat/completions", json={
+                        "messages": [{"role": "user", "content": "hi"}], "ignore_eos": True})).json()
+                    stop = (await c.post("/v1/completions", json={
+                        "prompt": "hello", "max_tokens": 6, "logit_bias": {"77": 100}})).json()
+                    return a, b, stop
+        out = asyncio.run(main())
+        pstate.destroy_model_parallel()
+        return out
+
+    a, b, stop = serve("")
+    # greedy by default and capped at 7 new tokens, both from the file
+    assert a["usage"]["completion_tokens"] == 7 and a["choices"][0]["message"] == b["choices"][0]["message"]
+    assert stop["choices"][0]["finish_reason"] == "stop" and stop["usage"]["completion_tokens"] == 1
+    a, b, stop = serve(" --generation-config vllm")
+    assert a["usage"]["completion_tokens"] > 7              # runs to the context limit: no cap from the file
+    assert stop["choices"][0]["finish_reason"] == "length" and stop["usage"]["completion_tokens"] == 6

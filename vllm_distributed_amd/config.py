@@ -111,6 +111,8 @@ class ModelConfig:
     quantization: Optional[str] = None
     trust_remote_code: bool = False
     revision: Optional[str] = None
+    # "auto": generation_config.json next to the weights; "vllm": none; else a directory (or file) to read
+    generation_config: str = "auto"
     hf_overrides: Dict[str, Any] = field(default_factory=dict)
     # populated by __post_init__
     hf_config: Dict[str, Any] = field(default_factory=dict)
@@ -148,6 +150,50 @@ class ModelConfig:
             logger.warning("no weights found for %s: using deterministic random init "
                            "(load_format=dummy)", self.model)
             self.load_format = "dummy"
+
+    # ---------------------------------------------------- generation defaults
+    def load_generation_config(self) -> Dict[str, Any]:
+        """The model's ``generation_config.json`` ({} when absent or disabled)."""
+        src = self.generation_config
+        if src == "vllm":
+            return {}
+        path = resolve_model_path(self.model) if src == "auto" else src
+        if path is None:
+            return {}
+        if os.path.isdir(path):
+            path = os.path.join(path, "generation_config.json")
+        if not os.path.isfile(path):
+            return {}
+        try:
+            with open(path) as f:
+                cfg = json.load(f)
+            return cfg if isinstance(cfg, dict) else {}
+        except (OSError, ValueError) as e:
+            logger.warning("could not read %s: %s", path, e)
+            return {}
+
+    def default_sampling_params(self) -> Dict[str, Any]:
+        """Sampling defaults the model's authors ship (applied to API requests that leave a field unset)."""
+        g = self.load_generation_config()
+        out: Dict[str, Any] = {}
+        for key in ("temperature", "top_p", "top_k", "min_p", "repetition_penalty"):
+            if g.get(key) is not None:
+                out[key] = g[key]
+        if g.get("max_new_tokens") is not None:
+            out["max_tokens"] = int(g["max_new_tokens"])
+        if g.get("do_sample") is False:             # greedy by declaration
+            out["temperature"] = 0.0
+        return out
+
+    def eos_token_ids(self) -> List[int]:
+        """Every id that ends a sequence: config.json and generation_config.json may each list several
+        (Llama-3 instruct: <|end_of_text|> and <|eot_id|>)."""
+        ids: List[int] = []
+        for src in (self.hf_config.get("eos_token_id"), self.load_generation_config().get("eos_token_id")):
+            for t in (src if isinstance(src, list) else [src]):
+                if isinstance(t, int) and t not in ids:
+                    ids.append(t)
+        return ids
 
     # ------------------------------------------------------------ accessors
     def derived_max_model_len(self) -> int:

@@ -29,6 +29,7 @@ class EngineArgs:
     quantization: Optional[str] = None
     trust_remote_code: bool = False
     revision: Optional[str] = None
+    generation_config: str = "auto"
     hf_overrides: Optional[Dict[str, Any]] = None
     tensor_parallel_size: int = 1
     pipeline_parallel_size: int = 1
@@ -73,6 +74,9 @@ class EngineArgs:
         g.add_argument("--quantization", "-q", type=str, default=None, choices=[None, "awq", "awq-dequant", "fp8", "nvfp4"])
         g.add_argument("--trust-remote-code", action="store_true")
         g.add_argument("--revision", type=str, default=None)
+        g.add_argument("--generation-config", type=str, default="auto",
+                       help="'auto': default sampling parameters and extra EOS ids come from the model's "
+                            "generation_config.json; 'vllm': ignore that file; or a directory holding one")
         g.add_argument("--hf-overrides", type=json.loads, default=None)
         g.add_argument("--tensor-parallel-size", "-tp", type=int, default=1)
         g.add_argument("--pipeline-parallel-size", "-pp", type=int, default=1)
@@ -115,6 +119,7 @@ class EngineArgs:
             dtype=self.dtype, seed=self.seed, max_model_len=self.max_model_len,
             load_format=self.load_format, quantization=self.quantization,
             trust_remote_code=self.trust_remote_code, revision=self.revision,
+            generation_config=self.generation_config,
             hf_overrides=self.hf_overrides or {})
         device_config = DeviceConfig(self.device)
         block_size = self.block_size or (64 if device_config.device == "cuda" else 16)

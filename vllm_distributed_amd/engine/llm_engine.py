@@ -58,6 +58,8 @@ class LLMEngine:
         self.eos_token_id = eos[0] if isinstance(eos, list) else eos
         if getattr(self.tokenizer, "eos_token_id", None) is not None:
             self.eos_token_id = self.tokenizer.eos_token_id
+        # further end-of-sequence ids (config.json / generation_config.json lists) act as stop tokens
+        self.extra_eos_ids = [t for t in self.model_config.eos_token_ids() if t != self.eos_token_id]
 
     @classmethod
     def from_engine_args(cls, engine_args: EngineArgs) -> "LLMEngine":
@@ -88,6 +90,9 @@ class LLMEngine:
         if params.max_tokens is None:
             params.max_tokens = max(1, max_len - len(ids))
         vocab = self.model_config.vocab_size
+        if self.extra_eos_ids and not params.ignore_eos:
+            params.stop_token_ids = params.stop_token_ids + [
+                t for t in self.extra_eos_ids if t not in params.stop_token_ids]
         self._resolve_token_lists(params)
         params.check_vocab(vocab)
         if any(t < 0 or t >= vocab for t in ids):

@@ -232,6 +232,10 @@ async def init_app_state(engine: AsyncLLM, vllm_config, state, args: argparse.Na
     state.args = args
     state.served_names = vllm_config.model_config.served_model_name
     state.max_model_len = vllm_config.model_config.max_model_len
+    # the model authors' generation_config.json fills in what a request leaves unset (--generation-config)
+    state.default_sampling = vllm_config.model_config.default_sampling_params()
+    if state.default_sampling:
+        logger.info("default sampling parameters from generation_config.json: %s", state.default_sampling)
     state.tool_parser = None
     name = getattr(args, "tool_call_parser", None)
     if getattr(args, "enable_auto_tool_choice", False) and name:
@@ -257,13 +261,22 @@ async def init_app_state(engine: AsyncLLM, vllm_config, state, args: argparse.Na
 
 # -------------------------------------------------------------------- routes
 def _sampling_params(req, default_max: Optional[int], max_model_len: int, logprobs: Optional[int],
-                     ) -> SamplingParams:
-    max_tokens = getattr(req, "max_completion_tokens", None) or req.max_tokens or default_max
+                     defaults: Optional[Dict[str, Any]] = None) -> SamplingParams:
+    given = req.model_fields_set
+    defaults = defaults or {}
+
+    def pick(name: str, fallback):
+        v = getattr(req, name)
+        if name not in given or v is None:
+            return defaults.get(name, fallback)
+        return v
+    max_tokens = getattr(req, "max_completion_tokens", None) or (
+        req.max_tokens if "max_tokens" in given else None) or defaults.get("max_tokens") or req.max_tokens \
+        or default_max
     return SamplingParams(
-        temperature=req.temperature if req.temperature is not None else 1.0,
-        top_p=req.top_p if req.top_p is not None else 1.0, top_k=req.top_k or -1,
-        min_p=req.min_p or 0.0, presence_penalty=req.presence_penalty or 0.0,
-        frequency_penalty=req.frequency_penalty or 0.0, repetition_penalty=req.repetition_penalty or 1.0,
+        temperature=pick("temperature", 1.0), top_p=pick("top_p", 1.0), top_k=pick("top_k", -1) or -1,
+        min_p=pick("min_p", 0.0) or 0.0, presence_penalty=req.presence_penalty or 0.0,
+        frequency_penalty=req.frequency_penalty or 0.0, repetition_penalty=pick("repetition_penalty", 1.0) or 1.0,
         seed=req.seed, max_tokens=max_tokens, min_tokens=req.min_tokens, stop=req.stop,
         stop_token_ids=req.stop_token_ids, ignore_eos=req.ignore_eos, logprobs=logprobs,
         skip_special_tokens=req.skip_special_tokens, logit_bias=req.logit_bias,
@@ -439,7 +452,7 @@ def _register_routes(app: FastAPI) -> None:
         rid = "cmpl-" + uuid.uuid4().hex
         created = int(time.time())
         try:
-            sp = _sampling_params(req, 16, st.max_model_len, req.logprobs)
+            sp = _sampling_params(req, 16, st.max_model_len, req.logprobs, st.default_sampling)
         except ValueError as e:
             return _error(str(e))
         # n samples per prompt = n requests sharing the prompt (its KV blocks are shared through the
@@ -549,7 +562,7 @@ def _register_routes(app: FastAPI) -> None:
         prompt_ids = tok.encode(prompt, add_special_tokens=False)
         n_lp = (req.top_logprobs or 0) if req.logprobs else None
         try:
-            sp = _sampling_params(req, None, st.max_model_len, n_lp)
+            sp = _sampling_params(req, None, st.max_model_len, n_lp, st.default_sampling)
         except ValueError as e:
             return _error(str(e))
         model = req.model or st.served_names[0]
