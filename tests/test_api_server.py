@@ -142,6 +142,19 @@ def test_server_endpoints_end_to_end(frontend_mp):
                 lp = r9.json()["choices"][0]["logprobs"]
                 assert r9.status_code == 200 and len(lp["token_logprobs"]) == 6 and lp["token_logprobs"][0] is None
                 assert all(isinstance(v, float) for v in lp["token_logprobs"][1:])
+                # JSON mode: the content parses as an object whatever the (random) model prefers
+                rj = await c.post("/v1/chat/completions", headers=hdr, json={
+                    "messages": [{"role": "user", "content": "hi"}], "max_tokens": 200, "seed": 1,
+                    "response_format": {"type": "json_object"},
+                    "logit_bias": {str(ord('"')): 4, str(ord("}")): 5, str(ord(":")): 3}})
+                assert rj.status_code == 200, rj.text
+                if rj.json()["choices"][0]["finish_reason"] == "stop":
+                    assert isinstance(json.loads(rj.json()["choices"][0]["message"]["content"]), dict)
+                else:
+                    assert rj.json()["choices"][0]["message"]["content"].lstrip().startswith("{")
+                assert (await c.post("/v1/chat/completions", headers=hdr, json={
+                    "messages": [{"role": "user", "content": "hi"}],
+                    "response_format": {"type": "json_schema", "json_schema": {}}})).status_code == 400
                 r10 = await c.post("/v1/chat/completions", headers=hdr, json={
                     "messages": [{"role": "user", "content": "hi"}], "max_tokens": 2, "prompt_logprobs": 0})
                 pl = r10.json()["prompt_logprobs"]

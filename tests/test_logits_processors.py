@@ -141,3 +141,87 @@ def test_prompt_logprobs_match_a_full_forward_across_chunks_and_cache_hits():
         assert math.isclose(d[t], ref[t], abs_tol=1e-4)
     m.shutdown()
     pstate.destroy_model_parallel()
+
+
+def test_json_automaton_accepts_exactly_json_objects():
+    import json
+    from vllm_distributed_amd.ops.grammar import JsonGrammar, TokenTable
+    good = ['{"a": 1, "b": [true, false, null, -0.5e+3, "x\\n\\u00e9"], "c": {"d": {}}}', ' {\n  "k" : [ ] }  ',
+            '{"a":0}', '{"a":10.25E-2 }', '{"\\"q\\"": "\\\\"}', '{"n":[[[]],{"z":[1,2]}]}']
+    bad = ['[1]', '"x"', '{"a": 01}', '{a:1}', '{"a":1,}', '{"a": tru }', '{"a":1}}', '{"a": "x\ny"}', '{"a":-}',
+           '{"a":1.}', '{"a":.5}', '{"a":1 "b":2}', '{"a":[1,]}', '{"a":"\\x"}', '{"a":"\\u12g4"}', '{"a":1e}']
+    for t in good:
+        json.loads(t)
+        g = JsonGrammar()
+        assert g.advance(t.encode()) and g.done, t
+        for i in range(len(t)):             # every prefix is a live state, and not "done" before the last brace
+            p = JsonGrammar()
+            assert p.advance(t[:i].encode()) and (not p.done or t[:i].strip() == t.strip()), (t, i)
+    for t in bad:
+        g = JsonGrammar()
+        assert not (g.advance(t.encode()) and g.done), t
+    # a rejected chunk leaves the state where it was
+    g = JsonGrammar()
+    assert g.advance(b'{"a":') and not g.advance(b'x') and g.advance(b'1}') and g.done
+    # masks: multi-byte tokens are judged as a whole; empty (special) tokens never pass
+    table = TokenTable([b'{', b'{"', b'"}', b'}', b'', b'a":', b' ', b'1', b'{}'], 12)
+    assert table.n == 12
+    g = JsonGrammar()
+    assert g.mask(table).tolist() == [1, 1, 0, 0, 0, 0, 1, 0, 1, 0, 0, 0]
+    g.advance(b'{"')
+    # inside a key: any text, or close it - but '"}' closes the key and then lacks its colon
+    assert g.mask(table).tolist() == [1, 1, 0, 1, 0, 1, 1, 1, 1, 0, 0, 0]
+    g.advance(b'a":1')
+    assert g.mask(table).tolist() == [0, 0, 0, 1, 0, 0, 1, 1, 0, 0, 0, 0]
+
+
+def test_json_object_mode_yields_parseable_json_from_random_weights():
+    """A random-init model under the JSON constraint: whatever it samples parses, ends with EOS
+    right after the closing brace, and an unconstrained neighbour in the batch is unaffected."""
+    import json
+    pstate.destroy_model_parallel()
+    llm = LLM(**KW)
+    base = _gen(llm, SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True)).outputs[0].token_ids
+    outs = llm.generate(
+        ["hello world"] * 4,
+        [SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True)] +
+        # a nudge towards closing quotes / braces keeps random weights from rambling inside one string
+        [SamplingParams(temperature=1.0, seed=s, max_tokens=120, json_object=True,
+                        logit_bias={ord('"'): 4.0, ord('}'): 4.0, ord(':'): 3.0}) for s in (1, 2, 3)])
+    assert outs[0].outputs[0].token_ids == base
+    finished = 0
+    for o in outs[1:]:
+        c = o.outputs[0]
+        if c.finish_reason == "stop":
+            finished += 1
+            assert c.token_ids[-1] == llm.engine.eos_token_id
+            assert isinstance(json.loads(c.text), dict)
+        else:                                   # ran out of tokens mid-object: still a valid prefix
+            from vllm_distributed_amd.ops.grammar import JsonGrammar
+            assert JsonGrammar().advance(bytes(t for t in c.token_ids if t < 256))
+    assert finished >= 1
+    llm.shutdown()
+    pstate.destroy_model_parallel()
+
+
+def test_token_bytes_of_a_byte_level_bpe_tokenizer_round_trip(tmp_path):
+    """The vocabulary byte table the grammar walks: for a byte-level BPE tokenizer (trained here,
+    offline) the bytes of the encoded ids concatenate back to the UTF-8 text, specials are empty."""
+    from tokenizers import Tokenizer, decoders, models, pre_tokenizers, trainers
+    from transformers import PreTrainedTokenizerFast
+    from vllm_distributed_amd.tokenizer import HFTokenizer
+    tk = Tokenizer(models.BPE())
+    tk.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False)
+    tk.decoder = decoders.ByteLevel()
+    corpus = ['{"name": "value", "list": [1, 2, 3], "nested": {"k": true}}', "héllo wörld ünïcode 你好",
+              "the quick brown fox jumps over the lazy dog " * 3]
+    tk.train_from_iterator(corpus * 20, trainers.BpeTrainer(
+        vocab_size=400, special_tokens=["<|eos|>"], initial_alphabet=pre_tokenizers.ByteLevel.alphabet()))
+    PreTrainedTokenizerFast(tokenizer_object=tk, eos_token="<|eos|>").save_pretrained(str(tmp_path))
+    tok = HFTokenizer(str(tmp_path))
+    table = tok.token_bytes()
+    assert len(table) == tok.vocab_size and table[tok.eos_token_id] == b""
+    for text in corpus + ['  {"a":\n\t"b"}', "é€"]:
+        ids = tok.encode(text, add_special_tokens=False)
+        assert b"".join(table[i] for i in ids) == text.encode("utf-8"), text
+    assert any(len(t) > 1 for t in table)            # merges exist, so multi-byte tokens are covered

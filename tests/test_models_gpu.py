@@ -97,3 +97,23 @@ def test_prompt_logprobs_on_gpu_match_generation_logprobs():
         assert got[i][prompt[i]] <= max(top.values()) + 0.05
     llm.shutdown()
     pstate.destroy_model_parallel()
+
+
+def test_json_mode_on_gpu():
+    """JSON-constrained sampling on device logits (vocabulary mask from the host automaton),
+    next to an unconstrained request, with decode running from the captured graph."""
+    pstate.destroy_model_parallel()
+    llm = LLM(model="llama-tiny", dtype="bfloat16", gpu_memory_utilization=0.3, max_model_len=256,
+              num_gpu_blocks_override=64, max_num_seqs=8)
+    bias = {ord('"'): 4.0, ord('}'): 5.0, ord(':'): 3.0}
+    outs = llm.generate([PROMPTS[0]] * 4,
+                        [SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True)] +
+                        [SamplingParams(temperature=1.0, seed=s, max_tokens=150, json_object=True, logit_bias=bias)
+                         for s in (1, 2, 3)])
+    assert len(outs[0].outputs[0].token_ids) == 6
+    done = [o.outputs[0] for o in outs[1:] if o.outputs[0].finish_reason == "stop"]
+    assert done, "no constrained request closed its object within 150 tokens"
+    for c in done:
+        assert isinstance(json.loads(c.text), dict)
+    llm.shutdown()
+    pstate.destroy_model_parallel()

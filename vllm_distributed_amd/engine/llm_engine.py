@@ -117,6 +117,7 @@ class LLMEngine:
                     if t and t not in words:
                         words.append(t)
             params.bad_words_token_ids = words
+        params.eos_token_id = self.eos_token_id
         if params.min_tokens > 0:
             ban = set(params.stop_token_ids)
             if self.eos_token_id is not None:

@@ -76,6 +76,7 @@ class CompletionRequest(_Base):
     bad_words: Optional[List[str]] = None
     truncate_prompt_tokens: Optional[int] = None
     prompt_logprobs: Optional[int] = None
+    response_format: Optional[Dict[str, Any]] = None
     priority: int = 0
 
 
@@ -120,6 +121,7 @@ class ChatCompletionRequest(_Base):
     bad_words: Optional[List[str]] = None
     truncate_prompt_tokens: Optional[int] = None
     prompt_logprobs: Optional[int] = None
+    response_format: Optional[Dict[str, Any]] = None
     priority: int = 0
 
 
@@ -270,6 +272,9 @@ def _sampling_params(req, default_max: Optional[int], max_model_len: int, logpro
         if name not in given or v is None:
             return defaults.get(name, fallback)
         return v
+    rf = (req.response_format or {}).get("type", "text")
+    if rf not in ("text", "json_object"):
+        raise ValueError(f"response_format type {rf!r} is not supported (text, json_object)")
     max_tokens = getattr(req, "max_completion_tokens", None) or (
         req.max_tokens if "max_tokens" in given else None) or defaults.get("max_tokens") or req.max_tokens \
         or default_max
@@ -281,7 +286,7 @@ def _sampling_params(req, default_max: Optional[int], max_model_len: int, logpro
         stop_token_ids=req.stop_token_ids, ignore_eos=req.ignore_eos, logprobs=logprobs,
         skip_special_tokens=req.skip_special_tokens, logit_bias=req.logit_bias,
         allowed_token_ids=req.allowed_token_ids, bad_words=req.bad_words,
-        truncate_prompt_tokens=req.truncate_prompt_tokens,
+        truncate_prompt_tokens=req.truncate_prompt_tokens, json_object=rf == "json_object",
         prompt_logprobs=(req.prompt_logprobs if req.prompt_logprobs is not None else
                          logprobs if getattr(req, "echo", False) and not req.stream else None))
 

@@ -31,6 +31,9 @@ class SamplingParams:
     bad_words: Optional[List[str]] = None                # never generated (tokenised by the engine front-end)
     bad_words_token_ids: Optional[List[List[int]]] = None
     truncate_prompt_tokens: Optional[int] = None         # keep only the last k prompt tokens
+    json_object: bool = False                            # constrain the output to one JSON object
+    # filled by the engine: the model's EOS id (the only token allowed once a constrained output is complete)
+    eos_token_id: Optional[int] = None
     # filled by the engine: EOS + stop token ids, masked until ``min_tokens`` outputs exist
     min_tokens_ban_ids: List[int] = field(default_factory=list)
 
@@ -97,6 +100,7 @@ class SamplingParams:
     def has_logit_adjust(self) -> bool:
         """True when logits must be edited before sampling (bias, allow / ban lists, min_tokens)."""
         return bool(self.logit_bias or self.allowed_token_ids is not None or self.bad_words_token_ids
+                    or self.json_object
                     or (self.min_tokens > 0 and self.min_tokens_ban_ids))
 
     def check_vocab(self, vocab_size: int) -> None:

@@ -46,6 +46,11 @@ class ByteTokenizer:
     def convert_ids_to_tokens(self, ids: Sequence[int]) -> List[str]:
         return [chr(i) if i < 256 else f"<{i}>" for i in ids]
 
+    def token_bytes(self) -> List[bytes]:
+        """The bytes each id contributes to the text (b"" for ids that contribute none)."""
+        special = set(self.all_special_ids)
+        return [bytes([i]) if i < 256 and i not in special else b"" for i in range(self.vocab_size)]
+
     def apply_chat_template(self, messages: List[Dict[str, Any]], tokenize: bool = False,
                             add_generation_prompt: bool = True, tools=None, **kw) -> Any:
         text = render_chat_template(self.chat_template, messages, add_generation_prompt, tools)
@@ -63,6 +68,20 @@ def render_chat_template(template: str, messages, add_generation_prompt: bool = 
     env.filters["tojson"] = lambda v, **k: json.dumps(v, ensure_ascii=False)
     return env.from_string(template).render(messages=messages, tools=tools,
                                             add_generation_prompt=add_generation_prompt, **extra)
+
+
+def _byte_level_decoder() -> Dict[str, int]:
+    """Inverse of the byte-level BPE alphabet: printable bytes map to themselves, the rest to
+    code points from U+0100 upwards in byte order."""
+    keep = list(range(ord("!"), ord("~") + 1)) + list(range(0xA1, 0xAD)) + list(range(0xAE, 0x100))
+    table, n = {}, 0
+    for b in range(256):
+        if b in keep:
+            table[chr(b)] = b
+        else:
+            table[chr(256 + n)] = b
+            n += 1
+    return table
 
 
 class HFTokenizer:
@@ -84,6 +103,30 @@ class HFTokenizer:
 
     def convert_ids_to_tokens(self, ids: Sequence[int]) -> List[str]:
         return self.tok.convert_ids_to_tokens(list(ids))
+
+    def token_bytes(self) -> List[bytes]:
+        """The bytes each id contributes to the text.  Byte-level BPE vocabularies (GPT-2 / Llama-3 /
+        Qwen) spell bytes through a fixed printable alphabet; SentencePiece ones use U+2581 for a
+        space and ``<0xNN>`` for raw bytes.  Special and added tokens get b"" (never produced by
+        constrained decoding)."""
+        toks = self.tok.convert_ids_to_tokens(list(range(self.vocab_size)))
+        special = set(self.all_special_ids) | set(getattr(self.tok, "added_tokens_decoder", {}) or {})
+        byte_level = _byte_level_decoder()
+        is_bl = sum(1 for t in toks[:4096] if t and "\u0120" in t) > 8          # the byte-level alphabet's space
+        out: List[bytes] = []
+        for i, t in enumerate(toks):
+            if t is None or i in special:
+                out.append(b"")
+            elif is_bl:
+                try:
+                    out.append(bytes(byte_level[ch] for ch in t))
+                except KeyError:
+                    out.append(b"")
+            elif len(t) == 6 and t.startswith("<0x") and t.endswith(">"):
+                out.append(bytes([int(t[3:5], 16)]))
+            else:
+                out.append(t.replace("\u2581", " ").encode("utf-8"))
+        return out
 
     def apply_chat_template(self, messages, tokenize: bool = False, add_generation_prompt: bool = True,
                             tools=None, **kw) -> Any:

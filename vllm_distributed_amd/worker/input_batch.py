@@ -51,6 +51,9 @@ class InputBatch:
         self.row_of: Dict[str, int] = {}
         self.params: List[Optional[SamplingParams]] = [None] * n
         self.generators: List[Optional[np.random.Generator]] = [None] * n
+        # constrained decoding: the request's grammar position and how many output tokens it has consumed
+        self.grammar: List[Optional[object]] = [None] * n
+        self.grammar_pos = np.zeros(n, dtype=np.int32)
         self._free_rows = list(range(n - 1, -1, -1))
 
     @property
@@ -88,6 +91,11 @@ class InputBatch:
         self.has_penalty[row] = sp.has_penalties
         self.has_adjust[row] = sp.has_logit_adjust
         self.num_prompt_logprobs[row] = -1 if sp.prompt_logprobs is None else sp.prompt_logprobs
+        self.grammar[row] = None
+        self.grammar_pos[row] = 0
+        if sp.json_object:
+            from ..ops.grammar import JsonGrammar
+            self.grammar[row] = JsonGrammar()
         self.num_logprobs[row] = -1 if sp.logprobs is None else sp.logprobs
         self.lora_id[row] = lora_id
         self.req_ids[row] = req_id
@@ -117,6 +125,7 @@ class InputBatch:
         self.lora_id[row] = 0
         self.has_adjust[row] = False
         self.num_prompt_logprobs[row] = -1
+        self.grammar[row] = None
         self.has_penalty[row] = False
         self._free_rows.append(row)
 

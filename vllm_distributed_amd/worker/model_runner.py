@@ -135,6 +135,7 @@ class ModelRunner:
         self.lora_manager = None
         self.sampled_dev: Optional[torch.Tensor] = None      # last sampled token per batch row (device)
         self._pending: List[PendingSample] = []
+        self._token_table = None          # vocabulary bytes for constrained decoding, built on first use
         self.defer_output = False        # set by in-process executors under async scheduling
         self.timing_enabled = vllm_config.observability_config.collect_step_timing
         CommTimer.configure()
@@ -582,6 +583,15 @@ class ModelRunner:
                     if k == 0 or b.token_ids[r, nt - k:nt].tolist() == list(w[:-1]):
                         ban_r.append(j); ban_c.append(w[-1])
         dev = logits.device
+        for j, r in enumerate(rows.tolist()):
+            if b.grammar[r] is not None:
+                if not synced:
+                    for pend in list(self._pending):
+                        pend.get()
+                    synced = True
+                keep = self._grammar_mask(r, v)
+                if keep is not None:
+                    logits[j].masked_fill_(~torch.from_numpy(keep).to(dev).bool(), neg)
         if add_r:
             logits.index_put_((torch.tensor(add_r, device=dev), torch.tensor(add_c, device=dev)),
                               torch.tensor(add_v, dtype=logits.dtype, device=dev), accumulate=True)
@@ -592,6 +602,34 @@ class ModelRunner:
         if ban_r:
             logits[torch.tensor(ban_r, device=dev), torch.tensor(ban_c, device=dev)] = neg
         return logits
+
+    def _grammar_mask(self, r: int, v: int) -> Optional[np.ndarray]:
+        """uint8 [v] of the tokens a constrained request may produce next: the grammar is first
+        advanced over the output tokens it has not seen yet.  Once the object is complete (or
+        nothing else fits) only EOS remains."""
+        b = self.batch
+        if self._token_table is None or self._token_table.n != v:
+            from ..ops.grammar import TokenTable
+            from ..tokenizer import get_tokenizer
+            self._token_table = TokenTable(get_tokenizer(self.model_config).token_bytes(), v)
+        table, g = self._token_table, b.grammar[r]
+        npt, nt = int(b.num_prompt_tokens[r]), int(b.num_tokens[r])
+        for t in b.token_ids[r, npt + int(b.grammar_pos[r]):nt].tolist():
+            if not g.advance(table.tokens[t] if t < table.n else b""):
+                # tokens from before a constraint could apply (should not happen): stop constraining
+                logger.warning("request %s left the JSON grammar; constraint dropped", b.req_ids[r])
+                b.grammar[r] = None
+                return None
+        b.grammar_pos[r] = nt - npt
+        keep = None if g.done else g.mask(table)
+        if keep is None or not keep.any():
+            keep = np.zeros(v, dtype=np.uint8)
+            eos = b.params[r].eos_token_id
+            if eos is not None and eos < v:
+                keep[eos] = 1
+            else:
+                return None
+        return keep
 
     def _apply_penalties(self, logits: torch.Tensor, rows: np.ndarray) -> torch.Tensor:
         b = self.batch
