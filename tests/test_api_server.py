@@ -45,6 +45,19 @@ def test_cli_parses_reference_command_line():
     assert a.enable_auto_tool_choice and a.tool_call_parser == "qwen3_coder" and a.api_key == "token-abc123"
     a = build_parser().parse_args(["serve", "m", "--max_model_len=64"])
     assert a.max_model_len == 64
+    # options of vLLM's own CLI that tune machinery absent here are accepted (and reported), rope overrides map
+    # onto the HF config, and an option that asks for a missing feature is refused
+    from vllm_distributed_amd.engine.arg_utils import EngineArgs
+    a = build_parser().parse_args(
+        ["serve", "llama-tiny", "--swap-space", "4", "--disable-log-requests", "-O", "3", "--max-seq-len-to-capture",
+         "8192", "--rope-theta", "1000000", "--rope-scaling", '{"rope_type": "dynamic", "factor": 2.0}',
+         "--no-enable-prefix-caching", "--device", "cpu"])
+    a.model = a.model_tag
+    e = EngineArgs.from_cli_args(a)
+    assert e.hf_overrides == {"rope_scaling": {"rope_type": "dynamic", "factor": 2.0}, "rope_theta": 1000000.0}
+    assert e.enable_prefix_caching is False and a.compat_swap_space == "4" and a.compat_disable_log_requests
+    with pytest.raises(ValueError):
+        EngineArgs.from_cli_args(build_parser().parse_args(["serve", "m", "--speculative-config", "{}"]))
 
 
 @pytest.mark.parametrize("frontend_mp", [True, False])

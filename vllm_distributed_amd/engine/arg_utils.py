@@ -13,8 +13,11 @@ import json
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional
 
+from ..logger import init_logger
 from ..config import (CacheConfig, CompilationConfig, DeviceConfig, KVTransferConfig, LoRAConfig, ModelConfig,
                       ObservabilityConfig, ParallelConfig, SchedulerConfig, VllmConfig)
+
+logger = init_logger(__name__)
 
 
 @dataclass
@@ -105,12 +108,39 @@ class EngineArgs:
         g.add_argument("--enable-lora", action="store_true", help="serve LoRA adapters next to the base model")
         g.add_argument("--max-loras", type=int, default=1, help="adapters resident (and usable in one batch) at once")
         g.add_argument("--max-lora-rank", type=int, default=16)
+        g.add_argument("--rope-scaling", type=json.loads, default=None,
+                       help='JSON, e.g. {"rope_type": "yarn", "factor": 4.0, "original_max_position_embeddings": 32768}')
+        g.add_argument("--rope-theta", type=float, default=None)
+        # vLLM options that tune machinery this build does not have (CPU swap space, torch.compile levels,
+        # CUDA-graph padding limits, request logging...): accepted so an existing command line keeps
+        # working, reported once at start-up, otherwise without effect
+        c = parser.add_argument_group("accepted for vLLM command-line compatibility (no effect)")
+        for flag in COMPAT_FLAGS_NO_VALUE:
+            c.add_argument(flag, action="store_true", dest="compat_" + flag.lstrip("-").replace("-", "_"),
+                           help=argparse.SUPPRESS)
+        for flag in COMPAT_FLAGS_ONE_VALUE:
+            c.add_argument(*flag.split("|"), type=str, default=None,
+                           dest="compat_" + flag.split("|")[0].lstrip("-").replace("-", "_"), help=argparse.SUPPRESS)
+        c.add_argument("--speculative-config", type=str, default=None, help=argparse.SUPPRESS)
         return parser
 
     @classmethod
     def from_cli_args(cls, args: argparse.Namespace) -> "EngineArgs":
         names = [f.name for f in dataclasses.fields(cls)]
-        return cls(**{n: getattr(args, n) for n in names if hasattr(args, n)})
+        self = cls(**{n: getattr(args, n) for n in names if hasattr(args, n)})
+        if getattr(args, "speculative_config", None):
+            raise ValueError("--speculative-config: speculative decoding is not implemented in this build")
+        overrides = dict(self.hf_overrides or {})
+        if getattr(args, "rope_scaling", None):
+            overrides["rope_scaling"] = args.rope_scaling
+        if getattr(args, "rope_theta", None):
+            overrides["rope_theta"] = args.rope_theta
+        self.hf_overrides = overrides or None
+        ignored = sorted("--" + k[len("compat_"):].replace("_", "-") for k, v in vars(args).items()
+                         if k.startswith("compat_") and v not in (None, False))
+        if ignored:
+            logger.warning("vLLM options without effect in this build: %s", " ".join(ignored))
+        return self
 
     # ------------------------------------------------------------- config
     def create_engine_config(self) -> VllmConfig:
@@ -155,5 +185,24 @@ class EngineArgs:
                           observability_config=ObservabilityConfig(), kv_transfer_config=kvt,
                           lora_config=lora)
 
+
+COMPAT_FLAGS_NO_VALUE = (
+    "--disable-log-requests", "--enable-log-requests", "--no-enable-log-requests", "--enable-sleep-mode",
+    "--disable-sliding-window", "--disable-cascade-attn", "--enable-request-id-headers",
+    "--return-tokens-as-token-ids", "--disable-fastapi-docs", "--enable-prompt-tokens-details",
+    "--enable-server-load-tracking", "--disable-hybrid-kv-cache-manager", "--enable-reasoning",
+    "--disable-async-output-proc", "--multi-step-stream-outputs", "--use-v2-block-manager", "--allow-credentials",
+    "--fully-sharded-loras")
+COMPAT_FLAGS_ONE_VALUE = (
+    "--swap-space", "--cpu-offload-gb", "--download-dir", "--tokenizer-mode", "--max-seq-len-to-capture",
+    "--max-logprobs", "--max-parallel-loading-workers", "--compilation-config|-O", "--guided-decoding-backend",
+    "--structured-outputs-config", "--reasoning-parser", "--response-role", "--root-path",
+    "--chat-template-content-format", "--limit-mm-per-prompt", "--tokenizer-revision", "--code-revision",
+    "--config-format", "--max-num-partial-prefills", "--max-long-partial-prefills", "--num-scheduler-steps",
+    "--preemption-mode", "--allowed-origins", "--allowed-methods", "--allowed-headers",
+    "--mm-processor-kwargs", "--override-generation-config", "--logits-processor-pattern", "--otlp-traces-endpoint",
+    "--worker-extension-cls", "--model-impl", "--task", "--runner", "--convert", "--tokenizer-pool-size",
+    "--num-lookahead-slots", "--scheduler-delay-factor", "--max-cpu-loras",
+    "--api-server-count", "--middleware", "--max-log-len")
 
 AsyncEngineArgs = EngineArgs
