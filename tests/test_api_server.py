@@ -314,3 +314,56 @@ def test_generation_config_supplies_defaults_and_extra_eos_ids(tmp_path):
     a, b, stop = serve(" --generation-config vllm")
     assert a["usage"]["completion_tokens"] > 7              # runs to the context limit: no cap from the file
     assert stop["choices"][0]["finish_reason"] == "length" and stop["usage"]["completion_tokens"] == 6
+
+
+def test_reasoning_splitters_are_chunking_invariant():
+    import random
+    from vllm_distributed_amd.entrypoints.openai.reasoning import (DeepSeekR1ReasoningSplitter as D,
+                                                                   Qwen3ReasoningSplitter as Q)
+    cases = [("<think>abc</think>hello", ("abc", "hello"), ("abc", "hello")),
+             ("  \n<think>a<b</thin</think>\n\nhi <think>", ("a<b</thin", "\n\nhi <think>"), ("a<b</thin", "\n\nhi <think>")),
+             ("plain answer", ("", "plain answer"), ("plain answer", "")),
+             ("abc</think>rest", ("", "abc</think>rest"), ("abc", "rest")),
+             ("<think>never ends", ("never ends", ""), ("never ends", "")),
+             ("<thi", ("", "<thi"), ("<thi", "")), ("", ("", ""), ("", ""))]
+    rnd = random.Random(0)
+    for text, want_q, want_d in cases:
+        for cls, want in ((Q, want_q), (D, want_d)):
+            assert cls.split(text) == want, (cls.__name__, text)
+            for _ in range(40):             # any way of cutting the text into deltas gives the same split
+                s, r, c, i = cls(), "", "", 0
+                while i < len(text):
+                    k = rnd.randint(1, 4)
+                    a, b = s.feed(text[i:i + k])
+                    r, c, i = r + a, c + b, i + k
+                a, b = s.flush()
+                assert (r + a, c + b) == want, (cls.__name__, text)
+
+
+def test_reasoning_parser_routes_chat_output_to_reasoning_content():
+    """--reasoning-parser deepseek_r1: text before </think> is reasoning_content.  A random-init model never
+    closes the block, so the whole completion lands there, streamed and not."""
+    pstate.destroy_model_parallel()
+    args = build_parser().parse_args(
+        ("serve llama-tiny --device cpu --dtype float32 --max-model-len 128 --block-size 16 "
+         "--num-gpu-blocks-override 64 --port 0 --disable-frontend-multiprocessing "
+         "--reasoning-parser deepseek_r1").split())
+    args.model = args.model_tag
+
+    async def main():
+        async with api_server.build_async_engine_client(args) as engine:
+            app = api_server.build_app(args)
+            await api_server.init_app_state(engine, await engine.get_vllm_config(), app.state, args)
+            async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://t") as c:
+                body = {"messages": [{"role": "user", "content": "hi"}], "max_tokens": 12, "temperature": 0,
+                        "ignore_eos": True, "allowed_token_ids": list(range(97, 123))}
+                r = (await c.post("/v1/chat/completions", json=body)).json()
+                msg = r["choices"][0]["message"]
+                assert msg["content"] is None and len(msg["reasoning_content"]) == 12
+                s = await c.post("/v1/chat/completions", json=dict(body, stream=True))
+                ev = [json.loads(l[6:]) for l in s.text.split("\n\n") if l.startswith("data: ") and l != "data: [DONE]"]
+                streamed = "".join(e["choices"][0]["delta"].get("reasoning_content", "") for e in ev)
+                assert streamed == msg["reasoning_content"]
+                assert not any(e["choices"][0]["delta"].get("content") for e in ev)
+    asyncio.run(main())
+    pstate.destroy_model_parallel()

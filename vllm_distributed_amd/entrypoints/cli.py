@@ -42,6 +42,8 @@ def add_server_args(p: argparse.ArgumentParser) -> None:
     g.add_argument("--enable-auto-tool-choice", action="store_true")
     g.add_argument("--tool-call-parser", type=str, default=None)
     g.add_argument("--tool-parser-plugin", type=str, default="")
+    g.add_argument("--reasoning-parser", type=str, default=None, choices=["qwen3", "deepseek_r1"],
+                   help="split <think>...</think> out of chat completions into reasoning_content")
     g.add_argument("--chat-template", type=str, default=None)
     g.add_argument("--enable-tokenizer-info-endpoint", action="store_true")
     g.add_argument("--lora-modules", type=str, nargs="+", default=None, metavar="NAME=PATH",

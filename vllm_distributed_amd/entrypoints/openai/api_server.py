@@ -242,6 +242,10 @@ async def init_app_state(engine: AsyncLLM, vllm_config, state, args: argparse.Na
     name = getattr(args, "tool_call_parser", None)
     if getattr(args, "enable_auto_tool_choice", False) and name:
         state.tool_parser = ToolParserManager.get_tool_parser(name)(engine.tokenizer)
+    state.reasoning = None
+    if getattr(args, "reasoning_parser", None):
+        from .reasoning import ReasoningParserManager
+        state.reasoning = ReasoningParserManager.get(args.reasoning_parser)
     state.chat_template = None
     ct = getattr(args, "chat_template", None)
     if ct:
@@ -604,12 +608,21 @@ def _register_routes(app: FastAPI) -> None:
                 final = None
                 held = ""
                 seen = 0
+                splitter = st.reasoning() if st.reasoning is not None else None
                 async for out in g:
                     seen += 1
                     if seen % 16 == 0 and await request.is_disconnected():
                         return
                     final = out
                     text = out.new_text
+                    if splitter is not None:
+                        thought, text = splitter.feed(text)
+                        if out.finished:
+                            t2, c2 = splitter.flush()
+                            thought, text = thought + t2, text + c2
+                        if thought:
+                            yield chunk(index, {"reasoning_content": thought}, lp=lp_content(out, sent))
+                            sent = len(out.outputs[0].token_ids)
                     if parser is not None:
                         # tool-call syntax must be parsed as a whole: hold text once a call starts
                         held += text
@@ -689,13 +702,20 @@ def _register_routes(app: FastAPI) -> None:
         choices, n_out = [], 0
         for j, final in enumerate(finals):
             c = final.outputs[0]
-            message: Dict[str, Any] = {"role": "assistant", "content": c.text}
+            text, thought = c.text, None
+            if st.reasoning is not None:
+                thought, text = st.reasoning.split(c.text)
+            message: Dict[str, Any] = {"role": "assistant", "content": text}
             finish = c.finish_reason
             if parser is not None:
-                content, calls = parser.extract(c.text, tools)
+                content, calls = parser.extract(text, tools)
                 if calls:
                     message = {"role": "assistant", "content": content, "tool_calls": calls}
                     finish = "tool_calls"
+            if st.reasoning is not None:
+                message["reasoning_content"] = thought or None
+                if not message["content"]:
+                    message["content"] = None
             choices.append({"index": j, "message": message, "logprobs": lp_content(final, 0),
                             "finish_reason": finish, "stop_reason": c.stop_reason})
             n_out += len(c.token_ids)
