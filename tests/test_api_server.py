@@ -180,6 +180,13 @@ def test_server_endpoints_end_to_end(frontend_mp):
                 met = (await c.get("/metrics")).text
                 assert "vllm:generation_tokens_total" in met and "vllm:time_to_first_token_seconds" in met
                 assert (await c.post("/reset_prefix_cache")).status_code == 200
+                inv = await c.post("/invocations", headers=hdr, json={"prompt": "hello", "max_tokens": 3, "temperature": 0})
+                assert inv.status_code == 200 and inv.json()["object"] == "text_completion"
+                inv = await c.post("/invocations", headers=hdr, json={
+                    "messages": [{"role": "user", "content": "hi"}], "max_tokens": 3})
+                assert inv.status_code == 200 and inv.json()["object"] == "chat.completion"
+                assert (await c.post("/invocations", headers=hdr, json={"x": 1})).status_code == 400
+                assert (await c.get("/is_sleeping", headers=hdr)).json() == {"is_sleeping": False}
     asyncio.run(main())
     pstate.destroy_model_parallel()
 

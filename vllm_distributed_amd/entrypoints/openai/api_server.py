@@ -396,12 +396,34 @@ def _register_routes(app: FastAPI) -> None:
     @app.post("/sleep")
     async def sleep(request: Request, level: int = 1):
         await request.app.state.engine.sleep(level)
+        request.app.state.sleeping = True
         return Response(status_code=200)
 
     @app.post("/wake_up")
     async def wake_up(request: Request):
         await request.app.state.engine.wake_up()
+        request.app.state.sleeping = False
         return Response(status_code=200)
+
+    @app.get("/is_sleeping")
+    async def is_sleeping(request: Request):
+        return {"is_sleeping": bool(getattr(request.app.state, "sleeping", False))}
+
+    @app.post("/invocations")
+    async def invocations(request: Request):
+        """Single-endpoint form (SageMaker-style): the body decides between chat and text completion."""
+        try:
+            body = await request.json()
+        except Exception:  # noqa: BLE001
+            return _error("the request body is not JSON")
+        try:
+            if isinstance(body, dict) and "messages" in body:
+                return await chat_completions(ChatCompletionRequest(**body), request)
+            if isinstance(body, dict) and "prompt" in body:
+                return await completions(CompletionRequest(**body), request)
+        except ValueError as e:             # pydantic validation errors are ValueErrors
+            return _error(str(e))
+        return _error("the body needs either `messages` (chat) or `prompt` (completion)")
 
     def _check_model(st, name: Optional[str]) -> Optional[JSONResponse]:
         if name and name not in st.served_names and name not in st.loras:
