@@ -797,8 +797,9 @@ class ModelRunner:
     def _enable_gemm_tuning(self) -> bool:
         """Let the library time its candidate kernels for each decode GEMM shape
         during the warm-up passes that precede graph capture (measured on
-        MI355X: Llama-3-8B decode at batch 256 -5% per step, Llama-3-70B at batch
-        2048 -1.7%).  Results persist in ``VDAMD_TUNE_GEMM_FILE``."""
+        MI355X: Llama-3-8B decode at batch 256 -5% per step; Llama-3-70B at batch
+        2048 between -1.7% and +3.4% from run to run, the short timing runs being
+        noisy at that size - hence opt-in).  Results persist in ``VDAMD_TUNE_GEMM_FILE``."""
         try:
             tun = torch.cuda.tunable
             tun.enable(True)
