@@ -423,7 +423,7 @@ class ParallelLMHead(VocabParallelEmbedding):
         self.bias = _param(self.rows, dtype=dtype) if bias else None
 
     def logits(self, hidden: torch.Tensor) -> torch.Tensor:
-        y = F.linear(hidden, self.weight, self.bias)
+        y = ops.linear(hidden, self.weight, self.bias)
         if self.tp > 1:
             y = tensor_model_parallel_all_gather(y, dim=-1)
         return y[..., :self.vocab_size]
@@ -433,7 +433,7 @@ class ParallelLMHead(VocabParallelEmbedding):
         ``(max, index)`` pair per row and only those pairs are all-gathered -
         ``8 * B`` bytes per rank instead of a ``[B, vocab]`` logits gather.
         Ties resolve to the lowest token id, like a full-row argmax."""
-        y = F.linear(hidden, self.weight, self.bias)
+        y = ops.linear(hidden, self.weight, self.bias)
         valid = max(0, min(self.rows, self.vocab_size - self.vocab_start))
         if valid == 0:
             val = torch.full((y.shape[0],), float("-inf"), dtype=torch.float32, device=y.device)

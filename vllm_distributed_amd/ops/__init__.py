@@ -145,7 +145,7 @@ def embedding(ids, weight, vocab_start=0, masked=False):
 def linear(x, weight, bias=None):
     """``x @ weight^T (+ bias)``: the library GEMM, except for short batches on
     long-reduction shapes where the weight-streaming HIP kernel is faster."""
-    if (x.is_cuda and x.dim() == 2 and x.shape[0] <= 128 and weight.shape[1] >= 2 * weight.shape[0]
+    if (x.is_cuda and x.dim() == 2 and x.shape[0] <= 128
             and envs.VDAMD_SKINNY_GEMM and _use_hip(x)
             and _hip.skinny_profitable(x.shape[0], weight.shape[0], weight.shape[1])
             and _hip.skinny_supported(x, weight)):
