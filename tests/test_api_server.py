@@ -168,6 +168,25 @@ def test_server_endpoints_end_to_end(frontend_mp):
                 assert (await c.post("/v1/chat/completions", headers=hdr, json={
                     "messages": [{"role": "user", "content": "hi"}],
                     "response_format": {"type": "json_schema", "json_schema": {}}})).status_code == 400
+                # a named tool choice: the reply is that call, its arguments one JSON object (streamed as fragments)
+                tool = {"type": "function", "function": {"name": "get_weather", "parameters": {"type": "object"}}}
+                named = {"messages": [{"role": "user", "content": "hi"}], "max_tokens": 200, "seed": 1, "tools": [tool],
+                         "tool_choice": {"type": "function", "function": {"name": "get_weather"}},
+                         "logit_bias": {str(ord('"')): 4, str(ord("}")): 5, str(ord(":")): 3}}
+                rt = (await c.post("/v1/chat/completions", headers=hdr, json=named)).json()
+                call = rt["choices"][0]["message"]["tool_calls"][0]
+                assert call["function"]["name"] == "get_weather" and rt["choices"][0]["message"]["content"] is None
+                if rt["choices"][0]["finish_reason"] == "tool_calls":
+                    assert isinstance(json.loads(call["function"]["arguments"]), dict)
+                rs = await c.post("/v1/chat/completions", headers=hdr, json=dict(named, stream=True))
+                evs = [json.loads(l[6:]) for l in rs.text.split("\n\n") if l.startswith("data: ") and l != "data: [DONE]"]
+                frags = [tc for e in evs for tc in e["choices"][0]["delta"].get("tool_calls", [])]
+                assert frags[0]["function"]["name"] == "get_weather"
+                assert "".join(f["function"].get("arguments", "") for f in frags) == call["function"]["arguments"]
+                assert (await c.post("/v1/chat/completions", headers=hdr, json=dict(
+                    named, tool_choice={"type": "function", "function": {"name": "nope"}}))).status_code == 400
+                assert (await c.post("/v1/chat/completions", headers=hdr, json=dict(
+                    named, tool_choice="required"))).status_code == 400
                 r10 = await c.post("/v1/chat/completions", headers=hdr, json={
                     "messages": [{"role": "user", "content": "hi"}], "max_tokens": 2, "prompt_logprobs": 0})
                 pl = r10.json()["prompt_logprobs"]

@@ -579,6 +579,15 @@ def _register_routes(app: FastAPI) -> None:
         tok = engine.tokenizer
         messages = _messages_to_dicts(req.messages)
         tools = req.tools if req.tool_choice != "none" else None
+        # a named tool: the reply *is* that call, its arguments constrained to one JSON object
+        forced_tool: Optional[str] = None
+        if isinstance(req.tool_choice, dict):
+            forced_tool = (req.tool_choice.get("function") or {}).get("name")
+            known = [(t.get("function") or {}).get("name") for t in (req.tools or [])]
+            if not forced_tool or forced_tool not in known:
+                return _error(f"tool_choice names {forced_tool!r}, which is not one of the request's tools")
+        elif req.tool_choice == "required":
+            return _error("tool_choice 'required' is not supported (use 'auto', 'none' or a named function)")
         try:
             kwargs = dict(req.chat_template_kwargs or {})
             template = req.chat_template or st.chat_template
@@ -596,10 +605,13 @@ def _register_routes(app: FastAPI) -> None:
             sp = _sampling_params(req, None, st.max_model_len, n_lp, st.default_sampling)
         except ValueError as e:
             return _error(str(e))
+        if forced_tool:
+            sp.json_object = True
         model = req.model or st.served_names[0]
         rid = "chatcmpl-" + uuid.uuid4().hex
         created = int(time.time())
-        parser = st.tool_parser if tools else None
+        parser = st.tool_parser if tools and not forced_tool else None
+        from .tool_parsers import _call_id
         gens = [engine.generate({"prompt": prompt, "prompt_token_ids": prompt_ids}, _nth_params(sp, j),
                                 rid if n == 1 else f"{rid}-{j}", req.priority,
                                 st.loras.get(req.model) if req.model else None) for j in range(n)]
@@ -626,6 +638,9 @@ def _register_routes(app: FastAPI) -> None:
             async def choice_events(index: int, g, counts: List[int]) -> AsyncIterator[str]:
                 """SSE events of one sample; ``counts[index]`` ends up holding its token count."""
                 yield chunk(index, {"role": "assistant", "content": ""})
+                if forced_tool:
+                    yield chunk(index, {"tool_calls": [{"index": 0, "id": _call_id(), "type": "function",
+                                                        "function": {"name": forced_tool, "arguments": ""}}]})
                 sent = 0
                 final = None
                 held = ""
@@ -652,12 +667,15 @@ def _register_routes(app: FastAPI) -> None:
                             text = ""
                         else:
                             text, held = held, ""
-                    if text or (parser is None and len(out.outputs[0].token_ids) > sent):
+                    if forced_tool:
+                        if text:
+                            yield chunk(index, {"tool_calls": [{"index": 0, "function": {"arguments": text}}]})
+                    elif text or (parser is None and len(out.outputs[0].token_ids) > sent):
                         yield chunk(index, {"content": text}, lp=lp_content(out, sent))
                         sent = len(out.outputs[0].token_ids)
                 c = final.outputs[0]
                 counts[index] = len(c.token_ids)
-                finish = c.finish_reason
+                finish = "tool_calls" if forced_tool and c.finish_reason == "stop" else c.finish_reason
                 if parser is not None and held:
                     content, calls = parser.extract(held, tools)
                     if calls:
@@ -734,6 +752,10 @@ def _register_routes(app: FastAPI) -> None:
                 if calls:
                     message = {"role": "assistant", "content": content, "tool_calls": calls}
                     finish = "tool_calls"
+            if forced_tool:
+                message = {"role": "assistant", "content": None, "tool_calls": [
+                    {"id": _call_id(), "type": "function", "function": {"name": forced_tool, "arguments": text}}]}
+                finish = "tool_calls" if c.finish_reason == "stop" else c.finish_reason
             if st.reasoning is not None:
                 message["reasoning_content"] = thought or None
                 if not message["content"]:
