@@ -9,7 +9,8 @@
 #   scripts/run_config.sh 4   Llama-3-70B, TP=8 (head owns all 8 GPUs)
 #   scripts/run_config.sh 5   Llama-3-70B, TP=4 x PP=2 (head 4 GPUs + one 4-GPU worker node)
 #
-# Environment: PORT (8000), NUM_PROMPTS (256), CONCURRENCY (64), INPUT_LEN (128), OUTPUT_LEN (64).
+# Environment: PORT (8000), NUM_PROMPTS (256), CONCURRENCY (64), INPUT_LEN (128), OUTPUT_LEN (64),
+# OUTPUT_JITTER (0: every request the same length; 0.5: lengths uniform in 32..96, requests desynchronised).
 set -euo pipefail
 cfg="${1:?config number 1-5}"
 here="$(cd "$(dirname "$0")/.." && pwd)"
@@ -56,4 +57,4 @@ done
 
 python "$here/benchmarks/serve_bench.py" --base-url "http://127.0.0.1:$port" --model "$model" \
   --vocab-size "$vocab" --num-prompts "${NUM_PROMPTS:-256}" --concurrency "${CONCURRENCY:-64}" \
-  --input-len "${INPUT_LEN:-128}" --output-len "${OUTPUT_LEN:-64}"
+  --input-len "${INPUT_LEN:-128}" --output-len "${OUTPUT_LEN:-64}" --output-len-jitter "${OUTPUT_JITTER:-0}"

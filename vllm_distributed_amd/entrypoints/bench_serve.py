@@ -61,7 +61,11 @@ async def run(args) -> dict:
     async with aiohttp.ClientSession(timeout=timeout, connector=aiohttp.TCPConnector(limit=0)) as session:
         async def guarded(i: int) -> None:
             prompt = [rng.randrange(3, args.vocab_size) for _ in range(args.input_len)]
-            payload = {"model": args.model, "prompt": prompt, "max_tokens": args.output_len, "temperature": 0.0,
+            out_len = args.output_len
+            jitter = float(getattr(args, "output_len_jitter", 0.0) or 0.0)
+            if jitter > 0:      # identical lengths make the requests finish (and the next ones arrive) in lock-step
+                out_len = max(1, round(args.output_len * (1.0 + rng.uniform(-jitter, jitter))))
+            payload = {"model": args.model, "prompt": prompt, "max_tokens": out_len, "temperature": 0.0,
                        "ignore_eos": True, "stream": True, "stream_options": {"include_usage": True}}
             async with sem:
                 await _one(session, url, headers, payload, result)
@@ -73,7 +77,8 @@ async def run(args) -> dict:
         xs = sorted(x for x in xs if x == x)
         return round(1e3 * xs[min(len(xs) - 1, int(p * len(xs)))], 2) if xs else None
     return {"num_prompts": args.num_prompts, "concurrency": args.concurrency, "input_len": args.input_len,
-            "output_len": args.output_len, "elapsed_s": round(elapsed, 3),
+            "output_len": args.output_len, "output_len_jitter": float(getattr(args, "output_len_jitter", 0.0) or 0.0),
+            "elapsed_s": round(elapsed, 3),
             "output_tokens_per_s": round(result["tokens"] / elapsed, 1),
             "requests_per_s": round(args.num_prompts / elapsed, 2),
             "ttft_p50_ms": pct(result["ttft"], 0.5), "ttft_p99_ms": pct(result["ttft"], 0.99),
@@ -87,6 +92,8 @@ def add_args(ap: argparse.ArgumentParser) -> None:
     ap.add_argument("--concurrency", type=int, default=16)
     ap.add_argument("--vocab-size", type=int, default=32000)
     ap.add_argument("--timeout", type=float, default=1800.0)
+    ap.add_argument("--output-len-jitter", type=float, default=0.0,
+                    help="draw each request's output length uniformly from output-len x (1 +- this fraction)")
 
 
 async def _first_model(args) -> str:
