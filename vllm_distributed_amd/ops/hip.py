@@ -477,11 +477,14 @@ def skinny_profitable(m: int, n: int, k: int) -> bool:
     graphs, benchmarks/skinny_gemm_bench.py): long reductions into a narrow
     output, for which the library's short-batch kernels reach only 1.6-4.8 TB/s
     (from 24 rows up when the output is 4096 wide or less - below that the
-    two are level), and very wide outputs over a short reduction at <= 16 rows."""
+    two are level), very wide outputs over a short reduction at <= 16 rows, and
+    4096-square projections at <= 16 rows."""
     if m > SKINNY_MAX_M:
         return False
     if k >= 2 * n and k >= 8192:
         return m >= 24 or n > 4096
+    if m <= 16 and n <= 4096 and 4096 <= k < 8192:      # a square 4096 projection: 11.2 vs 12.5 us at one row
+        return True
     return m <= 16 and n >= 16384 and k <= 4096
 
 
