@@ -225,3 +225,20 @@ def test_token_bytes_of_a_byte_level_bpe_tokenizer_round_trip(tmp_path):
         ids = tok.encode(text, add_special_tokens=False)
         assert b"".join(table[i] for i in ids) == text.encode("utf-8"), text
     assert any(len(t) > 1 for t in table)            # merges exist, so multi-byte tokens are covered
+
+
+def test_token_bytes_of_a_sentencepiece_style_vocabulary():
+    """SentencePiece spellings: U+2581 is a space, ``<0xNN>`` is one raw byte, specials are empty."""
+    from vllm_distributed_amd.tokenizer import HFTokenizer
+
+    class _Tok:
+        vocab = ["<s>", "</s>", "<0x0A>", "<0xE4>", "▁the", "▁", "ing", "▁{\"", "é"]
+        all_special_ids = [0, 1]
+        added_tokens_decoder = {0: None, 1: None}
+
+        def convert_ids_to_tokens(self, ids):
+            return [self.vocab[i] for i in ids]
+
+    tok = HFTokenizer.__new__(HFTokenizer)
+    tok.tok, tok.vocab_size, tok.all_special_ids = _Tok(), len(_Tok.vocab), [0, 1]
+    assert tok.token_bytes() == [b"", b"", b"\n", b"\xe4", b" the", b" ", b"ing", b' {"', "é".encode()]
