@@ -42,7 +42,7 @@ def run(t, h, f, hq, hkv, d=128, bs=64):
     print(f"T={t:5d} silu_and_mul F={f}: {us:7.1f} us  {3 * t * f * 2 / us / 1e6:5.2f} TB/s", flush=True)
     del gu
     qkv = [torch.randn(t, (hq + 2 * hkv) * d, device=dev, dtype=torch.bfloat16) for _ in range(COPIES)]
-    nblk = (t + bs - 1) // bs * 4
+    nblk = max((t + bs - 1) // bs * 4, t)          # the decode-like pattern below needs a block per token
     kc = torch.zeros(nblk, hkv, bs, d, device=dev, dtype=torch.bfloat16)
     vc = torch.zeros(nblk, hkv, d, bs, device=dev, dtype=torch.bfloat16)
     pos = torch.randint(0, 4096, (t,), device=dev, dtype=torch.int32)
@@ -53,6 +53,13 @@ def run(t, h, f, hq, hkv, d=128, bs=64):
     us = timeit(lambda i: hip.rope_and_cache(pos, qkv[i % COPIES], cs, kc, vc, slots, hq, hkv, d))
     by = t * ((hq + 2 * hkv) * d + (hq + hkv) * d + 2 * hkv * d) * 2
     print(f"T={t:5d} rope_and_cache Hq={hq} Hkv={hkv}: {us:7.1f} us  {by / us / 1e6:5.2f} TB/s", flush=True)
+    # a decode step: every sequence writes at (nearly) the same offset inside its own block
+    blocks = torch.randperm(nblk, device=dev)[:t]
+    for off, label in ((37, "same in-block offset"), (None, "in-block offset spread over 16")):
+        o = 37 if off is not None else (torch.arange(t, device=dev) % 16) + 30
+        dslots = (blocks * bs + o).to(torch.int32)
+        us = timeit(lambda i: hip.rope_and_cache(pos, qkv[i % COPIES], cs, kc, vc, dslots, hq, hkv, d))
+        print(f"T={t:5d} rope_and_cache, {label}: {us:7.1f} us", flush=True)
 
 
 for t in (256, 2048, 8192):
