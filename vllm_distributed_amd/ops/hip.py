@@ -357,7 +357,8 @@ def w4_choose_ksplit(m: int, n: int, k: int, variant: int = 0) -> int:
     mt = min(4, (m + 15) // 16)
     mz = (m + 16 * mt - 1) // (16 * mt)
     base = ((n // 16 + 3) // 4) * mz
-    return max(1, min((512 + base - 1) // base, (k // 128) // 8))
+    ks = max(1, min((512 + base - 1) // base, (k // 128) // 8))
+    return 1 << (ks.bit_length() - 1)       # power-of-two splits measured at or next to the optimum; 3 and 6 are not
 
 
 def w4_dequant(qw: torch.Tensor, sz: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
