@@ -484,7 +484,7 @@ def skinny_profitable(m: int, n: int, k: int) -> bool:
         return False
     if k >= 2 * n and k >= 8192:
         return m >= 24 or n > 4096
-    if m <= 16 and n <= 4096 and 4096 <= k < 8192:      # a square 4096 projection: 11.2 vs 12.5 us at one row
+    if m <= 16 and 2048 <= n <= 4096 and 4096 <= k < 8192:      # a square 4096 projection: 11.2 vs 12.5 us at one row
         return True
     return m <= 16 and n >= 16384 and k <= 4096
 
