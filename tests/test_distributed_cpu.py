@@ -144,6 +144,62 @@ def test_head_plus_remote_worker_matches_single_process(monkeypatch, model, tp, 
 
 
 @pytest.mark.slow
+@pytest.mark.parametrize("tp,pp", [(2, 1), (1, 2)])
+def test_request_level_features_through_remote_workers(monkeypatch, tp, pp):
+    """Logit edits, JSON mode and prompt logprobs travel with the request to every worker
+    (pickled sampling parameters, per-worker grammar state and vocabulary table) and give
+    what a single process gives."""
+    import json
+
+    def run(eng):
+        sps = [SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True, logit_bias={42: 100.0}),
+               SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True, allowed_token_ids=[3, 17, 99]),
+               SamplingParams(temperature=0.0, max_tokens=4, ignore_eos=True, prompt_logprobs=0),
+               SamplingParams(temperature=1.0, seed=1, max_tokens=60, json_object=True,
+                              logit_bias={ord('"'): 4.0, ord("}"): 5.0, ord(":"): 3.0})]
+        ids = [eng.add_request(None, PROMPTS[0], sp) for sp in sps]
+        final = {}
+        while eng.has_unfinished_requests():
+            for o in eng.step():
+                if o.finished:
+                    final[o.request_id] = o
+        return [final[i] for i in ids]
+
+    pstate.destroy_model_parallel()
+    single = LLMEngine.from_engine_args(EngineArgs(
+        model="llama-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,
+        num_gpu_blocks_override=64, max_num_seqs=8))
+    ref = run(single)
+    single.shutdown()
+    pstate.destroy_model_parallel()
+    port = get_open_port()
+    for k, v in _env(port, VLLM_HEAD_LOCAL_DEVICES="1").items():
+        monkeypatch.setenv(k, v)
+    remote = _start_remote(port, 1, 1)
+    eng = None
+    try:
+        eng = LLMEngine.from_engine_args(EngineArgs(
+            model="llama-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,
+            num_gpu_blocks_override=64, max_num_seqs=8, tensor_parallel_size=tp, pipeline_parallel_size=pp,
+            distributed_executor_backend="distributed"))
+        got = run(eng)
+    finally:
+        if eng is not None:
+            eng.shutdown()
+        remote.terminate()
+        remote.wait(timeout=10)
+    assert got[0].outputs[0].token_ids == [42] * 6
+    assert set(got[1].outputs[0].token_ids) <= {3, 17, 99}
+    assert got[1].outputs[0].token_ids == ref[1].outputs[0].token_ids
+    for a, b in zip(got[2].prompt_logprobs[1:], ref[2].prompt_logprobs[1:]):
+        (t, lp), = a.items()
+        assert abs(lp - b[t]) < 1e-3
+    assert got[3].outputs[0].token_ids == ref[3].outputs[0].token_ids
+    if got[3].outputs[0].finish_reason == "stop":
+        assert isinstance(json.loads(got[3].outputs[0].text), dict)
+
+
+@pytest.mark.slow
 def test_worker_death_fails_fast_and_unused_worker_is_tolerated(monkeypatch):
     port = get_open_port()
     for k, v in _env(port, VLLM_HEAD_LOCAL_DEVICES="1").items():
