@@ -1,12 +1,13 @@
 """Check: the reference's documented flags (--max-model-len 262144, Qwen3-Coder-480B shapes, AWQ) on a
 cut-down layer count: decode graphs capture, memory for the per-request tables stays small, and short
 and long contexts both decode.  Prints the time per decode step at a short and at a 100k-token context."""
+import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vllm_distributed_amd import LLM, SamplingParams  # noqa: E402
 
 llm = LLM(model="qwen3-coder-480b-a35b", load_format="dummy", quantization="awq", max_model_len=262144,
