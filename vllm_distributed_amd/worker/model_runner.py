@@ -561,14 +561,17 @@ class ModelRunner:
             if sp.logit_bias:
                 for t, val in sp.logit_bias.items():
                     if t < v:
-                        add_r.append(j); add_c.append(t); add_v.append(val)
+                        add_r.append(j)
+                        add_c.append(t)
+                        add_v.append(val)
             if sp.allowed_token_ids is not None:
                 allow.append((j, [t for t in sp.allowed_token_ids if t < v]))
             n_out = int(b.num_tokens[r]) - int(b.num_prompt_tokens[r])
             if sp.min_tokens > 0 and n_out < sp.min_tokens:
                 for t in sp.min_tokens_ban_ids:
                     if t < v:
-                        ban_r.append(j); ban_c.append(t)
+                        ban_r.append(j)
+                        ban_c.append(t)
             if sp.bad_words_token_ids:
                 if not synced:                      # the tail must hold every token generated so far
                     for pend in list(self._pending):
@@ -581,7 +584,8 @@ class ModelRunner:
                     if w[-1] >= v or k > nt - npt:
                         continue                    # the prefix has to come from generated tokens
                     if k == 0 or b.token_ids[r, nt - k:nt].tolist() == list(w[:-1]):
-                        ban_r.append(j); ban_c.append(w[-1])
+                        ban_r.append(j)
+                        ban_c.append(w[-1])
         dev = logits.device
         for j, r in enumerate(rows.tolist()):
             if b.grammar[r] is not None:
