@@ -10,7 +10,7 @@ from __future__ import annotations
 import argparse
 import dataclasses
 import json
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Any, Dict, List, Optional
 
 from ..logger import init_logger
