@@ -15,7 +15,7 @@ import itertools
 import queue
 import threading
 import time
-from typing import AsyncIterator, Dict, List, Optional, Sequence, Union
+from typing import AsyncIterator, Dict, Optional, Sequence, Union
 
 from ..config import VllmConfig
 from ..logger import init_logger

@@ -1,7 +1,7 @@
 """Incremental detokenisation with stop-string handling."""
 from __future__ import annotations
 
-from typing import List, Optional, Tuple
+from typing import List, Optional
 
 from ..sampling_params import SamplingParams
 

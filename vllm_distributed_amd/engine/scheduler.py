@@ -17,8 +17,8 @@ from __future__ import annotations
 
 import time
 from collections import deque
-from dataclasses import dataclass, field
-from typing import Deque, Dict, Iterable, List, Optional, Set, Tuple
+from dataclasses import dataclass
+from typing import Deque, Dict, Iterable, List, Optional, Set
 
 from ..config import CacheConfig, SchedulerConfig
 from ..logger import init_logger

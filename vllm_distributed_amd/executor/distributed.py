@@ -28,12 +28,11 @@ import asyncio
 import concurrent.futures
 import multiprocessing
 import os
-import sys
 import threading
 import time
 import traceback
 import weakref
-from typing import Any, Callable, Dict, List, Optional, Tuple, Union
+from typing import Any, Callable, Dict, List, Optional, Union
 
 import cloudpickle
 

@@ -12,7 +12,6 @@ Rank and world size come from ``RANK`` / ``LOCAL_RANK`` / ``WORLD_SIZE`` /
 """
 from __future__ import annotations
 
-import concurrent.futures
 import os
 from typing import Any, Callable, List, Optional, Union
 

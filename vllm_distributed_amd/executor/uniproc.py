@@ -1,10 +1,9 @@
 """Single worker in the engine's own process (TP=PP=1)."""
 from __future__ import annotations
 
-import concurrent.futures
 from typing import Any, Callable, List, Optional, Union
 
-from ..utils import get_distributed_init_method, get_ip, get_open_port, run_method
+from ..utils import run_method
 from ..worker.worker_base import WorkerWrapperBase
 from .abstract import Executor, LazyFuture
 

@@ -15,7 +15,6 @@ import multiprocessing
 import multiprocessing.connection
 import os
 import sys
-import time
 import traceback
 import uuid
 from typing import Any, Dict, Optional

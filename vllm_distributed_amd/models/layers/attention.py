@@ -9,7 +9,7 @@ prefix) go to the varlen prefill kernel.  Both read K/V through block tables.
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List, Optional
+from typing import Optional
 
 import torch
 import torch.nn as nn

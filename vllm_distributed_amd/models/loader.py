@@ -24,7 +24,7 @@ import hashlib
 import json
 import os
 import re
-from typing import Callable, Dict, Iterable, Iterator, List, Optional, Tuple
+from typing import Callable, Dict, Iterable, Iterator, Optional, Tuple
 
 import torch
 

@@ -10,8 +10,6 @@ from __future__ import annotations
 
 import gc
 import os
-import sys
-import time
 from typing import Any, Dict, List, Optional
 
 import torch
