@@ -206,6 +206,13 @@ def test_server_endpoints_end_to_end(frontend_mp):
                 assert inv.status_code == 200 and inv.json()["object"] == "chat.completion"
                 assert (await c.post("/invocations", headers=hdr, json={"x": 1})).status_code == 400
                 assert (await c.get("/is_sleeping", headers=hdr)).json() == {"is_sleeping": False}
+                # browser clients: the CORS preflight is answered without a key, responses carry the allow header
+                pre = await c.options("/v1/chat/completions", headers={
+                    "Origin": "http://ui.example", "Access-Control-Request-Method": "POST",
+                    "Access-Control-Request-Headers": "authorization,content-type"})
+                assert pre.status_code == 200 and pre.headers["access-control-allow-origin"] == "*"
+                got = await c.get("/v1/models", headers=dict(hdr, Origin="http://ui.example"))
+                assert got.headers["access-control-allow-origin"] == "*"
     asyncio.run(main())
     pstate.destroy_model_parallel()
 

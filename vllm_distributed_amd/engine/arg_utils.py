@@ -191,7 +191,7 @@ COMPAT_FLAGS_NO_VALUE = (
     "--disable-sliding-window", "--disable-cascade-attn", "--enable-request-id-headers",
     "--return-tokens-as-token-ids", "--disable-fastapi-docs", "--enable-prompt-tokens-details",
     "--enable-server-load-tracking", "--disable-hybrid-kv-cache-manager", "--enable-reasoning",
-    "--disable-async-output-proc", "--multi-step-stream-outputs", "--use-v2-block-manager", "--allow-credentials",
+    "--disable-async-output-proc", "--multi-step-stream-outputs", "--use-v2-block-manager",
     "--fully-sharded-loras")
 COMPAT_FLAGS_ONE_VALUE = (
     "--swap-space", "--cpu-offload-gb", "--download-dir", "--tokenizer-mode", "--max-seq-len-to-capture",
@@ -199,7 +199,7 @@ COMPAT_FLAGS_ONE_VALUE = (
     "--structured-outputs-config", "--response-role", "--root-path",
     "--chat-template-content-format", "--limit-mm-per-prompt", "--tokenizer-revision", "--code-revision",
     "--config-format", "--max-num-partial-prefills", "--max-long-partial-prefills", "--num-scheduler-steps",
-    "--preemption-mode", "--allowed-origins", "--allowed-methods", "--allowed-headers",
+    "--preemption-mode",
     "--mm-processor-kwargs", "--override-generation-config", "--logits-processor-pattern", "--otlp-traces-endpoint",
     "--worker-extension-cls", "--model-impl", "--task", "--runner", "--convert", "--tokenizer-pool-size",
     "--num-lookahead-slots", "--scheduler-delay-factor", "--max-cpu-loras",

@@ -42,6 +42,10 @@ def add_server_args(p: argparse.ArgumentParser) -> None:
     g.add_argument("--enable-auto-tool-choice", action="store_true")
     g.add_argument("--tool-call-parser", type=str, default=None)
     g.add_argument("--tool-parser-plugin", type=str, default="")
+    g.add_argument("--allowed-origins", type=json.loads, default=["*"], help="CORS: JSON list of origins")
+    g.add_argument("--allowed-methods", type=json.loads, default=["*"])
+    g.add_argument("--allowed-headers", type=json.loads, default=["*"])
+    g.add_argument("--allow-credentials", action="store_true")
     g.add_argument("--reasoning-parser", type=str, default=None, choices=["qwen3", "deepseek_r1"],
                    help="split <think>...</think> out of chat completions into reasoning_content")
     g.add_argument("--chat-template", type=str, default=None)

@@ -199,6 +199,13 @@ async def build_async_engine_client(args: argparse.Namespace, client_config: Opt
 def build_app(args: argparse.Namespace) -> FastAPI:
     app = FastAPI(title="vllm-distributed-amd", version=__version__)
     api_key = getattr(args, "api_key", None) or envs.VLLM_API_KEY
+    # cross-origin access for browser clients; open by default, as in vLLM's server
+    from fastapi.middleware.cors import CORSMiddleware
+    app.add_middleware(CORSMiddleware,
+                       allow_origins=getattr(args, "allowed_origins", None) or ["*"],
+                       allow_credentials=bool(getattr(args, "allow_credentials", False)),
+                       allow_methods=getattr(args, "allowed_methods", None) or ["*"],
+                       allow_headers=getattr(args, "allowed_headers", None) or ["*"])
 
     if api_key:
         @app.middleware("http")
