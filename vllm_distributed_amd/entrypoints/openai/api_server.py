@@ -283,6 +283,11 @@ def _sampling_params(req, default_max: Optional[int], max_model_len: int, logpro
         if name not in given or v is None:
             return defaults.get(name, fallback)
         return v
+    extra = req.model_extra or {}
+    unsupported = [k for k in ("guided_json", "guided_regex", "guided_choice", "guided_grammar", "structured_outputs")
+                   if extra.get(k) is not None]
+    if unsupported:      # refusing beats silently generating unconstrained text
+        raise ValueError(f"{', '.join(unsupported)}: guided decoding beyond response_format json_object is not supported")
     rf = (req.response_format or {}).get("type", "text")
     if rf not in ("text", "json_object"):
         raise ValueError(f"response_format type {rf!r} is not supported (text, json_object)")
