@@ -169,7 +169,12 @@ def test_server_endpoints_end_to_end(frontend_mp):
                     "messages": [{"role": "user", "content": "hi"}],
                     "response_format": {"type": "json_schema", "json_schema": {}}})).status_code == 400
                 assert (await c.post("/v1/completions", headers=hdr, json={
-                    "prompt": "x", "guided_choice": ["a", "b"]})).status_code == 400
+                    "prompt": "x", "guided_regex": "a|b"})).status_code == 400
+                gc = await c.post("/v1/chat/completions", headers=hdr, json={
+                    "messages": [{"role": "user", "content": "hi"}], "max_tokens": 16, "temperature": 1.0, "seed": 2,
+                    "guided_choice": ["positive", "negative", "neutral"]})
+                assert gc.status_code == 200, gc.text
+                assert gc.json()["choices"][0]["message"]["content"] in ("positive", "negative", "neutral")
                 # a named tool choice: the reply is that call, its arguments one JSON object (streamed as fragments)
                 tool = {"type": "function", "function": {"name": "get_weather", "parameters": {"type": "object"}}}
                 named = {"messages": [{"role": "user", "content": "hi"}], "max_tokens": 200, "seed": 1, "tools": [tool],

@@ -242,3 +242,25 @@ def test_token_bytes_of_a_sentencepiece_style_vocabulary():
     tok = HFTokenizer.__new__(HFTokenizer)
     tok.tok, tok.vocab_size, tok.all_special_ids = _Tok(), len(_Tok.vocab), [0, 1]
     assert tok.token_bytes() == [b"", b"", b"\n", b"\xe4", b" the", b" ", b"ing", b' {"', "é".encode()]
+
+
+def test_guided_choice_yields_exactly_one_of_the_strings():
+    from vllm_distributed_amd.ops.grammar import ChoiceGrammar, TokenTable
+    table = TokenTable([b"y", b"ye", b"yes", b"n", b"no", b"o", b"s", b"", b"x", b"yesterday"], 10)
+    g = ChoiceGrammar(["yes", "no", "yesterday"])
+    assert g.mask(table).tolist() == [1, 1, 1, 1, 1, 0, 0, 0, 0, 1]
+    assert g.advance(b"ye") and not g.advance(b"x") and not g.done and not g.may_stop
+    assert g.mask(table).tolist() == [0, 0, 0, 0, 0, 0, 1, 0, 0, 0]
+    assert g.advance(b"s") and g.may_stop and not g.done          # "yesterday" is still possible
+    assert g.advance(b"terday") and g.done
+    pstate.destroy_model_parallel()
+    llm = LLM(**KW)
+    choices = ["alpha", "beta", "alphabet"]
+    outs = llm.generate(["hello world"] * 6,
+                        [SamplingParams(temperature=1.0, seed=s, max_tokens=20, guided_choice=choices) for s in range(6)])
+    for o in outs:
+        assert o.outputs[0].text in choices and o.outputs[0].finish_reason == "stop"
+    with pytest.raises(ValueError):
+        SamplingParams(guided_choice=[])
+    llm.shutdown()
+    pstate.destroy_model_parallel()

@@ -284,10 +284,11 @@ def _sampling_params(req, default_max: Optional[int], max_model_len: int, logpro
             return defaults.get(name, fallback)
         return v
     extra = req.model_extra or {}
-    unsupported = [k for k in ("guided_json", "guided_regex", "guided_choice", "guided_grammar", "structured_outputs")
+    unsupported = [k for k in ("guided_json", "guided_regex", "guided_grammar", "structured_outputs")
                    if extra.get(k) is not None]
     if unsupported:      # refusing beats silently generating unconstrained text
-        raise ValueError(f"{', '.join(unsupported)}: guided decoding beyond response_format json_object is not supported")
+        raise ValueError(f"{', '.join(unsupported)}: guided decoding beyond response_format json_object and "
+                         f"guided_choice is not supported")
     rf = (req.response_format or {}).get("type", "text")
     if rf not in ("text", "json_object"):
         raise ValueError(f"response_format type {rf!r} is not supported (text, json_object)")
@@ -303,6 +304,7 @@ def _sampling_params(req, default_max: Optional[int], max_model_len: int, logpro
         skip_special_tokens=req.skip_special_tokens, logit_bias=req.logit_bias,
         allowed_token_ids=req.allowed_token_ids, bad_words=req.bad_words,
         truncate_prompt_tokens=req.truncate_prompt_tokens, json_object=rf == "json_object",
+        guided_choice=extra.get("guided_choice"),
         prompt_logprobs=(req.prompt_logprobs if req.prompt_logprobs is not None else
                          logprobs if getattr(req, "echo", False) and not req.stream else None))
 

@@ -51,6 +51,18 @@ class TokenTable:
         np.cumsum([len(t) for t in toks], out=self.offsets[1:])
         self.blob = np.frombuffer(b"".join(toks) or b"\0", dtype=np.uint8).copy()
         self.mask_cache: dict = {}
+        self._by_bytes: Optional[dict] = None
+
+    @property
+    def by_bytes(self) -> dict:
+        """bytes -> token ids spelled exactly so (built on first use)."""
+        if self._by_bytes is None:
+            d: dict = {}
+            for i, t in enumerate(self.tokens):
+                if t:
+                    d.setdefault(t, []).append(i)
+            self._by_bytes = d
+        return self._by_bytes
 
 
 class JsonGrammar:
@@ -82,4 +94,48 @@ class JsonGrammar:
             if len(table.mask_cache) >= 512:
                 table.mask_cache.clear()
             table.mask_cache[key] = out
+        return out
+
+
+class ChoiceGrammar:
+    """Output restricted to one of a few fixed strings (vLLM's ``guided_choice``).  The
+    position is the text produced so far; a token may come next when its bytes are a
+    prefix of what is left of some still-matching choice, found by looking every such
+    prefix up in the vocabulary (no walk over the vocabulary)."""
+
+    def __init__(self, choices: List[str]) -> None:
+        self.choices = [c.encode("utf-8") for c in choices if c]
+        if not self.choices:
+            raise ValueError("guided_choice needs at least one non-empty string")
+        self.text = b""
+
+    def _live(self) -> List[bytes]:
+        return [c for c in self.choices if c.startswith(self.text)]
+
+    def advance(self, data: bytes) -> bool:
+        new = self.text + data
+        if not any(c.startswith(new) for c in self.choices):
+            return False
+        self.text = new
+        return True
+
+    @property
+    def may_stop(self) -> bool:
+        """The text is one of the choices (EOS is allowed next)."""
+        return self.text in self.choices
+
+    @property
+    def done(self) -> bool:
+        """A complete choice that no other choice extends: only EOS may follow."""
+        return self.may_stop and not any(len(c) > len(self.text) for c in self._live())
+
+    def mask(self, table: TokenTable) -> np.ndarray:
+        out = np.zeros(table.n, dtype=np.uint8)
+        lookup = table.by_bytes
+        for c in self._live():
+            rest = c[len(self.text):]
+            for n in range(1, len(rest) + 1):
+                ids = lookup.get(rest[:n])
+                if ids:
+                    out[ids] = 1
         return out

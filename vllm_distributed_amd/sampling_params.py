@@ -32,6 +32,7 @@ class SamplingParams:
     bad_words_token_ids: Optional[List[List[int]]] = None
     truncate_prompt_tokens: Optional[int] = None         # keep only the last k prompt tokens
     json_object: bool = False                            # constrain the output to one JSON object
+    guided_choice: Optional[List[str]] = None            # the output is exactly one of these strings
     # filled by the engine: the model's EOS id (the only token allowed once a constrained output is complete)
     eos_token_id: Optional[int] = None
     # filled by the engine: EOS + stop token ids, masked until ``min_tokens`` outputs exist
@@ -80,6 +81,12 @@ class SamplingParams:
             self.bad_words = [self.bad_words]
         if self.bad_words_token_ids is not None:
             self.bad_words_token_ids = [[int(t) for t in w] for w in self.bad_words_token_ids if len(w)]
+        if self.guided_choice is not None:
+            self.guided_choice = [str(c) for c in self.guided_choice]
+            if not self.guided_choice or not all(self.guided_choice):
+                raise ValueError("guided_choice must be a non-empty list of non-empty strings")
+            if self.json_object:
+                raise ValueError("guided_choice and JSON mode exclude each other")
         if self.truncate_prompt_tokens is not None and self.truncate_prompt_tokens < 1:
             raise ValueError("truncate_prompt_tokens must be >= 1")
         if self.prompt_logprobs is not None and self.prompt_logprobs < 0:
@@ -100,7 +107,7 @@ class SamplingParams:
     def has_logit_adjust(self) -> bool:
         """True when logits must be edited before sampling (bias, allow / ban lists, min_tokens)."""
         return bool(self.logit_bias or self.allowed_token_ids is not None or self.bad_words_token_ids
-                    or self.json_object
+                    or self.json_object or self.guided_choice
                     or (self.min_tokens > 0 and self.min_tokens_ban_ids))
 
     def check_vocab(self, vocab_size: int) -> None:

@@ -96,6 +96,9 @@ class InputBatch:
         if sp.json_object:
             from ..ops.grammar import JsonGrammar
             self.grammar[row] = JsonGrammar()
+        elif sp.guided_choice:
+            from ..ops.grammar import ChoiceGrammar
+            self.grammar[row] = ChoiceGrammar(sp.guided_choice)
         self.num_logprobs[row] = -1 if sp.logprobs is None else sp.logprobs
         self.lora_id[row] = lora_id
         self.req_ids[row] = req_id

@@ -621,18 +621,21 @@ class ModelRunner:
         for t in b.token_ids[r, npt + int(b.grammar_pos[r]):nt].tolist():
             if not g.advance(table.tokens[t] if t < table.n else b""):
                 # tokens from before a constraint could apply (should not happen): stop constraining
-                logger.warning("request %s left the JSON grammar; constraint dropped", b.req_ids[r])
+                logger.warning("request %s left its output grammar; constraint dropped", b.req_ids[r])
                 b.grammar[r] = None
                 return None
         b.grammar_pos[r] = nt - npt
         keep = None if g.done else g.mask(table)
+        eos = b.params[r].eos_token_id
         if keep is None or not keep.any():
             keep = np.zeros(v, dtype=np.uint8)
-            eos = b.params[r].eos_token_id
             if eos is not None and eos < v:
                 keep[eos] = 1
             else:
                 return None
+        elif getattr(g, "may_stop", False) and eos is not None and eos < v:
+            keep = keep.copy()                    # complete already, but a longer alternative exists
+            keep[eos] = 1
         return keep
 
     def _apply_penalties(self, logits: torch.Tensor, rows: np.ndarray) -> torch.Tensor:
