@@ -170,6 +170,8 @@ def test_server_endpoints_end_to_end(frontend_mp):
                     "response_format": {"type": "json_schema", "json_schema": {}}})).status_code == 400
                 assert (await c.post("/v1/completions", headers=hdr, json={
                     "prompt": "x", "guided_regex": "a|b"})).status_code == 400
+                assert (await c.post("/v1/completions", headers=hdr, json={
+                    "prompt": "x", "logprobs": 5000})).status_code == 400       # --max-logprobs (20)
                 gc = await c.post("/v1/chat/completions", headers=hdr, json={
                     "messages": [{"role": "user", "content": "hi"}], "max_tokens": 16, "temperature": 1.0, "seed": 2,
                     "guided_choice": ["positive", "negative", "neutral"]})

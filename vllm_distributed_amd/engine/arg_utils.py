@@ -195,7 +195,7 @@ COMPAT_FLAGS_NO_VALUE = (
     "--fully-sharded-loras")
 COMPAT_FLAGS_ONE_VALUE = (
     "--swap-space", "--cpu-offload-gb", "--download-dir", "--tokenizer-mode", "--max-seq-len-to-capture",
-    "--max-logprobs", "--max-parallel-loading-workers", "--compilation-config|-O", "--guided-decoding-backend",
+    "--max-parallel-loading-workers", "--compilation-config|-O", "--guided-decoding-backend",
     "--structured-outputs-config", "--response-role", "--root-path",
     "--chat-template-content-format", "--limit-mm-per-prompt", "--tokenizer-revision", "--code-revision",
     "--config-format", "--max-num-partial-prefills", "--max-long-partial-prefills", "--num-scheduler-steps",

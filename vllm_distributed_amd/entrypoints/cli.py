@@ -42,6 +42,8 @@ def add_server_args(p: argparse.ArgumentParser) -> None:
     g.add_argument("--enable-auto-tool-choice", action="store_true")
     g.add_argument("--tool-call-parser", type=str, default=None)
     g.add_argument("--tool-parser-plugin", type=str, default="")
+    g.add_argument("--max-logprobs", type=int, default=20,
+                   help="largest logprobs / top_logprobs / prompt_logprobs a request may ask for")
     g.add_argument("--allowed-origins", type=json.loads, default=["*"], help="CORS: JSON list of origins")
     g.add_argument("--allowed-methods", type=json.loads, default=["*"])
     g.add_argument("--allowed-headers", type=json.loads, default=["*"])

@@ -241,6 +241,7 @@ async def init_app_state(engine: AsyncLLM, vllm_config, state, args: argparse.Na
     state.args = args
     state.served_names = vllm_config.model_config.served_model_name
     state.max_model_len = vllm_config.model_config.max_model_len
+    state.max_logprobs = int(getattr(args, "max_logprobs", 20) or 20)
     # the model authors' generation_config.json fills in what a request leaves unset (--generation-config)
     state.default_sampling = vllm_config.model_config.default_sampling_params()
     if state.default_sampling:
@@ -274,7 +275,10 @@ async def init_app_state(engine: AsyncLLM, vllm_config, state, args: argparse.Na
 
 # -------------------------------------------------------------------- routes
 def _sampling_params(req, default_max: Optional[int], max_model_len: int, logprobs: Optional[int],
-                     defaults: Optional[Dict[str, Any]] = None) -> SamplingParams:
+                     defaults: Optional[Dict[str, Any]] = None, max_logprobs: int = 20) -> SamplingParams:
+    for name, val in (("logprobs", logprobs), ("prompt_logprobs", req.prompt_logprobs)):
+        if val is not None and val > max_logprobs:
+            raise ValueError(f"{name}={val} exceeds this server's limit of {max_logprobs} (--max-logprobs)")
     given = req.model_fields_set
     defaults = defaults or {}
 
@@ -497,7 +501,7 @@ def _register_routes(app: FastAPI) -> None:
         rid = "cmpl-" + uuid.uuid4().hex
         created = int(time.time())
         try:
-            sp = _sampling_params(req, 16, st.max_model_len, req.logprobs, st.default_sampling)
+            sp = _sampling_params(req, 16, st.max_model_len, req.logprobs, st.default_sampling, st.max_logprobs)
         except ValueError as e:
             return _error(str(e))
         # n samples per prompt = n requests sharing the prompt (its KV blocks are shared through the
@@ -616,7 +620,7 @@ def _register_routes(app: FastAPI) -> None:
         prompt_ids = tok.encode(prompt, add_special_tokens=False)
         n_lp = (req.top_logprobs or 0) if req.logprobs else None
         try:
-            sp = _sampling_params(req, None, st.max_model_len, n_lp, st.default_sampling)
+            sp = _sampling_params(req, None, st.max_model_len, n_lp, st.default_sampling, st.max_logprobs)
         except ValueError as e:
             return _error(str(e))
         if forced_tool:
