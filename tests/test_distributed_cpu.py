@@ -318,3 +318,44 @@ def test_executor_contract_with_stub_workers(monkeypatch):
             eng.shutdown()
         remote.terminate()
         remote.wait(timeout=10)
+
+
+@pytest.mark.slow
+def test_step_breakdown_adds_up_through_the_distributed_executor(monkeypatch):
+    """With one step in flight at a time, the time the head spends blocked in
+    ``execute_model`` is the sum of what the output rank reports: control-plane
+    transit in, queueing, input preparation, device time (forward + sampling) and
+    transit out.  Two workers spawned by the head, TP=2 over gloo."""
+    port = get_open_port()
+    for k, v in _env(port, VLLM_HEAD_LOCAL_DEVICES="2").items():
+        monkeypatch.setenv(k, v)
+    eng = None
+    try:
+        eng = LLMEngine.from_engine_args(EngineArgs(
+            model="llama-tiny", device="cpu", dtype="float32", max_model_len=256, block_size=16,
+            num_gpu_blocks_override=256, max_num_seqs=16, tensor_parallel_size=2,
+            distributed_executor_backend="distributed", async_scheduling=False))
+        sp = SamplingParams(temperature=0.0, max_tokens=48, ignore_eos=True)
+        for i in range(16):
+            eng.add_request(None, [3 + i, 9, 27, 81], sp)
+        for _ in range(6):               # prefill + settle
+            eng.step()
+        timer = eng.core.timer
+        timer.reset()
+        t0 = time.perf_counter()
+        for _ in range(30):
+            eng.step()
+        wall = (time.perf_counter() - t0) / 30 * 1e3
+        s = timer.summary()
+        assert s["steps"] == 30
+        head = s["schedule_ms"] + s["execute_ms"] + s["update_ms"]
+        assert head == pytest.approx(wall, rel=0.1)
+        parts = (s["rpc_in_ms"] + s["worker_queued_ms"] + s["worker_prepare_ms"] + s["worker_forward_ms"]
+                 + s["worker_sample_ms"] + s["rpc_out_ms"])
+        assert parts == pytest.approx(s["execute_ms"], rel=0.2), s
+        assert s["rpc_overhead_ms"] == pytest.approx(s["rpc_in_ms"] + s["rpc_out_ms"])
+        # the device-side period (busy + idle between steps) is the step period
+        assert s["device_period_ms"] == pytest.approx(wall, rel=0.2), s
+    finally:
+        if eng is not None:
+            eng.shutdown()

@@ -77,20 +77,54 @@ def test_spmd_tp2_quantised_shards_match_single_process(quant):
     assert got[0] == ref and got[1] == ref
 
 
-@pytest.mark.slow
-def test_bench_script_multi_rank_rehearsal_on_cpu():
-    """bench.py exactly as the driver launches it for N=2 (torch.distributed.run,
-    one rank per device), on gloo with a tiny model: one JSON line from rank 0."""
-    port = get_open_port()
-    env = dict(os.environ, VLLM_LOGGING_LEVEL="ERROR", GLOO_SOCKET_IFNAME="lo", OMP_NUM_THREADS="2")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "3", "--warmup", "1", "--device", "cpu", "--model", "llama-tiny",
-           "--dtype", "float32", "--batch-per-gpu", "4", "--prompt-len", "12", "--ttft-requests", "1"]
+BENCH_ARGS = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--device", "cpu", "--model", "llama-tiny",
+              "--dtype", "float32", "--batch-per-gpu", "4", "--prompt-len", "12", "--ttft-requests", "1",
+              "--strong-batch", "4"]
+
+
+def _bench_json(cmd, env):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
-    j = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("executor", ["auto", "spmd"])
+def test_bench_script_multi_rank_rehearsal_on_cpu(executor):
+    """bench.py exactly as the driver launches it for N=2 (torch.distributed.run,
+    one rank per device), on gloo with a tiny model: one JSON line from rank 0, every
+    launched process exits 0.  By default rank 0 is the head and rank 1 registers
+    with it as a worker; ``--executor spmd`` is the launcher-only lower bound."""
+    port = get_open_port()
+    env = dict(os.environ, VLLM_LOGGING_LEVEL="ERROR", GLOO_SOCKET_IFNAME="lo", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           *BENCH_ARGS, "--executor", executor]
+    j = _bench_json(cmd, env)
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["config"]["global_batch"] == 8
     assert j["config"]["parallelism"] == "tp2" and j["value"] > 0
+    if executor == "auto":
+        assert j["config"]["executor"] == "distributed"
+        assert "head + 1 registered workers" in j["config"]["launch"]
+        assert j["rpc_overhead_ms"] > 0
+    else:
+        assert j["config"]["executor"] == "spmd"
+
+
+@pytest.mark.slow
+def test_bench_script_without_a_launcher_spawns_its_workers():
+    """``python bench.py --gpus 2`` alone: the head spawns both workers and drives them
+    over the RPC control plane; weak- and strong-scaling points and the RPC overhead are reported."""
+    env = dict(os.environ, VLLM_LOGGING_LEVEL="ERROR", GLOO_SOCKET_IFNAME="lo", OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    j = _bench_json([sys.executable, os.path.join(ROOT, "bench.py"), *BENCH_ARGS[:-2], "--strong-batch", "2"], env)
+    assert j["n_gpus"] == 2 and j["config"]["executor"] == "distributed"
+    assert j["config"]["launch"] == "head spawns every worker"
+    assert j["scaling"] == "weak" and j["config"]["global_batch"] == 8
+    assert j["strong_scaling"]["scaling"] == "strong" and j["strong_scaling"]["global_batch"] == 2
+    assert j["strong_scaling"]["tokens_per_s"] > 0
+    bd = j["config"]["step_breakdown_ms"]
+    assert bd["steps"] == 3 and bd["rpc_overhead_ms"] == pytest.approx(bd["rpc_in_ms"] + bd["rpc_out_ms"])

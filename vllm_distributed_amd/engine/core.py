@@ -29,25 +29,50 @@ class EngineDeadError(RuntimeError):
 
 
 class StepTimer:
-    """Rolling per-step breakdown: schedule / execute (RPC + forward + sample) / update;
-    ``worker_comm`` (time inside collectives, part of forward) when it is being measured."""
+    """Rolling per-step breakdown.
+
+    Head side (host clock): ``schedule``, ``launch`` (handing a step to the executor
+    without waiting), ``execute`` (blocked on the oldest step in flight), ``update``.
+    Worker side, from the reply of the output rank: ``worker_prepare`` / ``worker_launch``
+    (host time building inputs / enqueueing device work), ``worker_forward`` and
+    ``worker_sample`` (device time between event stamps), ``worker_device_idle`` (device
+    time between the end of the previous step and the start of this one: what host
+    and control plane fail to hide), ``rpc_in`` (head send -> arrival at the worker
+    process), ``worker_queued`` (waiting behind the previous call on the worker thread;
+    healthy when steps are scheduled ahead) and ``rpc_out`` (worker reply -> head future).  With the device saturated,
+    forward + sample + device_idle is the step period."""
+
+    WORKER_KEYS = {"prepare": "worker_prepare", "launch": "worker_launch", "forward": "worker_forward",
+                   "sample": "worker_sample", "device_idle": "worker_device_idle", "comm": "worker_comm",
+                   "rpc_in": "rpc_in", "rpc_out": "rpc_out", "queued": "worker_queued"}
 
     def __init__(self) -> None:
-        self.n = 0
-        self.tot = {"schedule": 0.0, "execute": 0.0, "update": 0.0,
-                    "worker_prepare": 0.0, "worker_forward": 0.0, "worker_sample": 0.0}
+        self.reset()
 
-    def add(self, **kw: float) -> None:
-        self.n += 1
+    def reset(self) -> None:
+        self.n = 0
+        self.tot = {"schedule": 0.0, "launch": 0.0, "execute": 0.0, "update": 0.0, "worker_prepare": 0.0,
+                    "worker_forward": 0.0, "worker_sample": 0.0, "worker_device_idle": 0.0,
+                    "rpc_in": 0.0, "rpc_out": 0.0}
+
+    def add_head(self, **kw: float) -> None:
         for k, v in kw.items():
             self.tot[k] = self.tot.get(k, 0.0) + v
+
+    def add_step(self, out: Optional[ModelRunnerOutput]) -> None:
+        """One finished step, with the worker-side timing its output carries."""
+        self.n += 1
+        wt = (out.timing if out is not None else None) or {}
+        for k, name in self.WORKER_KEYS.items():
+            if k in wt:
+                self.tot[name] = self.tot.get(name, 0.0) + wt[k]
 
     def summary(self) -> Dict[str, float]:
         n = max(self.n, 1)
         d = {k + "_ms": 1e3 * v / n for k, v in self.tot.items()}
         d["steps"] = self.n
-        d["rpc_overhead_ms"] = max(0.0, d["execute_ms"] + d.get("launch_ms", 0.0) - d["worker_prepare_ms"]
-                                   - d["worker_forward_ms"] - d["worker_sample_ms"])
+        d["rpc_overhead_ms"] = d["rpc_in_ms"] + d["rpc_out_ms"]
+        d["device_period_ms"] = d["worker_forward_ms"] + d["worker_sample_ms"] + d["worker_device_idle_ms"]
         return d
 
 
@@ -135,14 +160,9 @@ class EngineCore:
         t2 = time.perf_counter()
         res = self.scheduler.update_from_output(so, out)
         t3 = time.perf_counter()
-        self._record(t1 - t0, t2 - t1, t3 - t2, out)
+        self.timer.add_head(schedule=t1 - t0, execute=t2 - t1, update=t3 - t2)
+        self.timer.add_step(out)
         return res
-
-    def _record(self, ts: float, te: float, tu: float, out: Optional[ModelRunnerOutput]) -> None:
-        wt = (out.timing if out is not None else None) or {}
-        extra = {"worker_comm": wt["comm"]} if "comm" in wt else {}      # only with VDAMD_TIME_COLLECTIVES
-        self.timer.add(schedule=ts, execute=te, update=tu, worker_prepare=wt.get("prepare", 0.0),
-                       worker_forward=wt.get("forward", 0.0), worker_sample=wt.get("sample", 0.0), **extra)
 
     def _step_with_batch_queue(self) -> List[EngineCoreOutput]:
         """Fill the pipeline before draining it: schedule a new batch whenever
@@ -155,7 +175,7 @@ class EngineCore:
             if not so.is_empty or so.finished_req_ids or so.preempted_req_ids:
                 fut = self.executor.execute_model(so, non_block=True)
                 self.batch_queue.append((fut, so))
-                self.timer.add(schedule=t1 - t0, launch=time.perf_counter() - t1)
+                self.timer.add_head(schedule=t1 - t0, launch=time.perf_counter() - t1)
                 if len(self.batch_queue) < self.max_concurrent and not so.is_empty:
                     return []            # try to put another batch in flight first
         if not self.batch_queue:
@@ -166,14 +186,8 @@ class EngineCore:
         t1 = time.perf_counter()
         res = self.scheduler.update_from_output(so, out)
         t2 = time.perf_counter()
-        wt = (out.timing if out is not None else None) or {}
-        tot = self.timer.tot
-        tot["execute"] += t1 - t0           # time blocked waiting for the oldest in-flight step
-        tot["update"] += t2 - t1
-        for k in ("prepare", "forward", "sample"):
-            tot["worker_" + k] += wt.get(k, 0.0)
-        if "comm" in wt:
-            tot["worker_comm"] = tot.get("worker_comm", 0.0) + wt["comm"]
+        self.timer.add_head(execute=t1 - t0, update=t2 - t1)   # execute: blocked on the oldest step in flight
+        self.timer.add_step(out)
         return res
 
     # ----------------------------------------------------------------- admin

@@ -210,10 +210,11 @@ class DistributedExecutor(Executor):
                     self._nodes_changed.set()
 
     def _head_local_devices(self) -> int:
-        n = hip_device_count_stateless() if current_platform.is_rocm() else 1
-        if self.device_config.device == "cpu":
-            n = 1
         cap = envs.VLLM_HEAD_LOCAL_DEVICES
+        if self.device_config.device == "cpu" or envs.VDAMD_SHARE_DEVICE:
+            # no device to run out of: as many local workers as asked for (default one)
+            return max(cap, 0) if cap >= 0 else 1
+        n = hip_device_count_stateless() if current_platform.is_rocm() else 1
         return n if cap < 0 else min(n, cap)
 
     def _registered_nodes(self) -> List[NodeInfo]:
@@ -358,14 +359,18 @@ class DistributedExecutor(Executor):
             timeout = envs.VLLM_RPC_TIMEOUT
         if callable(method) and not isinstance(method, (str, bytes)):
             method = cloudpickle.dumps(method)
-        payload = cloudpickle.dumps((method, unique_reply_rank, list(args), kwargs))   # once
+        payload = cloudpickle.dumps((method, unique_reply_rank, list(args), kwargs, time.time()))   # once
         reply_ranks = list(range(self.world_size)) if unique_reply_rank is None else [unique_reply_rank]
 
         async def call(rank: int, want_reply: bool) -> Any:
             ret = await self.workers[rank](payload, timeout=timeout)
-            if not want_reply:
+            if not want_reply or ret is None:
                 return None
-            return cloudpickle.loads(ret) if ret is not None else None
+            out = cloudpickle.loads(ret)
+            timing = getattr(out, "timing", None)
+            if isinstance(timing, dict) and "t_reply" in timing:
+                timing["rpc_out"] = max(0.0, time.time() - timing.pop("t_reply"))
+            return out
 
         futures: List[concurrent.futures.Future] = []
         for rank in range(self.world_size):
@@ -399,6 +404,21 @@ class DistributedExecutor(Executor):
             return
         self.shutdown_event.set()
         loop = getattr(self, "loop", None)
+
+        async def goodbye() -> None:
+            async def one(peer: RpcPeer) -> None:
+                try:
+                    fn = await peer.get_param("goodbye", timeout=2)
+                    await fn(timeout=2)
+                except Exception:  # noqa: BLE001 - local workers have no such param; dead peers cannot answer
+                    pass
+            await asyncio.gather(*(one(p) for p in self._peers if p is not None and p.killed is None))
+
+        if loop is not None and loop.is_running() and not self.is_failed:
+            try:        # remote workers exit 0 instead of treating the closed connection as a failure
+                asyncio.run_coroutine_threadsafe(goodbye(), loop).result(timeout=5)
+            except Exception:  # noqa: BLE001
+                pass
 
         def stop() -> None:
             for p in self._peers:

@@ -15,6 +15,7 @@ import multiprocessing
 import multiprocessing.connection
 import os
 import sys
+import time
 import traceback
 import uuid
 from typing import Any, Dict, Optional
@@ -36,16 +37,23 @@ logger = init_logger(__name__)
 def set_peer_run_worker(peer: RpcPeer, wrapper: Any, rank: int, local_rank: int):
     """Publish ``run_worker(pickled)`` on ``peer``.
 
-    The payload is ``(method, unique_reply_rank, args, kwargs)``; ``method`` is a
-    name or a pickled callable.  Calls execute strictly in arrival order on one
+    The payload is ``(method, unique_reply_rank, args, kwargs[, t_send])``; ``method``
+    is a name or a pickled callable.  Calls execute strictly in arrival order on one
     dedicated thread (the data-plane collectives deadlock otherwise) while the
-    event loop stays free to answer health checks.  Only the reply rank ships
-    a result back; the work is done on every rank.
+    event loop stays free to answer health checks.  A step whose sampled tokens
+    are still on the device is handed to a second, reply thread that waits for
+    them and pickles the output, so the worker thread can launch the next queued
+    step meanwhile and the device never idles between steps.  Only the reply rank
+    ships a result back; the work is done on every rank.
     """
     executor = concurrent.futures.ThreadPoolExecutor(1, thread_name_prefix=f"worker-{rank}")
+    replier = concurrent.futures.ThreadPoolExecutor(1, thread_name_prefix=f"reply-{rank}")
 
-    def _run(pickled: bytes) -> Optional[bytes]:
-        method, unique_reply_rank, args, kwargs = cloudpickle.loads(pickled)
+    def _run(pickled: bytes, t_arrive: float):
+        t_dequeue = time.time()
+        call = cloudpickle.loads(pickled)
+        method, unique_reply_rank, args, kwargs = call[:4]
+        t_send = call[4] if len(call) > 4 else None
         try:
             result = run_method(wrapper, method, args or [], kwargs or {})
         except Exception as e:
@@ -53,14 +61,30 @@ def set_peer_run_worker(peer: RpcPeer, wrapper: Any, rank: int, local_rank: int)
                          method if isinstance(method, str) else "<callable>", rank, e,
                          traceback.format_exc())
             raise
-        if getattr(result, "lazy_step_result", False):      # resolved after the next step is queued
-            result = result.get()
+        if method == "load_model":
+            runner = getattr(getattr(wrapper, "worker", None), "model_runner", None)
+            if runner is not None:
+                runner.defer_output = True      # the reply thread waits for the device, not this one
+        return result, unique_reply_rank, t_send, t_arrive, t_dequeue
+
+    def _finish(result: Any, unique_reply_rank: Optional[int], t_send: Optional[float], t_arrive: float,
+                t_dequeue: float) -> Optional[bytes]:
+        if getattr(result, "lazy_step_result", False):
+            result = result.wait()
         if unique_reply_rank is not None and unique_reply_rank != rank:
             return None
+        timing = getattr(result, "timing", None)
+        if isinstance(timing, dict) and t_send is not None:
+            # control-plane transit, wall clocks of head and worker (one host, or NTP-close hosts)
+            timing["rpc_in"] = max(0.0, t_arrive - t_send)
+            timing["queued"] = t_dequeue - t_arrive      # behind the previous call on the worker thread
+            timing["t_reply"] = time.time()
         return cloudpickle.dumps(result)
 
     async def run_worker(pickled: bytes):
-        return await asyncio.get_running_loop().run_in_executor(executor, _run, pickled)
+        loop = asyncio.get_running_loop()
+        done = await loop.run_in_executor(executor, _run, pickled, time.time())
+        return await loop.run_in_executor(replier, _finish, *done)
 
     peer.params["run_worker"] = run_worker
     return run_worker
@@ -115,6 +139,13 @@ async def remote_worker_async_main(server_ip: str, available_devices: int, local
     loop = asyncio.get_running_loop()
     port = port or envs.VLLM_SERVER_PORT
     wrapper: Optional[Any] = None
+    graceful = False
+
+    def goodbye() -> None:
+        """The head announces an orderly shutdown: the connection loss that follows is not a failure."""
+        nonlocal graceful
+        graceful = True
+
     while True:
         try:
             reader, writer = await asyncio.open_connection(server_ip, port)
@@ -126,6 +157,7 @@ async def remote_worker_async_main(server_ip: str, available_devices: int, local
             peer.params["local_rank"] = local_rank
             peer.params["node_id"] = node_id
             peer.params["open_port"] = get_open_port
+            peer.params["goodbye"] = goodbye
 
             async def create_worker(vllm_config_blob: bytes, rank: int, environ: Dict[str, str]):
                 nonlocal wrapper
@@ -145,6 +177,9 @@ async def remote_worker_async_main(server_ip: str, available_devices: int, local
             # retry for as long as no worker has been created; once one exists
             # the whole node must tear down and restart (reference :576-586)
             if wrapper is not None:
+                if graceful:
+                    logger.info("head shut down; worker %s/%d exits", node_id, local_rank)
+                    os._exit(0)
                 logger.error("running worker lost its head connection (%r), shutting down", e)
                 os._exit(1)
             logger.info("connection to %s:%d failed (%r); retrying in %.0fs", server_ip, port, e,

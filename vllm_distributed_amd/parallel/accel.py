@@ -101,3 +101,26 @@ def attach_accelerated_collectives(pc: ParallelConfig) -> None:
                 logger.info("tp group: direct (peer-mapped) all-reduce active")
             elif car is not None:
                 car.close()
+
+
+def reverify_after_failed_capture(group: GroupCoordinator) -> None:
+    """A hipGraph capture that aborted may have left a communicator half-way through an
+    enqueue.  All ranks of the group re-run the self-checks together and drop (together)
+    whichever accelerated path no longer gives the right sum; a path that still works
+    keeps carrying the eager steps."""
+    if group.custom_ar is not None:
+        car = group.custom_ar
+        ok = _verify_all_reduce(group, car.all_reduce,
+                                [n for n in (4096, 1 << 19) if 2 * n <= car.max_bytes]) and not car.timed_out()
+        if not _all_agree(group, ok):
+            logger.warning("%s group: direct all-reduce failed its re-check after an aborted capture; dropped",
+                           group.name)
+            group.custom_ar = None
+            car.close()
+    if group.rccl is not None:
+        comm = group.rccl
+        ok = _verify_all_reduce(group, lambda t: (comm.all_reduce(t), t)[1])
+        if not _all_agree(group, ok):
+            logger.warning("%s group: direct RCCL communicator failed its re-check after an aborted capture; "
+                           "torch.distributed carries the traffic", group.name)
+            group.rccl = None

@@ -9,6 +9,7 @@ one graph launch instead of ~10 kernel launches per layer.
 from __future__ import annotations
 
 import os
+import threading
 import time
 from typing import Any, Dict, List, Optional, Tuple
 
@@ -31,57 +32,122 @@ from .input_batch import InputBatch
 logger = init_logger(__name__)
 
 
-class PendingSample:
-    """Tokens sampled on the device whose values have not reached the host yet."""
+class StepMarks:
+    """Device-side stamps of one step: start of its device work, end of the forward,
+    end of sampling (= the event the token readback waits for), and the end stamp of
+    the previous step on the same stream.  GPU: timing events, resolved once the
+    last one has completed; CPU: ``perf_counter`` values (the forward is synchronous)."""
 
-    lazy_step_result = True       # executors call .get() on results carrying this mark
+    __slots__ = ("start", "fwd", "end", "prev_end", "gpu")
+
+    def __init__(self, gpu: bool):
+        self.gpu = gpu
+        self.start = self.fwd = self.end = self.prev_end = None
+
+    def stamp(self, which: str) -> None:
+        if self.gpu:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            setattr(self, which, ev)
+        else:
+            setattr(self, which, time.perf_counter())
+
+    def resolve(self) -> Dict[str, float]:
+        """Seconds per segment; the end stamp must have completed (GPU)."""
+        if self.start is None or self.end is None:
+            return {}
+        fwd = self.fwd if self.fwd is not None else self.end
+        if self.gpu:
+            try:
+                d = {"forward": self.start.elapsed_time(fwd) * 1e-3, "sample": fwd.elapsed_time(self.end) * 1e-3}
+                if self.prev_end is not None:
+                    d["device_idle"] = max(0.0, self.prev_end.elapsed_time(self.start) * 1e-3)
+                return d
+            except RuntimeError:          # a measurement must never take a step down
+                return {}
+        d = {"forward": fwd - self.start, "sample": self.end - fwd}
+        if self.prev_end is not None:
+            d["device_idle"] = max(0.0, self.start - self.prev_end)
+        return d
+
+
+class PendingSample:
+    """Tokens sampled on the device whose values have not reached the host yet.
+
+    ``wait()`` blocks until they have and builds the step's output; it touches no
+    runner state, so a reply thread may call it while the worker thread is already
+    preparing the next step.  ``publish()`` folds the token values into the
+    persistent batch and belongs to the thread that runs ``execute_model``."""
+
+    lazy_step_result = True       # executors call .get() / .wait() on results carrying this mark
     __slots__ = ("runner", "step_id", "req_ids", "nreq", "sel", "rows", "gens", "pos", "tokens",
-                 "event", "logprobs", "timing", "t_launch", "_result", "prompt_logprobs")
+                 "event", "logprobs", "timing", "marks", "_result", "prompt_logprobs", "_lock", "_toks",
+                 "_published")
 
     def __init__(self, runner: "ModelRunner", step_id: int, req_ids: List[str], sel: Optional[np.ndarray],
                  rows: Optional[np.ndarray], pos: Optional[np.ndarray], tokens: Optional[torch.Tensor],
-                 event: Optional["torch.cuda.Event"], logprobs, timing: Optional[Dict[str, float]]):
+                 event: Optional["torch.cuda.Event"], logprobs, timing: Optional[Dict[str, float]],
+                 marks: Optional[StepMarks] = None):
         self.runner, self.step_id, self.req_ids, self.nreq = runner, step_id, req_ids, len(req_ids)
         self.sel, self.rows, self.pos, self.tokens, self.event = sel, rows, pos, tokens, event
         self.gens = runner.batch.row_gen[rows].copy() if rows is not None else None
-        self.logprobs, self.timing = logprobs, timing
+        self.logprobs, self.timing, self.marks = logprobs, timing, marks
         self.prompt_logprobs = None
-        self.t_launch = time.perf_counter()
         self._result: Optional[ModelRunnerOutput] = None
+        self._toks: Optional[np.ndarray] = None
+        self._lock = threading.Lock()
+        self._published = False
 
-    def get(self) -> ModelRunnerOutput:
-        """Wait for the device, publish the token values into the persistent
-        batch (unless the row changed owner meanwhile) and build the output."""
-        if self._result is not None:
-            return self._result
-        out_tokens: List[List[int]] = [[] for _ in range(self.nreq)]
-        logprobs_out = None
-        if self.sel is not None:
+    @property
+    def resolved(self) -> bool:
+        return self._result is not None
+
+    def wait(self) -> ModelRunnerOutput:
+        """Wait for the device and build the output.  Thread-safe; no runner state is modified."""
+        with self._lock:
+            if self._result is not None:
+                return self._result
+            out_tokens: List[List[int]] = [[] for _ in range(self.nreq)]
+            logprobs_out = None
             if self.event is not None:
                 self.event.synchronize()
-            toks = self.tokens.numpy()
+            if self.sel is not None:
+                self._toks = toks = self.tokens.numpy()
+                tok_list = toks.tolist()
+                for j, i in enumerate(self.sel.tolist()):
+                    out_tokens[i] = [tok_list[j]]
+                if self.logprobs is not None:
+                    logprobs_out = [None] * self.nreq
+                    for j, i in enumerate(self.sel.tolist()):
+                        logprobs_out[i] = self.logprobs[j]
+            timing = self.timing
+            if timing is not None and self.marks is not None:
+                timing.update(self.marks.resolve())
+            self._result = ModelRunnerOutput(step_id=self.step_id, req_ids=self.req_ids,
+                                             sampled_token_ids=out_tokens, logprobs=logprobs_out, timing=timing,
+                                             prompt_logprobs=self.prompt_logprobs)
+            return self._result
+
+    def publish(self) -> None:
+        """Fold the token values into the persistent batch (unless the row changed
+        owner meanwhile).  Only the thread that runs ``execute_model`` calls this."""
+        if self._published:
+            return
+        self.wait()
+        self._published = True
+        if self.sel is not None:
             b = self.runner.batch
             ok = b.row_gen[self.rows] == self.gens
             rows, pos = self.rows[ok], self.pos[ok]
-            b.token_ids[rows, pos] = toks[ok]
+            b.token_ids[rows, pos] = self._toks[ok]
             b.num_known[rows] = np.maximum(b.num_known[rows], pos + 1)
-            tok_list = toks.tolist()
-            for j, i in enumerate(self.sel.tolist()):
-                out_tokens[i] = [tok_list[j]]
-            if self.logprobs is not None:
-                logprobs_out = [None] * self.nreq
-                for j, i in enumerate(self.sel.tolist()):
-                    logprobs_out[i] = self.logprobs[j]
-        timing = self.timing
-        if timing is not None:
-            timing["sample"] = timing.get("sample", 0.0) + (time.perf_counter() - self.t_launch)
-        self._result = ModelRunnerOutput(step_id=self.step_id, req_ids=self.req_ids,
-                                         sampled_token_ids=out_tokens, logprobs=logprobs_out, timing=timing,
-                                         prompt_logprobs=self.prompt_logprobs)
         try:
             self.runner._pending.remove(self)
         except ValueError:
             pass
+
+    def get(self) -> ModelRunnerOutput:
+        self.publish()
         return self._result
 
 
@@ -95,6 +161,10 @@ class _Discard:
 
     def get(self) -> None:
         self.pending.get()
+        return None
+
+    def wait(self) -> None:
+        self.pending.wait()
         return None
 
 
@@ -127,6 +197,7 @@ class ModelRunner:
         self.graphs: Dict[int, DecodeGraph] = {}
         self.graph_sizes: List[int] = []
         self.graph_pool = None
+        self.graph_fallback_reason: Optional[str] = "not captured yet"
         self._static: Dict[str, torch.Tensor] = {}
         self.decode_workspace: Optional[torch.Tensor] = None
         self.step_count = 0
@@ -135,6 +206,7 @@ class ModelRunner:
         self.lora_manager = None
         self.sampled_dev: Optional[torch.Tensor] = None      # last sampled token per batch row (device)
         self._pending: List[PendingSample] = []
+        self._last_end_mark = None        # end stamp of the previous step (device idle time between steps)
         self._token_table = None          # vocabulary bytes for constrained decoding, built on first use
         self.defer_output = False        # set by in-process executors under async scheduling
         self.timing_enabled = vllm_config.observability_config.collect_step_timing
@@ -318,6 +390,9 @@ class ModelRunner:
     def execute_model(self, so: SchedulerOutput) -> Optional[ModelRunnerOutput]:
         t0 = time.perf_counter()
         with trace_range("step.prepare"):
+            for pend in list(self._pending):      # values a reply thread has already read back
+                if pend.resolved:
+                    pend.publish()
             self._update_states(so)
             self.step_count += 1
             if so.total_num_scheduled_tokens == 0:
@@ -325,6 +400,11 @@ class ModelRunner:
             p = self._prepare_inputs(so)
         nreq, nd, total = len(p["req_ids"]), p["num_decodes"], p["total"]
         t1 = time.perf_counter()
+        marks = None
+        if self.timing_enabled:
+            marks = StepMarks(self.is_gpu)
+            marks.prev_end = self._last_end_mark
+            marks.stamp("start")
 
         lora_step = None
         if self.lora_manager is not None:
@@ -347,8 +427,12 @@ class ModelRunner:
         self.batch.num_computed[p["rows"]] += p["n_sched"]
 
         if not self.pp.is_last_rank:
+            if marks is not None:
+                marks.stamp("end")
+                self._last_end_mark = marks.end
             return None
-        t2 = time.perf_counter()
+        if marks is not None:
+            marks.stamp("fwd")
         prompt_lps = None
         if nd < nreq and (self.batch.num_prompt_logprobs[p["rows"][nd:]] >= 0).any():
             prompt_lps = self._prompt_logprobs(hidden, p)
@@ -374,16 +458,22 @@ class ModelRunner:
             if self.is_gpu:
                 host_tokens = torch.empty(len(sel), dtype=torch.int32, pin_memory=True)
                 host_tokens.copy_(tokens, non_blocking=True)
-                event = torch.cuda.Event()
-                event.record()
             else:
                 host_tokens = tokens
-        t3 = time.perf_counter()
-        timing = {"prepare": t1 - t0, "forward": t2 - t1, "sample": t3 - t2} if self.timing_enabled else None
+        if marks is not None:
+            marks.stamp("end")
+            self._last_end_mark = marks.end
+            if self.is_gpu:
+                event = marks.end
+        elif self.is_gpu and sel is not None:
+            event = torch.cuda.Event()
+            event.record()
+        # host time of this call: building inputs, and launching (not running) the device work
+        timing = {"prepare": t1 - t0, "launch": time.perf_counter() - t1} if self.timing_enabled else None
         if timing is not None and CommTimer.enabled:
             timing["comm"] = CommTimer.drain()
         pending = PendingSample(self, so.step_id, p["req_ids"], sel, rows_sel, pos_sel, host_tokens, event,
-                                logprobs_sel, timing)
+                                logprobs_sel, timing, marks)
         pending.prompt_logprobs = prompt_lps
         self._pending.append(pending)
         if self.defer_output:
@@ -695,37 +785,55 @@ class ModelRunner:
     @torch.inference_mode()
     def capture_graphs(self) -> None:
         cc = self.vllm_config.compilation_config
-        if not (self.is_gpu and cc.use_hip_graph and envs.VDAMD_USE_HIP_GRAPH):
+        self.graph_fallback_reason = None
+        if not self.is_gpu:
+            return
+        if not (cc.use_hip_graph and envs.VDAMD_USE_HIP_GRAPH):
+            self.graph_fallback_reason = "disabled (enforce_eager / VDAMD_USE_HIP_GRAPH=0)"
             return
         if self.pp.world_size > 1:
+            self.graph_fallback_reason = "pipeline parallelism: stages run eagerly"
             logger.info("hipGraph decode capture is disabled with pipeline parallelism")
             return
         if not ops.hip_supports_head_dim(self.model_config.head_dim):
+            self.graph_fallback_reason = f"no HIP attention kernel for head_dim {self.model_config.head_dim}"
             logger.info("hipGraph decode capture needs the HIP attention kernels (head_dim 64 or 128): "
                         "running eagerly")
             return
         if self.tp.world_size > 1 and self.tp.rccl is None and self.tp.device_group is not None:
             # torch.distributed collectives keep host-side work objects; only the
             # direct RCCL binding is a pure stream enqueue that a capture can record
+            self.graph_fallback_reason = "no direct RCCL communicator (torch.distributed collectives cannot be captured)"
             logger.info("hipGraph decode capture needs the direct RCCL communicator: running eagerly")
             return
         sizes = [s for s in cc.sizes(self.max_num_reqs) if s <= self.max_num_reqs]
         if not sizes:
+            self.graph_fallback_reason = "no capture sizes configured"
             return
         t0 = time.time()
         self._alloc_static(max(sizes))
         self._ensure_decode_workspace(max(sizes))
+        error: Optional[BaseException] = None
         try:
             for bs in sorted(sizes, reverse=True):
                 self._capture_one(bs)
         except Exception as e:  # capture is an optimisation: fall back to eager
-            logger.warning("hipGraph capture failed (%r): running decode eagerly", e)
+            error = e
+            torch.cuda.synchronize()
+        # every rank of the group takes the same decision: a rank replaying a graph and a
+        # rank running eagerly would still issue the same collectives, but a communicator
+        # that failed mid-capture has to be re-checked by all of its ranks together
+        verdicts = self.tp.all_gather_object(None if error is None else repr(error))
+        failed = [(r, v) for r, v in enumerate(verdicts) if v is not None]
+        if failed:
+            self.graph_fallback_reason = "capture failed on tp rank(s) " + ", ".join(f"{r}: {v}" for r, v in failed)
+            logger.warning("hipGraph %s: running decode eagerly", self.graph_fallback_reason)
             self.graphs.clear()
             self.graph_sizes = []
-            if self.tp.rccl is not None:
-                # a communicator that was mid-capture cannot be trusted afterwards
-                self.tp.rccl = None
-            torch.cuda.synchronize()
+            self.graph_pool = None
+            if self.tp.world_size > 1 and (self.tp.rccl is not None or self.tp.custom_ar is not None):
+                from ..parallel.accel import reverify_after_failed_capture
+                reverify_after_failed_capture(self.tp)
             return
         self.graph_sizes = sorted(self.graphs)
         logger.info("captured %d decode graphs (%s) in %.1fs", len(self.graphs),

@@ -70,6 +70,10 @@ class Worker:
             torch.set_num_threads(max(1, min(8, (os.cpu_count() or 2) // max(1, self.parallel_config.world_size))))
         pc = self.parallel_config
         self._default_loopback_interfaces()
+        if (self.distributed_init_method or "").startswith("tcp://"):
+            # a launcher's "the agent hosts the store" flag would stop rank 0 from hosting the
+            # store of the address the head generated
+            os.environ.pop("TORCHELASTIC_USE_AGENT_STORE", None)
         pstate.init_distributed_environment(pc.world_size, self.rank, self.distributed_init_method,
                                             self.local_rank, backend, self.device)
         pstate.initialize_model_parallel(pc.tensor_parallel_size, pc.pipeline_parallel_size)
@@ -146,11 +150,27 @@ class Worker:
     def check_health(self) -> bool:
         return True
 
+    def synchronize(self) -> float:
+        """Wait for everything this worker has queued on its device; returns the wall clock after."""
+        if self.device is not None and self.device.type == "cuda":
+            torch.cuda.synchronize()
+        import time
+        return time.time()
+
     def get_stats(self) -> Dict[str, Any]:
         d: Dict[str, Any] = {"rank": self.rank, "steps": self._steps}
         if self.device is not None and self.device.type == "cuda":
             free, total = torch.cuda.mem_get_info()
             d.update(mem_free=free, mem_total=total, mem_torch=torch.cuda.memory_allocated())
+        mr = self.model_runner
+        if mr is not None:
+            d.update(hip_graph_sizes=list(mr.graph_sizes), hip_graph_fallback=mr.graph_fallback_reason,
+                     block_size=mr.block_size)
+            tp = getattr(mr, "tp", None)
+            if tp is not None:
+                d.update(tp_rccl=tp.rccl is not None, tp_direct_all_reduce=tp.custom_ar is not None,
+                         tp_backend=(None if tp.device_group is None else
+                                     torch.distributed.get_backend(tp.device_group)))
         return d
 
     # ------------------------------------------------------------- profiling
