@@ -127,4 +127,4 @@ def test_bench_script_without_a_launcher_spawns_its_workers():
     assert j["strong_scaling"]["scaling"] == "strong" and j["strong_scaling"]["global_batch"] == 2
     assert j["strong_scaling"]["tokens_per_s"] > 0
     bd = j["config"]["step_breakdown_ms"]
-    assert bd["steps"] == 3 and bd["rpc_overhead_ms"] == pytest.approx(bd["rpc_in_ms"] + bd["rpc_out_ms"])
+    assert bd["steps"] == 3 and bd["rpc_overhead_ms"] == pytest.approx(bd["rpc_in_ms"] + bd["rpc_out_ms"], abs=0.01)
