@@ -68,7 +68,7 @@ def test_server_endpoints_end_to_end(frontend_mp):
     args = build_parser().parse_args(
         ("serve llama-tiny --device cpu --dtype float32 --max-model-len 256 --block-size 16 "
          "--num-gpu-blocks-override 128 --served-model-name tiny --api-key sekret "
-         "--enable-auto-tool-choice --tool-call-parser hermes --port 0"
+         "--enable-auto-tool-choice --tool-call-parser hermes --port 0 --enable-dev-endpoints"
          + ("" if frontend_mp else " --disable-frontend-multiprocessing")).split())
     args.model = args.model_tag
 
@@ -82,6 +82,28 @@ def test_server_endpoints_end_to_end(frontend_mp):
                 assert (await c.get("/health")).status_code == 200
                 assert (await c.get("/version")).json()["version"]
                 assert (await c.get("/v1/models")).status_code == 401          # key required
+                # ... on everything that generates, tokenizes or administers, not only under /v1
+                assert (await c.post("/invocations", json={"prompt": "x", "max_tokens": 1})).status_code == 401
+                assert (await c.post("/tokenize", json={"prompt": "abc"})).status_code == 401
+                assert (await c.post("/sleep")).status_code == 401
+                assert (await c.get("/v1/models", headers={"Authorization": "Bearer sekre"})).status_code == 401
+                # a bad request costs an error reply and nothing else, whichever process owns the core:
+                # over-long and empty prompts, a negative seed, then a normal request
+                too_long = await c.post("/v1/completions", headers=hdr, json={"prompt": [5] * 400, "max_tokens": 1})
+                assert too_long.status_code == 400, too_long.text
+                assert (await c.post("/v1/completions", headers=hdr, json={"prompt": [], "max_tokens": 1})).status_code == 400
+                neg = await c.post("/v1/completions", headers=hdr, json={
+                    "prompt": "hello", "max_tokens": 3, "temperature": 1.0, "seed": -1})
+                assert neg.status_code == 200, neg.text
+                assert (await c.post("/v1/completions", headers=hdr, json={
+                    "prompt": "hello", "max_tokens": 3, "temperature": 1.0, "seed": -7})).status_code == 400
+                big = await c.post("/v1/completions", headers=hdr, json={
+                    "prompt": "hello", "max_tokens": 3, "temperature": 1.0, "seed": 2 ** 63 - 1, "n": 2})
+                assert big.status_code == 200, big.text
+                # a chat template in the request body is refused unless the operator opted in
+                assert (await c.post("/v1/chat/completions", headers=hdr, json={
+                    "messages": [{"role": "user", "content": "hi"}], "max_tokens": 1,
+                    "chat_template": "{{ messages[0].content }}"})).status_code == 400
                 m = (await c.get("/v1/models", headers=hdr)).json()
                 assert m["data"][0]["id"] == "tiny"
                 r = await c.post("/v1/completions", headers=hdr, json={
@@ -201,13 +223,13 @@ def test_server_endpoints_end_to_end(frontend_mp):
                 pl = r10.json()["prompt_logprobs"]
                 assert r10.status_code == 200 and pl[0] is None and len(pl) == r10.json()["usage"]["prompt_tokens"]
                 assert all(len(d) == 1 and "logprob" in next(iter(d.values())) for d in pl[1:])
-                t = (await c.post("/tokenize", json={"prompt": "abc"})).json()
+                t = (await c.post("/tokenize", headers=hdr, json={"prompt": "abc"})).json()
                 assert t["count"] == len(t["tokens"])
-                d = (await c.post("/detokenize", json={"tokens": t["tokens"]})).json()
+                d = (await c.post("/detokenize", headers=hdr, json={"tokens": t["tokens"]})).json()
                 assert "abc" in d["prompt"]
                 met = (await c.get("/metrics")).text
                 assert "vllm:generation_tokens_total" in met and "vllm:time_to_first_token_seconds" in met
-                assert (await c.post("/reset_prefix_cache")).status_code == 200
+                assert (await c.post("/reset_prefix_cache", headers=hdr)).status_code == 200
                 inv = await c.post("/invocations", headers=hdr, json={"prompt": "hello", "max_tokens": 3, "temperature": 0})
                 assert inv.status_code == 200 and inv.json()["object"] == "text_completion"
                 inv = await c.post("/invocations", headers=hdr, json={
@@ -407,5 +429,47 @@ def test_reasoning_parser_routes_chat_output_to_reasoning_content():
                 streamed = "".join(e["choices"][0]["delta"].get("reasoning_content", "") for e in ev)
                 assert streamed == msg["reasoning_content"]
                 assert not any(e["choices"][0]["delta"].get("content") for e in ev)
+    asyncio.run(main())
+    pstate.destroy_model_parallel()
+
+
+def test_chat_templates_render_in_a_sandbox():
+    """Templates come from model repositories and, with --trust-request-chat-template, from
+    request bodies: attribute walks into Python internals must fail, ordinary templates work."""
+    import jinja2
+    from vllm_distributed_amd.tokenizer import render_chat_template
+    msgs = [{"role": "user", "content": "hi"}]
+    assert render_chat_template("{% for m in messages %}{{ m.role }}:{{ m.content }}{% endfor %}", msgs) == "user:hi"
+    for evil in ("{{ ''.__class__.__mro__[1].__subclasses__() }}",
+                 "{{ messages.__class__.__base__.__subclasses__() }}",
+                 "{{ cycler.__init__.__globals__.os.popen('id').read() }}",
+                 "{% set _ = messages.append({'role': 'x'}) %}ok"):
+        with pytest.raises((jinja2.exceptions.SecurityError, jinja2.exceptions.UndefinedError)):
+            render_chat_template(evil, msgs)
+    assert msgs == [{"role": "user", "content": "hi"}]
+
+
+def test_admin_endpoints_need_the_dev_flag_and_request_templates_need_trust():
+    pstate.destroy_model_parallel()
+    base = ("serve llama-tiny --device cpu --dtype float32 --max-model-len 128 --block-size 16 "
+            "--num-gpu-blocks-override 64 --port 0 --disable-frontend-multiprocessing")
+    args = build_parser().parse_args((base + " --trust-request-chat-template").split())
+    args.model = args.model_tag
+
+    async def main():
+        async with api_server.build_async_engine_client(args) as engine:
+            app = api_server.build_app(args)
+            await api_server.init_app_state(engine, await engine.get_vllm_config(), app.state, args)
+            async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://t") as c:
+                for path in ("/sleep", "/wake_up", "/start_profile", "/stop_profile", "/reset_prefix_cache"):
+                    assert (await c.post(path)).status_code == 404, path
+                ok = await c.post("/v1/chat/completions", json={
+                    "messages": [{"role": "user", "content": "hi"}], "max_tokens": 1,
+                    "chat_template": "{{ messages[0].content }}"})
+                assert ok.status_code == 200, ok.text
+                bad = await c.post("/v1/chat/completions", json={
+                    "messages": [{"role": "user", "content": "hi"}], "max_tokens": 1,
+                    "chat_template": "{{ ''.__class__.__mro__[1].__subclasses__() }}"})
+                assert bad.status_code == 400 and "template" in bad.text
     asyncio.run(main())
     pstate.destroy_model_parallel()

@@ -26,41 +26,139 @@ dev = torch.device("cuda:0")
 pstate.init_distributed_environment(world, rank, "tcp://127.0.0.1:" + os.environ["MASTER_PORT"], 0, "gloo", dev)
 pstate.initialize_model_parallel(world, 1)
 g = pstate.get_tp_group()
-car = CustomAllReduce(g, max_bytes=4 << 20)
-ok = True
+car = CustomAllReduce(g, max_bytes=4 << 20, ranks_per_device=world)
+car.fence_start = os.environ.get("FENCE_START") == "1"
+ok, why = True, []
 worst = 0.0
-for it in range(6):
-    for n, mode in ((8, 1), (4096, 1), (8192 * 7, 1), (8192 * 7, 2), (1 << 20, 2), (2 << 20, 0), (1000 * 8, 0)):
+
+def fail(msg):
+    global ok
+    ok = False
+    why.append(msg)
+
+def gathered(x):
+    return g.all_gather_object(x.float().cpu())
+
+# ---- all-reduce: one-shot / two-shot, from the stage area and from ordinary memory
+for it in range(4):
+    for n, two in ((8, False), (4096, False), (8192 * 7, False), (8192 * 7, True), (1 << 20, True),
+                   (2 << 20, None), (1000 * 8, None), (40, True)):
         for dtype in (torch.bfloat16, torch.float16):
             torch.manual_seed(1000 * it + n + rank)
             x = torch.randn(n, device=dev).to(dtype)
-            out = car.all_reduce(x, mode)
+            src = x
+            if it % 2:
+                src = car.stage_view((n,), dtype)
+                src.copy_(x)
+            out = car.all_reduce(src, two_shot=two)
             torch.cuda.synchronize()
-            parts = g.all_gather_object(x.float().cpu())
-            ref = sum(parts).to(dtype).float()
+            ref = sum(gathered(x)).to(dtype).float()
             err = (out.float().cpu() - ref).abs().max().item()
             worst = max(worst, err)
-            tol = 0.05 * world
-            if not err <= tol:
-                ok = False
+            if not err <= 0.05 * world:
+                fail(f"all_reduce n={{n}} two={{two}} err={{err}}")
             bits = g.all_gather_object(out.cpu().view(torch.int16).sum().item())
             if len(set(bits)) != 1:       # every rank must hold identical bits
-                ok = False
-# graph capture + replay
-x = torch.ones(4096, device=dev, dtype=torch.bfloat16) * (rank + 1)
+                fail(f"all_reduce n={{n}}: ranks disagree")
+
+# ---- all-reduce + residual add + RMSNorm, residual replicated and row-sharded
+def norm_ref(parts, res, w, eps):
+    tot = (sum(parts) + res.float().cpu()).to(res.dtype).float()
+    return tot, tot * torch.rsqrt(tot.pow(2).mean(-1, keepdim=True) + eps) * w.float().cpu()
+
+for it, (rows, h) in enumerate(((1, 512), (5, 512), (64, 1024), (200, 8192), (37, 4096), (3, 8192))):
+    for sharded in (False, True):
+        torch.manual_seed(77 * it + rank)
+        x = torch.randn(rows, h, device=dev).to(torch.bfloat16)
+        torch.manual_seed(5 * it)                       # same residual and weight on every rank
+        res = torch.randn(rows, h, device=dev).to(torch.bfloat16)
+        w = (torch.rand(h, device=dev) + 0.5).to(torch.bfloat16)
+        per, mine = car.shard_rows(rows)
+        lo = min(rank * per, rows)
+        my_res = torch.zeros(per, h, dtype=res.dtype, device=dev) if sharded else res.clone()
+        if sharded:
+            my_res[:mine] = res[lo:lo + mine]
+        src = x
+        if it % 2 == 0:
+            src = car.stage_view((rows, h), torch.bfloat16)
+            src.copy_(x)
+        got = car.all_reduce_add_rms_norm(src, my_res, w, 1e-5, sharded)
+        torch.cuda.synchronize()
+        tot, want = norm_ref(gathered(x), res, w, 1e-5)
+        e1 = (got.float().cpu() - want).abs().max().item()
+        got_res = my_res[:mine].float().cpu() if sharded else my_res.float().cpu()
+        e2 = (got_res - (tot[lo:lo + mine] if sharded else tot)).abs().max().item() if got_res.numel() else 0.0
+        worst = max(worst, e1)
+        if not (e1 <= 0.06 and e2 <= 0.05 * world):
+            fail(f"fused norm rows={{rows}} h={{h}} sharded={{sharded}} e1={{e1}} e2={{e2}}")
+        bits = g.all_gather_object(got.cpu().view(torch.int16).sum().item())
+        if len(set(bits)) != 1:
+            fail(f"fused norm rows={{rows}}: ranks disagree")
+
+# ---- all-gather of arbitrary 16-byte-multiple pieces
+for dtype, shape in ((torch.float32, (3, 8)), (torch.bfloat16, (40, 16)), (torch.int32, (4,))):
+    piece = (torch.arange(int(torch.tensor(shape).prod()), device=dev).reshape(shape) + 1000 * rank).to(dtype)
+    out = car.all_gather(piece)
+    want = torch.cat([(torch.arange(piece.numel(), device=dev).reshape(shape) + 1000 * q).to(dtype) for q in range(world)])
+    if not torch.equal(out, want):
+        fail(f"all_gather {{dtype}}")
+car.end_step()
+if car.parity != 0:
+    fail("parity after end_step")
+
+# ---- one captured graph with every form, replayed 100 times on changing data
+rows, h = 48, 1024
+xin = torch.zeros(rows, h, device=dev, dtype=torch.bfloat16)
+res_r = torch.zeros(rows, h, device=dev, dtype=torch.bfloat16)
+per, mine = car.shard_rows(rows)
+lo = min(rank * per, rows)
+res_s = torch.zeros(per, h, device=dev, dtype=torch.bfloat16)
+w = torch.ones(h, device=dev, dtype=torch.bfloat16)
+
+def body():
+    a = car.stage_view((rows, h), torch.bfloat16)
+    a.copy_(xin)
+    y0 = car.all_reduce(a, two_shot=False)
+    b = car.stage_view((rows, h), torch.bfloat16)
+    b.copy_(xin)
+    y1 = car.all_reduce_add_rms_norm(b, res_r, w, 1e-5, False)
+    y2 = car.all_reduce_add_rms_norm(xin, res_s, w, 1e-5, True)      # input copied into the stage area
+    y3 = car.all_gather(y0[:2])
+    y4 = car.all_reduce(xin, two_shot=True)
+    car.end_step()
+    return y0, y1, y2, y3, y4
+
 s = torch.cuda.Stream()
+s.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(s):
-    car.all_reduce(x)
+    body()
+torch.cuda.current_stream().wait_stream(s)
 torch.cuda.synchronize()
 gr = torch.cuda.CUDAGraph()
 with torch.cuda.graph(gr):
-    y = car.all_reduce(x)
-for _ in range(3):
+    outs = body()
+tri = world * (world + 1) / 2
+for rep in range(100):
+    val = float(rep % 7 + 1)
+    xin.fill_(val * (rank + 1) / 8)
+    res_r.zero_()
+    res_s.zero_()
     gr.replay()
+    if rep % 10 == 9 or rep < 3:
+        torch.cuda.synchronize()
+        tot = val * tri / 8
+        y0, y1, y2, y3, y4 = outs
+        good = (bool((y0.float() == tot).all()) and bool((y4.float() == tot).all())
+                and bool((res_r.float() == tot).all()) and bool((res_s[:mine].float() == tot).all())
+                and bool((y1.float() - 1.0).abs().max() < 0.02) and bool((y2.float() - 1.0).abs().max() < 0.02)
+                and bool((y3.float() == tot).all()) and y3.shape[0] == 2 * world)
+        if not good:
+            fail(f"graph replay {{rep}}")
+            break
 torch.cuda.synchronize()
-ok = ok and bool((y.float() == sum(range(1, world + 1))).all().item())
-ok = ok and not car.timed_out()
-print("RESULT " + json.dumps(dict(ok=ok, worst=worst)), flush=True)
+if car.timed_out():
+    fail("timed out")
+print("RESULT " + json.dumps(dict(ok=ok, worst=worst, why=why[:6])), flush=True)
 g.barrier()
 car.close()
 """
@@ -87,21 +185,48 @@ def test_rccl_binding_single_rank_and_graph_capture():
     g.replay()
     torch.cuda.synchronize()
     assert bool((y == 3.0).all())
+    # grouped point-to-point: a send to and a receive from this same rank is a real device copy
+    src = torch.arange(4096, device="cuda", dtype=torch.float32)
+    dst = torch.zeros_like(src)
+    comm.send_recv(src, 0, dst, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(dst, src)
+    # ... and, captured, a graph that is NOT empty: every replay moves the current contents
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        comm.send_recv(src, 0, dst, 0)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        comm.send_recv(src, 0, dst, 0)
+    for k in range(3):
+        src.fill_(float(k + 5))
+        dst.zero_()
+        g2.replay()
+        torch.cuda.synchronize()
+        assert bool((dst == float(k + 5)).all()), "captured RCCL send/recv did not run on replay"
+    del g, g2             # RCCL waits for graphs that captured its calls before it lets go of the communicator
     comm.close()
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_direct_all_reduce_between_processes_sharing_one_gpu(world):
+@pytest.mark.parametrize("world,fence_start", [(2, False), (4, False), (8, False), (4, True)])
+def test_direct_collectives_between_processes_sharing_one_gpu(world, fence_start):
+    """All-reduce (one- and two-shot, staged and copied input), all-reduce + add + RMSNorm with
+    replicated and row-sharded residual, all-gather, and one hipGraph holding all of them
+    replayed 100 times on changing data, between 2 / 4 / 8 processes over hipIpc mappings."""
     port = get_open_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_PORT=str(port),
-                   VLLM_LOGGING_LEVEL="WARNING", GLOO_SOCKET_IFNAME="lo")
+                   VLLM_LOGGING_LEVEL="WARNING", GLOO_SOCKET_IFNAME="lo", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   FENCE_START="1" if fence_start else "0")
         procs.append(subprocess.Popen([sys.executable, "-c", CAR_SCRIPT.format(root=ROOT)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     results = []
     for p in procs:
-        so, _ = p.communicate(timeout=110)
+        so, _ = p.communicate(timeout=115)
         assert p.returncode == 0, so[-3000:]
         line = [l for l in so.splitlines() if l.startswith("RESULT ")][-1]
         results.append(json.loads(line[7:]))
@@ -161,7 +286,7 @@ eng = LLMEngine.from_engine_args(EngineArgs(
     distributed_executor_backend="spmd" if tp > 1 else "uni", enable_expert_parallel=os.environ.get("EP") == "1",
     async_scheduling=os.environ.get("ASYNC") == "1", gpu_memory_utilization=0.2,
     hf_overrides=json.loads(os.environ.get("OVERRIDES", "{{}}"))))
-g = SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True, logprobs=8)
+g = SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True, logprobs=int(os.environ.get("LOGPROBS", "8")))
 ids = [eng.add_request(None, p, g) for p in ([5, 9, 200, 17], list(range(10, 90)), [7, 7])]
 final, first_lp = {{}}, {{}}
 while eng.has_unfinished_requests():
@@ -170,13 +295,30 @@ while eng.has_unfinished_requests():
             final[o.request_id] = o.outputs[0].token_ids
             first_lp[o.request_id] = {{str(k): v for k, v in o.outputs[0].logprobs[0].items()}}
 from vllm_distributed_amd.parallel import state as pstate
+runner = eng.core.executor.driver.worker.model_runner
 print("RESULT " + json.dumps(dict(tokens=[final[i] for i in ids], first_lp=[first_lp[i] for i in ids],
-                                  direct_ar=pstate.get_tp_group().custom_ar is not None)), flush=True)
+                                  direct_ar=pstate.get_tp_group().custom_ar is not None,
+                                  graphs=list(runner.graph_sizes), fallback=runner.graph_fallback_reason)), flush=True)
 eng.shutdown()
 """
 
 
-def _run_spmd_shared(world, async_sched, sp="0", overrides=None, model="llama-tiny", ep=False):
+def _assert_distributions_close(ref_lps, got_lps, atol=0.08, rtol=2e-2, min_entries=512):
+    """Full-vocabulary log-probabilities of the first generated token (fp32, one vector per
+    prompt) of a sharded run against the unsharded model.  A mis-sharded weight or a wrong
+    reduction shifts logits by their own order of magnitude; bf16 summation order by ~1e-2."""
+    worst = 0.0
+    for ref, got in zip(ref_lps, got_lps):
+        assert len(ref) >= min_entries and set(ref) == set(got)
+        for tok, v in ref.items():
+            d = abs(got[tok] - v)
+            worst = max(worst, d)
+            assert d <= atol + rtol * abs(v), (tok, v, got[tok])
+    return worst
+
+
+def _run_spmd_shared(world, async_sched, sp="0", overrides=None, model="llama-tiny", ep=False, logprobs=8,
+                     extra_env=None):
     port = get_open_port()
     procs = []
     for r in range(world):
@@ -184,7 +326,7 @@ def _run_spmd_shared(world, async_sched, sp="0", overrides=None, model="llama-ti
                    MASTER_PORT=str(port), VLLM_LOGGING_LEVEL="WARNING", GLOO_SOCKET_IFNAME="lo",
                    VDAMD_SHARE_DEVICE="1", ASYNC="1" if async_sched else "0", HSA_ENABLE_IPC_MODE_LEGACY="0",
                    VDAMD_SEQUENCE_PARALLEL=sp, OVERRIDES=json.dumps(overrides or {}), MODEL=model,
-                   EP="1" if ep else "0")
+                   EP="1" if ep else "0", LOGPROBS=str(logprobs), **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, "-c", SPMD_SCRIPT.format(root=ROOT)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -201,12 +343,19 @@ def test_spmd_tensor_parallel_ranks_sharing_one_gpu_match_single_rank():
     model, peer-mapped all-reduce, vocab-parallel argmax) with ranks mapped
     onto one device.  bf16 partial sums are reduced in a different order than
     the unsharded GEMM, so the first tokens (largest margins) are compared."""
-    ref = _run_spmd_shared(1, False)[0]["tokens"]
-    for async_sched, sp in ((False, "0"), (True, "0"), (False, "force")):
-        got = _run_spmd_shared(2, async_sched, sp)
+    ref = _run_spmd_shared(1, False, logprobs=512)[0]
+    # fused all-reduce + norm inside captured decode graphs (default), the same eagerly, the
+    # unfused peer-mapped all-reduce, and the sequence-parallel form over host-staged gloo
+    for async_sched, sp, extra in ((False, "0", {}), (True, "0", {}), (False, "0", {"VDAMD_USE_HIP_GRAPH": "0"}),
+                                   (False, "0", {"VDAMD_FUSED_ALL_REDUCE_NORM": "0"}),
+                                   (False, "force", {"VDAMD_FUSED_ALL_REDUCE_NORM": "0"})):
+        got = _run_spmd_shared(2, async_sched, sp, logprobs=512, extra_env=extra)
         assert got[0]["tokens"] == got[1]["tokens"]
         assert got[0]["direct_ar"] and got[1]["direct_ar"]
-        assert [t[:2] for t in got[0]["tokens"]] == [t[:2] for t in ref]
+        if not extra.get("VDAMD_USE_HIP_GRAPH") == "0":
+            # the decode graph must really hold the step (peer-mapped collectives are capturable)
+            assert got[0]["graphs"], got[0]["fallback"]
+        _assert_distributions_close(ref["first_lp"], got[0]["first_lp"])
 
 
 @pytest.mark.parametrize("tp,pp", [(1, 2), (2, 1)])
@@ -224,13 +373,13 @@ def test_head_plus_remote_worker_sharing_one_gpu(monkeypatch, tp, pp):
     prompts = [[5, 9, 200, 17, 3, 3, 8], list(range(10, 90)), [7, 7, 7]]
 
     def generate(engine):
-        sp = SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True)
+        sp = SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True, logprobs=512)
         ids = [engine.add_request(None, p, sp) for p in prompts]
         final = {}
         while engine.has_unfinished_requests():
             for o in engine.step():
                 if o.finished:
-                    final[o.request_id] = o.outputs[0].token_ids
+                    final[o.request_id] = o.outputs[0].logprobs[0]
         return [final[i] for i in ids]
 
     common = dict(model="llama-tiny", device="cuda", dtype="bfloat16", max_model_len=256,
@@ -257,7 +406,7 @@ def test_head_plus_remote_worker_sharing_one_gpu(monkeypatch, tp, pp):
             **common))
         assert [a.node_id is None for a in eng.core.executor.assignments] == [True, False]
         got = generate(eng)
-        assert [t[:2] for t in got] == [t[:2] for t in ref]
+        _assert_distributions_close(ref, got)
     finally:
         if eng is not None:
             eng.shutdown()
@@ -271,15 +420,14 @@ def test_spmd_wide_tensor_parallel_sharing_one_gpu(world):
     through the HIP kernels, the peer-mapped all-reduce between 4 / 8 processes
     and the vocab-parallel argmax, against the unsharded model."""
     ov = {"num_attention_heads": 8, "num_key_value_heads": 8, "head_dim": 64, "intermediate_size": 1024}
-    ref = _run_spmd_shared(1, False, overrides=ov)[0]
-    got = _run_spmd_shared(world, False, overrides=ov)
+    ref = _run_spmd_shared(1, False, overrides=ov, logprobs=512)[0]
+    got = _run_spmd_shared(world, False, overrides=ov, logprobs=512)
     assert all(g["tokens"] == got[0]["tokens"] for g in got)
     assert all(g["direct_ar"] for g in got)
+    assert got[0]["graphs"], got[0]["fallback"]
     # bf16 partial sums are added in a different order than in the unsharded GEMM, which can
-    # flip near-ties of a random-init model: compare the first-token distributions instead
-    for lp_ref, lp_tp, toks in zip(ref["first_lp"], got[0]["first_lp"], ref["tokens"]):
-        top = str(toks[0])
-        assert top in lp_tp and abs(lp_tp[top] - lp_ref[top]) < 0.1, (lp_ref, lp_tp)
+    # flip near-ties of a random-init model: compare the whole first-token distributions
+    _assert_distributions_close(ref["first_lp"], got[0]["first_lp"])
 
 
 @pytest.mark.parametrize("ep", [False, True])

@@ -359,3 +359,34 @@ def test_step_breakdown_adds_up_through_the_distributed_executor(monkeypatch):
     finally:
         if eng is not None:
             eng.shutdown()
+
+
+def test_registration_channel_needs_a_real_secret_off_loopback(monkeypatch):
+    """The head refuses to listen beyond loopback, and a worker refuses to connect to another
+    host, with an empty or placeholder secret (pickles travel on that channel)."""
+    from vllm_distributed_amd.executor.distributed import check_rpc_secret
+    monkeypatch.delenv("VLLM_RPC_INSECURE", raising=False)
+    assert check_rpc_secret("", "127.0.0.1", "bind") == ""
+    assert check_rpc_secret("s3cr3t-9f2c", "0.0.0.0", "bind") == "s3cr3t-9f2c"
+    for weak in ("", "change-me", "Change-Me"):
+        with pytest.raises(RuntimeError, match="VLLM_RPC_SECRET"):
+            check_rpc_secret(weak, "0.0.0.0", "bind")
+        with pytest.raises(RuntimeError, match="VLLM_RPC_SECRET"):
+            check_rpc_secret(weak, "192.168.2.145", "connect to")
+    monkeypatch.setenv("VLLM_RPC_INSECURE", "1")
+    assert check_rpc_secret("", "0.0.0.0", "bind") == ""
+    monkeypatch.delenv("VLLM_RPC_INSECURE")
+    # end to end: an explicit public bind without a secret fails engine start-up
+    monkeypatch.setenv("VLLM_RPC_BIND", "0.0.0.0")
+    monkeypatch.setenv("VLLM_RPC_SECRET", "")
+    monkeypatch.setenv("VLLM_SERVER_PORT", str(get_open_port()))
+    monkeypatch.setenv("VLLM_HEAD_LOCAL_DEVICES", "2")
+    with pytest.raises(RuntimeError, match="VLLM_RPC_SECRET"):
+        LLMEngine.from_engine_args(EngineArgs(
+            model="llama-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,
+            num_gpu_blocks_override=64, max_num_seqs=8, tensor_parallel_size=2,
+            distributed_executor_backend="distributed"))
+    # remote role, other host, no secret
+    from vllm_distributed_amd.launch import remote_main
+    with pytest.raises(RuntimeError, match="VLLM_RPC_SECRET"):
+        remote_main("192.168.2.145", num_devices=1)

@@ -336,3 +336,17 @@ def test_unknown_rope_scaling_is_rejected():
     from vllm_distributed_amd.ops import build_cos_sin_cache
     with pytest.raises(ValueError, match="not supported"):
         build_cos_sin_cache(128, 64, 10000.0, {"rope_type": "longrope", "factor": 2.0})
+
+
+def test_auto_load_format_refuses_a_checkpoint_that_is_not_there(tmp_path, monkeypatch):
+    """`serve <hub id>` with nothing on disk must fail, not serve random weights; bundled
+    architecture names and an explicit --load-format dummy keep working."""
+    from vllm_distributed_amd.config import ModelConfig
+    monkeypatch.setenv("HUGGINGFACE_HUB_CACHE", str(tmp_path))
+    with pytest.raises(FileNotFoundError, match="no weights found"):
+        ModelConfig(model="meta-llama/Meta-Llama-3-8B")
+    assert ModelConfig(model="meta-llama/Meta-Llama-3-8B", load_format="dummy").load_format == "dummy"
+    assert ModelConfig(model="llama-tiny").load_format == "dummy"
+    assert ModelConfig(model="llama-3-70b").load_format == "dummy"
+    with pytest.raises(FileNotFoundError):
+        ModelConfig(model=str(tmp_path / "typo-in-the-path"))

@@ -82,6 +82,15 @@ def load_hf_config(model: str) -> Dict[str, Any]:
         f"not bundled; bundled: {sorted(set(_BUILTIN_ALIASES.values()))})")
 
 
+def is_bundled_architecture_name(model: str) -> bool:
+    """Short names of the config files shipped in ``models/configs`` (``llama-tiny``,
+    ``llama-3-70b``, ...): architecture descriptions for tests and benchmarks, which only
+    ever run with random weights.  Hub ids (``org/name``) and paths are not."""
+    name = model.lower()
+    return ("/" not in name and os.sep not in name
+            and os.path.isfile(os.path.join(_CONFIG_DIR, _BUILTIN_ALIASES.get(name, name + ".json"))))
+
+
 def resolve_model_path(model: str) -> Optional[str]:
     """Directory holding weights/tokenizer for ``model`` or None."""
     if os.path.isdir(model):
@@ -147,8 +156,14 @@ class ModelConfig:
             elif "nvfp4" in str(q.get("format", "")).lower() or str(q.get("quant_algo", "")).upper() == "NVFP4":
                 self.quantization = "nvfp4"      # compressed-tensors / modelopt exports
         if self.load_format == "auto" and resolve_model_path(self.model) is None:
-            logger.warning("no weights found for %s: using deterministic random init "
-                           "(load_format=dummy)", self.model)
+            if not is_bundled_architecture_name(self.model):
+                # a typo, an id that is not in the cache, an unmounted volume: serving random
+                # weights behind a healthy-looking API would be the worst possible answer
+                raise FileNotFoundError(
+                    f"no weights found for model {self.model!r} (not a local directory and not in the "
+                    f"Hugging Face cache); pass --load-format dummy to run its architecture with random weights")
+            logger.warning("%s names a bundled architecture description, not a checkpoint: using "
+                           "deterministic random init (load_format=dummy)", self.model)
             self.load_format = "dummy"
 
     # ---------------------------------------------------- generation defaults

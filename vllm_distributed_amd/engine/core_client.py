@@ -59,11 +59,23 @@ def _core_main(vllm_config: VllmConfig, executor_class: Optional[Type[Executor]]
                 idle = False
                 kind = msg[0]
                 if kind == "add":
-                    core.add_request(msg[1])
+                    try:
+                        core.add_request(msg[1])
+                    except EngineDeadError:
+                        raise
+                    except Exception as e:  # noqa: BLE001 - one bad request must not take the core down
+                        logger.warning("request %s rejected: %r", msg[1].request_id, e)
+                        conn.send(("reject", msg[1].request_id, repr(e)))
                 elif kind == "abort":
-                    core.abort_requests(msg[1])
+                    try:
+                        core.abort_requests(msg[1])
+                    except Exception as e:  # noqa: BLE001
+                        logger.warning("abort of %s failed: %r", msg[1], e)
                 elif kind == "finish":
-                    core.finish_requests(msg[1], RequestStatus.FINISHED_STOPPED)
+                    try:
+                        core.finish_requests(msg[1], RequestStatus.FINISHED_STOPPED)
+                    except Exception as e:  # noqa: BLE001
+                        logger.warning("finish of %s failed: %r", msg[1], e)
                 elif kind == "call":
                     _, call_id, name, args = msg
                     try:
@@ -211,6 +223,10 @@ class MPEngineCoreClient:
                 return outs
             if kind == "ret":
                 self._calls[msg[1]] = msg[2:]
+            elif kind == "reject":        # the core refused the request: it ends with an error, nothing else does
+                self._live.discard(msg[1])
+                return [EngineCoreOutput(request_id=msg[1], new_token_ids=[], finish_reason="error",
+                                         stop_reason=msg[2])]
             elif kind == "dead":
                 self.dead = True
                 raise EngineDeadError(f"engine core process failed: {msg[1]}")
@@ -234,6 +250,8 @@ class MPEngineCoreClient:
                 raise EngineDeadError(f"engine core process failed: {msg[1]}")
             elif msg[0] == "out" and msg[2] is not None:
                 self._stats, self.timer.snapshot = msg[2]
+            elif msg[0] == "reject":
+                self._live.discard(msg[1])
         ok, value = self._calls.pop(call_id)
         if not ok:
             raise RuntimeError(f"engine core call {name} failed: {value}")

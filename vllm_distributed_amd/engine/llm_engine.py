@@ -97,6 +97,16 @@ class LLMEngine:
         params.check_vocab(vocab)
         if any(t < 0 or t >= vocab for t in ids):
             raise ValueError("prompt contains token ids outside the model vocabulary")
+        # everything the scheduler would refuse is refused here, in the caller's process and
+        # before anything is sent: a bad request must cost one error reply, never the engine
+        if not ids:
+            raise ValueError("empty prompt")
+        if len(ids) >= max_len:
+            raise ValueError(f"prompt ({len(ids)} tokens) does not fit max_model_len ({max_len})")
+        if request_id in self.states:
+            raise ValueError(f"duplicate request id {request_id}")
+        if lora_request is not None and self.vllm_config.lora_config is None:
+            raise ValueError("the engine was started without --enable-lora")
         req = Request(request_id, ids, params, self.eos_token_id, arrival_time, priority, text, lora_request)
         detok = IncrementalDetokenizer(self.tokenizer, ids, params) if params.detokenize else None
         self.core.add_request(req)

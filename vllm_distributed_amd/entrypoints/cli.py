@@ -52,6 +52,10 @@ def add_server_args(p: argparse.ArgumentParser) -> None:
                    help="split <think>...</think> out of chat completions into reasoning_content")
     g.add_argument("--chat-template", type=str, default=None)
     g.add_argument("--enable-tokenizer-info-endpoint", action="store_true")
+    g.add_argument("--trust-request-chat-template", action="store_true",
+                   help="honour a chat_template sent in a request body (rendered in a sandbox either way)")
+    g.add_argument("--enable-dev-endpoints", action="store_true",
+                   help="register /sleep, /wake_up, /start_profile, /stop_profile and /reset_prefix_cache")
     g.add_argument("--lora-modules", type=str, nargs="+", default=None, metavar="NAME=PATH",
                    help="LoRA adapters served under their own model names (needs --enable-lora)")
     g.add_argument("--disable-frontend-multiprocessing", action="store_true",

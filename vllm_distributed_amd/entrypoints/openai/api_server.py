@@ -161,7 +161,7 @@ def _nth_params(sp: SamplingParams, j: int) -> SamplingParams:
     out = sp.clone()
     out.n = 1
     if out.seed is not None:
-        out.seed = out.seed + j
+        out.seed = (out.seed + j) % (2 ** 63)
     return out
 
 
@@ -208,14 +208,21 @@ def build_app(args: argparse.Namespace) -> FastAPI:
                        allow_headers=getattr(args, "allowed_headers", None) or ["*"])
 
     if api_key:
+        import hmac
+        want = ("Bearer " + api_key).encode()
+        # liveness / scrape endpoints stay open; everything that generates, tokenizes or
+        # administers needs the key (``/invocations`` reaches the same handlers as ``/v1``)
+        public = {"/health", "/ping", "/version", "/metrics"}
+
         @app.middleware("http")
         async def auth(request: Request, call_next):
-            if request.method != "OPTIONS" and request.url.path.startswith("/v1"):
-                if request.headers.get("Authorization") != "Bearer " + api_key:
+            if request.method != "OPTIONS" and request.url.path.rstrip("/") not in public:
+                got = (request.headers.get("Authorization") or "").encode()
+                if not hmac.compare_digest(got, want):
                     return JSONResponse({"error": "Unauthorized"}, status_code=401)
             return await call_next(request)
 
-    _register_routes(app)
+    _register_routes(app, dev_mode=bool(getattr(args, "enable_dev_endpoints", False)) or envs.VLLM_SERVER_DEV_MODE)
     return app
 
 
@@ -340,7 +347,7 @@ def _messages_to_dicts(messages: List[ChatMessage]) -> List[dict]:
     return out
 
 
-def _register_routes(app: FastAPI) -> None:
+def _register_routes(app: FastAPI, dev_mode: bool = False) -> None:
     @app.get("/health")
     async def health(request: Request):
         try:
@@ -396,36 +403,42 @@ def _register_routes(app: FastAPI) -> None:
                 "chat_template": getattr(tok, "chat_template", None),
                 "bos_token_id": tok.bos_token_id, "eos_token_id": tok.eos_token_id}
 
-    @app.post("/start_profile")
-    async def start_profile(request: Request):
-        await request.app.state.engine.start_profile()
-        return Response(status_code=200)
+    # profiling, sleep / wake-up and cache resets change the engine under its users' feet: only
+    # registered when the operator asks for them (--enable-dev-endpoints / VLLM_SERVER_DEV_MODE=1)
+    if dev_mode:
+        @app.post("/start_profile")
+        async def start_profile(request: Request):
+            await request.app.state.engine.start_profile()
+            return Response(status_code=200)
 
-    @app.post("/stop_profile")
-    async def stop_profile(request: Request):
-        await request.app.state.engine.stop_profile()
-        return Response(status_code=200)
+        @app.post("/stop_profile")
+        async def stop_profile(request: Request):
+            await request.app.state.engine.stop_profile()
+            return Response(status_code=200)
 
-    @app.post("/reset_prefix_cache")
-    async def reset_prefix_cache(request: Request):
-        ok = await request.app.state.engine.reset_prefix_cache()
-        return Response(status_code=200 if ok else 409)
+        @app.post("/reset_prefix_cache")
+        async def reset_prefix_cache(request: Request):
+            ok = await request.app.state.engine.reset_prefix_cache()
+            return Response(status_code=200 if ok else 409)
 
-    @app.post("/sleep")
-    async def sleep(request: Request, level: int = 1):
-        await request.app.state.engine.sleep(level)
-        request.app.state.sleeping = True
-        return Response(status_code=200)
+        @app.post("/sleep")
+        async def sleep(request: Request, level: int = 1):
+            if request.app.state.engine.engine.get_num_unfinished_requests() > 0:
+                return JSONResponse({"error": "requests are in flight; retry when the server is idle"},
+                                    status_code=409)
+            await request.app.state.engine.sleep(level)
+            request.app.state.sleeping = True
+            return Response(status_code=200)
 
-    @app.post("/wake_up")
-    async def wake_up(request: Request):
-        await request.app.state.engine.wake_up()
-        request.app.state.sleeping = False
-        return Response(status_code=200)
+        @app.post("/wake_up")
+        async def wake_up(request: Request):
+            await request.app.state.engine.wake_up()
+            request.app.state.sleeping = False
+            return Response(status_code=200)
 
-    @app.get("/is_sleeping")
-    async def is_sleeping(request: Request):
-        return {"is_sleeping": bool(getattr(request.app.state, "sleeping", False))}
+        @app.get("/is_sleeping")
+        async def is_sleeping(request: Request):
+            return {"is_sleeping": bool(getattr(request.app.state, "sleeping", False))}
 
     @app.post("/invocations")
     async def invocations(request: Request):
@@ -608,6 +621,9 @@ def _register_routes(app: FastAPI) -> None:
             return _error("tool_choice 'required' is not supported (use 'auto', 'none' or a named function)")
         try:
             kwargs = dict(req.chat_template_kwargs or {})
+            if req.chat_template and not getattr(st.args, "trust_request_chat_template", False):
+                return _error("a chat_template in the request is only honoured when the server was started "
+                              "with --trust-request-chat-template")
             template = req.chat_template or st.chat_template
             if template:
                 from ...tokenizer import render_chat_template

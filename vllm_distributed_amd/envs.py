@@ -47,8 +47,9 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     "VLLM_SERVER_PORT": _int("VLLM_SERVER_PORT", 30044),
     # Shared secret for the RPC handshake (HMAC-SHA256 challenge/response).
     "VLLM_RPC_SECRET": _str("VLLM_RPC_SECRET", ""),
-    # Address the head's RPC server binds to.
-    "VLLM_RPC_BIND": _str("VLLM_RPC_BIND", "0.0.0.0"),
+    # Address the head's RPC server binds to.  Unset: every interface when a real shared
+    # secret is configured, loopback only (workers on this host) when it is not.
+    "VLLM_RPC_BIND": _str("VLLM_RPC_BIND", None),
     # Seconds a remote worker waits between reconnect attempts.
     "VLLM_REMOTE_RETRY_SECONDS": _float("VLLM_REMOTE_RETRY_SECONDS", 10.0),
     # Cap on GPUs the head uses for its own (forked) workers; -1 = all.
@@ -62,6 +63,10 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     # --- http ------------------------------------------------------------
     "VLLM_HTTP_TIMEOUT_KEEP_ALIVE": _int("VLLM_HTTP_TIMEOUT_KEEP_ALIVE", 5),
     "VLLM_API_KEY": _str("VLLM_API_KEY", None),
+    # Register /sleep, /wake_up, /start_profile, /stop_profile, /reset_prefix_cache.
+    "VLLM_SERVER_DEV_MODE": _bool("VLLM_SERVER_DEV_MODE", False),
+    # Run the worker-registration port without a shared secret on a non-loopback address.
+    "VLLM_RPC_INSECURE": _bool("VLLM_RPC_INSECURE", False),
     # --- engine ----------------------------------------------------------
     "VLLM_USE_V1": _bool("VLLM_USE_V1", True),
     "VLLM_PP_LAYER_PARTITION": _str("VLLM_PP_LAYER_PARTITION", None),
@@ -75,7 +80,18 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     "VDAMD_COMM_BACKEND": _str("VDAMD_COMM_BACKEND", "auto"),
     # Enable the peer-mapped direct all-reduce for small messages.
     "VDAMD_CUSTOM_ALL_REDUCE": _bool("VDAMD_CUSTOM_ALL_REDUCE", True),
-    "VDAMD_CUSTOM_ALL_REDUCE_MAX_BYTES": _int("VDAMD_CUSTOM_ALL_REDUCE_MAX_BYTES", 8 << 20),
+    # Largest message the peer-mapped path takes (it owns 4x this much uncached memory per rank);
+    # larger ones go to RCCL.
+    "VDAMD_CUSTOM_ALL_REDUCE_MAX_BYTES": _int("VDAMD_CUSTOM_ALL_REDUCE_MAX_BYTES", 16 << 20),
+    # Messages up to this size are summed by every rank in one pass (one barrier, W x the
+    # traffic); larger ones are reduce-scattered and gathered (two barriers, 2 x the traffic).
+    "VDAMD_CUSTOM_ALL_REDUCE_ONE_SHOT_BYTES": _int("VDAMD_CUSTOM_ALL_REDUCE_ONE_SHOT_BYTES", 256 << 10),
+    # System-scope release fence also in the barrier that opens a kernel (the data it
+    # publishes was written by an earlier kernel into uncached memory): "0", "1", or
+    # "auto" = turned on if the start-up self-check fails without it.
+    "VDAMD_CUSTOM_ALL_REDUCE_FENCE_START": _str("VDAMD_CUSTOM_ALL_REDUCE_FENCE_START", "auto"),
+    # Fused all-reduce + residual add + RMSNorm in the decoder layers (needs the peer-mapped path).
+    "VDAMD_FUSED_ALL_REDUCE_NORM": _bool("VDAMD_FUSED_ALL_REDUCE_NORM", True),
     # Micro-batch overlap of TP all-reduces with compute in decode:
     # "auto" (TP>1 and batch >= MIN_BATCH), "0" (off), "force" (also at TP=1; tests).
     "VDAMD_TP_OVERLAP": _str("VDAMD_TP_OVERLAP", "auto"),

@@ -51,6 +51,32 @@ from .placement import (Assignment, NodeInfo, PlacementError, max_concurrent_bat
 logger = init_logger(__name__)
 
 
+PLACEHOLDER_SECRETS = {"change-me", "changeme", "secret", "password"}
+
+
+def _is_loopback(addr: str) -> bool:
+    return addr in ("localhost", "::1") or addr.startswith("127.")
+
+
+def check_rpc_secret(secret: str, addr: str, what: str) -> str:
+    """Policy for the worker-registration channel, on which pickled payloads travel once a
+    peer has passed the handshake: off loopback it needs a real shared secret (the handshake
+    is an HMAC over it; with an empty or published key any peer can compute it).  Refuses to
+    start otherwise, unless the operator sets ``VLLM_RPC_INSECURE=1``."""
+    weak = not secret or secret.strip().lower() in PLACEHOLDER_SECRETS
+    if not weak or _is_loopback(addr):
+        return secret
+    if envs.VLLM_RPC_INSECURE:
+        logger.warning("VLLM_RPC_INSECURE=1: the worker-registration channel (%s %s) runs without a real "
+                       "shared secret; anyone who can reach it can run code on head and workers", what, addr)
+        return secret
+    raise RuntimeError(
+        f"refusing to {what} the worker-registration channel on {addr} with "
+        f"{'an empty' if not secret else 'a placeholder'} VLLM_RPC_SECRET: set the same random secret on "
+        "the head and every worker (e.g. `openssl rand -hex 32`), keep the channel on loopback "
+        "(VLLM_RPC_BIND=127.0.0.1), or accept the risk explicitly with VLLM_RPC_INSECURE=1")
+
+
 class _RemoteWorkerSlot:
     """One registered remote worker process (one TCP connection)."""
 
@@ -82,10 +108,14 @@ class DistributedExecutor(Executor):
             f"world_size ({self.world_size}) must be equal to the tensor_parallel_size ({tp}) x "
             f"pipeline_parallel_size ({pp})")
         self.port = envs.VLLM_SERVER_PORT
-        self.secret = envs.VLLM_RPC_SECRET
-        if not self.secret:
-            logger.warning("VLLM_RPC_SECRET is not set: the worker-registration port accepts any "
-                           "peer that speaks the protocol; set the same secret on head and workers")
+        self.bind = envs.VLLM_RPC_BIND
+        if not self.bind:
+            weak = not envs.VLLM_RPC_SECRET or envs.VLLM_RPC_SECRET.strip().lower() in PLACEHOLDER_SECRETS
+            self.bind = "127.0.0.1" if weak else "0.0.0.0"
+            if weak:
+                logger.info("no VLLM_RPC_SECRET: worker registration listens on loopback only "
+                            "(workers on other hosts need a shared secret on both sides)")
+        self.secret = check_rpc_secret(envs.VLLM_RPC_SECRET, self.bind, "bind")
         self._slots: Dict[str, List[_RemoteWorkerSlot]] = {}     # node_id -> registered slots
         self._node_expected: Dict[str, int] = {}
         self._local_procs: List[multiprocessing.Process] = []
@@ -153,8 +183,8 @@ class DistributedExecutor(Executor):
     # ------------------------------------------------------------ rpc thread
     async def _serve(self, workers_ready: "concurrent.futures.Future[None]") -> None:
         self._nodes_changed = asyncio.Event()
-        self._server = await asyncio.start_server(self._handle_client, envs.VLLM_RPC_BIND, self.port)
-        logger.info("worker registration server listening on %s:%d", envs.VLLM_RPC_BIND, self.port)
+        self._server = await asyncio.start_server(self._handle_client, self.bind, self.port)
+        logger.info("worker registration server listening on %s:%d", self.bind, self.port)
         try:
             await self._spawn_and_listen_for_workers()
             workers_ready.set_result(None)

@@ -213,6 +213,8 @@ def remote_main(server_ip: str, port: Optional[int] = None, num_devices: Optiona
     """One process per local GPU; if any of them exits the node is torn down
     with a non-zero status so the supervisor (docker ``restart:
     unless-stopped``) brings it back (reference ``src/launch.py:608-632``)."""
+    from .executor.distributed import check_rpc_secret
+    check_rpc_secret(envs.VLLM_RPC_SECRET, server_ip, "connect to")     # workers unpickle what the head sends
     if num_devices is None:
         num_devices = hip_device_count_stateless() if current_platform.is_rocm() else 1
         num_devices = max(1, num_devices - device_offset)

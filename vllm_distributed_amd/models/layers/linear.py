@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from ...parallel.state import (get_tensor_model_parallel_rank,
+from ...parallel.state import (get_tp_group, get_tensor_model_parallel_rank,
                                get_tensor_model_parallel_world_size,
                                tensor_model_parallel_all_gather,
                                tensor_model_parallel_all_reduce)
@@ -206,8 +206,9 @@ class _LinearBase(nn.Module):
             self.quant = None
             self.weight = nn.Parameter(awq_dequantize(qweight, qzeros, scales, self.dtype), requires_grad=False)
 
-    def _matmul(self, x: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
-        y = self._base_matmul(x, bias)
+    def _matmul(self, x: torch.Tensor, bias: Optional[torch.Tensor],
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        y = self._base_matmul(x, bias, out)
         if self.lora is not None:
             y = self.lora.apply(x, y)
         return y
@@ -227,14 +228,16 @@ class _LinearBase(nn.Module):
         else:
             self.dense_shadow = hip.w4_dequant(self.qw, self.sz)
 
-    def _base_matmul(self, x: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    def _base_matmul(self, x: torch.Tensor, bias: Optional[torch.Tensor],
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``out`` is a hint (dense 16-bit weights honour it): callers use what is returned."""
         if self.qw is not None:
             if self.alpha is not None:
                 return ops.fp4_linear(x, self.qw, self.sz, self.alpha, bias, self.dense_shadow)
             return ops.w4a16_linear(x, self.qw, self.sz, bias, self.dense_shadow)
         if self.weight_scale is not None:
             return ops.fp8_linear(x, self.weight, self.weight_scale, bias)
-        return ops.linear(x, self.weight, bias)
+        return ops.linear(x, self.weight, bias, out if x.dim() == 2 else None)
 
 
 def divide(a: int, b: int) -> int:
@@ -369,11 +372,16 @@ class RowParallelLinear(_LinearBase):
         n = self.in_local // in_div
         param.data.copy_(w.narrow(1 - od, self.tp_rank * n, n))
 
-    def forward(self, x: torch.Tensor, reduce: bool = True) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, reduce: bool = True, staged: bool = False) -> torch.Tensor:
         """``reduce=False`` returns this rank's partial sums; the caller owns the
-        all-reduce (used to overlap it with another micro-batch's compute)."""
+        all-reduce (used to overlap it with another micro-batch's compute, or to
+        fuse it with the following add + norm).  ``staged``: the partial sums are
+        written where the TP group's next direct all-reduce reads its input."""
+        out = None
+        if staged and self.tp > 1 and x.dim() == 2:
+            out = get_tp_group().stage_view((x.shape[0], self.out_local), x.dtype)
         # bias is added once (rank 0) so the all-reduce does not multiply it
-        y = self._matmul(x, self.bias if self.tp_rank == 0 else None)
+        y = self._matmul(x, self.bias if self.tp_rank == 0 else None, out)
         if reduce and self.reduce_results and self.tp > 1:
             y = tensor_model_parallel_all_reduce(y)
         return y
@@ -405,10 +413,13 @@ class VocabParallelEmbedding(nn.Module):
         if n < self.rows:
             param.data[n:].zero_()
 
-    def forward(self, ids: torch.Tensor, reduce: bool = True) -> torch.Tensor:
+    def forward(self, ids: torch.Tensor, reduce: bool = True, staged: bool = False) -> torch.Tensor:
         """``reduce=False`` returns this rank's partial rows (zero for ids of
-        other shards); the caller owns the reduction."""
-        out = ops.embedding(ids, self.weight, self.vocab_start, masked=self.tp > 1)
+        other shards); the caller owns the reduction (``staged``: see ``RowParallelLinear``)."""
+        dst = None
+        if staged and self.tp > 1:
+            dst = get_tp_group().stage_view((ids.shape[0], self.weight.shape[1]), self.weight.dtype)
+        out = ops.embedding(ids, self.weight, self.vocab_start, masked=self.tp > 1, out=dst)
         if reduce and self.tp > 1:
             out = tensor_model_parallel_all_reduce(out)
         return out

@@ -245,7 +245,8 @@ class FusedMoE(nn.Module):
         y = self._experts_grouped(x.index_select(0, src_row), tiles, tile_rows)
         return ops.moe_combine(y, topw, topi, inv, self.expert_start, local)
 
-    def forward(self, x: torch.Tensor, reduce: bool = True) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, reduce: bool = True, staged: bool = False) -> torch.Tensor:
+        # `staged` (write the partial sums where the next direct all-reduce reads) is a hint only
         logits = self.gate(x)
         tile_rows = self._grouped_tile_rows(x)
         if tile_rows and x.dim() == 2 and ops.moe_route_fused_ok(logits, self.num_experts, self.top_k):

@@ -28,8 +28,8 @@ class LlamaMLP(nn.Module):
         self.gate_up_proj = ColumnParallelLinear(hidden, [inter, inter], bias, dtype)
         self.down_proj = RowParallelLinear(inter, hidden, bias, dtype)
 
-    def forward(self, x: torch.Tensor, reduce: bool = True) -> torch.Tensor:
-        return self.down_proj(ops.silu_and_mul(self.gate_up_proj(x)), reduce)
+    def forward(self, x: torch.Tensor, reduce: bool = True, staged: bool = False) -> torch.Tensor:
+        return self.down_proj(ops.silu_and_mul(self.gate_up_proj(x)), reduce, staged)
 
 
 class LlamaAttention(nn.Module):
@@ -55,7 +55,8 @@ class LlamaAttention(nn.Module):
         self.attn = Attention(self.num_heads, self.head_dim, self.num_kv_heads,
                               self.head_dim ** -0.5, layer_idx)
 
-    def forward(self, positions: torch.Tensor, hidden: torch.Tensor, reduce: bool = True) -> torch.Tensor:
+    def forward(self, positions: torch.Tensor, hidden: torch.Tensor, reduce: bool = True,
+                staged: bool = False) -> torch.Tensor:
         qkv = self.qkv_proj(hidden)
         md = get_forward_context().attn_metadata
         if self.qk_norm and md is not None and self.attn.k_cache is not None:
@@ -79,7 +80,7 @@ class LlamaAttention(nn.Module):
                                    self.attn.v_cache, md.slot_mapping, self.num_heads,
                                    self.num_kv_heads, self.head_dim)
             out = self.attn.forward_cached(q)
-        return self.o_proj(out, reduce)
+        return self.o_proj(out, reduce, staged)
 
 
 class LlamaDecoderLayer(nn.Module):
@@ -173,6 +174,9 @@ class LlamaForCausalLM(nn.Module):
 
     def forward(self, input_ids: Optional[torch.Tensor], positions: torch.Tensor,
                 intermediate: Optional[IntermediateTensors] = None):
+        fused = self.fused_tp_mode(positions.shape[0])
+        if fused is not None:
+            return self.forward_fused_tp(input_ids, positions, intermediate, sharded=fused)
         if intermediate is None and self.sequence_parallel_ok(positions.shape[0]):
             return self.forward_sequence_parallel(input_ids, positions)
         if self.is_first:
@@ -186,6 +190,63 @@ class LlamaForCausalLM(nn.Module):
             return IntermediateTensors(hidden, residual)
         hidden, _ = self.norm(hidden, residual)
         return hidden
+
+    # ------------------------------------------ fused all-reduce + add + norm
+    def fused_tp_mode(self, num_tokens: int) -> Optional[bool]:
+        """None: the TP group's peer-mapped collectives do not take this batch (no such path,
+        or the messages are too large for it).  Otherwise the batch runs ``forward_fused_tp``:
+        False = residual stream replicated (small messages, one pass over every peer's partial
+        sums), True = residual stream row-sharded (reduce-scatter + norm on the shard + gather)."""
+        tp = get_tp_group()
+        h = self.cfg["hidden_size"]
+        dtype = self.norm.weight.dtype if self.is_last else next(iter(self.parameters())).dtype
+        if tp.world_size == 1 or num_tokens == 0 or not tp.fused_all_reduce_norm_ok(num_tokens, h, dtype):
+            return None
+        small = num_tokens * h * 2 <= tp.custom_ar.one_shot_bytes
+        if small:
+            return False
+        # rows of the residual live on different ranks: only when one stage runs the whole model
+        return True if (self.is_first and self.is_last) else None
+
+    def forward_fused_tp(self, input_ids: Optional[torch.Tensor], positions: torch.Tensor,
+                         intermediate: Optional[IntermediateTensors], sharded: bool):
+        """The decoder with every TP all-reduce folded into the add + RMSNorm that follows it:
+        row-parallel GEMMs (and the vocab-parallel embedding) leave their partial sums in the
+        peer-mapped stage area and one kernel per norm does reduce + residual add + norm
+        (``csrc/custom_all_reduce.hip``).  Per layer that is 2 kernels where the unfused form
+        runs 2 copies + 2 all-reduces + 2 norms."""
+        tp = get_tp_group()
+        layers = list(self.layers.values())
+        t, h = positions.shape[0], self.cfg["hidden_size"]
+        if self.is_first:
+            part = self.embed_tokens(input_ids, reduce=False, staged=True)
+            rows = tp.custom_ar.shard_rows(t)[0] if sharded else t
+            # the residual starts at zero so that the embedding is reduced by the same fused kernel
+            res = torch.zeros((rows, h), dtype=part.dtype, device=part.device)
+            reduced = False
+        else:
+            part, res = intermediate.hidden, intermediate.residual
+            reduced = True                      # what crossed the stage boundary is already summed
+
+        def add_norm(x: torch.Tensor, norm) -> torch.Tensor:
+            nonlocal reduced, res
+            if reduced:
+                reduced = False
+                normed, res = norm(x, res)
+                return normed
+            return tp.all_reduce_add_rms_norm(x, res, norm.weight, norm.eps, sharded)
+
+        norm = layers[0].input_layernorm if layers else self.norm
+        for li, layer in enumerate(layers):
+            normed = add_norm(part, norm)
+            part = layer.self_attn(positions, normed, reduce=False, staged=True)
+            normed = add_norm(part, layer.post_attention_layernorm)
+            part = layer.mlp(normed, reduce=False, staged=True)
+            norm = layers[li + 1].input_layernorm if li + 1 < len(layers) else (self.norm if self.is_last else None)
+        if not self.is_last:
+            hidden = part if reduced else tp.all_reduce(part)
+            return IntermediateTensors(hidden, res)
+        return add_norm(part, self.norm)
 
     # ---------------------------------------------------- sequence parallel
     def sequence_parallel_ok(self, num_tokens: int) -> bool:

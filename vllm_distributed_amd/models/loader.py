@@ -296,7 +296,7 @@ def load_model(vllm_config: VllmConfig, device: torch.device) -> torch.nn.Module
 
     path = resolve_model_path(mc.model)
     if mc.load_format == "dummy" or path is None:
-        if mc.load_format not in ("dummy", "auto"):
+        if mc.load_format != "dummy":       # "auto" without weights was settled (or refused) by ModelConfig
             raise FileNotFoundError(f"no weights for {mc.model!r}")
         it: Iterable[Tuple[str, torch.Tensor]] = dummy_weights_iterator(mc, device, want)
         if mc.quantization == "awq-dequant":

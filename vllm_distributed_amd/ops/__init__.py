@@ -136,21 +136,31 @@ def argmax(logits):
     return logits.argmax(-1)
 
 
-def embedding(ids, weight, vocab_start=0, masked=False):
+def embedding(ids, weight, vocab_start=0, masked=False, out=None):
     if _use_hip(weight):
-        return _hip.embedding(ids, weight, vocab_start)
-    return torch_ref.embedding(ids, weight, vocab_start, masked)
+        return _hip.embedding(ids, weight, vocab_start, out)
+    res = torch_ref.embedding(ids, weight, vocab_start, masked)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
 
 
-def linear(x, weight, bias=None):
+def linear(x, weight, bias=None, out=None):
     """``x @ weight^T (+ bias)``: the library GEMM, except for short batches on
-    long-reduction shapes where the weight-streaming HIP kernel is faster."""
+    long-reduction shapes where the weight-streaming HIP kernel is faster.
+    ``out`` (2-D ``x`` only): write the result there (e.g. straight into the
+    buffer the following all-reduce reads)."""
     if (x.is_cuda and x.dim() == 2 and x.shape[0] <= 128
             and envs.VDAMD_SKINNY_GEMM and _use_hip(x)
             and _hip.skinny_profitable(x.shape[0], weight.shape[0], weight.shape[1])
             and _hip.skinny_supported(x, weight)):
-        y = _hip.skinny_gemm(x, weight)
-        return y if bias is None else y + bias
+        y = _hip.skinny_gemm(x, weight, out=out)
+        return y if bias is None else y.add_(bias)
+    if out is not None and x.dim() == 2:
+        if bias is None:
+            return torch.mm(x, weight.t(), out=out)
+        return torch.addmm(bias, x, weight.t(), out=out)
     return torch.nn.functional.linear(x, weight, bias)
 
 

@@ -145,7 +145,8 @@ def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
     return out.view(x.shape[:-1] + (f,))
 
 
-def embedding(ids: torch.Tensor, weight: torch.Tensor, vocab_start: int = 0) -> torch.Tensor:
+def embedding(ids: torch.Tensor, weight: torch.Tensor, vocab_start: int = 0,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
     if not _half(weight):
         from . import torch_ref
         return torch_ref.embedding(ids, weight, vocab_start, True)
@@ -153,7 +154,9 @@ def embedding(ids: torch.Tensor, weight: torch.Tensor, vocab_start: int = 0) -> 
     if ids.dtype != torch.int32:
         ids = ids.to(torch.int32)
     t, h = ids.shape[0], weight.shape[1]
-    out = torch.empty((t, h), dtype=weight.dtype, device=weight.device)
+    if out is None:
+        out = torch.empty((t, h), dtype=weight.dtype, device=weight.device)
+    assert out.shape == (t, h) and out.dtype == weight.dtype and out.is_contiguous()
     _check(_LIB.vdamd_embedding(out.data_ptr(), ids.data_ptr(), weight.data_ptr(), t, h, vocab_start,
                                 weight.shape[0], _dt(weight), _stream()), "embedding")
     return out
@@ -490,7 +493,7 @@ def skinny_profitable(m: int, n: int, k: int) -> bool:
 
 
 def skinny_gemm(x: torch.Tensor, w: torch.Tensor, ntw: Optional[int] = None, ksplit: Optional[int] = None,
-                ) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``x [M<=128, K] @ w [N, K]^T`` streaming ``w`` once at HBM speed."""
     assert skinny_supported(x, w), (x.shape, x.stride(), w.shape, w.stride(), x.dtype)
     m, k = x.shape
@@ -499,7 +502,9 @@ def skinny_gemm(x: torch.Tensor, w: torch.Tensor, ntw: Optional[int] = None, ksp
     ntw = a if ntw is None else ntw
     ksplit = b if ksplit is None else ksplit
     assert 1 <= ksplit <= k // 128
-    out = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    if out is None:
+        out = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    assert out.shape == (m, n) and out.dtype == x.dtype and out.is_contiguous() and out.data_ptr() % 16 == 0
     partial = torch.empty(ksplit * m * n, dtype=torch.float32, device=x.device) if ksplit > 1 else None
     _check(_LIB.vdamd_skinny_gemm(out.data_ptr(), n, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
                                   None if partial is None else partial.data_ptr(), m, n, k, ksplit, ntw,

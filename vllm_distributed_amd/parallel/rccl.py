@@ -65,8 +65,10 @@ def load_rccl() -> ctypes.CDLL:
     lib.ncclSend.argtypes = [P, Z, I, I, P, P]
     lib.ncclRecv.argtypes = [P, Z, I, I, P, P]
     lib.ncclCommDestroy.argtypes = [P]
+    lib.ncclCommAbort.argtypes = [P]
     for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllReduce", "ncclAllGather", "ncclReduceScatter",
-                 "ncclBroadcast", "ncclSend", "ncclRecv", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd"):
+                 "ncclBroadcast", "ncclSend", "ncclRecv", "ncclCommDestroy", "ncclCommAbort", "ncclGroupStart",
+                 "ncclGroupEnd"):
         getattr(lib, name).restype = I
     _lib = lib
     return lib
@@ -136,10 +138,43 @@ class RcclCommunicator:
         assert x.is_contiguous()
         _check(self.lib.ncclRecv(x.data_ptr(), x.numel(), _NCCL_DT[x.dtype], src, self.comm, self._stream()))
 
-    def close(self) -> None:
-        if getattr(self, "comm", None) is not None and self.comm.value:
+    def group_start(self) -> None:
+        """Open a group: the point-to-point calls up to ``group_end`` are issued as one operation
+        (a send and the matching receive of one rank cannot deadlock each other)."""
+        _check(self.lib.ncclGroupStart())
+
+    def group_end(self) -> None:
+        _check(self.lib.ncclGroupEnd())
+
+    def send_recv(self, send: Optional[torch.Tensor], dst: int, recv: Optional[torch.Tensor], src: int) -> None:
+        """One grouped exchange: ``send`` goes to rank ``dst`` while ``recv`` is filled from rank ``src``."""
+        self.group_start()
+        try:
+            if send is not None:
+                self.send(send, dst)
+            if recv is not None:
+                self.recv(recv, src)
+        finally:
+            self.group_end()
+
+    def close(self, timeout: float = 5.0) -> None:
+        """Free the communicator.  RCCL does not return from destroying (or aborting) a
+        communicator while a hipGraph that captured one of its calls is alive, and decode
+        graphs may well outlive it at shutdown: the call runs on a helper thread that is
+        abandoned after ``timeout`` seconds (process exit reclaims what it holds)."""
+        comm, self.comm = getattr(self, "comm", None), ctypes.c_void_p()
+        if comm is None or not comm.value:
+            return
+        import threading
+
+        def destroy() -> None:
             try:
-                self.lib.ncclCommDestroy(self.comm)
+                self.lib.ncclCommAbort(comm)
             except Exception:  # noqa: BLE001
                 pass
-            self.comm = ctypes.c_void_p()
+
+        t = threading.Thread(target=destroy, name="rccl-close", daemon=True)
+        t.start()
+        t.join(timeout)
+        if t.is_alive():
+            logger.warning("RCCL communicator still referenced by a captured graph: left to process exit")

@@ -207,6 +207,32 @@ class GroupCoordinator:
         self._td_all_reduce(x)
         return x
 
+    def fused_all_reduce_norm_ok(self, rows: int, hidden: int, dtype: torch.dtype) -> bool:
+        """Whether ``all_reduce_add_rms_norm`` takes a ``[rows, hidden]`` message (peer-mapped path)."""
+        car = self.custom_ar
+        return (car is not None and envs.VDAMD_FUSED_ALL_REDUCE_NORM and dtype in (torch.bfloat16, torch.float16)
+                and hidden % 8 == 0 and hidden <= 32768 and car.fits(rows * hidden * 2))
+
+    def all_reduce_add_rms_norm(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float,
+                                sharded_residual: bool) -> torch.Tensor:
+        """One kernel for all-reduce + residual add + RMSNorm (see ``CustomAllReduce``)."""
+        self._note("all_reduce_norm", x)
+        return self.custom_ar.all_reduce_add_rms_norm(x, residual, weight, eps, sharded_residual)
+
+    def stage_view(self, shape, dtype: torch.dtype) -> Optional[torch.Tensor]:
+        """Where the producer of the next all-reduce input should write (None: anywhere)."""
+        return None if self.custom_ar is None else self.custom_ar.stage_view(tuple(shape), dtype)
+
+    def end_step(self) -> None:
+        if self.custom_ar is not None:
+            self.custom_ar.end_step()
+
+    def graph_capturable(self) -> bool:
+        """Whether this group's collectives are plain stream enqueues a hipGraph capture can
+        record: the direct RCCL binding, or the peer-mapped kernels alone (then every message
+        of the captured step has to fit them)."""
+        return self.world_size == 1 or self.rccl is not None or self.custom_ar is not None
+
     def all_reduce_(self, x: torch.Tensor) -> torch.Tensor:
         """Strictly in-place sum on the current stream (RCCL / gloo only)."""
         if self.world_size == 1:
@@ -231,7 +257,9 @@ class GroupCoordinator:
         # RCCL and gloo produce), then moved to the requested dim
         flat = torch.empty((self.world_size * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype,
                            device=x.device)
-        if self.rccl is not None:
+        if self.custom_ar is not None and self.custom_ar.can_gather(x):
+            self.custom_ar.all_gather(x, out=flat)
+        elif self.rccl is not None:
             self.rccl.all_gather(flat, x)
         else:
             self._td_all_gather(flat, x)
@@ -248,7 +276,9 @@ class GroupCoordinator:
             out.copy_(x)
             return out
         self._note("all_gather", x)
-        if self.rccl is not None:
+        if self.custom_ar is not None and self.custom_ar.can_gather(x) and out.is_contiguous():
+            self.custom_ar.all_gather(x, out=out)
+        elif self.rccl is not None:
             self.rccl.all_gather(out, x)
         else:
             self._td_all_gather(out, x)

@@ -53,6 +53,14 @@ class SamplingParams:
             raise ValueError("max_tokens must be >= 1")
         if self.n < 1:
             raise ValueError("n must be >= 1")
+        if self.seed is not None:
+            # clients commonly send -1 for "no seed"; anything else must be usable as a generator seed
+            if isinstance(self.seed, bool) or not isinstance(self.seed, int):
+                raise ValueError("seed must be an integer")
+            if self.seed == -1:
+                self.seed = None
+            elif not 0 <= self.seed < 2 ** 63:
+                raise ValueError("seed must be in [0, 2**63) (or -1 / null for a random seed)")
         if self.repetition_penalty <= 0:
             raise ValueError("repetition_penalty must be > 0")
         if isinstance(self.stop, str):

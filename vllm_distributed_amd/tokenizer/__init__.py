@@ -62,8 +62,11 @@ class ByteTokenizer:
 
 def render_chat_template(template: str, messages, add_generation_prompt: bool = True,
                          tools=None, **extra) -> str:
-    import jinja2
-    env = jinja2.Environment(trim_blocks=True, lstrip_blocks=True)
+    # templates come from model repositories and (when the operator allows it) from requests:
+    # always rendered in the immutable sandbox, where attribute walks to Python internals,
+    # mutation of passed objects and unsafe callables raise SecurityError
+    from jinja2.sandbox import ImmutableSandboxedEnvironment
+    env = ImmutableSandboxedEnvironment(trim_blocks=True, lstrip_blocks=True)
     env.globals["raise_exception"] = lambda m: (_ for _ in ()).throw(ValueError(m))
     env.filters["tojson"] = lambda v, **k: json.dumps(v, ensure_ascii=False)
     return env.from_string(template).render(messages=messages, tools=tools,

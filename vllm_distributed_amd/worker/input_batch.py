@@ -110,7 +110,8 @@ class InputBatch:
             # independent of batch composition: seeded per request
             seed = sp.seed if sp.seed is not None else (
                 (self.base_seed * 1000003 + zlib.crc32(req_id.encode())) & 0x7FFFFFFF)
-            self.generators[row] = np.random.default_rng(seed)
+            # masked, so that no value a client manages to send can raise here, inside a worker step
+            self.generators[row] = np.random.default_rng(int(seed) & 0x7FFFFFFFFFFFFFFF)
         return row
 
     def remove_request(self, req_id: str) -> None:

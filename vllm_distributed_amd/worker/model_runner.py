@@ -251,6 +251,7 @@ class ModelRunner:
         if self.pp.is_last_rank:
             n = min(self.max_num_reqs, t)
             self.model.compute_logits(out[:n])
+        self.tp.end_step()
         if self.is_gpu:
             torch.cuda.synchronize()
 
@@ -460,6 +461,7 @@ class ModelRunner:
                 host_tokens.copy_(tokens, non_blocking=True)
             else:
                 host_tokens = tokens
+        self.tp.end_step()                # sampling may have gathered over the TP group
         if marks is not None:
             marks.stamp("end")
             self._last_end_mark = marks.end
@@ -500,18 +502,22 @@ class ModelRunner:
             max_decode_seq_len=md.max_decode_seq_len, decode_workspace=md.decode_workspace)
 
     def _forward_decode(self, md: AttentionMetadata, input_ids: torch.Tensor, positions: torch.Tensor):
-        """Pure-decode forward on a single pipeline stage, overlapped when enabled."""
-        bounds = self._overlap_bounds(md.num_decodes)
-        if bounds is None:
-            set_forward_context(md, positions)
-            out = self.model(input_ids, positions, None)
-            set_forward_context(None)
-            return out
-        mds = [self._slice_decode_metadata(md, s, e) for s, e in bounds]
-        sp_ok = getattr(self.model, "sequence_parallel_ok", None)
-        if sp_ok is not None and sp_ok(md.num_decodes) and all(sp_ok(e - s) for s, e in bounds):
-            return self.model.forward_overlapped_sp(input_ids, positions, mds, bounds, self.comm_stream)
-        return self.model.forward_overlapped(input_ids, positions, mds, bounds, self.comm_stream)
+        """Pure-decode forward on a single pipeline stage, overlapped when enabled.  Leaves the TP
+        group's peer-mapped buffers at parity 0, so a capture of this call can be replayed anywhere."""
+        try:
+            bounds = self._overlap_bounds(md.num_decodes)
+            if bounds is None:
+                set_forward_context(md, positions)
+                out = self.model(input_ids, positions, None)
+                set_forward_context(None)
+                return out
+            mds = [self._slice_decode_metadata(md, s, e) for s, e in bounds]
+            sp_ok = getattr(self.model, "sequence_parallel_ok", None)
+            if sp_ok is not None and sp_ok(md.num_decodes) and all(sp_ok(e - s) for s, e in bounds):
+                return self.model.forward_overlapped_sp(input_ids, positions, mds, bounds, self.comm_stream)
+            return self.model.forward_overlapped(input_ids, positions, mds, bounds, self.comm_stream)
+        finally:
+            self.tp.end_step()
 
     def _is_output_rank(self) -> bool:
         return self.pp.is_last_rank and (self.tp.rank_in_group == 0 or self.report_on_all_ranks)
@@ -527,6 +533,7 @@ class ModelRunner:
         set_forward_context(md, positions)
         out = self.model(input_ids, positions, inter)
         set_forward_context(None)
+        self.tp.end_step()
         if not self.pp.is_last_rank:
             self._send_intermediate(out)
             return None
@@ -800,11 +807,12 @@ class ModelRunner:
             logger.info("hipGraph decode capture needs the HIP attention kernels (head_dim 64 or 128): "
                         "running eagerly")
             return
-        if self.tp.world_size > 1 and self.tp.rccl is None and self.tp.device_group is not None:
-            # torch.distributed collectives keep host-side work objects; only the
-            # direct RCCL binding is a pure stream enqueue that a capture can record
-            self.graph_fallback_reason = "no direct RCCL communicator (torch.distributed collectives cannot be captured)"
-            logger.info("hipGraph decode capture needs the direct RCCL communicator: running eagerly")
+        if self.tp.world_size > 1 and self.tp.device_group is not None and not self.tp.graph_capturable():
+            # torch.distributed collectives keep host-side work objects; the direct RCCL binding
+            # and the peer-mapped kernels are pure stream enqueues that a capture can record
+            self.graph_fallback_reason = ("neither the direct RCCL communicator nor the peer-mapped collectives "
+                                          "are active (torch.distributed collectives cannot be captured)")
+            logger.info("hipGraph decode capture needs capturable TP collectives: running eagerly")
             return
         sizes = [s for s in cc.sizes(self.max_num_reqs) if s <= self.max_num_reqs]
         if not sizes:
