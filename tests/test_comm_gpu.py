@@ -352,8 +352,10 @@ def test_spmd_tensor_parallel_ranks_sharing_one_gpu_match_single_rank():
         got = _run_spmd_shared(2, async_sched, sp, logprobs=512, extra_env=extra)
         assert got[0]["tokens"] == got[1]["tokens"]
         assert got[0]["direct_ar"] and got[1]["direct_ar"]
-        if not extra.get("VDAMD_USE_HIP_GRAPH") == "0":
-            # the decode graph must really hold the step (peer-mapped collectives are capturable)
+        if extra.get("VDAMD_USE_HIP_GRAPH") != "0" and sp != "force":
+            # the decode graph must really hold the step (peer-mapped collectives are capturable;
+            # the host-staged gloo reduce-scatter of the forced sequence-parallel form is not, and
+            # that run exercises the fall-back to eager decode after a failed capture)
             assert got[0]["graphs"], got[0]["fallback"]
         _assert_distributions_close(ref["first_lp"], got[0]["first_lp"])
 

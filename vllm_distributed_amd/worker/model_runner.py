@@ -827,6 +827,7 @@ class ModelRunner:
                 self._capture_one(bs)
         except Exception as e:  # capture is an optimisation: fall back to eager
             error = e
+            logger.warning("hipGraph capture raised", exc_info=True)
             torch.cuda.synchronize()
         # every rank of the group takes the same decision: a rank replaying a graph and a
         # rank running eagerly would still issue the same collectives, but a communicator
