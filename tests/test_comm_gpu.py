@@ -409,6 +409,10 @@ def test_head_plus_remote_worker_sharing_one_gpu(monkeypatch, tp, pp):
         assert [a.node_id is None for a in eng.core.executor.assignments] == [True, False]
         got = generate(eng)
         _assert_distributions_close(ref, got)
+        # decode runs from captured graphs on every rank: per pipeline stage (the transfers stay
+        # outside the graph), and under TP with the peer-mapped collectives inside it
+        stats = eng.core.executor.collective_rpc("get_stats")
+        assert all(st["hip_graph_sizes"] for st in stats), [st["hip_graph_fallback"] for st in stats]
     finally:
         if eng is not None:
             eng.shutdown()

@@ -390,3 +390,67 @@ def test_registration_channel_needs_a_real_secret_off_loopback(monkeypatch):
     from vllm_distributed_amd.launch import remote_main
     with pytest.raises(RuntimeError, match="VLLM_RPC_SECRET"):
         remote_main("192.168.2.145", num_devices=1)
+
+
+@pytest.mark.slow
+def test_tp2_x_pp2_head_plus_three_remote_workers_two_batches_in_flight_then_a_kill(monkeypatch):
+    """The reference's documented deployment shape (`-tp 2 -pp 2`): the head's own device plus a
+    three-device worker node, real model, gloo.  Two micro-batches are in flight (one per stage),
+    tokens match a single process; then a worker of the second stage dies mid-run and the head
+    fails fast."""
+    ref = _reference("llama-tiny")
+    port = get_open_port()
+    for k, v in _env(port, VLLM_HEAD_LOCAL_DEVICES="1").items():
+        monkeypatch.setenv(k, v)
+    common = dict(model="llama-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,
+                  num_gpu_blocks_override=64, max_num_seqs=2, tensor_parallel_size=2, pipeline_parallel_size=2,
+                  distributed_executor_backend="distributed")
+
+    def run(eng, watch):
+        sp = SamplingParams(temperature=0.0, max_tokens=10, ignore_eos=True)
+        ids = [eng.add_request(None, p, sp) for p in PROMPTS + [[11, 12, 13, 14]]]
+        final = {}
+        while eng.has_unfinished_requests():
+            outs = eng.step()
+            watch.append(len(eng.core.batch_queue))
+            for o in outs:
+                if o.finished:
+                    final[o.request_id] = o.outputs[0].token_ids
+        return [final[i] for i in ids]
+
+    remote = _start_remote(port, 3, 1)
+    eng = None
+    try:
+        eng = LLMEngine.from_engine_args(EngineArgs(**common))
+        ex = eng.core.executor
+        assert ex.max_concurrent_batches == 2 and ex.output_rank == 2
+        assert sorted(a.node_id is None for a in ex.assignments) == [False, False, False, True]
+        depth = []
+        got = run(eng, depth)
+        assert got[:3] == ref                       # the first three prompts are the reference's
+        assert max(depth) >= 1 and eng.core.max_concurrent == 2
+    finally:
+        if eng is not None:
+            eng.shutdown()
+        remote.terminate()
+        remote.wait(timeout=10)
+
+    # same shape, rank 3 (second stage) exits at its 5th step
+    port = get_open_port()
+    for k, v in _env(port, VLLM_HEAD_LOCAL_DEVICES="1").items():
+        monkeypatch.setenv(k, v)
+    remote = _start_remote(port, 3, 1, VDAMD_FAULT_DIE_AT="3:5")
+    eng = None
+    try:
+        eng = LLMEngine.from_engine_args(EngineArgs(**common))
+        with pytest.raises(Exception):
+            run(eng, [])
+        deadline = time.time() + 10
+        while not eng.core.executor.is_failed and time.time() < deadline:
+            time.sleep(0.05)
+        assert eng.core.executor.is_failed
+    finally:
+        if eng is not None:
+            eng.shutdown()
+        remote.terminate()
+        remote.wait(timeout=10)

@@ -222,6 +222,10 @@ class ModelRunner:
         if (self.is_gpu and self.pp.world_size == 1 and hasattr(self.model, "forward_overlapped")
                 and (mode == "force" or (mode == "auto" and self.tp.world_size > 1))):
             self.comm_stream = torch.cuda.Stream(priority=-1)
+        self.pp_link = None
+        if self.pp.world_size > 1:
+            from ..parallel.pipeline import PipelineLink
+            self.pp_link = PipelineLink(self.pp, self.device, use_rccl=envs.VDAMD_COMM_BACKEND in ("auto", "rccl"))
         if self.vllm_config.lora_config is not None:
             from ..lora import LoRAManager
             self.lora_manager = LoRAManager(self.model, self.vllm_config.lora_config,
@@ -539,19 +543,27 @@ class ModelRunner:
             return None
         return out
 
-    def _recv_intermediate(self, total: int) -> IntermediateTensors:
+    def _recv_intermediate(self, total: int, static: bool = False) -> IntermediateTensors:
+        """``(hidden, residual)`` of the previous stage for ``total`` tokens: one message, received
+        on the pipeline link's own stream.  ``static``: into the buffers a captured graph reads."""
         h = self.model_config.hidden_size
         dtype = self.model_config.torch_dtype
-        hidden = self.pp.recv((total, h), dtype)
-        residual = None
-        if self._pp_sends_residual():
-            residual = self.pp.recv((total, h), dtype)
+        want_res = self._pp_sends_residual()
+        if static:
+            hidden = self._static["pp_hidden"][:total]
+            residual = self._static["pp_residual"][:total] if want_res else None
+        else:
+            hidden = torch.empty((total, h), dtype=dtype, device=self.device)
+            residual = torch.empty((total, h), dtype=dtype, device=self.device) if want_res else None
+        self.pp_link.recv(hidden, residual)
         return IntermediateTensors(hidden, residual)
 
-    def _send_intermediate(self, out: IntermediateTensors) -> None:
-        self.pp.send(out.hidden)
-        if self._pp_sends_residual():
-            self.pp.send(out.residual)
+    def _send_intermediate(self, out: IntermediateTensors, total: Optional[int] = None) -> None:
+        hidden, residual = out.hidden, out.residual if self._pp_sends_residual() else None
+        if total is not None:                  # a padded graph batch: only the real rows travel
+            hidden = hidden[:total]
+            residual = residual[:total] if residual is not None else None
+        self.pp_link.send(hidden.contiguous(), None if residual is None else residual.contiguous())
 
     def _pp_sends_residual(self) -> bool:
         return self.model_config.architecture != "OPTForCausalLM"
@@ -798,10 +810,6 @@ class ModelRunner:
         if not (cc.use_hip_graph and envs.VDAMD_USE_HIP_GRAPH):
             self.graph_fallback_reason = "disabled (enforce_eager / VDAMD_USE_HIP_GRAPH=0)"
             return
-        if self.pp.world_size > 1:
-            self.graph_fallback_reason = "pipeline parallelism: stages run eagerly"
-            logger.info("hipGraph decode capture is disabled with pipeline parallelism")
-            return
         if not ops.hip_supports_head_dim(self.model_config.head_dim):
             self.graph_fallback_reason = f"no HIP attention kernel for head_dim {self.model_config.head_dim}"
             logger.info("hipGraph decode capture needs the HIP attention kernels (head_dim 64 or 128): "
@@ -820,6 +828,10 @@ class ModelRunner:
             return
         t0 = time.time()
         self._alloc_static(max(sizes))
+        if not self.pp.is_first_rank:         # what the previous stage sends lands here, in front of the graph
+            h, dt = self.model_config.hidden_size, self.model_config.torch_dtype
+            self._static["pp_hidden"] = torch.zeros(max(sizes), h, dtype=dt, device=self.device)
+            self._static["pp_residual"] = torch.zeros(max(sizes), h, dtype=dt, device=self.device)
         self._ensure_decode_workspace(max(sizes))
         error: Optional[BaseException] = None
         try:
@@ -857,16 +869,37 @@ class ModelRunner:
                                         attn.num_kv_heads, self.max_model_len)
         self.decode_workspace = torch.empty(n, dtype=torch.float32, device=self.device)
 
+    def _forward_stage(self, md: AttentionMetadata, input_ids: torch.Tensor, positions: torch.Tensor,
+                       inter: Optional[IntermediateTensors]):
+        """This pipeline stage's layers on a decode batch (no transfers: those stay outside a capture)."""
+        try:
+            set_forward_context(md, positions)
+            out = self.model(input_ids, positions, inter)
+            set_forward_context(None)
+            return out
+        finally:
+            self.tp.end_step()
+
     def _capture_one(self, bs: int) -> None:
         s = self._static
         md = self._static_metadata(bs, self.max_model_len)
         ids, pos = s["input_ids"][:bs], s["positions"][:bs]
+        inter = None
+        if not self.pp.is_first_rank:
+            inter = IntermediateTensors(s["pp_hidden"][:bs],
+                                        s["pp_residual"][:bs] if self._pp_sends_residual() else None)
+        if self.pp.world_size > 1:
+            def run():
+                return self._forward_stage(md, ids, pos, inter)
+        else:
+            def run():
+                return self._forward_decode(md, ids, pos)
         # warm up on a side stream (allocator + lazy init), then capture
         stream = torch.cuda.Stream()
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):
             for _ in range(2):
-                self._forward_decode(md, ids, pos)
+                run()
         torch.cuda.current_stream().wait_stream(stream)
         torch.cuda.synchronize()
         g = DecodeGraph(bs)
@@ -874,7 +907,7 @@ class ModelRunner:
         # thread_local: API calls on other threads (RCCL watchdog, HTTP loop) must not
         # invalidate this capture
         with torch.cuda.graph(g.graph, pool=self.graph_pool, capture_error_mode="thread_local"):
-            g.output = self._forward_decode(md, ids, pos)
+            g.output = run()
         set_forward_context(None)
         if self.graph_pool is None:
             self.graph_pool = g.graph.pool()
@@ -898,6 +931,16 @@ class ModelRunner:
             s[k][:bs].copy_(st[k][:bs], non_blocking=True)
         s["block_table"][:n, :mb].copy_(st["block_table"][:n, :mb], non_blocking=True)
         self._patch_unknown_inputs(s["input_ids"], p)
+        if self.pp_link is not None:
+            # the stage's layers are the graph; the transfers around it run on the link's streams
+            if not self.pp.is_first_rank:
+                self._recv_intermediate(n, static=True)
+            self.pp_link.wait_send()           # the previous batch's transfer has read the output buffers
+            g.graph.replay()
+            if not self.pp.is_last_rank:
+                self._send_intermediate(g.output, n)
+                return None
+            return g.output
         g.graph.replay()
         return g.output
 
