@@ -454,3 +454,34 @@ def test_tp2_x_pp2_head_plus_three_remote_workers_two_batches_in_flight_then_a_k
             eng.shutdown()
         remote.terminate()
         remote.wait(timeout=10)
+
+
+@pytest.mark.slow
+def test_kv_connector_reports_are_aggregated_over_tp_ranks(monkeypatch, tmp_path):
+    """TP=2 through the distributed executor with the shared-storage KV connector: both ranks
+    write / read their halves of the KV heads, the executor counts a transfer as finished when
+    both have reported, and a second engine generates from the stored prefill."""
+    ref = _reference("llama-tiny")
+    kv = {"kv_connector": "SharedStorageConnector", "kv_role": "kv_both",
+          "kv_connector_extra_config": {"shared_storage_path": str(tmp_path)}}
+    outs = []
+    for _ in range(2):
+        port = get_open_port()
+        for k, v in _env(port, VLLM_HEAD_LOCAL_DEVICES="2").items():
+            monkeypatch.setenv(k, v)
+        eng = LLMEngine.from_engine_args(EngineArgs(
+            model="llama-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,
+            num_gpu_blocks_override=64, max_num_seqs=8, tensor_parallel_size=2,
+            distributed_executor_backend="distributed", kv_transfer_config=kv, enable_prefix_caching=False))
+        try:
+            assert eng.core.executor.has_connector
+            outs.append((_generate(eng), eng.core.scheduler.kv_connector))
+            assert not outs[-1][1].sending and not outs[-1][1].held_until_sent
+        finally:
+            eng.shutdown()
+    (first, c1), (second, c2) = outs
+    assert first == ref and second == ref
+    assert c1.num_saved_requests == 1 and c1.num_loaded_tokens == 0      # only the 50-token prompt spans whole blocks
+    assert c2.num_saved_requests == 0 and c2.num_loaded_tokens == 48
+    assert sorted(os.listdir(os.path.join(str(tmp_path), os.listdir(str(tmp_path))[0]))) == [
+        "meta.json", "rank0.safetensors", "rank1.safetensors"]

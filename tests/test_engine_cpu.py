@@ -161,3 +161,50 @@ def test_async_scheduling_with_preemption_and_chunked_prefill():
     got, _ = _run_tokens(prompts, sp, num_gpu_blocks_override=11, async_scheduling=True,
                          max_num_batched_tokens=24)
     assert got == ref
+
+
+def test_shared_storage_kv_connector_moves_prefill_between_engines(tmp_path):
+    """Disaggregated prefill: a producer engine prefills and writes each prompt's KV blocks to
+    shared storage, a consumer engine loads them instead of computing them, and generates what
+    an engine that computed everything itself generates.  The producer frees a finished
+    request's blocks only once its save has been confirmed."""
+    from vllm_distributed_amd import SamplingParams
+    from vllm_distributed_amd.engine.arg_utils import EngineArgs
+    from vllm_distributed_amd.engine.llm_engine import LLMEngine
+    from vllm_distributed_amd.parallel import state as pstate
+    prompts = [list(range(3, 3 + 70)), [9, 8, 7] * 15, [4, 5]]           # 4, 2 and 0 whole blocks to hand over
+
+    def make(role):
+        pstate.destroy_model_parallel()
+        kv = None if role is None else {"kv_connector": "SharedStorageConnector", "kv_role": role,
+                                        "kv_connector_extra_config": {"shared_storage_path": str(tmp_path)}}
+        return LLMEngine.from_engine_args(EngineArgs(
+            model="llama-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,
+            num_gpu_blocks_override=64, max_num_seqs=8, kv_transfer_config=kv, enable_prefix_caching=False))
+
+    def run(eng, max_tokens):
+        sp = SamplingParams(temperature=0.0, max_tokens=max_tokens, ignore_eos=True)
+        ids = [eng.add_request(None, p, sp) for p in prompts]
+        final = {}
+        while eng.has_unfinished_requests():
+            for o in eng.step():
+                if o.finished:
+                    final[o.request_id] = o.outputs[0].token_ids
+        return [final[i] for i in ids]
+
+    eng = make(None)
+    ref = run(eng, 6)
+    eng.shutdown()
+    prod = make("kv_producer")
+    first = run(prod, 1)                                   # prefill-only requests
+    conn = prod.core.scheduler.kv_connector
+    assert [t[0] for t in ref] == [t[0] for t in first]
+    assert conn.num_saved_requests == 2 and not conn.sending and not conn.held_until_sent
+    assert prod.core.scheduler.kv.pool.num_free_blocks == 64 - 0 or prod.core.scheduler.kv.usage == 0.0
+    prod.shutdown()
+    cons = make("kv_consumer")
+    got = run(cons, 6)
+    assert got == ref
+    assert cons.core.scheduler.kv_connector.num_loaded_tokens == 64 + 32
+    cons.shutdown()
+    pstate.destroy_model_parallel()

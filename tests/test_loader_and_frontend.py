@@ -350,3 +350,75 @@ def test_auto_load_format_refuses_a_checkpoint_that_is_not_there(tmp_path, monke
     assert ModelConfig(model="llama-3-70b").load_format == "dummy"
     with pytest.raises(FileNotFoundError):
         ModelConfig(model=str(tmp_path / "typo-in-the-path"))
+
+
+def test_lazy_tensor_reads_only_the_requested_slice(tmp_path):
+    import torch
+    from safetensors import safe_open
+    from safetensors.torch import save_file
+    from vllm_distributed_amd.models.utils import LazyTensor, materialize
+    w = torch.arange(24 * 10, dtype=torch.float32).reshape(24, 10).to(torch.bfloat16)
+    v = torch.arange(7, dtype=torch.int32)
+    save_file({"w": w, "v": v}, str(tmp_path / "m.safetensors"))
+    with safe_open(str(tmp_path / "m.safetensors"), framework="pt", device="cpu") as f:
+        lw = LazyTensor(f, "w")
+        assert lw.shape == w.shape and lw.dtype == torch.bfloat16 and lw.dim() == 2
+        part = lw.narrow(0, 6, 12).narrow(1, 2, 5).narrow(0, 3, 4)        # ranges compose
+        assert part.shape == (4, 5)
+        assert torch.equal(materialize(part), w[9:13, 2:7])
+        assert torch.equal(materialize(lw[4:9]), w[4:9])
+        assert torch.equal(lw.t(), w.t())                                  # anything else reads the whole tensor
+        assert torch.equal(materialize(LazyTensor(f, "v").narrow(0, 2, 3)), v[2:5])
+        with pytest.raises(IndexError):
+            lw.narrow(1, 8, 5)
+    assert materialize(w) is w
+
+
+@pytest.mark.slow
+def test_sharded_state_round_trip_tp2(tmp_path, monkeypatch):
+    """TP=2 workers load their slices of a safetensors checkpoint (slice reads), generate,
+    save their shards; a second engine started with --load-format sharded_state from that
+    directory produces the same tokens, and a different TP degree is refused."""
+    import os
+    from vllm_distributed_amd import SamplingParams
+    from vllm_distributed_amd.config import ModelConfig
+    from vllm_distributed_amd.engine.arg_utils import EngineArgs
+    from vllm_distributed_amd.engine.llm_engine import LLMEngine
+    from vllm_distributed_amd.models.loader import save_dummy_checkpoint
+    from vllm_distributed_amd.parallel import state as pstate
+    from vllm_distributed_amd.utils import get_open_port
+    ckpt, shards = str(tmp_path / "ckpt"), str(tmp_path / "shards")
+    save_dummy_checkpoint(ModelConfig(model="llama-tiny", dtype="float32", load_format="dummy"), ckpt)
+    for k, v in dict(VLLM_RPC_SECRET="s", VLLM_HOST_IP="127.0.0.1", GLOO_SOCKET_IFNAME="lo",
+                     VLLM_HEAD_LOCAL_DEVICES="2", OMP_NUM_THREADS="2").items():
+        monkeypatch.setenv(k, v)
+
+    def run(model, load_format, tp=2):
+        pstate.destroy_model_parallel()
+        monkeypatch.setenv("VLLM_SERVER_PORT", str(get_open_port()))
+        eng = LLMEngine.from_engine_args(EngineArgs(
+            model=model, device="cpu", dtype="float32", max_model_len=128, block_size=16, load_format=load_format,
+            num_gpu_blocks_override=64, max_num_seqs=8, tensor_parallel_size=tp,
+            distributed_executor_backend="distributed" if tp > 1 else "uni"))
+        try:
+            sp = SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True)
+            ids = [eng.add_request(None, p, sp) for p in ([5, 9, 200, 17], list(range(10, 40)))]
+            final = {}
+            while eng.has_unfinished_requests():
+                for o in eng.step():
+                    if o.finished:
+                        final[o.request_id] = o.outputs[0].token_ids
+            if load_format == "auto" and tp > 1:
+                eng.core.executor.save_sharded_state(shards)
+            return [final[i] for i in ids]
+        finally:
+            eng.shutdown()
+            pstate.destroy_model_parallel()
+
+    ref = run(ckpt, "auto", tp=1)
+    assert run(ckpt, "auto") == ref
+    assert sorted(os.listdir(shards)) == ["config.json", "model-rank-0.safetensors", "model-rank-1.safetensors",
+                                          "sharded_state.json"]
+    assert run(shards, "sharded_state") == ref
+    with pytest.raises(Exception):
+        run(shards, "sharded_state", tp=1)

@@ -181,7 +181,10 @@ class Scheduler:
                 continue
             self._add_cached(cached, req, new_blocks)
             num_scheduled[req.request_id] = n
+            before = req.num_computed_tokens
             req.num_computed_tokens += n
+            if self.kv_connector is not None and before < req.num_prompt_tokens <= req.num_computed_tokens:
+                self.kv_connector.note_prefill_scheduled(req, self.kv.get_block_ids(req.request_id))
             self._note_sampling(req)
             budget -= n
 
@@ -196,7 +199,12 @@ class Scheduler:
                 computed_blocks, num_cached = ([], 0)
                 if req.num_computed_tokens == 0:
                     computed_blocks, num_cached = self.kv.get_computed_blocks(req)
-                n = req.num_tokens - num_cached
+                # prompt KV another engine left in the shared storage: loaded by the workers into
+                # fresh blocks before this step runs, so it counts as computed like a cache hit
+                ext = 0
+                if self.kv_connector is not None and req.num_computed_tokens == 0:
+                    ext = self.kv_connector.get_num_new_matched_tokens(req, num_cached)
+                n = req.num_tokens - num_cached - ext
                 if not self.config.enable_chunked_prefill and n > budget:
                     break
                 n = min(n, budget)
@@ -204,9 +212,12 @@ class Scheduler:
                     n = min(n, self.config.long_prefill_token_threshold)
                 if n <= 0:
                     break
-                blocks = self.kv.allocate_slots(req, n, computed_blocks)
+                blocks = self.kv.allocate_slots(req, n + ext, computed_blocks)
                 if blocks is None:
                     break
+                if ext:
+                    self.kv_connector.note_load(req, num_cached, ext, self.kv.get_block_ids(req.request_id))
+                    num_cached += ext
                 self.waiting.popleft()
                 resumed = req.status == RequestStatus.PREEMPTED
                 req.status = RequestStatus.RUNNING
@@ -229,6 +240,8 @@ class Scheduler:
                 self._pending_new_tokens.pop(req.request_id, None)
                 num_scheduled[req.request_id] = n
                 req.num_computed_tokens += n
+                if self.kv_connector is not None and req.num_computed_tokens >= req.num_prompt_tokens:
+                    self.kv_connector.note_prefill_scheduled(req, self.kv.get_block_ids(req.request_id))
                 self._note_sampling(req)
                 budget -= n
 
@@ -304,6 +317,9 @@ class Scheduler:
         outputs: List[EngineCoreOutput] = []
         if runner_output is None:
             return outputs
+        if self.kv_connector is not None:
+            for held in self.kv_connector.update_from_output(runner_output):
+                self.kv.free(held)                 # its save has been confirmed by every rank
         lps = dict(zip(runner_output.req_ids, runner_output.logprobs)) if runner_output.logprobs else None
         now = time.time()
         requests = self.requests
@@ -410,7 +426,8 @@ class Scheduler:
             self._free_request(req)
 
     def _free_request(self, req: Request) -> None:
-        self.kv.free(req)
+        if self.kv_connector is None or not self.kv_connector.request_finished(req):
+            self.kv.free(req)                      # (a producer keeps the blocks while a save reads them)
         if req.request_id in self._known_to_workers:
             self._known_to_workers.discard(req.request_id)
             self._finished_since_last.add(req.request_id)

@@ -69,16 +69,171 @@ class KVOutputAggregator:
         return result
 
 
+def kv_prefix_key(token_ids: Sequence[int], num_tokens: int, salt: str = "") -> str:
+    """Name of the stored KV of the first ``num_tokens`` tokens of a prompt."""
+    import hashlib
+    h = hashlib.sha256(salt.encode())
+    h.update(b"|" + str(num_tokens).encode() + b"|")
+    h.update(",".join(str(int(t)) for t in token_ids[:num_tokens]).encode())
+    return h.hexdigest()[:40]
+
+
+def transferable_tokens(num_prompt_tokens: int, block_size: int) -> int:
+    """Whole blocks of a prompt that can be handed over: at least one prompt token stays
+    behind for the receiver to run, because a forward pass is what produces its first logits."""
+    return max(0, (num_prompt_tokens - 1) // block_size) * block_size
+
+
 class SchedulerKVConnector:
-    """Scheduler-side hook: attaches connector metadata to each step.  The
-    bundled connector is a no-op placeholder that keeps the aggregation path
-    exercised; real transports plug in by name."""
+    """Scheduler side of the shared-storage KV connector (disaggregated prefill / decode).
+
+    A *producer* engine writes the KV blocks of every prompt it has prefilled under
+    ``kv_connector_extra_config["shared_storage_path"]``; a *consumer* engine that meets the
+    same prompt finds them there, has its workers copy them into freshly allocated blocks and
+    schedules only the rest of the prompt.  The scheduler decides (storage lookups happen here,
+    once, not on every rank), the workers move bytes and report ``finished_sending`` /
+    ``finished_recving``, and the executor counts a transfer as done when every rank has
+    reported it (``KVOutputAggregator``).  A producer keeps a finished request's blocks until
+    its save has been confirmed."""
 
     def __init__(self, vllm_config: VllmConfig):
+        import os
         self.config = vllm_config.kv_transfer_config
+        extra = self.config.kv_connector_extra_config or {}
+        self.path = extra.get("shared_storage_path")
+        self.block_size = vllm_config.cache_config.block_size
+        self.produce = self.path is not None and self.config.kv_role in ("kv_producer", "kv_both")
+        self.consume = self.path is not None and self.config.kv_role in ("kv_consumer", "kv_both")
+        mc, pc = vllm_config.model_config, vllm_config.parallel_config
+        # KV of another model, dtype or sharding must never be mistaken for this engine's
+        self.salt = "|".join(str(x) for x in (mc.model, mc.dtype, vllm_config.cache_config.block_size,
+                                              pc.tensor_parallel_size, pc.pipeline_parallel_size,
+                                              getattr(vllm_config.cache_config, "cache_dtype", "auto")))
+        if self.path:
+            os.makedirs(self.path, exist_ok=True)
+        self._loads: List[dict] = []              # decided while scheduling, shipped with the step
+        self._saves: List[dict] = []
+        self.sending: Set[str] = set()            # saves asked for and not yet confirmed by every rank
+        self.held_until_sent: Dict[str, object] = {}
+        self.num_loaded_tokens = 0
+        self.num_saved_requests = 0
+
+    # -- consumer -----------------------------------------------------------------------
+    def get_num_new_matched_tokens(self, request, num_local_tokens: int) -> int:
+        """Prompt tokens beyond the ``num_local_tokens`` already in this engine's cache whose
+        KV can be loaded from storage."""
+        import os
+        if not self.consume:
+            return 0
+        n = transferable_tokens(request.num_prompt_tokens, self.block_size)
+        if n <= num_local_tokens:
+            return 0
+        key = kv_prefix_key(request.prompt_token_ids, n, self.salt)
+        if not os.path.isfile(os.path.join(self.path, key, "meta.json")):      # written last: the commit mark
+            return 0
+        return n - num_local_tokens
+
+    def note_load(self, request, first_token: int, num_tokens: int, block_ids: List[int]) -> None:
+        key = kv_prefix_key(request.prompt_token_ids, first_token + num_tokens, self.salt)
+        self._loads.append({"req_id": request.request_id, "key": key, "first_block": first_token // self.block_size,
+                            "num_blocks": num_tokens // self.block_size, "block_ids": list(block_ids)})
+        self.num_loaded_tokens += num_tokens
+
+    # -- producer -----------------------------------------------------------------------
+    def note_prefill_scheduled(self, request, block_ids: List[int]) -> None:
+        """Called when the step that computes the last prompt token has been scheduled."""
+        import os
+        if not self.produce or request.request_id in self.sending:
+            return
+        n = transferable_tokens(request.num_prompt_tokens, self.block_size)
+        if n == 0:
+            return
+        key = kv_prefix_key(request.prompt_token_ids, n, self.salt)
+        if os.path.isfile(os.path.join(self.path, key, "meta.json")):
+            return
+        self._saves.append({"req_id": request.request_id, "key": key, "num_blocks": n // self.block_size,
+                            "block_ids": list(block_ids[:n // self.block_size])})
+        self.sending.add(request.request_id)
+        self.num_saved_requests += 1
 
     def build_connector_meta(self, scheduler_output) -> dict:
-        return {"role": self.config.kv_role, "step": scheduler_output.step_id}
+        loads, self._loads = self._loads, []
+        saves, self._saves = self._saves, []
+        return {"role": self.config.kv_role, "step": scheduler_output.step_id, "path": self.path,
+                "load": loads, "save": saves}
+
+    def update_from_output(self, runner_output) -> List[object]:
+        """Fold the aggregated worker reports in; returns the requests whose blocks were being
+        held for a save and may be freed now."""
+        done = []
+        for rid in (getattr(runner_output, "finished_sending", None) or ()):
+            self.sending.discard(rid)
+            req = self.held_until_sent.pop(rid, None)
+            if req is not None:
+                done.append(req)
+        return done
+
+    def request_finished(self, request) -> bool:
+        """True: keep the request's blocks, a save still reads them."""
+        if request.request_id in self.sending:
+            self.held_until_sent[request.request_id] = request
+            return True
+        return False
+
+
+class WorkerKVConnector:
+    """Worker side: copies KV blocks between this rank's cache and the shared storage.
+
+    One file per (prompt prefix, rank): ``<path>/<key>/rank<r>.safetensors`` with ``k.<i>`` /
+    ``v.<i>`` = the blocks of the rank's i-th attention layer in cache layout.  ``meta.json``
+    appears once every rank's file is in place (the last writer renames it in)."""
+
+    def __init__(self, vllm_config: VllmConfig, rank: int, world_size: int):
+        self.rank, self.world_size = rank, world_size
+
+    def load(self, meta: dict, kv_caches) -> Set[str]:
+        import os
+
+        import torch
+        from safetensors import safe_open
+        done: Set[str] = set()
+        for op in meta.get("load", ()):
+            fn = os.path.join(meta["path"], op["key"], f"rank{self.rank}.safetensors")
+            fb, nb = op["first_block"], op["num_blocks"]
+            dst = torch.as_tensor(op["block_ids"][fb:fb + nb], dtype=torch.int64, device=kv_caches[0][0].device)
+            with safe_open(fn, framework="pt", device="cpu") as f:
+                for i, (k, v) in enumerate(kv_caches):
+                    k.index_copy_(0, dst, f.get_slice(f"k.{i}")[fb:fb + nb].to(k.device))
+                    v.index_copy_(0, dst, f.get_slice(f"v.{i}")[fb:fb + nb].to(v.device))
+            done.add(op["req_id"])
+        return done
+
+    def save(self, meta: dict, kv_caches) -> Set[str]:
+        import json
+        import os
+
+        import torch
+        from safetensors.torch import save_file
+        done: Set[str] = set()
+        for op in meta.get("save", ()):
+            d = os.path.join(meta["path"], op["key"])
+            os.makedirs(d, exist_ok=True)
+            src = torch.as_tensor(op["block_ids"], dtype=torch.int64, device=kv_caches[0][0].device)
+            tensors = {}
+            for i, (k, v) in enumerate(kv_caches):
+                tensors[f"k.{i}"] = k.index_select(0, src).cpu().contiguous()
+                tensors[f"v.{i}"] = v.index_select(0, src).cpu().contiguous()
+            tmp = os.path.join(d, f".rank{self.rank}.tmp")
+            save_file(tensors, tmp)
+            os.replace(tmp, os.path.join(d, f"rank{self.rank}.safetensors"))
+            have = [f for f in os.listdir(d) if f.startswith("rank") and f.endswith(".safetensors")]
+            if len(have) == self.world_size:           # every rank's part is there: commit
+                tmpm = os.path.join(d, f".meta.{self.rank}.tmp")
+                with open(tmpm, "w") as f:
+                    json.dump({"num_blocks": op["num_blocks"], "world_size": self.world_size}, f)
+                os.replace(tmpm, os.path.join(d, "meta.json"))
+            done.add(op["req_id"])
+        return done
 
 
 def make_scheduler_connector(vllm_config: VllmConfig) -> SchedulerKVConnector:

@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
+from ..utils import materialize
 from ...parallel.state import (get_tp_group, get_tensor_model_parallel_rank,
                                get_tensor_model_parallel_world_size,
                                tensor_model_parallel_all_gather,
@@ -82,7 +83,7 @@ def _scalar_param(n: int) -> nn.Parameter:
 
 
 def _fill_scalar(dst: torch.Tensor, w: torch.Tensor) -> None:
-    dst.copy_(w.reshape(-1)[:1].to(torch.float32).expand(dst.shape))
+    dst.copy_(materialize(w).reshape(-1)[:1].to(torch.float32).expand(dst.shape))
 
 
 def nvfp4_rename(name: str, w: torch.Tensor) -> Optional[Tuple[str, torch.Tensor]]:
@@ -257,7 +258,7 @@ class ReplicatedLinear(_LinearBase):
         if getattr(param, "per_shard_scalar", False):
             return _fill_scalar(param.data, w)
         assert param.shape == w.shape, (param.shape, w.shape)
-        param.data.copy_(w)
+        param.data.copy_(materialize(w))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self._matmul(x, self.bias)
@@ -296,7 +297,7 @@ class ColumnParallelLinear(_LinearBase):
         size = self.shard_sizes[shard_id] // pack
         dst_off = sum(self.shard_sizes[:shard_id]) // pack
         src = w.narrow(od, self.tp_rank * size, size)
-        param.data.narrow(od, dst_off, size).copy_(src)
+        param.data.narrow(od, dst_off, size).copy_(materialize(src))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         y = self._matmul(x, self.bias)
@@ -349,7 +350,7 @@ class QKVParallelLinear(_LinearBase):
             dst = self.q_size + (0 if shard_id == "k" else self.kv_size)
             src_idx = self.tp_rank // self.kv_replicas
         size, dst = size // pack, dst // pack
-        param.data.narrow(od, dst, size).copy_(w.narrow(od, src_idx * size, size))
+        param.data.narrow(od, dst, size).copy_(materialize(w.narrow(od, src_idx * size, size)))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self._matmul(x, self.bias)
@@ -370,7 +371,7 @@ class RowParallelLinear(_LinearBase):
             return _fill_scalar(param.data, w)
         od, _, in_div = _meta(param)
         n = self.in_local // in_div
-        param.data.copy_(w.narrow(1 - od, self.tp_rank * n, n))
+        param.data.copy_(materialize(w.narrow(1 - od, self.tp_rank * n, n)))
 
     def forward(self, x: torch.Tensor, reduce: bool = True, staged: bool = False) -> torch.Tensor:
         """``reduce=False`` returns this rank's partial sums; the caller owns the
@@ -409,7 +410,7 @@ class VocabParallelEmbedding(nn.Module):
         end = min(start + self.rows, w.shape[0])
         n = max(0, end - start)
         if n > 0:
-            param.data[:n].copy_(w[start:end])
+            param.data[:n].copy_(materialize(w[start:end]))
         if n < self.rows:
             param.data[n:].zero_()
 

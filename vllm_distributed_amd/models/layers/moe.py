@@ -16,6 +16,8 @@ from typing import Optional
 
 import torch
 import torch.nn as nn
+
+from ..utils import materialize
 import torch.nn.functional as F
 
 from ... import envs, ops
@@ -101,7 +103,7 @@ class FusedMoE(nn.Module):
             return _fill_scalar(param.data[e].narrow(0, which * n, n), w)
         if not self.expert_parallel:
             w = w.narrow(od, self.tp_rank * n, n)
-        param.data[e].narrow(od, which * n, n).copy_(w)
+        param.data[e].narrow(od, which * n, n).copy_(materialize(w))
 
     def _load_w2(self, param: nn.Parameter, w: torch.Tensor, shard_id) -> None:
         expert_id, _ = shard_id
@@ -113,7 +115,7 @@ class FusedMoE(nn.Module):
         if not self.expert_parallel:
             n = self.inter_local // param.in_div
             w = w.narrow(1 - param.out_dim, self.tp_rank * n, n)
-        param.data[e].copy_(w)
+        param.data[e].copy_(materialize(w))
 
     def finalize_weights(self) -> None:
         """Repack the experts' AWQ shards into the 4-bit kernel layout (or

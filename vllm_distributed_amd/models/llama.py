@@ -19,7 +19,7 @@ from ..parallel.state import get_pp_group, get_tp_group
 from .layers.attention import Attention, RMSNorm, get_forward_context
 from .layers.linear import (ColumnParallelLinear, ParallelLMHead, QKVParallelLinear, QuantSpec,
                             RowParallelLinear, VocabParallelEmbedding, nvfp4_rename, quantized_linears)
-from .utils import IntermediateTensors, get_pp_layer_range
+from .utils import IntermediateTensors, get_pp_layer_range, materialize
 
 
 class LlamaMLP(nn.Module):
@@ -434,7 +434,7 @@ class LlamaForCausalLM(nn.Module):
                 continue             # e.g. lm_head on a non-last stage
             loader = getattr(p, "weight_loader", None)
             if loader is None:
-                p.data.copy_(w)
+                p.data.copy_(materialize(w))
             else:
                 loader(p, w, shard)
             loaded.append(name)

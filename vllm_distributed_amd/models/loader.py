@@ -31,6 +31,7 @@ import torch
 from ..config import ModelConfig, VllmConfig, resolve_model_path
 from ..logger import init_logger
 from .registry import get_model_class
+from .utils import LazyTensor
 
 logger = init_logger(__name__)
 
@@ -248,8 +249,10 @@ def safetensors_weights_iterator(path: str, dtype: torch.dtype,
             for k in keys:
                 if keep_quantized:
                     if want is None or want(k):
-                        t = f.get_tensor(k)
-                        yield k, (t.to(dtype) if k.endswith(".scales") else t)
+                        if k.endswith(".scales"):
+                            yield k, f.get_tensor(k).to(dtype)
+                        else:
+                            yield k, LazyTensor(f, k)
                     continue
                 if k.endswith((".qzeros", ".scales")):
                     continue
@@ -264,7 +267,9 @@ def safetensors_weights_iterator(path: str, dtype: torch.dtype,
                     continue
                 if want is not None and not want(k):
                     continue
-                yield k, f.get_tensor(k)
+                # not read yet: the weight loaders narrow it to this rank's shard first, and only
+                # that hyper-rectangle is then read from the file
+                yield k, LazyTensor(f, k)
 
 
 def _with_progress(items: Iterable, what: str, every: float = 20.0) -> Iterator:
@@ -295,6 +300,13 @@ def load_model(vllm_config: VllmConfig, device: torch.device) -> torch.nn.Module
         return mapped is not None and model._owns_layer(mapped)
 
     path = resolve_model_path(mc.model)
+    if mc.load_format == "sharded_state":
+        if path is None:
+            raise FileNotFoundError(f"no sharded state for {mc.model!r}")
+        from ..parallel.state import get_world_group
+        n = load_sharded_state(model, path, get_world_group().rank, vllm_config)
+        logger.info("loaded %d tensors of this rank's shard from %s", n, path)
+        return model
     if mc.load_format == "dummy" or path is None:
         if mc.load_format != "dummy":       # "auto" without weights was settled (or refused) by ModelConfig
             raise FileNotFoundError(f"no weights for {mc.model!r}")
@@ -323,3 +335,80 @@ def save_dummy_checkpoint(mc: ModelConfig, out_dir: str) -> None:
     save_file(tensors, os.path.join(out_dir, "model.safetensors"))
     with open(os.path.join(out_dir, "config.json"), "w") as f:
         json.dump(mc.hf_config, f)
+
+
+# ------------------------------------------------------------ sharded state
+SHARDED_STATE_PATTERN = "model-rank-{rank}.safetensors"
+SHARDED_STATE_META = "sharded_state.json"
+
+
+def save_sharded_state(model: torch.nn.Module, path: str, rank: int, vllm_config: VllmConfig,
+                       pattern: Optional[str] = None) -> str:
+    """Write this rank's tensors exactly as it holds them (already cut to its TP shard and PP
+    layer range, quantised layers already in kernel layout), so a later start with
+    ``--load-format sharded_state`` reads one file per rank and repacks nothing."""
+    from safetensors.torch import save_file
+    os.makedirs(path, exist_ok=True)
+    sd = {k: v.detach().to("cpu").contiguous() for k, v in model.state_dict().items()}
+    fn = os.path.join(path, (pattern or SHARDED_STATE_PATTERN).format(rank=rank))
+    save_file(sd, fn)
+    if rank == 0:
+        pc, mc = vllm_config.parallel_config, vllm_config.model_config
+        with open(os.path.join(path, SHARDED_STATE_META), "w") as f:
+            json.dump({"tensor_parallel_size": pc.tensor_parallel_size,
+                       "pipeline_parallel_size": pc.pipeline_parallel_size,
+                       "pp_layer_partition": pc.pp_layer_partition, "quantization": mc.quantization,
+                       "dtype": mc.dtype, "pattern": pattern or SHARDED_STATE_PATTERN}, f)
+        if not os.path.isfile(os.path.join(path, "config.json")):
+            with open(os.path.join(path, "config.json"), "w") as f:
+                json.dump(mc.hf_config, f)
+    return fn
+
+
+def load_sharded_state(model: torch.nn.Module, path: str, rank: int, vllm_config: VllmConfig) -> int:
+    """Inverse of ``save_sharded_state``: the layout the files were written for (TP / PP
+    degree, layer partition, quantisation) must be the layout of this start."""
+    from safetensors import safe_open
+    pattern = SHARDED_STATE_PATTERN
+    meta_fn = os.path.join(path, SHARDED_STATE_META)
+    if os.path.isfile(meta_fn):
+        with open(meta_fn) as f:
+            meta = json.load(f)
+        pc, mc = vllm_config.parallel_config, vllm_config.model_config
+        have = {"tensor_parallel_size": pc.tensor_parallel_size, "pipeline_parallel_size": pc.pipeline_parallel_size,
+                "pp_layer_partition": pc.pp_layer_partition, "quantization": mc.quantization}
+        for k, v in have.items():
+            if meta.get(k) != v:
+                raise ValueError(f"sharded state in {path} was saved with {k}={meta.get(k)!r}, "
+                                 f"this engine runs with {k}={v!r}")
+        pattern = meta.get("pattern", pattern)
+    fn = os.path.join(path, pattern.format(rank=rank))
+    if not os.path.isfile(fn):
+        raise FileNotFoundError(f"no shard file for rank {rank}: {fn}")
+    n = 0
+    with safe_open(fn, framework="pt", device="cpu") as f, torch.no_grad():
+        for name in f.keys():
+            t = f.get_tensor(name)
+            mod_name, _, attr = name.rpartition(".")
+            mod = model.get_submodule(mod_name) if mod_name else model
+            cur = getattr(mod, attr, None)
+            if isinstance(cur, torch.Tensor) and tuple(cur.shape) == tuple(t.shape) and cur.dtype == t.dtype:
+                cur.data.copy_(t)
+            else:
+                # tensors that only exist once weights are finalised (packed 4-bit tiles, fp8
+                # weights and their scales) take the place of the checkpoint-layout parameters
+                dev = next(model.parameters()).device
+                t = t.to(dev)
+                if attr in mod._buffers:
+                    mod._buffers[attr] = t
+                elif attr in mod._parameters:
+                    mod._parameters[attr] = torch.nn.Parameter(t, requires_grad=False)
+                else:
+                    raise KeyError(f"sharded state names {name}, which this model does not have")
+            n += 1
+    for mod in model.modules():            # checkpoint-layout leftovers of layers loaded in kernel layout
+        if getattr(mod, "qw", None) is not None:
+            for raw in ("qweight", "qzeros", "scales", "weight_packed", "weight_block_scale", "weight_alpha"):
+                if raw in mod._parameters:
+                    del mod._parameters[raw]
+    return n

@@ -13,7 +13,7 @@ from ..parallel.state import get_pp_group
 from .layers.attention import Attention, LayerNorm
 from .layers.linear import (ColumnParallelLinear, QKVParallelLinear, ReplicatedLinear,
                             RowParallelLinear, VocabParallelEmbedding)
-from .utils import IntermediateTensors, get_pp_layer_range
+from .utils import IntermediateTensors, get_pp_layer_range, materialize
 
 
 class OPTDecoderLayer(nn.Module):
@@ -148,7 +148,7 @@ class OPTForCausalLM(nn.Module):
                 continue
             loader = getattr(p, "weight_loader", None)
             if loader is None:
-                p.data.copy_(w)
+                p.data.copy_(materialize(w))
             else:
                 loader(p, w, shard)
             loaded.append(name)

@@ -44,27 +44,32 @@ class Qwen3MoeForCausalLM(LlamaForCausalLM):
 
     def load_weights(self, weights: Iterable[Tuple[str, torch.Tensor]]) -> List[str]:
         params: Dict[str, nn.Parameter] = dict(self.named_parameters())
-        rest, loaded = [], []
-        for name, w in weights:
-            mapped = self.map_weight_name(name)
-            m = self._expert_re.match(mapped) if mapped else None
-            if m is None:
-                rest.append((name, w))
-                continue
-            if not self._owns_layer(mapped):
-                continue
-            prefix, eid, proj, kind = m.group(1), int(m.group(2)), m.group(3), m.group(4)
-            if self.quant_method == "nvfp4":
-                renamed = nvfp4_rename("." + kind, w)
-                if renamed is None:
+        loaded: List[str] = []
+
+        def others():
+            """Expert tensors are placed as they stream by; everything else is handed on, still
+            unread, to the dense loader (tensors are only valid while their file is open)."""
+            for name, w in weights:
+                mapped = self.map_weight_name(name)
+                m = self._expert_re.match(mapped) if mapped else None
+                if m is None:
+                    yield name, w
                     continue
-                kind, w = renamed[0][1:], renamed[1]
-            suffix = "" if kind == "weight" else "_" + kind
-            if proj == "down_proj":
-                p = params[prefix + ".w2" + suffix]
-                p.weight_loader(p, w, (eid, 0))
-            else:
-                p = params[prefix + ".w13" + suffix]
-                p.weight_loader(p, w, (eid, 0 if proj == "gate_proj" else 1))
-            loaded.append(mapped)
-        return loaded + super().load_weights(rest)
+                if not self._owns_layer(mapped):
+                    continue
+                prefix, eid, proj, kind = m.group(1), int(m.group(2)), m.group(3), m.group(4)
+                if self.quant_method == "nvfp4":
+                    renamed = nvfp4_rename("." + kind, w)
+                    if renamed is None:
+                        continue
+                    kind, w = renamed[0][1:], renamed[1]
+                suffix = "" if kind == "weight" else "_" + kind
+                if proj == "down_proj":
+                    p = params[prefix + ".w2" + suffix]
+                    p.weight_loader(p, w, (eid, 0))
+                else:
+                    p = params[prefix + ".w13" + suffix]
+                    p.weight_loader(p, w, (eid, 0 if proj == "gate_proj" else 1))
+                loaded.append(mapped)
+        dense = super().load_weights(others())
+        return loaded + dense

@@ -82,7 +82,7 @@ class PendingSample:
     lazy_step_result = True       # executors call .get() / .wait() on results carrying this mark
     __slots__ = ("runner", "step_id", "req_ids", "nreq", "sel", "rows", "gens", "pos", "tokens",
                  "event", "logprobs", "timing", "marks", "_result", "prompt_logprobs", "_lock", "_toks",
-                 "_published")
+                 "_published", "kv_sent", "kv_recv")
 
     def __init__(self, runner: "ModelRunner", step_id: int, req_ids: List[str], sel: Optional[np.ndarray],
                  rows: Optional[np.ndarray], pos: Optional[np.ndarray], tokens: Optional[torch.Tensor],
@@ -93,6 +93,7 @@ class PendingSample:
         self.gens = runner.batch.row_gen[rows].copy() if rows is not None else None
         self.logprobs, self.timing, self.marks = logprobs, timing, marks
         self.prompt_logprobs = None
+        self.kv_sent = self.kv_recv = None
         self._result: Optional[ModelRunnerOutput] = None
         self._toks: Optional[np.ndarray] = None
         self._lock = threading.Lock()
@@ -125,7 +126,9 @@ class PendingSample:
                 timing.update(self.marks.resolve())
             self._result = ModelRunnerOutput(step_id=self.step_id, req_ids=self.req_ids,
                                              sampled_token_ids=out_tokens, logprobs=logprobs_out, timing=timing,
-                                             prompt_logprobs=self.prompt_logprobs)
+                                             prompt_logprobs=self.prompt_logprobs,
+                                             finished_sending=self.kv_sent or None,
+                                             finished_recving=self.kv_recv or None)
             return self._result
 
     def publish(self) -> None:
@@ -210,6 +213,13 @@ class ModelRunner:
         self._token_table = None          # vocabulary bytes for constrained decoding, built on first use
         self.defer_output = False        # set by in-process executors under async scheduling
         self.timing_enabled = vllm_config.observability_config.collect_step_timing
+        self.kv_connector = None
+        if vllm_config.kv_transfer_config is not None and \
+                (vllm_config.kv_transfer_config.kv_connector_extra_config or {}).get("shared_storage_path"):
+            from ..executor.kv_transfer import WorkerKVConnector
+            from ..parallel.state import get_world_group
+            w = get_world_group()
+            self.kv_connector = WorkerKVConnector(vllm_config, w.rank, w.world_size)
         CommTimer.configure()
 
     # ------------------------------------------------------------------ setup
@@ -400,6 +410,8 @@ class ModelRunner:
                     pend.publish()
             self._update_states(so)
             self.step_count += 1
+            kv_meta = so.kv_connector_metadata if self.kv_connector is not None else None
+            kv_recv = self.kv_connector.load(kv_meta, self.kv_caches) if kv_meta else None
             if so.total_num_scheduled_tokens == 0:
                 return ModelRunnerOutput(step_id=so.step_id) if self._is_output_rank() else None   # nothing to wait for
             p = self._prepare_inputs(so)
@@ -430,11 +442,17 @@ class ModelRunner:
 
         # advance computed-token counts (the scheduler did the same when it scheduled)
         self.batch.num_computed[p["rows"]] += p["n_sched"]
+        kv_sent = None
+        if kv_meta and kv_meta.get("save"):
+            kv_sent = self.kv_connector.save(kv_meta, self.kv_caches)     # this step wrote the last prompt blocks
 
         if not self.pp.is_last_rank:
             if marks is not None:
                 marks.stamp("end")
                 self._last_end_mark = marks.end
+            if kv_sent or kv_recv:                 # every rank's report is counted by the executor
+                return ModelRunnerOutput(step_id=so.step_id, finished_sending=kv_sent or None,
+                                         finished_recving=kv_recv or None)
             return None
         if marks is not None:
             marks.stamp("fwd")
@@ -481,11 +499,13 @@ class ModelRunner:
         pending = PendingSample(self, so.step_id, p["req_ids"], sel, rows_sel, pos_sel, host_tokens, event,
                                 logprobs_sel, timing, marks)
         pending.prompt_logprobs = prompt_lps
+        pending.kv_sent, pending.kv_recv = kv_sent, kv_recv
         self._pending.append(pending)
+        report_all = self.kv_connector is not None      # the executor aggregates transfer reports of all ranks
         if self.defer_output:
-            return pending if self._is_output_rank() else _Discard(pending)
+            return pending if (self._is_output_rank() or report_all) else _Discard(pending)
         out = pending.get()
-        return out if self._is_output_rank() else None
+        return out if (self._is_output_rank() or report_all) else None
 
     def _overlap_bounds(self, nreq: int):
         """Micro-batch row ranges for all-reduce/compute overlap, or None."""

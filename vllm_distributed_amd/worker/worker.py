@@ -217,10 +217,9 @@ class Worker:
 
     def save_sharded_state(self, path: str, pattern: Optional[str] = None,
                            max_size: Optional[int] = None) -> None:
-        from safetensors.torch import save_file
-        os.makedirs(path, exist_ok=True)
-        sd = {k: v.detach().to("cpu").contiguous() for k, v in self.model_runner.model.state_dict().items()}
-        save_file(sd, os.path.join(path, (pattern or "model-rank-{rank}.safetensors").format(rank=self.rank)))
+        """This rank's tensors as it holds them; ``--load-format sharded_state`` reads them back."""
+        from ..models.loader import save_sharded_state
+        save_sharded_state(self.model_runner.model, path, self.rank, self.vllm_config, pattern)
 
     # ------------------------------------------------------------------ LoRA
     def _lora(self):
