@@ -31,6 +31,38 @@ __device__ __forceinline__ typename Vec8<T>::type zero8() {
   return z;
 }
 
+// 8 OCP e4m3 bytes -> 8 elements of T (gfx950 packed convert, two elements per instruction).
+// The instruction's scale operand is only ever given 1.0 here: the per-head K scale is folded
+// into the softmax scale and the V scale into the output normalisation, which costs nothing
+// per element and does not depend on how the hardware rounds a general scale.
+template <typename T>
+__device__ __forceinline__ typename Vec8<T>::type fp8x8_to(uint2 w, float scale) {
+  union { uint32_t u[4]; typename Vec8<T>::type v; } r;
+  if constexpr (sizeof(T) == 2 && __is_same(T, bf16_t)) {
+    r.u[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.x, scale, false));
+    r.u[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.x, scale, true));
+    r.u[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.y, scale, false));
+    r.u[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.y, scale, true));
+  } else {
+    r.u[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.x, scale, false));
+    r.u[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.x, scale, true));
+    r.u[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.y, scale, false));
+    r.u[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.y, scale, true));
+  }
+  return r.v;
+}
+
+// 8 consecutive cache elements starting at element offset `off`: 16 bytes of T, or 8 bytes
+// of e4m3 widened to T (KV8: the cache holds one byte per element, same layouts).
+template <typename T, bool KV8>
+__device__ __forceinline__ typename Vec8<T>::type ld_kv(const void* cache, long off, float scale) {
+  if constexpr (KV8) {
+    return fp8x8_to<T>(*reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(cache) + off), scale);
+  } else {
+    return ld8<T>(reinterpret_cast<const T*>(cache) + off);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // One 32-key group for NQ query sub-tiles of 16 rows each.
 //   qf[n][s]   : Q^T B-operand fragments (s = k-step over D)
@@ -43,10 +75,11 @@ struct KVFrag {
   typename Vec8<T>::type kfa[D / 32], kfb[D / 32], vf[D / 16];
 };
 
-template <typename T, int D>
-__device__ __forceinline__ void load_kv_group(KVFrag<T, D>& f, const T* __restrict__ k_cache,
-                                              const T* __restrict__ v_cache, const int* __restrict__ bt_row,
-                                              int kvh, int Hkv, int block_size, int base, int seq_len) {
+template <typename T, int D, bool KV8>
+__device__ __forceinline__ void load_kv_group(KVFrag<T, D>& f, const void* __restrict__ k_cache,
+                                              const void* __restrict__ v_cache, const int* __restrict__ bt_row,
+                                              int kvh, int Hkv, int block_size, int base, int seq_len,
+                                              float k_scale, float v_scale) {
   const int lane = threadIdx.x & 63;
   const int r16 = lane & 15, g4 = lane >> 4;
   // ---- K rows for the two interleaved tiles
@@ -54,16 +87,19 @@ __device__ __forceinline__ void load_kv_group(KVFrag<T, D>& f, const T* __restri
   const int ka = min(key0, seq_len - 1);
   const int kb = min(key0 + 4, seq_len - 1);
   const long blk_a = bt_row[ka / block_size], blk_b = bt_row[kb / block_size];
-  const T* ka_ptr = k_cache + ((blk_a * Hkv + kvh) * block_size + (ka % block_size)) * (long)D + 8 * g4;
-  const T* kb_ptr = k_cache + ((blk_b * Hkv + kvh) * block_size + (kb % block_size)) * (long)D + 8 * g4;
+  const long ka_off = ((blk_a * Hkv + kvh) * block_size + (ka % block_size)) * (long)D + 8 * g4;
+  const long kb_off = ((blk_b * Hkv + kvh) * block_size + (kb % block_size)) * (long)D + 8 * g4;
 #pragma unroll
-  for (int s = 0; s < D / 32; ++s) { f.kfa[s] = ld8<T>(ka_ptr + 32 * s); f.kfb[s] = ld8<T>(kb_ptr + 32 * s); }
+  for (int s = 0; s < D / 32; ++s) {
+    f.kfa[s] = ld_kv<T, KV8>(k_cache, ka_off + 32 * s, k_scale);
+    f.kfb[s] = ld_kv<T, KV8>(k_cache, kb_off + 32 * s, k_scale);
+  }
   // ---- V^T rows: this lane's 8 keys are base + 8*g4 .. +7 (one block: block_size % 8 == 0)
   const int vkey = min(base + 8 * g4, seq_len - 1) & ~7;
   const long blk_v = bt_row[vkey / block_size];
-  const T* v_ptr = v_cache + ((blk_v * Hkv + kvh) * (long)D + r16) * block_size + (vkey % block_size);
+  const long v_off = ((blk_v * Hkv + kvh) * (long)D + r16) * block_size + (vkey % block_size);
 #pragma unroll
-  for (int dt = 0; dt < D / 16; ++dt) f.vf[dt] = ld8<T>(v_ptr + (long)(16 * dt) * block_size);
+  for (int dt = 0; dt < D / 16; ++dt) f.vf[dt] = ld_kv<T, KV8>(v_cache, v_off + (long)(16 * dt) * block_size, v_scale);
 }
 
 template <typename T, int D, int NQ>
@@ -113,13 +149,14 @@ __device__ __forceinline__ void attend_loaded(
   }
 }
 
-template <typename T, int D, int NQ>
+template <typename T, int D, int NQ, bool KV8>
 __device__ __forceinline__ void attend_group(
-    const T* __restrict__ k_cache, const T* __restrict__ v_cache, const int* __restrict__ bt_row, int kvh, int Hkv,
-    int block_size, int base, int seq_len, float scale_log2e, const typename Vec8<T>::type (&qf)[NQ][D / 32],
-    f32x4 (&acc)[NQ][D / 16], float (&m)[NQ], float (&l)[NQ], const int (&qpos_hi)[NQ]) {
+    const void* __restrict__ k_cache, const void* __restrict__ v_cache, const int* __restrict__ bt_row, int kvh,
+    int Hkv, int block_size, int base, int seq_len, float scale_log2e,
+    const typename Vec8<T>::type (&qf)[NQ][D / 32], f32x4 (&acc)[NQ][D / 16], float (&m)[NQ], float (&l)[NQ],
+    const int (&qpos_hi)[NQ], float k_scale, float v_scale) {
   KVFrag<T, D> f;
-  load_kv_group<T, D>(f, k_cache, v_cache, bt_row, kvh, Hkv, block_size, base, seq_len);
+  load_kv_group<T, D, KV8>(f, k_cache, v_cache, bt_row, kvh, Hkv, block_size, base, seq_len, k_scale, v_scale);
   attend_loaded<T, D, NQ>(f, base, seq_len, scale_log2e, qf, acc, m, l, qpos_hi);
 }
 
@@ -128,12 +165,13 @@ __device__ __forceinline__ void attend_group(
 // q-tile, sequence); its 4 waves stride over the split's 32-key groups and are
 // merged through LDS.  The 16 MFMA columns carry the GQA group's query heads.
 // ---------------------------------------------------------------------------
-template <typename T, int D>
+template <typename T, int D, bool KV8>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void paged_decode_kernel(
     T* __restrict__ out, float* __restrict__ part_o, float* __restrict__ part_ml, const T* __restrict__ q,
-    long q_stride, const T* __restrict__ k_cache, const T* __restrict__ v_cache,
+    long q_stride, const void* __restrict__ k_cache, const void* __restrict__ v_cache,
     const int* __restrict__ block_table, int bt_stride, const int* __restrict__ seq_lens, float scale_log2e,
-    int Hq, int Hkv, int block_size, int num_splits, long out_stride) {
+    int Hq, int Hkv, int block_size, int num_splits, long out_stride, const float* __restrict__ k_scales,
+    const float* __restrict__ v_scales) {
   using V = typename Vec8<T>::type;
   constexpr int LDS_ROW = D + 4;
   __shared__ float s_o[4][16][LDS_ROW];
@@ -149,6 +187,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r16 = lane & 15, g4 = lane >> 4;
   const int seq_len = seq_lens[b];
+  const float k_scale = (KV8 && k_scales != nullptr) ? k_scales[kvh] : 1.f;
+  const float v_scale = (KV8 && v_scales != nullptr) ? v_scales[kvh] : 1.f;
 
   const int n_groups = (seq_len + 31) >> 5;
   const int gps = (n_groups + num_splits - 1) / num_splits;
@@ -170,8 +210,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // no register double-buffering here: it halves the occupancy (202 VGPRs) and
   // measured 3-8% slower than letting 4 resident workgroups per CU hide the latency
   for (int g = g_begin + wid; g < g_end; g += 4)
-    attend_group<T, D, 1>(k_cache, v_cache, bt_row, kvh, Hkv, block_size, g * 32, seq_len, scale_log2e, qf, acc, m,
-                          l, qpos_hi);
+    attend_group<T, D, 1, KV8>(k_cache, v_cache, bt_row, kvh, Hkv, block_size, g * 32, seq_len,
+                               scale_log2e * k_scale, qf, acc, m, l, qpos_hi, 1.f, 1.f);
 
   float lsum = l[0];
   lsum += __shfl_xor(lsum, 16, 64);
@@ -188,7 +228,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const float m0 = s_m[0][qi], m1 = s_m[1][qi], m2 = s_m[2][qi], m3 = s_m[3][qi];
     const float mm = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
     const float a0 = exp2f(m0 - mm), a1 = exp2f(m1 - mm), a2 = exp2f(m2 - mm), a3 = exp2f(m3 - mm);
-    const float o = s_o[0][qi][d] * a0 + s_o[1][qi][d] * a1 + s_o[2][qi][d] * a2 + s_o[3][qi][d] * a3;
+    const float o = (s_o[0][qi][d] * a0 + s_o[1][qi][d] * a1 + s_o[2][qi][d] * a2 + s_o[3][qi][d] * a3) * v_scale;
     const float lt = s_l[0][qi] * a0 + s_l[1][qi] * a1 + s_l[2][qi] * a2 + s_l[3][qi] * a3;
     const int qh = qh0 + qi;
     if (num_splits == 1) {
@@ -224,12 +264,12 @@ __global__ void decode_reduce_kernel(T* __restrict__ out, const float* __restric
 // Workgroup = 128 query tokens of one head; each wave owns 32 tokens as two
 // 16-row MFMA column tiles that share every K / V^T fragment it loads.
 // ---------------------------------------------------------------------------
-template <typename T, int D>
+template <typename T, int D, bool KV8>
 __global__ __launch_bounds__(256) void paged_prefill_kernel(
-    T* __restrict__ out, const T* __restrict__ q, long q_stride, const T* __restrict__ k_cache,
-    const T* __restrict__ v_cache, const int* __restrict__ block_table, int bt_stride,
+    T* __restrict__ out, const T* __restrict__ q, long q_stride, const void* __restrict__ k_cache,
+    const void* __restrict__ v_cache, const int* __restrict__ block_table, int bt_stride,
     const int* __restrict__ query_start_loc, const int* __restrict__ seq_lens, float scale_log2e, int Hq, int Hkv,
-    int block_size, long out_stride) {
+    int block_size, long out_stride, const float* __restrict__ k_scales, const float* __restrict__ v_scales) {
   using V = typename Vec8<T>::type;
   constexpr int NQ = 2;
   const int z = blockIdx.z, h = blockIdx.y;
@@ -242,6 +282,8 @@ __global__ __launch_bounds__(256) void paged_prefill_kernel(
   const int seq_len = seq_lens[z];
   const int ctx = seq_len - q_len;
   const int kvh = h / (Hq / Hkv);
+  const float k_scale = (KV8 && k_scales != nullptr) ? k_scales[kvh] : 1.f;
+  const float v_scale = (KV8 && v_scales != nullptr) ? v_scales[kvh] : 1.f;
 
   V qf[NQ][D / 32];
   int qpos_hi[NQ];
@@ -266,14 +308,14 @@ __global__ __launch_bounds__(256) void paged_prefill_kernel(
   const int last_key = min(seq_len - 1, ctx + min(t_wave + 31, q_len - 1));
   const int n_groups = (last_key >> 5) + 1;
   for (int g = 0; g < n_groups; ++g)
-    attend_group<T, D, NQ>(k_cache, v_cache, bt_row, kvh, Hkv, block_size, g * 32, seq_len, scale_log2e, qf, acc,
-                           m, l, qpos_hi);
+    attend_group<T, D, NQ, KV8>(k_cache, v_cache, bt_row, kvh, Hkv, block_size, g * 32, seq_len,
+                                scale_log2e * k_scale, qf, acc, m, l, qpos_hi, 1.f, 1.f);
 #pragma unroll
   for (int n = 0; n < NQ; ++n) {
     float lsum = l[n];
     lsum += __shfl_xor(lsum, 16, 64);
     lsum += __shfl_xor(lsum, 32, 64);
-    const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+    const float inv = lsum > 0.f ? v_scale / lsum : 0.f;
     const int tok = t_wave + 16 * n + r16;
     if (tok < q_len) {
       T* orow = out + (long)(q0 + tok) * out_stride + (long)h * D + 4 * g4;
@@ -309,12 +351,13 @@ __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-template <typename T>
+template <typename T, bool KV8>
 __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
-    T* __restrict__ out, const T* __restrict__ q, long q_stride, const T* __restrict__ k_cache,
-    const T* __restrict__ v_cache, const int* __restrict__ block_table, int bt_stride,
+    T* __restrict__ out, const T* __restrict__ q, long q_stride, const void* __restrict__ k_cache,
+    const void* __restrict__ v_cache, const int* __restrict__ block_table, int bt_stride,
     const int* __restrict__ query_start_loc, const int* __restrict__ seq_lens, float scale_log2e, int Hq, int Hkv,
-    int block_size, long out_stride, int q_tiles, int total_wgs, int xcd_remap) {
+    int block_size, long out_stride, int q_tiles, int total_wgs, int xcd_remap,
+    const float* __restrict__ k_scales, const float* __restrict__ v_scales) {
   using V = typename Vec8<T>::type;
   constexpr int D = 128, KT = 64, TILE_BYTES = KT * D * 2;
   __shared__ __attribute__((aligned(16))) char smem[2][2][TILE_BYTES];     // [buffer][K | V^T]
@@ -340,6 +383,10 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
   const int seq_len = seq_lens[z];
   const int ctx = seq_len - q_len;
   const int kvh = head / (Hq / Hkv);
+  // an e4m3 cache is widened on its way into LDS: the tiles the MFMAs read are T either way
+  const float k_scale = (KV8 && k_scales != nullptr) ? k_scales[kvh] : 1.f;
+  const float v_scale = (KV8 && v_scales != nullptr) ? v_scales[kvh] : 1.f;
+  const float sl2e = scale_log2e * k_scale;
   const int t_wave = t_blk + wid * 32;
   const int tok = t_wave + l32;
   const bool wave_active = t_wave < q_len;
@@ -371,11 +418,13 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
       const int row = c >> 4, cc = c & 15;
       const int key = min(base + row, seq_len - 1);
       const long blk = bt_row[key / block_size];
-      stage_k[i] = ld8<T>(k_cache + ((blk * Hkv + kvh) * block_size + (key % block_size)) * (long)D + 8 * cc);
+      stage_k[i] = ld_kv<T, KV8>(k_cache, ((blk * Hkv + kvh) * block_size + (key % block_size)) * (long)D + 8 * cc,
+                                 1.f);
       const int d = c >> 3, kc = c & 7;
       const int vkey = min(base + 8 * kc, seq_len - 1) & ~7;
       const long blkv = bt_row[vkey / block_size];
-      stage_v[i] = ld8<T>(v_cache + ((blkv * Hkv + kvh) * (long)D + d) * block_size + (vkey % block_size));
+      stage_v[i] = ld_kv<T, KV8>(v_cache, ((blkv * Hkv + kvh) * (long)D + d) * block_size + (vkey % block_size),
+                                 1.f);
     }
   };
   auto store_tile = [&](int buf) {
@@ -424,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float v = sc[u][r] * scale_log2e;
+          float v = sc[u][r] * sl2e;
           if (need_mask) {
             const int key = base + 32 * u + 16 * (r >> 3) + 8 * h + (r & 7);
             v = key <= q_hi ? v : NEG_BIG;
@@ -466,7 +515,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
 
   if (tok < q_len) {
     float lsum = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+    const float inv = lsum > 0.f ? v_scale / lsum : 0.f;
     T* orow = out + (long)(q0 + tok) * out_stride + (long)head * D + 4 * h;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
@@ -482,18 +531,18 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
   }
 }
 
-template <typename T, int D>
+template <typename T, int D, bool KV8>
 int launch_decode(void* out, float* ws, const void* q, long q_stride, const void* kc, const void* vc, const int* bt,
                   int bt_stride, const int* seq_lens, float scale, int B, int Hq, int Hkv, int block_size,
-                  int num_splits, long out_stride, hipStream_t s) {
+                  int num_splits, long out_stride, const float* k_scales, const float* v_scales, hipStream_t s) {
   const int G = Hq / Hkv;
   const int q_tiles = (G + 15) / 16;
   float* part_o = ws;
   float* part_ml = ws ? ws + (long)B * Hq * num_splits * D : nullptr;
   const float sl2 = scale * 1.4426950408889634f;
-  hipLaunchKernelGGL((paged_decode_kernel<T, D>), dim3(num_splits, Hkv * q_tiles, B), dim3(256), 0, s, (T*)out,
-                     part_o, part_ml, (const T*)q, q_stride, (const T*)kc, (const T*)vc, bt, bt_stride, seq_lens,
-                     sl2, Hq, Hkv, block_size, num_splits, out_stride);
+  hipLaunchKernelGGL((paged_decode_kernel<T, D, KV8>), dim3(num_splits, Hkv * q_tiles, B), dim3(256), 0, s, (T*)out,
+                     part_o, part_ml, (const T*)q, q_stride, kc, vc, bt, bt_stride, seq_lens,
+                     sl2, Hq, Hkv, block_size, num_splits, out_stride, k_scales, v_scales);
   HIP_LAUNCH_CHECK();
   if (num_splits > 1) {
     hipLaunchKernelGGL((decode_reduce_kernel<T, D>), dim3(Hq, B), dim3(D), 0, s, (T*)out, part_o, part_ml, Hq,
@@ -503,10 +552,11 @@ int launch_decode(void* out, float* ws, const void* q, long q_stride, const void
   return 0;
 }
 
-template <typename T, int D>
+template <typename T, int D, bool KV8>
 int launch_prefill(void* out, const void* q, long q_stride, const void* kc, const void* vc, const int* bt,
                    int bt_stride, const int* qsl, const int* seq_lens, float scale, int num_seqs, int max_q_len,
-                   int Hq, int Hkv, int block_size, long out_stride, hipStream_t s) {
+                   int Hq, int Hkv, int block_size, long out_stride, const float* k_scales, const float* v_scales,
+                   hipStream_t s) {
   const float sl2 = scale * 1.4426950408889634f;
   const int tiles = (max_q_len + 127) / 128;
   if constexpr (D == 128) {
@@ -518,16 +568,16 @@ int launch_prefill(void* out, const void* q, long q_stride, const void* kc, cons
       const long total = (long)tiles * Hq * num_seqs;
       if (total > (1L << 30)) return -3;
       const int grid = remap ? (int)((total + 7) / 8 * 8) : (int)total;
-      hipLaunchKernelGGL((paged_prefill_lds_kernel<T>), dim3(grid), dim3(256), 0, s, (T*)out,
-                         (const T*)q, q_stride, (const T*)kc, (const T*)vc, bt, bt_stride, qsl, seq_lens, sl2, Hq,
-                         Hkv, block_size, out_stride, tiles, (int)total, remap);
+      hipLaunchKernelGGL((paged_prefill_lds_kernel<T, KV8>), dim3(grid), dim3(256), 0, s, (T*)out,
+                         (const T*)q, q_stride, kc, vc, bt, bt_stride, qsl, seq_lens, sl2, Hq,
+                         Hkv, block_size, out_stride, tiles, (int)total, remap, k_scales, v_scales);
       HIP_LAUNCH_CHECK();
       return 0;
     }
   }
-  hipLaunchKernelGGL((paged_prefill_kernel<T, D>), dim3(tiles, Hq, num_seqs), dim3(256), 0, s, (T*)out,
-                     (const T*)q, q_stride, (const T*)kc, (const T*)vc, bt, bt_stride, qsl, seq_lens, sl2, Hq, Hkv,
-                     block_size, out_stride);
+  hipLaunchKernelGGL((paged_prefill_kernel<T, D, KV8>), dim3(tiles, Hq, num_seqs), dim3(256), 0, s, (T*)out,
+                     (const T*)q, q_stride, kc, vc, bt, bt_stride, qsl, seq_lens, sl2, Hq, Hkv,
+                     block_size, out_stride, k_scales, v_scales);
   HIP_LAUNCH_CHECK();
   return 0;
 }
@@ -541,17 +591,27 @@ VDAMD_API long vdamd_decode_workspace_floats(int B, int Hq, int D) {
   return (long)B * Hq * MAX_SPLITS * (D + 2);
 }
 
+// kv_fp8 != 0: k_cache / v_cache hold OCP e4m3 bytes in the same layouts; k_scales / v_scales
+// (one float per KV head, or null for 1.0) multiply the stored values back to their range.
 VDAMD_API int vdamd_paged_attention_decode(void* out, float* workspace, const void* q, long q_stride,
                                            const void* k_cache, const void* v_cache, const int* block_table,
                                            int bt_stride, const int* seq_lens, float scale, int B, int Hq, int Hkv,
                                            int D, int block_size, int num_splits, long out_stride, int dtype,
+                                           int kv_fp8, const float* k_scales, const float* v_scales,
                                            hipStream_t s) {
   if (B == 0) return 0;
   if (Hq % Hkv != 0 || block_size % 8 != 0 || num_splits < 1 || num_splits > MAX_SPLITS) return -1;
   if (num_splits > 1 && workspace == nullptr) return -3;
-#define CASE(TY, DD)                                                                                           \
-  return launch_decode<TY, DD>(out, workspace, q, q_stride, k_cache, v_cache, block_table, bt_stride, seq_lens, \
-                               scale, B, Hq, Hkv, block_size, num_splits, out_stride, s)
+#define CASE(TY, DD)                                                                                             \
+  do {                                                                                                           \
+    if (kv_fp8)                                                                                                  \
+      return launch_decode<TY, DD, true>(out, workspace, q, q_stride, k_cache, v_cache, block_table, bt_stride,   \
+                                         seq_lens, scale, B, Hq, Hkv, block_size, num_splits, out_stride,         \
+                                         k_scales, v_scales, s);                                                  \
+    return launch_decode<TY, DD, false>(out, workspace, q, q_stride, k_cache, v_cache, block_table, bt_stride,    \
+                                        seq_lens, scale, B, Hq, Hkv, block_size, num_splits, out_stride, nullptr, \
+                                        nullptr, s);                                                              \
+  } while (0)
   if (dtype == DT_BF16) { if (D == 128) CASE(bf16_t, 128); if (D == 64) CASE(bf16_t, 64); }
   if (dtype == DT_F16) { if (D == 128) CASE(f16_t, 128); if (D == 64) CASE(f16_t, 64); }
 #undef CASE
@@ -562,12 +622,20 @@ VDAMD_API int vdamd_paged_attention_prefill(void* out, const void* q, long q_str
                                             const void* v_cache, const int* block_table, int bt_stride,
                                             const int* query_start_loc, const int* seq_lens, float scale,
                                             int num_seqs, int max_q_len, int Hq, int Hkv, int D, int block_size,
-                                            long out_stride, int dtype, hipStream_t s) {
+                                            long out_stride, int dtype, int kv_fp8, const float* k_scales,
+                                            const float* v_scales, hipStream_t s) {
   if (num_seqs == 0 || max_q_len == 0) return 0;
   if (Hq % Hkv != 0 || block_size % 8 != 0) return -1;
-#define CASE(TY, DD)                                                                                          \
-  return launch_prefill<TY, DD>(out, q, q_stride, k_cache, v_cache, block_table, bt_stride, query_start_loc,   \
-                                seq_lens, scale, num_seqs, max_q_len, Hq, Hkv, block_size, out_stride, s)
+#define CASE(TY, DD)                                                                                             \
+  do {                                                                                                           \
+    if (kv_fp8)                                                                                                  \
+      return launch_prefill<TY, DD, true>(out, q, q_stride, k_cache, v_cache, block_table, bt_stride,             \
+                                          query_start_loc, seq_lens, scale, num_seqs, max_q_len, Hq, Hkv,         \
+                                          block_size, out_stride, k_scales, v_scales, s);                         \
+    return launch_prefill<TY, DD, false>(out, q, q_stride, k_cache, v_cache, block_table, bt_stride,              \
+                                         query_start_loc, seq_lens, scale, num_seqs, max_q_len, Hq, Hkv,          \
+                                         block_size, out_stride, nullptr, nullptr, s);                            \
+  } while (0)
   if (dtype == DT_BF16) { if (D == 128) CASE(bf16_t, 128); if (D == 64) CASE(bf16_t, 64); }
   if (dtype == DT_F16) { if (D == 128) CASE(f16_t, 128); if (D == 64) CASE(f16_t, 64); }
 #undef CASE

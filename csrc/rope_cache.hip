@@ -18,13 +18,31 @@
 
 namespace {
 
-template <typename T, bool WRITE_CACHE, bool ROTATE>
+// 8 floats (already divided by the cache scale) -> 8 OCP e4m3 bytes, saturating at +-448
+__device__ __forceinline__ uint2 pack_fp8x8(const float (&f)[8]) {
+  float c[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c[j] = fminf(fmaxf(f[j], -448.f), 448.f);
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], hi, true);
+  return make_uint2((unsigned)lo, (unsigned)hi);
+}
+
+// KV8: the cache holds one e4m3 byte per element (same layouts); values are divided by the
+// KV head's scale before they are narrowed.
+template <typename T, bool WRITE_CACHE, bool ROTATE, bool KV8>
 __global__ void rope_cache_kernel(const int* __restrict__ positions, T* __restrict__ q, T* __restrict__ k,
                                   const T* __restrict__ v, long q_stride, long k_stride, long v_stride,
-                                  const float* __restrict__ cos_sin, T* __restrict__ k_cache,
-                                  T* __restrict__ v_cache, const int* __restrict__ slot_mapping, int Hq, int Hkv,
+                                  const float* __restrict__ cos_sin, void* __restrict__ k_cache_v,
+                                  void* __restrict__ v_cache_v, const int* __restrict__ slot_mapping, int Hq, int Hkv,
                                   int D, int block_size, int T_tokens, const T* __restrict__ q_norm_w,
-                                  const T* __restrict__ k_norm_w, float norm_eps) {
+                                  const T* __restrict__ k_norm_w, float norm_eps,
+                                  const float* __restrict__ k_scales, const float* __restrict__ v_scales) {
+  T* k_cache = reinterpret_cast<T*>(k_cache_v);
+  T* v_cache = reinterpret_cast<T*>(v_cache_v);
   using V = typename Vec8<T>::type;
   const int half = D >> 1;
   const int cpp = half >> 3;                 // 8-element chunks per half head
@@ -83,9 +101,20 @@ __global__ void rope_cache_kernel(const int* __restrict__ positions, T* __restri
       } else {
         if (!WRITE_CACHE && ROTATE) { st8<T>(base + 8 * c, o1); st8<T>(base + half + 8 * c, o2); }
         if (WRITE_CACHE && slot >= 0) {
-          T* dst = k_cache + (((blk * Hkv + h) * block_size + off) * (long)D);
-          st8<T>(dst + 8 * c, o1);
-          st8<T>(dst + half + 8 * c, o2);
+          const long row = ((blk * Hkv + h) * block_size + off) * (long)D;
+          if constexpr (KV8) {
+            const float inv = (k_scales != nullptr) ? 1.f / k_scales[h] : 1.f;
+            float g1[8], g2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { g1[j] = (float)o1[j] * inv; g2[j] = (float)o2[j] * inv; }
+            uint8_t* dst = reinterpret_cast<uint8_t*>(k_cache_v) + row;
+            *reinterpret_cast<uint2*>(dst + 8 * c) = pack_fp8x8(g1);
+            *reinterpret_cast<uint2*>(dst + half + 8 * c) = pack_fp8x8(g2);
+          } else {
+            T* dst = k_cache + row;
+            st8<T>(dst + 8 * c, o1);
+            st8<T>(dst + half + 8 * c, o2);
+          }
         }
       }
     } else if (slot >= 0) {
@@ -93,9 +122,22 @@ __global__ void rope_cache_kernel(const int* __restrict__ positions, T* __restri
       const int cpd = D >> 3;
       const int h = it / cpd, c = it - h * cpd;
       V x = ld8<T>(v + t * v_stride + (long)h * D + 8 * c);
-      T* dst = v_cache + ((blk * Hkv + h) * (long)D + 8 * c) * block_size + off;
+      const long first = ((blk * Hkv + h) * (long)D + 8 * c) * block_size + off;
+      if constexpr (KV8) {
+        const float inv = (v_scales != nullptr) ? 1.f / v_scales[h] : 1.f;
+        float g[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dst[(long)j * block_size] = x[j];
+        for (int j = 0; j < 8; ++j) g[j] = (float)x[j] * inv;
+        const uint2 pk = pack_fp8x8(g);
+        uint8_t* dst = reinterpret_cast<uint8_t*>(v_cache_v) + first;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          dst[(long)j * block_size] = (uint8_t)(((j < 4 ? pk.x : pk.y) >> (8 * (j & 3))) & 0xFF);
+      } else {
+        T* dst = v_cache + first;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[(long)j * block_size] = x[j];
+      }
     }
   }
 }
@@ -103,19 +145,23 @@ __global__ void rope_cache_kernel(const int* __restrict__ positions, T* __restri
 template <typename T>
 int launch(const int* positions, void* q, void* k, const void* v, long qs, long ks, long vs, const float* cos_sin,
            void* k_cache, void* v_cache, const int* slot_mapping, int T_tokens, int Hq, int Hkv, int D,
-           int block_size, int mode, const void* qnw, const void* knw, float eps, hipStream_t s) {
+           int block_size, int mode, const void* qnw, const void* knw, float eps, int kv_fp8,
+           const float* k_scales, const float* v_scales, hipStream_t s) {
   // mode 0 and 2 write the cache (v items exist), mode 1 rotates only
   const long items = Hq * (D >> 4) + Hkv * (D >> 4) + (mode == 1 ? 0 : Hkv * (D >> 3));
   const long total = items * T_tokens;
   const int threads = 256;
   const unsigned blocks = (unsigned)((total + threads - 1) / threads);
-#define L(WC, ROT)                                                                                          \
-  hipLaunchKernelGGL((rope_cache_kernel<T, WC, ROT>), dim3(blocks), dim3(threads), 0, s, positions, (T*)q,  \
-                     (T*)k, (const T*)v, qs, ks, vs, cos_sin, (T*)k_cache, (T*)v_cache, slot_mapping, Hq, Hkv, \
-                     D, block_size, T_tokens, (const T*)qnw, (const T*)knw, eps)
-  if (mode == 0) L(true, true);          // rotate q,k + write k,v to cache
-  else if (mode == 1) L(false, true);    // rotate q,k in place only
-  else L(true, false);                   // cache write only (k,v already final)
+#define L(WC, ROT, K8)                                                                                          \
+  hipLaunchKernelGGL((rope_cache_kernel<T, WC, ROT, K8>), dim3(blocks), dim3(threads), 0, s, positions, (T*)q,  \
+                     (T*)k, (const T*)v, qs, ks, vs, cos_sin, k_cache, v_cache, slot_mapping, Hq, Hkv,          \
+                     D, block_size, T_tokens, (const T*)qnw, (const T*)knw, eps, k_scales, v_scales)
+  if (mode == 1) L(false, true, false);  // rotate q,k in place only
+  else if (mode == 0) {                  // rotate q,k + write k,v to cache
+    if (kv_fp8) L(true, true, true); else L(true, true, false);
+  } else {                               // cache write only (k,v already final)
+    if (kv_fp8) L(true, false, true); else L(true, false, false);
+  }
 #undef L
   HIP_LAUNCH_CHECK();
   return 0;
@@ -129,7 +175,7 @@ VDAMD_API int vdamd_rope_cache(const int* positions, void* q, void* k, const voi
                                long k_stride, long v_stride, const float* cos_sin, void* k_cache, void* v_cache,
                                const int* slot_mapping, int T, int Hq, int Hkv, int D, int block_size, int mode,
                                const void* q_norm_w, const void* k_norm_w, float norm_eps, int dtype,
-                               hipStream_t s) {
+                               int kv_fp8, const float* k_scales, const float* v_scales, hipStream_t s) {
   if (T == 0) return 0;
   if (D % 16 != 0) return -1;
   if ((q_norm_w == nullptr) != (k_norm_w == nullptr)) return -1;
@@ -137,9 +183,11 @@ VDAMD_API int vdamd_rope_cache(const int* positions, void* q, void* k, const voi
   if (q_norm_w != nullptr && (mode == 2 || ((D / 16) & (D / 16 - 1)) != 0 || D / 16 > 64)) return -1;
   if (dtype == DT_BF16)
     return launch<bf16_t>(positions, q, k, v, q_stride, k_stride, v_stride, cos_sin, k_cache, v_cache,
-                          slot_mapping, T, Hq, Hkv, D, block_size, mode, q_norm_w, k_norm_w, norm_eps, s);
+                          slot_mapping, T, Hq, Hkv, D, block_size, mode, q_norm_w, k_norm_w, norm_eps, kv_fp8,
+                          k_scales, v_scales, s);
   if (dtype == DT_F16)
     return launch<f16_t>(positions, q, k, v, q_stride, k_stride, v_stride, cos_sin, k_cache, v_cache,
-                         slot_mapping, T, Hq, Hkv, D, block_size, mode, q_norm_w, k_norm_w, norm_eps, s);
+                         slot_mapping, T, Hq, Hkv, D, block_size, mode, q_norm_w, k_norm_w, norm_eps, kv_fp8,
+                         k_scales, v_scales, s);
   return -2;
 }

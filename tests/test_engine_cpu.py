@@ -208,3 +208,40 @@ def test_shared_storage_kv_connector_moves_prefill_between_engines(tmp_path):
     assert cons.core.scheduler.kv_connector.num_loaded_tokens == 64 + 32
     cons.shutdown()
     pstate.destroy_model_parallel()
+
+
+def test_fp8_kv_cache_reference_ops_and_engine_cpu():
+    """The e4m3 KV cache on the CPU reference path: write / read round trip with per-head scales,
+    half the bytes per block, and an engine that generates with it."""
+    import math
+    from vllm_distributed_amd import LLM, SamplingParams
+    from vllm_distributed_amd.ops import torch_ref
+    fp8 = torch.float8_e4m3fn
+    T, hkv, d, bs, nb = 9, 2, 16, 4, 6
+    k, v = torch.randn(T, hkv, d), torch.randn(T, hkv, d)
+    ks, vs = torch.tensor([0.5, 0.3]), torch.tensor([1.7, 0.9])
+    kc, vc = torch.zeros(nb, hkv, bs, d, dtype=fp8), torch.zeros(nb, hkv, d, bs, dtype=fp8)
+    slots = torch.arange(T, dtype=torch.int32)
+    torch_ref.reshape_and_cache(k, v, kc, vc, slots, (ks, vs))
+    bt = torch.arange(nb, dtype=torch.int32).view(1, -1)
+    kk, vv = torch_ref._gather_kv(kc, vc, bt[0], T, (ks, vs))
+    # e4m3 keeps 3 mantissa bits: relative error of a stored value is at most 2^-4
+    torch.testing.assert_close(kk.transpose(0, 1), k, rtol=0.07, atol=0.02)     # [H, S, D] -> [S, H, D]
+    q = torch.randn(1, 4, d)
+    out8 = torch_ref.paged_attention_decode(q, kc, vc, bt, torch.tensor([T], dtype=torch.int32),
+                                            1 / math.sqrt(d), (ks, vs))
+    kc32, vc32 = torch.zeros(nb, hkv, bs, d), torch.zeros(nb, hkv, d, bs)
+    torch_ref.reshape_and_cache(k, v, kc32, vc32, slots)
+    out32 = torch_ref.paged_attention_decode(q, kc32, vc32, bt, torch.tensor([T], dtype=torch.int32),
+                                             1 / math.sqrt(d))
+    torch.testing.assert_close(out8, out32, rtol=0.1, atol=0.1)
+
+    llm = LLM(model="llama-tiny", device="cpu", dtype="float32", kv_cache_dtype="fp8", max_model_len=128,
+              num_gpu_blocks_override=32, max_num_seqs=4)
+    runner = llm.engine.core.executor.driver.worker.model_runner
+    assert runner.kv_caches[0][0].dtype == fp8
+    assert runner.get_kv_cache_spec().dtype_bytes == 1
+    out = llm.generate([{"prompt_token_ids": list(range(5, 40))}], SamplingParams(temperature=0.0, max_tokens=6))
+    assert len(out[0].outputs[0].token_ids) == 6
+    with pytest.raises(ValueError):
+        LLM(model="llama-tiny", device="cpu", kv_cache_dtype="fp8_e5m2")

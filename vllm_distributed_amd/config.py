@@ -285,10 +285,15 @@ class CacheConfig:
     num_gpu_blocks: Optional[int] = None
 
     def __post_init__(self) -> None:
-        # the paged cache holds K/V in the model dtype; the attention kernels read it as MFMA operands
-        if self.cache_dtype not in ("auto", "bfloat16", "float16", "bf16", "fp16", "half"):
-            raise ValueError(f"kv cache dtype {self.cache_dtype!r} is not supported: the cache is kept in the "
-                             "model's 16-bit dtype (use 'auto')")
+        # the paged cache holds K/V in the model dtype, or in OCP e4m3 with per-head scales
+        # (e5m2 and the fnuz encodings have no conversion instructions on gfx950)
+        if self.cache_dtype not in ("auto", "bfloat16", "float16", "bf16", "fp16", "half", "fp8", "fp8_e4m3"):
+            raise ValueError(f"kv cache dtype {self.cache_dtype!r} is not supported: use 'auto' (the model's "
+                             "16-bit dtype) or 'fp8' / 'fp8_e4m3'")
+
+    @property
+    def kv_fp8(self) -> bool:
+        return self.cache_dtype in ("fp8", "fp8_e4m3")
 
 
 @dataclass

@@ -65,9 +65,20 @@ class Attention(nn.Module):
         self.layer_idx = layer_idx
         self.k_cache: Optional[torch.Tensor] = None
         self.v_cache: Optional[torch.Tensor] = None
+        # e4m3 cache only: (k_scale[Hkv], v_scale[Hkv]) fp32; stored = value / scale.  None = 1.0
+        self.kv_scales: Optional[tuple] = None
 
-    def bind_kv_cache(self, k_cache: torch.Tensor, v_cache: torch.Tensor) -> None:
-        self.k_cache, self.v_cache = k_cache, v_cache
+    def bind_kv_cache(self, k_cache: torch.Tensor, v_cache: torch.Tensor, kv_scales: Optional[tuple] = None) -> None:
+        self.k_cache, self.v_cache, self.kv_scales = k_cache, v_cache, kv_scales
+
+    def set_kv_scale(self, which: str, value: torch.Tensor) -> None:
+        """Checkpoint ``k_scale`` / ``v_scale`` (a scalar, or one value per local KV head)."""
+        ks, vs = self.kv_scales or (None, None)
+        t = value.detach().float().reshape(-1)
+        t = (t.expand(self.num_kv_heads) if t.numel() == 1 else t).contiguous().clone()
+        ones = torch.ones(self.num_kv_heads, dtype=torch.float32, device=t.device)
+        ks, vs = (t, vs if vs is not None else ones) if which == "k" else (ks if ks is not None else ones, t)
+        self.kv_scales = (ks, vs)
 
     def forward_cached(self, q: torch.Tensor) -> torch.Tensor:
         """``q[T, Hq*D]`` (already rotated; this step's K/V already in the cache)."""
@@ -82,12 +93,12 @@ class Attention(nn.Module):
             ops.paged_attention_decode(
                 qv[:nd], self.k_cache, self.v_cache, md.block_table[:md.num_decodes],
                 md.seq_lens[:md.num_decodes], self.scale, md.max_decode_seq_len,
-                out=out[:nd], workspace=md.decode_workspace)
+                out=out[:nd], workspace=md.decode_workspace, kv_scales=self.kv_scales)
         if md.num_prefills > 0:
             ops.paged_attention(
                 qv[nd:], self.k_cache, self.v_cache, md.block_table[md.num_decodes:],
                 md.prefill_query_start_loc, md.seq_lens[md.num_decodes:], self.scale,
-                md.max_prefill_query_len, md.max_seq_len, out=out[nd:])
+                md.max_prefill_query_len, md.max_seq_len, out=out[nd:], kv_scales=self.kv_scales)
         return out.view(t, self.num_heads * self.head_dim)
 
     def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
@@ -97,7 +108,7 @@ class Attention(nn.Module):
             t = k.shape[0]
             ops.reshape_and_cache(k.reshape(t, self.num_kv_heads, self.head_dim),
                                   v.reshape(t, self.num_kv_heads, self.head_dim),
-                                  self.k_cache, self.v_cache, md.slot_mapping)
+                                  self.k_cache, self.v_cache, md.slot_mapping, self.kv_scales)
         return self.forward_cached(q)
 
 

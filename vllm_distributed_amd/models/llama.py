@@ -63,7 +63,8 @@ class LlamaAttention(nn.Module):
             # per-head RMSNorm of q and k, rotation and the cache write in one kernel
             q = ops.rope_and_cache(positions, qkv, self.cos_sin, self.attn.k_cache, self.attn.v_cache,
                                    md.slot_mapping, self.num_heads, self.num_kv_heads, self.head_dim,
-                                   self.q_norm.weight, self.k_norm.weight, self.q_norm.eps)
+                                   self.q_norm.weight, self.k_norm.weight, self.q_norm.eps,
+                                   kv_scales=self.attn.kv_scales)
             out = self.attn.forward_cached(q)
         elif self.qk_norm:
             t = qkv.shape[0]
@@ -78,7 +79,7 @@ class LlamaAttention(nn.Module):
         else:
             q = ops.rope_and_cache(positions, qkv, self.cos_sin, self.attn.k_cache,
                                    self.attn.v_cache, md.slot_mapping, self.num_heads,
-                                   self.num_kv_heads, self.head_dim)
+                                   self.num_kv_heads, self.head_dim, kv_scales=self.attn.kv_scales)
             out = self.attn.forward_cached(q)
         return self.o_proj(out, reduce, staged)
 
@@ -424,6 +425,12 @@ class LlamaForCausalLM(nn.Module):
                 if renamed is None:
                     continue
                 name, w = renamed
+            if name.endswith((".k_scale", ".v_scale")) and ".self_attn." in name:
+                # per-tensor scales of an fp8 KV cache (read only when the cache is e4m3)
+                layer = self.layers[name.split("layers.")[1].split(".")[0]]
+                layer.self_attn.attn.set_kv_scale(name[-7], materialize(w))
+                loaded.append(name)
+                continue
             target, shard = name, None
             for frag, fused, sid in self.stacked_params:
                 if frag in name:

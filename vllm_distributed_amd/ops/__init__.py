@@ -84,28 +84,32 @@ def rotary_embedding(positions, q, k, cos_sin_cache, head_dim):
     return torch_ref.rotary_embedding(positions, q, k, cos_sin_cache, head_dim)
 
 
-def reshape_and_cache(k, v, k_cache, v_cache, slot_mapping):
+def reshape_and_cache(k, v, k_cache, v_cache, slot_mapping, kv_scales=None):
+    """``kv_scales = (k_scale[Hkv], v_scale[Hkv])`` fp32: only read for an e4m3 cache."""
     if _use_hip(k):
-        return _hip.reshape_and_cache(k, v, k_cache, v_cache, slot_mapping)
-    return torch_ref.reshape_and_cache(k, v, k_cache, v_cache, slot_mapping)
+        return _hip.reshape_and_cache(k, v, k_cache, v_cache, slot_mapping, kv_scales)
+    return torch_ref.reshape_and_cache(k, v, k_cache, v_cache, slot_mapping, kv_scales)
 
 
 def rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping,
-                   num_heads, num_kv_heads, head_dim, q_norm_weight=None, k_norm_weight=None, norm_eps=0.0):
+                   num_heads, num_kv_heads, head_dim, q_norm_weight=None, k_norm_weight=None, norm_eps=0.0,
+                   kv_scales=None):
     if _use_hip(qkv):
         return _hip.rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping,
-                                   num_heads, num_kv_heads, head_dim, q_norm_weight, k_norm_weight, norm_eps)
+                                   num_heads, num_kv_heads, head_dim, q_norm_weight, k_norm_weight, norm_eps,
+                                   kv_scales)
     return torch_ref.rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping,
-                                    num_heads, num_kv_heads, head_dim, q_norm_weight, k_norm_weight, norm_eps)
+                                    num_heads, num_kv_heads, head_dim, q_norm_weight, k_norm_weight, norm_eps,
+                                    kv_scales)
 
 
 def paged_attention(q, k_cache, v_cache, block_table, query_start_loc, seq_lens, scale,
-                    max_query_len: int = 0, max_seq_len: int = 0, out=None):
+                    max_query_len: int = 0, max_seq_len: int = 0, out=None, kv_scales=None):
     if _use_hip(q) and _hip.supports_head_dim(q.shape[-1]):
         return _hip.paged_attention_prefill(q, k_cache, v_cache, block_table, query_start_loc,
-                                            seq_lens, scale, max_query_len, max_seq_len, out)
+                                            seq_lens, scale, max_query_len, max_seq_len, out, kv_scales)
     res = torch_ref.paged_attention(q, k_cache, v_cache, block_table, query_start_loc,
-                                    seq_lens, scale)
+                                    seq_lens, scale, kv_scales)
     if out is not None:
         out.copy_(res)
         return out
@@ -113,11 +117,11 @@ def paged_attention(q, k_cache, v_cache, block_table, query_start_loc, seq_lens,
 
 
 def paged_attention_decode(q, k_cache, v_cache, block_table, seq_lens, scale,
-                           max_seq_len: int = 0, out=None, workspace=None):
+                           max_seq_len: int = 0, out=None, workspace=None, kv_scales=None):
     if _use_hip(q) and _hip.supports_head_dim(q.shape[-1]):
         return _hip.paged_attention_decode(q, k_cache, v_cache, block_table, seq_lens, scale,
-                                           max_seq_len, out, workspace)
-    res = torch_ref.paged_attention_decode(q, k_cache, v_cache, block_table, seq_lens, scale)
+                                           max_seq_len, out, workspace, kv_scales=kv_scales)
+    res = torch_ref.paged_attention_decode(q, k_cache, v_cache, block_table, seq_lens, scale, kv_scales)
     if out is not None:
         out.copy_(res)
         return out

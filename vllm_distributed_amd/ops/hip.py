@@ -35,9 +35,9 @@ def load() -> ctypes.CDLL:
         "vdamd_layer_norm": [P, P, P, P, F, I, I, I, P],
         "vdamd_silu_and_mul": [P, P, L, I, I, P],
         "vdamd_embedding": [P, P, P, I, I, I, I, I, P],
-        "vdamd_rope_cache": [P, P, P, P, L, L, L, P, P, P, P, I, I, I, I, I, I, P, P, F, I, P],
-        "vdamd_paged_attention_decode": [P, P, P, L, P, P, P, I, P, F, I, I, I, I, I, I, L, I, P],
-        "vdamd_paged_attention_prefill": [P, P, L, P, P, P, I, P, P, F, I, I, I, I, I, I, L, I, P],
+        "vdamd_rope_cache": [P, P, P, P, L, L, L, P, P, P, P, I, I, I, I, I, I, P, P, F, I, I, P, P, P],
+        "vdamd_paged_attention_decode": [P, P, P, L, P, P, P, I, P, F, I, I, I, I, I, I, L, I, I, P, P, P],
+        "vdamd_paged_attention_prefill": [P, P, L, P, P, P, I, P, P, F, I, I, I, I, I, I, L, I, I, P, P, P],
         "vdamd_argmax": [P, P, I, I, L, I, P],
         "vdamd_sample": [P, P, I, I, L, P, P, P, P, P, I, P],
         "vdamd_w4a16_gemm": [P, L, P, L, P, P, P, I, I, I, I, I, I, I, P],
@@ -163,7 +163,23 @@ def embedding(ids: torch.Tensor, weight: torch.Tensor, vocab_start: int = 0,
 
 
 # ---------------------------------------------------------- rotary + cache
+FP8_KV = torch.float8_e4m3fn
+
+
+def _kv_args(k_cache: torch.Tensor, kv_scales, hkv: int):
+    """(kv_fp8 flag, k_scale pointer, v_scale pointer) for a cache tensor pair."""
+    if k_cache.dtype != FP8_KV:
+        return 0, None, None
+    if kv_scales is None:
+        return 1, None, None
+    ks, vs = kv_scales
+    for t in (ks, vs):
+        assert t.dtype == torch.float32 and t.numel() == hkv and t.is_contiguous() and t.device == k_cache.device
+    return 1, ks.data_ptr(), vs.data_ptr()
+
+
 def _check_cache(k_cache: torch.Tensor, v_cache: torch.Tensor, hkv: int, d: int) -> int:
+    assert k_cache.dtype == v_cache.dtype
     assert k_cache.dim() == 4 and v_cache.dim() == 4 and k_cache.is_contiguous() and v_cache.is_contiguous()
     nb, h, bs, dd = k_cache.shape
     assert (h, dd) == (hkv, d) and tuple(v_cache.shape) == (nb, hkv, d, bs), (k_cache.shape, v_cache.shape)
@@ -172,12 +188,14 @@ def _check_cache(k_cache: torch.Tensor, v_cache: torch.Tensor, hkv: int, d: int)
 
 
 def rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping, num_heads, num_kv_heads,
-                   head_dim, q_norm_weight=None, k_norm_weight=None, norm_eps: float = 0.0) -> torch.Tensor:
+                   head_dim, q_norm_weight=None, k_norm_weight=None, norm_eps: float = 0.0,
+                   kv_scales=None) -> torch.Tensor:
     """``q_norm_weight`` / ``k_norm_weight``: RMSNorm each q and k head before rotating (Qwen3)."""
     if not _half(qkv):
         from . import torch_ref
         return torch_ref.rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping,
-                                        num_heads, num_kv_heads, head_dim, q_norm_weight, k_norm_weight, norm_eps)
+                                        num_heads, num_kv_heads, head_dim, q_norm_weight, k_norm_weight, norm_eps,
+                                        kv_scales)
     if q_norm_weight is not None:
         for w in (q_norm_weight, k_norm_weight):
             assert w.dtype == qkv.dtype and w.numel() == head_dim and w.is_contiguous()
@@ -196,7 +214,7 @@ def rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping
                                  slot_mapping.data_ptr(), t, num_heads, num_kv_heads, head_dim, bs, 0,
                                  None if q_norm_weight is None else q_norm_weight.data_ptr(),
                                  None if k_norm_weight is None else k_norm_weight.data_ptr(), norm_eps,
-                                 _dt(qkv), _stream()), "rope_and_cache")
+                                 _dt(qkv), *_kv_args(k_cache, kv_scales, num_kv_heads), _stream()), "rope_and_cache")
     return qkv[:, :qs]
 
 
@@ -210,20 +228,21 @@ def rotary_embedding(positions, q, k, cos_sin_cache, head_dim) -> None:
     _check(_LIB.vdamd_rope_cache(positions.data_ptr(), q.data_ptr(), k.data_ptr(), None, q.stride(0),
                                  k.stride(0), 0, cos_sin_cache.data_ptr(), None, None, None, t,
                                  q.shape[1] // head_dim, k.shape[1] // head_dim, head_dim, 16, 1, None, None, 0.0,
-                                 _dt(q), _stream()), "rotary_embedding")
+                                 _dt(q), 0, None, None, _stream()), "rotary_embedding")
 
 
-def reshape_and_cache(k, v, k_cache, v_cache, slot_mapping) -> None:
+def reshape_and_cache(k, v, k_cache, v_cache, slot_mapping, kv_scales=None) -> None:
     if not _half(k):
         from . import torch_ref
-        return torch_ref.reshape_and_cache(k, v, k_cache, v_cache, slot_mapping)
+        return torch_ref.reshape_and_cache(k, v, k_cache, v_cache, slot_mapping, kv_scales)
     t, hkv, d = k.shape
     assert k.stride(2) == 1 and v.stride(2) == 1 and k.stride(1) == d and v.stride(1) == d
     assert slot_mapping.dtype == torch.int32 and slot_mapping.numel() >= t
     bs = _check_cache(k_cache, v_cache, hkv, d)
     _check(_LIB.vdamd_rope_cache(None, None, k.data_ptr(), v.data_ptr(), 0, k.stride(0), v.stride(0), None,
                                  k_cache.data_ptr(), v_cache.data_ptr(), slot_mapping.data_ptr(), t, 0, hkv, d,
-                                 bs, 2, None, None, 0.0, _dt(k), _stream()), "reshape_and_cache")
+                                 bs, 2, None, None, 0.0, _dt(k), *_kv_args(k_cache, kv_scales, hkv), _stream()),
+           "reshape_and_cache")
 
 
 # ---------------------------------------------------------------- attention
@@ -244,7 +263,7 @@ def choose_num_splits(batch: int, num_kv_heads: int, max_seq_len: int) -> int:
 
 
 def paged_attention_decode(q, k_cache, v_cache, block_table, seq_lens, scale, max_seq_len=0, out=None,
-                           workspace=None, num_splits: Optional[int] = None) -> torch.Tensor:
+                           workspace=None, num_splits: Optional[int] = None, kv_scales=None) -> torch.Tensor:
     b, hq, d = q.shape
     hkv = k_cache.shape[1]
     bs = _check_cache(k_cache, v_cache, hkv, d)
@@ -268,12 +287,12 @@ def paged_attention_decode(q, k_cache, v_cache, block_table, seq_lens, scale, ma
     _check(_LIB.vdamd_paged_attention_decode(
         out.data_ptr(), ws_ptr, q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(),
         block_table.data_ptr(), block_table.stride(0), seq_lens.data_ptr(), float(scale), b, hq, hkv, d, bs,
-        num_splits, hq * d, _dt(q), _stream()), "paged_attention_decode")
+        num_splits, hq * d, _dt(q), *_kv_args(k_cache, kv_scales, hkv), _stream()), "paged_attention_decode")
     return out
 
 
 def paged_attention_prefill(q, k_cache, v_cache, block_table, query_start_loc, seq_lens, scale,
-                            max_query_len=0, max_seq_len=0, out=None) -> torch.Tensor:
+                            max_query_len=0, max_seq_len=0, out=None, kv_scales=None) -> torch.Tensor:
     t, hq, d = q.shape
     hkv = k_cache.shape[1]
     bs = _check_cache(k_cache, v_cache, hkv, d)
@@ -292,8 +311,8 @@ def paged_attention_prefill(q, k_cache, v_cache, block_table, query_start_loc, s
     _check(_LIB.vdamd_paged_attention_prefill(
         out.data_ptr(), q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(),
         block_table.data_ptr(), block_table.stride(0), query_start_loc.data_ptr(), seq_lens.data_ptr(),
-        float(scale), nseq, max_query_len, hq, hkv, d, bs, hq * d, _dt(q), _stream()),
-        "paged_attention_prefill")
+        float(scale), nseq, max_query_len, hq, hkv, d, bs, hq * d, _dt(q), *_kv_args(k_cache, kv_scales, hkv),
+        _stream()), "paged_attention_prefill")
     return out
 
 

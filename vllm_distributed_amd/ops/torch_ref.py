@@ -125,13 +125,32 @@ def rotary_embedding(positions: torch.Tensor, q: torch.Tensor, k: torch.Tensor,
 
 
 # ---------------------------------------------------------------- KV cache
+FP8_KV = torch.float8_e4m3fn
+FP8_MAX = 448.0
+
+
+def _to_cache(x: torch.Tensor, cache: torch.Tensor, scale: Optional[torch.Tensor]) -> torch.Tensor:
+    """``x[T, Hkv, D]`` in the cache's element type; an e4m3 cache stores ``x / scale[head]``, saturated."""
+    if cache.dtype != FP8_KV:
+        return x.to(cache.dtype)
+    xf = x.float()
+    if scale is not None:
+        xf = xf / scale.float().view(1, -1, 1)
+    return xf.clamp_(-FP8_MAX, FP8_MAX).to(FP8_KV)
+
+
 def reshape_and_cache(k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor,
-                      v_cache: torch.Tensor, slot_mapping: torch.Tensor) -> None:
+                      v_cache: torch.Tensor, slot_mapping: torch.Tensor, kv_scales=None) -> None:
     """Scatter ``k,v[T, Hkv, D]`` into the paged caches; slot < 0 is skipped."""
     bs = k_cache.shape[2]
     valid = slot_mapping >= 0
     slots = slot_mapping[valid].long()
     blk, off = slots // bs, slots % bs
+    ks, vs = kv_scales if kv_scales is not None else (None, None)
+    if k_cache.dtype == FP8_KV:      # index assignment is not implemented for 8-bit floats: go through the bytes
+        k_cache.view(torch.uint8)[blk, :, off, :] = _to_cache(k[valid], k_cache, ks).view(torch.uint8)
+        v_cache.view(torch.uint8)[blk, :, :, off] = _to_cache(v[valid], v_cache, vs).view(torch.uint8)
+        return
     k_cache[blk, :, off, :] = k[valid].to(k_cache.dtype)
     v_cache[blk, :, :, off] = v[valid].to(v_cache.dtype)
 
@@ -139,7 +158,7 @@ def reshape_and_cache(k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor,
 def rope_and_cache(positions: torch.Tensor, qkv: torch.Tensor, cos_sin_cache: torch.Tensor,
                    k_cache: torch.Tensor, v_cache: torch.Tensor, slot_mapping: torch.Tensor,
                    num_heads: int, num_kv_heads: int, head_dim: int, q_norm_weight=None, k_norm_weight=None,
-                   norm_eps: float = 0.0) -> torch.Tensor:
+                   norm_eps: float = 0.0, kv_scales=None) -> torch.Tensor:
     """Rotate q and k inside the packed ``qkv[T, (Hq+2Hkv)*D]``, write k/v to
     the cache, return the rotated ``q[T, Hq*D]`` (a view of qkv).  With norm
     weights each q and k head is RMS-normalised first."""
@@ -152,16 +171,23 @@ def rope_and_cache(positions: torch.Tensor, qkv: torch.Tensor, cos_sin_cache: to
             part.copy_(h.reshape(part.shape).to(part.dtype))
     rotary_embedding(positions, q, k, cos_sin_cache, head_dim)
     reshape_and_cache(k.reshape(-1, num_kv_heads, head_dim), v.reshape(-1, num_kv_heads, head_dim),
-                      k_cache, v_cache, slot_mapping)
+                      k_cache, v_cache, slot_mapping, kv_scales)
     return q
 
 
-def _gather_kv(k_cache, v_cache, block_table_row, seq_len):
+def _gather_kv(k_cache, v_cache, block_table_row, seq_len, kv_scales=None):
     bs = k_cache.shape[2]
     nb = (seq_len + bs - 1) // bs
     blocks = block_table_row[:nb].long()
-    k = k_cache[blocks]                       # [nb, H, bs, D]
-    v = v_cache[blocks]                       # [nb, H, D, bs]
+    if k_cache.dtype == FP8_KV:
+        k = k_cache.view(torch.uint8)[blocks].view(FP8_KV).float()
+        v = v_cache.view(torch.uint8)[blocks].view(FP8_KV).float()
+        if kv_scales is not None:
+            k = k * kv_scales[0].float().view(1, -1, 1, 1)
+            v = v * kv_scales[1].float().view(1, -1, 1, 1)
+    else:
+        k = k_cache[blocks]                   # [nb, H, bs, D]
+        v = v_cache[blocks]                   # [nb, H, D, bs]
     k = k.permute(1, 0, 2, 3).reshape(k.shape[1], nb * bs, -1)[:, :seq_len]
     v = v.permute(1, 0, 3, 2).reshape(v.shape[1], nb * bs, -1)[:, :seq_len]
     return k, v                               # [H, S, D]
@@ -169,7 +195,7 @@ def _gather_kv(k_cache, v_cache, block_table_row, seq_len):
 
 def paged_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                     block_table: torch.Tensor, query_start_loc: torch.Tensor,
-                    seq_lens: torch.Tensor, scale: float) -> torch.Tensor:
+                    seq_lens: torch.Tensor, scale: float, kv_scales=None) -> torch.Tensor:
     """Causal attention of each sequence's query chunk against its paged KV
     (which already contains the chunk).  ``q[T, Hq, D]``; sequence ``i`` owns
     query rows ``query_start_loc[i]:query_start_loc[i+1]`` which are the last
@@ -185,7 +211,7 @@ def paged_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tenso
         ql = e - s
         if ql == 0:
             continue
-        k, v = _gather_kv(k_cache, v_cache, block_table[i], sl)
+        k, v = _gather_kv(k_cache, v_cache, block_table[i], sl, kv_scales)
         k = k.float().repeat_interleave(g, dim=0)
         v = v.float().repeat_interleave(g, dim=0)
         qi = q[s:e].float().transpose(0, 1)                     # [Hq, ql, D]
@@ -199,10 +225,10 @@ def paged_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tenso
 
 def paged_attention_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                            block_table: torch.Tensor, seq_lens: torch.Tensor,
-                           scale: float) -> torch.Tensor:
+                           scale: float, kv_scales=None) -> torch.Tensor:
     b = q.shape[0]
     qsl = torch.arange(b + 1, device=q.device, dtype=torch.int32)
-    return paged_attention(q, k_cache, v_cache, block_table, qsl, seq_lens, scale)
+    return paged_attention(q, k_cache, v_cache, block_table, qsl, seq_lens, scale, kv_scales)
 
 
 # ---------------------------------------------------------------- sampling

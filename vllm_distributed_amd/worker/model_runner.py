@@ -245,8 +245,9 @@ class ModelRunner:
     def get_kv_cache_spec(self) -> KVCacheSpec:
         layers = self.model.attention_layers()
         a = layers[0]
+        fp8 = self.vllm_config.cache_config.kv_fp8
         return KVCacheSpec(num_layers=len(layers), num_kv_heads=a.num_kv_heads, head_dim=a.head_dim,
-                           block_size=self.block_size, dtype_bytes=self.model_config.dtype_bytes)
+                           block_size=self.block_size, dtype_bytes=1 if fp8 else self.model_config.dtype_bytes)
 
     @torch.inference_mode()
     def profile_run(self) -> None:
@@ -271,7 +272,11 @@ class ModelRunner:
 
     def initialize_kv_cache(self, num_blocks: int) -> None:
         spec = self.get_kv_cache_spec()
-        dtype = self.model_config.torch_dtype
+        # an e4m3 cache halves the bytes decode attention streams; K/V are widened to the model
+        # dtype in registers before the MFMA, with one fp32 scale per KV head (1.0 unless a
+        # checkpoint supplies k_scale / v_scale)
+        fp8 = self.vllm_config.cache_config.kv_fp8
+        dtype = torch.float8_e4m3fn if fp8 else self.model_config.torch_dtype
         self.num_blocks = num_blocks
         self.kv_caches = []
         for attn in self.model.attention_layers():
@@ -279,7 +284,10 @@ class ModelRunner:
                             dtype=dtype, device=self.device)
             v = torch.zeros(num_blocks, spec.num_kv_heads, spec.head_dim, self.block_size,
                             dtype=dtype, device=self.device)
-            attn.bind_kv_cache(k, v)
+            scales = attn.kv_scales if fp8 else None
+            if scales is not None:
+                scales = tuple(t.to(self.device) for t in scales)
+            attn.bind_kv_cache(k, v, scales)
             self.kv_caches.append((k, v))
         logger.info("KV cache: %d blocks x %d tokens (%.2f GiB)", num_blocks, self.block_size,
                     num_blocks * spec.bytes_per_block / 2**30)
