@@ -111,6 +111,9 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     "VDAMD_SHARE_DEVICE": _bool("VDAMD_SHARE_DEVICE", False),
     # Short-batch weight-streaming GEMM for long-reduction shapes (0 = library GEMM only).
     "VDAMD_SKINNY_GEMM": _bool("VDAMD_SKINNY_GEMM", True),
+    # Elements of padding after every row of a dense 16-bit weight on the GPU (0 = none): breaks the
+    # power-of-two row stride that puts all rows of a tile on the same HBM channels.
+    "VDAMD_WEIGHT_ROW_PAD": _int("VDAMD_WEIGHT_ROW_PAD", 128),
     # W4A16 linears: largest batch that runs the fused 4-bit GEMM (larger ones
     # dequantise + library GEMM); kernel variant override (0/1) for experiments.
     "VDAMD_W4_MAX_FUSED_M": _int("VDAMD_W4_MAX_FUSED_M", 256),

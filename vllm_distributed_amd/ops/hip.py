@@ -35,6 +35,7 @@ def load() -> ctypes.CDLL:
         "vdamd_layer_norm": [P, P, P, P, F, I, I, I, P],
         "vdamd_silu_and_mul": [P, P, L, I, I, P],
         "vdamd_embedding": [P, P, P, I, I, I, I, I, P],
+        "vdamd_stream_gemm": [P, L, P, L, P, L, P, P, L, I, I, I, I, I, I, I, I, I, P],
         "vdamd_rope_cache": [P, P, P, P, L, L, L, P, P, P, P, I, I, I, I, I, I, P, P, F, I, I, P, P, P],
         "vdamd_paged_attention_decode": [P, P, P, L, P, P, P, I, P, F, I, I, I, I, I, I, L, I, I, P, P, P],
         "vdamd_paged_attention_prefill": [P, P, L, P, P, P, I, P, P, F, I, I, I, I, I, I, L, I, I, P, P, P],
@@ -528,6 +529,60 @@ def skinny_gemm(x: torch.Tensor, w: torch.Tensor, ntw: Optional[int] = None, ksp
     _check(_LIB.vdamd_skinny_gemm(out.data_ptr(), n, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
                                   None if partial is None else partial.data_ptr(), m, n, k, ksplit, ntw,
                                   _dt(x), _stream()), "skinny_gemm")
+    return out
+
+
+# ------------------------------------------- weight-streaming GEMM, M <= 16
+STREAM_MAX_M = 16
+EPI_NONE, EPI_RESIDUAL, EPI_SILU_MUL = 0, 1, 2
+
+
+def stream_supported(x: torch.Tensor, w: torch.Tensor) -> bool:
+    return (x.dim() == 2 and w.dim() == 2 and 0 < x.shape[0] <= STREAM_MAX_M and x.dtype == w.dtype
+            and x.dtype in (torch.bfloat16, torch.float16) and x.shape[1] == w.shape[1]
+            and w.shape[1] % 128 == 0 and w.shape[0] % 16 == 0 and x.stride(1) == 1 and w.stride(1) == 1
+            and x.stride(0) % 8 == 0 and w.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
+            and w.data_ptr() % 16 == 0)
+
+
+def stream_choose(n: int, k: int, silu: bool = False) -> Tuple[int, int, int]:
+    """``(ntw, ksplit, depth)``.  One output tile per workgroup until N alone gives several
+    workgroups per CU; K is split across workgroups only when even that leaves CUs idle."""
+    tiles = n // 16
+    ntw = 2 if (silu or tiles >= 4096) else 1
+    wgs = tiles // ntw
+    ksplit = 1
+    while wgs * ksplit < 1024 and (k // 128) // (ksplit * 2) >= 8:
+        ksplit *= 2
+    return ntw, ksplit, 3
+
+
+def stream_gemm(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None,
+                residual: Optional[torch.Tensor] = None, silu_mul: bool = False, ntw: Optional[int] = None,
+                ksplit: Optional[int] = None, depth: Optional[int] = None, nt: bool = False) -> torch.Tensor:
+    """``x [M<=16, K] @ w [N, K]^T`` reading ``w`` once at HBM speed.  ``residual [M, N]`` is added in
+    the epilogue; ``silu_mul`` treats ``w`` as ``[gate ; up]`` and returns ``silu(gate) * up`` (``N/2`` wide)."""
+    assert stream_supported(x, w), (x.shape, x.stride(), w.shape, w.stride(), x.dtype)
+    assert not (silu_mul and residual is not None)
+    m, k = x.shape
+    n = w.shape[0]
+    a, b, c = stream_choose(n, k, silu_mul)
+    ntw = a if ntw is None else ntw
+    ksplit = b if ksplit is None else ksplit
+    depth = c if depth is None else depth
+    n_out = n // 2 if silu_mul else n
+    if out is None:
+        out = torch.empty((m, n_out), dtype=x.dtype, device=x.device)
+    assert out.shape == (m, n_out) and out.dtype == x.dtype and out.stride(1) == 1 and out.data_ptr() % 8 == 0
+    epi = EPI_SILU_MUL if silu_mul else (EPI_RESIDUAL if residual is not None else EPI_NONE)
+    if residual is not None:
+        assert residual.shape == (m, n) and residual.dtype == x.dtype and residual.stride(1) == 1
+    partial = torch.empty(ksplit * m * n, dtype=torch.float32, device=x.device) if ksplit > 1 else None
+    _check(_LIB.vdamd_stream_gemm(out.data_ptr(), out.stride(0), x.data_ptr(), x.stride(0), w.data_ptr(),
+                                  w.stride(0), None if partial is None else partial.data_ptr(),
+                                  None if residual is None else residual.data_ptr(),
+                                  0 if residual is None else residual.stride(0), m, n, k, ksplit, ntw, depth,
+                                  int(nt), epi, _dt(x), _stream()), "stream_gemm")
     return out
 
 

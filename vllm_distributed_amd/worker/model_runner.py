@@ -226,6 +226,10 @@ class ModelRunner:
     def load_model(self) -> None:
         t0 = time.time()
         self.model = load_model(self.vllm_config, self.device)
+        if self.is_gpu and envs.VDAMD_WEIGHT_ROW_PAD > 0:
+            from ..models.layers.linear import pad_dense_weight_rows
+            n = pad_dense_weight_rows(self.model, int(envs.VDAMD_WEIGHT_ROW_PAD))
+            logger.info("padded the rows of %d dense weights by %d elements", n, envs.VDAMD_WEIGHT_ROW_PAD)
         self.pp = get_pp_group()
         self.tp = get_tp_group()
         mode = envs.VDAMD_TP_OVERLAP
