@@ -90,12 +90,31 @@ def main():
                           f"{nbytes / t / 1e6:5.2f} TB/s", flush=True)
             if best is not None:
                 res["stream"] = best[0]
+            mbest = None
+            if m > 16 and hip.mid_supported(x, copies[0]):
+                mcfgs = [(None, None, None)]
+                if args.full:
+                    mcfgs = [(bm, bn, ks) for bm, bn in ((256, 256), (256, 128), (128, 256), (128, 128), (64, 256), (64, 512))
+                             for ks in (1, 2, 4, 8, 16) if bm >= min(m, 256) or (bm == 128 and m > 128)]
+                for bm, bn, ks in mcfgs:
+                    got = hip.mid_gemm(x, copies[0], bm=bm, bn=bn, ksplit=ks)
+                    err = (got.float() - ref).abs().max().item()
+                    assert err < 0.05 * max(1.0, ref.abs().max().item()), (name, m, bm, bn, ks, err)
+                    t = timed(lambda w: hip.mid_gemm(x, w, bm=bm, bn=bn, ksplit=ks), copies)
+                    if mbest is None or t < mbest[0]:
+                        mbest = (t, bm, bn, ks)
+                    if args.full:
+                        print(f"    {name} M={m} bm={bm} bn={bn} ks={ks}: {t:7.1f} us {nbytes / t / 1e6:5.2f} TB/s "
+                              f"{2 * m * n * k / t / 1e6:6.0f} TF", flush=True)
+                res["mid"] = mbest[0]
             line = f"{name:16s} N={n:6d} K={k:5d} M={m:2d} | " + " | ".join(
                 f"{kk} {v:7.1f} us {nbytes / v / 1e6:5.2f} TB/s" for kk, v in res.items())
             if args.full and best is not None:
                 line += f" | best ntw={best[1]} ks={best[2]} d={best[3]} nt={int(best[4])}"
-            else:
+            elif best is not None:
                 line += f" | cfg {hip.stream_choose(n, k)}"
+            if mbest is not None:
+                line += f" | mid cfg {mbest[1:] if args.full else hip.mid_choose(m, n, k)}"
             print(line, flush=True)
         del copies
         torch.cuda.empty_cache()

@@ -1,22 +1,23 @@
 // GEMM for decode batches of 17..512 rows:  y[M][N] = x[M][K] . W[N][K]^T  (bf16 / f16, fp32 accumulate).
 //
 // In this range a step is bound by reading W once from HBM while the MFMA work per weight byte is
-// already substantial (M flops per byte), and the output has too few 256 x 256 tiles to fill 256 CUs
-// (N = 8192 gives 32).  Hence:
+// already substantial (M flops per byte), and the output has too few large tiles to fill 256 CUs
+// (N = 8192 gives 32 tiles of 256 columns).  Hence:
 //
 //  * one workgroup tile spans BM rows - all of M when M <= 256 - so every W byte is fetched from
 //    HBM exactly once, and K is split across workgroups (SPLITK slices; fp32 partial slabs and a
 //    small reduce kernel) until the grid covers the chip;
-//  * both operands go global -> LDS with the 16-byte LDS-DMA (`global_load_lds_dwordx4`), in
-//    pieces of 8 rows x 128 bytes (full cache lines of each row, one KiB per wave instruction), into
-//    a double-buffered image; the next K tile's DMA is in flight while the MFMAs of this one run,
-//    and there is exactly one barrier per 64-deep K tile;
-//  * the LDS image keeps 128-byte rows; its 16-byte slots are XOR-ed with (row >> 1) & 7, applied to
-//    the per-lane *source* address of the DMA (the destination of an LDS-DMA is lane-linear) and
-//    again on the read, which makes every 16-lane group of a `ds_read_b128` fragment read hit 16
-//    distinct slots of the 256-byte bank row;
-//  * 8 waves as 2 (M) x 4 (N) on v_mfma_f32_16x16x32: W is the A operand, so a lane ends up with
-//    four consecutive output columns of one row;
+//  * W never touches LDS.  The 8 waves of a workgroup sit side by side along N; a wave owns 16*FN
+//    output columns for ALL rows of the tile, so its W fragments (the MFMA A operand: lane (r, q)
+//    holds W[n + r][k + 8q .. +8], 16 rows x 64 bytes per instruction) are private to it and go from
+//    global memory straight into a three-deep register ring: two K tiles of W (8 KiB per wave,
+//    64 KiB per CU) are in flight while the third is multiplied, with no barrier in their way;
+//  * x is shared by all waves and comes from L2: 128-byte lines into registers two tiles ahead,
+//    into a double-buffered LDS image one tile ahead (16-byte slots XOR-ed with (row >> 1) & 7, so
+//    the 16-lane groups of a `ds_read_b128` fragment read hit 16 distinct slots of the 256-byte
+//    bank row), one barrier per 64-deep K tile;
+//  * every load is an ordinary one, issued in the fixed order x(t+2), W(t+2): the compiler's own
+//    counted `s_waitcnt vmcnt(N)` then leaves exactly the younger tiles in flight at each use;
 //  * workgroup id -> (tile, slice) puts equal slices on the same XCD (ids are dealt round-robin to
 //    the 8 XCDs), so an XCD's L2 only has to hold its slice of x.
 #include "common.h"
@@ -25,70 +26,52 @@ namespace {
 
 constexpr int MG_BK = 64;            // K elements per tile = 128 bytes per row
 constexpr int MG_THREADS = 512;
+constexpr int MG_WAVES = 8;
 
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
-
-template <typename T, int BM, int BN>
+template <typename T, int BM, int FN>
 __global__ __launch_bounds__(MG_THREADS) void mid_gemm_kernel(
-    const T* __restrict__ x, long x_stride, const T* __restrict__ w, long w_stride, T* __restrict__ out,
-    long out_stride, float* __restrict__ partial, int M, int N, int K, int ksplit) {
+    const T* x, long x_stride, const T* w, long w_stride, T* out, long out_stride, float* partial, int M, int N,
+    int K, int ksplit) {
+  // x and w are deliberately not __restrict__: loads from provably unaliased read-only memory may be
+  // moved across the barriers, and the pipeline below depends on WHEN each load is issued.
   using V8 = typename Vec8<T>::type;
-  constexpr int ROWS = BM + BN;                 // rows of one stage: x rows, then W rows
-  constexpr int STAGE = ROWS * 128;             // bytes
-  constexpr int PIECES = ROWS / 8;              // 1 KiB DMA pieces per stage
-  constexpr int PPW = PIECES / 8;               // pieces per wave
-  constexpr int FM = BM / 2 / 16, FN = BN / 4 / 16;
-  static_assert(PIECES % 8 == 0, "tile rows must split evenly over 8 waves");
+  constexpr int BN = MG_WAVES * 16 * FN;
+  constexpr int FM = BM / 16;
+  constexpr int XL = BM * 8 / MG_THREADS;       // 16-byte chunks of the x tile per thread
+  constexpr int STAGE = BM * 128;               // bytes of one x image
+  static_assert(XL >= 1 && FM % 2 == 0, "unsupported tile");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int wm = wid >> 2, wn = wid & 3;
   const int r16 = lane & 15, q = lane >> 4;
 
   const int ntn = (N + BN - 1) / BN;
   const int id = blockIdx.x;
   const int ks = id % ksplit, tn = id / ksplit;
   if (tn >= ntn) return;
-  const int m0 = blockIdx.y * BM, n0 = tn * BN;
+  const int m0 = blockIdx.y * BM, n0 = tn * BN + wid * 16 * FN;
   const int KT = K / MG_BK;
   const int kt_lo = (int)((long)KT * ks / ksplit), kt_hi = (int)((long)KT * (ks + 1) / ksplit);
   const int nt = kt_hi - kt_lo;
 
-  // ---- DMA source addresses: piece p covers tile rows 8p..8p+7; this lane brings the 16-byte chunk
-  // (lane & 7) ^ swz(row) of row 8p + (lane >> 3), which lands at LDS slot (lane & 7) of that row.
-  const T* src[PPW];
+  // W fragment rows of this lane (clamped: columns past N are computed and dropped)
+  const T* wsrc[FN];
 #pragma unroll
-  for (int i = 0; i < PPW; ++i) {
-    const int p = wid * PPW + i;
-    const int row = 8 * p + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    if (row < BM) src[i] = x + (long)min(m0 + row, M - 1) * x_stride + 8 * chunk;
-    else src[i] = w + (long)min(n0 + row - BM, N - 1) * w_stride + 8 * chunk;
-    src[i] += (long)kt_lo * MG_BK;
+  for (int j = 0; j < FN; ++j)
+    wsrc[j] = w + (long)min(n0 + 16 * j + r16, N - 1) * w_stride + 8 * q + (long)kt_lo * MG_BK;
+  // x staging: chunk c = threadIdx.x + 512 i -> row c >> 3, 16-byte slot c & 7 (8 threads = one 128-byte line)
+  const T* xsrc[XL];
+  int xdst[XL];
+#pragma unroll
+  for (int i = 0; i < XL; ++i) {
+    const int c = threadIdx.x + MG_THREADS * i;
+    const int row = c >> 3, slot = c & 7;
+    xsrc[i] = x + (long)min(m0 + row, M - 1) * x_stride + 8 * slot + (long)kt_lo * MG_BK;
+    xdst[i] = row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
   }
-  auto stage = [&](int buf, int t) {
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      unsigned char* dst = smem + buf * STAGE + (wid * PPW + i) * 1024;
-      __builtin_amdgcn_global_load_lds((glb_void*)(src[i] + (long)t * MG_BK), (lds_void*)dst, 16, 0, 0);
-    }
-  };
-
-  // ---- fragment read offsets inside a stage (bytes), for k32-step s: XOR the slot with swz(row)
-  int xoff[FM], woff[FN], xswz[FM], wswz[FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int row = wm * (BM / 2) + 16 * i + r16;
-    xoff[i] = row * 128;
-    xswz[i] = (row >> 1) & 7;
-  }
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    const int row = BM + wn * (BN / 4) + 16 * j + r16;
-    woff[j] = row * 128;
-    wswz[j] = (row >> 1) & 7;
-  }
+  // x fragment reads: lane (r16, q) of fragment i reads row 16 i + r16, slot (4 s + q) ^ swz(row)
+  int xoff = r16 * 128;                       // + 16 i * 128
+  const int xswz = (r16 >> 1) & 7;            // (16 i + r16) >> 1 & 7 == r16 >> 1 & 7
 
   f32x4 acc[FN][FM];
 #pragma unroll
@@ -96,37 +79,81 @@ __global__ __launch_bounds__(MG_THREADS) void mid_gemm_kernel(
 #pragma unroll
     for (int i = 0; i < FM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (nt > 0) stage(0, 0);
-  for (int t = 0; t < nt; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                       // tile t has landed; everyone has finished reading the other buffer
-    if (t + 1 < nt) stage((t + 1) & 1, t + 1);
-    const unsigned char* base = smem + (t & 1) * STAGE;
+  V8 wreg[3][FN][2], xreg[2][XL];
+  auto load_w = [&](int slot, int t) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      V8 a[FN], b[FM];
+    for (int j = 0; j < FN; ++j)
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
-        a[j] = *reinterpret_cast<const V8*>(base + woff[j] + (((4 * s + q) ^ wswz[j]) << 4));
+      for (int s = 0; s < 2; ++s) wreg[slot][j][s] = ld8(wsrc[j] + (long)t * MG_BK + 32 * s);
+  };
+  auto load_x = [&](int slot, int t) {
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
-        b[i] = *reinterpret_cast<const V8*>(base + xoff[i] + (((4 * s + q) ^ xswz[i]) << 4));
+    for (int i = 0; i < XL; ++i) xreg[slot][i] = ld8(xsrc[i] + (long)t * MG_BK);
+  };
+  auto write_x = [&](int slot, int stage) {
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
+    for (int i = 0; i < XL; ++i) *reinterpret_cast<V8*>(smem + stage * STAGE + xdst[i]) = xreg[slot][i];
+  };
+  // One K tile: 2 k-steps x FM row fragments, taken two fragments at a time.  The reads of pair p + 1
+  // are issued before the MFMAs of pair p, so an LDS round trip is covered by 2 * FN MFMAs of this
+  // wave plus whatever the SIMD's other wave issues.
+  auto compute = [&](int wslot, int stage) {
+    const unsigned char* base = smem + stage * STAGE + xoff;
+    constexpr int PAIRS = FM;                      // 2 k-steps * FM / 2
+    const int so0 = ((q) ^ xswz) << 4, so1 = ((4 + q) ^ xswz) << 4;
+    V8 b[2][2];
+    auto rd = [&](int p, V8 (&dst)[2]) {
+      const int s = p / (FM / 2), i = (p % (FM / 2)) * 2;
+      const int so = s ? so1 : so0;
+      dst[0] = *reinterpret_cast<const V8*>(base + i * 2048 + so);
+      dst[1] = *reinterpret_cast<const V8*>(base + (i + 1) * 2048 + so);
+    };
+    rd(0, b[0]);
 #pragma unroll
-        for (int i = 0; i < FM; ++i) acc[j][i] = mfma16(a[j], b[i], acc[j][i]);
+    for (int p = 0; p < PAIRS; ++p) {
+      if (p + 1 < PAIRS) rd(p + 1, b[(p + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);           // or the reads sink down to their first use
+      const int s = p / (FM / 2), i = (p % (FM / 2)) * 2;
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[j][i + e] = mfma16(wreg[wslot][j][s], b[p & 1][e], acc[j][i + e]);
+    }
+  };
+
+  // Loads and LDS writes are unconditional (past the end they repeat the last tile and are never
+  // used): a branch around a load would make the compiler's wait for it a full drain.
+  if (nt <= 0) return;                     // block-uniform; cannot happen for ksplit <= K / 64
+  const int last = nt - 1;
+  load_x(0, 0); load_w(0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  load_x(1, min(1, last)); load_w(1, min(1, last));
+  __builtin_amdgcn_sched_barrier(0);
+  write_x(0, 0);
+  __syncthreads();
+  for (int t = 0; t < nt; t += 6) {
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int tt = t + u;
+      if (tt >= nt) break;
+      load_x(u & 1, min(tt + 2, last));
+      load_w((u + 2) % 3, min(tt + 2, last));
+      __builtin_amdgcn_sched_barrier(0);     // keep the issue order the in-flight accounting relies on
+      compute(u % 3, u & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      write_x((u + 1) & 1, (u + 1) & 1);
+      __syncthreads();
     }
   }
 
-  // ---- epilogue: lane (r16, q) of fragment (j, i) holds y[m][n .. n+3], m = row r16 of x fragment i,
-  // n = 4q of W fragment j
+  // ---- epilogue: lane (r16, q) of fragment (j, i) holds y[m0 + 16 i + r16][n0 + 16 j + 4 q .. +4]
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
-    const int m = m0 + wm * (BM / 2) + 16 * i + r16;
+    const int m = m0 + 16 * i + r16;
     if (m >= M) continue;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      const int n = n0 + wn * (BN / 4) + 16 * j + 4 * q;
+      const int n = n0 + 16 * j + 4 * q;
       if (n >= N) continue;                  // N % 16 == 0: a fragment column group is all in or all out
       if (ksplit == 1) {
         typename Vec4<T>::type o;
@@ -155,12 +182,13 @@ __global__ void mid_reduce_kernel(T* __restrict__ out, long out_stride, const fl
   *reinterpret_cast<typename Vec4<T>::type*>(out + (long)m * out_stride + n) = o;
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int FN>
 int launch(const void* x, long xs, const void* w, long ws, void* out, long os, void* partial, int M, int N, int K,
            int ksplit, hipStream_t st) {
+  constexpr int BN = MG_WAVES * 16 * FN;
   const int ntn = (N + BN - 1) / BN;
   dim3 grid(ntn * ksplit, (M + BM - 1) / BM);
-  mid_gemm_kernel<T, BM, BN><<<grid, MG_THREADS, 0, st>>>((const T*)x, xs, (const T*)w, ws, (T*)out, os,
+  mid_gemm_kernel<T, BM, FN><<<grid, MG_THREADS, 0, st>>>((const T*)x, xs, (const T*)w, ws, (T*)out, os,
                                                           (float*)partial, M, N, K, ksplit);
   HIP_LAUNCH_CHECK();
   if (ksplit > 1) {
@@ -175,18 +203,18 @@ int launch(const void* x, long xs, const void* w, long ws, void* out, long os, v
 template <typename T>
 int dispatch(const void* x, long xs, const void* w, long ws, void* out, long os, void* partial, int M, int N, int K,
              int ksplit, int bm, int bn, hipStream_t st) {
-  if (bm == 256 && bn == 256) return launch<T, 256, 256>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st);
-  if (bm == 256 && bn == 128) return launch<T, 256, 128>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st);
-  if (bm == 128 && bn == 256) return launch<T, 128, 256>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st);
-  if (bm == 128 && bn == 128) return launch<T, 128, 128>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st);
-  if (bm == 64 && bn == 256) return launch<T, 64, 256>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st);
+#define MG_CASE(BM_, FN_)                                                                       \
+  if (bm == BM_ && bn == MG_WAVES * 16 * FN_)                                                   \
+    return launch<T, BM_, FN_>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st);
+  MG_CASE(256, 2) MG_CASE(256, 1) MG_CASE(128, 2) MG_CASE(128, 1) MG_CASE(64, 2) MG_CASE(64, 4)
+#undef MG_CASE
   return -4;
 }
 
 }  // namespace
 
 // out[M][N] = x[M][K] . w[N][K]^T.  K % 64 == 0, N % 16 == 0; strides in elements, multiples of 8;
-// pointers 16-byte aligned.  (bm, bn) is the workgroup tile: (256|128, 256|128) or (64, 256).
+// pointers 16-byte aligned.  (bm, bn) is the workgroup tile: (256, 128|256), (128, 128|256), (64, 256|512).
 // partial holds ksplit * M * N floats when ksplit > 1.
 VDAMD_API int vdamd_mid_gemm(void* out, long out_stride, const void* x, long x_stride, const void* w, long w_stride,
                              void* partial, int M, int N, int K, int ksplit, int bm, int bn, int dtype,

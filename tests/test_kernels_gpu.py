@@ -565,3 +565,82 @@ def test_fp8_kv_cache_engine_matches_bf16_greedy():
             la, lb = a.outputs[0].logprobs[0][ta], b.outputs[0].logprobs[0][tb]
             la, lb = getattr(la, "logprob", la), getattr(lb, "logprob", lb)
             assert abs(la - lb) < 0.25, (la, lb)
+
+
+# ------------------------------------------------------- decode GEMM kernels
+def _padded_weight(n, k, pad, dtype=torch.bfloat16):
+    buf = torch.zeros(n, k + pad, device=DEV, dtype=dtype)
+    buf[:, :k] = (torch.randn(n, k, device=DEV) * 0.05).to(dtype)
+    return buf[:, :k]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,n,k,pad", [(1, 4096, 4096, 0), (3, 1024, 8192, 128), (16, 6144, 4096, 128),
+                                       (7, 48, 256, 0), (16, 2064, 1152, 8), (2, 28672, 1024, 128)])
+def test_stream_gemm_matches_fp32(dtype, m, n, k, pad):
+    from vllm_distributed_amd.ops import hip
+    x = _rand(m, k, dtype=dtype)
+    w = _padded_weight(n, k, pad, dtype)
+    ref = x.float() @ w.float().t()
+    tol = dict(rtol=2e-2, atol=2e-2 * max(1.0, ref.abs().max().item()) / 4)
+    for ntw, ks, depth, nt in [(None, None, None, False), (1, 1, 2, True), (2, 2, 4, False), (2, 1, 3, True)]:
+        if ks is not None and ks > k // 128:
+            continue
+        got = hip.stream_gemm(x, w, ntw=ntw, ksplit=ks, depth=depth, nt=nt)
+        torch.testing.assert_close(got.float(), ref, **tol)
+    res = _rand(m, n, dtype=dtype)
+    got = hip.stream_gemm(x, w, residual=res)
+    torch.testing.assert_close(got.float(), ref + res.float(), **tol)
+    got = hip.stream_gemm(x, w, residual=res, ksplit=2) if k >= 256 else got
+    torch.testing.assert_close(got.float(), ref + res.float(), **tol)
+    if n % 32 == 0:
+        act = torch_ref.silu_and_mul(ref)
+        for ks in (1, 2):
+            if ks > k // 128:
+                continue
+            got = hip.stream_gemm(x, w, silu_mul=True, ksplit=ks)
+            torch.testing.assert_close(got.float(), act, rtol=3e-2, atol=3e-2 * max(1.0, act.abs().max().item()) / 4)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,n,k,pad", [(256, 2048, 2048, 128), (255, 1040, 1024, 0), (100, 4096, 4096, 128),
+                                       (17, 512, 8192, 128), (64, 272, 512, 8), (300, 1024, 1024, 128),
+                                       (48, 8192, 1024, 0)])
+def test_mid_gemm_matches_fp32(dtype, m, n, k, pad):
+    from vllm_distributed_amd.ops import hip
+    x = _rand(m, k, dtype=dtype)
+    w = _padded_weight(n, k, pad, dtype)
+    ref = x.float() @ w.float().t()
+    tol = dict(rtol=2e-2, atol=2e-2 * max(1.0, ref.abs().max().item()) / 4)
+    got = hip.mid_gemm(x, w)
+    torch.testing.assert_close(got.float(), ref, **tol)
+    for bm, bn in [(256, 256), (256, 128), (128, 256), (128, 128), (64, 256), (64, 512)]:
+        for ks in (1, 3, 4):
+            if ks > k // 64:
+                continue
+            got = hip.mid_gemm(x, w, bm=bm, bn=bn, ksplit=ks)
+            torch.testing.assert_close(got.float(), ref, **tol)
+    # strided output (a slice of a wider buffer), as the fused-collective path uses
+    wide = torch.zeros(m, n + 64, device=DEV, dtype=dtype)
+    hip.mid_gemm(x, w, out=wide[:, :n])
+    torch.testing.assert_close(wide[:, :n].float(), ref, **tol)
+    assert wide[:, n:].abs().sum() == 0
+
+
+def test_linear_dispatch_uses_hand_written_kernels_in_their_range(monkeypatch):
+    """ops.linear must reach the hand-written kernels where they are profitable, and agree with the
+    library on the same padded weight."""
+    from vllm_distributed_amd.ops import hip
+    calls = []
+    real_mid = hip.mid_gemm
+    monkeypatch.setattr(hip, "mid_gemm", lambda *a, **kw: (calls.append("mid"), real_mid(*a, **kw))[1])
+    w = _padded_weight(8192, 8192, 128)
+    for m in (64, 128, 256):
+        x = _rand(m, 8192)
+        y = ops.linear(x, w)
+        ref = torch.nn.functional.linear(x, w)
+        torch.testing.assert_close(y.float(), ref.float(), rtol=2e-2, atol=0.1)
+    assert calls == ["mid"] * 3
+    x = _rand(512, 8192)
+    ops.linear(x, w)
+    assert len(calls) == 3            # above the range: library

@@ -155,12 +155,14 @@ def linear(x, weight, bias=None, out=None):
     long-reduction shapes where the weight-streaming HIP kernel is faster.
     ``out`` (2-D ``x`` only): write the result there (e.g. straight into the
     buffer the following all-reduce reads)."""
-    if (x.is_cuda and x.dim() == 2 and x.shape[0] <= 128
-            and envs.VDAMD_SKINNY_GEMM and _use_hip(x)
-            and _hip.skinny_profitable(x.shape[0], weight.shape[0], weight.shape[1])
-            and _hip.skinny_supported(x, weight)):
-        y = _hip.skinny_gemm(x, weight, out=out)
-        return y if bias is None else y.add_(bias)
+    if x.is_cuda and x.dim() == 2 and x.shape[0] <= 256 and envs.VDAMD_SKINNY_GEMM and _use_hip(x):
+        m, n, k = x.shape[0], weight.shape[0], weight.shape[1]
+        if _hip.mid_profitable(m, n, k) and _hip.mid_supported(x, weight):
+            y = _hip.mid_gemm(x, weight, out=out)
+            return y if bias is None else y.add_(bias)
+        if m <= 128 and _hip.skinny_profitable(m, n, k) and _hip.skinny_supported(x, weight):
+            y = _hip.skinny_gemm(x, weight, out=out)
+            return y if bias is None else y.add_(bias)
     if out is not None and x.dim() == 2:
         if bias is None:
             return torch.mm(x, weight.t(), out=out)

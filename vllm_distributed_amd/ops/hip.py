@@ -35,6 +35,7 @@ def load() -> ctypes.CDLL:
         "vdamd_layer_norm": [P, P, P, P, F, I, I, I, P],
         "vdamd_silu_and_mul": [P, P, L, I, I, P],
         "vdamd_embedding": [P, P, P, I, I, I, I, I, P],
+        "vdamd_mid_gemm": [P, L, P, L, P, L, P, I, I, I, I, I, I, I, P],
         "vdamd_stream_gemm": [P, L, P, L, P, L, P, P, L, I, I, I, I, I, I, I, I, I, P],
         "vdamd_rope_cache": [P, P, P, P, L, L, L, P, P, P, P, I, I, I, I, I, I, P, P, F, I, I, P, P, P],
         "vdamd_paged_attention_decode": [P, P, P, L, P, P, P, I, P, F, I, I, I, I, I, I, L, I, I, P, P, P],
@@ -583,6 +584,84 @@ def stream_gemm(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = 
                                   None if residual is None else residual.data_ptr(),
                                   0 if residual is None else residual.stride(0), m, n, k, ksplit, ntw, depth,
                                   int(nt), epi, _dt(x), _stream()), "stream_gemm")
+    return out
+
+
+# ---------------------------------------- split-K LDS-DMA GEMM, 16 < M <= 512
+MID_MAX_M = 512
+
+
+def mid_supported(x: torch.Tensor, w: torch.Tensor) -> bool:
+    return (x.dim() == 2 and w.dim() == 2 and 0 < x.shape[0] <= MID_MAX_M and x.dtype == w.dtype
+            and x.dtype in (torch.bfloat16, torch.float16) and x.shape[1] == w.shape[1]
+            and w.shape[1] % 64 == 0 and w.shape[0] % 16 == 0 and x.stride(1) == 1 and w.stride(1) == 1
+            and x.stride(0) % 8 == 0 and w.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
+            and w.data_ptr() % 16 == 0)
+
+
+# measured time of one 64-deep K tile of one workgroup, us (70B o-projection, unsplit): the part of it
+# that does not shrink with the tile is the HBM latency the two-tile prefetch cannot cover
+_MID_TILE_US = {(256, 256): 1.6, (256, 128): 1.05, (128, 256): 1.2, (128, 128): 0.75, (64, 256): 1.0}
+
+
+def _mid_estimate(m: int, n: int, k: int, bm: int, bn: int, ksplit: int) -> float:
+    """Modelled run time in us: rounds of workgroups x K tiles x time per tile (at least the HBM time
+    of W), plus the fp32 slab round trip and the reduce launch when K is split."""
+    blocks = -(-n // bn) * ksplit * -(-m // bm)
+    rounds = -(-blocks // 256)
+    main = max(rounds * (k / 64 / ksplit) * _MID_TILE_US[(bm, bn)], n * k * 2 / 5.0e6)
+    slabs = (3.0 + 2 * ksplit * m * n * 4 / 3.5e6) if ksplit > 1 else 0.0
+    return 6.0 + main + slabs
+
+
+def mid_choose(m: int, n: int, k: int) -> Tuple[int, int, int]:
+    """``(bm, bn, ksplit)`` with the smallest modelled time.  The row tile covers all of M up to 256
+    (W is then read from HBM once); splitting K buys parallelism and costs slab traffic."""
+    best = None
+    for (bm, bn) in _MID_TILE_US:
+        if bm < min(m, 256) or (bm == 64 and m > 48 and k < 2 * n):
+            continue
+        for ksplit in (1, 2, 4, 8, 16):
+            if k // 64 // ksplit < 4:
+                break
+            e = _mid_estimate(m, n, k, bm, bn, ksplit)
+            if best is None or e < best[0]:
+                best = (e, bm, bn, ksplit)
+    return best[1], best[2], best[3]
+
+
+def mid_profitable(m: int, n: int, k: int) -> bool:
+    """Where this kernel beats the library GEMM on MI355X (benchmarks/stream_gemm_sweep.py, padded weight
+    rows): outputs too narrow to fill the chip with the library's tiles.  Down-projection shapes
+    (K >= 2 N) from 48 rows, square-ish ones from 128 rows (from 48 when K >= 8192 and N <= 8192);
+    very wide outputs (a 70B gate_up) stay with the library, which already has enough tiles there."""
+    if m <= 16 or m > 256 or n > 12288 or k < 2048:
+        return False
+    if k >= 2 * n:
+        return m >= 48
+    if m >= 128:
+        return True
+    return m >= 48 and n <= 8192 and k >= 8192
+
+
+def mid_gemm(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, ksplit: Optional[int] = None,
+             bm: Optional[int] = None, bn: Optional[int] = None) -> torch.Tensor:
+    """``x [M<=512, K] @ w [N, K]^T`` with W streamed once and K split over the chip."""
+    assert mid_supported(x, w), (x.shape, x.stride(), w.shape, w.stride(), x.dtype)
+    m, k = x.shape
+    n = w.shape[0]
+    a, b, c = mid_choose(m, n, k)
+    bm = a if bm is None else bm
+    bn = b if bn is None else bn
+    ksplit = c if ksplit is None else ksplit
+    assert 1 <= ksplit <= k // 64
+    if out is None:
+        out = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    assert out.shape == (m, n) and out.dtype == x.dtype and out.stride(1) == 1 and out.data_ptr() % 8 == 0
+    partial = torch.empty(ksplit * m * n, dtype=torch.float32, device=x.device) if ksplit > 1 else None
+    _check(_LIB.vdamd_mid_gemm(out.data_ptr(), out.stride(0), x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
+                               None if partial is None else partial.data_ptr(), m, n, k, ksplit, bm, bn, _dt(x),
+                               _stream()), "mid_gemm")
     return out
 
 
