@@ -190,8 +190,26 @@ def test_server_endpoints_end_to_end(frontend_mp):
                 assert (await c.post("/v1/chat/completions", headers=hdr, json={
                     "messages": [{"role": "user", "content": "hi"}],
                     "response_format": {"type": "json_schema", "json_schema": {}}})).status_code == 400
-                assert (await c.post("/v1/completions", headers=hdr, json={
-                    "prompt": "x", "guided_regex": "a|b"})).status_code == 400
+                # regular-expression and JSON-schema constraints (a DFA over the vocabulary's bytes)
+                rr = await c.post("/v1/completions", headers=hdr, json={
+                    "prompt": "x", "guided_regex": "(yes|no)!{1,2}", "max_tokens": 16, "seed": 3})
+                assert rr.status_code == 200, rr.text
+                assert rr.json()["choices"][0]["text"] in ("yes!", "yes!!", "no!", "no!!")
+                assert rr.json()["choices"][0]["finish_reason"] == "stop"
+                schema = {"type": "object", "required": ["a", "b"],
+                          "properties": {"a": {"type": "integer"}, "b": {"enum": ["x", "y"]}, "c": {"type": "boolean"}}}
+                for body in ({"response_format": {"type": "json_schema", "json_schema": {"name": "t", "schema": schema}}},
+                             {"guided_json": schema}, {"structured_outputs": {"json": schema}}):
+                    rg = await c.post("/v1/chat/completions", headers=hdr, json=dict(
+                        body, messages=[{"role": "user", "content": "hi"}], max_tokens=64, seed=4))
+                    assert rg.status_code == 200, rg.text
+                    got = json.loads(rg.json()["choices"][0]["message"]["content"])
+                    assert isinstance(got["a"], int) and got["b"] in ("x", "y") and set(got) <= {"a", "b", "c"}
+                for bad_body in ({"guided_regex": "(unclosed"}, {"guided_grammar": "root ::= x"},
+                                 {"guided_regex": "a", "guided_choice": ["a"]},
+                                 {"guided_json": {"type": "object", "properties": {"a": {"$ref": "http://x/y"}}}}):
+                    assert (await c.post("/v1/completions", headers=hdr, json=dict(
+                        bad_body, prompt="x"))).status_code == 400, bad_body
                 assert (await c.post("/v1/completions", headers=hdr, json={
                     "prompt": "x", "logprobs": 5000})).status_code == 400       # --max-logprobs (20)
                 gc = await c.post("/v1/chat/completions", headers=hdr, json={
@@ -216,8 +234,26 @@ def test_server_endpoints_end_to_end(frontend_mp):
                 assert "".join(f["function"].get("arguments", "") for f in frags) == call["function"]["arguments"]
                 assert (await c.post("/v1/chat/completions", headers=hdr, json=dict(
                     named, tool_choice={"type": "function", "function": {"name": "nope"}}))).status_code == 400
+                # tool_choice "required": the reply is a list of calls, arguments following each tool's schema
+                tool2 = {"type": "function", "function": {"name": "add", "parameters": {
+                    "type": "object", "required": ["x"], "properties": {"x": {"type": "integer"}}}}}
+                rq = await c.post("/v1/chat/completions", headers=hdr, json={
+                    "messages": [{"role": "user", "content": "hi"}], "max_tokens": 200, "seed": 5,
+                    "tools": [tool2], "tool_choice": "required", "logit_bias": {str(ord("]")): 6}})
+                assert rq.status_code == 200, rq.text
+                ch = rq.json()["choices"][0]
+                assert ch["finish_reason"] == "tool_calls" and ch["message"]["content"] is None
+                assert ch["message"]["tool_calls"] and all(
+                    tc["function"]["name"] == "add" and isinstance(json.loads(tc["function"]["arguments"])["x"], int)
+                    for tc in ch["message"]["tool_calls"])
+                rqs = await c.post("/v1/chat/completions", headers=hdr, json={
+                    "messages": [{"role": "user", "content": "hi"}], "max_tokens": 200, "seed": 5, "stream": True,
+                    "tools": [tool2], "tool_choice": "required", "logit_bias": {str(ord("]")): 6}})
+                evq = [json.loads(l[6:]) for l in rqs.text.split("\n\n") if l.startswith("data: ") and l != "data: [DONE]"]
+                assert any(e["choices"][0]["delta"].get("tool_calls") for e in evq)
+                assert evq[-1]["choices"][0]["finish_reason"] == "tool_calls"
                 assert (await c.post("/v1/chat/completions", headers=hdr, json=dict(
-                    named, tool_choice="required"))).status_code == 400
+                    named, tools=[], tool_choice="required"))).status_code == 400
                 r10 = await c.post("/v1/chat/completions", headers=hdr, json={
                     "messages": [{"role": "user", "content": "hi"}], "max_tokens": 2, "prompt_logprobs": 0})
                 pl = r10.json()["prompt_logprobs"]

@@ -264,3 +264,71 @@ def test_guided_choice_yields_exactly_one_of_the_strings():
         SamplingParams(guided_choice=[])
     llm.shutdown()
     pstate.destroy_model_parallel()
+
+
+def test_regex_dfa_agrees_with_python_re_and_masks_tokens():
+    """The byte-level DFA against Python's ``re`` on random strings; dead transitions are trimmed,
+    so a token is allowed exactly when some completion still matches."""
+    import random
+    import re
+    from vllm_distributed_amd.ops.grammar import RegexGrammar, TokenTable, compile_regex
+    rng = random.Random(0)
+    patterns = [r"(\d{3})-[a-c]+x?", r"(ab|a)(bc|c)?d*", r"[^a-y]{2,4}!", r"(?:foo|ba[rz]){1,3}", r"\w+@\w+\.(com|org)",
+                r"-?(0|[1-9][0-9]*)(\.[0-9]+)?", r'"([^"\\]|\\.)*"', r"a{0}b", r"x{2,}", r"\s*\S+\s*"]
+    alphabet = "abcdxyz019-!@. \"\\fo_r"
+    for pat in patterns:
+        rx = re.compile(pat.encode())
+        for _ in range(300):
+            s = "".join(rng.choice(alphabet) for _ in range(rng.randint(0, 9))).encode()
+            g = RegexGrammar(pat)
+            ok = g.advance(s)
+            assert (ok and g.may_stop) == (rx.fullmatch(s) is not None), (pat, s)
+    g = RegexGrammar(r"(\d{3})-[a-c]+x?")
+    assert g.advance(b"12") and not g.may_stop and g.advance(b"3-ab") and g.may_stop and not g.done
+    assert not g.advance(b"d") and g.state >= 0 and g.advance(b"x") and g.done
+    toks = [b"1", b"12", b"1234", b"-", b"a", b"", b"12-", b"123-a", b"9x"]
+    t = TokenTable(toks, len(toks))
+    assert RegexGrammar(r"(\d{3})-[a-c]+x?").mask(t).tolist() == [1, 1, 0, 0, 0, 0, 0, 1, 0]
+    g = RegexGrammar(r"(\d{3})-[a-c]+x?")
+    g.advance(b"12")
+    assert g.mask(t).tolist() == [1, 0, 0, 0, 0, 0, 0, 0, 0]
+    for bad in ["(", "a{5,2}", "[z-a]", "\\p", "a(?=b)", "a{200000}", "(a{1000}){1000}"]:
+        with pytest.raises(ValueError):
+            compile_regex(bad)
+    assert compile_regex("é+").num_states >= 2       # UTF-8 literals are byte sequences
+
+
+def test_json_schema_lowering_accepts_and_rejects():
+    import json
+    from vllm_distributed_amd.ops.grammar import RegexGrammar, json_schema_to_regex
+    from vllm_distributed_amd.sampling_params import SamplingParams
+    schema = {"type": "object", "properties": {
+        "name": {"type": "string", "minLength": 1}, "age": {"type": "integer"},
+        "tags": {"type": "array", "items": {"enum": ["a", "b"]}, "minItems": 1, "maxItems": 3},
+        "addr": {"$ref": "#/$defs/addr"}, "when": {"type": "string", "format": "date"},
+        "v": {"anyOf": [{"type": "number"}, {"type": "null"}]}},
+        "required": ["name", "tags"],
+        "$defs": {"addr": {"type": "object", "required": ["zip"],
+                           "properties": {"zip": {"type": "string", "pattern": "^[0-9]{5}$"}}}}}
+    rx = json_schema_to_regex(schema)
+    good = ['{"name":"x","tags":["a"]}', '{"name": "y\\n", "age": -12, "tags": ["a", "b"], "addr": {"zip": "12345"}}',
+            '{"name":"é","tags":["b","b","a"],"when":"2024-01-31","v":null}', '{"name":"q","tags":["a"],"v":-1.5e3}']
+    bad = ['{"name":"x"}', '{"tags":["a"],"name":"x"}', '{"name":"x","tags":[]}', '{"name":"x","tags":["c"]}',
+           '{"name":"","tags":["a"]}', '{"name":"x","tags":["a","a","a","a"]}',
+           '{"name":"x","tags":["a"],"addr":{"zip":"1234"}}', '{"name":"x","tags":["a"],"extra":1}']
+    for s in good:
+        json.loads(s)
+        g = RegexGrammar(rx)
+        assert g.advance(s.encode()) and g.may_stop, s
+    for s in bad:
+        g = RegexGrammar(rx)
+        assert not (g.advance(s.encode()) and g.may_stop), s
+    g = RegexGrammar(json_schema_to_regex({}))                # no type: any JSON value
+    assert g.advance(b'{"a": [1, {"b": null}]}') and g.may_stop
+    sp = SamplingParams(guided_json=schema)
+    assert sp.guided_regex == rx and sp.guided_json is None and sp.has_logit_adjust
+    for broken in ({"type": "object", "properties": {"a": {"$ref": "http://x"}}}, {"type": "frob"}, {"enum": []}):
+        with pytest.raises(ValueError):
+            SamplingParams(guided_json=broken)
+    with pytest.raises(ValueError):
+        SamplingParams(guided_regex="a", json_object=True)

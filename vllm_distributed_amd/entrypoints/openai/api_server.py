@@ -295,14 +295,7 @@ def _sampling_params(req, default_max: Optional[int], max_model_len: int, logpro
             return defaults.get(name, fallback)
         return v
     extra = req.model_extra or {}
-    unsupported = [k for k in ("guided_json", "guided_regex", "guided_grammar", "structured_outputs")
-                   if extra.get(k) is not None]
-    if unsupported:      # refusing beats silently generating unconstrained text
-        raise ValueError(f"{', '.join(unsupported)}: guided decoding beyond response_format json_object and "
-                         f"guided_choice is not supported")
-    rf = (req.response_format or {}).get("type", "text")
-    if rf not in ("text", "json_object"):
-        raise ValueError(f"response_format type {rf!r} is not supported (text, json_object)")
+    guided = _guided_options(req, extra)
     max_tokens = getattr(req, "max_completion_tokens", None) or (
         req.max_tokens if "max_tokens" in given else None) or defaults.get("max_tokens") or req.max_tokens \
         or default_max
@@ -314,10 +307,44 @@ def _sampling_params(req, default_max: Optional[int], max_model_len: int, logpro
         stop_token_ids=req.stop_token_ids, ignore_eos=req.ignore_eos, logprobs=logprobs,
         skip_special_tokens=req.skip_special_tokens, logit_bias=req.logit_bias,
         allowed_token_ids=req.allowed_token_ids, bad_words=req.bad_words,
-        truncate_prompt_tokens=req.truncate_prompt_tokens, json_object=rf == "json_object",
-        guided_choice=extra.get("guided_choice"),
+        truncate_prompt_tokens=req.truncate_prompt_tokens, **guided,
         prompt_logprobs=(req.prompt_logprobs if req.prompt_logprobs is not None else
                          logprobs if getattr(req, "echo", False) and not req.stream else None))
+
+
+def _guided_options(req, extra: Dict[str, Any]) -> Dict[str, Any]:
+    """The one output constraint a request asks for, as SamplingParams fields.  Accepted spellings:
+    ``response_format`` (json_object, json_schema), vLLM's ``guided_json`` / ``guided_regex`` /
+    ``guided_choice`` and the ``structured_outputs`` object carrying ``json`` / ``regex`` /
+    ``choice`` / ``json_object``.  Context-free grammars are refused: refusing beats silently
+    generating unconstrained text."""
+    so = extra.get("structured_outputs") or {}
+    if not isinstance(so, dict):
+        raise ValueError("structured_outputs must be an object")
+    if extra.get("guided_grammar") is not None or so.get("grammar") is not None:
+        raise ValueError("guided_grammar: context-free grammars are not supported "
+                         "(use a JSON schema, a regular expression or a choice list)")
+    out: Dict[str, Any] = {}
+    rf = req.response_format or {}
+    kind = rf.get("type", "text")
+    if kind == "json_object" or so.get("json_object") or extra.get("guided_json_object"):
+        out["json_object"] = True
+    elif kind == "json_schema":
+        js = rf.get("json_schema") or {}
+        schema = js.get("schema", js.get("json_schema"))
+        if schema is None:
+            raise ValueError("response_format json_schema needs json_schema.schema")
+        out["guided_json"] = schema
+    elif kind != "text":
+        raise ValueError(f"response_format type {kind!r} is not supported (text, json_object, json_schema)")
+    for field, keys in (("guided_json", ("guided_json", "json")), ("guided_regex", ("guided_regex", "regex")),
+                        ("guided_choice", ("guided_choice", "choice"))):
+        val = extra.get(keys[0]) if extra.get(keys[0]) is not None else so.get(keys[1])
+        if val is not None:
+            out[field] = val
+    if len(out) > 1:
+        raise ValueError(f"a request can carry one output constraint, got {sorted(out)}")
+    return out
 
 
 def _prompt_logprobs_json(tok, plps) -> Optional[list]:
@@ -618,7 +645,8 @@ def _register_routes(app: FastAPI, dev_mode: bool = False) -> None:
             if not forced_tool or forced_tool not in known:
                 return _error(f"tool_choice names {forced_tool!r}, which is not one of the request's tools")
         elif req.tool_choice == "required":
-            return _error("tool_choice 'required' is not supported (use 'auto', 'none' or a named function)")
+            if not req.tools:
+                return _error("tool_choice 'required' needs a non-empty tools list")
         try:
             kwargs = dict(req.chat_template_kwargs or {})
             if req.chat_template and not getattr(st.args, "trust_request_chat_template", False):
@@ -639,12 +667,28 @@ def _register_routes(app: FastAPI, dev_mode: bool = False) -> None:
             sp = _sampling_params(req, None, st.max_model_len, n_lp, st.default_sampling, st.max_logprobs)
         except ValueError as e:
             return _error(str(e))
-        if forced_tool:
-            sp.json_object = True
+        required_tools = req.tool_choice == "required"
+        try:
+            if forced_tool:
+                # the arguments follow the tool's parameter schema when it has one
+                fn = next((t.get("function") or {}) for t in req.tools
+                          if (t.get("function") or {}).get("name") == forced_tool)
+                sp = _constrain(sp, fn.get("parameters"))
+            elif required_tools:
+                # the reply is a JSON array of at least one {"name", "parameters"} call
+                calls = [{"type": "object", "required": ["name", "parameters"], "properties": {
+                    "name": {"const": (t.get("function") or {}).get("name")},
+                    "parameters": (t.get("function") or {}).get("parameters") or {"type": "object"}}}
+                    for t in req.tools]
+                sp = _constrain(sp, {"type": "array", "minItems": 1, "items": {"anyOf": calls}})
+        except ValueError as e:
+            return _error(str(e))
         model = req.model or st.served_names[0]
         rid = "chatcmpl-" + uuid.uuid4().hex
         created = int(time.time())
-        parser = st.tool_parser if tools and not forced_tool else None
+        parser = st.tool_parser if tools and not forced_tool and not required_tools else None
+        if required_tools:
+            parser = _RequiredToolsParser()
         from .tool_parsers import _call_id
         gens = [engine.generate({"prompt": prompt, "prompt_token_ids": prompt_ids}, _nth_params(sp, j),
                                 rid if n == 1 else f"{rid}-{j}", req.priority,
@@ -697,7 +741,8 @@ def _register_routes(app: FastAPI, dev_mode: bool = False) -> None:
                     if parser is not None:
                         # tool-call syntax must be parsed as a whole: hold text once a call starts
                         held += text
-                        if "<tool_call>" in held or held.lstrip().startswith(("{", "<|python_tag|>")):
+                        if required_tools or "<tool_call>" in held or \
+                                held.lstrip().startswith(("{", "<|python_tag|>")):
                             text = ""
                         else:
                             text, held = held, ""
@@ -804,6 +849,34 @@ def _register_routes(app: FastAPI, dev_mode: bool = False) -> None:
         return body
 
 
+def _constrain(sp: SamplingParams, schema) -> SamplingParams:
+    """``sp`` with its output held to ``schema`` (a plain JSON object when there is none)."""
+    import dataclasses
+    if sp.guided_regex is not None or sp.guided_choice is not None:
+        raise ValueError("tool_choice cannot be combined with another output constraint")
+    if sp.json_object and schema:
+        raise ValueError("tool_choice cannot be combined with response_format json_object")
+    if not schema or schema == {"type": "object"}:
+        return dataclasses.replace(sp, json_object=True)
+    return dataclasses.replace(sp, guided_json=schema)
+
+
+class _RequiredToolsParser:
+    """Reads the constrained reply of ``tool_choice: "required"``: a JSON array of calls."""
+
+    def extract(self, text: str, tools) -> tuple:
+        from .tool_parsers import _call_id
+        try:
+            items = json.loads(text)
+        except json.JSONDecodeError:
+            return text, []               # cut off by max_tokens: hand back what there is
+        calls = [{"id": _call_id(), "type": "function",
+                  "function": {"name": it.get("name"),
+                               "arguments": json.dumps(it.get("parameters", {}), ensure_ascii=False)}}
+                 for it in items if isinstance(it, dict)]
+        return None, calls
+
+
 # ------------------------------------------------------------------- run
 async def run_server(args: argparse.Namespace, client_config: Optional[dict] = None, **uvicorn_kwargs) -> None:
     from ..launcher import serve_http
@@ -829,8 +902,9 @@ async def run_server(args: argparse.Namespace, client_config: Optional[dict] = N
             ssl_keyfile=getattr(args, "ssl_keyfile", None), ssl_certfile=getattr(args, "ssl_certfile", None),
             ssl_ca_certs=getattr(args, "ssl_ca_certs", None),
             ssl_cert_reqs=getattr(args, "ssl_cert_reqs", 0), **uvicorn_kwargs)
-        try:
-            await shutdown_task
-        finally:
-            pass
-    sock.close()
+    # the server's shutdown completes only after the engine context has been left
+    # (reference src/launch.py:453-457)
+    try:
+        await shutdown_task
+    finally:
+        sock.close()

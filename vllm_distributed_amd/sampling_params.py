@@ -2,7 +2,7 @@
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Union
+from typing import Any, Dict, List, Optional, Union
 
 
 @dataclass
@@ -33,6 +33,8 @@ class SamplingParams:
     truncate_prompt_tokens: Optional[int] = None         # keep only the last k prompt tokens
     json_object: bool = False                            # constrain the output to one JSON object
     guided_choice: Optional[List[str]] = None            # the output is exactly one of these strings
+    guided_regex: Optional[str] = None                   # the output matches this regular expression
+    guided_json: Optional[Any] = None                    # the output is JSON satisfying this schema (dict or str)
     # filled by the engine: the model's EOS id (the only token allowed once a constrained output is complete)
     eos_token_id: Optional[int] = None
     # filled by the engine: EOS + stop token ids, masked until ``min_tokens`` outputs exist
@@ -95,6 +97,20 @@ class SamplingParams:
                 raise ValueError("guided_choice must be a non-empty list of non-empty strings")
             if self.json_object:
                 raise ValueError("guided_choice and JSON mode exclude each other")
+        if self.guided_json is not None:
+            # a schema is served as the regular expression of its compact JSON texts
+            if self.guided_regex is not None and not getattr(self, "_lowered", False):
+                raise ValueError("guided_json and guided_regex exclude each other")
+            from .ops.grammar import json_schema_to_regex
+            self.guided_regex = json_schema_to_regex(self.guided_json)
+            self.guided_json = None
+        if self.guided_regex is not None:
+            if self.json_object or self.guided_choice is not None:
+                raise ValueError("a request can carry one output constraint")
+            if not isinstance(self.guided_regex, str) or not self.guided_regex:
+                raise ValueError("guided_regex must be a non-empty string")
+            from .ops.grammar import compile_regex
+            compile_regex(self.guided_regex)          # ValueError for what the automaton cannot express
         if self.truncate_prompt_tokens is not None and self.truncate_prompt_tokens < 1:
             raise ValueError("truncate_prompt_tokens must be >= 1")
         if self.prompt_logprobs is not None and self.prompt_logprobs < 0:
@@ -115,7 +131,7 @@ class SamplingParams:
     def has_logit_adjust(self) -> bool:
         """True when logits must be edited before sampling (bias, allow / ban lists, min_tokens)."""
         return bool(self.logit_bias or self.allowed_token_ids is not None or self.bad_words_token_ids
-                    or self.json_object or self.guided_choice
+                    or self.json_object or self.guided_choice or self.guided_regex
                     or (self.min_tokens > 0 and self.min_tokens_ban_ids))
 
     def check_vocab(self, vocab_size: int) -> None:

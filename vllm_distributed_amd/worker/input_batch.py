@@ -99,6 +99,9 @@ class InputBatch:
         elif sp.guided_choice:
             from ..ops.grammar import ChoiceGrammar
             self.grammar[row] = ChoiceGrammar(sp.guided_choice)
+        elif sp.guided_regex:
+            from ..ops.grammar import RegexGrammar
+            self.grammar[row] = RegexGrammar(sp.guided_regex)
         self.num_logprobs[row] = -1 if sp.logprobs is None else sp.logprobs
         self.lora_id[row] = lora_id
         self.req_ids[row] = req_id
