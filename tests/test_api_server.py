@@ -254,6 +254,66 @@ def test_server_endpoints_end_to_end(frontend_mp):
                 assert evq[-1]["choices"][0]["finish_reason"] == "tool_calls"
                 assert (await c.post("/v1/chat/completions", headers=hdr, json=dict(
                     named, tools=[], tool_choice="required"))).status_code == 400
+                # embeddings / pooling / scoring: a prefill whose pooled hidden state comes back
+                em = await c.post("/v1/embeddings", headers=hdr, json={"input": ["hello world", "hello world", "zq"]})
+                assert em.status_code == 200, em.text
+                ed = em.json()["data"]
+                assert [d["index"] for d in ed] == [0, 1, 2] and ed[0]["object"] == "embedding"
+                assert ed[0]["embedding"] == ed[1]["embedding"] != ed[2]["embedding"]
+                assert abs(sum(x * x for x in ed[0]["embedding"]) - 1.0) < 1e-4
+                assert em.json()["usage"]["prompt_tokens"] > 0
+                import base64
+                import struct
+                eb = await c.post("/v1/embeddings", headers=hdr, json={
+                    "input": "hello world", "encoding_format": "base64", "dimensions": 8})
+                raw = base64.b64decode(eb.json()["data"][0]["embedding"])
+                assert len(raw) == 32 and abs(sum(x * x for x in struct.unpack("<8f", raw)) - 1.0) < 1e-4
+                pm = await c.post("/pooling", headers=hdr, json={"input": [[1, 2, 3, 4]], "pooling_type": "mean"})
+                assert pm.status_code == 200 and pm.json()["data"][0]["object"] == "pooling"
+                assert abs(sum(x * x for x in pm.json()["data"][0]["data"]) - 1.0) > 1e-3      # raw, not normalised
+                sc = await c.post("/score", headers=hdr, json={"text_1": "hello", "text_2": ["hello", "zzz other"]})
+                assert sc.status_code == 200, sc.text
+                scores = [d["score"] for d in sc.json()["data"]]
+                assert abs(scores[0] - 1.0) < 1e-4 and scores[1] < 0.999
+                assert (await c.post("/v1/score", headers=hdr, json={
+                    "text_1": ["a", "b", "c"], "text_2": ["a", "b"]})).status_code == 400
+                assert (await c.post("/v1/embeddings", headers=hdr, json={"input": []})).status_code == 400
+                assert (await c.post("/v1/embeddings", json={"input": "x"})).status_code == 401
+                # the Responses API rides on the chat pipeline
+                rp = await c.post("/v1/responses", headers=hdr, json={
+                    "input": "hi", "instructions": "be brief", "max_output_tokens": 5, "temperature": 0})
+                assert rp.status_code == 200, rp.text
+                ro = rp.json()
+                assert ro["object"] == "response" and ro["status"] in ("completed", "incomplete")
+                assert ro["output"][0]["type"] == "message" and ro["output"][0]["content"][0]["type"] == "output_text"
+                assert ro["output_text"] == ro["output"][0]["content"][0]["text"]
+                assert ro["usage"]["output_tokens"] == 5 and ro["usage"]["input_tokens"] > 0
+                assert (await c.get(f"/v1/responses/{ro['id']}", headers=hdr)).json()["output"] == ro["output"]
+                r2 = await c.post("/v1/responses", headers=hdr, json={
+                    "input": [{"type": "message", "role": "user", "content": [{"type": "input_text", "text": "more"}]}],
+                    "previous_response_id": ro["id"], "max_output_tokens": 3, "temperature": 0})
+                assert r2.status_code == 200 and r2.json()["usage"]["input_tokens"] > ro["usage"]["input_tokens"]
+                rs = await c.post("/v1/responses", headers=hdr, json={
+                    "input": "hi", "max_output_tokens": 5, "temperature": 0, "stream": True, "ignore_eos": True})
+                kinds = [l.split("\n")[0][7:] for l in rs.text.split("\n\n") if l.startswith("event: ")]
+                assert kinds[0] == "response.created" and kinds[-1] in ("response.completed", "response.incomplete")
+                assert "response.output_text.delta" in kinds and "response.output_item.done" in kinds
+                last = json.loads(rs.text.split("\n\n")[-2].split("\n")[1][6:])
+                assert last["response"]["usage"]["output_tokens"] == 5
+                deltas = [json.loads(l.split("\n")[1][6:])["delta"] for l in rs.text.split("\n\n")
+                          if l.startswith("event: response.output_text.delta")]
+                assert "".join(deltas) == last["response"]["output_text"]
+                rt2 = await c.post("/v1/responses", headers=hdr, json={
+                    "input": "hi", "max_output_tokens": 120, "seed": 5, "tool_choice": "required",
+                    "tools": [{"type": "function", "name": "add", "parameters": {
+                        "type": "object", "required": ["x"], "properties": {"x": {"type": "integer"}}}}],
+                    "logit_bias": {str(ord("]")): 6}})
+                assert rt2.status_code == 200, rt2.text
+                assert any(it["type"] == "function_call" and it["name"] == "add" for it in rt2.json()["output"])
+                assert (await c.delete(f"/v1/responses/{ro['id']}", headers=hdr)).json()["deleted"] is True
+                assert (await c.get(f"/v1/responses/{ro['id']}", headers=hdr)).status_code == 404
+                assert (await c.post("/v1/responses", headers=hdr, json={
+                    "input": "x", "previous_response_id": "resp_nope"})).status_code == 400
                 r10 = await c.post("/v1/chat/completions", headers=hdr, json={
                     "messages": [{"role": "user", "content": "hi"}], "max_tokens": 2, "prompt_logprobs": 0})
                 pl = r10.json()["prompt_logprobs"]

@@ -245,3 +245,30 @@ def test_fp8_kv_cache_reference_ops_and_engine_cpu():
     assert len(out[0].outputs[0].token_ids) == 6
     with pytest.raises(ValueError):
         LLM(model="llama-tiny", device="cpu", kv_cache_dtype="fp8_e5m2")
+
+
+def test_pooling_requests_last_and_mean_chunked_equals_unchunked():
+    """Embedding-style requests: the pooled final hidden state is the same whether the prompt runs as
+    one chunk or several (a 16-token step budget), and rides along with ordinary generation."""
+    import numpy as np
+    from vllm_distributed_amd import LLM, SamplingParams
+    prompts = [{"prompt_token_ids": list(range(5, 45))}, {"prompt_token_ids": [7, 8, 9]}]
+    kw = dict(model="llama-tiny", device="cpu", dtype="float32", max_model_len=128, num_gpu_blocks_override=64,
+              max_num_seqs=4)
+    small = LLM(max_num_batched_tokens=16, **kw)
+    whole = LLM(**kw)
+    for mode in ("last", "mean"):
+        a, b = small.encode(prompts, mode), whole.encode(prompts, mode)
+        assert len(a[0]) == 256
+        np.testing.assert_allclose(np.array(a), np.array(b), rtol=1e-4, atol=1e-5)
+    assert not np.allclose(small.encode(prompts, "last")[0], small.encode(prompts, "mean")[0])
+    e = whole.embed(prompts)
+    assert abs(sum(x * x for x in e[0]) - 1.0) < 1e-6
+    s = whole.score("hello", ["hello", "something else"])
+    assert abs(s[0] - 1.0) < 1e-6 and s[1] < 0.9999
+    # pooled and generating requests in the same batch
+    outs = whole.generate(prompts, [SamplingParams(pooling="mean"), SamplingParams(max_tokens=4, temperature=0.0)])
+    assert outs[0].pooled is not None and len(outs[0].outputs[0].token_ids) == 1
+    assert outs[1].pooled is None and len(outs[1].outputs[0].token_ids) == 4
+    with pytest.raises(ValueError):
+        SamplingParams(pooling="max")

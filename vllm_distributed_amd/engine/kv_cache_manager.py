@@ -132,7 +132,8 @@ class KVCacheManager:
     def get_computed_blocks(self, request: Request) -> Tuple[List[KVCacheBlock], int]:
         """Longest cached prefix of the request's tokens.  Never covers the whole
         sequence: at least one token must be computed to produce logits."""
-        if not self.enable_caching or request.sampling_params.prompt_logprobs is not None:
+        if (not self.enable_caching or request.sampling_params.prompt_logprobs is not None
+                or request.sampling_params.pooling == "mean"):
             return [], 0          # prompt logprobs need every prompt position computed
         self._extend_hashes(request, request.num_tokens)
         max_hit_blocks = (request.num_tokens - 1) // self.block_size

@@ -27,7 +27,7 @@ logger = init_logger(__name__)
 
 class _ReqState:
     __slots__ = ("request", "detok", "prompt", "cumulative_logprob", "logprobs", "finish_reason",
-                 "stop_reason", "prompt_logprobs")
+                 "stop_reason", "prompt_logprobs", "pooled")
 
     def __init__(self, request: Request, detok: Optional[IncrementalDetokenizer], prompt: Optional[str]):
         self.request = request
@@ -38,6 +38,7 @@ class _ReqState:
         self.finish_reason: Optional[str] = None
         self.stop_reason = None
         self.prompt_logprobs = None
+        self.pooled = None
 
 
 class LLMEngine:
@@ -183,6 +184,8 @@ class LLMEngine:
                         st.cumulative_logprob = (st.cumulative_logprob or 0.0) + lp[tok]
             if co.prompt_logprobs is not None:
                 st.prompt_logprobs = co.prompt_logprobs
+            if co.pooled is not None:
+                st.pooled = co.pooled
             finished = finish_reason is not None
             new_text = st.detok.take_delta(finished) if st.detok is not None else ""
             # the live list while the request runs (no per-step copy); a snapshot once it is final
@@ -194,7 +197,7 @@ class LLMEngine:
                                       prompt_token_ids=req.prompt_token_ids, outputs=[comp],
                                       finished=finished, metrics=req.metrics,
                                       new_token_ids=co.new_token_ids, new_text=new_text,
-                                      prompt_logprobs=st.prompt_logprobs))
+                                      prompt_logprobs=st.prompt_logprobs, pooled=st.pooled))
             if finished:
                 if req.metrics.finished_time is None:
                     req.metrics.finished_time = time.time()
@@ -241,5 +244,35 @@ class LLM:
                                                            add_generation_prompt=True, tools=tools)
         return self.generate([prompt], sampling_params)
 
+    def encode(self, prompts, pooling: str = "last", normalize: bool = False, lora_request=None) -> List[List[float]]:
+        """Pooled final hidden state of each prompt ("last" token or "mean" over the prompt)."""
+        outs = self.generate(prompts, SamplingParams(pooling=pooling, temperature=0.0, detokenize=False),
+                             lora_request)
+        vecs = [o.pooled for o in outs]
+        if normalize:
+            vecs = [l2_normalize(v) for v in vecs]
+        return vecs
+
+    def embed(self, prompts, lora_request=None) -> List[List[float]]:
+        """Unit-length last-token embeddings (the default pooling of a causal LM used as an embedder)."""
+        return self.encode(prompts, "last", True, lora_request)
+
+    def score(self, text_1, text_2) -> List[float]:
+        """Cosine similarity of the embeddings of ``text_1[i]`` and ``text_2[i]`` (one ``text_1`` is
+        paired with every ``text_2``)."""
+        a = [text_1] if isinstance(text_1, str) else list(text_1)
+        b = [text_2] if isinstance(text_2, str) else list(text_2)
+        if len(a) == 1:
+            a = a * len(b)
+        if len(a) != len(b):
+            raise ValueError("text_1 must hold one entry, or as many as text_2")
+        vecs = self.embed(a + b)
+        return [float(sum(x * y for x, y in zip(vecs[i], vecs[len(a) + i]))) for i in range(len(a))]
+
     def shutdown(self) -> None:
         self.engine.shutdown()
+
+
+def l2_normalize(v: List[float]) -> List[float]:
+    n = sum(x * x for x in v) ** 0.5
+    return [x / n for x in v] if n > 0 else list(v)

@@ -42,6 +42,7 @@ class EngineCoreOutput:
     num_cached_tokens: int = 0
     # with the first output token of a request that asked: one entry per prompt token (None for the first)
     prompt_logprobs: Optional[List[Optional[Dict[int, float]]]] = None
+    pooled: Optional[List[float]] = None
 
 
 @dataclass
@@ -380,6 +381,8 @@ class Scheduler:
                 rid, accepted, req.status.finish_reason if finished else None, req.stop_reason,
                 req_lps[:len(accepted)] if req_lps else None,
                 req.num_cached_tokens if req.num_cached_tokens > 0 else 0))
+            if runner_output.pooled and rid in runner_output.pooled:
+                outputs[-1].pooled = runner_output.pooled[rid]
             if req.prompt_logprobs is not None:
                 got = req.prompt_logprobs
                 outputs[-1].prompt_logprobs = [got.get(i) for i in range(req.num_prompt_tokens)]

@@ -70,6 +70,8 @@ class ModelRunnerOutput:
     # optional: req_id -> (position of the first prompt token covered, [{token_id: logprob}, ...]) for the
     # prompt tokens this step's prefill chunk predicted (requests with ``prompt_logprobs`` only)
     prompt_logprobs: Optional[Dict[str, Any]] = None
+    # req_id -> pooled final hidden state (float32 list) for requests with ``pooling`` that finished their prompt
+    pooled: Optional[Dict[str, List[float]]] = None
     # KV-transfer completion sets (aggregated over workers by KVOutputAggregator)
     finished_sending: Optional[Set[str]] = None
     finished_recving: Optional[Set[str]] = None

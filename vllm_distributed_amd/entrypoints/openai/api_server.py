@@ -849,6 +849,11 @@ def _register_routes(app: FastAPI, dev_mode: bool = False) -> None:
         return body
 
 
+    from . import pooling_routes, responses_routes
+    pooling_routes.register(app, _error, _check_model)
+    responses_routes.register(app, chat_completions, ChatCompletionRequest, _error)
+
+
 def _constrain(sp: SamplingParams, schema) -> SamplingParams:
     """``sp`` with its output held to ``schema`` (a plain JSON object when there is none)."""
     import dataclasses

@@ -50,3 +50,5 @@ class RequestOutput:
     new_text: str = ""
     # one {token_id: logprob} per prompt token (None for the first), when ``prompt_logprobs`` was requested
     prompt_logprobs: Optional[List[Optional[Dict[int, float]]]] = None
+    # pooled final hidden state of the prompt (requests with ``SamplingParams.pooling``), once finished
+    pooled: Optional[List[float]] = None

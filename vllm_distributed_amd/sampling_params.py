@@ -33,6 +33,9 @@ class SamplingParams:
     truncate_prompt_tokens: Optional[int] = None         # keep only the last k prompt tokens
     json_object: bool = False                            # constrain the output to one JSON object
     guided_choice: Optional[List[str]] = None            # the output is exactly one of these strings
+    # "last" | "mean": return the pooled final hidden state of the prompt (embeddings, scoring)
+    # with the request's single output token; the request then ends after that token
+    pooling: Optional[str] = None
     guided_regex: Optional[str] = None                   # the output matches this regular expression
     guided_json: Optional[Any] = None                    # the output is JSON satisfying this schema (dict or str)
     # filled by the engine: the model's EOS id (the only token allowed once a constrained output is complete)
@@ -97,6 +100,10 @@ class SamplingParams:
                 raise ValueError("guided_choice must be a non-empty list of non-empty strings")
             if self.json_object:
                 raise ValueError("guided_choice and JSON mode exclude each other")
+        if self.pooling is not None:
+            if self.pooling not in ("last", "mean"):
+                raise ValueError("pooling must be 'last' or 'mean'")
+            self.max_tokens, self.min_tokens, self.logprobs = 1, 0, None
         if self.guided_json is not None:
             # a schema is served as the regular expression of its compact JSON texts
             if self.guided_regex is not None and not getattr(self, "_lowered", False):

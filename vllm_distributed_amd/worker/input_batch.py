@@ -45,6 +45,7 @@ class InputBatch:
         self.num_logprobs = np.full(n, -1, dtype=np.int32)
         self.has_penalty = np.zeros(n, dtype=bool)
         self.num_prompt_logprobs = np.full(n, -1, dtype=np.int32)
+        self.pooling = np.zeros(n, dtype=np.int8)           # 0 none, 1 last token, 2 mean over the prompt
         self.has_adjust = np.zeros(n, dtype=bool)             # logit bias / allow / ban lists / min_tokens
         self.lora_id = np.zeros(n, dtype=np.int32)              # 0 = base model
         self.req_ids: List[Optional[str]] = [None] * n
@@ -91,6 +92,7 @@ class InputBatch:
         self.has_penalty[row] = sp.has_penalties
         self.has_adjust[row] = sp.has_logit_adjust
         self.num_prompt_logprobs[row] = -1 if sp.prompt_logprobs is None else sp.prompt_logprobs
+        self.pooling[row] = {None: 0, "last": 1, "mean": 2}[sp.pooling]
         self.grammar[row] = None
         self.grammar_pos[row] = 0
         if sp.json_object:
@@ -132,6 +134,7 @@ class InputBatch:
         self.lora_id[row] = 0
         self.has_adjust[row] = False
         self.num_prompt_logprobs[row] = -1
+        self.pooling[row] = 0
         self.grammar[row] = None
         self.has_penalty[row] = False
         self._free_rows.append(row)

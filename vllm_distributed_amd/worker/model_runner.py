@@ -82,7 +82,7 @@ class PendingSample:
     lazy_step_result = True       # executors call .get() / .wait() on results carrying this mark
     __slots__ = ("runner", "step_id", "req_ids", "nreq", "sel", "rows", "gens", "pos", "tokens",
                  "event", "logprobs", "timing", "marks", "_result", "prompt_logprobs", "_lock", "_toks",
-                 "_published", "kv_sent", "kv_recv")
+                 "_published", "kv_sent", "kv_recv", "pooled")
 
     def __init__(self, runner: "ModelRunner", step_id: int, req_ids: List[str], sel: Optional[np.ndarray],
                  rows: Optional[np.ndarray], pos: Optional[np.ndarray], tokens: Optional[torch.Tensor],
@@ -93,6 +93,7 @@ class PendingSample:
         self.gens = runner.batch.row_gen[rows].copy() if rows is not None else None
         self.logprobs, self.timing, self.marks = logprobs, timing, marks
         self.prompt_logprobs = None
+        self.pooled = None                   # (req ids, [k, H] float32 device tensor)
         self.kv_sent = self.kv_recv = None
         self._result: Optional[ModelRunnerOutput] = None
         self._toks: Optional[np.ndarray] = None
@@ -121,12 +122,16 @@ class PendingSample:
                     logprobs_out = [None] * self.nreq
                     for j, i in enumerate(self.sel.tolist()):
                         logprobs_out[i] = self.logprobs[j]
+            pooled = None
+            if self.pooled is not None:
+                ids, vecs = self.pooled
+                pooled = dict(zip(ids, vecs.cpu().tolist()))
             timing = self.timing
             if timing is not None and self.marks is not None:
                 timing.update(self.marks.resolve())
             self._result = ModelRunnerOutput(step_id=self.step_id, req_ids=self.req_ids,
                                              sampled_token_ids=out_tokens, logprobs=logprobs_out, timing=timing,
-                                             prompt_logprobs=self.prompt_logprobs,
+                                             prompt_logprobs=self.prompt_logprobs, pooled=pooled,
                                              finished_sending=self.kv_sent or None,
                                              finished_recving=self.kv_recv or None)
             return self._result
@@ -221,6 +226,7 @@ class ModelRunner:
             w = get_world_group()
             self.kv_connector = WorkerKVConnector(vllm_config, w.rank, w.world_size)
         CommTimer.configure()
+        self._pool_acc: Dict[str, torch.Tensor] = {}        # running sums of "mean" pooling requests
 
     # ------------------------------------------------------------------ setup
     def load_model(self) -> None:
@@ -471,6 +477,9 @@ class ModelRunner:
         prompt_lps = None
         if nd < nreq and (self.batch.num_prompt_logprobs[p["rows"][nd:]] >= 0).any():
             prompt_lps = self._prompt_logprobs(hidden, p)
+        pooled = None
+        if nd < nreq and self.batch.pooling[p["rows"][nd:]].any():
+            pooled = self._pool(hidden, p)
         sample_mask = p["sample_mask"]
         sel = rows_sel = pos_sel = host_tokens = event = logprobs_sel = None
         if sample_mask.any():
@@ -511,6 +520,7 @@ class ModelRunner:
         pending = PendingSample(self, so.step_id, p["req_ids"], sel, rows_sel, pos_sel, host_tokens, event,
                                 logprobs_sel, timing, marks)
         pending.prompt_logprobs = prompt_lps
+        pending.pooled = pooled
         pending.kv_sent, pending.kv_recv = kv_sent, kv_recv
         self._pending.append(pending)
         report_all = self.kv_connector is not None      # the executor aggregates transfer reports of all ranks
@@ -643,6 +653,41 @@ class ModelRunner:
                     d.setdefault(t_id, t_lp)
                 logprobs.append([d])
         return tokens.to(torch.int32), logprobs
+
+    def _pool(self, hidden: torch.Tensor, p: dict):
+        """Pooled final hidden states of the prefill rows that asked for them (embedding / scoring
+        requests; reference ``src/launch.py:429`` serves vLLM's pooling routes with the rest of its
+        app).  "last": the prompt's last position.  "mean": the sum over this chunk joins the
+        request's running sum; the mean leaves with the chunk that completes the prompt.  Returns
+        ``(req ids, [k, H] float32 on the device)`` for the prompts completed by this step."""
+        b = self.batch
+        nd, qsl, rows = p["num_decodes"], p["qsl"], p["rows"]
+        ids, vecs = [], []
+        for i in range(nd, len(rows)):
+            r = int(rows[i])
+            mode = int(b.pooling[r])
+            if mode == 0:
+                continue
+            lo, hi = int(qsl[i]), int(qsl[i + 1])
+            done = bool(p["sample_mask"][i])
+            rid = b.req_ids[r]
+            if mode == 1:
+                if done:
+                    ids.append(rid)
+                    vecs.append(hidden[hi - 1].float())
+                continue
+            part = hidden[lo:hi].float().sum(0)
+            acc = self._pool_acc.pop(rid, None)
+            part = part if acc is None else acc + part
+            if done:
+                ids.append(rid)
+                vecs.append(part / float(b.num_prompt_tokens[r]))
+            else:
+                self._pool_acc[rid] = part
+        if len(self._pool_acc) > 4 * self.max_num_reqs:      # sums of requests aborted mid-prompt
+            live = set(b.req_ids)
+            self._pool_acc = {k: v for k, v in self._pool_acc.items() if k in live}
+        return (ids, torch.stack(vecs)) if ids else None
 
     def _prompt_logprobs(self, hidden: torch.Tensor, p: dict) -> Optional[dict]:
         """Log-probabilities of the prompt tokens this step's prefill chunks predict:
