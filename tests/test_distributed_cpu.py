@@ -485,3 +485,39 @@ def test_kv_connector_reports_are_aggregated_over_tp_ranks(monkeypatch, tmp_path
     assert c2.num_saved_requests == 0 and c2.num_loaded_tokens == 48
     assert sorted(os.listdir(os.path.join(str(tmp_path), os.listdir(str(tmp_path))[0]))) == [
         "meta.json", "rank0.safetensors", "rank1.safetensors"]
+
+
+def test_speculative_decoding_through_the_distributed_executor(monkeypatch):
+    """Draft verification on workers behind the RPC (their replies are read by a reply thread): the
+    accepted-token accounting of scheduler and workers stays in step; TP=2 over gloo."""
+    port = get_open_port()
+    for k, v in _env(port, VLLM_HEAD_LOCAL_DEVICES="2").items():
+        monkeypatch.setenv(k, v)
+    base = [3, 9, 4, 7, 11, 5]
+    prompts = [base * 6 + [3, 9], list(range(20, 60)), [5, 6] * 20]
+    sp = SamplingParams(temperature=0.0, max_tokens=32, ignore_eos=True)
+    kw = dict(model="llama-tiny", device="cpu", dtype="float32", max_model_len=256, block_size=16,
+              num_gpu_blocks_override=256, max_num_seqs=8)
+
+    def run(eng):
+        ids = [eng.add_request(None, p, sp) for p in prompts]
+        done = {}
+        while eng.has_unfinished_requests():
+            for o in eng.step():
+                if o.finished:
+                    done[o.request_id] = o.outputs[0].token_ids
+        return [done[i] for i in ids]
+    ref = LLMEngine.from_engine_args(EngineArgs(**kw))
+    want = run(ref)
+    ref.shutdown()
+    eng = None
+    try:
+        eng = LLMEngine.from_engine_args(EngineArgs(
+            tensor_parallel_size=2, distributed_executor_backend="distributed",
+            speculative_config={"method": "ngram", "num_speculative_tokens": 3, "prompt_lookup_min": 1}, **kw))
+        got = run(eng)
+        assert got == want
+        assert eng.core.scheduler.spec_stats["accepted"] > 0
+    finally:
+        if eng is not None:
+            eng.shutdown()

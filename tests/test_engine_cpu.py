@@ -272,3 +272,43 @@ def test_pooling_requests_last_and_mean_chunked_equals_unchunked():
     assert outs[1].pooled is None and len(outs[1].outputs[0].token_ids) == 4
     with pytest.raises(ValueError):
         SamplingParams(pooling="max")
+
+
+def test_ngram_speculative_decoding_reproduces_greedy_output():
+    """Prompt-lookup drafts are verified in one step: the text is exactly what one-token-at-a-time
+    greedy decoding writes, in fewer steps; requests with logprobs, a seed or logit edits in the same
+    batch keep the one-token path; max_tokens cuts an accepted run at the right token."""
+    from vllm_distributed_amd import LLM, SamplingParams
+    kw = dict(model="llama-tiny", device="cpu", dtype="float32", max_model_len=256, num_gpu_blocks_override=128,
+              max_num_seqs=8)
+    base = [3, 9, 4, 7, 11, 5]
+    prompts = [{"prompt_token_ids": base * 6 + [3, 9]}, {"prompt_token_ids": list(range(20, 60))},
+               {"prompt_token_ids": [5, 6] * 20}, {"prompt_token_ids": base * 4}]
+    sps = [SamplingParams(temperature=0.0, max_tokens=40, ignore_eos=True),
+           SamplingParams(temperature=0.0, max_tokens=23, ignore_eos=True),
+           SamplingParams(temperature=0.0, max_tokens=40, ignore_eos=True, logprobs=1),
+           SamplingParams(temperature=0.0, max_tokens=17, ignore_eos=True, logit_bias={7: 2.0})]
+    ref = LLM(**kw)
+    want = [o.outputs[0].token_ids for o in ref.generate(prompts, sps)]
+    spec = LLM(speculative_config={"method": "ngram", "num_speculative_tokens": 4, "prompt_lookup_max": 3,
+                                   "prompt_lookup_min": 1}, **kw)
+    assert not spec.engine.vllm_config.scheduler_config.async_scheduling
+    outs = spec.generate(prompts, sps)
+    got = [o.outputs[0].token_ids for o in outs]
+    assert got == want
+    assert [len(g) for g in got] == [40, 23, 40, 17]
+    assert len(outs[2].outputs[0].logprobs) == 40
+    sched = spec.engine.core.scheduler
+    assert sched.spec_stats["drafted"] > 0 and sched.spec_stats["accepted"] > 0
+    solo_ref, solo_spec = LLM(**kw), LLM(speculative_config={"num_speculative_tokens": 4, "prompt_lookup_min": 1}, **kw)
+    a = solo_ref.generate(prompts[:1], sps[0])[0].outputs[0].token_ids
+    b = solo_spec.generate(prompts[:1], sps[0])[0].outputs[0].token_ids
+    assert a == b and solo_spec.engine.core.scheduler.step_id < solo_ref.engine.core.scheduler.step_id
+    # sampling at temperature > 0 also goes through verification (tokens differ run to run; lengths hold)
+    hot = spec.generate(prompts[:2], SamplingParams(temperature=0.8, max_tokens=30, ignore_eos=True))
+    assert [len(o.outputs[0].token_ids) for o in hot] == [30, 30]
+    # prefix-cache hits after a verified run: same answer again
+    again = [o.outputs[0].token_ids for o in spec.generate(prompts, sps)]
+    assert again == want
+    with pytest.raises(ValueError):
+        LLM(speculative_config={"method": "eagle"}, **kw)

@@ -297,6 +297,37 @@ class CacheConfig:
 
 
 @dataclass
+class SpeculativeConfig:
+    """Speculative decoding by prompt lookup: drafts are the tokens that followed the most recent
+    earlier occurrence of the text's current n-gram suffix; the model scores them all in one step
+    and keeps the prefix it agrees with (vLLM's ``--speculative-config '{"method": "ngram", ...}'``)."""
+    method: str = "ngram"
+    num_speculative_tokens: int = 4
+    prompt_lookup_max: int = 4
+    prompt_lookup_min: int = 2
+
+    def __post_init__(self) -> None:
+        if self.method not in ("ngram", "[ngram]"):
+            raise ValueError(f"speculative method {self.method!r} is not supported (ngram)")
+        self.method = "ngram"
+        if not 1 <= self.num_speculative_tokens <= 16:
+            raise ValueError("num_speculative_tokens must be between 1 and 16")
+        if not 1 <= self.prompt_lookup_min <= self.prompt_lookup_max:
+            raise ValueError("need 1 <= prompt_lookup_min <= prompt_lookup_max")
+
+    @classmethod
+    def from_value(cls, value) -> Optional["SpeculativeConfig"]:
+        import json
+        if value in (None, "", {}):
+            return None
+        if isinstance(value, str):
+            value = json.loads(value)
+        known = {k: value[k] for k in ("method", "num_speculative_tokens", "prompt_lookup_max", "prompt_lookup_min")
+                 if k in value}
+        return cls(**known)
+
+
+@dataclass
 class ParallelConfig:
     tensor_parallel_size: int = 1
     pipeline_parallel_size: int = 1
@@ -418,10 +449,18 @@ class VllmConfig:
     observability_config: ObservabilityConfig = field(default_factory=ObservabilityConfig)
     kv_transfer_config: Optional[KVTransferConfig] = None
     lora_config: Optional[LoRAConfig] = None
+    speculative_config: Optional[SpeculativeConfig] = None
 
     def __post_init__(self) -> None:
         self.scheduler_config.max_model_len = self.model_config.max_model_len
         pc, mc = self.parallel_config, self.model_config
+        if self.speculative_config is not None:
+            if pc.pipeline_parallel_size > 1:
+                raise ValueError("speculative decoding is not supported with pipeline parallelism")
+            if self.scheduler_config.async_scheduling:
+                # drafts are looked up in the tokens generated so far: the scheduler cannot run ahead of them
+                logger.info("speculative decoding: async scheduling off")
+                self.scheduler_config.async_scheduling = False
         if mc.num_attention_heads % pc.tensor_parallel_size != 0:
             raise ValueError(f"num_attention_heads ({mc.num_attention_heads}) must be divisible "
                              f"by tensor_parallel_size ({pc.tensor_parallel_size})")

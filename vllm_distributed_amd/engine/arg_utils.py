@@ -15,6 +15,7 @@ from typing import Any, Dict, List, Optional
 
 from ..logger import init_logger
 from ..config import (CacheConfig, CompilationConfig, DeviceConfig, KVTransferConfig, LoRAConfig, ModelConfig,
+                      SpeculativeConfig,
                       ObservabilityConfig, ParallelConfig, SchedulerConfig, VllmConfig)
 
 logger = init_logger(__name__)
@@ -57,6 +58,7 @@ class EngineArgs:
     hip_graph_sizes: Optional[List[int]] = None
     max_capture_size: int = 512
     kv_transfer_config: Optional[Dict[str, Any]] = None
+    speculative_config: Optional[Any] = None          # dict or JSON text: {"method": "ngram", "num_speculative_tokens": 4, ...}
     disable_log_stats: bool = False
     enable_lora: bool = False
     max_loras: int = 1
@@ -104,6 +106,9 @@ class EngineArgs:
         g.add_argument("--hip-graph-sizes", "--cuda-graph-sizes", type=int, nargs="*", default=None)
         g.add_argument("--max-capture-size", type=int, default=512)
         g.add_argument("--kv-transfer-config", type=json.loads, default=None)
+        g.add_argument("--speculative-config", type=json.loads, default=None,
+                       help='prompt-lookup speculative decoding, e.g. {"method": "ngram", "num_speculative_tokens": 4, '
+                            '"prompt_lookup_max": 4, "prompt_lookup_min": 2}')
         g.add_argument("--disable-log-stats", action="store_true")
         g.add_argument("--enable-lora", action="store_true", help="serve LoRA adapters next to the base model")
         g.add_argument("--max-loras", type=int, default=1, help="adapters resident (and usable in one batch) at once")
@@ -183,7 +188,8 @@ class EngineArgs:
                           parallel_config=parallel_config, scheduler_config=scheduler_config,
                           device_config=device_config, compilation_config=compilation_config,
                           observability_config=ObservabilityConfig(), kv_transfer_config=kvt,
-                          lora_config=lora)
+                          lora_config=lora,
+                          speculative_config=SpeculativeConfig.from_value(self.speculative_config))
 
 
 COMPAT_FLAGS_NO_VALUE = (

@@ -92,7 +92,8 @@ class EngineCore:
             kv_connector = make_scheduler_connector(vllm_config)
         self.scheduler = Scheduler(vllm_config.scheduler_config, vllm_config.cache_config, num_blocks,
                                    include_new_token_ids=pp > 1, kv_connector=kv_connector,
-                                   max_loras=vllm_config.lora_config.max_loras if vllm_config.lora_config else 0)
+                                   max_loras=vllm_config.lora_config.max_loras if vllm_config.lora_config else 0,
+                                   speculative_config=vllm_config.speculative_config)
         self.max_concurrent = max(1, self.executor.max_concurrent_batches)
         self.batch_queue: Deque[Tuple[object, SchedulerOutput]] = deque()
         self.timer = StepTimer()

@@ -20,6 +20,8 @@ from collections import deque
 from dataclasses import dataclass
 from typing import Deque, Dict, Iterable, List, Optional, Set
 
+import numpy as np
+
 from ..config import CacheConfig, SchedulerConfig
 from ..logger import init_logger
 from .kv_cache_manager import KVCacheManager
@@ -56,9 +58,11 @@ class SchedulerStats:
 
 
 class Scheduler:
+    SPEC_WINDOW = 8192            # most recent tokens searched for a draft
+
     def __init__(self, scheduler_config: SchedulerConfig, cache_config: CacheConfig,
                  num_blocks: int, include_new_token_ids: bool = True,
-                 kv_connector=None, max_loras: int = 0):
+                 kv_connector=None, max_loras: int = 0, speculative_config=None):
         self.config = scheduler_config
         self.cache_config = cache_config
         self.max_num_seqs = scheduler_config.max_num_seqs
@@ -80,6 +84,17 @@ class Scheduler:
         self._pending_new_tokens: Dict[str, List[int]] = {}
         self.include_new_token_ids = include_new_token_ids
         self.kv_connector = kv_connector
+        self.spec = speculative_config
+        self.spec_stats = {"drafted": 0, "accepted": 0}
+        self._ngram = None
+        if self.spec is not None:
+            import ctypes
+            from ..ops.grammar import load as load_core
+            lib = load_core()
+            lib.vdamd_ngram_propose.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_void_p]
+            lib.vdamd_ngram_propose.restype = ctypes.c_int
+            self._ngram = lib.vdamd_ngram_propose
         # distinct adapters one batch may use (= the workers' resident slots); 0 = LoRA off
         self.max_loras = max_loras
         self.step_id = 0
@@ -109,6 +124,28 @@ class Scheduler:
             self.waiting.appendleft(request)
         else:
             self.waiting.append(request)
+
+    # ------------------------------------------------------- speculative decoding
+    def _propose_drafts(self, req: Request, budget: int) -> List[int]:
+        """Prompt-lookup drafts for a request in plain decode, or [].  Requests whose next-token
+        distribution depends on more than the text (penalties, logit edits, grammars, a seed's
+        draw order) or that report logprobs are decoded one token at a time."""
+        sc = self.spec
+        sp = req.sampling_params
+        if (req.num_computed_tokens != req.num_tokens - 1 or req.num_output_placeholders
+                or sp.has_penalties or sp.has_logit_adjust or sp.logprobs is not None or sp.seed is not None
+                or sp.pooling is not None or req.lora_request is not None):
+            return []
+        room = min(sc.num_speculative_tokens, budget - 1, self.max_model_len - req.num_tokens - 1)
+        if req.max_tokens is not None:
+            room = min(room, req.max_tokens - len(req.output_token_ids) - 1)
+        if room <= 0:
+            return []
+        ids = req.all_token_ids
+        arr = np.asarray(ids[-self.SPEC_WINDOW:], dtype=np.int32)
+        out = np.empty(room, dtype=np.int32)
+        n = self._ngram(arr.ctypes.data, len(arr), sc.prompt_lookup_max, sc.prompt_lookup_min, room, out.ctypes.data)
+        return out[:n].tolist()
 
     def abort_requests(self, request_ids: Iterable[str]) -> List[str]:
         aborted = []
@@ -144,6 +181,7 @@ class Scheduler:
         new_reqs: List[NewRequestData] = []
         cached = CachedRequestData()
         preempted: List[Request] = []
+        spec_tokens: Dict[str, List[int]] = {}
         now = time.time()
         req_blocks, block_size = self.kv.req_blocks, self.kv.block_size
 
@@ -164,6 +202,9 @@ class Scheduler:
             n = min(n, self.max_model_len - req.num_computed_tokens)
             if n <= 0:
                 continue
+            drafts = self._propose_drafts(req, budget) if self.spec is not None and n == 1 else None
+            if drafts:
+                n = 1 + len(drafts)
             held = req_blocks.get(req.request_id)
             if held is not None and req.num_computed_tokens + n <= len(held) * block_size:
                 new_blocks = _NO_BLOCKS          # the common decode step: room left in the last block
@@ -182,6 +223,9 @@ class Scheduler:
                 continue
             self._add_cached(cached, req, new_blocks)
             num_scheduled[req.request_id] = n
+            if drafts:
+                spec_tokens[req.request_id] = drafts
+                self.spec_stats["drafted"] += len(drafts)
             before = req.num_computed_tokens
             req.num_computed_tokens += n
             if self.kv_connector is not None and before < req.num_prompt_tokens <= req.num_computed_tokens:
@@ -251,7 +295,8 @@ class Scheduler:
             step_id=self.step_id, scheduled_new_reqs=new_reqs, scheduled_cached_reqs=cached,
             num_scheduled_tokens=num_scheduled, total_num_scheduled_tokens=total,
             finished_req_ids=self._finished_since_last,
-            preempted_req_ids=self._preempted_since_last)
+            preempted_req_ids=self._preempted_since_last,
+            scheduled_spec_decode_tokens=spec_tokens or None)
         self._finished_since_last = set()
         self._preempted_since_last = set()
         if self.kv_connector is not None:
@@ -325,6 +370,7 @@ class Scheduler:
         now = time.time()
         requests = self.requests
         scheduled = scheduler_output.num_scheduled_tokens
+        spec = scheduler_output.scheduled_spec_decode_tokens
         if runner_output.prompt_logprobs:
             for rid, (first, entries) in runner_output.prompt_logprobs.items():
                 req = requests.get(rid)
@@ -340,6 +386,11 @@ class Scheduler:
             req = requests.get(rid)
             if req is None or req.status != running_state or rid not in scheduled:
                 continue             # aborted / preempted / finished while in flight
+            if spec and new_tokens and rid in spec:
+                # 1 + len(drafts) positions ran; the accepted drafts and one more token came back:
+                # the positions of the rejected drafts count as not computed (their KV is overwritten)
+                req.num_computed_tokens -= len(spec[rid]) + 1 - len(new_tokens)
+                self.spec_stats["accepted"] += len(new_tokens) - 1
             if caching:              # blocks that are now full and fully known can be shared
                 self.kv.cache_blocks(req, req.num_computed_tokens)
             if not new_tokens:

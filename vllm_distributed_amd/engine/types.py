@@ -52,6 +52,9 @@ class SchedulerOutput:
     finished_req_ids: Set[str] = field(default_factory=set)
     preempted_req_ids: Set[str] = field(default_factory=set)
     # KV-transfer work attached by the connector (disaggregated prefill)
+    # req_id -> draft tokens to verify this step (speculative decoding); the request is scheduled
+    # for 1 + len(drafts) tokens
+    scheduled_spec_decode_tokens: Optional[Dict[str, List[int]]] = None
     kv_connector_metadata: Optional[Any] = None
 
     @property

@@ -82,7 +82,7 @@ class PendingSample:
     lazy_step_result = True       # executors call .get() / .wait() on results carrying this mark
     __slots__ = ("runner", "step_id", "req_ids", "nreq", "sel", "rows", "gens", "pos", "tokens",
                  "event", "logprobs", "timing", "marks", "_result", "prompt_logprobs", "_lock", "_toks",
-                 "_published", "kv_sent", "kv_recv", "pooled")
+                 "_published", "kv_sent", "kv_recv", "pooled", "counts", "drafts", "_accepted")
 
     def __init__(self, runner: "ModelRunner", step_id: int, req_ids: List[str], sel: Optional[np.ndarray],
                  rows: Optional[np.ndarray], pos: Optional[np.ndarray], tokens: Optional[torch.Tensor],
@@ -94,6 +94,10 @@ class PendingSample:
         self.logprobs, self.timing, self.marks = logprobs, timing, marks
         self.prompt_logprobs = None
         self.pooled = None                   # (req ids, [k, H] float32 device tensor)
+        # speculative decoding: sampled positions per selected request, and each one's draft tokens (or None)
+        self.counts: Optional[np.ndarray] = None
+        self.drafts: Optional[List[Optional[List[int]]]] = None
+        self._accepted: Optional[List[List[int]]] = None
         self.kv_sent = self.kv_recv = None
         self._result: Optional[ModelRunnerOutput] = None
         self._toks: Optional[np.ndarray] = None
@@ -113,7 +117,7 @@ class PendingSample:
             logprobs_out = None
             if self.event is not None:
                 self.event.synchronize()
-            if self.sel is not None:
+            if self.sel is not None and self.counts is None:
                 self._toks = toks = self.tokens.numpy()
                 tok_list = toks.tolist()
                 for j, i in enumerate(self.sel.tolist()):
@@ -122,6 +126,26 @@ class PendingSample:
                     logprobs_out = [None] * self.nreq
                     for j, i in enumerate(self.sel.tolist()):
                         logprobs_out[i] = self.logprobs[j]
+            elif self.sel is not None:
+                # some requests were sampled at several positions (their last token + drafts): keep
+                # the drafts the model reproduced, and the token it put after the last of them
+                tok_list = self.tokens.numpy().tolist()
+                self._accepted = []
+                if self.logprobs is not None:
+                    logprobs_out = [None] * self.nreq
+                off = 0
+                for j, i in enumerate(self.sel.tolist()):
+                    c = int(self.counts[j])
+                    mine, d = tok_list[off:off + c], self.drafts[j]
+                    n_acc = 0
+                    if d:
+                        while n_acc < len(d) and mine[n_acc] == d[n_acc]:
+                            n_acc += 1
+                    out_tokens[i] = mine[:n_acc + 1]
+                    self._accepted.append(out_tokens[i])
+                    if self.logprobs is not None:
+                        logprobs_out[i] = self.logprobs[off + c - 1]
+                    off += c
             pooled = None
             if self.pooled is not None:
                 ids, vecs = self.pooled
@@ -143,12 +167,23 @@ class PendingSample:
             return
         self.wait()
         self._published = True
-        if self.sel is not None:
+        if self.sel is not None and self.counts is None:
             b = self.runner.batch
             ok = b.row_gen[self.rows] == self.gens
             rows, pos = self.rows[ok], self.pos[ok]
             b.token_ids[rows, pos] = self._toks[ok]
             b.num_known[rows] = np.maximum(b.num_known[rows], pos + 1)
+        elif self.sel is not None:
+            b = self.runner.batch
+            for j, (r, p0) in enumerate(zip(self.rows.tolist(), self.pos.tolist())):
+                if b.row_gen[r] != self.gens[j]:
+                    continue
+                acc = self._accepted[j]
+                m, ran = len(acc), int(self.counts[j])
+                b.token_ids[r, p0:p0 + m] = acc
+                b.num_tokens[r] = p0 + m                  # execute_model had counted one token
+                b.num_computed[r] -= ran - m              # positions of rejected drafts were not computed
+                b.num_known[r] = p0 + m
         try:
             self.runner._pending.remove(self)
         except ValueError:
@@ -329,6 +364,16 @@ class ModelRunner:
             if toks and not samples_here:
                 # stages that do not sample learn new tokens from the scheduler
                 b.append_tokens(row, toks)
+        if so.scheduled_spec_decode_tokens:
+            # draft tokens sit behind the last real token as this step's extra inputs; they are not
+            # part of the request (num_tokens stays) until the step has verified them
+            for rid, drafts in so.scheduled_spec_decode_tokens.items():
+                row = b.row_of.get(rid)
+                if row is None:
+                    continue
+                nt = int(b.num_tokens[row])
+                b.token_ids[row, nt:nt + len(drafts)] = drafts
+                b.num_known[row] = nt + len(drafts)
 
     def loras_in_batch(self):
         b = self.batch
@@ -370,7 +415,9 @@ class ModelRunner:
         max_blocks = int(cdiv(int(seq_lens.max()), self.block_size))
         # which requests reach the end of their known tokens -> sample
         sample_mask = seq_lens >= b.num_tokens[rows]
-        return dict(req_ids=req_ids, rows=rows, n_sched=n_sched, num_decodes=num_decodes,
+        spec = so.scheduled_spec_decode_tokens
+        return dict(spec=spec if spec else None,
+                    req_ids=req_ids, rows=rows, n_sched=n_sched, num_decodes=num_decodes,
                     seq_lens=seq_lens, qsl=qsl, total=total, positions=positions,
                     input_ids=input_ids, slot_mapping=slot_mapping, max_blocks=max_blocks,
                     sample_mask=sample_mask, unknown=unknown if unknown.any() else None,
@@ -424,8 +471,8 @@ class ModelRunner:
         t0 = time.perf_counter()
         with trace_range("step.prepare"):
             for pend in list(self._pending):      # values a reply thread has already read back
-                if pend.resolved:
-                    pend.publish()
+                if pend.resolved or so.scheduled_spec_decode_tokens or pend.counts is not None:
+                    pend.publish()                # (a verified step changes token counts: always fold it in first)
             self._update_states(so)
             self.step_count += 1
             kv_meta = so.kv_connector_metadata if self.kv_connector is not None else None
@@ -482,25 +529,38 @@ class ModelRunner:
             pooled = self._pool(hidden, p)
         sample_mask = p["sample_mask"]
         sel = rows_sel = pos_sel = host_tokens = event = logprobs_sel = None
+        counts = drafts_sel = None
         if sample_mask.any():
             sel = np.nonzero(sample_mask)[0]
             last_idx = p["qsl"][1:][sel] - 1
-            if len(sel) == total:        # every token is a sampling position (pure decode)
+            rows_sel = p["rows"][sel]
+            rows_smp = rows_sel
+            if p["spec"]:
+                # a request with drafts is sampled at every one of its positions
+                drafts_sel = [p["spec"].get(p["req_ids"][i]) for i in sel.tolist()]
+                counts = np.array([1 + len(d) if d else 1 for d in drafts_sel], dtype=np.int64)
+                ends = np.cumsum(counts)
+                within = np.arange(int(ends[-1])) - np.repeat(ends - counts, counts)
+                idx = np.repeat(last_idx - (counts - 1), counts) + within
+                rows_smp = np.repeat(rows_sel, counts)
+                hs = hidden.index_select(0, self._to_dev(idx, torch.int64))
+            elif len(sel) == total:        # every token is a sampling position (pure decode)
                 hs = hidden[:total]
             else:
                 hs = hidden.index_select(0, self._to_dev(last_idx, torch.int64))
-            rows_sel = p["rows"][sel]
             with trace_range("step.sample"):
-                tokens, logprobs_sel = self._sample(hs, rows_sel)
+                tokens, logprobs_sel = self._sample(hs, rows_smp)
             b = self.batch
             if self.sampled_dev is None:
                 self.sampled_dev = torch.zeros(self.max_num_reqs, dtype=torch.int32, device=self.device)
             # every TP rank samples the same token; keep it on the device for the next step
-            self.sampled_dev.index_copy_(0, self._to_dev(rows_sel, torch.int64), tokens)
+            self.sampled_dev.index_copy_(0, self._to_dev(rows_sel, torch.int64),
+                                         tokens if counts is None else
+                                         tokens.index_select(0, self._to_dev(np.cumsum(counts) - 1, torch.int64)))
             pos_sel = b.num_tokens[rows_sel].copy()
             b.num_tokens[rows_sel] = pos_sel + 1
             if self.is_gpu:
-                host_tokens = torch.empty(len(sel), dtype=torch.int32, pin_memory=True)
+                host_tokens = torch.empty(tokens.shape[0], dtype=torch.int32, pin_memory=True)
                 host_tokens.copy_(tokens, non_blocking=True)
             else:
                 host_tokens = tokens
@@ -520,6 +580,7 @@ class ModelRunner:
         pending = PendingSample(self, so.step_id, p["req_ids"], sel, rows_sel, pos_sel, host_tokens, event,
                                 logprobs_sel, timing, marks)
         pending.prompt_logprobs = prompt_lps
+        pending.counts, pending.drafts = counts, drafts_sel
         pending.pooled = pooled
         pending.kv_sent, pending.kv_recv = kv_sent, kv_recv
         self._pending.append(pending)
