@@ -56,8 +56,16 @@ def test_cli_parses_reference_command_line():
     e = EngineArgs.from_cli_args(a)
     assert e.hf_overrides == {"rope_scaling": {"rope_type": "dynamic", "factor": 2.0}, "rope_theta": 1000000.0}
     assert e.enable_prefix_caching is False and a.compat_swap_space == "4" and a.compat_disable_log_requests
+    sa = build_parser().parse_args(["serve", "llama-tiny", "--device", "cpu", "--speculative-config",
+                                    '{"method": "ngram", "num_speculative_tokens": 3}'])
+    sa.model = sa.model_tag
+    cfg = EngineArgs.from_cli_args(sa).create_engine_config()
+    assert cfg.speculative_config.num_speculative_tokens == 3 and not cfg.scheduler_config.async_scheduling
+    bad = build_parser().parse_args(["serve", "llama-tiny", "--device", "cpu", "--speculative-config",
+                                     '{"method": "medusa"}'])
+    bad.model = bad.model_tag
     with pytest.raises(ValueError):
-        EngineArgs.from_cli_args(build_parser().parse_args(["serve", "m", "--speculative-config", "{}"]))
+        EngineArgs.from_cli_args(bad).create_engine_config()
 
 
 @pytest.mark.parametrize("frontend_mp", [True, False])

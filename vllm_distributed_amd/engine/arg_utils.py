@@ -126,15 +126,12 @@ class EngineArgs:
         for flag in COMPAT_FLAGS_ONE_VALUE:
             c.add_argument(*flag.split("|"), type=str, default=None,
                            dest="compat_" + flag.split("|")[0].lstrip("-").replace("-", "_"), help=argparse.SUPPRESS)
-        c.add_argument("--speculative-config", type=str, default=None, help=argparse.SUPPRESS)
         return parser
 
     @classmethod
     def from_cli_args(cls, args: argparse.Namespace) -> "EngineArgs":
         names = [f.name for f in dataclasses.fields(cls)]
         self = cls(**{n: getattr(args, n) for n in names if hasattr(args, n)})
-        if getattr(args, "speculative_config", None):
-            raise ValueError("--speculative-config: speculative decoding is not implemented in this build")
         overrides = dict(self.hf_overrides or {})
         if getattr(args, "rope_scaling", None):
             overrides["rope_scaling"] = args.rope_scaling
