@@ -241,6 +241,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
 }
 
+// Short contexts, large batches: one WAVE per (sequence, KV head, 16-query tile), four sequences per
+// workgroup.  A context of a few hundred keys is 5-10 groups of 32; giving it four waves leaves
+// most of them one group each and then pays an LDS exchange, a barrier and a cross-wave combine
+// per sequence.  Here a wave walks all groups of its sequence and writes its rows itself: no LDS,
+// no barrier, and consecutive sequences of a workgroup keep the load queues of the CU busy.
+template <typename T, int D, bool KV8>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void paged_decode_wave_kernel(
+    T* __restrict__ out, const T* __restrict__ q, long q_stride, const void* __restrict__ k_cache,
+    const void* __restrict__ v_cache, const int* __restrict__ block_table, int bt_stride,
+    const int* __restrict__ seq_lens, float scale_log2e, int B, int Hq, int Hkv, int block_size, long out_stride,
+    const float* __restrict__ k_scales, const float* __restrict__ v_scales) {
+  using V = typename Vec8<T>::type;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wid;
+  if (b >= B) return;
+  const int G = Hq / Hkv;
+  const int q_tiles = (G + 15) >> 4;
+  const int kvh = blockIdx.y / q_tiles, qt = blockIdx.y - kvh * q_tiles;
+  const int qh0 = kvh * G + qt * 16;
+  const int nq = min(16, G - qt * 16);
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int seq_len = seq_lens[b];
+  const float k_scale = (KV8 && k_scales != nullptr) ? k_scales[kvh] : 1.f;
+  const float v_scale = (KV8 && v_scales != nullptr) ? v_scales[kvh] : 1.f;
+
+  V qf[1][D / 32];
+#pragma unroll
+  for (int s = 0; s < D / 32; ++s)
+    qf[0][s] = (r16 < nq) ? ld8<T>(q + b * q_stride + (long)(qh0 + r16) * D + 32 * s + 8 * g4) : zero8<T>();
+  f32x4 acc[1][D / 16];
+#pragma unroll
+  for (int dt = 0; dt < D / 16; ++dt) acc[0][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m[1] = {NEG_BIG}, l[1] = {0.f};
+  const int qpos_hi[1] = {seq_len - 1};
+  const int* bt_row = block_table + (long)b * bt_stride;
+  const int n_groups = (seq_len + 31) >> 5;
+  for (int g = 0; g < n_groups; ++g)
+    attend_group<T, D, 1, KV8>(k_cache, v_cache, bt_row, kvh, Hkv, block_size, g * 32, seq_len,
+                               scale_log2e * k_scale, qf, acc, m, l, qpos_hi, 1.f, 1.f);
+  float lsum = l[0];
+  lsum += __shfl_xor(lsum, 16, 64);
+  lsum += __shfl_xor(lsum, 32, 64);
+  if (r16 >= nq) return;
+  const float inv = lsum > 0.f ? v_scale / lsum : 0.f;
+  T* orow = out + b * out_stride + (long)(qh0 + r16) * D + 4 * g4;
+#pragma unroll
+  for (int dt = 0; dt < D / 16; ++dt) {
+    typename Vec4<T>::type o4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o4[r] = (T)(acc[0][dt][r] * inv);
+    *reinterpret_cast<typename Vec4<T>::type*>(orow + 16 * dt) = o4;
+  }
+}
+
 template <typename T, int D>
 __global__ void decode_reduce_kernel(T* __restrict__ out, const float* __restrict__ part_o,
                                      const float* __restrict__ part_ml, int Hq, int num_splits, long out_stride) {
@@ -540,6 +594,13 @@ int launch_decode(void* out, float* ws, const void* q, long q_stride, const void
   float* part_o = ws;
   float* part_ml = ws ? ws + (long)B * Hq * num_splits * D : nullptr;
   const float sl2 = scale * 1.4426950408889634f;
+  if (num_splits == 0) {      // one wave per sequence
+    hipLaunchKernelGGL((paged_decode_wave_kernel<T, D, KV8>), dim3((B + 3) / 4, Hkv * q_tiles), dim3(256), 0, s,
+                       (T*)out, (const T*)q, q_stride, kc, vc, bt, bt_stride, seq_lens, sl2, B, Hq, Hkv, block_size,
+                       out_stride, k_scales, v_scales);
+    HIP_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL((paged_decode_kernel<T, D, KV8>), dim3(num_splits, Hkv * q_tiles, B), dim3(256), 0, s, (T*)out,
                      part_o, part_ml, (const T*)q, q_stride, kc, vc, bt, bt_stride, seq_lens,
                      sl2, Hq, Hkv, block_size, num_splits, out_stride, k_scales, v_scales);
@@ -600,7 +661,8 @@ VDAMD_API int vdamd_paged_attention_decode(void* out, float* workspace, const vo
                                            int kv_fp8, const float* k_scales, const float* v_scales,
                                            hipStream_t s) {
   if (B == 0) return 0;
-  if (Hq % Hkv != 0 || block_size % 8 != 0 || num_splits < 1 || num_splits > MAX_SPLITS) return -1;
+  // num_splits == 0 selects the one-wave-per-sequence kernel (short contexts, large batches)
+  if (Hq % Hkv != 0 || block_size % 8 != 0 || num_splits < 0 || num_splits > MAX_SPLITS) return -1;
   if (num_splits > 1 && workspace == nullptr) return -3;
 #define CASE(TY, DD)                                                                                             \
   do {                                                                                                           \

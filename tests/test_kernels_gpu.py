@@ -146,7 +146,7 @@ def _make_paged(seq_lens, hkv, d, bs, dtype=torch.bfloat16, extra_blocks=3):
 
 @pytest.mark.parametrize("hq,hkv,d,bs", [(32, 8, 128, 64), (64, 8, 128, 64), (12, 12, 64, 16),
                                          (24, 2, 128, 32), (4, 2, 64, 128)])
-@pytest.mark.parametrize("splits", [None, 1, 4])
+@pytest.mark.parametrize("splits", [None, 0, 1, 4])          # 0 = the one-wave-per-sequence kernel
 def test_paged_attention_decode(hq, hkv, d, bs, splits):
     from vllm_distributed_amd.ops import hip
     seq_lens = [1, 31, 32, 33, 64, 100, 517, 1000, 129, 64 * 7]
@@ -458,7 +458,7 @@ def _fp8_caches(seq_lens, hkv, d, bs):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("hq,hkv,d,bs", [(32, 8, 128, 64), (64, 8, 128, 64), (12, 12, 64, 16), (24, 2, 128, 32)])
-@pytest.mark.parametrize("splits", [None, 1, 4])
+@pytest.mark.parametrize("splits", [None, 0, 1, 4])
 def test_paged_attention_decode_fp8_cache(dtype, hq, hkv, d, bs, splits):
     from vllm_distributed_amd.ops import hip
     seq_lens = [1, 31, 33, 64, 100, 517, 1000, 64 * 7]

@@ -281,6 +281,7 @@ def paged_attention_decode(q, k_cache, v_cache, block_table, seq_lens, scale, ma
     if num_splits is None:
         num_splits = choose_num_splits(b, hkv, max_seq_len)
     ws_ptr = None
+    assert 0 <= num_splits <= MAX_SPLITS       # 0 = the one-wave-per-sequence kernel
     if num_splits > 1:
         need = b * hq * num_splits * (d + 2)
         if workspace is None or workspace.numel() < need:

@@ -238,6 +238,8 @@ class ModelRunner:
                                 self.model_config.vocab_size, self.model_config.seed)
         self.kv_caches: List[Tuple[torch.Tensor, torch.Tensor]] = []
         self.graphs: Dict[int, DecodeGraph] = {}
+        # batch size -> [(context limit, graph)] ascending; the last entry is also graphs[batch size]
+        self.graph_ctx: Dict[int, List[Tuple[int, DecodeGraph]]] = {}
         self.graph_sizes: List[int] = []
         self.graph_pool = None
         self.graph_fallback_reason: Optional[str] = "not captured yet"
@@ -911,8 +913,30 @@ class ModelRunner:
             return None
         for s in self.graph_sizes:
             if s >= nreq:
+                # the variant captured for the shortest context that covers this batch: its split-KV
+                # factor was chosen for that length (a short context is not cut into needless splits)
+                ctx = max_blocks * self.block_size
+                for limit, g in self.graph_ctx.get(s, ()):
+                    if limit >= ctx:
+                        return g
                 return self.graphs[s]
         return None
+
+    CONTEXT_BUCKETS = (512, 4096, 32768)
+
+    def _context_variants(self, bs: int) -> List[int]:
+        """Context limits worth a graph of their own at this batch size: those at which the decode
+        kernel's split-KV factor differs from the next larger limit's."""
+        if not ops.hip_available():
+            return [self.max_model_len]
+        from ..ops import hip
+        hkv = self.model.attention_layers()[0].num_kv_heads
+        limits = [c for c in self.CONTEXT_BUCKETS if c < self.max_model_len] + [self.max_model_len]
+        keep = [limits[-1]]
+        for c in reversed(limits[:-1]):
+            if hip.choose_num_splits(bs, hkv, c) != hip.choose_num_splits(bs, hkv, keep[0]):
+                keep.insert(0, c)
+        return keep
 
     def _alloc_static(self, max_bs: int) -> None:
         dev = self.device
@@ -965,6 +989,8 @@ class ModelRunner:
             self.graph_fallback_reason = "no capture sizes configured"
             return
         t0 = time.time()
+        self.graphs.clear()
+        self.graph_ctx.clear()
         self._alloc_static(max(sizes))
         if not self.pp.is_first_rank:         # what the previous stage sends lands here, in front of the graph
             h, dt = self.model_config.hidden_size, self.model_config.torch_dtype
@@ -974,7 +1000,11 @@ class ModelRunner:
         error: Optional[BaseException] = None
         try:
             for bs in sorted(sizes, reverse=True):
-                self._capture_one(bs)
+                variants = self._context_variants(bs)
+                for ctx in reversed(variants):             # the full-length one first: it sizes the pool
+                    g = self._capture_one(bs, ctx)
+                    self.graph_ctx.setdefault(bs, []).insert(0, (ctx, g))
+                self.graphs[bs] = self.graph_ctx[bs][-1][1]
         except Exception as e:  # capture is an optimisation: fall back to eager
             error = e
             logger.warning("hipGraph capture raised", exc_info=True)
@@ -988,6 +1018,7 @@ class ModelRunner:
             self.graph_fallback_reason = "capture failed on tp rank(s) " + ", ".join(f"{r}: {v}" for r, v in failed)
             logger.warning("hipGraph %s: running decode eagerly", self.graph_fallback_reason)
             self.graphs.clear()
+            self.graph_ctx.clear()
             self.graph_sizes = []
             self.graph_pool = None
             if self.tp.world_size > 1 and (self.tp.rccl is not None or self.tp.custom_ar is not None):
@@ -995,8 +1026,9 @@ class ModelRunner:
                 reverify_after_failed_capture(self.tp)
             return
         self.graph_sizes = sorted(self.graphs)
-        logger.info("captured %d decode graphs (%s) in %.1fs", len(self.graphs),
-                    self.graph_sizes, time.time() - t0)
+        logger.info("captured %d decode graphs (batch sizes %s, %d context variants) in %.1fs",
+                    sum(len(v) for v in self.graph_ctx.values()), self.graph_sizes,
+                    sum(len(v) - 1 for v in self.graph_ctx.values()), time.time() - t0)
 
     def _ensure_decode_workspace(self, max_bs: int) -> None:
         if not self.is_gpu or not ops.hip_available():
@@ -1018,9 +1050,9 @@ class ModelRunner:
         finally:
             self.tp.end_step()
 
-    def _capture_one(self, bs: int) -> None:
+    def _capture_one(self, bs: int, ctx: Optional[int] = None) -> DecodeGraph:
         s = self._static
-        md = self._static_metadata(bs, self.max_model_len)
+        md = self._static_metadata(bs, ctx or self.max_model_len)
         ids, pos = s["input_ids"][:bs], s["positions"][:bs]
         inter = None
         if not self.pp.is_first_rank:
@@ -1050,6 +1082,7 @@ class ModelRunner:
         if self.graph_pool is None:
             self.graph_pool = g.graph.pool()
         self.graphs[bs] = g
+        return g
 
     def _run_graph(self, g: DecodeGraph, p: dict):
         s, st = self._static, self._stage

@@ -202,6 +202,7 @@ class Worker:
             attn.k_cache = attn.v_cache = None
         self.model_runner.kv_caches = []
         self.model_runner.graphs.clear()
+        self.model_runner.graph_ctx.clear()
         self.model_runner.graph_sizes = []
         gc.collect()
         if self.device.type == "cuda":
