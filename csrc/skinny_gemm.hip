@@ -20,11 +20,13 @@ constexpr int SG_XPAD = 128;   // 256-byte rows; 16-byte slots XOR-swizzled by t
 constexpr int SG_WAVES = 4;
 
 // grid = (ceil(N / (64*NTW)), ksplit), block = 256.  Requires K % 128 == 0, N % 16 == 0, M <= 16*MT.
-template <typename T, int MT, int NTW>
+// SILU: x is [M][2K] = [gate | up] and the operand is silu(gate) * up, formed on the way into LDS
+// (up_off = K): the activation kernel between the two MLP GEMMs and its round trip disappear.
+template <typename T, int MT, int NTW, bool SILU = false>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(
     const T* __restrict__ x, long x_stride, const T* __restrict__ w, long w_stride, T* __restrict__ out,
     long out_stride, float* __restrict__ partial, int M, int N, int K, int ksplit,
-    const int* __restrict__ tiles, long w_group_stride) {
+    const int* __restrict__ tiles, long w_group_stride, long up_off = 0) {
   using V8 = typename Vec8<T>::type;
   __shared__ __attribute__((aligned(16))) T xl[2][MT * 16][SG_XPAD];
   if (tiles != nullptr) {
@@ -66,12 +68,24 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(
 #pragma unroll
       for (int s = 0; s < 4; ++s) a[t][s] = ld8(wrow[t] + (kb << 7) + 32 * s);
   };
+  auto load_x = [&](int p, int kb) -> V8 {
+    V8 gt = ld8(xsrc[p] + (kb << 7));
+    if constexpr (SILU) {
+      const V8 up = ld8(xsrc[p] + up_off + (kb << 7));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float gv = (float)gt[j];
+        gt[j] = (T)(gv / (1.f + __expf(-gv)) * (float)up[j]);
+      }
+    }
+    return gt;
+  };
   V8 ac[NTW][4], an[NTW][4];
   V8 xreg[MT];
   if (kb_lo < kb_hi) {
     load_w(kb_lo, ac);
 #pragma unroll
-    for (int p = 0; p < MT; ++p) st8(&xl[0][16 * p + xr][8 * (xc ^ xr)], ld8(xsrc[p] + (kb_lo << 7)));
+    for (int p = 0; p < MT; ++p) st8(&xl[0][16 * p + xr][8 * (xc ^ xr)], load_x(p, kb_lo));
   }
   __syncthreads();
   for (int kb = kb_lo; kb < kb_hi; ++kb) {
@@ -80,7 +94,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(
     if (more) {
       load_w(kb + 1, an);
 #pragma unroll
-      for (int p = 0; p < MT; ++p) xreg[p] = ld8(xsrc[p] + ((kb + 1) << 7));
+      for (int p = 0; p < MT; ++p) xreg[p] = load_x(p, kb + 1);
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -140,27 +154,33 @@ __global__ void skinny_reduce_kernel(T* __restrict__ out, long out_stride, const
 template <typename T, int MT, int NTW>
 static void launch_one(const void* x, long xs, const void* w, long ws, void* out, long os, void* partial, int M,
                        int N, int K, int ksplit, hipStream_t st, const int* tiles = nullptr, int num_tiles = 1,
-                       long w_group_stride = 0) {
+                       long w_group_stride = 0, long up_off = 0) {
   dim3 grid((N / 16 + SG_WAVES * NTW - 1) / (SG_WAVES * NTW), ksplit, num_tiles);
-  skinny_gemm_kernel<T, MT, NTW><<<grid, 256, 0, st>>>((const T*)x, xs, (const T*)w, ws, (T*)out, os,
-                                                       (float*)partial, M, N, K, ksplit, tiles, w_group_stride);
+  if (up_off)
+    skinny_gemm_kernel<T, MT, NTW, true><<<grid, 256, 0, st>>>((const T*)x, xs, (const T*)w, ws, (T*)out, os,
+                                                                (float*)partial, M, N, K, ksplit, tiles,
+                                                                w_group_stride, up_off);
+  else
+    skinny_gemm_kernel<T, MT, NTW, false><<<grid, 256, 0, st>>>((const T*)x, xs, (const T*)w, ws, (T*)out, os,
+                                                                 (float*)partial, M, N, K, ksplit, tiles,
+                                                                 w_group_stride, 0);
 }
 
 template <typename T>
 static int launch_skinny(const void* x, long xs, const void* w, long ws, void* out, long os, void* partial, int M,
                          int N, int K, int ksplit, int ntw, hipStream_t st, const int* tiles = nullptr,
-                         int num_tiles = 1, long wgs = 0) {
+                         int num_tiles = 1, long wgs = 0, long up = 0) {
   const int mt = (M + 15) / 16;        // grouped mode: M is the row capacity of a tile
 #define SG_CASE(MT_)                                                                                            \
-  if (ntw == 1) launch_one<T, MT_, 1>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st, tiles, num_tiles, wgs);       \
-  else if (ntw == 2) launch_one<T, MT_, 2>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st, tiles, num_tiles, wgs);  \
-  else launch_one<T, MT_, 4>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st, tiles, num_tiles, wgs)
+  if (ntw == 1) launch_one<T, MT_, 1>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st, tiles, num_tiles, wgs, up);       \
+  else if (ntw == 2) launch_one<T, MT_, 2>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st, tiles, num_tiles, wgs, up);  \
+  else launch_one<T, MT_, 4>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st, tiles, num_tiles, wgs, up)
   if (mt <= 1) { SG_CASE(1); }
   else if (mt <= 2) { SG_CASE(2); }
   else if (mt <= 4) { SG_CASE(4); }
   else {       // 8 row tiles: at most two output tiles per wave fit the register file
-    if (ntw == 1) launch_one<T, 8, 1>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st, tiles, num_tiles, wgs);
-    else launch_one<T, 8, 2>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st, tiles, num_tiles, wgs);
+    if (ntw == 1) launch_one<T, 8, 1>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st, tiles, num_tiles, wgs, up);
+    else launch_one<T, 8, 2>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st, tiles, num_tiles, wgs, up);
   }
 #undef SG_CASE
   HIP_LAUNCH_CHECK();
@@ -176,17 +196,24 @@ static int launch_skinny(const void* x, long xs, const void* w, long ws, void* o
 // ntw = output tiles per wave (1, 2 or 4; 4 is clamped to 2 when M > 64).
 // `partial` holds ksplit*M*N floats when ksplit > 1.  Strides in elements,
 // multiples of 8; pointers 16-byte aligned.
+// up_off != 0: x holds [gate | up] per row (up at x + up_off elements) and the product is taken with
+// silu(gate) * up.
 VDAMD_API int vdamd_skinny_gemm(void* out, long out_stride, const void* x, long x_stride, const void* w,
                                 long w_stride, void* partial, int M, int N, int K, int ksplit, int ntw,
-                                int dtype, void* stream) {
+                                int dtype, long up_off, void* stream) {
   if (M <= 0) return 0;
+  if (up_off % 8) return -5;
   if (M > 128 || K % 128 || N % 16 || ksplit < 1 || ksplit > K / 128) return -1;
   if (ntw != 1 && ntw != 2 && ntw != 4) return -4;
   if (ksplit > 1 && partial == nullptr) return -2;
   if ((x_stride | w_stride) % 8 || out_stride % 4) return -5;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DT_BF16) return launch_skinny<bf16_t>(x, x_stride, w, w_stride, out, out_stride, partial, M, N, K, ksplit, ntw, st);
-  if (dtype == DT_F16) return launch_skinny<f16_t>(x, x_stride, w, w_stride, out, out_stride, partial, M, N, K, ksplit, ntw, st);
+  if (dtype == DT_BF16)
+    return launch_skinny<bf16_t>(x, x_stride, w, w_stride, out, out_stride, partial, M, N, K, ksplit, ntw, st, nullptr,
+                                 1, 0, up_off);
+  if (dtype == DT_F16)
+    return launch_skinny<f16_t>(x, x_stride, w, w_stride, out, out_stride, partial, M, N, K, ksplit, ntw, st, nullptr,
+                                1, 0, up_off);
   return -3;
 }
 

@@ -644,3 +644,23 @@ def test_linear_dispatch_uses_hand_written_kernels_in_their_range(monkeypatch):
     x = _rand(512, 8192)
     ops.linear(x, w)
     assert len(calls) == 3            # above the range: library
+
+
+@pytest.mark.parametrize("m", [1, 5, 16, 40, 128])
+def test_skinny_gemm_with_silu_mul_operand(m):
+    """The down projection fed with [gate | up]: silu(gate) * up is formed inside the GEMM."""
+    from vllm_distributed_amd.ops import hip
+    k, n = 1024, 512
+    gate_up = _rand(m, 2 * k)
+    w = _padded_weight(n, k, 128)
+    act = torch_ref.silu_and_mul(gate_up.float()).to(torch.bfloat16).float()
+    ref = act @ w.float().t()
+    for ks in (1, 2):
+        got = hip.skinny_gemm(gate_up, w, ksplit=ks, silu_mul=True)
+        torch.testing.assert_close(got.float(), ref, rtol=2e-2, atol=2e-2 * max(1.0, ref.abs().max().item()) / 4)
+    # the dispatching op agrees with activation + linear whichever path it takes
+    w2 = _padded_weight(8192, 28672, 128)
+    gu = _rand(2, 2 * 28672, scale=0.5)
+    a = ops.silu_mul_linear(gu, w2)
+    b = ops.linear(ops.silu_and_mul(gu), w2)
+    torch.testing.assert_close(a.float(), b.float(), rtol=3e-2, atol=0.3)

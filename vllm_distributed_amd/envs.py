@@ -111,6 +111,10 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     "VDAMD_SHARE_DEVICE": _bool("VDAMD_SHARE_DEVICE", False),
     # Short-batch weight-streaming GEMM for long-reduction shapes (0 = library GEMM only).
     "VDAMD_SKINNY_GEMM": _bool("VDAMD_SKINNY_GEMM", True),
+    # Form silu(gate) * up inside the weight-streaming down projection instead of a separate activation
+    # kernel.  Off by default: at 70B batch 1 the two dependent loads in front of the LDS store cost the
+    # GEMM more (about 7 us) than the 4.8 us activation kernel they replace (26.05 vs 25.85 ms per token).
+    "VDAMD_FUSE_SILU_GEMM": _bool("VDAMD_FUSE_SILU_GEMM", False),
     # Elements of padding after every row of a dense 16-bit weight on the GPU (0 = none): breaks the
     # power-of-two row stride that puts all rows of a tile on the same HBM channels.
     "VDAMD_WEIGHT_ROW_PAD": _int("VDAMD_WEIGHT_ROW_PAD", 128),

@@ -420,6 +420,21 @@ class RowParallelLinear(_LinearBase):
             y = tensor_model_parallel_all_reduce(y)
         return y
 
+    def forward_gated(self, gate_up: torch.Tensor, reduce: bool = True, staged: bool = False) -> torch.Tensor:
+        """``forward(silu(gate) * up)`` for ``gate_up = [gate | up]``.  A dense 16-bit layer hands the
+        pair to the GEMM, which forms the activation while it stages its operand (short batches on
+        the weight-streaming kernel); every other layer runs the activation kernel first."""
+        if (self.qw is not None or self.weight_scale is not None or self.lora is not None or self.bias is not None
+                or gate_up.dim() != 2):
+            return self.forward(ops.silu_and_mul(gate_up), reduce, staged)
+        out = None
+        if staged and self.tp > 1:
+            out = get_tp_group().stage_view((gate_up.shape[0], self.out_local), gate_up.dtype)
+        y = ops.silu_mul_linear(gate_up, self.weight, out)
+        if reduce and self.reduce_results and self.tp > 1:
+            y = tensor_model_parallel_all_reduce(y)
+        return y
+
 
 def pad_vocab(vocab_size: int, tp: int, multiple: int = 64) -> int:
     m = multiple * tp

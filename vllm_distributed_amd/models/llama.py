@@ -29,7 +29,7 @@ class LlamaMLP(nn.Module):
         self.down_proj = RowParallelLinear(inter, hidden, bias, dtype)
 
     def forward(self, x: torch.Tensor, reduce: bool = True, staged: bool = False) -> torch.Tensor:
-        return self.down_proj(ops.silu_and_mul(self.gate_up_proj(x)), reduce, staged)
+        return self.down_proj.forward_gated(self.gate_up_proj(x), reduce, staged)
 
 
 class LlamaAttention(nn.Module):

@@ -170,6 +170,19 @@ def linear(x, weight, bias=None, out=None):
     return torch.nn.functional.linear(x, weight, bias)
 
 
+def silu_mul_linear(gate_up, weight, out=None):
+    """``(silu(gate) * up) @ weight^T`` for ``gate_up = [gate | up]``: one kernel when the
+    weight-streaming GEMM takes the shape (it forms the activation while staging its operand),
+    otherwise the activation kernel followed by ``linear``."""
+    if (gate_up.is_cuda and gate_up.dim() == 2 and gate_up.shape[0] <= 128 and envs.VDAMD_SKINNY_GEMM
+            and envs.VDAMD_FUSE_SILU_GEMM and _use_hip(gate_up)):
+        m, n, k = gate_up.shape[0], weight.shape[0], weight.shape[1]
+        if (gate_up.shape[1] == 2 * k and not _hip.mid_profitable(m, n, k) and _hip.skinny_profitable(m, n, k)
+                and _hip.skinny_supported(gate_up[:, :k], weight)):
+            return _hip.skinny_gemm(gate_up, weight, out=out, silu_mul=True)
+    return linear(silu_and_mul(gate_up), weight, None, out)
+
+
 FP8_MAX = 448.0        # largest finite OCP e4m3 value
 
 

@@ -44,7 +44,7 @@ def load() -> ctypes.CDLL:
         "vdamd_sample": [P, P, I, I, L, P, P, P, P, P, I, P],
         "vdamd_w4a16_gemm": [P, L, P, L, P, P, P, I, I, I, I, I, I, I, P],
         "vdamd_w4_dequant": [P, P, P, I, I, I, I, P],
-        "vdamd_skinny_gemm": [P, L, P, L, P, L, P, I, I, I, I, I, I, P],
+        "vdamd_skinny_gemm": [P, L, P, L, P, L, P, I, I, I, I, I, I, L, P],
         "vdamd_dynamic_fp8_quant": [P, P, P, I, I, L, I, P],
         "vdamd_skinny_gemm_grouped": [P, L, P, L, P, L, L, P, I, I, I, I, I, I, P],
         "vdamd_w4a16_gemm_grouped": [P, L, P, L, P, P, L, L, P, I, I, I, I, I, I, P],
@@ -515,8 +515,14 @@ def skinny_profitable(m: int, n: int, k: int) -> bool:
 
 
 def skinny_gemm(x: torch.Tensor, w: torch.Tensor, ntw: Optional[int] = None, ksplit: Optional[int] = None,
-                out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``x [M<=128, K] @ w [N, K]^T`` streaming ``w`` once at HBM speed."""
+                out: Optional[torch.Tensor] = None, silu_mul: bool = False) -> torch.Tensor:
+    """``x [M<=128, K] @ w [N, K]^T`` streaming ``w`` once at HBM speed.  ``silu_mul``: ``x`` is
+    ``[M, 2K] = [gate | up]`` and the left operand is ``silu(gate) * up``, formed inside the kernel."""
+    up_off = 0
+    if silu_mul:
+        assert x.dim() == 2 and x.shape[1] == 2 * w.shape[1] and x.stride(1) == 1
+        up_off = w.shape[1]
+        x = x[:, :up_off]                      # the gate half; the kernel finds the up half up_off further on
     assert skinny_supported(x, w), (x.shape, x.stride(), w.shape, w.stride(), x.dtype)
     m, k = x.shape
     n = w.shape[0]
@@ -530,7 +536,7 @@ def skinny_gemm(x: torch.Tensor, w: torch.Tensor, ntw: Optional[int] = None, ksp
     partial = torch.empty(ksplit * m * n, dtype=torch.float32, device=x.device) if ksplit > 1 else None
     _check(_LIB.vdamd_skinny_gemm(out.data_ptr(), n, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
                                   None if partial is None else partial.data_ptr(), m, n, k, ksplit, ntw,
-                                  _dt(x), _stream()), "skinny_gemm")
+                                  _dt(x), up_off, _stream()), "skinny_gemm")
     return out
 
 
