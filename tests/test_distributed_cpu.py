@@ -521,3 +521,44 @@ def test_speculative_decoding_through_the_distributed_executor(monkeypatch):
     finally:
         if eng is not None:
             eng.shutdown()
+
+
+def test_bootstrap_blobs_travel_over_the_control_plane(monkeypatch):
+    """Workers behind the RPC exchange their bring-up values (what carries the RCCL unique id and
+    the IPC handles on a GPU box) through the head's rendezvous, not through gloo."""
+    import asyncio
+    from vllm_distributed_amd.parallel.bootstrap import HeadRendezvous
+
+    async def unit():
+        rv = HeadRendezvous()
+        got = await asyncio.gather(rv.exchange("k#0", 1, 3, b"one"), rv.exchange("k#0", 0, 3, None),
+                                   rv.exchange("k#0", 2, 3, [b"two", 2]))
+        assert got[0] == got[1] == got[2] == [None, b"one", [b"two", 2]]
+        assert not rv._slots
+        with pytest.raises(ValueError):
+            await asyncio.gather(rv.exchange("j#0", 0, 2, 1), rv.exchange("j#0", 0, 2, 1))
+    asyncio.run(unit())
+
+    port = get_open_port()
+    for k, v in _env(port, VLLM_HEAD_LOCAL_DEVICES="2").items():
+        monkeypatch.setenv(k, v)
+    eng = None
+    try:
+        eng = LLMEngine.from_engine_args(EngineArgs(
+            model="llama-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,
+            num_gpu_blocks_override=64, max_num_seqs=4, tensor_parallel_size=2,
+            distributed_executor_backend="distributed"))
+
+        def probe(self):
+            from vllm_distributed_amd.parallel import bootstrap
+            from vllm_distributed_amd.parallel.state import get_tp_group
+            tp = get_tp_group()
+            vals = tp.bootstrap_all_gather(("blob", tp.rank_in_group, b"\\x00\\x01"), "test")
+            return bootstrap.available(), vals
+        res = eng.core.executor.collective_rpc(probe)
+        for avail, vals in res:
+            assert avail
+            assert [list(v) for v in vals] == [["blob", 0, b"\\x00\\x01"], ["blob", 1, b"\\x00\\x01"]]
+    finally:
+        if eng is not None:
+            eng.shutdown()

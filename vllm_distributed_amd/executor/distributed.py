@@ -120,6 +120,9 @@ class DistributedExecutor(Executor):
         self._node_expected: Dict[str, int] = {}
         self._local_procs: List[multiprocessing.Process] = []
         self._peers: List[Optional[RpcPeer]] = [None] * self.world_size
+        # data-plane bring-up blobs (RCCL unique ids, IPC handles) are relayed between workers here
+        from ..parallel.bootstrap import HeadRendezvous
+        self.rendezvous = HeadRendezvous()
         self.workers: List[Any] = [None] * self.world_size
         self.assignments: List[Assignment] = []
         self._nodes_changed: Optional[asyncio.Event] = None
@@ -204,6 +207,7 @@ class DistributedExecutor(Executor):
             await server_handshake(transport, self.secret)
             peer, read_loop = await prepare_peer_readloop(asyncio.get_running_loop(), transport,
                                                           "head", f"worker@{ip}")
+            peer.params["bootstrap_exchange"] = self.rendezvous.exchange
             loop_task = asyncio.get_running_loop().create_task(read_loop())
             available = int(await peer.get_param("available_devices", timeout=30))
             local_rank = int(await peer.get_param("local_rank", timeout=30))
@@ -313,6 +317,7 @@ class DistributedExecutor(Executor):
         transport = ConnectionTransport(parent_conn)
         loop = asyncio.get_running_loop()
         peer, read_loop = await prepare_peer_readloop(loop, transport, "head", f"local-worker-{a.rank}")
+        peer.params["bootstrap_exchange"] = self.rendezvous.exchange
         self._peers[a.rank] = peer
 
         async def worker_read_loop() -> None:

@@ -26,6 +26,7 @@ from . import envs
 from .logger import init_logger
 from .rpc import (ConnectionTransport, RpcPeer, StreamTransport, client_handshake,
                   prepare_peer_readloop)
+from .parallel.bootstrap import install_worker_exchange
 from .utils import current_platform, get_open_port, hip_device_count_stateless, run_method
 
 logger = init_logger(__name__)
@@ -108,6 +109,7 @@ async def worker_async_main(transport, vllm_config, rank: int, local_rank: int) 
     peer, read_loop = await prepare_peer_readloop(loop, transport, f"worker-{rank}", "head")
     peer.params["print"] = print
     peer.params["local_rank"] = local_rank
+    install_worker_exchange(peer, loop)
     wrapper = WorkerWrapper(vllm_config=vllm_config, rpc_rank=rank, local_rank=local_rank)
     set_peer_run_worker(peer, wrapper, rank, local_rank)
     try:
@@ -164,6 +166,7 @@ async def remote_worker_async_main(server_ip: str, available_devices: int, local
                 if wrapper is not None:
                     raise RuntimeError("Worker already created.")
                 os.environ.update(environ)
+                install_worker_exchange(peer, loop)
                 vllm_config = cloudpickle.loads(vllm_config_blob)
                 wrapper = WorkerWrapper(vllm_config=vllm_config, rpc_rank=rank, local_rank=local_rank)
                 return set_peer_run_worker(peer, wrapper, rank, local_rank)

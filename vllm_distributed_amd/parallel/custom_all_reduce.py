@@ -55,7 +55,7 @@ class CustomAllReduce:
         self.ctx = self.lib.vdamd_car_create(self.rank, self.world, self.max_bytes, dh, sh)
         if not self.ctx:
             raise RuntimeError("could not allocate IPC staging memory")
-        handles = group.all_gather_object((dh.raw, sh.raw))
+        handles = group.bootstrap_all_gather((dh.raw, sh.raw), "ipc-handles")
         data_handles = b"".join(h[0] for h in handles)
         sig_handles = b"".join(h[1] for h in handles)
         rc = self.lib.vdamd_car_open_peers(self.ctx, data_handles, sig_handles)

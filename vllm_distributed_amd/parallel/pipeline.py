@@ -60,7 +60,7 @@ class PipelineLink:
             u = ncclUniqueId()
             _check(lib.ncclGetUniqueId(ctypes.byref(u)))
             uid = bytes(u.internal)
-        ids = pp.all_gather_object(uid)
+        ids = pp.bootstrap_all_gather(uid, "edge-ids")
         # every rank joins its upstream edge first: stage 0 has none and opens the chain
         if not pp.is_first_rank:
             self.prev = RcclCommunicator(rank=1, world_size=2, unique_id=ids[r - 1])

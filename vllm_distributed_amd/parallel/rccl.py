@@ -90,7 +90,8 @@ class RcclCommunicator:
             uid = ncclUniqueId()
             if rank == 0:
                 _check(self.lib.ncclGetUniqueId(ctypes.byref(uid)))
-            blob = group.broadcast_object(bytes(uid.internal) if rank == 0 else None, src=0)
+            # the id reaches the other ranks over the control plane (the head relays it) when there is one
+            blob = group.bootstrap_all_gather(bytes(uid.internal) if rank == 0 else None, "rccl-id")[0]
         else:
             assert rank is not None and world_size is not None
             if unique_id is None:

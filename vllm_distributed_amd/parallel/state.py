@@ -346,6 +346,17 @@ class GroupCoordinator:
     all_reduce, all_reduce_, all_gather = _timed(all_reduce), _timed(all_reduce_), _timed(all_gather)
     reduce_scatter, broadcast, send = _timed(reduce_scatter), _timed(broadcast), _timed(send)
 
+    def bootstrap_all_gather(self, obj: Any, tag: str) -> List[Any]:
+        """``all_gather_object`` for data-plane bring-up values (RCCL unique ids, IPC handles): over
+        the control plane when this process has one, else over the group's CPU channel."""
+        if self.world_size == 1:
+            return [obj]
+        from . import bootstrap
+        if bootstrap.available():
+            scope = f"{self.name}:{','.join(map(str, self.ranks))}:{tag}"
+            return bootstrap.exchange(scope, self.rank_in_group, self.world_size, obj)
+        return self.all_gather_object(obj)
+
     def broadcast_object(self, obj: Any = None, src: int = 0) -> Any:
         if self.world_size == 1:
             return obj
