@@ -60,6 +60,37 @@ __global__ __launch_bounds__(256) void k_rows16(const f4* __restrict__ p, int N,
   if (acc.x == 12345.678f) sink[0] = acc.y + acc.z + acc.w;
 }
 
+// pattern 3: what a split-K GEMM with a 64-deep K tile issues: every wave owns 16 rows and walks K alone,
+// SEG bytes of each row per visit (SEG = 128: two instructions), DEPTH visits in flight.
+template <int SEG, int DEPTH>
+__global__ __launch_bounds__(512) void k_rows16_solo(const f4* __restrict__ p, int N, int K, float* sink, int pad16,
+                                                     int ksplit) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const size_t row16 = (size_t)K / 8 + pad16;
+  constexpr int PER = SEG / 64;                        // instructions per visit
+  f4 acc = {0, 0, 0, 0};
+  const int tiles = N / 128;                           // 8 waves x 16 rows
+  const int id = blockIdx.x, ks = id % ksplit, tn = id / ksplit;
+  if (tn >= tiles) return;
+  const int visits = K * 2 / SEG;                      // along the whole row
+  const int v_lo = visits * ks / ksplit, v_hi = visits * (ks + 1) / ksplit;
+  const f4* r = p + ((size_t)tn * 128 + wid * 16 + c) * row16 + g;
+  for (int v = v_lo; v < v_hi; v += DEPTH) {
+    f4 t[DEPTH][PER];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+      for (int s = 0; s < PER; ++s)
+        t[d][s] = (v + d < v_hi) ? r[(size_t)(v + d) * (SEG / 16) + 4 * s] : f4{0, 0, 0, 0};
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+      for (int s = 0; s < PER; ++s) acc += t[d][s];
+  }
+  if (acc.x == 12345.678f) sink[0] = acc.y + acc.z + acc.w;
+}
+
 // pattern 2: one row per wave instruction (1 KiB contiguous of ONE row), wave walks its row; 16 rows per wave
 // are visited one after the other (what a direct-to-LDS staging of W would issue).
 template <int U, bool NT>
@@ -128,6 +159,20 @@ int main() {
       RUN(nm, (k_rows16<2, true><<<grid, 256>>>(q, N, K, sink, pad16)));
       snprintf(nm, 128, "rows16x64B U=4 nt pad=%dB grid=%d", pad16 * 16, grid);
       RUN(nm, (k_rows16<4, true><<<grid, 256>>>(q, N, K, sink, pad16)));
+    }
+  }
+  {
+    char nm[128];
+    const int tiles = N / 128;
+    for (int ksplit : {1, 2, 4}) {
+      snprintf(nm, 128, "solo 16 rows/wave, 128 B/visit, depth 4, ksplit=%d pad=256B", ksplit);
+      RUN(nm, (k_rows16_solo<128, 4><<<tiles * ksplit, 512>>>(q, N, K, sink, 16, ksplit)));
+      snprintf(nm, 128, "solo 16 rows/wave, 256 B/visit, depth 4, ksplit=%d pad=256B", ksplit);
+      RUN(nm, (k_rows16_solo<256, 4><<<tiles * ksplit, 512>>>(q, N, K, sink, 16, ksplit)));
+      snprintf(nm, 128, "solo 16 rows/wave, 512 B/visit, depth 2, ksplit=%d pad=256B", ksplit);
+      RUN(nm, (k_rows16_solo<512, 2><<<tiles * ksplit, 512>>>(q, N, K, sink, 16, ksplit)));
+      snprintf(nm, 128, "solo 16 rows/wave, 1024 B/visit, depth 2, ksplit=%d pad=256B", ksplit);
+      RUN(nm, (k_rows16_solo<1024, 2><<<tiles * ksplit, 512>>>(q, N, K, sink, 16, ksplit)));
     }
   }
   for (int grid : {3584}) {

@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--shapes", type=str, default="")
     ap.add_argument("--ms", type=str, default="1,8,16")
+    ap.add_argument("--variant", type=int, default=-1, help="mid_gemm variant to sweep (-1: both with --full)")
     ap.add_argument("--pad", type=int, default=0, help="row padding of W in elements (W is a [:, :K] view)")
     args = ap.parse_args()
     names = [s for s in args.shapes.split(",") if s] or list(SHAPES)
@@ -96,15 +97,21 @@ def main():
                 if args.full:
                     mcfgs = [(bm, bn, ks) for bm, bn in ((256, 256), (256, 128), (128, 256), (128, 128), (64, 256), (64, 512))
                              for ks in (1, 2, 4, 8, 16) if bm >= min(m, 256) or (bm == 128 and m > 128)]
-                for bm, bn, ks in mcfgs:
-                    got = hip.mid_gemm(x, copies[0], bm=bm, bn=bn, ksplit=ks)
+                if args.variant >= 0:
+                    mcfgs = [c + (args.variant,) for c in mcfgs]
+                elif args.full:
+                    mcfgs = [c + (v,) for c in mcfgs for v in (0, 1) if not (v == 1 and c[1] > 256)]
+                else:
+                    mcfgs = [c + (None,) for c in mcfgs]
+                for bm, bn, ks, var in mcfgs:
+                    got = hip.mid_gemm(x, copies[0], bm=bm, bn=bn, ksplit=ks, variant=var)
                     err = (got.float() - ref).abs().max().item()
-                    assert err < 0.05 * max(1.0, ref.abs().max().item()), (name, m, bm, bn, ks, err)
-                    t = timed(lambda w: hip.mid_gemm(x, w, bm=bm, bn=bn, ksplit=ks), copies)
+                    assert err < 0.05 * max(1.0, ref.abs().max().item()), (name, m, bm, bn, ks, var, err)
+                    t = timed(lambda w: hip.mid_gemm(x, w, bm=bm, bn=bn, ksplit=ks, variant=var), copies)
                     if mbest is None or t < mbest[0]:
-                        mbest = (t, bm, bn, ks)
+                        mbest = (t, bm, bn, ks, var)
                     if args.full:
-                        print(f"    {name} M={m} bm={bm} bn={bn} ks={ks}: {t:7.1f} us {nbytes / t / 1e6:5.2f} TB/s "
+                        print(f"    {name} M={m} bm={bm} bn={bn} ks={ks} v={var}: {t:7.1f} us {nbytes / t / 1e6:5.2f} TB/s "
                               f"{2 * m * n * k / t / 1e6:6.0f} TF", flush=True)
                 res["mid"] = mbest[0]
             line = f"{name:16s} N={n:6d} K={k:5d} M={m:2d} | " + " | ".join(

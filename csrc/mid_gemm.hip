@@ -167,6 +167,161 @@ __global__ __launch_bounds__(MG_THREADS) void mid_gemm_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Deep-prefetch variant.  The loop above can keep two K tiles of W in flight and no more: loads
+// retire in order, and the wait for the x registers of tile t+1 also waits for every W load issued
+// before them.  Here x never enters a register: it goes global -> LDS by LDS-DMA
+// (`global_load_lds_dwordx4`, 8 rows x 128 bytes per wave instruction, the XOR swizzle applied to
+// the per-lane SOURCE address because the destination of an LDS-DMA is lane-linear) into a
+// three-stage image, two tiles ahead; W goes into a four-slot register ring, four tiles ahead.
+// Issue order per iteration is [x(t+2) | ... compute(t) ... | W(t+4)], so the one wait of an
+// iteration, `vmcnt(12)`, retires x(t) - and with it W(t), W(t+1), which are older - while W(t+2),
+// x(t+1), W(t+3) stay in flight: an HBM round trip has three to four tile times to complete.
+// The W loads are inline asm: next to an LDS-DMA in flight the compiler would wait `vmcnt(0)` for
+// any ordinary load it can see; their destinations are only read after the counted wait, which
+// names them as read-write operands so that nothing can be scheduled across it.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+template <typename V8>
+__device__ __forceinline__ void asm_load2(V8& a, V8& b, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:64"
+               : "=&v"(a), "=&v"(b) : "v"(p) : "memory");
+}
+
+template <typename T, int BM, int FN>
+__global__ __launch_bounds__(MG_THREADS) void mid_gemm_deep_kernel(
+    const T* x, long x_stride, const T* w, long w_stride, T* out, long out_stride, float* partial, int M, int N,
+    int K, int ksplit) {
+  using V8 = typename Vec8<T>::type;
+  constexpr int BN = MG_WAVES * 16 * FN;
+  constexpr int FM = BM / 16;
+  constexpr int STAGE = BM * 128;               // bytes of one x image
+  constexpr int XS = 3;                         // x stages
+  constexpr int WS = 4;                         // W ring slots
+  constexpr int PPW = BM / 8 / MG_WAVES;        // 1 KiB DMA pieces per wave per tile
+  static_assert(PPW >= 1 && FM % 2 == 0, "unsupported tile");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[XS * STAGE];
+
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r16 = lane & 15, q = lane >> 4;
+  const int ntn = (N + BN - 1) / BN;
+  const int id = blockIdx.x;
+  const int ks = id % ksplit, tn = id / ksplit;
+  if (tn >= ntn) return;
+  const int m0 = blockIdx.y * BM, n0 = tn * BN + wid * 16 * FN;
+  const int KT = K / MG_BK;
+  const int kt_lo = (int)((long)KT * ks / ksplit), kt_hi = (int)((long)KT * (ks + 1) / ksplit);
+  const int nt = kt_hi - kt_lo;
+  if (nt <= 0) return;
+  const int last = nt - 1;
+
+  const T* wsrc[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j)
+    wsrc[j] = w + (long)min(n0 + 16 * j + r16, N - 1) * w_stride + 8 * q + (long)kt_lo * MG_BK;
+  // DMA piece p (8 rows x 128 B) of this wave: lane -> row 8p + (lane >> 3), source chunk (lane & 7) ^ swz(row)
+  const T* xsrc[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int row = 8 * (wid * PPW + i) + (lane >> 3);
+    xsrc[i] = x + (long)min(m0 + row, M - 1) * x_stride + 8 * ((lane & 7) ^ ((row >> 1) & 7)) + (long)kt_lo * MG_BK;
+  }
+  const int xoff = r16 * 128;
+  const int xswz = (r16 >> 1) & 7;
+  const int so0 = (q ^ xswz) << 4, so1 = ((4 + q) ^ xswz) << 4;
+
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int j = 0; j < FN; ++j)
+#pragma unroll
+    for (int i = 0; i < FM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  V8 wreg[WS][FN][2];
+
+  auto dma_x = [&](int stage, int t) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void*)(xsrc[i] + (long)t * MG_BK),
+                                       (lds_void*)(smem + stage * STAGE + (wid * PPW + i) * 1024), 16, 0, 0);
+  };
+  auto load_w = [&](int slot, int t) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) asm_load2(wreg[slot][j][0], wreg[slot][j][1], wsrc[j] + (long)t * MG_BK);
+  };
+
+  // prologue, in the order the steady-state accounting expects: W(0) W(1) x(0) W(2) x(1) W(3)
+  load_w(0, 0);
+  load_w(1, min(1, last));
+  dma_x(0, 0);
+  load_w(2, min(2, last));
+  dma_x(1, min(1, last));
+  load_w(3, min(3, last));
+
+  for (int t = 0; t < nt; t += 12) {
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+      const int tt = t + u;
+      if (tt >= nt) break;
+      const int stage = u % XS, slot = u % WS;
+      // x(tt) and W(tt) have landed once only W(tt+2), x(tt+1), W(tt+3) are outstanding
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * 2 * FN + PPW) : "memory");
+      // the W fragments of this slot are valid from here on: make every later use depend on this point
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        asm volatile("" : "+v"(wreg[slot][j][0]), "+v"(wreg[slot][j][1]));
+      __builtin_amdgcn_s_barrier();               // every wave's pieces of x(tt) are in LDS; stage of x(tt-1) is free
+      __builtin_amdgcn_sched_barrier(0);
+      dma_x((u + 2) % XS, min(tt + 2, last));
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const unsigned char* base = smem + stage * STAGE + xoff;
+        V8 b[2][2];
+        auto rd = [&](int p, V8 (&dst)[2]) {
+          const int s = p / (FM / 2), i = (p % (FM / 2)) * 2;
+          const int so = s ? so1 : so0;
+          dst[0] = *reinterpret_cast<const V8*>(base + i * 2048 + so);
+          dst[1] = *reinterpret_cast<const V8*>(base + (i + 1) * 2048 + so);
+        };
+        rd(0, b[0]);
+#pragma unroll
+        for (int p = 0; p < FM; ++p) {
+          if (p + 1 < FM) rd(p + 1, b[(p + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          const int s = p / (FM / 2), i = (p % (FM / 2)) * 2;
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[j][i + e] = mfma16(wreg[slot][j][s], b[p & 1][e], acc[j][i + e]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_w(slot, min(tt + WS, last));           // into the slot just consumed
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stray tail prefetches must not outlive the registers / LDS
+
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int m = m0 + 16 * i + r16;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int n = n0 + 16 * j + 4 * q;
+      if (n >= N) continue;
+      if (ksplit == 1) {
+        typename Vec4<T>::type o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (T)acc[j][i][r];
+        *reinterpret_cast<typename Vec4<T>::type*>(out + (long)m * out_stride + n) = o;
+      } else {
+        *reinterpret_cast<f32x4*>(partial + ((size_t)ks * M + m) * N + n) = acc[j][i];
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ void mid_reduce_kernel(T* __restrict__ out, long out_stride, const float* __restrict__ partial, int M,
                                   int N, int ksplit) {
@@ -184,12 +339,22 @@ __global__ void mid_reduce_kernel(T* __restrict__ out, long out_stride, const fl
 
 template <typename T, int BM, int FN>
 int launch(const void* x, long xs, const void* w, long ws, void* out, long os, void* partial, int M, int N, int K,
-           int ksplit, hipStream_t st) {
+           int ksplit, int variant, hipStream_t st) {
   constexpr int BN = MG_WAVES * 16 * FN;
   const int ntn = (N + BN - 1) / BN;
   dim3 grid(ntn * ksplit, (M + BM - 1) / BM);
-  mid_gemm_kernel<T, BM, FN><<<grid, MG_THREADS, 0, st>>>((const T*)x, xs, (const T*)w, ws, (T*)out, os,
-                                                          (float*)partial, M, N, K, ksplit);
+  if constexpr (BM >= 64 && FN <= 2) {
+    if (variant == 1) {
+      mid_gemm_deep_kernel<T, BM, FN><<<grid, MG_THREADS, 0, st>>>((const T*)x, xs, (const T*)w, ws, (T*)out, os,
+                                                                   (float*)partial, M, N, K, ksplit);
+    } else {
+      mid_gemm_kernel<T, BM, FN><<<grid, MG_THREADS, 0, st>>>((const T*)x, xs, (const T*)w, ws, (T*)out, os,
+                                                              (float*)partial, M, N, K, ksplit);
+    }
+  } else {
+    mid_gemm_kernel<T, BM, FN><<<grid, MG_THREADS, 0, st>>>((const T*)x, xs, (const T*)w, ws, (T*)out, os,
+                                                            (float*)partial, M, N, K, ksplit);
+  }
   HIP_LAUNCH_CHECK();
   if (ksplit > 1) {
     const long n = (long)M * (N / 4);
@@ -202,10 +367,10 @@ int launch(const void* x, long xs, const void* w, long ws, void* out, long os, v
 
 template <typename T>
 int dispatch(const void* x, long xs, const void* w, long ws, void* out, long os, void* partial, int M, int N, int K,
-             int ksplit, int bm, int bn, hipStream_t st) {
+             int ksplit, int bm, int bn, int variant, hipStream_t st) {
 #define MG_CASE(BM_, FN_)                                                                       \
   if (bm == BM_ && bn == MG_WAVES * 16 * FN_)                                                   \
-    return launch<T, BM_, FN_>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, st);
+    return launch<T, BM_, FN_>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, variant, st);
   MG_CASE(256, 2) MG_CASE(256, 1) MG_CASE(128, 2) MG_CASE(128, 1) MG_CASE(64, 2) MG_CASE(64, 4)
 #undef MG_CASE
   return -4;
@@ -215,9 +380,10 @@ int dispatch(const void* x, long xs, const void* w, long ws, void* out, long os,
 
 // out[M][N] = x[M][K] . w[N][K]^T.  K % 64 == 0, N % 16 == 0; strides in elements, multiples of 8;
 // pointers 16-byte aligned.  (bm, bn) is the workgroup tile: (256, 128|256), (128, 128|256), (64, 256|512).
-// partial holds ksplit * M * N floats when ksplit > 1.
+// partial holds ksplit * M * N floats when ksplit > 1.  variant 0: x staged through registers, W two tiles
+// ahead; variant 1: x by LDS-DMA, W four tiles ahead (tiles with bn <= 256).
 VDAMD_API int vdamd_mid_gemm(void* out, long out_stride, const void* x, long x_stride, const void* w, long w_stride,
-                             void* partial, int M, int N, int K, int ksplit, int bm, int bn, int dtype,
+                             void* partial, int M, int N, int K, int ksplit, int bm, int bn, int variant, int dtype,
                              void* stream) {
   if (M <= 0) return 0;
   if (K % MG_BK || N % 16 || ksplit < 1 || ksplit > K / MG_BK) return -1;
@@ -225,8 +391,8 @@ VDAMD_API int vdamd_mid_gemm(void* out, long out_stride, const void* x, long x_s
   if ((x_stride | w_stride) % 8 || out_stride % 4) return -5;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16)
-    return dispatch<bf16_t>(x, x_stride, w, w_stride, out, out_stride, partial, M, N, K, ksplit, bm, bn, st);
+    return dispatch<bf16_t>(x, x_stride, w, w_stride, out, out_stride, partial, M, N, K, ksplit, bm, bn, variant, st);
   if (dtype == DT_F16)
-    return dispatch<f16_t>(x, x_stride, w, w_stride, out, out_stride, partial, M, N, K, ksplit, bm, bn, st);
+    return dispatch<f16_t>(x, x_stride, w, w_stride, out, out_stride, partial, M, N, K, ksplit, bm, bn, variant, st);
   return -3;
 }

@@ -618,8 +618,9 @@ def test_mid_gemm_matches_fp32(dtype, m, n, k, pad):
         for ks in (1, 3, 4):
             if ks > k // 64:
                 continue
-            got = hip.mid_gemm(x, w, bm=bm, bn=bn, ksplit=ks)
-            torch.testing.assert_close(got.float(), ref, **tol)
+            for variant in ((0, 1) if bn <= 256 else (0,)):      # register-staged x / LDS-DMA x with deep W prefetch
+                got = hip.mid_gemm(x, w, bm=bm, bn=bn, ksplit=ks, variant=variant)
+                torch.testing.assert_close(got.float(), ref, **tol)
     # strided output (a slice of a wider buffer), as the fused-collective path uses
     wide = torch.zeros(m, n + 64, device=DEV, dtype=dtype)
     hip.mid_gemm(x, w, out=wide[:, :n])

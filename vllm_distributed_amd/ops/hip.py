@@ -35,7 +35,7 @@ def load() -> ctypes.CDLL:
         "vdamd_layer_norm": [P, P, P, P, F, I, I, I, P],
         "vdamd_silu_and_mul": [P, P, L, I, I, P],
         "vdamd_embedding": [P, P, P, I, I, I, I, I, P],
-        "vdamd_mid_gemm": [P, L, P, L, P, L, P, I, I, I, I, I, I, I, P],
+        "vdamd_mid_gemm": [P, L, P, L, P, L, P, I, I, I, I, I, I, I, I, P],
         "vdamd_stream_gemm": [P, L, P, L, P, L, P, P, L, I, I, I, I, I, I, I, I, I, P],
         "vdamd_rope_cache": [P, P, P, P, L, L, L, P, P, P, P, I, I, I, I, I, I, P, P, F, I, I, P, P, P],
         "vdamd_paged_attention_decode": [P, P, P, L, P, P, P, I, P, F, I, I, I, I, I, I, L, I, I, P, P, P],
@@ -596,6 +596,9 @@ def stream_gemm(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = 
 
 # ---------------------------------------- split-K LDS-DMA GEMM, 16 < M <= 512
 MID_MAX_M = 512
+# -1: the LDS-DMA / four-tile-prefetch kernel for 256-row tiles (2-7 % faster there), the register-staged
+# one for smaller tiles (where the deep variant is 2-5 % slower); 0 / 1 force one of them
+MID_VARIANT = int(os.environ.get("VDAMD_MID_GEMM_VARIANT", "-1"))
 
 
 def mid_supported(x: torch.Tensor, w: torch.Tensor) -> bool:
@@ -652,7 +655,7 @@ def mid_profitable(m: int, n: int, k: int) -> bool:
 
 
 def mid_gemm(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, ksplit: Optional[int] = None,
-             bm: Optional[int] = None, bn: Optional[int] = None) -> torch.Tensor:
+             bm: Optional[int] = None, bn: Optional[int] = None, variant: Optional[int] = None) -> torch.Tensor:
     """``x [M<=512, K] @ w [N, K]^T`` with W streamed once and K split over the chip."""
     assert mid_supported(x, w), (x.shape, x.stride(), w.shape, w.stride(), x.dtype)
     m, k = x.shape
@@ -662,13 +665,17 @@ def mid_gemm(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = Non
     bn = b if bn is None else bn
     ksplit = c if ksplit is None else ksplit
     assert 1 <= ksplit <= k // 64
+    if variant is None:
+        variant = MID_VARIANT
+    if variant < 0:
+        variant = 1 if bm == 256 and bn <= 256 else 0
     if out is None:
         out = torch.empty((m, n), dtype=x.dtype, device=x.device)
     assert out.shape == (m, n) and out.dtype == x.dtype and out.stride(1) == 1 and out.data_ptr() % 8 == 0
     partial = torch.empty(ksplit * m * n, dtype=torch.float32, device=x.device) if ksplit > 1 else None
     _check(_LIB.vdamd_mid_gemm(out.data_ptr(), out.stride(0), x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
-                               None if partial is None else partial.data_ptr(), m, n, k, ksplit, bm, bn, _dt(x),
-                               _stream()), "mid_gemm")
+                               None if partial is None else partial.data_ptr(), m, n, k, ksplit, bm, bn,
+                               variant, _dt(x), _stream()), "mid_gemm")
     return out
 
 
