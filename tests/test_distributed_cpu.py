@@ -562,3 +562,38 @@ def test_bootstrap_blobs_travel_over_the_control_plane(monkeypatch):
     finally:
         if eng is not None:
             eng.shutdown()
+
+
+def test_head_spawns_eight_workers_tp8_matches_single_process(monkeypatch):
+    """The headline topology in miniature: one head, eight workers it spawns itself, TP=8 (gloo here,
+    RCCL on a GPU node), bring-up blobs relayed by the head's rendezvous.  Greedy text equals the
+    single-process engine's."""
+    port = get_open_port()
+    for k, v in _env(port, VLLM_HEAD_LOCAL_DEVICES="8").items():
+        monkeypatch.setenv(k, v)
+    kw = dict(model="llama-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,
+              num_gpu_blocks_override=128, max_num_seqs=8,
+              hf_overrides={"num_attention_heads": 8, "num_key_value_heads": 8})
+    sp = SamplingParams(temperature=0.0, max_tokens=10, ignore_eos=True)
+    prompts = [[3 + i, 9, 27, 81, 5] for i in range(6)]
+
+    def run(eng):
+        ids = [eng.add_request(None, p, sp) for p in prompts]
+        done = {}
+        while eng.has_unfinished_requests():
+            for o in eng.step():
+                if o.finished:
+                    done[o.request_id] = o.outputs[0].token_ids
+        return [done[i] for i in ids]
+    ref = LLMEngine.from_engine_args(EngineArgs(**kw))
+    want = run(ref)
+    ref.shutdown()
+    eng = None
+    try:
+        eng = LLMEngine.from_engine_args(EngineArgs(tensor_parallel_size=8,
+                                                    distributed_executor_backend="distributed", **kw))
+        assert eng.core.executor.world_size == 8
+        assert run(eng) == want
+    finally:
+        if eng is not None:
+            eng.shutdown()
