@@ -5,9 +5,7 @@ owns the block ids.  A full block's identity is the hash chain of the tokens
 it and its predecessors hold, so two requests with a common prefix share
 blocks (ref-counted).  Freed blocks keep their hash and stay reusable until
 the allocator evicts them in LRU order.  (The reference obtains this from the
-vLLM engine it embeds - reference ``src/launch.py:407-410``; the scheduler/KV
-manager contract is summarised in the survey as "paged KV block manager
-(+prefix cache)".)
+vLLM engine it embeds - reference ``src/launch.py:407-410``.)
 """
 from __future__ import annotations
 
