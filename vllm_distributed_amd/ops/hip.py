@@ -37,6 +37,7 @@ def load() -> ctypes.CDLL:
         "vdamd_embedding": [P, P, P, I, I, I, I, I, P],
         "vdamd_mid_gemm": [P, L, P, L, P, L, P, I, I, I, I, I, I, I, I, P],
         "vdamd_stream_gemm": [P, L, P, L, P, L, P, P, L, I, I, I, I, I, I, I, I, I, P],
+        "vdamd_big_gemm": [P, L, P, L, P, L, P, L, I, I, I, I, I, P],
         "vdamd_rope_cache": [P, P, P, P, L, L, L, P, P, P, P, I, I, I, I, I, I, P, P, F, I, I, P, P, P],
         "vdamd_paged_attention_decode": [P, P, P, L, P, P, P, I, P, F, I, I, I, I, I, I, L, I, I, P, P, P],
         "vdamd_paged_attention_prefill": [P, P, L, P, P, P, I, P, P, F, I, I, I, I, I, I, L, I, I, P, P, P],
@@ -676,6 +677,44 @@ def mid_gemm(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = Non
     _check(_LIB.vdamd_mid_gemm(out.data_ptr(), out.stride(0), x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
                                None if partial is None else partial.data_ptr(), m, n, k, ksplit, bm, bn,
                                variant, _dt(x), _stream()), "mid_gemm")
+    return out
+
+
+# ------------------------------------- 256 x 256 tile LDS-DMA GEMM, M >= 512
+BIG_MIN_M = 512
+
+
+def big_supported(x: torch.Tensor, w: torch.Tensor, silu_mul: bool = False) -> bool:
+    return (x.dim() == 2 and w.dim() == 2 and x.shape[0] > 0 and x.dtype == w.dtype
+            and x.dtype in (torch.bfloat16, torch.float16) and x.shape[1] == w.shape[1]
+            and w.shape[1] % 128 == 0 and w.shape[0] % (32 if silu_mul else 16) == 0
+            and x.stride(1) == 1 and w.stride(1) == 1 and x.stride(0) % 8 == 0 and w.stride(0) % 8 == 0
+            and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
+            and x.shape[0] * x.stride(0) * 2 < (1 << 32) and w.shape[0] * w.stride(0) * 2 < (1 << 32))
+
+
+def big_gemm(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None,
+             residual: Optional[torch.Tensor] = None, silu_mul: bool = False) -> torch.Tensor:
+    """``x [M, K] @ w [N, K]^T`` on 256 x 256 tiles with both operands fed by LDS-DMA.  ``residual
+    [M, N]`` is added in the epilogue; ``silu_mul`` treats ``w`` as ``[gate ; up]`` and returns
+    ``silu(gate) * up`` (``N/2`` wide)."""
+    assert big_supported(x, w, silu_mul), (x.shape, x.stride(), w.shape, w.stride(), x.dtype)
+    assert not (silu_mul and residual is not None)
+    m, k = x.shape
+    n = w.shape[0]
+    n_out = n // 2 if silu_mul else n
+    if out is None:
+        out = torch.empty((m, n_out), dtype=x.dtype, device=x.device)
+    assert out.shape == (m, n_out) and out.dtype == x.dtype and out.stride(1) == 1 and out.data_ptr() % 8 == 0
+    assert out.stride(0) % 4 == 0
+    epi = EPI_SILU_MUL if silu_mul else (EPI_RESIDUAL if residual is not None else EPI_NONE)
+    if residual is not None:
+        assert (residual.shape == (m, n) and residual.dtype == x.dtype and residual.stride(1) == 1
+                and residual.stride(0) % 4 == 0 and residual.data_ptr() % 8 == 0)
+    _check(_LIB.vdamd_big_gemm(out.data_ptr(), out.stride(0), x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
+                               None if residual is None else residual.data_ptr(),
+                               0 if residual is None else residual.stride(0), m, n, k, epi, _dt(x), _stream()),
+           "big_gemm")
     return out
 
 
