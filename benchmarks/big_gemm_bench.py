@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--shapes", type=str, nargs="*", default=None)
+    ap.add_argument("--variants", type=int, nargs="*", default=[0])
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--fused", action="store_true")
     args = ap.parse_args()
     hip.load()
     torch.manual_seed(0)
@@ -82,15 +85,17 @@ def main():
             w = padded(n, k)
             xk = x[:, :k]
             out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
-            t_lib = timeit(lambda: torch.mm(xk, w.t(), out=out), args.iters)
-            t_big = timeit(lambda: hip.big_gemm(xk, w, out=out), args.iters)
-            t_lib2 = timeit(lambda: torch.mm(xk, w.t(), out=out), args.iters)
-            t_big2 = timeit(lambda: hip.big_gemm(xk, w, out=out), args.iters)
-            t_lib, t_big = min(t_lib, t_lib2), min(t_big, t_big2)
             fl = 2.0 * m * n * k
-            line = (f"M={m:5d} {name:16s} N={n:6d} K={k:5d}  lib {t_lib:8.1f} us {fl / t_lib / 1e6:7.1f} TF/s | "
-                    f"big {t_big:8.1f} us {fl / t_big / 1e6:7.1f} TF/s  ({t_lib / t_big:.2f}x)")
-            if "gate_up" in name:
+            fns = {"lib": lambda: torch.mm(xk, w.t(), out=out)}
+            for v in args.variants:
+                fns[f"v{v}"] = (lambda v=v: hip.big_gemm(xk, w, out=out, variant=v))
+            best = {kk: 1e30 for kk in fns}
+            for _ in range(args.rounds):
+                for kk, fn in fns.items():
+                    best[kk] = min(best[kk], timeit(fn, args.iters))
+            line = f"M={m:5d} {name:16s} N={n:6d} K={k:5d} " + " | ".join(
+                f"{kk} {tt:7.1f} us {fl / tt / 1e6:6.0f} TF" for kk, tt in best.items())
+            if "gate_up" in name and args.fused:
                 act = torch.empty((m, n // 2), dtype=torch.bfloat16, device="cuda")
                 from vllm_distributed_amd import ops
                 t_f = timeit(lambda: hip.big_gemm(xk, w, out=act, silu_mul=True), args.iters)

@@ -37,7 +37,7 @@ def load() -> ctypes.CDLL:
         "vdamd_embedding": [P, P, P, I, I, I, I, I, P],
         "vdamd_mid_gemm": [P, L, P, L, P, L, P, I, I, I, I, I, I, I, I, P],
         "vdamd_stream_gemm": [P, L, P, L, P, L, P, P, L, I, I, I, I, I, I, I, I, I, P],
-        "vdamd_big_gemm": [P, L, P, L, P, L, P, L, I, I, I, I, I, P],
+        "vdamd_big_gemm": [P, L, P, L, P, L, P, L, I, I, I, I, I, I, P],
         "vdamd_rope_cache": [P, P, P, P, L, L, L, P, P, P, P, I, I, I, I, I, I, P, P, F, I, I, P, P, P],
         "vdamd_paged_attention_decode": [P, P, P, L, P, P, P, I, P, F, I, I, I, I, I, I, L, I, I, P, P, P],
         "vdamd_paged_attention_prefill": [P, P, L, P, P, P, I, P, P, F, I, I, I, I, I, I, L, I, I, P, P, P],
@@ -682,6 +682,7 @@ def mid_gemm(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = Non
 
 # ------------------------------------- 256 x 256 tile LDS-DMA GEMM, M >= 512
 BIG_MIN_M = 512
+BIG_VARIANT = int(os.environ.get("VDAMD_BIG_GEMM_VARIANT", "0"))
 
 
 def big_supported(x: torch.Tensor, w: torch.Tensor, silu_mul: bool = False) -> bool:
@@ -694,7 +695,8 @@ def big_supported(x: torch.Tensor, w: torch.Tensor, silu_mul: bool = False) -> b
 
 
 def big_gemm(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None,
-             residual: Optional[torch.Tensor] = None, silu_mul: bool = False) -> torch.Tensor:
+             residual: Optional[torch.Tensor] = None, silu_mul: bool = False,
+             variant: Optional[int] = None) -> torch.Tensor:
     """``x [M, K] @ w [N, K]^T`` on 256 x 256 tiles with both operands fed by LDS-DMA.  ``residual
     [M, N]`` is added in the epilogue; ``silu_mul`` treats ``w`` as ``[gate ; up]`` and returns
     ``silu(gate) * up`` (``N/2`` wide)."""
@@ -713,8 +715,8 @@ def big_gemm(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = Non
                 and residual.stride(0) % 4 == 0 and residual.data_ptr() % 8 == 0)
     _check(_LIB.vdamd_big_gemm(out.data_ptr(), out.stride(0), x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
                                None if residual is None else residual.data_ptr(),
-                               0 if residual is None else residual.stride(0), m, n, k, epi, _dt(x), _stream()),
-           "big_gemm")
+                               0 if residual is None else residual.stride(0), m, n, k, epi,
+                               BIG_VARIANT if variant is None else variant, _dt(x), _stream()), "big_gemm")
     return out
 
 
