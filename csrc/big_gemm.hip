@@ -27,9 +27,9 @@
 //  * The MFMA A operand is the W fragment, so a lane ends up with 4 consecutive output columns of one
 //    row, and gate / up of the same column in the same lane for the SiLU epilogue; `v_permlane16_swap`
 //    pairs the two column fragments of a lane with its neighbour row's, giving 16-byte stores.
-//  * Workgroup -> tiles: workgroup ids are dealt round-robin to the 8 XCDs, so XCD i takes the i-th
-//    contiguous chunk of a tile order in which 32 consecutive tiles form an 8 x 4 block: they run side by
-//    side on one L2 and share their x and W panels (81 % L2 hit rate measured).
+//  * Workgroup -> tiles: bands of 8 row tiles; inside a band each XCD owns a range of tile columns and
+//    its 32 workgroups hold an 8 x 4 block of tiles at a time, sharing x and W panels in that XCD's L2
+//    (81 % L2 hit rate measured).
 #include "common.h"
 
 namespace {
@@ -66,19 +66,23 @@ __global__ __launch_bounds__(BG_THREADS) void big_gemm_kernel(
   const int wr = wid >> 2, wc = wid & 3;
   const int r16 = lane & 15, q = lane >> 4;
 
-  // ---- this workgroup's tiles
-  const int ntiles = ntm * ntn;
-  const int per = (ntiles + 7) >> 3;
+  // ---- this workgroup's tiles.  The output is cut into bands of 8 row tiles; inside a band XCD i
+  // (workgroup ids are dealt round-robin to the XCDs) owns a contiguous range of tile columns and walks
+  // it column by column, so at any time the 32 workgroups of an XCD hold an 8 x 4 block of tiles sharing
+  // 12 operand panels in that XCD's L2, and all XCDs work on the same band of x (which then stays in
+  // the memory-side cache while its W panels stream past).
   const int xcd = blockIdx.x & 7, stride = gridDim.x >> 3;
-  const int chunk_end = min((xcd + 1) * per, ntiles);
-  int tile = xcd * per + (blockIdx.x >> 3);
+  const int c0 = (int)((long)ntn * xcd >> 3), c1 = (int)((long)ntn * (xcd + 1) >> 3);
+  const int ncols = c1 - c0;
+  const int chunk_end = ntm * ncols;         // tiles of this XCD
+  int tile = blockIdx.x >> 3;                // index into this XCD's tile list
   if (tile >= chunk_end) return;
-  auto decode = [&](int tl, int& m0_, int& tn_) {     // bands of 8 row tiles, column by column inside a band
-    const int band = tl / (8 * ntn);
+  auto decode = [&](int tl, int& m0_, int& tn_) {
+    const int band = tl / (8 * ncols);
     const int rows = min(8, ntm - 8 * band);
-    const int inband = tl - band * 8 * ntn;
+    const int inband = tl - band * 8 * ncols;
     m0_ = (8 * band + inband % rows) * 256;
-    tn_ = inband / rows;
+    tn_ = c0 + inband / rows;
   };
 
   // ---- staging: this wave moves pieces 2 wid and 2 wid + 1 (8 rows x 128 B each) of every half-tile
@@ -314,7 +318,7 @@ int launch(void* out, long os, const void* x, long xs, const void* w, long ws, c
            int K, int up_row, hipStream_t st) {
   const int ntm = (M + 255) / 256;
   const int ntn = EPI == BG_EPI_SILU_MUL ? (up_row + 127) / 128 : (N + 255) / 256;
-  const int per = (ntm * ntn + 7) / 8;                       // tiles per XCD
+  const int per = ntm * ((ntn + 7) / 8);                     // most tiles any XCD gets
   const int grid = 8 * (per < bg_num_cus() / 8 ? per : bg_num_cus() / 8);
   big_gemm_kernel<T, EPI, VAR><<<grid, BG_THREADS, 0, st>>>((const T*)x, xs, (const T*)w, ws, (T*)out, os,
                                                             (const T*)res, rs, M, N, K, ntm, ntn, up_row);

@@ -628,6 +628,82 @@ def test_mid_gemm_matches_fp32(dtype, m, n, k, pad):
     assert wide[:, n:].abs().sum() == 0
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,n,k,pad", [(256, 256, 128, 0), (512, 512, 256, 128), (300, 336, 384, 8),
+                                       (1000, 2048, 2048, 128), (2048, 1024, 8192, 128),
+                                       # more tiles than CUs (9 x 30): workgroups walk several tiles, with a
+                                       # ragged last band; and a second, short band (ntm = 9)
+                                       (2200, 7680, 256, 128), (2304, 8192, 128, 0),
+                                       # fewer tile columns than XCDs
+                                       (4096, 1024, 512, 128)])
+def test_big_gemm_matches_fp32(dtype, m, n, k, pad):
+    """Large-batch 256 x 256-tile GEMM: plain, + residual and SiLU*mul epilogues, both store widths,
+    against an fp32 product of the same (padded-row) operands."""
+    from vllm_distributed_amd.ops import hip
+    x = _rand(m, k, dtype=dtype)
+    w = _padded_weight(n, k, pad, dtype)
+    ref = x.float() @ w.float().t()
+    tol = dict(rtol=2e-2, atol=2e-2 * max(1.0, ref.abs().max().item()) / 4)
+    variants = (0, 1) if dtype == torch.bfloat16 else (0,)
+    for variant in variants:
+        got = hip.big_gemm(x, w, variant=variant)
+        torch.testing.assert_close(got.float(), ref, **tol)
+        r = _rand(m, n, dtype=dtype)
+        got = hip.big_gemm(x, w, residual=r, variant=variant)
+        torch.testing.assert_close(got.float(), ref + r.float(), **tol)
+        if n % 32 == 0:
+            act = torch_ref.silu_and_mul(ref)
+            got = hip.big_gemm(x, w, silu_mul=True, variant=variant)
+            torch.testing.assert_close(got.float(), act, rtol=3e-2, atol=3e-2 * max(1.0, act.abs().max().item()) / 4)
+    # in place on the residual, and a strided output (a slice of a wider buffer)
+    r = _rand(m, n, dtype=dtype)
+    want = ref + r.float()
+    hip.big_gemm(x, w, out=r, residual=r)
+    torch.testing.assert_close(r.float(), want, **tol)
+    wide = torch.zeros(m, n + 64, device=DEV, dtype=dtype)
+    hip.big_gemm(x, w, out=wide[:, :n])
+    torch.testing.assert_close(wide[:, :n].float(), ref, **tol)
+    assert wide[:, n:].abs().sum() == 0
+
+
+def test_big_gemm_exact_integers_catch_any_misplaced_tile():
+    """Small-integer operands make every output an exact integer: a fragment written to the wrong row,
+    column or half-tile cannot hide inside a tolerance."""
+    from vllm_distributed_amd.ops import hip
+    m, n, k = 768, 1280, 256
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x = torch.randint(-1, 2, (m, k), generator=g).to(torch.bfloat16).to(DEV)
+    w = torch.randint(-2, 3, (n, k), generator=g).to(torch.bfloat16).to(DEV)
+    ref = x.float() @ w.float().t()
+    assert ref.abs().max() <= 256         # every output exactly representable in bf16
+    for variant in (0, 1):
+        assert torch.equal(hip.big_gemm(x, w, variant=variant).float(), ref)
+
+
+def test_large_batch_dispatch_reaches_the_big_gemm(monkeypatch):
+    """At decode-batch sizes that fill the chip ops.linear and the gated MLP front half run the
+    hand-written large-batch kernel, and agree with library GEMM + activation kernel."""
+    from vllm_distributed_amd.ops import hip
+    calls = []
+    real = hip.big_gemm
+    monkeypatch.setattr(hip, "big_gemm", lambda *a, **kw: (calls.append(bool(kw.get("silu_mul"))), real(*a, **kw))[1])
+    x = _rand(2048, 4096)
+    w = _padded_weight(8192, 4096, 128)
+    y = ops.linear(x, w)
+    ref = torch.nn.functional.linear(x, w)
+    torch.testing.assert_close(y.float(), ref.float(), rtol=2e-2, atol=0.1)
+    assert calls == [False]
+    wgu = _padded_weight(2 * 7168, 4096, 128)
+    act = ops.gate_up_silu(x, wgu)
+    assert calls == [False, True] and act is not None and act.shape == (2048, 7168)
+    want = ops.silu_and_mul(torch.nn.functional.linear(x, wgu))
+    torch.testing.assert_close(act.float(), want.float(), rtol=3e-2, atol=0.1)
+    # too few tiles to fill the chip: the library keeps the shape
+    assert ops.gate_up_silu(_rand(512, 4096), _padded_weight(2 * 1024, 4096, 128)) is None
+    ops.linear(_rand(512, 4096), w)
+    assert len(calls) == 2
+
+
 def test_linear_dispatch_uses_hand_written_kernels_in_their_range(monkeypatch):
     """ops.linear must reach the hand-written kernels where they are profitable, and agree with the
     library on the same padded weight."""

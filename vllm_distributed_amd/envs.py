@@ -111,6 +111,9 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     "VDAMD_SHARE_DEVICE": _bool("VDAMD_SHARE_DEVICE", False),
     # Short-batch weight-streaming GEMM for long-reduction shapes (0 = library GEMM only).
     "VDAMD_SKINNY_GEMM": _bool("VDAMD_SKINNY_GEMM", True),
+    # Large-batch (M >= 512) 256 x 256-tile LDS-DMA GEMM with fused SiLU*mul / residual epilogues
+    # (0 = library GEMM + separate activation kernel).
+    "VDAMD_BIG_GEMM": _bool("VDAMD_BIG_GEMM", True),
     # Form silu(gate) * up inside the weight-streaming down projection instead of a separate activation
     # kernel.  Off by default: at 70B batch 1 the two dependent loads in front of the LDS store cost the
     # GEMM more (about 7 us) than the 4.8 us activation kernel they replace (26.05 vs 25.85 ms per token).

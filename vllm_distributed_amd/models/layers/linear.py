@@ -338,6 +338,15 @@ class ColumnParallelLinear(_LinearBase):
             y = tensor_model_parallel_all_gather(y, dim=-1)
         return y
 
+    def forward_silu(self, x: torch.Tensor) -> Optional[torch.Tensor]:
+        """``silu(gate) * up`` straight from ``x`` for a ``[gate ; up]`` layer when one kernel can do
+        it (dense 16-bit weights, large batch), else None: the caller falls back to ``forward`` plus
+        the activation."""
+        if (self.qw is not None or self.weight_scale is not None or self.lora is not None or self.bias is not None
+                or self.gather_output or len(self.shard_sizes) != 2 or self.shard_sizes[0] != self.shard_sizes[1]):
+            return None
+        return ops.gate_up_silu(x, self.weight)
+
 
 class QKVParallelLinear(_LinearBase):
     """Fused q/k/v projection.  Query heads are split across ranks; KV heads

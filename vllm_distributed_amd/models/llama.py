@@ -29,6 +29,9 @@ class LlamaMLP(nn.Module):
         self.down_proj = RowParallelLinear(inter, hidden, bias, dtype)
 
     def forward(self, x: torch.Tensor, reduce: bool = True, staged: bool = False) -> torch.Tensor:
+        act = self.gate_up_proj.forward_silu(x)       # large batches: activation formed in the GEMM epilogue
+        if act is not None:
+            return self.down_proj(act, reduce, staged)
         return self.down_proj.forward_gated(self.gate_up_proj(x), reduce, staged)
 
 

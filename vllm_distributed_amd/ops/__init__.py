@@ -163,11 +163,32 @@ def linear(x, weight, bias=None, out=None):
         if m <= 128 and _hip.skinny_profitable(m, n, k) and _hip.skinny_supported(x, weight):
             y = _hip.skinny_gemm(x, weight, out=out)
             return y if bias is None else y.add_(bias)
+    if (x.is_cuda and x.dim() == 2 and envs.VDAMD_BIG_GEMM and _use_hip(x) and x.shape[0] >= _hip.BIG_MIN_M
+            and _hip.big_profitable(x.shape[0], weight.shape[0], weight.shape[1])
+            and _hip.big_supported(x, weight) and _big_out_ok(out, x.shape[0])):
+        y = _hip.big_gemm(x, weight, out=out)
+        return y if bias is None else y.add_(bias)
     if out is not None and x.dim() == 2:
         if bias is None:
             return torch.mm(x, weight.t(), out=out)
         return torch.addmm(bias, x, weight.t(), out=out)
     return torch.nn.functional.linear(x, weight, bias)
+
+
+def _big_out_ok(out, m):
+    return out is None or (out.stride(1) == 1 and out.stride(0) % 8 == 0 and out.data_ptr() % 16 == 0
+                           and m * out.stride(0) * 2 < (1 << 32) - 64)
+
+
+def gate_up_silu(x, weight):
+    """``silu(x @ Wg^T) * (x @ Wu^T)`` for ``weight = [Wg ; Wu]`` in one kernel (the large-batch GEMM
+    forms the activation in its epilogue: the ``[M, 2F]`` intermediate is never written), or ``None``
+    when that kernel does not take the shape - the caller then runs the two-step path."""
+    if (x.is_cuda and x.dim() == 2 and envs.VDAMD_BIG_GEMM and _use_hip(x) and x.shape[0] >= _hip.BIG_MIN_M
+            and _hip.big_profitable(x.shape[0], weight.shape[0], weight.shape[1], True)
+            and _hip.big_supported(x, weight, True)):
+        return _hip.big_gemm(x, weight, silu_mul=True)
+    return None
 
 
 def silu_mul_linear(gate_up, weight, out=None):

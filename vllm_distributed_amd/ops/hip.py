@@ -691,7 +691,23 @@ def big_supported(x: torch.Tensor, w: torch.Tensor, silu_mul: bool = False) -> b
             and w.shape[1] % 128 == 0 and w.shape[0] % (32 if silu_mul else 16) == 0
             and x.stride(1) == 1 and w.stride(1) == 1 and x.stride(0) % 8 == 0 and w.stride(0) % 8 == 0
             and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
-            and x.shape[0] * x.stride(0) * 2 < (1 << 32) and w.shape[0] * w.stride(0) * 2 < (1 << 32))
+            and x.shape[0] * x.stride(0) * 2 < (1 << 32) - 64 and w.shape[0] * w.stride(0) * 2 < (1 << 32) - 64)
+
+
+def big_profitable(m: int, n: int, k: int, silu_mul: bool = False) -> bool:
+    """Where the 256 x 256-tile kernel is level with or ahead of the library GEMM on MI355X
+    (benchmarks/big_gemm_bench.py, profiles/r2_big_gemm_vs_library.txt): enough tiles to fill the
+    chip's 256 CUs in whole rounds.  With the SiLU*mul epilogue it also saves the activation kernel
+    and wins at every batch size measured (512 .. 16384 rows); without it the library is 1-4 % ahead
+    from 4096 rows up and stays in charge there."""
+    if m < BIG_MIN_M or k < 1024:
+        return False
+    tiles = -(-m // 256) * (-(-(n // 2) // 128) if silu_mul else -(-n // 256))
+    rounds = -(-tiles // 256)
+    eff = tiles / (rounds * 256.0)
+    if silu_mul:
+        return tiles >= 200 and eff >= 0.85
+    return m <= 3072 and tiles >= 224 and eff >= 0.9
 
 
 def big_gemm(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None,
@@ -707,8 +723,8 @@ def big_gemm(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = Non
     n_out = n // 2 if silu_mul else n
     if out is None:
         out = torch.empty((m, n_out), dtype=x.dtype, device=x.device)
-    assert out.shape == (m, n_out) and out.dtype == x.dtype and out.stride(1) == 1 and out.data_ptr() % 8 == 0
-    assert out.stride(0) % 4 == 0
+    assert out.shape == (m, n_out) and out.dtype == x.dtype and out.stride(1) == 1 and out.data_ptr() % 16 == 0
+    assert out.stride(0) % 8 == 0 and m * out.stride(0) * 2 < (1 << 32) - 64
     epi = EPI_SILU_MUL if silu_mul else (EPI_RESIDUAL if residual is not None else EPI_NONE)
     if residual is not None:
         assert (residual.shape == (m, n) and residual.dtype == x.dtype and residual.stride(1) == 1
