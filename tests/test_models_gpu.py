@@ -117,3 +117,39 @@ def test_json_mode_on_gpu():
         assert isinstance(json.loads(c.text), dict)
     llm.shutdown()
     pstate.destroy_model_parallel()
+
+
+def test_large_batch_fused_gemm_epilogues_track_the_unfused_path(monkeypatch):
+    """A 2048-token prefill step of two 70B-shaped layers: with the large-batch GEMM the activation is
+    formed in the gate_up epilogue and the o / down projections add straight into the residual stream;
+    the tokens and their logprobs must track the library-GEMM + separate-kernel path."""
+    from vllm_distributed_amd.ops import hip
+    hip.load()
+    calls = {"silu": 0, "res": 0, "plain": 0}
+    real = hip.big_gemm
+
+    def spy(x, w, out=None, residual=None, silu_mul=False, variant=None):
+        calls["silu" if silu_mul else "res" if residual is not None else "plain"] += 1
+        return real(x, w, out=out, residual=residual, silu_mul=silu_mul, variant=variant)
+
+    monkeypatch.setattr(hip, "big_gemm", spy)
+    prompts = [[(7 * i + 3 * j) % 1000 + 5 for i in range(1024)] for j in range(2)]
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("VDAMD_BIG_GEMM", flag)
+        llm = LLM(model="llama-3-70b", load_format="dummy", dtype="bfloat16", hf_overrides={"num_hidden_layers": 2},
+                  max_model_len=1100, max_num_seqs=4, max_num_batched_tokens=2048, num_gpu_blocks_override=64,
+                  gpu_memory_utilization=0.5, enforce_eager=True, enable_prefix_caching=False)
+        outs[flag] = llm.generate(prompts, SamplingParams(temperature=0.0, max_tokens=2, ignore_eos=True, logprobs=5))
+        llm.shutdown()
+        pstate.destroy_model_parallel()
+        if flag == "1":
+            # two layers: gate_up with SiLU*mul, o and down adding into the residual; the LM head (2 rows) not
+            assert calls["silu"] >= 2 and calls["res"] >= 4, calls
+            seen = dict(calls)
+    assert calls == seen, "VDAMD_BIG_GEMM=0 must not reach the kernel"
+    for a, b in zip(outs["1"], outs["0"]):
+        la, lb = a.outputs[0].logprobs[0], b.outputs[0].logprobs[0]
+        top_a, top_b = max(la, key=la.get), max(lb, key=lb.get)
+        assert top_a in lb and top_b in la
+        assert abs(la[top_a] - lb[top_a]) < 0.15

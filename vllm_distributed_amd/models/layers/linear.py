@@ -429,6 +429,15 @@ class RowParallelLinear(_LinearBase):
             y = tensor_model_parallel_all_reduce(y)
         return y
 
+    def forward_add(self, x: torch.Tensor, residual: torch.Tensor) -> bool:
+        """``residual += x W^T`` in the GEMM's epilogue, for an unsharded dense 16-bit layer and a
+        batch the large-batch kernel takes; False (nothing done) otherwise.  The add + RMSNorm that
+        follows then only has to normalise ``residual``."""
+        if (self.tp > 1 or self.qw is not None or self.weight_scale is not None or self.lora is not None
+                or self.bias is not None or x.dim() != 2):
+            return False
+        return ops.linear_add(x, self.weight, residual)
+
     def forward_gated(self, gate_up: torch.Tensor, reduce: bool = True, staged: bool = False) -> torch.Tensor:
         """``forward(silu(gate) * up)`` for ``gate_up = [gate | up]``.  A dense 16-bit layer hands the
         pair to the GEMM, which forms the activation while it stages its operand (short batches on

@@ -28,9 +28,15 @@ class LlamaMLP(nn.Module):
         self.gate_up_proj = ColumnParallelLinear(hidden, [inter, inter], bias, dtype)
         self.down_proj = RowParallelLinear(inter, hidden, bias, dtype)
 
-    def forward(self, x: torch.Tensor, reduce: bool = True, staged: bool = False) -> torch.Tensor:
+    supports_residual = True
+
+    def forward(self, x: torch.Tensor, reduce: bool = True, staged: bool = False,
+                residual: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """With ``residual``: None is returned when the down projection added its product into it."""
         act = self.gate_up_proj.forward_silu(x)       # large batches: activation formed in the GEMM epilogue
         if act is not None:
+            if residual is not None and self.down_proj.forward_add(act, residual):
+                return None
             return self.down_proj(act, reduce, staged)
         return self.down_proj.forward_gated(self.gate_up_proj(x), reduce, staged)
 
@@ -59,7 +65,8 @@ class LlamaAttention(nn.Module):
                               self.head_dim ** -0.5, layer_idx)
 
     def forward(self, positions: torch.Tensor, hidden: torch.Tensor, reduce: bool = True,
-                staged: bool = False) -> torch.Tensor:
+                staged: bool = False, residual: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """With ``residual``: None is returned when the output projection added its product into it."""
         qkv = self.qkv_proj(hidden)
         md = get_forward_context().attn_metadata
         if self.qk_norm and md is not None and self.attn.k_cache is not None:
@@ -84,6 +91,8 @@ class LlamaAttention(nn.Module):
                                    self.attn.v_cache, md.slot_mapping, self.num_heads,
                                    self.num_kv_heads, self.head_dim, kv_scales=self.attn.kv_scales)
             out = self.attn.forward_cached(q)
+        if residual is not None and self.o_proj.forward_add(out, residual):
+            return None
         return self.o_proj(out, reduce, staged)
 
 
@@ -114,16 +123,26 @@ class LlamaDecoderLayer(nn.Module):
         hidden, residual = self.post_attention_layernorm(hidden, residual)
         return self.mlp(hidden, reduce=False), residual
 
-    def forward(self, positions: torch.Tensor, hidden: torch.Tensor,
-                residual: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    def forward(self, positions: torch.Tensor, hidden: Optional[torch.Tensor],
+                residual: Optional[torch.Tensor]) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
+        """``hidden`` None (in or out): the producing GEMM has already added its product into
+        ``residual`` (large unsharded batches), so the norm that follows is a plain one."""
         if residual is None:
             residual = hidden
             hidden = self.input_layernorm(hidden)
+        elif hidden is None:
+            hidden = self.input_layernorm(residual)
         else:
             hidden, residual = self.input_layernorm(hidden, residual)
-        hidden = self.self_attn(positions, hidden)
-        hidden, residual = self.post_attention_layernorm(hidden, residual)
-        hidden = self.mlp(hidden)
+        hidden = self.self_attn(positions, hidden, residual=residual)
+        if hidden is None:
+            hidden = self.post_attention_layernorm(residual)
+        else:
+            hidden, residual = self.post_attention_layernorm(hidden, residual)
+        if getattr(self.mlp, "supports_residual", False):
+            hidden = self.mlp(hidden, residual=residual)
+        else:
+            hidden = self.mlp(hidden)
         return hidden, residual
 
 
@@ -191,7 +210,11 @@ class LlamaForCausalLM(nn.Module):
         for layer in self.layers.values():
             hidden, residual = layer(positions, hidden, residual)
         if not self.is_last:
+            if hidden is None:                  # the last GEMM already added its product into the residual
+                hidden = torch.zeros_like(residual)
             return IntermediateTensors(hidden, residual)
+        if hidden is None:
+            return self.norm(residual)
         hidden, _ = self.norm(hidden, residual)
         return hidden
 

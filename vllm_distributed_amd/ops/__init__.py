@@ -180,6 +180,18 @@ def _big_out_ok(out, m):
                            and m * out.stride(0) * 2 < (1 << 32) - 64)
 
 
+def linear_add(x, weight, residual) -> bool:
+    """``residual += x @ weight^T`` inside the large-batch GEMM (its epilogue reads and rewrites the
+    residual tile it has just computed); False when that kernel does not take the shape."""
+    if (x.is_cuda and x.dim() == 2 and envs.VDAMD_BIG_GEMM and _use_hip(x) and x.shape[0] >= _hip.BIG_MIN_M
+            and _hip.big_profitable(x.shape[0], weight.shape[0], weight.shape[1])
+            and _hip.big_supported(x, weight) and residual.shape == (x.shape[0], weight.shape[0])
+            and residual.dtype == x.dtype and _big_out_ok(residual, x.shape[0])):
+        _hip.big_gemm(x, weight, out=residual, residual=residual)
+        return True
+    return False
+
+
 def gate_up_silu(x, weight):
     """``silu(x @ Wg^T) * (x @ Wu^T)`` for ``weight = [Wg ; Wu]`` in one kernel (the large-batch GEMM
     forms the activation in its epilogue: the ``[M, 2F]`` intermediate is never written), or ``None``
