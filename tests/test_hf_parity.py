@@ -1,0 +1,76 @@
+"""Every model family against the implementation in the installed ``transformers`` package: a tiny
+random-init Hugging Face model is saved as a safetensors checkpoint, loaded through the engine's own
+loader and run on the CPU in fp32; first-token log-probabilities and greedy continuations must agree
+with the Hugging Face forward pass on the same weights."""
+import pytest
+import torch
+
+from vllm_distributed_amd import LLM, SamplingParams
+from vllm_distributed_amd.parallel import state as pstate
+
+transformers = pytest.importorskip("transformers")
+
+BASE = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+            num_key_value_heads=2, vocab_size=320, max_position_embeddings=128)
+CASES = {
+    "llama": ("LlamaConfig", dict(BASE, rope_theta=10000.0)),
+    "llama3-rope": ("LlamaConfig", dict(BASE, rope_theta=500000.0, rope_scaling=dict(
+        rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0,
+        original_max_position_embeddings=32))),
+    "llama-bias-tied": ("LlamaConfig", dict(BASE, attention_bias=True, mlp_bias=True, tie_word_embeddings=True)),
+    "mistral": ("MistralConfig", dict(BASE, sliding_window=None)),
+    "qwen2": ("Qwen2Config", dict(BASE)),
+    "qwen3": ("Qwen3Config", dict(BASE, head_dim=32)),
+    "phi3": ("Phi3Config", dict(BASE, pad_token_id=0)),
+    "opt": ("OPTConfig", dict(hidden_size=64, ffn_dim=128, num_hidden_layers=2, num_attention_heads=4, vocab_size=320,
+                              max_position_embeddings=128, word_embed_proj_dim=64)),
+    "mixtral": ("MixtralConfig", dict(BASE, num_local_experts=4, num_experts_per_tok=2, sliding_window=None)),
+    "qwen3-moe": ("Qwen3MoeConfig", dict(BASE, head_dim=32, moe_intermediate_size=64, num_experts=8,
+                                         num_experts_per_tok=2, norm_topk_prob=True, decoder_sparse_step=1,
+                                         mlp_only_layers=[])),
+}
+PROMPTS = [[5, 9, 200, 17, 33, 2, 90], list(range(10, 60)), [7, 7, 300, 2, 2, 41, 8, 100, 101]]
+
+
+def _hf_model(name, tmp_path):
+    cls, kw = CASES[name]
+    cfg_cls = getattr(transformers, cls, None)
+    if cfg_cls is None:
+        pytest.skip(f"transformers has no {cls}")
+    torch.manual_seed(1234)
+    cfg = cfg_cls(**kw)
+    model = transformers.AutoModelForCausalLM.from_config(cfg).eval().float()
+    # the default initialisation leaves norms at one and biases at zero: perturb them so that a missing
+    # bias, a swapped norm or an unapplied scale shows
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    model.save_pretrained(str(tmp_path), safe_serialization=True)
+    return model
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_family_matches_transformers(name, tmp_path):
+    model = _hf_model(name, tmp_path)
+    ref_lp, ref_tokens = [], []
+    with torch.no_grad():
+        for p in PROMPTS:
+            ids = torch.tensor([p])
+            ref_lp.append(model(ids).logits[0, -1].float().log_softmax(-1))
+            gen = model.generate(ids, max_new_tokens=4, do_sample=False, pad_token_id=0)
+            ref_tokens.append(gen[0, len(p):].tolist())
+    llm = LLM(model=str(tmp_path), dtype="float32", device="cpu", max_model_len=128, num_gpu_blocks_override=64,
+              max_num_seqs=8)
+    try:
+        outs = llm.generate(PROMPTS, SamplingParams(temperature=0.0, max_tokens=4, ignore_eos=True, logprobs=10))
+    finally:
+        llm.shutdown()
+        pstate.destroy_model_parallel()
+    for out, lp, toks in zip(outs, ref_lp, ref_tokens):
+        got = out.outputs[0].logprobs[0]
+        top = torch.topk(lp, 5).indices.tolist()
+        assert set(top) <= set(got), (name, top, sorted(got))
+        for t in top:
+            assert abs(got[t] - lp[t].item()) < 2e-3, (name, t, got[t], lp[t].item())
+        assert list(out.outputs[0].token_ids) == toks, (name, out.outputs[0].token_ids, toks)

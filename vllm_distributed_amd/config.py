@@ -82,6 +82,27 @@ def load_hf_config(model: str) -> Dict[str, Any]:
         f"not bundled; bundled: {sorted(set(_BUILTIN_ALIASES.values()))})")
 
 
+def normalize_hf_config(cfg: Dict[str, Any]) -> None:
+    """Key spellings that differ between ``transformers`` releases, mapped onto the ones the model
+    code reads (in place): newer releases write ``num_local_experts`` / ``dtype`` / a ``rope_parameters``
+    block where older checkpoints have ``num_experts`` / ``torch_dtype`` / ``rope_theta`` + ``rope_scaling``."""
+    if cfg.get("num_experts") is None and cfg.get("num_local_experts") is not None:
+        cfg["num_experts"] = cfg["num_local_experts"]
+    if cfg.get("num_local_experts") is None and cfg.get("num_experts") is not None:
+        cfg["num_local_experts"] = cfg["num_experts"]
+    if "torch_dtype" not in cfg and isinstance(cfg.get("dtype"), str):
+        cfg["torch_dtype"] = cfg["dtype"]
+    rp = cfg.get("rope_parameters")
+    if isinstance(rp, dict):
+        if "rope_theta" in rp and cfg.get("rope_theta") is None:
+            cfg["rope_theta"] = rp["rope_theta"]
+        if cfg.get("rope_scaling") is None and rp.get("rope_type", "default") not in ("default", None):
+            cfg["rope_scaling"] = {k: v for k, v in rp.items() if k != "rope_theta"}
+        for k in ("partial_rotary_factor",):
+            if k in rp and cfg.get(k) is None:
+                cfg[k] = rp[k]
+
+
 def is_bundled_architecture_name(model: str) -> bool:
     """Short names of the config files shipped in ``models/configs`` (``llama-tiny``,
     ``llama-3-70b``, ...): architecture descriptions for tests and benchmarks, which only
@@ -130,6 +151,7 @@ class ModelConfig:
         if not self.hf_config:
             self.hf_config = dict(load_hf_config(self.model))
         self.hf_config.update(self.hf_overrides or {})
+        normalize_hf_config(self.hf_config)
         if self.tokenizer is None:
             self.tokenizer = self.model
         if self.served_model_name is None:
