@@ -25,6 +25,17 @@ CASES = {
     "opt": ("OPTConfig", dict(hidden_size=64, ffn_dim=128, num_hidden_layers=2, num_attention_heads=4, vocab_size=320,
                               max_position_embeddings=128, word_embed_proj_dim=64)),
     "mixtral": ("MixtralConfig", dict(BASE, num_local_experts=4, num_experts_per_tok=2, sliding_window=None)),
+    "gemma": ("GemmaConfig", dict(BASE, head_dim=32, hidden_activation="gelu_pytorch_tanh")),
+    "granite": ("GraniteConfig", dict(BASE, embedding_multiplier=6.0, residual_multiplier=0.4,
+                                      attention_multiplier=0.1, logits_scaling=4.0, tie_word_embeddings=True)),
+    "gpt2": ("GPT2Config", dict(n_embd=64, n_layer=2, n_head=4, vocab_size=320, n_positions=128)),
+    "gpt-neox": ("GPTNeoXConfig", dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+                                       num_attention_heads=4, vocab_size=320, max_position_embeddings=128,
+                                       rotary_pct=0.5, use_parallel_residual=True)),
+    "gpt-neox-serial": ("GPTNeoXConfig", dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+                                              num_attention_heads=4, vocab_size=320, max_position_embeddings=128,
+                                              rotary_pct=0.25, use_parallel_residual=False)),
+    "starcoder2": ("Starcoder2Config", dict(BASE, sliding_window=None, use_bias=True)),
     "qwen3-moe": ("Qwen3MoeConfig", dict(BASE, head_dim=32, moe_intermediate_size=64, num_experts=8,
                                          num_experts_per_tok=2, norm_topk_prob=True, decoder_sparse_step=1,
                                          mlp_only_layers=[])),

@@ -86,6 +86,11 @@ def normalize_hf_config(cfg: Dict[str, Any]) -> None:
     """Key spellings that differ between ``transformers`` releases, mapped onto the ones the model
     code reads (in place): newer releases write ``num_local_experts`` / ``dtype`` / a ``rope_parameters``
     block where older checkpoints have ``num_experts`` / ``torch_dtype`` / ``rope_theta`` + ``rope_scaling``."""
+    # GPT-2 era spellings
+    for old, new in (("n_embd", "hidden_size"), ("n_head", "num_attention_heads"), ("n_layer", "num_hidden_layers"),
+                     ("n_positions", "max_position_embeddings")):
+        if cfg.get(new) is None and cfg.get(old) is not None:
+            cfg[new] = cfg[old]
     if cfg.get("num_experts") is None and cfg.get("num_local_experts") is not None:
         cfg["num_experts"] = cfg["num_local_experts"]
     if cfg.get("num_local_experts") is None and cfg.get("num_experts") is not None:

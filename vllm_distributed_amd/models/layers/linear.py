@@ -460,8 +460,11 @@ def pad_vocab(vocab_size: int, tp: int, multiple: int = 64) -> int:
 
 
 class VocabParallelEmbedding(nn.Module):
-    def __init__(self, vocab_size: int, hidden_size: int, dtype: torch.dtype):
+    def __init__(self, vocab_size: int, hidden_size: int, dtype: torch.dtype, out_scale: Optional[float] = None):
         super().__init__()
+        # factor on the looked-up rows (not on the weight: a tied LM head reads it unscaled); rounded
+        # to the activation dtype first, as the defining implementations do
+        self.out_scale = out_scale
         self.tp = get_tensor_model_parallel_world_size()
         self.tp_rank = get_tensor_model_parallel_rank()
         self.vocab_size = vocab_size
@@ -487,6 +490,8 @@ class VocabParallelEmbedding(nn.Module):
         if staged and self.tp > 1:
             dst = get_tp_group().stage_view((ids.shape[0], self.weight.shape[1]), self.weight.dtype)
         out = ops.embedding(ids, self.weight, self.vocab_start, masked=self.tp > 1, out=dst)
+        if self.out_scale is not None:
+            out.mul_(torch.tensor(self.out_scale, dtype=out.dtype, device=out.device))
         if reduce and self.tp > 1:
             out = tensor_model_parallel_all_reduce(out)
         return out

@@ -23,16 +23,19 @@ from .utils import IntermediateTensors, get_pp_layer_range, materialize
 
 
 class LlamaMLP(nn.Module):
-    def __init__(self, hidden: int, inter: int, dtype: torch.dtype, bias: bool = False):
+    def __init__(self, hidden: int, inter: int, dtype: torch.dtype, bias: bool = False, act: str = "silu"):
         super().__init__()
         self.gate_up_proj = ColumnParallelLinear(hidden, [inter, inter], bias, dtype)
         self.down_proj = RowParallelLinear(inter, hidden, bias, dtype)
+        self.act = act                      # "silu" (SwiGLU) or a GELU flavour (GeGLU: Gemma)
 
     supports_residual = True
 
     def forward(self, x: torch.Tensor, reduce: bool = True, staged: bool = False,
                 residual: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         """With ``residual``: None is returned when the down projection added its product into it."""
+        if self.act != "silu":
+            return self.down_proj(ops.act_and_mul(self.gate_up_proj(x), self.act), reduce, staged)
         act = self.gate_up_proj.forward_silu(x)       # large batches: activation formed in the GEMM epilogue
         if act is not None:
             if residual is not None and self.down_proj.forward_add(act, residual):
@@ -61,8 +64,9 @@ class LlamaAttention(nn.Module):
             eps = cfg.get("rms_norm_eps", 1e-6)
             self.q_norm = RMSNorm(self.head_dim, eps, dtype)
             self.k_norm = RMSNorm(self.head_dim, eps, dtype)
-        self.attn = Attention(self.num_heads, self.head_dim, self.num_kv_heads,
-                              self.head_dim ** -0.5, layer_idx)
+        # Granite scales the scores by ``attention_multiplier`` instead of 1 / sqrt(head_dim)
+        scale = cfg.get("attention_multiplier") or self.head_dim ** -0.5
+        self.attn = Attention(self.num_heads, self.head_dim, self.num_kv_heads, float(scale), layer_idx)
 
     def forward(self, positions: torch.Tensor, hidden: torch.Tensor, reduce: bool = True,
                 staged: bool = False, residual: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
@@ -106,8 +110,9 @@ class LlamaDecoderLayer(nn.Module):
         self.post_attention_layernorm = RMSNorm(cfg["hidden_size"], eps, dtype)
 
     def _make_mlp(self, cfg: dict, dtype: torch.dtype) -> nn.Module:
+        act = cfg.get("hidden_activation") or cfg.get("hidden_act") or "silu"
         return LlamaMLP(cfg["hidden_size"], cfg["intermediate_size"], dtype,
-                        bool(cfg.get("mlp_bias", False)))
+                        bool(cfg.get("mlp_bias", False)), "silu" if act in ("silu", "swish") else act)
 
     # the layer split in two at its all-reduces, for micro-batch overlap
     def attn_phase(self, positions: torch.Tensor, hidden: torch.Tensor,
@@ -171,7 +176,8 @@ class LlamaForCausalLM(nn.Module):
         self.register_buffer("cos_sin_cache", cos_sin, persistent=False)
         tie = bool(cfg.get("tie_word_embeddings", False))
         if self.is_first or (tie and self.is_last):
-            self.embed_tokens = VocabParallelEmbedding(cfg["vocab_size"], cfg["hidden_size"], dtype)
+            self.embed_tokens = VocabParallelEmbedding(cfg["vocab_size"], cfg["hidden_size"], dtype,
+                                                       out_scale=self.embedding_scale(cfg))
         spec = {"awq": QuantSpec("awq", mc.quant_group_size), "fp8": QuantSpec("fp8"),
                 "nvfp4": QuantSpec("nvfp4", 16, 1)}.get(mc.quantization)
         self.quant_method = spec.method if spec is not None else None
@@ -186,6 +192,15 @@ class LlamaForCausalLM(nn.Module):
             else:
                 self.lm_head = ParallelLMHead(cfg["vocab_size"], cfg["hidden_size"], dtype)
         self.tie = tie
+
+    # ---- what differs between the Llama-shaped families (see llama_variants.py)
+    def embedding_scale(self, cfg: dict) -> Optional[float]:
+        """Factor applied to the embedding output (Gemma: sqrt(hidden), Granite: a config value)."""
+        return None
+
+    def transform_weight(self, name: str, w):
+        """Checkpoint tensor -> the tensor this implementation wants under the (mapped) ``name``."""
+        return w
 
     def rebind_buffers(self) -> None:
         """After ``.to(device)`` the layers must see the moved cos/sin table."""
@@ -451,6 +466,7 @@ class LlamaForCausalLM(nn.Module):
                 if renamed is None:
                     continue
                 name, w = renamed
+            w = self.transform_weight(name, w)
             if name.endswith((".k_scale", ".v_scale")) and ".self_attn." in name:
                 # per-tensor scales of an fp8 KV cache (read only when the cache is e4m3)
                 layer = self.layers[name.split("layers.")[1].split(".")[0]]

@@ -72,10 +72,56 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
                 shapes[q + n + ".weight"] = (h,)
                 shapes[q + n + ".bias"] = (h,)
         return shapes
+    if arch == "GPT2LMHeadModel":
+        inner = c.get("n_inner") or 4 * h
+        shapes["transformer.wte.weight"] = (c["vocab_size"], h)
+        shapes["transformer.wpe.weight"] = (c.get("n_positions", c.get("max_position_embeddings", 1024)), h)
+        shapes["transformer.ln_f.weight"] = shapes["transformer.ln_f.bias"] = (h,)
+        for i in range(L):
+            q = f"transformer.h.{i}."
+            for n in ("ln_1", "ln_2"):
+                shapes[q + n + ".weight"] = shapes[q + n + ".bias"] = (h,)
+            # Conv1D weights are stored [in, out]
+            shapes[q + "attn.c_attn.weight"], shapes[q + "attn.c_attn.bias"] = (h, 3 * h), (3 * h,)
+            shapes[q + "attn.c_proj.weight"], shapes[q + "attn.c_proj.bias"] = (h, h), (h,)
+            shapes[q + "mlp.c_fc.weight"], shapes[q + "mlp.c_fc.bias"] = (h, inner), (inner,)
+            shapes[q + "mlp.c_proj.weight"], shapes[q + "mlp.c_proj.bias"] = (inner, h), (h,)
+        return shapes
+    if arch == "GPTNeoXForCausalLM":
+        inter = c["intermediate_size"]
+        shapes["gpt_neox.embed_in.weight"] = (c["vocab_size"], h)
+        shapes["gpt_neox.final_layer_norm.weight"] = shapes["gpt_neox.final_layer_norm.bias"] = (h,)
+        if not c.get("tie_word_embeddings", False):
+            shapes["embed_out.weight"] = (c["vocab_size"], h)
+        for i in range(L):
+            q = f"gpt_neox.layers.{i}."
+            for n in ("input_layernorm", "post_attention_layernorm"):
+                shapes[q + n + ".weight"] = shapes[q + n + ".bias"] = (h,)
+            shapes[q + "attention.query_key_value.weight"] = (3 * h, h)
+            shapes[q + "attention.query_key_value.bias"] = (3 * h,)
+            shapes[q + "attention.dense.weight"], shapes[q + "attention.dense.bias"] = (h, h), (h,)
+            shapes[q + "mlp.dense_h_to_4h.weight"], shapes[q + "mlp.dense_h_to_4h.bias"] = (inter, h), (inter,)
+            shapes[q + "mlp.dense_4h_to_h.weight"], shapes[q + "mlp.dense_4h_to_h.bias"] = (h, inter), (h,)
+        return shapes
     heads = c["num_attention_heads"]
     kvh = c.get("num_key_value_heads") or heads
     hd = c.get("head_dim") or h // heads
     inter = c.get("intermediate_size", 0)
+    if arch == "Starcoder2ForCausalLM":
+        shapes["model.embed_tokens.weight"] = (c["vocab_size"], h)
+        shapes["model.norm.weight"] = shapes["model.norm.bias"] = (h,)
+        if not c.get("tie_word_embeddings", True):
+            shapes["lm_head.weight"] = (c["vocab_size"], h)
+        for i in range(L):
+            q = f"model.layers.{i}."
+            for n in ("input_layernorm", "post_attention_layernorm"):
+                shapes[q + n + ".weight"] = shapes[q + n + ".bias"] = (h,)
+            for n, rows in (("q_proj", heads * hd), ("k_proj", kvh * hd), ("v_proj", kvh * hd), ("o_proj", h)):
+                shapes[q + f"self_attn.{n}.weight"] = (rows, h if n != "o_proj" else heads * hd)
+                shapes[q + f"self_attn.{n}.bias"] = (rows,)
+            shapes[q + "mlp.c_fc.weight"], shapes[q + "mlp.c_fc.bias"] = (inter, h), (inter,)
+            shapes[q + "mlp.c_proj.weight"], shapes[q + "mlp.c_proj.bias"] = (h, inter), (h,)
+        return shapes
     moe = arch == "Qwen3MoeForCausalLM"
     mixtral = arch == "MixtralForCausalLM"
     phi3 = arch == "Phi3ForCausalLM"

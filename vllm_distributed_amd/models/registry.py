@@ -14,6 +14,11 @@ _MODELS: Dict[str, Tuple[str, str]] = {
     # Phi-3 checkpoints store qkv and gate/up already fused: the fused loaders take them whole
     "Phi3ForCausalLM": ("llama", "LlamaForCausalLM"),
     "OPTForCausalLM": ("opt", "OPTForCausalLM"),
+    "GemmaForCausalLM": ("llama_variants", "GemmaForCausalLM"),
+    "GraniteForCausalLM": ("llama_variants", "GraniteForCausalLM"),
+    "GPT2LMHeadModel": ("gpt2", "GPT2LMHeadModel"),
+    "GPTNeoXForCausalLM": ("gpt_neox", "GPTNeoXForCausalLM"),
+    "Starcoder2ForCausalLM": ("starcoder2", "Starcoder2ForCausalLM"),
 }
 
 

@@ -79,7 +79,8 @@ def silu_and_mul(x):
 
 
 def rotary_embedding(positions, q, k, cos_sin_cache, head_dim):
-    if _use_hip(q):
+    # the HIP kernel rotates whole heads; a partial rotation (GPT-NeoX's rotary_pct) takes the reference ops
+    if _use_hip(q) and cos_sin_cache.shape[-1] == head_dim:
         return _hip.rotary_embedding(positions, q, k, cos_sin_cache, head_dim)
     return torch_ref.rotary_embedding(positions, q, k, cos_sin_cache, head_dim)
 
@@ -173,6 +174,29 @@ def linear(x, weight, bias=None, out=None):
             return torch.mm(x, weight.t(), out=out)
         return torch.addmm(bias, x, weight.t(), out=out)
     return torch.nn.functional.linear(x, weight, bias)
+
+
+_GELU_KINDS = {"gelu": "none", "gelu_new": "tanh", "gelu_pytorch_tanh": "tanh", "gelu_fast": "tanh",
+               "gelu_tanh": "tanh"}
+
+
+def activation(x, kind: str):
+    """Element-wise activation by its Hugging Face name."""
+    if kind in ("silu", "swish"):
+        return torch.nn.functional.silu(x)
+    if kind == "relu":
+        return torch.relu(x)
+    if kind in _GELU_KINDS:
+        return torch.nn.functional.gelu(x, approximate=_GELU_KINDS[kind])
+    raise ValueError(f"unsupported activation {kind!r}")
+
+
+def act_and_mul(x, kind: str):
+    """``act(x[..., :F]) * x[..., F:]`` for a gated MLP with an activation other than SiLU (GeGLU)."""
+    if kind in ("silu", "swish"):
+        return silu_and_mul(x)
+    f = x.shape[-1] // 2
+    return activation(x[..., :f], kind) * x[..., f:]
 
 
 def _big_out_ok(out, m):
