@@ -174,6 +174,15 @@ class ModelConfig:
         if self.dtype in ("float", "fp32"):
             self.dtype = "float32"
         derived = self.derived_max_model_len()
+        window = self.sliding_window()
+        if window is not None and window < derived:
+            # Attention here is over the whole context.  Inside the window that IS the checkpoint's
+            # attention; beyond it the outputs would silently differ, so the context is capped there.
+            if self.max_model_len is not None and self.max_model_len > window:
+                raise ValueError(
+                    f"{self.model}: sliding-window attention (window {window}) is not implemented; "
+                    f"--max-model-len must not exceed {window} (got {self.max_model_len})")
+            derived = window
         if self.max_model_len is None:
             self.max_model_len = derived
         if self.quantization is None:
@@ -244,6 +253,16 @@ class ModelConfig:
             if key in c and c[key]:
                 return int(c[key])
         return 2048
+
+    def sliding_window(self) -> Optional[int]:
+        """The attention window of a checkpoint that restricts every layer to one, else None."""
+        c = self.hf_config
+        w = c.get("sliding_window")
+        if not w or c.get("use_sliding_window") is False:      # Qwen2 ships a value with the feature off
+            return None
+        if c.get("layer_types") and not all(t == "sliding_attention" for t in c["layer_types"]):
+            return None if not any(t == "sliding_attention" for t in c["layer_types"]) else int(w)
+        return int(w)
 
     @property
     def architecture(self) -> str:

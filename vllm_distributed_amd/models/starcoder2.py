@@ -52,10 +52,7 @@ class Starcoder2ForCausalLM(nn.Module):
         mc = vllm_config.model_config
         cfg, dtype = mc.hf_config, mc.torch_dtype
         self.cfg = cfg
-        window = cfg.get("sliding_window")
-        if window is not None and mc.max_model_len > window:
-            raise ValueError(f"sliding-window attention is not implemented: max_model_len {mc.max_model_len} "
-                             f"exceeds the checkpoint's window of {window} tokens (pass --max-model-len {window})")
+        # (a checkpoint's sliding window caps max_model_len in ModelConfig: attention here is global)
         pp = get_pp_group()
         self.is_first, self.is_last = pp.is_first_rank, pp.is_last_rank
         self.start_layer, self.end_layer = get_pp_layer_range(
