@@ -134,6 +134,42 @@ def test_server_endpoints_end_to_end(frontend_mp):
                 r = await c.post("/v1/chat/completions", headers=hdr, json={
                     "model": "tiny", "messages": [{"role": "user", "content": "hi"}], "max_tokens": 3, "n": 2})
                 assert r.status_code == 200 and len(r.json()["choices"]) == 2
+                # best_of: five seeded samples, the two most probable returned; usage counts all five;
+                # the same five come back (in sample order) from n = 5 with the same seed
+                r = await c.post("/v1/completions", headers=hdr, json={
+                    "prompt": "hello", "max_tokens": 4, "temperature": 1.0, "seed": 11, "ignore_eos": True,
+                    "n": 2, "best_of": 5})
+                assert r.status_code == 200, r.text
+                best = r.json()
+                assert len(best["choices"]) == 2 and best["usage"]["completion_tokens"] == 20
+                allfive = (await c.post("/v1/completions", headers=hdr, json={
+                    "prompt": "hello", "max_tokens": 4, "temperature": 1.0, "seed": 11, "ignore_eos": True,
+                    "n": 5, "logprobs": 0})).json()
+                ranked = sorted(allfive["choices"], key=lambda ch: -sum(ch["logprobs"]["token_logprobs"]))
+                assert [ch["text"] for ch in best["choices"]] == [ch["text"] for ch in ranked[:2]]
+                assert (await c.post("/v1/completions", headers=hdr, json={
+                    "prompt": "hello", "max_tokens": 2, "n": 2, "best_of": 4, "stream": True})).status_code == 400
+                assert (await c.post("/v1/completions", headers=hdr, json={
+                    "prompt": "hello", "max_tokens": 2, "n": 3, "best_of": 2})).status_code == 400
+                # beam search: n is the beam width, beams come back best first; width 1 is greedy decoding
+                greedy = (await c.post("/v1/completions", headers=hdr, json={
+                    "prompt": [1, 2, 3, 4], "max_tokens": 4, "temperature": 0, "ignore_eos": True, "logprobs": 0})).json()
+                b1 = (await c.post("/v1/completions", headers=hdr, json={
+                    "prompt": [1, 2, 3, 4], "max_tokens": 4, "use_beam_search": True, "n": 1, "ignore_eos": True})).json()
+                # (texts differ only in how a dangling partial UTF-8 sequence is rendered: compare the scores)
+                assert abs(b1["choices"][0]["cumulative_logprob"]
+                           - sum(greedy["choices"][0]["logprobs"]["token_logprobs"])) < 1e-3
+                r = await c.post("/v1/completions", headers=hdr, json={
+                    "prompt": [1, 2, 3, 4], "max_tokens": 4, "use_beam_search": True, "n": 3, "ignore_eos": True})
+                assert r.status_code == 200, r.text
+                beams = r.json()["choices"]
+                scores = [ch["cumulative_logprob"] for ch in beams]
+                assert len(beams) == 3 and scores == sorted(scores, reverse=True)
+                assert scores[0] >= b1["choices"][0]["cumulative_logprob"] - 1e-6
+                r = await c.post("/v1/chat/completions", headers=hdr, json={
+                    "model": "tiny", "messages": [{"role": "user", "content": "hi"}], "max_tokens": 3,
+                    "use_beam_search": True, "n": 2})
+                assert r.status_code == 200 and len(r.json()["choices"]) == 2, r.text
                 r2 = await c.post("/v1/completions", headers=hdr, json={
                     "prompt": [1, 2, 3, 4], "max_tokens": 4, "temperature": 0, "stream": True,
                     "stream_options": {"include_usage": True}})

@@ -312,3 +312,40 @@ def test_ngram_speculative_decoding_reproduces_greedy_output():
     assert again == want
     with pytest.raises(ValueError):
         LLM(speculative_config={"method": "eagle"}, **kw)
+
+
+def test_offline_n_best_of_and_beam_search():
+    """``LLM.generate`` fans ``n`` / ``best_of`` out into requests that share the prompt; beam search runs
+    on one-token requests: width 1 is greedy decoding, beams come back best first and every beam's
+    cumulative log-probability is what scoring its tokens as a prompt gives."""
+    from vllm_distributed_amd import BeamSearchParams
+    llm = LLM(model="llama-tiny", load_format="dummy", dtype="float32", device="cpu", max_model_len=128,
+              num_gpu_blocks_override=128, max_num_seqs=16)
+    try:
+        prompt = [5, 9, 200, 17, 33]
+        sp = SamplingParams(temperature=1.0, seed=7, max_tokens=5, ignore_eos=True, n=4, logprobs=0)
+        out = llm.generate([prompt], sp)[0]
+        assert [c.index for c in out.outputs] == [0, 1, 2, 3]
+        again = llm.generate([prompt], sp)[0]
+        assert [c.token_ids for c in again.outputs] == [c.token_ids for c in out.outputs]
+        assert len({tuple(c.token_ids) for c in out.outputs}) > 1            # the seed is advanced per sample
+        best = llm.generate([prompt], SamplingParams(temperature=1.0, seed=7, max_tokens=5, ignore_eos=True,
+                                                     n=2, best_of=4))[0]
+        ranked = sorted(out.outputs, key=lambda c: -c.cumulative_logprob)
+        assert [list(c.token_ids) for c in best.outputs] == [list(c.token_ids) for c in ranked[:2]]
+
+        greedy = llm.generate([prompt], SamplingParams(temperature=0.0, max_tokens=5, ignore_eos=True))[0]
+        b1 = llm.beam_search([prompt], BeamSearchParams(beam_width=1, max_tokens=5, ignore_eos=True))[0]
+        assert list(b1.outputs[0].token_ids) == list(greedy.outputs[0].token_ids)
+        res = llm.beam_search([prompt], BeamSearchParams(beam_width=3, max_tokens=5, ignore_eos=True))[0]
+        assert len(res.outputs) == 3
+        scores = [c.cumulative_logprob for c in res.outputs]
+        assert scores == sorted(scores, reverse=True) and scores[0] >= b1.outputs[0].cumulative_logprob - 1e-6
+        for c in res.outputs:
+            scored = llm.generate([prompt + list(c.token_ids)],
+                                  SamplingParams(temperature=0.0, max_tokens=1, prompt_logprobs=0))[0]
+            lp = sum(d[t] for t, d in zip(c.token_ids, scored.prompt_logprobs[len(prompt):]))
+            assert abs(lp - c.cumulative_logprob) < 1e-3
+    finally:
+        llm.shutdown()
+        pstate.destroy_model_parallel()

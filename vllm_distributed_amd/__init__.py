@@ -6,7 +6,7 @@ Public API mirrors what a user of the reference reaches through vLLM:
 """
 from .version import __version__
 
-__all__ = ["__version__", "LLM", "SamplingParams", "EngineArgs", "RequestOutput"]
+__all__ = ["__version__", "LLM", "SamplingParams", "BeamSearchParams", "EngineArgs", "RequestOutput"]
 
 
 def __getattr__(name):
@@ -16,6 +16,9 @@ def __getattr__(name):
     if name == "SamplingParams":
         from .sampling_params import SamplingParams
         return SamplingParams
+    if name == "BeamSearchParams":
+        from .engine.beam_search import BeamSearchParams
+        return BeamSearchParams
     if name == "EngineArgs":
         from .engine.arg_utils import EngineArgs
         return EngineArgs

@@ -15,6 +15,8 @@ from ..executor.abstract import Executor
 from ..logger import init_logger
 from ..outputs import CompletionOutput, RequestOutput
 from ..sampling_params import SamplingParams
+from .beam_search import BeamSearchParams
+from .beam_search import beam_search as run_beam_search
 from ..tokenizer import get_tokenizer
 from .arg_utils import EngineArgs
 from .core import EngineCore
@@ -230,13 +232,57 @@ class LLM:
         else:
             sps = list(sampling_params)
         loras = lora_request if isinstance(lora_request, (list, tuple)) else [lora_request] * n
-        ids = [self.engine.add_request(None, p, sp, lora_request=lr) for p, sp, lr in zip(prompts, sps, loras)]
+        # ``n`` (or ``best_of``) samples of a prompt are that many requests sharing the prompt (and,
+        # through the prefix cache, its KV blocks); a fixed seed is advanced per sample
+        groups: List[List[str]] = []
+        for p, sp, lr in zip(prompts, sps, loras):
+            fan = sp.best_of or sp.n
+            if fan == 1:
+                groups.append([self.engine.add_request(None, p, sp, lora_request=lr)])
+                continue
+            members = []
+            for j in range(fan):
+                one = sp.clone()
+                one.n, one.best_of = 1, None
+                if one.seed is not None:
+                    one.seed = (one.seed + j) % (2 ** 63)
+                if sp.best_of is not None and sp.best_of > sp.n and one.logprobs is None:
+                    one.logprobs = 0            # the ranking needs each sample's cumulative logprob
+                members.append(self.engine.add_request(None, p, one, lora_request=lr))
+            groups.append(members)
         final: Dict[str, RequestOutput] = {}
         while self.engine.has_unfinished_requests():
             for out in self.engine.step():
                 if out.finished:
                     final[out.request_id] = out
-        return [final[i] for i in ids]
+        return [merge_samples([final[i] for i in g], sp) for g, sp in zip(groups, sps)]
+
+    def beam_search(self, prompts, params: Optional[BeamSearchParams] = None, lora_request=None,
+                    ) -> List[RequestOutput]:
+        """Best ``beam_width`` continuations of every prompt (``outputs`` sorted best first, each with its
+        ``cumulative_logprob``)."""
+        params = params or BeamSearchParams()
+        if isinstance(prompts, (str, dict)) or (prompts and isinstance(prompts[0], int)):
+            prompts = [prompts]  # type: ignore[list-item]
+        tok = self.engine.tokenizer
+        results = []
+        for k, p in enumerate(prompts):
+            if isinstance(p, dict):
+                ids = p.get("prompt_token_ids") or tok.encode(p.get("prompt"))
+                text = p.get("prompt")
+            elif isinstance(p, str):
+                ids, text = tok.encode(p), p
+            else:
+                ids, text = list(p), None
+            beams = run_beam_search(self.engine, ids, params, lora_request)
+            outs = [CompletionOutput(index=i, text=tok.decode(b.tokens), token_ids=list(b.tokens),
+                                     cumulative_logprob=b.cum_logprob, logprobs=None,
+                                     finish_reason="stop" if b.finished else "length", stop_reason=None)
+                    for i, b in enumerate(beams)]
+            results.append(RequestOutput(request_id=f"beam-{k}", prompt=text, prompt_token_ids=list(ids),
+                                         outputs=outs, finished=True, metrics=None, new_token_ids=[],
+                                         new_text="", prompt_logprobs=None, pooled=None))
+        return results
 
     def chat(self, messages: List[dict], sampling_params: Optional[SamplingParams] = None,
              tools=None) -> List[RequestOutput]:
@@ -271,6 +317,22 @@ class LLM:
 
     def shutdown(self) -> None:
         self.engine.shutdown()
+
+
+def merge_samples(outs: List[RequestOutput], sp: SamplingParams) -> RequestOutput:
+    """The finished requests of one prompt's samples as one ``RequestOutput``: the ``n`` best by
+    cumulative log-probability when ``best_of`` asked for more samples than it returns."""
+    if len(outs) == 1:
+        return outs[0]
+    comps = [o.outputs[0] for o in outs]
+    if sp.best_of is not None and sp.best_of > sp.n:
+        comps.sort(key=lambda c: -(c.cumulative_logprob if c.cumulative_logprob is not None else float("-inf")))
+        comps = comps[:sp.n]
+    for i, c in enumerate(comps):
+        c.index = i
+    first = outs[0]
+    first.outputs = comps
+    return first
 
 
 def l2_normalize(v: List[float]) -> List[float]:

@@ -34,6 +34,7 @@ from ...engine.async_llm import AsyncLLM
 from ...engine.core import EngineDeadError
 from ...logger import init_logger
 from ...sampling_params import SamplingParams
+from ...engine.beam_search import BeamSearchParams, beam_search_async
 from ...version import __version__
 from .tool_parsers import ToolParserManager
 
@@ -58,6 +59,9 @@ class CompletionRequest(_Base):
     top_k: Optional[int] = -1
     min_p: Optional[float] = 0.0
     n: int = 1
+    best_of: Optional[int] = None          # sample this many, return the n most probable (not streamable)
+    use_beam_search: bool = False          # n = beam width; deterministic (not streamable)
+    length_penalty: float = 1.0
     stream: bool = False
     stream_options: Optional[StreamOptions] = None
     stop: Union[None, str, List[str]] = None
@@ -98,6 +102,8 @@ class ChatCompletionRequest(_Base):
     top_k: Optional[int] = -1
     min_p: Optional[float] = 0.0
     n: int = 1
+    use_beam_search: bool = False          # n = beam width; deterministic (not streamable)
+    length_penalty: float = 1.0
     stream: bool = False
     stream_options: Optional[StreamOptions] = None
     stop: Union[None, str, List[str]] = None
@@ -544,11 +550,42 @@ def _register_routes(app: FastAPI, dev_mode: bool = False) -> None:
             sp = _sampling_params(req, 16, st.max_model_len, req.logprobs, st.default_sampling, st.max_logprobs)
         except ValueError as e:
             return _error(str(e))
-        # n samples per prompt = n requests sharing the prompt (its KV blocks are shared through the
-        # prefix cache); a fixed seed is advanced per sample so the samples differ reproducibly
         lora = st.loras.get(req.model) if req.model else None
+        best_of = int(req.best_of or n)
+        if best_of < n:
+            return _error("best_of must be >= n")
+        if (req.use_beam_search or best_of > n) and req.stream:
+            return _error("beam search and best_of > n rank finished sequences: they cannot be streamed")
+        if req.use_beam_search:
+            tok = engine.tokenizer
+            bp = BeamSearchParams(beam_width=n, max_tokens=sp.max_tokens or 16, length_penalty=req.length_penalty,
+                                  ignore_eos=req.ignore_eos)
+            try:
+                id_lists = [list(pr) if not isinstance(pr, str) else tok.encode(pr) for pr in prompts]
+                found = await asyncio.gather(*[
+                    beam_search_async(engine, ids, bp, req.priority, lora, st.max_logprobs) for ids in id_lists])
+            except ValueError as e:
+                return _error(str(e))
+            except EngineDeadError as e:
+                return _error(str(e), 500, "InternalServerError")
+            choices, n_out = [], 0
+            for i, (pr, beams) in enumerate(zip(prompts, found)):
+                for b in beams:
+                    text = tok.decode(b.tokens)
+                    if req.echo:
+                        text = (pr if isinstance(pr, str) else tok.decode(list(pr))) + text
+                    choices.append({"index": len(choices), "text": text, "logprobs": None,
+                                    "cumulative_logprob": b.cum_logprob,
+                                    "finish_reason": "stop" if b.finished else "length", "stop_reason": None})
+                    n_out += len(b.tokens)
+            return {"id": rid, "object": "text_completion", "created": created, "model": model,
+                    "choices": choices, "usage": _usage(sum(len(x) for x in id_lists), n_out)}
+        if best_of > n and sp.logprobs is None:
+            sp.logprobs = 0                   # the ranking needs every sample's cumulative logprob
+        # n (or best_of) samples per prompt = that many requests sharing the prompt (its KV blocks are shared
+        # through the prefix cache); a fixed seed is advanced per sample so the samples differ reproducibly
         gens = [engine.generate(pr, _nth_params(sp, j), f"{rid}-{i}-{j}", req.priority, lora)
-                for i, pr in enumerate(prompts) for j in range(n)]
+                for i, pr in enumerate(prompts) for j in range(best_of)]
 
         def lp_block(out, start: int, with_prompt: bool = False) -> Optional[dict]:
             lps = out.outputs[0].logprobs
@@ -611,7 +648,16 @@ def _register_routes(app: FastAPI, dev_mode: bool = False) -> None:
         except EngineDeadError as e:
             return _error(str(e), 500, "InternalServerError")
         choices = []
-        n_prompt = n_out = 0
+        n_prompt = sum(len(finals[i].prompt_token_ids) for i in range(0, len(finals), best_of))
+        n_out = sum(len(out.outputs[0].token_ids) for out in finals)      # every sample was generated, kept or not
+        if best_of > n:
+            kept = []
+            for g in range(0, len(finals), best_of):
+                group = sorted(finals[g:g + best_of], key=lambda o: -(
+                    o.outputs[0].cumulative_logprob if o.outputs[0].cumulative_logprob is not None
+                    else float("-inf")))
+                kept.extend(group[:n])
+            finals = kept
         for i, out in enumerate(finals):
             c = out.outputs[0]
             text = ((out.prompt or "") if req.echo else "") + c.text
@@ -619,9 +665,6 @@ def _register_routes(app: FastAPI, dev_mode: bool = False) -> None:
                             "finish_reason": c.finish_reason, "stop_reason": c.stop_reason})
             if req.prompt_logprobs is not None:
                 choices[-1]["prompt_logprobs"] = _prompt_logprobs_json(engine.tokenizer, out.prompt_logprobs)
-            if i % n == 0:
-                n_prompt += len(out.prompt_token_ids)
-            n_out += len(c.token_ids)
         return {"id": rid, "object": "text_completion", "created": created, "model": model,
                 "choices": choices, "usage": _usage(n_prompt, n_out)}
 
@@ -689,6 +732,24 @@ def _register_routes(app: FastAPI, dev_mode: bool = False) -> None:
         parser = st.tool_parser if tools and not forced_tool and not required_tools else None
         if required_tools:
             parser = _RequiredToolsParser()
+        if req.use_beam_search:
+            if req.stream:
+                return _error("beam search ranks finished sequences: it cannot be streamed")
+            bp = BeamSearchParams(beam_width=n, max_tokens=sp.max_tokens or max(1, st.max_model_len - len(prompt_ids)),
+                                  length_penalty=req.length_penalty, ignore_eos=req.ignore_eos)
+            try:
+                beams = await beam_search_async(engine, prompt_ids, bp, req.priority,
+                                                st.loras.get(req.model) if req.model else None, st.max_logprobs)
+            except ValueError as e:
+                return _error(str(e))
+            except EngineDeadError as e:
+                return _error(str(e), 500, "InternalServerError")
+            choices = [{"index": i, "message": {"role": "assistant", "content": tok.decode(b.tokens)},
+                        "logprobs": None, "cumulative_logprob": b.cum_logprob,
+                        "finish_reason": "stop" if b.finished else "length", "stop_reason": None}
+                       for i, b in enumerate(beams)]
+            return {"id": rid, "object": "chat.completion", "created": created, "model": model, "choices": choices,
+                    "usage": _usage(len(prompt_ids), sum(len(b.tokens) for b in beams))}
         from .tool_parsers import _call_id
         gens = [engine.generate({"prompt": prompt, "prompt_token_ids": prompt_ids}, _nth_params(sp, j),
                                 rid if n == 1 else f"{rid}-{j}", req.priority,

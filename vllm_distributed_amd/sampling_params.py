@@ -8,6 +8,7 @@ from typing import Any, Dict, List, Optional, Union
 @dataclass
 class SamplingParams:
     n: int = 1
+    best_of: Optional[int] = None   # sample this many, return the n with the highest cumulative logprob
     temperature: float = 1.0
     top_p: float = 1.0
     top_k: int = -1                 # -1 / 0 = disabled
@@ -58,6 +59,8 @@ class SamplingParams:
             raise ValueError("max_tokens must be >= 1")
         if self.n < 1:
             raise ValueError("n must be >= 1")
+        if self.best_of is not None and self.best_of < self.n:
+            raise ValueError("best_of must be >= n")
         if self.seed is not None:
             # clients commonly send -1 for "no seed"; anything else must be usable as a generator seed
             if isinstance(self.seed, bool) or not isinstance(self.seed, int):
