@@ -106,7 +106,7 @@ template <typename T, int D, int NQ>
 __device__ __forceinline__ void attend_loaded(
     const KVFrag<T, D>& f, int base, int seq_len, float scale_log2e,
     const typename Vec8<T>::type (&qf)[NQ][D / 32], f32x4 (&acc)[NQ][D / 16], float (&m)[NQ], float (&l)[NQ],
-    const int (&qpos_hi)[NQ]) {
+    const int (&qpos_hi)[NQ], const int (&qpos_lo)[NQ]) {
   using V = typename Vec8<T>::type;
   const int g4 = (threadIdx.x & 63) >> 4;
   const int kidx0 = base + 8 * g4;     // key index of P element j is kidx0 + j
@@ -119,12 +119,13 @@ __device__ __forceinline__ void attend_loaded(
       s1 = mfma16(f.kfb[s], qf[n][s], s1);
     }
     const int hi = min(qpos_hi[n], seq_len - 1);
+    const int lo = qpos_lo[n];           // first key inside the sliding window (0 without one)
     float p[8];
     float tmax = NEG_BIG;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float sv = (j < 4 ? s0[j & 3] : s1[j & 3]) * scale_log2e;
-      p[j] = (kidx0 + j <= hi) ? sv : NEG_BIG;
+      p[j] = (kidx0 + j <= hi && kidx0 + j >= lo) ? sv : NEG_BIG;
       tmax = fmaxf(tmax, p[j]);
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
@@ -135,7 +136,9 @@ __device__ __forceinline__ void attend_loaded(
     V pf;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float e = exp2f(p[j] - m_new);
+      // (a row may have no visible key in a group below its window: its running max is still the
+      // sentinel then, and the masked scores must not turn into exp2(0))
+      const float e = p[j] <= 0.5f * NEG_BIG ? 0.f : exp2f(p[j] - m_new);
       psum += e;
       pf[j] = (T)e;
     }
@@ -154,10 +157,10 @@ __device__ __forceinline__ void attend_group(
     const void* __restrict__ k_cache, const void* __restrict__ v_cache, const int* __restrict__ bt_row, int kvh,
     int Hkv, int block_size, int base, int seq_len, float scale_log2e,
     const typename Vec8<T>::type (&qf)[NQ][D / 32], f32x4 (&acc)[NQ][D / 16], float (&m)[NQ], float (&l)[NQ],
-    const int (&qpos_hi)[NQ], float k_scale, float v_scale) {
+    const int (&qpos_hi)[NQ], const int (&qpos_lo)[NQ], float k_scale, float v_scale) {
   KVFrag<T, D> f;
   load_kv_group<T, D, KV8>(f, k_cache, v_cache, bt_row, kvh, Hkv, block_size, base, seq_len, k_scale, v_scale);
-  attend_loaded<T, D, NQ>(f, base, seq_len, scale_log2e, qf, acc, m, l, qpos_hi);
+  attend_loaded<T, D, NQ>(f, base, seq_len, scale_log2e, qf, acc, m, l, qpos_hi, qpos_lo);
 }
 
 // ---------------------------------------------------------------------------
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     long q_stride, const void* __restrict__ k_cache, const void* __restrict__ v_cache,
     const int* __restrict__ block_table, int bt_stride, const int* __restrict__ seq_lens, float scale_log2e,
     int Hq, int Hkv, int block_size, int num_splits, long out_stride, const float* __restrict__ k_scales,
-    const float* __restrict__ v_scales) {
+    const float* __restrict__ v_scales, int window) {
   using V = typename Vec8<T>::type;
   constexpr int LDS_ROW = D + 4;
   __shared__ float s_o[4][16][LDS_ROW];
@@ -190,10 +193,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const float k_scale = (KV8 && k_scales != nullptr) ? k_scales[kvh] : 1.f;
   const float v_scale = (KV8 && v_scales != nullptr) ? v_scales[kvh] : 1.f;
 
-  const int n_groups = (seq_len + 31) >> 5;
+  // sliding window: the query (position seq_len - 1) sees the last `window` keys only
+  const int key_lo = window > 0 ? max(0, seq_len - window) : 0;
+  const int g_first = key_lo >> 5;
+  const int n_groups = ((seq_len + 31) >> 5) - g_first;
   const int gps = (n_groups + num_splits - 1) / num_splits;
-  const int g_begin = split * gps;
-  const int g_end = min(g_begin + gps, n_groups);
+  const int g_begin = g_first + split * gps;
+  const int g_end = min(g_begin + gps, g_first + n_groups);
 
   V qf[1][D / 32];
 #pragma unroll
@@ -205,13 +211,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   for (int dt = 0; dt < D / 16; ++dt) acc[0][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m[1] = {NEG_BIG}, l[1] = {0.f};
   const int qpos_hi[1] = {seq_len - 1};
+  const int qpos_lo[1] = {key_lo};
   const int* bt_row = block_table + (long)b * bt_stride;
 
   // no register double-buffering here: it halves the occupancy (202 VGPRs) and
   // measured 3-8% slower than letting 4 resident workgroups per CU hide the latency
   for (int g = g_begin + wid; g < g_end; g += 4)
     attend_group<T, D, 1, KV8>(k_cache, v_cache, bt_row, kvh, Hkv, block_size, g * 32, seq_len,
-                               scale_log2e * k_scale, qf, acc, m, l, qpos_hi, 1.f, 1.f);
+                               scale_log2e * k_scale, qf, acc, m, l, qpos_hi, qpos_lo, 1.f, 1.f);
 
   float lsum = l[0];
   lsum += __shfl_xor(lsum, 16, 64);
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     T* __restrict__ out, const T* __restrict__ q, long q_stride, const void* __restrict__ k_cache,
     const void* __restrict__ v_cache, const int* __restrict__ block_table, int bt_stride,
     const int* __restrict__ seq_lens, float scale_log2e, int B, int Hq, int Hkv, int block_size, long out_stride,
-    const float* __restrict__ k_scales, const float* __restrict__ v_scales) {
+    const float* __restrict__ k_scales, const float* __restrict__ v_scales, int window) {
   using V = typename Vec8<T>::type;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int b = blockIdx.x * 4 + wid;
@@ -275,11 +282,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   for (int dt = 0; dt < D / 16; ++dt) acc[0][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m[1] = {NEG_BIG}, l[1] = {0.f};
   const int qpos_hi[1] = {seq_len - 1};
+  const int qpos_lo[1] = {window > 0 ? max(0, seq_len - window) : 0};
   const int* bt_row = block_table + (long)b * bt_stride;
   const int n_groups = (seq_len + 31) >> 5;
-  for (int g = 0; g < n_groups; ++g)
+  for (int g = qpos_lo[0] >> 5; g < n_groups; ++g)
     attend_group<T, D, 1, KV8>(k_cache, v_cache, bt_row, kvh, Hkv, block_size, g * 32, seq_len,
-                               scale_log2e * k_scale, qf, acc, m, l, qpos_hi, 1.f, 1.f);
+                               scale_log2e * k_scale, qf, acc, m, l, qpos_hi, qpos_lo, 1.f, 1.f);
   float lsum = l[0];
   lsum += __shfl_xor(lsum, 16, 64);
   lsum += __shfl_xor(lsum, 32, 64);
@@ -323,7 +331,8 @@ __global__ __launch_bounds__(256) void paged_prefill_kernel(
     T* __restrict__ out, const T* __restrict__ q, long q_stride, const void* __restrict__ k_cache,
     const void* __restrict__ v_cache, const int* __restrict__ block_table, int bt_stride,
     const int* __restrict__ query_start_loc, const int* __restrict__ seq_lens, float scale_log2e, int Hq, int Hkv,
-    int block_size, long out_stride, const float* __restrict__ k_scales, const float* __restrict__ v_scales) {
+    int block_size, long out_stride, const float* __restrict__ k_scales, const float* __restrict__ v_scales,
+    int window) {
   using V = typename Vec8<T>::type;
   constexpr int NQ = 2;
   const int z = blockIdx.z, h = blockIdx.y;
@@ -340,11 +349,12 @@ __global__ __launch_bounds__(256) void paged_prefill_kernel(
   const float v_scale = (KV8 && v_scales != nullptr) ? v_scales[kvh] : 1.f;
 
   V qf[NQ][D / 32];
-  int qpos_hi[NQ];
+  int qpos_hi[NQ], qpos_lo[NQ];
 #pragma unroll
   for (int n = 0; n < NQ; ++n) {
     const int tok = t_wave + 16 * n + r16;
     qpos_hi[n] = ctx + tok;
+    qpos_lo[n] = window > 0 ? max(0, ctx + tok - window + 1) : 0;
 #pragma unroll
     for (int s = 0; s < D / 32; ++s)
       qf[n][s] = (tok < q_len) ? ld8<T>(q + (long)(q0 + tok) * q_stride + (long)h * D + 32 * s + 8 * g4)
@@ -361,9 +371,10 @@ __global__ __launch_bounds__(256) void paged_prefill_kernel(
   const int* bt_row = block_table + (long)z * bt_stride;
   const int last_key = min(seq_len - 1, ctx + min(t_wave + 31, q_len - 1));
   const int n_groups = (last_key >> 5) + 1;
-  for (int g = 0; g < n_groups; ++g)
+  const int g_first = window > 0 ? max(0, ctx + t_wave - window + 1) >> 5 : 0;     // the wave's earliest window edge
+  for (int g = g_first; g < n_groups; ++g)
     attend_group<T, D, NQ, KV8>(k_cache, v_cache, bt_row, kvh, Hkv, block_size, g * 32, seq_len,
-                                scale_log2e * k_scale, qf, acc, m, l, qpos_hi, 1.f, 1.f);
+                                scale_log2e * k_scale, qf, acc, m, l, qpos_hi, qpos_lo, 1.f, 1.f);
 #pragma unroll
   for (int n = 0; n < NQ; ++n) {
     float lsum = l[n];
@@ -411,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
     const void* __restrict__ v_cache, const int* __restrict__ block_table, int bt_stride,
     const int* __restrict__ query_start_loc, const int* __restrict__ seq_lens, float scale_log2e, int Hq, int Hkv,
     int block_size, long out_stride, int q_tiles, int total_wgs, int xcd_remap,
-    const float* __restrict__ k_scales, const float* __restrict__ v_scales) {
+    const float* __restrict__ k_scales, const float* __restrict__ v_scales, int window) {
   using V = typename Vec8<T>::type;
   constexpr int D = 128, KT = 64, TILE_BYTES = KT * D * 2;
   __shared__ __attribute__((aligned(16))) char smem[2][2][TILE_BYTES];     // [buffer][K | V^T]
@@ -459,8 +470,13 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
     for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
   float m_run = NEG_BIG, l_run = 0.f;
   const int q_hi = min(ctx + tok, seq_len - 1);                    // last key this lane's query sees
+  const int q_lo = window > 0 ? max(0, ctx + tok - window + 1) : 0;  // first one, under a sliding window
   const int wave_last_key = min(seq_len - 1, ctx + min(t_wave + 31, q_len - 1));
   const int n_tiles = (min(seq_len - 1, ctx + min(t_blk + 127, q_len - 1)) >> 6) + 1;
+  // tiles wholly below the window of the workgroup's first query are skipped; the largest window edge
+  // of this wave decides which tiles need the lower compare
+  const int t_first = window > 0 ? max(0, ctx + t_blk - window + 1) >> 6 : 0;
+  const int wave_lo_max = window > 0 ? max(0, ctx + min(t_wave + 31, q_len - 1) - window + 1) : 0;
 
   // per-thread staging coordinates: 4 K chunks + 4 V^T chunks of 16 bytes
   V stage_k[4], stage_v[4];
@@ -495,11 +511,11 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
   // MFMA row rho of a 32-key sub-tile reads LDS key row kappa(rho): bits 2 and 3 swapped
   const int kappa = (l32 & ~12) | ((l32 & 4) << 1) | ((l32 & 8) >> 1);
 
-  load_tile(0);
-  store_tile(0);
+  load_tile(t_first);
+  store_tile(t_first & 1);
   __syncthreads();
 
-  for (int t = 0; t < n_tiles; ++t) {
+  for (int t = t_first; t < n_tiles; ++t) {
     const int buf = t & 1;
     const bool more = t + 1 < n_tiles;
     if (more) load_tile(t + 1);
@@ -521,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
         }
       }
       // scale + causal mask (only tiles that straddle the diagonal need the compare)
-      const bool need_mask = base + KT - 1 > min(ctx + t_wave, seq_len - 1);
+      const bool need_mask = base + KT - 1 > min(ctx + t_wave, seq_len - 1) || base < wave_lo_max;
       float tmax = NEG_BIG;
 #pragma unroll
       for (int u = 0; u < 2; ++u)
@@ -530,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
           float v = sc[u][r] * sl2e;
           if (need_mask) {
             const int key = base + 32 * u + 16 * (r >> 3) + 8 * h + (r & 7);
-            v = key <= q_hi ? v : NEG_BIG;
+            v = (key <= q_hi && key >= q_lo) ? v : NEG_BIG;
           }
           sc[u][r] = v;
           tmax = fmaxf(tmax, v);
@@ -544,7 +560,8 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float e = exp2f(sc[u][r] - m_new);
+          // (a query whose window starts above this tile has no visible key in it: see attend_loaded)
+          const float e = sc[u][r] <= 0.5f * NEG_BIG ? 0.f : exp2f(sc[u][r] - m_new);
           psum += e;
           pf[2 * u + (r >> 3)][r & 7] = (T)e;
         }
@@ -588,7 +605,8 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
 template <typename T, int D, bool KV8>
 int launch_decode(void* out, float* ws, const void* q, long q_stride, const void* kc, const void* vc, const int* bt,
                   int bt_stride, const int* seq_lens, float scale, int B, int Hq, int Hkv, int block_size,
-                  int num_splits, long out_stride, const float* k_scales, const float* v_scales, hipStream_t s) {
+                  int num_splits, long out_stride, const float* k_scales, const float* v_scales, int window,
+                  hipStream_t s) {
   const int G = Hq / Hkv;
   const int q_tiles = (G + 15) / 16;
   float* part_o = ws;
@@ -597,13 +615,13 @@ int launch_decode(void* out, float* ws, const void* q, long q_stride, const void
   if (num_splits == 0) {      // one wave per sequence
     hipLaunchKernelGGL((paged_decode_wave_kernel<T, D, KV8>), dim3((B + 3) / 4, Hkv * q_tiles), dim3(256), 0, s,
                        (T*)out, (const T*)q, q_stride, kc, vc, bt, bt_stride, seq_lens, sl2, B, Hq, Hkv, block_size,
-                       out_stride, k_scales, v_scales);
+                       out_stride, k_scales, v_scales, window);
     HIP_LAUNCH_CHECK();
     return 0;
   }
   hipLaunchKernelGGL((paged_decode_kernel<T, D, KV8>), dim3(num_splits, Hkv * q_tiles, B), dim3(256), 0, s, (T*)out,
                      part_o, part_ml, (const T*)q, q_stride, kc, vc, bt, bt_stride, seq_lens,
-                     sl2, Hq, Hkv, block_size, num_splits, out_stride, k_scales, v_scales);
+                     sl2, Hq, Hkv, block_size, num_splits, out_stride, k_scales, v_scales, window);
   HIP_LAUNCH_CHECK();
   if (num_splits > 1) {
     hipLaunchKernelGGL((decode_reduce_kernel<T, D>), dim3(Hq, B), dim3(D), 0, s, (T*)out, part_o, part_ml, Hq,
@@ -617,7 +635,7 @@ template <typename T, int D, bool KV8>
 int launch_prefill(void* out, const void* q, long q_stride, const void* kc, const void* vc, const int* bt,
                    int bt_stride, const int* qsl, const int* seq_lens, float scale, int num_seqs, int max_q_len,
                    int Hq, int Hkv, int block_size, long out_stride, const float* k_scales, const float* v_scales,
-                   hipStream_t s) {
+                   int window, hipStream_t s) {
   const float sl2 = scale * 1.4426950408889634f;
   const int tiles = (max_q_len + 127) / 128;
   if constexpr (D == 128) {
@@ -631,14 +649,14 @@ int launch_prefill(void* out, const void* q, long q_stride, const void* kc, cons
       const int grid = remap ? (int)((total + 7) / 8 * 8) : (int)total;
       hipLaunchKernelGGL((paged_prefill_lds_kernel<T, KV8>), dim3(grid), dim3(256), 0, s, (T*)out,
                          (const T*)q, q_stride, kc, vc, bt, bt_stride, qsl, seq_lens, sl2, Hq,
-                         Hkv, block_size, out_stride, tiles, (int)total, remap, k_scales, v_scales);
+                         Hkv, block_size, out_stride, tiles, (int)total, remap, k_scales, v_scales, window);
       HIP_LAUNCH_CHECK();
       return 0;
     }
   }
   hipLaunchKernelGGL((paged_prefill_kernel<T, D, KV8>), dim3(tiles, Hq, num_seqs), dim3(256), 0, s, (T*)out,
                      (const T*)q, q_stride, kc, vc, bt, bt_stride, qsl, seq_lens, sl2, Hq, Hkv,
-                     block_size, out_stride, k_scales, v_scales);
+                     block_size, out_stride, k_scales, v_scales, window);
   HIP_LAUNCH_CHECK();
   return 0;
 }
@@ -658,7 +676,7 @@ VDAMD_API int vdamd_paged_attention_decode(void* out, float* workspace, const vo
                                            const void* k_cache, const void* v_cache, const int* block_table,
                                            int bt_stride, const int* seq_lens, float scale, int B, int Hq, int Hkv,
                                            int D, int block_size, int num_splits, long out_stride, int dtype,
-                                           int kv_fp8, const float* k_scales, const float* v_scales,
+                                           int kv_fp8, const float* k_scales, const float* v_scales, int window,
                                            hipStream_t s) {
   if (B == 0) return 0;
   // num_splits == 0 selects the one-wave-per-sequence kernel (short contexts, large batches)
@@ -669,10 +687,10 @@ VDAMD_API int vdamd_paged_attention_decode(void* out, float* workspace, const vo
     if (kv_fp8)                                                                                                  \
       return launch_decode<TY, DD, true>(out, workspace, q, q_stride, k_cache, v_cache, block_table, bt_stride,   \
                                          seq_lens, scale, B, Hq, Hkv, block_size, num_splits, out_stride,         \
-                                         k_scales, v_scales, s);                                                  \
+                                         k_scales, v_scales, window, s);                                          \
     return launch_decode<TY, DD, false>(out, workspace, q, q_stride, k_cache, v_cache, block_table, bt_stride,    \
                                         seq_lens, scale, B, Hq, Hkv, block_size, num_splits, out_stride, nullptr, \
-                                        nullptr, s);                                                              \
+                                        nullptr, window, s);                                                      \
   } while (0)
   if (dtype == DT_BF16) { if (D == 128) CASE(bf16_t, 128); if (D == 64) CASE(bf16_t, 64); }
   if (dtype == DT_F16) { if (D == 128) CASE(f16_t, 128); if (D == 64) CASE(f16_t, 64); }
@@ -685,7 +703,7 @@ VDAMD_API int vdamd_paged_attention_prefill(void* out, const void* q, long q_str
                                             const int* query_start_loc, const int* seq_lens, float scale,
                                             int num_seqs, int max_q_len, int Hq, int Hkv, int D, int block_size,
                                             long out_stride, int dtype, int kv_fp8, const float* k_scales,
-                                            const float* v_scales, hipStream_t s) {
+                                            const float* v_scales, int window, hipStream_t s) {
   if (num_seqs == 0 || max_q_len == 0) return 0;
   if (Hq % Hkv != 0 || block_size % 8 != 0) return -1;
 #define CASE(TY, DD)                                                                                             \
@@ -693,10 +711,10 @@ VDAMD_API int vdamd_paged_attention_prefill(void* out, const void* q, long q_str
     if (kv_fp8)                                                                                                  \
       return launch_prefill<TY, DD, true>(out, q, q_stride, k_cache, v_cache, block_table, bt_stride,             \
                                           query_start_loc, seq_lens, scale, num_seqs, max_q_len, Hq, Hkv,         \
-                                          block_size, out_stride, k_scales, v_scales, s);                         \
+                                          block_size, out_stride, k_scales, v_scales, window, s);                 \
     return launch_prefill<TY, DD, false>(out, q, q_stride, k_cache, v_cache, block_table, bt_stride,              \
                                          query_start_loc, seq_lens, scale, num_seqs, max_q_len, Hq, Hkv,          \
-                                         block_size, out_stride, nullptr, nullptr, s);                            \
+                                         block_size, out_stride, nullptr, nullptr, window, s);                    \
   } while (0)
   if (dtype == DT_BF16) { if (D == 128) CASE(bf16_t, 128); if (D == 64) CASE(bf16_t, 64); }
   if (dtype == DT_F16) { if (D == 128) CASE(f16_t, 128); if (D == 64) CASE(f16_t, 64); }

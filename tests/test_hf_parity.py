@@ -19,6 +19,10 @@ CASES = {
         original_max_position_embeddings=32))),
     "llama-bias-tied": ("LlamaConfig", dict(BASE, attention_bias=True, mlp_bias=True, tie_word_embeddings=True)),
     "mistral": ("MistralConfig", dict(BASE, sliding_window=None)),
+    # sliding windows shorter than the prompts: every query loses its oldest keys
+    "mistral-window": ("MistralConfig", dict(BASE, sliding_window=16)),
+    "starcoder2-window": ("Starcoder2Config", dict(BASE, sliding_window=24, use_bias=True)),
+    "qwen2-window": ("Qwen2Config", dict(BASE, use_sliding_window=True, sliding_window=16, max_window_layers=1)),
     "qwen2": ("Qwen2Config", dict(BASE)),
     "qwen3": ("Qwen3Config", dict(BASE, head_dim=32)),
     "phi3": ("Phi3Config", dict(BASE, pad_token_id=0)),

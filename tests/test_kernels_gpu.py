@@ -208,6 +208,47 @@ def test_paged_attention_prefill_varlen_and_chunked(hq, hkv, d, bs):
     torch.testing.assert_close(got.float(), ref, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("window", [1, 16, 33, 100, 512, 5000])
+@pytest.mark.parametrize("kv8", [False, True])
+def test_sliding_window_attention_decode_and_prefill(window, kv8):
+    """A query sees its last ``window`` keys only: both decode kernels, every split count, the
+    fragment-direct and the LDS-staged prefill kernels (full prompts and chunks over a cached prefix),
+    bf16 and e4m3 caches, windows shorter than a key group and longer than every context."""
+    from vllm_distributed_amd.ops import hip
+    hq, hkv, d, bs = 32, 8, 128, 64
+    scale = 1.0 / math.sqrt(d)
+    seq_lens = [1, 31, 33, 64, 100, 517, 1000, 129]
+    kc, vc, bt = _make_paged(seq_lens, hkv, d, bs)
+    kv_scales = None
+    if kv8:
+        kv_scales = (torch.rand(hkv, device=DEV) + 0.5, torch.rand(hkv, device=DEV) + 0.5)
+        kc, vc = kc.to(torch.float8_e4m3fn), vc.to(torch.float8_e4m3fn)
+    sl = torch.tensor(seq_lens, device=DEV, dtype=torch.int32)
+    q = _rand(len(seq_lens), hq, d)
+    ref = torch_ref.paged_attention_decode(q.float(), kc, vc, bt, sl, scale, kv_scales, window)
+    for splits in (None, 0, 1, 4):
+        got = hip.paged_attention_decode(q, kc, vc, bt, sl, scale, max_seq_len=max(seq_lens), num_splits=splits,
+                                         kv_scales=kv_scales, window=window)
+        torch.testing.assert_close(got.float(), ref, rtol=3e-2, atol=3e-2)
+    # prefill: (q_len, seq_len)
+    for cases in ([(5, 5), (20, 300), (1, 77), (30, 30)],                   # every chunk <= 32 rows: fragment-direct
+                  [(128, 128), (130, 130), (40, 300), (257, 600), (33, 33)]):    # LDS-staged kernel
+        sls = [c[1] for c in cases]
+        kc2, vc2, bt2 = _make_paged(sls, hkv, d, bs)
+        if kv8:
+            kc2, vc2 = kc2.to(torch.float8_e4m3fn), vc2.to(torch.float8_e4m3fn)
+        qsl = [0]
+        for ql, _ in cases:
+            qsl.append(qsl[-1] + ql)
+        q2 = _rand(qsl[-1], hq, d)
+        qsl_t = torch.tensor(qsl, device=DEV, dtype=torch.int32)
+        sl2 = torch.tensor(sls, device=DEV, dtype=torch.int32)
+        ref2 = torch_ref.paged_attention(q2.float(), kc2, vc2, bt2, qsl_t, sl2, scale, kv_scales, window)
+        got2 = ops.paged_attention(q2, kc2, vc2, bt2, qsl_t, sl2, scale, max(c[0] for c in cases), max(sls),
+                                   kv_scales=kv_scales, window=window)
+        torch.testing.assert_close(got2.float(), ref2, rtol=3e-2, atol=3e-2)
+
+
 def test_mfma_operand_maps_with_exact_integer_data():
     """A = I style check with asymmetric data: one-hot queries pick out single
     K dimensions, V holds distinct small integers, so any swapped lane/row map

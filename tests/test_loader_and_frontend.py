@@ -424,20 +424,13 @@ def test_sharded_state_round_trip_tp2(tmp_path, monkeypatch):
         run(shards, "sharded_state", tp=1)
 
 
-def test_sliding_window_checkpoints_are_capped_to_their_window():
-    """Attention is global here: a checkpoint that restricts every layer to a window is served up to
-    that window (where the two coincide) and a longer explicit context is refused, not silently served."""
-    from vllm_distributed_amd.config import ModelConfig
-    hf = dict(architectures=["MistralForCausalLM"], hidden_size=64, intermediate_size=128, num_hidden_layers=2,
-              num_attention_heads=4, num_key_value_heads=2, vocab_size=320, max_position_embeddings=32768,
-              sliding_window=4096)
-    mc = ModelConfig(model="llama-tiny", load_format="dummy", hf_config=dict(hf))
-    assert mc.max_model_len == 4096
-    assert ModelConfig(model="llama-tiny", load_format="dummy", hf_config=dict(hf), max_model_len=2048).max_model_len == 2048
-    with pytest.raises(ValueError, match="sliding-window"):
-        ModelConfig(model="llama-tiny", load_format="dummy", hf_config=dict(hf), max_model_len=8192)
-    # Qwen2 ships a window with the feature switched off; no window at all
-    assert ModelConfig(model="llama-tiny", load_format="dummy",
-                       hf_config=dict(hf, use_sliding_window=False)).max_model_len == 32768
-    assert ModelConfig(model="llama-tiny", load_format="dummy",
-                       hf_config=dict(hf, sliding_window=None)).max_model_len == 32768
+def test_sliding_window_is_resolved_per_layer():
+    from vllm_distributed_amd.config import layer_sliding_window
+    base = dict(sliding_window=4096, num_hidden_layers=4)
+    assert [layer_sliding_window(base, i) for i in range(4)] == [4096] * 4          # Mistral, StarCoder2, Phi-3
+    assert layer_sliding_window(dict(base, sliding_window=None), 0) is None
+    assert layer_sliding_window(dict(base, use_sliding_window=False), 0) is None    # Qwen2 default
+    q = dict(base, use_sliding_window=True, max_window_layers=2)
+    assert [layer_sliding_window(q, i) for i in range(4)] == [None, None, 4096, 4096]
+    t = dict(base, layer_types=["sliding_attention", "full_attention", "sliding_attention", "full_attention"])
+    assert [layer_sliding_window(t, i) for i in range(4)] == [4096, None, 4096, None]

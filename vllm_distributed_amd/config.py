@@ -108,6 +108,22 @@ def normalize_hf_config(cfg: Dict[str, Any]) -> None:
                 cfg[k] = rp[k]
 
 
+def layer_sliding_window(c: Dict[str, Any], layer_idx: int) -> Optional[int]:
+    """The attention window of decoder layer ``layer_idx`` of a model with config ``c``, or None for
+    global attention.  Mistral / StarCoder2 / Phi-3 give every layer ``sliding_window``; Qwen2 only with
+    ``use_sliding_window`` and only from layer ``max_window_layers`` on; newer configs list a
+    ``layer_types`` entry per layer."""
+    w = c.get("sliding_window")
+    if not w or c.get("use_sliding_window") is False:
+        return None
+    types = c.get("layer_types")
+    if types:
+        return int(w) if layer_idx < len(types) and types[layer_idx] == "sliding_attention" else None
+    if c.get("use_sliding_window") is True and c.get("max_window_layers") is not None:
+        return int(w) if layer_idx >= int(c["max_window_layers"]) else None
+    return int(w)
+
+
 def is_bundled_architecture_name(model: str) -> bool:
     """Short names of the config files shipped in ``models/configs`` (``llama-tiny``,
     ``llama-3-70b``, ...): architecture descriptions for tests and benchmarks, which only
@@ -174,15 +190,6 @@ class ModelConfig:
         if self.dtype in ("float", "fp32"):
             self.dtype = "float32"
         derived = self.derived_max_model_len()
-        window = self.sliding_window()
-        if window is not None and window < derived:
-            # Attention here is over the whole context.  Inside the window that IS the checkpoint's
-            # attention; beyond it the outputs would silently differ, so the context is capped there.
-            if self.max_model_len is not None and self.max_model_len > window:
-                raise ValueError(
-                    f"{self.model}: sliding-window attention (window {window}) is not implemented; "
-                    f"--max-model-len must not exceed {window} (got {self.max_model_len})")
-            derived = window
         if self.max_model_len is None:
             self.max_model_len = derived
         if self.quantization is None:
@@ -254,15 +261,8 @@ class ModelConfig:
                 return int(c[key])
         return 2048
 
-    def sliding_window(self) -> Optional[int]:
-        """The attention window of a checkpoint that restricts every layer to one, else None."""
-        c = self.hf_config
-        w = c.get("sliding_window")
-        if not w or c.get("use_sliding_window") is False:      # Qwen2 ships a value with the feature off
-            return None
-        if c.get("layer_types") and not all(t == "sliding_attention" for t in c["layer_types"]):
-            return None if not any(t == "sliding_attention" for t in c["layer_types"]) else int(w)
-        return int(w)
+    def layer_sliding_window(self, layer_idx: int) -> Optional[int]:
+        return layer_sliding_window(self.hf_config, layer_idx)
 
     @property
     def architecture(self) -> str:

@@ -58,10 +58,12 @@ class Attention(nn.Module):
     """Owns one layer's slice of the KV cache (bound by the model runner)."""
 
     def __init__(self, num_heads: int, head_dim: int, num_kv_heads: int, scale: float,
-                 layer_idx: int):
+                 layer_idx: int, sliding_window: Optional[int] = None):
         super().__init__()
         self.num_heads, self.head_dim, self.num_kv_heads = num_heads, head_dim, num_kv_heads
         self.scale = scale
+        # a query sees its last `window` keys only (0 = the whole context)
+        self.window = int(sliding_window or 0)
         self.layer_idx = layer_idx
         self.k_cache: Optional[torch.Tensor] = None
         self.v_cache: Optional[torch.Tensor] = None
@@ -93,12 +95,13 @@ class Attention(nn.Module):
             ops.paged_attention_decode(
                 qv[:nd], self.k_cache, self.v_cache, md.block_table[:md.num_decodes],
                 md.seq_lens[:md.num_decodes], self.scale, md.max_decode_seq_len,
-                out=out[:nd], workspace=md.decode_workspace, kv_scales=self.kv_scales)
+                out=out[:nd], workspace=md.decode_workspace, kv_scales=self.kv_scales, window=self.window)
         if md.num_prefills > 0:
             ops.paged_attention(
                 qv[nd:], self.k_cache, self.v_cache, md.block_table[md.num_decodes:],
                 md.prefill_query_start_loc, md.seq_lens[md.num_decodes:], self.scale,
-                md.max_prefill_query_len, md.max_seq_len, out=out[nd:], kv_scales=self.kv_scales)
+                md.max_prefill_query_len, md.max_seq_len, out=out[nd:], kv_scales=self.kv_scales,
+                window=self.window)
         return out.view(t, self.num_heads * self.head_dim)
 
     def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:

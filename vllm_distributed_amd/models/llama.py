@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from .. import envs, ops
-from ..config import VllmConfig
+from ..config import VllmConfig, layer_sliding_window
 from ..parallel.state import get_pp_group, get_tp_group
 from .layers.attention import Attention, RMSNorm, get_forward_context
 from .layers.linear import (ColumnParallelLinear, ParallelLMHead, QKVParallelLinear, QuantSpec,
@@ -66,7 +66,8 @@ class LlamaAttention(nn.Module):
             self.k_norm = RMSNorm(self.head_dim, eps, dtype)
         # Granite scales the scores by ``attention_multiplier`` instead of 1 / sqrt(head_dim)
         scale = cfg.get("attention_multiplier") or self.head_dim ** -0.5
-        self.attn = Attention(self.num_heads, self.head_dim, self.num_kv_heads, float(scale), layer_idx)
+        self.attn = Attention(self.num_heads, self.head_dim, self.num_kv_heads, float(scale), layer_idx,
+                              layer_sliding_window(cfg, layer_idx))
 
     def forward(self, positions: torch.Tensor, hidden: torch.Tensor, reduce: bool = True,
                 staged: bool = False, residual: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:

@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..config import VllmConfig
+from ..config import VllmConfig, layer_sliding_window
 from ..parallel.state import get_pp_group
 from .layers.attention import Attention, LayerNorm
 from .layers.linear import (ColumnParallelLinear, ParallelLMHead, QKVParallelLinear, RowParallelLinear,
@@ -29,7 +29,7 @@ class Starcoder2Layer(nn.Module):
         self.qkv_proj = QKVParallelLinear(h, self.head_dim, heads, kv, bias, dtype)
         self.o_proj = RowParallelLinear(h, h, bias, dtype)
         self.attn = Attention(self.qkv_proj.num_heads, self.head_dim, self.qkv_proj.num_kv_heads,
-                              self.head_dim ** -0.5, layer_idx)
+                              self.head_dim ** -0.5, layer_idx, layer_sliding_window(cfg, layer_idx))
         self.c_fc = ColumnParallelLinear(h, [cfg["intermediate_size"]], bias, dtype)
         self.c_proj = RowParallelLinear(cfg["intermediate_size"], h, bias, dtype)
         self.act = cfg.get("hidden_act", "gelu_pytorch_tanh")
@@ -52,7 +52,6 @@ class Starcoder2ForCausalLM(nn.Module):
         mc = vllm_config.model_config
         cfg, dtype = mc.hf_config, mc.torch_dtype
         self.cfg = cfg
-        # (a checkpoint's sliding window caps max_model_len in ModelConfig: attention here is global)
         pp = get_pp_group()
         self.is_first, self.is_last = pp.is_first_rank, pp.is_last_rank
         self.start_layer, self.end_layer = get_pp_layer_range(
