@@ -434,3 +434,66 @@ def test_sliding_window_is_resolved_per_layer():
     assert [layer_sliding_window(q, i) for i in range(4)] == [None, None, 4096, 4096]
     t = dict(base, layer_types=["sliding_attention", "full_attention", "sliding_attention", "full_attention"])
     assert [layer_sliding_window(t, i) for i in range(4)] == [4096, None, 4096, None]
+
+
+def test_gptq_checkpoint_is_the_same_model_as_its_awq_twin(tmp_path):
+    """A 4-bit GPTQ checkpoint holds the integers, zero points and scales of an AWQ one in another
+    packing: writing the dummy AWQ model's tensors in GPTQ form (rows packed eight to a word, zero
+    points stored minus one, ``g_idx`` alongside) must load to exactly the same generations; act-order
+    checkpoints are refused."""
+    import json
+    from safetensors.torch import save_file
+    from vllm_distributed_amd.models.loader import dummy_weights_iterator
+    from vllm_distributed_amd.ops import quant
+    mc = ModelConfig(model="llama-tiny", dtype="float32", load_format="dummy", quantization="awq")
+    g = mc.quant_group_size
+    shifts = torch.arange(0, 32, 4, dtype=torch.int64)
+
+    def wrap(x):          # [.., 8] nibbles -> int32 words, low nibble first
+        w = (x.to(torch.int64) << shifts).sum(-1)
+        return torch.where(w >= (1 << 31), w - (1 << 32), w).to(torch.int32)
+
+    def write(dirname, desc_act):
+        tensors = {}
+        for name, w in dummy_weights_iterator(mc, torch.device("cpu")):
+            if name.endswith(".qweight"):
+                vals = quant.awq_unpack(w)                                     # [in, out]
+                tensors[name] = wrap(vals.view(vals.shape[0] // 8, 8, -1).transpose(1, 2)).contiguous()
+                idx = torch.arange(vals.shape[0], dtype=torch.int32) // g
+                tensors[name[:-len("qweight")] + "g_idx"] = idx.flip(0).contiguous() if desc_act else idx
+            elif name.endswith(".qzeros"):
+                z = quant.awq_unpack(w).clamp(min=1)          # GPTQ stores zero - 1: a zero of 0 has no GPTQ form
+                tensors[name] = wrap((z - 1).view(z.shape[0], -1, 8)).contiguous()
+                tensors[name + ".awq"] = quant.awq_pack(z)
+            else:
+                tensors[name] = w.contiguous()
+        awq = {k[:-4] if k.endswith(".awq") else k: v for k, v in tensors.items()
+               if not k.endswith((".g_idx",)) and not (k.endswith(".qzeros") and k + ".awq" in tensors)
+               and not k.endswith(".qweight")}
+        awq.update({k: v for k, v in dummy_weights_iterator(mc, torch.device("cpu")) if k.endswith(".qweight")})
+        for sub, tens, method in (("gptq", {k: v for k, v in tensors.items() if not k.endswith(".awq")}, "gptq"),
+                                  ("awq", awq, "awq")):
+            d = tmp_path / dirname / sub
+            d.mkdir(parents=True)
+            save_file(tens, str(d / "model.safetensors"))
+            cfg = dict(mc.hf_config, quantization_config={"quant_method": method, "bits": 4, "group_size": g,
+                                                          "desc_act": desc_act, "sym": False})
+            (d / "config.json").write_text(json.dumps(cfg))
+        return str(tmp_path / dirname)
+
+    root = write("plain", False)
+    outs = {}
+    for sub in ("gptq", "awq"):
+        llm = LLM(model=f"{root}/{sub}", device="cpu", dtype="float32", max_model_len=128, block_size=16,
+                  num_gpu_blocks_override=64, max_num_seqs=8)
+        assert llm.engine.model_config.quantization == "awq"
+        o = llm.generate([[5, 9, 200, 17], list(range(10, 50))],
+                         SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True, logprobs=3))
+        outs[sub] = [(list(x.outputs[0].token_ids), x.outputs[0].logprobs[0]) for x in o]
+        llm.shutdown()
+        pstate.destroy_model_parallel()
+    assert outs["gptq"] == outs["awq"]
+    bad = write("actorder", True)
+    with pytest.raises(NotImplementedError, match="desc_act"):
+        LLM(model=f"{bad}/gptq", device="cpu", dtype="float32", max_model_len=128, num_gpu_blocks_override=64)
+    pstate.destroy_model_parallel()

@@ -196,6 +196,8 @@ class ModelConfig:
             q = self.hf_config.get("quantization_config") or {}
             if q.get("quant_method") == "awq":
                 self.quantization = "awq"
+            elif q.get("quant_method") == "gptq":
+                self.quantization = "awq"        # same integers, repacked at load (models/loader._gptq_as_awq)
             elif "nvfp4" in str(q.get("format", "")).lower() or str(q.get("quant_algo", "")).upper() == "NVFP4":
                 self.quantization = "nvfp4"      # compressed-tensors / modelopt exports
         if self.load_format == "auto" and resolve_model_path(self.model) is None:

@@ -31,7 +31,7 @@ import torch
 from ..config import ModelConfig, VllmConfig, resolve_model_path
 from ..logger import init_logger
 from .registry import get_model_class
-from .utils import LazyTensor
+from .utils import LazyTensor, materialize
 
 logger = init_logger(__name__)
 
@@ -318,6 +318,28 @@ def safetensors_weights_iterator(path: str, dtype: torch.dtype,
                 yield k, LazyTensor(f, k)
 
 
+def _gptq_as_awq(items: Iterable[Tuple[str, torch.Tensor]], mc: ModelConfig) -> Iterator[Tuple[str, torch.Tensor]]:
+    """A 4-bit GPTQ checkpoint as the AWQ tensors the quantised linears load: same integers, scales and
+    groups, repacked (``ops/quant.gptq_to_awq``).  Activation reordering (``desc_act`` with a
+    non-sequential ``g_idx``) permutes the input rows per group and is refused."""
+    from ..ops import quant
+    q = mc.hf_config.get("quantization_config") or {}
+    if int(q.get("bits", 4)) != 4:
+        raise NotImplementedError(f"GPTQ with {q.get('bits')} bits (4-bit only)")
+    g = int(q.get("group_size", 128))
+    offset = 0 if str(q.get("checkpoint_format", "gptq")) == "gptq_v2" else 1
+    for name, w in items:
+        if name.endswith(".g_idx"):
+            idx = materialize(w).long()
+            group = g if g > 0 else idx.numel()
+            if not torch.equal(idx, torch.arange(idx.numel()) // group):
+                raise NotImplementedError(f"{name}: GPTQ activation reordering (desc_act) is not supported")
+            continue
+        if name.endswith((".qweight", ".qzeros")):
+            w = quant.gptq_to_awq(name, materialize(w), offset)
+        yield name, w
+
+
 def _with_progress(items: Iterable, what: str, every: float = 20.0) -> Iterator:
     """Pass ``items`` through, logging a count every ``every`` seconds (large
     models take minutes to load; silence looks like a hang)."""
@@ -361,6 +383,8 @@ def load_model(vllm_config: VllmConfig, device: torch.device) -> torch.nn.Module
             it = _dequantize_stream(it, mc.torch_dtype)
     else:
         it = safetensors_weights_iterator(path, mc.torch_dtype, want, keep_quantized=mc.quantization in ("awq", "nvfp4"))
+        if (mc.hf_config.get("quantization_config") or {}).get("quant_method") == "gptq":
+            it = _gptq_as_awq(it, mc)
     with torch.no_grad():
         loaded = model.load_weights(_with_progress(it, "checkpoint tensors read"))
         mods = [m for m in model.modules() if getattr(m, "finalize_weights", None) is not None]

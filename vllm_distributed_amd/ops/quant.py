@@ -53,6 +53,25 @@ def awq_pack(vals: torch.Tensor) -> torch.Tensor:
     return out.to(torch.int32)
 
 
+def gptq_to_awq(name: str, w: torch.Tensor, zero_offset: int = 1) -> torch.Tensor:
+    """One tensor of a 4-bit GPTQ linear (``qweight [in/8, out]``: eight input rows per word, low nibble
+    first; ``qzeros [in/g, out/8]``: eight output columns per word in natural order, stored minus
+    ``zero_offset`` by the original format; ``scales [in/g, out]``) in the AWQ arrangement the
+    W4A16 path consumes (``qweight [in, out/8]``, ``qzeros [in/g, out/8]``, AWQ nibble order).
+    The two formats hold the same integers: only the packing differs."""
+    shifts = torch.arange(0, 32, 4, dtype=torch.int32, device=w.device)
+    if name.endswith(".qweight"):
+        rows = ((w.unsqueeze(1) >> shifts.view(1, 8, 1)) & 0xF)           # [in/8, 8, out]
+        return awq_pack(rows.reshape(-1, w.shape[1]))
+    if name.endswith(".qzeros"):
+        z = ((w.unsqueeze(-1) >> shifts) & 0xF).reshape(w.shape[0], -1) + zero_offset
+        if int(z.max()) > 15:
+            raise NotImplementedError(f"{name}: a GPTQ zero point of 16 does not fit the 4-bit zero points "
+                                      "of the W4A16 kernels (load with --quantization awq-dequant)")
+        return awq_pack(z)
+    return w
+
+
 def pack_w4(q: torch.Tensor, z: torch.Tensor, s: torch.Tensor, dtype: torch.dtype,
             ) -> Tuple[torch.Tensor, torch.Tensor]:
     """``q [N, K]``, ``z [N, K/G]``, ``s [N, K/G]`` -> ``(qw, sz)`` as described above."""

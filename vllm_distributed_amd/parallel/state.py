@@ -457,10 +457,14 @@ def init_distributed_environment(world_size: int, rank: int, init_method: Option
     _WORLD = GroupCoordinator("world", ranks, rank, dist.group.WORLD, cpu_group, device)
 
 
+_GENERATION = 0
+
+
 def initialize_model_parallel(tp_size: int, pp_size: int) -> None:
     """Build TP and PP groups.  Every rank must call this with the same sizes
     (``new_group`` is collective over the world)."""
-    global _TP, _PP
+    global _TP, _PP, _GENERATION
+    _GENERATION += 1
     world = get_world_group()
     ws, rank, device = world.world_size, world.rank, world.device
     if ws == 1:
@@ -535,8 +539,17 @@ def ensure_single_process_groups(device: Optional[torch.device] = None) -> None:
         _PP = _single("pp", device)
 
 
-def destroy_model_parallel() -> None:
+def current_generation() -> int:
+    """Counts ``initialize_model_parallel`` calls: a worker remembers the value it set the groups up
+    under, so that a stale worker being finalised late cannot tear down its successor's groups."""
+    return _GENERATION
+
+
+def destroy_model_parallel(generation: Optional[int] = None) -> None:
+    """``generation``: only act if the groups are still the ones set up under that generation."""
     global _WORLD, _TP, _PP, _OWNS_PROCESS_GROUP
+    if generation is not None and generation != _GENERATION:
+        return
     for g in (_TP, _PP):
         if g is not None:
             if g.custom_ar is not None:

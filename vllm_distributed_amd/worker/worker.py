@@ -77,6 +77,7 @@ class Worker:
         pstate.init_distributed_environment(pc.world_size, self.rank, self.distributed_init_method,
                                             self.local_rank, backend, self.device)
         pstate.initialize_model_parallel(pc.tensor_parallel_size, pc.pipeline_parallel_size)
+        self._pstate_generation = pstate.current_generation()
         if dev_type == "cuda" and pc.world_size > 1:
             self._attach_fast_collectives()
         torch.manual_seed(self.vllm_config.model_config.seed)
@@ -246,5 +247,6 @@ class Worker:
 
     def shutdown(self) -> None:
         self.model_runner = None
-        pstate.destroy_model_parallel()
+        # only the groups this worker set up: an engine built later in the same process owns newer ones
+        pstate.destroy_model_parallel(getattr(self, "_pstate_generation", None))
         gc.collect()
