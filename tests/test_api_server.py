@@ -151,6 +151,10 @@ def test_server_endpoints_end_to_end(frontend_mp):
                     "prompt": "hello", "max_tokens": 2, "n": 2, "best_of": 4, "stream": True})).status_code == 400
                 assert (await c.post("/v1/completions", headers=hdr, json={
                     "prompt": "hello", "max_tokens": 2, "n": 3, "best_of": 2})).status_code == 400
+                assert (await c.post("/v1/completions", headers=hdr, json={
+                    "prompt": "hello", "max_tokens": 2, "best_of": 100000})).status_code == 400
+                assert (await c.post("/v1/chat/completions", headers=hdr, json={
+                    "messages": [{"role": "user", "content": "hi"}], "max_tokens": 1, "n": 5000})).status_code == 400
                 # beam search: n is the beam width, beams come back best first; width 1 is greedy decoding
                 greedy = (await c.post("/v1/completions", headers=hdr, json={
                     "prompt": [1, 2, 3, 4], "max_tokens": 4, "temperature": 0, "ignore_eos": True, "logprobs": 0})).json()

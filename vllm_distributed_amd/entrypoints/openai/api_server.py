@@ -162,6 +162,10 @@ def setup_server(args: argparse.Namespace) -> Tuple[str, socket.socket]:
     return f"{scheme}://{host}:{sock.getsockname()[1]}", sock
 
 
+MAX_SAMPLES_PER_PROMPT = 128      # n / best_of: each sample is a request sharing the prompt's KV blocks
+MAX_BEAM_WIDTH = 32
+
+
 def _nth_params(sp: SamplingParams, j: int) -> SamplingParams:
     """Sampling parameters of the ``j``-th of ``n`` samples of one prompt."""
     out = sp.clone()
@@ -554,6 +558,10 @@ def _register_routes(app: FastAPI, dev_mode: bool = False) -> None:
         best_of = int(req.best_of or n)
         if best_of < n:
             return _error("best_of must be >= n")
+        if best_of > MAX_SAMPLES_PER_PROMPT or (req.use_beam_search and n > MAX_BEAM_WIDTH):
+            # every sample (and every beam, every step) is a request of its own
+            return _error(f"at most {MAX_SAMPLES_PER_PROMPT} samples (n / best_of) and beams of width "
+                          f"{MAX_BEAM_WIDTH} per prompt")
         if (req.use_beam_search or best_of > n) and req.stream:
             return _error("beam search and best_of > n rank finished sequences: they cannot be streamed")
         if req.use_beam_search:
@@ -732,6 +740,8 @@ def _register_routes(app: FastAPI, dev_mode: bool = False) -> None:
         parser = st.tool_parser if tools and not forced_tool and not required_tools else None
         if required_tools:
             parser = _RequiredToolsParser()
+        if n > MAX_SAMPLES_PER_PROMPT or (req.use_beam_search and n > MAX_BEAM_WIDTH):
+            return _error(f"at most {MAX_SAMPLES_PER_PROMPT} samples (n) and beams of width {MAX_BEAM_WIDTH} per prompt")
         if req.use_beam_search:
             if req.stream:
                 return _error("beam search ranks finished sequences: it cannot be streamed")
