@@ -739,6 +739,13 @@ def test_large_batch_dispatch_reaches_the_big_gemm(monkeypatch):
     assert calls == [False, True] and act is not None and act.shape == (2048, 7168)
     want = ops.silu_and_mul(torch.nn.functional.linear(x, wgu))
     torch.testing.assert_close(act.float(), want.float(), rtol=3e-2, atol=0.1)
+    # a qkv-shaped matrix whose q part alone is whole rounds of tiles: split in two GEMMs, one buffer
+    wqkv = _padded_weight(8192 + 2048, 4096, 128)
+    y = ops.linear_split(x, wqkv, 8192)
+    assert y is not None and calls == [False, True, False]
+    torch.testing.assert_close(y.float(), torch.nn.functional.linear(x, wqkv).float(), rtol=2e-2, atol=0.1)
+    assert ops.linear_split(x, w, 4096) is None              # the whole matrix already tiles the chip
+    calls.pop()
     # too few tiles to fill the chip: the library keeps the shape
     assert ops.gate_up_silu(_rand(512, 4096), _padded_weight(2 * 1024, 4096, 128)) is None
     ops.linear(_rand(512, 4096), w)

@@ -395,6 +395,11 @@ class QKVParallelLinear(_LinearBase):
         param.data.narrow(od, dst, size).copy_(materialize(w.narrow(od, src_idx * size, size)))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.qw is None and self.weight_scale is None and self.lora is None and x.dim() == 2:
+            # large batches: the q columns alone tile the chip exactly, the k/v columns follow separately
+            y = ops.linear_split(x, self.weight, self.q_size)
+            if y is not None:
+                return y if self.bias is None else y.add_(self.bias)
         return self._matmul(x, self.bias)
 
 
