@@ -2,12 +2,15 @@
 //
 // Cache layouts are MFMA-operand-native (see attention.hip):
 //   k_cache[num_blocks][Hkv][block_size][D]   key row contiguous in D
-//   v_cache[num_blocks][Hkv][D][block_size]   transposed: D row contiguous in keys
+//   v_cache[num_blocks][Hkv][block_size/8][D][8]   transposed in groups of 8 keys
 //
 // Each thread owns one 8-element (16-byte) piece of one token; a token has
 //   items [0, Hq*D/16)            rotate a q pair-chunk in place
 //   items [.., +Hkv*D/16)         rotate a k pair-chunk, write it to k_cache
-//   items [.., +Hkv*D/8)          copy a v chunk to v_cache (2-byte strided stores)
+//   items [.., +Hkv*D/8)          copy 8 v elements (head-dim index c, c + D/8, ...) to v_cache:
+//                                 element-sized stores 16 bytes apart, so the D/8 lanes of a head
+//                                 fill 8 element slots of each 128-byte line per store instruction
+//                                 and a token dirties D*16 contiguous bytes per head
 // and (token, item) pairs are laid out flat over the grid, so a rank that holds
 // one KV head (TP=8: 88 items per token) still fills 256-thread workgroups.
 //
@@ -121,8 +124,12 @@ __global__ void rope_cache_kernel(const int* __restrict__ positions, T* __restri
       const int it = item - q_items - k_items;
       const int cpd = D >> 3;
       const int h = it / cpd, c = it - h * cpd;
-      V x = ld8<T>(v + t * v_stride + (long)h * D + 8 * c);
-      const long first = ((blk * Hkv + h) * (long)D + 8 * c) * block_size + off;
+      // this thread's head-dim indices are c + cpd*j: the head's cpd lanes store adjacent 16-byte groups
+      const T* src = v + t * v_stride + (long)h * D + c;
+      T x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = src[j * cpd];
+      const long first = (((blk * Hkv + h) * (long)(block_size >> 3) + (off >> 3)) * D + c) * 8 + (off & 7);
       if constexpr (KV8) {
         const float inv = (v_scales != nullptr) ? 1.f / v_scales[h] : 1.f;
         float g[8];
@@ -132,11 +139,11 @@ __global__ void rope_cache_kernel(const int* __restrict__ positions, T* __restri
         uint8_t* dst = reinterpret_cast<uint8_t*>(v_cache_v) + first;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          dst[(long)j * block_size] = (uint8_t)(((j < 4 ? pk.x : pk.y) >> (8 * (j & 3))) & 0xFF);
+          dst[(long)j * cpd * 8] = (uint8_t)(((j < 4 ? pk.x : pk.y) >> (8 * (j & 3))) & 0xFF);
       } else {
         T* dst = v_cache + first;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dst[(long)j * block_size] = x[j];
+        for (int j = 0; j < 8; ++j) dst[(long)j * cpd * 8] = x[j];
       }
     }
   }

@@ -338,6 +338,9 @@ class CacheConfig:
         if self.cache_dtype not in ("auto", "bfloat16", "float16", "bf16", "fp16", "half", "fp8", "fp8_e4m3"):
             raise ValueError(f"kv cache dtype {self.cache_dtype!r} is not supported: use 'auto' (the model's "
                              "16-bit dtype) or 'fp8' / 'fp8_e4m3'")
+        # the V cache stores keys in groups of 8 (one 16-byte MFMA operand chunk per head-dim row)
+        if self.block_size < 8 or self.block_size % 8 != 0:
+            raise ValueError("block_size must be a positive multiple of 8")
 
     @property
     def kv_fp8(self) -> bool:

@@ -13,6 +13,7 @@ import torch
 
 from .. import envs
 from . import torch_ref
+from .torch_ref import k_cache_shape, v_cache_shape  # noqa: F401  (the paged-cache layouts every backend shares)
 
 _hip = None
 _hip_error: Optional[BaseException] = None

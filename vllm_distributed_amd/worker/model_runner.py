@@ -327,10 +327,9 @@ class ModelRunner:
         self.num_blocks = num_blocks
         self.kv_caches = []
         for attn in self.model.attention_layers():
-            k = torch.zeros(num_blocks, spec.num_kv_heads, self.block_size, spec.head_dim,
-                            dtype=dtype, device=self.device)
-            v = torch.zeros(num_blocks, spec.num_kv_heads, spec.head_dim, self.block_size,
-                            dtype=dtype, device=self.device)
+            dims = (num_blocks, spec.num_kv_heads, spec.head_dim, self.block_size)
+            k = torch.zeros(ops.k_cache_shape(*dims), dtype=dtype, device=self.device)
+            v = torch.zeros(ops.v_cache_shape(*dims), dtype=dtype, device=self.device)
             scales = attn.kv_scales if fp8 else None
             if scales is not None:
                 scales = tuple(t.to(self.device) for t in scales)
