@@ -27,7 +27,7 @@ def timeit(fn, iters=20):
 
 def caches(nblocks, hkv, d, bs):
     k = (torch.randn(nblocks, hkv, bs, d, device=dev) * 0.5).to(torch.bfloat16)
-    v = (torch.randn(nblocks, hkv, bs // 8, d, 8, device=dev) * 0.5).to(torch.bfloat16)
+    v = (torch.randn(nblocks, hkv, d // 16, bs // 8, 16, 8, device=dev) * 0.5).to(torch.bfloat16)
     return k, v
 
 

@@ -44,7 +44,7 @@ def run(t, h, f, hq, hkv, d=128, bs=64):
     qkv = [torch.randn(t, (hq + 2 * hkv) * d, device=dev, dtype=torch.bfloat16) for _ in range(COPIES)]
     nblk = max((t + bs - 1) // bs * 4, t)          # the decode-like pattern below needs a block per token
     kc = torch.zeros(nblk, hkv, bs, d, device=dev, dtype=torch.bfloat16)
-    vc = torch.zeros(nblk, hkv, bs // 8, d, 8, device=dev, dtype=torch.bfloat16)
+    vc = torch.zeros(nblk, hkv, d // 16, bs // 8, 16, 8, device=dev, dtype=torch.bfloat16)
     pos = torch.randint(0, 4096, (t,), device=dev, dtype=torch.int32)
     slots = (torch.randperm(nblk * bs, device=dev)[:t]).to(torch.int32)
     inv = 1.0 / (500000.0 ** (torch.arange(0, d, 2, device=dev).float() / d))

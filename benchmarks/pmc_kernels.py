@@ -46,7 +46,7 @@ def main() -> None:
     b, ctx, hq, hkv, d, bs = 256, 2048, 64, 8, 128, 64
     nb = ctx // bs
     k = (torch.randn(b * nb, hkv, bs, d, device=dev) * 0.5).to(bf)
-    v = (torch.randn(b * nb, hkv, bs // 8, d, 8, device=dev) * 0.5).to(bf)
+    v = (torch.randn(b * nb, hkv, d // 16, bs // 8, 16, 8, device=dev) * 0.5).to(bf)
     bt = torch.randperm(b * nb, device=dev).to(torch.int32).view(b, nb)
     sl = torch.full((b,), ctx, device=dev, dtype=torch.int32)
     q = torch.randn(b, hq, d, device=dev).to(bf)

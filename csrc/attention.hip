@@ -3,11 +3,11 @@
 // Cache layouts make K and V^T direct MFMA operands from global memory (no LDS
 // staging, no transposes):
 //   k_cache[num_blocks][Hkv][block_size][D]     key row contiguous in D
-//   v_cache[num_blocks][Hkv][block_size/8][D][8]  transposed in groups of 8 keys: one D row's 8
-//                                                 keys are a 16-byte chunk, the D rows of a key
-//                                                 group are adjacent (a wave's V^T fragment load is
-//                                                 four contiguous 256-byte runs; a new token's
-//                                                 values land in D*16 contiguous bytes per head)
+//   v_cache[num_blocks][Hkv][D/16][block_size/8][16][8]
+//       V^T in MFMA-fragment order: the 8 keys of one D row are a 16-byte chunk, 16 D rows of a
+//       key group are adjacent (256 bytes), and the key groups of a block follow each other inside
+//       a 16-row slab.  One V^T fragment load of a wave (16 D rows x 32 keys) is one contiguous
+//       1 KiB run, and a new token's values land in D/16 runs of 256 bytes per head.
 //
 // Both kernels use the "swapped" formulation on v_mfma_f32_16x16x32:
 //   S^T[key][q]  = K[key][:] . Q[q][:]          A = K rows,   B = Q^T
@@ -101,9 +101,10 @@ __device__ __forceinline__ void load_kv_group(KVFrag<T, D>& f, const void* __res
   // ---- V^T rows: this lane's 8 keys are base + 8*g4 .. +7 (one block: block_size % 8 == 0)
   const int vkey = min(base + 8 * g4, seq_len - 1) & ~7;
   const long blk_v = bt_row[vkey / block_size];
-  const long v_off = ((blk_v * Hkv + kvh) * (long)(block_size >> 3) + ((vkey % block_size) >> 3)) * (D * 8) + 8 * r16;
+  const int slab = block_size * 16;                           // elements of one 16-row slab of a block
+  const long v_off = (blk_v * Hkv + kvh) * (long)(D / 16) * slab + ((vkey % block_size) >> 3) * 128 + 8 * r16;
 #pragma unroll
-  for (int dt = 0; dt < D / 16; ++dt) f.vf[dt] = ld_kv<T, KV8>(v_cache, v_off + 128 * dt, v_scale);
+  for (int dt = 0; dt < D / 16; ++dt) f.vf[dt] = ld_kv<T, KV8>(v_cache, v_off + (long)dt * slab, v_scale);
 }
 
 template <typename T, int D, int NQ>
@@ -494,11 +495,12 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
       const long blk = bt_row[key / block_size];
       stage_k[i] = ld_kv<T, KV8>(k_cache, ((blk * Hkv + kvh) * block_size + (key % block_size)) * (long)D + 8 * cc,
                                  1.f);
-      const int d = c & 127, kc = c >> 7;        // consecutive lanes: consecutive D rows of one key group
+      const int d = ((c >> 7) << 4) | (c & 15), kc = (c >> 4) & 7;    // lanes walk the cache's chunk order
       const int vkey = min(base + 8 * kc, seq_len - 1) & ~7;
       const long blkv = bt_row[vkey / block_size];
       stage_v[i] = ld_kv<T, KV8>(
-          v_cache, ((blkv * Hkv + kvh) * (long)(block_size >> 3) + ((vkey % block_size) >> 3)) * (D * 8) + 8 * d, 1.f);
+          v_cache, ((blkv * Hkv + kvh) * (long)(D / 16) + (d >> 4)) * (block_size * 16) +
+                       ((vkey % block_size) >> 3) * 128 + 8 * (d & 15), 1.f);
     }
   };
   auto store_tile = [&](int buf) {
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
       const int c = tid + 256 * i;
       const int row = c >> 4, cc = c & 15;
       *reinterpret_cast<V*>(&smem[buf][0][row * 256 + ((cc ^ (row & 15)) << 4)]) = stage_k[i];
-      const int d = c & 127, kc = c >> 7;
+      const int d = ((c >> 7) << 4) | (c & 15), kc = (c >> 4) & 7;
       *reinterpret_cast<V*>(&smem[buf][1][d * 128 + ((kc ^ ((d >> 1) & 7)) << 4)]) = stage_v[i];
     }
   };

@@ -2,15 +2,15 @@
 //
 // Cache layouts are MFMA-operand-native (see attention.hip):
 //   k_cache[num_blocks][Hkv][block_size][D]   key row contiguous in D
-//   v_cache[num_blocks][Hkv][block_size/8][D][8]   transposed in groups of 8 keys
+//   v_cache[num_blocks][Hkv][D/16][block_size/8][16][8]   V^T in MFMA-fragment order
 //
 // Each thread owns one 8-element (16-byte) piece of one token; a token has
 //   items [0, Hq*D/16)            rotate a q pair-chunk in place
 //   items [.., +Hkv*D/16)         rotate a k pair-chunk, write it to k_cache
 //   items [.., +Hkv*D/8)          copy 8 v elements (head-dim index c, c + D/8, ...) to v_cache:
-//                                 element-sized stores 16 bytes apart, so the D/8 lanes of a head
-//                                 fill 8 element slots of each 128-byte line per store instruction
-//                                 and a token dirties D*16 contiguous bytes per head
+//                                 element-sized stores 16 bytes apart, so the lanes of a head fill
+//                                 8 element slots of each 128-byte line per store instruction and a
+//                                 token dirties D/16 runs of 256 bytes per head
 // and (token, item) pairs are laid out flat over the grid, so a rank that holds
 // one KV head (TP=8: 88 items per token) still fills 256-thread workgroups.
 //
@@ -129,21 +129,22 @@ __global__ void rope_cache_kernel(const int* __restrict__ positions, T* __restri
       T x[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) x[j] = src[j * cpd];
-      const long first = (((blk * Hkv + h) * (long)(block_size >> 3) + (off >> 3)) * D + c) * 8 + (off & 7);
+      // element index of head-dim row d: 16-row slab d/16, key group off/8, row d%16, key off%8
+      const long head0 = (blk * Hkv + h) * (long)D * block_size + (off >> 3) * 128 + (off & 7);
+      auto at = [&](int d) { return head0 + (long)(d >> 4) * (block_size * 16) + (d & 15) * 8; };
       if constexpr (KV8) {
         const float inv = (v_scales != nullptr) ? 1.f / v_scales[h] : 1.f;
         float g[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) g[j] = (float)x[j] * inv;
         const uint2 pk = pack_fp8x8(g);
-        uint8_t* dst = reinterpret_cast<uint8_t*>(v_cache_v) + first;
+        uint8_t* dst = reinterpret_cast<uint8_t*>(v_cache_v);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          dst[(long)j * cpd * 8] = (uint8_t)(((j < 4 ? pk.x : pk.y) >> (8 * (j & 3))) & 0xFF);
+          dst[at(c + j * cpd)] = (uint8_t)(((j < 4 ? pk.x : pk.y) >> (8 * (j & 3))) & 0xFF);
       } else {
-        T* dst = v_cache + first;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dst[(long)j * cpd * 8] = x[j];
+        for (int j = 0; j < 8; ++j) v_cache[at(c + j * cpd)] = x[j];
       }
     }
   }

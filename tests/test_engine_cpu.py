@@ -220,7 +220,7 @@ def test_fp8_kv_cache_reference_ops_and_engine_cpu():
     T, hkv, d, bs, nb = 19, 2, 16, 8, 4
     k, v = torch.randn(T, hkv, d), torch.randn(T, hkv, d)
     ks, vs = torch.tensor([0.5, 0.3]), torch.tensor([1.7, 0.9])
-    kc, vc = torch.zeros(nb, hkv, bs, d, dtype=fp8), torch.zeros(nb, hkv, bs // 8, d, 8, dtype=fp8)
+    kc, vc = torch.zeros(nb, hkv, bs, d, dtype=fp8), torch.zeros(nb, hkv, d // 16, bs // 8, 16, 8, dtype=fp8)
     slots = torch.arange(T, dtype=torch.int32)
     torch_ref.reshape_and_cache(k, v, kc, vc, slots, (ks, vs))
     bt = torch.arange(nb, dtype=torch.int32).view(1, -1)
@@ -230,7 +230,7 @@ def test_fp8_kv_cache_reference_ops_and_engine_cpu():
     q = torch.randn(1, 4, d)
     out8 = torch_ref.paged_attention_decode(q, kc, vc, bt, torch.tensor([T], dtype=torch.int32),
                                             1 / math.sqrt(d), (ks, vs))
-    kc32, vc32 = torch.zeros(nb, hkv, bs, d), torch.zeros(nb, hkv, bs // 8, d, 8)
+    kc32, vc32 = torch.zeros(nb, hkv, bs, d), torch.zeros(nb, hkv, d // 16, bs // 8, 16, 8)
     torch_ref.reshape_and_cache(k, v, kc32, vc32, slots)
     out32 = torch_ref.paged_attention_decode(q, kc32, vc32, bt, torch.tensor([T], dtype=torch.int32),
                                              1 / math.sqrt(d))

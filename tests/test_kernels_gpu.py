@@ -79,7 +79,7 @@ def test_rope_and_cache_matches_reference(hq, hkv, d, bs):
     slots = torch.randperm(nb * bs, device=DEV)[:T].to(torch.int32)
     slots[5] = -1                                       # padding token: no cache write
     kc = torch.zeros(nb, hkv, bs, d, device=DEV, dtype=torch.bfloat16)
-    vc = torch.zeros(nb, hkv, bs // 8, d, 8, device=DEV, dtype=torch.bfloat16)
+    vc = torch.zeros(nb, hkv, d // 16, bs // 8, 16, 8, device=DEV, dtype=torch.bfloat16)
     kc_ref, vc_ref = kc.float(), vc.float()
     q_ref = torch_ref.rope_and_cache(pos, qkv.float().clone(), cos_sin, kc_ref, vc_ref, slots, hq, hkv, d)
     q = ops.rope_and_cache(pos, qkv, cos_sin, kc, vc, slots, hq, hkv, d)
@@ -99,7 +99,7 @@ def test_rope_and_cache_with_per_head_rms_norm(hq, hkv, d, bs):
     pos = torch.randint(0, 4096, (T,), device=DEV, dtype=torch.int32)
     slots = torch.randperm(nb * bs, device=DEV)[:T].to(torch.int32)
     kc = torch.zeros(nb, hkv, bs, d, device=DEV, dtype=torch.bfloat16)
-    vc = torch.zeros(nb, hkv, bs // 8, d, 8, device=DEV, dtype=torch.bfloat16)
+    vc = torch.zeros(nb, hkv, d // 16, bs // 8, 16, 8, device=DEV, dtype=torch.bfloat16)
     kc_ref, vc_ref = kc.float(), vc.float()
     q_ref = torch_ref.rope_and_cache(pos, qkv.float().clone(), cos_sin, kc_ref, vc_ref, slots, hq, hkv, d,
                                      qw.float(), kw.float(), 1e-6)
@@ -121,7 +121,7 @@ def test_rotary_and_reshape_unfused():
     torch.testing.assert_close(k.float(), kr, rtol=2e-2, atol=2e-2)
     slots = torch.randperm(nb * bs, device=DEV)[:T].to(torch.int32)
     kc = torch.zeros(nb, hkv, bs, d, device=DEV, dtype=torch.bfloat16)
-    vc = torch.zeros(nb, hkv, bs // 8, d, 8, device=DEV, dtype=torch.bfloat16)
+    vc = torch.zeros(nb, hkv, d // 16, bs // 8, 16, 8, device=DEV, dtype=torch.bfloat16)
     kc_ref, vc_ref = kc.clone(), vc.clone()
     torch_ref.reshape_and_cache(k.view(T, hkv, d), v.view(T, hkv, d), kc_ref, vc_ref, slots)
     ops.reshape_and_cache(k.view(T, hkv, d), v.view(T, hkv, d), kc, vc, slots)
@@ -140,7 +140,7 @@ def _make_paged(seq_lens, hkv, d, bs, dtype=torch.bfloat16, extra_blocks=3):
         for j in range(n):
             bt[i, j] = next(it)
     kc = _rand(total, hkv, bs, d, dtype=dtype)
-    vc = _rand(total, hkv, bs // 8, d, 8, dtype=dtype)
+    vc = _rand(total, hkv, d // 16, bs // 8, 16, 8, dtype=dtype)
     return kc, vc, bt.to(DEV)
 
 
@@ -256,14 +256,14 @@ def test_mfma_operand_maps_with_exact_integer_data():
     from vllm_distributed_amd.ops import hip
     hq, hkv, d, bs, S = 8, 1, 128, 64, 64
     kc = torch.zeros(1, hkv, bs, d, device=DEV, dtype=torch.bfloat16)
-    vc = torch.zeros(1, hkv, bs // 8, d, 8, device=DEV, dtype=torch.bfloat16)
+    vc = torch.zeros(1, hkv, d // 16, bs // 8, 16, 8, device=DEV, dtype=torch.bfloat16)
     # key j has a large value only in dimension j -> query one-hot(dim j) selects key j
     for j in range(S):
         kc[0, 0, j, j] = 64.0
     keys = torch.arange(S, device=DEV).float()
     dims = torch.arange(d, device=DEV).float()
     vt = ((dims[:, None] * 2 + keys[None, :] * 3) % 61).to(torch.bfloat16)         # [d, key], asymmetric
-    vc[0, 0] = vt.view(d, bs // 8, 8).permute(1, 0, 2)                               # keys in groups of 8
+    vc[0, 0] = vt.view(d // 16, 16, bs // 8, 8).permute(0, 2, 1, 3)                 # fragment order
     q = torch.zeros(1, hq, d, device=DEV, dtype=torch.bfloat16)
     picks = [3, 17, 40, 63, 0, 9, 31, 32]
     for h, j in enumerate(picks):
@@ -491,10 +491,10 @@ def _fp8_caches(seq_lens, hkv, d, bs):
     ks = torch.rand(hkv, device=DEV) * 0.7 + 0.3            # deliberately not powers of two
     vs = torch.rand(hkv, device=DEV) * 1.5 + 0.5
     kc8 = (kc.float() / ks.view(1, -1, 1, 1)).clamp(-448, 448).to(FP8)
-    vc8 = (vc.float() / vs.view(1, -1, 1, 1, 1)).clamp(-448, 448).to(FP8)
+    vc8 = (vc.float() / vs.view(1, -1, 1, 1, 1, 1)).clamp(-448, 448).to(FP8)
     # what the kernels must see: the stored bytes widened exactly, times the head's scale
     kref = kc8.float() * ks.view(1, -1, 1, 1)
-    vref = vc8.float() * vs.view(1, -1, 1, 1, 1)
+    vref = vc8.float() * vs.view(1, -1, 1, 1, 1, 1)
     return kc8, vc8, bt, (ks, vs), kref, vref
 
 
@@ -552,7 +552,7 @@ def test_rope_and_cache_fp8_cache(hq, hkv, d, bs):
     ks = torch.rand(hkv, device=DEV) * 0.7 + 0.3
     vs = torch.rand(hkv, device=DEV) * 1.5 + 0.5
     kc = torch.zeros(nb, hkv, bs, d, device=DEV, dtype=FP8)
-    vc = torch.zeros(nb, hkv, bs // 8, d, 8, device=DEV, dtype=FP8)
+    vc = torch.zeros(nb, hkv, d // 16, bs // 8, 16, 8, device=DEV, dtype=FP8)
     kc_ref, vc_ref = torch.zeros_like(kc), torch.zeros_like(vc)
     q_ref = torch_ref.rope_and_cache(pos, qkv.float().clone(), cos_sin, kc_ref, vc_ref, slots, hq, hkv, d,
                                      kv_scales=(ks, vs))

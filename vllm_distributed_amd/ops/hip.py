@@ -183,9 +183,9 @@ def _kv_args(k_cache: torch.Tensor, kv_scales, hkv: int):
 
 def _check_cache(k_cache: torch.Tensor, v_cache: torch.Tensor, hkv: int, d: int) -> int:
     assert k_cache.dtype == v_cache.dtype
-    assert k_cache.dim() == 4 and v_cache.dim() == 5 and k_cache.is_contiguous() and v_cache.is_contiguous()
+    assert k_cache.dim() == 4 and v_cache.dim() == 6 and k_cache.is_contiguous() and v_cache.is_contiguous()
     nb, h, bs, dd = k_cache.shape
-    assert (h, dd) == (hkv, d) and bs % 8 == 0 and tuple(v_cache.shape) == (nb, hkv, bs // 8, d, 8), \
+    assert (h, dd) == (hkv, d) and bs % 8 == 0 and tuple(v_cache.shape) == (nb, hkv, d // 16, bs // 8, 16, 8), \
         (k_cache.shape, v_cache.shape)
     assert bs % 8 == 0
     return bs

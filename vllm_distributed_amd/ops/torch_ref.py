@@ -6,12 +6,13 @@ kernels consume as MFMA operands straight from global memory:
 
 * ``k_cache[num_blocks, num_kv_heads, block_size, head_dim]``  - a key row is
   contiguous in ``head_dim`` (the QK^T reduction axis);
-* ``v_cache[num_blocks, num_kv_heads, block_size // 8, head_dim, 8]``  - transposed
-  in groups of 8 keys: the 8 keys of one ``head_dim`` row are contiguous (one
-  16-byte chunk of the PV reduction axis), and the ``head_dim`` rows of a key
-  group follow each other, so a decode step's new token lands in
-  ``head_dim * 16`` contiguous bytes per head instead of one element in each of
-  ``head_dim`` separate rows.
+* ``v_cache[num_blocks, num_kv_heads, head_dim // 16, block_size // 8, 16, 8]``  -
+  V^T in MFMA-fragment order: the 8 keys of one ``head_dim`` row are a 16-byte
+  chunk (the PV reduction axis), 16 rows of a key group are adjacent, and the
+  key groups of a block follow each other inside a 16-row slab.  A wave's
+  16-row x 32-key fragment is one contiguous 1 KiB run, and a decode step's new
+  token lands in ``head_dim / 16`` runs of 256 bytes per head instead of one
+  element in each of ``head_dim`` separate rows.
 """
 from __future__ import annotations
 
@@ -132,12 +133,15 @@ def rotary_embedding(positions: torch.Tensor, q: torch.Tensor, k: torch.Tensor,
 FP8_KV = torch.float8_e4m3fn
 FP8_MAX = 448.0
 V_GROUP = 8          # keys per contiguous chunk of the V cache
+V_ROWS = 16          # head_dim rows per slab (the M of one MFMA fragment)
 
 
 def v_cache_shape(num_blocks: int, num_kv_heads: int, head_dim: int, block_size: int) -> Tuple[int, ...]:
     if block_size % V_GROUP != 0:
         raise ValueError(f"block_size must be a multiple of {V_GROUP}")
-    return (num_blocks, num_kv_heads, block_size // V_GROUP, head_dim, V_GROUP)
+    if head_dim % V_ROWS != 0:
+        raise ValueError(f"head_dim must be a multiple of {V_ROWS}")
+    return (num_blocks, num_kv_heads, head_dim // V_ROWS, block_size // V_GROUP, V_ROWS, V_GROUP)
 
 
 def k_cache_shape(num_blocks: int, num_kv_heads: int, head_dim: int, block_size: int) -> Tuple[int, ...]:
@@ -164,11 +168,11 @@ def reshape_and_cache(k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor,
     ks, vs = kv_scales if kv_scales is not None else (None, None)
     if k_cache.dtype == FP8_KV:      # index assignment is not implemented for 8-bit floats: go through the bytes
         k_cache.view(torch.uint8)[blk, :, off, :] = _to_cache(k[valid], k_cache, ks).view(torch.uint8)
-        v_cache.view(torch.uint8)[blk, :, off // V_GROUP, :, off % V_GROUP] = \
-            _to_cache(v[valid], v_cache, vs).view(torch.uint8)
+        vv = _to_cache(v[valid], v_cache, vs).view(torch.uint8)
+        v_cache.view(torch.uint8)[blk, :, :, off // V_GROUP, :, off % V_GROUP] = vv.unflatten(-1, (-1, V_ROWS))
         return
     k_cache[blk, :, off, :] = k[valid].to(k_cache.dtype)
-    v_cache[blk, :, off // V_GROUP, :, off % V_GROUP] = v[valid].to(v_cache.dtype)
+    v_cache[blk, :, :, off // V_GROUP, :, off % V_GROUP] = v[valid].to(v_cache.dtype).unflatten(-1, (-1, V_ROWS))
 
 
 def rope_and_cache(positions: torch.Tensor, qkv: torch.Tensor, cos_sin_cache: torch.Tensor,
@@ -200,12 +204,12 @@ def _gather_kv(k_cache, v_cache, block_table_row, seq_len, kv_scales=None):
         v = v_cache.view(torch.uint8)[blocks].view(FP8_KV).float()
         if kv_scales is not None:
             k = k * kv_scales[0].float().view(1, -1, 1, 1)
-            v = v * kv_scales[1].float().view(1, -1, 1, 1, 1)
+            v = v * kv_scales[1].float().view(1, -1, 1, 1, 1, 1)
     else:
         k = k_cache[blocks]                   # [nb, H, bs, D]
-        v = v_cache[blocks]                   # [nb, H, bs/8, D, 8]
+        v = v_cache[blocks]                   # [nb, H, D/16, bs/8, 16, 8]
     k = k.permute(1, 0, 2, 3).reshape(k.shape[1], nb * bs, -1)[:, :seq_len]
-    v = v.permute(1, 0, 2, 4, 3).reshape(v.shape[1], nb * bs, -1)[:, :seq_len]
+    v = v.permute(1, 0, 3, 5, 2, 4).reshape(v.shape[1], nb * bs, -1)[:, :seq_len]
     return k, v                               # [H, S, D]
 
 
