@@ -595,7 +595,9 @@ class ModelRunner:
         """Micro-batch row ranges for all-reduce/compute overlap, or None."""
         if self.comm_stream is None or nreq < 2:
             return None
-        if envs.VDAMD_TP_OVERLAP != "force" and nreq < envs.VDAMD_TP_OVERLAP_MIN_BATCH:
+        if envs.VDAMD_TP_OVERLAP != "force" and (nreq < envs.VDAMD_TP_OVERLAP_MIN_BATCH or self.tp.rccl is None):
+            # without the RCCL binding the in-place all-reduce is host-staged: nothing to overlap with,
+            # and it could not be captured into a hipGraph
             return None
         half = (nreq // 2 + 7) // 8 * 8 if nreq >= 32 else nreq // 2
         return [(0, half), (half, nreq)]
