@@ -43,6 +43,15 @@ CASES = {
     "qwen3-moe": ("Qwen3MoeConfig", dict(BASE, head_dim=32, moe_intermediate_size=64, num_experts=8,
                                          num_experts_per_tok=2, norm_topk_prob=True, decoder_sparse_step=1,
                                          mlp_only_layers=[])),
+    # sliding layers (own rotary base) and a global one, q/k norms, norms on both sides of each branch
+    "gemma3": ("Gemma3TextConfig", dict(BASE, head_dim=32, sliding_window=16, query_pre_attn_scalar=24,
+                                        num_hidden_layers=3, final_logit_softcapping=20.0,
+                                        layer_types=["sliding_attention", "full_attention", "sliding_attention"])),
+    "phi": ("PhiConfig", dict(BASE, partial_rotary_factor=0.5, layer_norm_eps=1e-5)),
+    # routed experts + a sigmoid-gated shared expert; one dense layer in between (mlp_only_layers)
+    "qwen2-moe": ("Qwen2MoeConfig", dict(BASE, moe_intermediate_size=64, shared_expert_intermediate_size=96,
+                                         num_experts=8, num_experts_per_tok=2, norm_topk_prob=False,
+                                         decoder_sparse_step=1, mlp_only_layers=[1])),
 }
 PROMPTS = [[5, 9, 200, 17, 33, 2, 90], list(range(10, 60)), [7, 7, 300, 2, 2, 41, 8, 100, 101]]
 

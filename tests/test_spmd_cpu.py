@@ -19,7 +19,7 @@ from vllm_distributed_amd.engine.arg_utils import EngineArgs
 from vllm_distributed_amd.engine.llm_engine import LLMEngine
 tp = int(os.environ.get("WORLD_SIZE", "1"))
 eng = LLMEngine.from_engine_args(EngineArgs(
-    model="llama-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,
+    model=os.environ.get("MODEL") or "llama-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,
     num_gpu_blocks_override=64, max_num_seqs=8, tensor_parallel_size=tp,
     distributed_executor_backend="spmd" if tp > 1 else "uni",
     async_scheduling=os.environ.get("ASYNC") == "1", quantization=os.environ.get("QUANT") or None))
@@ -36,14 +36,14 @@ eng.shutdown()
 """
 
 
-def _run(world, async_sched=False, sp="0", quant=""):
+def _run(world, async_sched=False, sp="0", quant="", model=""):
     port = get_open_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VLLM_LOGGING_LEVEL="WARNING",
                    GLOO_SOCKET_IFNAME="lo", OMP_NUM_THREADS="2", ASYNC="1" if async_sched else "0",
-                   VDAMD_SEQUENCE_PARALLEL=sp, QUANT=quant)
+                   VDAMD_SEQUENCE_PARALLEL=sp, QUANT=quant, MODEL=model)
         procs.append(subprocess.Popen([sys.executable, "-c", SCRIPT.format(root=ROOT)], env=env,
                                       stdout=subprocess.PIPE, text=True))
     outs = []
@@ -64,6 +64,17 @@ def test_spmd_tp2_matches_single_process_on_every_rank():
     assert got[0] == ref and got[1] == ref
     # sequence-parallel residual stream wherever the token count divides by TP
     got = _run(2, sp="force")
+    assert got[0] == ref and got[1] == ref
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("model", ["qwen2-moe-tiny", "gemma3-tiny", "phi-tiny"])
+def test_spmd_tp2_other_families_match_single_process(model):
+    """Shared-expert MoE (routed and shared halves under one all-reduce), Gemma-3 (norms on the branch
+    outputs: must stay on the plain layer loop even when the sharded residual stream is forced) and Phi
+    (parallel branches, biased vocab-parallel LM head) at TP=2 reproduce TP=1."""
+    ref = _run(1, model=model)[0]
+    got = _run(2, model=model, sp="force")
     assert got[0] == ref and got[1] == ref
 
 

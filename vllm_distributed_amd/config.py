@@ -274,6 +274,8 @@ class ModelConfig:
         mt = self.hf_config.get("model_type", "llama")
         return {"llama": "LlamaForCausalLM", "opt": "OPTForCausalLM",
                 "qwen3_moe": "Qwen3MoeForCausalLM", "qwen2": "Qwen2ForCausalLM",
+                "qwen2_moe": "Qwen2MoeForCausalLM", "phi": "PhiForCausalLM",
+                "gemma3_text": "Gemma3ForCausalLM",
                 "qwen3": "Qwen3ForCausalLM", "mistral": "MistralForCausalLM",
                 "mixtral": "MixtralForCausalLM", "phi3": "Phi3ForCausalLM"}.get(mt, mt)
 

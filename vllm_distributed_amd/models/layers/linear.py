@@ -509,6 +509,8 @@ class ParallelLMHead(VocabParallelEmbedding):
     def __init__(self, vocab_size: int, hidden_size: int, dtype: torch.dtype, bias: bool = False):
         super().__init__(vocab_size, hidden_size, dtype)
         self.bias = _param(self.rows, dtype=dtype) if bias else None
+        if bias:
+            self.bias.weight_loader = self.weight_loader      # type: ignore[attr-defined]  (same vocab shard)
 
     def logits(self, hidden: torch.Tensor) -> torch.Tensor:
         y = ops.linear(hidden, self.weight, self.bias)

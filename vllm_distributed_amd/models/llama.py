@@ -51,7 +51,7 @@ class LlamaAttention(nn.Module):
         heads = cfg["num_attention_heads"]
         kv_heads = cfg.get("num_key_value_heads") or heads
         self.head_dim = cfg.get("head_dim") or hidden // heads
-        bias = bool(cfg.get("attention_bias", False)) or cfg.get("model_type") == "qwen2"
+        bias = bool(cfg.get("attention_bias", False)) or cfg.get("model_type") in ("qwen2", "qwen2_moe")
         self.qkv_proj = QKVParallelLinear(hidden, self.head_dim, heads, kv_heads, bias, dtype)
         self.o_proj = RowParallelLinear(heads * self.head_dim, hidden,
                                         bool(cfg.get("attention_bias", False)), dtype)
@@ -59,7 +59,7 @@ class LlamaAttention(nn.Module):
         self.num_kv_heads = self.qkv_proj.num_kv_heads
         self.q_size, self.kv_size = self.qkv_proj.q_size, self.qkv_proj.kv_size
         self.cos_sin = cos_sin
-        self.qk_norm = cfg.get("model_type") in ("qwen3", "qwen3_moe")
+        self.qk_norm = cfg.get("model_type") in ("qwen3", "qwen3_moe", "gemma3_text")
         if self.qk_norm:
             eps = cfg.get("rms_norm_eps", 1e-6)
             self.q_norm = RMSNorm(self.head_dim, eps, dtype)
@@ -211,9 +211,14 @@ class LlamaForCausalLM(nn.Module):
     def attention_layers(self) -> List[Attention]:
         return [layer.self_attn.attn for layer in self.layers.values()]
 
+    # False for families whose layers are not "norm -> branch -> add into the residual" (norms on the
+    # branch outputs as well): they run the plain layer loop, without the fused / sharded / overlapped
+    # forms of the TP all-reduces, which are written against that layer shape
+    tp_fusions = True
+
     def forward(self, input_ids: Optional[torch.Tensor], positions: torch.Tensor,
                 intermediate: Optional[IntermediateTensors] = None):
-        fused = self.fused_tp_mode(positions.shape[0])
+        fused = self.fused_tp_mode(positions.shape[0]) if self.tp_fusions else None
         if fused is not None:
             return self.forward_fused_tp(input_ids, positions, intermediate, sharded=fused)
         if intermediate is None and self.sequence_parallel_ok(positions.shape[0]):
@@ -299,7 +304,7 @@ class LlamaForCausalLM(nn.Module):
         and the add+RMSNorm between them touches ``1/TP`` of the rows, where
         the replicated form makes every rank normalise all of them."""
         mode = envs.VDAMD_SEQUENCE_PARALLEL
-        if mode == "0" or not (self.is_first and self.is_last):
+        if mode == "0" or not self.tp_fusions or not (self.is_first and self.is_last):
             return False
         w = get_tp_group().world_size
         if num_tokens % w:

@@ -107,6 +107,18 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
     kvh = c.get("num_key_value_heads") or heads
     hd = c.get("head_dim") or h // heads
     inter = c.get("intermediate_size", 0)
+    if arch == "PhiForCausalLM":
+        shapes["model.embed_tokens.weight"] = (c["vocab_size"], h)
+        shapes["model.final_layernorm.weight"] = shapes["model.final_layernorm.bias"] = (h,)
+        shapes["lm_head.weight"], shapes["lm_head.bias"] = (c["vocab_size"], h), (c["vocab_size"],)
+        for i in range(L):
+            q = f"model.layers.{i}."
+            shapes[q + "input_layernorm.weight"] = shapes[q + "input_layernorm.bias"] = (h,)
+            for n, rows in (("q_proj", heads * hd), ("k_proj", kvh * hd), ("v_proj", kvh * hd), ("dense", h)):
+                shapes[q + f"self_attn.{n}.weight"], shapes[q + f"self_attn.{n}.bias"] = (rows, h), (rows,)
+            shapes[q + "mlp.fc1.weight"], shapes[q + "mlp.fc1.bias"] = (inter, h), (inter,)
+            shapes[q + "mlp.fc2.weight"], shapes[q + "mlp.fc2.bias"] = (h, inter), (h,)
+        return shapes
     if arch == "Starcoder2ForCausalLM":
         shapes["model.embed_tokens.weight"] = (c["vocab_size"], h)
         shapes["model.norm.weight"] = shapes["model.norm.bias"] = (h,)
@@ -122,10 +134,10 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
             shapes[q + "mlp.c_fc.weight"], shapes[q + "mlp.c_fc.bias"] = (inter, h), (inter,)
             shapes[q + "mlp.c_proj.weight"], shapes[q + "mlp.c_proj.bias"] = (h, inter), (h,)
         return shapes
-    moe = arch == "Qwen3MoeForCausalLM"
+    moe = arch in ("Qwen3MoeForCausalLM", "Qwen2MoeForCausalLM")
     mixtral = arch == "MixtralForCausalLM"
     phi3 = arch == "Phi3ForCausalLM"
-    qkv_bias = bool(c.get("attention_bias", False)) or c.get("model_type") == "qwen2"
+    qkv_bias = bool(c.get("attention_bias", False)) or c.get("model_type") in ("qwen2", "qwen2_moe")
     shapes["model.embed_tokens.weight"] = (c["vocab_size"], h)
     shapes["model.norm.weight"] = (h,)
     if not c.get("tie_word_embeddings", False):
@@ -143,9 +155,12 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
             shapes[q + "self_attn.q_proj.bias"] = (heads * hd,)
             shapes[q + "self_attn.k_proj.bias"] = (kvh * hd,)
             shapes[q + "self_attn.v_proj.bias"] = (kvh * hd,)
-        if c.get("model_type") in ("qwen3", "qwen3_moe"):
+        if c.get("model_type") in ("qwen3", "qwen3_moe", "gemma3_text"):
             shapes[q + "self_attn.q_norm.weight"] = (hd,)
             shapes[q + "self_attn.k_norm.weight"] = (hd,)
+        if c.get("model_type") == "gemma3_text":
+            shapes[q + "pre_feedforward_layernorm.weight"] = (h,)
+            shapes[q + "post_feedforward_layernorm.weight"] = (h,)
         shapes[q + "input_layernorm.weight"] = (h,)
         shapes[q + "post_attention_layernorm.weight"] = (h,)
         step = c.get("decoder_sparse_step", 1)
@@ -158,6 +173,13 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
                 shapes[q + f"mlp.experts.{e}.gate_proj.weight"] = (mi, h)
                 shapes[q + f"mlp.experts.{e}.up_proj.weight"] = (mi, h)
                 shapes[q + f"mlp.experts.{e}.down_proj.weight"] = (h, mi)
+            if arch == "Qwen2MoeForCausalLM":
+                si = int(c.get("shared_expert_intermediate_size") or 0)
+                shapes[q + "mlp.shared_expert_gate.weight"] = (1, h)
+                if si > 0:
+                    shapes[q + "mlp.shared_expert.gate_proj.weight"] = (si, h)
+                    shapes[q + "mlp.shared_expert.up_proj.weight"] = (si, h)
+                    shapes[q + "mlp.shared_expert.down_proj.weight"] = (h, si)
         elif mixtral:
             shapes[q + "block_sparse_moe.gate.weight"] = (c["num_local_experts"], h)
             for e in range(c["num_local_experts"]):

@@ -10,11 +10,14 @@ _MODELS: Dict[str, Tuple[str, str]] = {
     "Qwen2ForCausalLM": ("llama", "LlamaForCausalLM"),
     "Qwen3ForCausalLM": ("llama", "LlamaForCausalLM"),
     "Qwen3MoeForCausalLM": ("qwen3_moe", "Qwen3MoeForCausalLM"),
+    "Qwen2MoeForCausalLM": ("qwen2_moe", "Qwen2MoeForCausalLM"),
     "MixtralForCausalLM": ("mixtral", "MixtralForCausalLM"),
     # Phi-3 checkpoints store qkv and gate/up already fused: the fused loaders take them whole
     "Phi3ForCausalLM": ("llama", "LlamaForCausalLM"),
+    "PhiForCausalLM": ("phi", "PhiForCausalLM"),
     "OPTForCausalLM": ("opt", "OPTForCausalLM"),
     "GemmaForCausalLM": ("llama_variants", "GemmaForCausalLM"),
+    "Gemma3ForCausalLM": ("llama_variants", "Gemma3ForCausalLM"),
     "GraniteForCausalLM": ("llama_variants", "GraniteForCausalLM"),
     "GPT2LMHeadModel": ("gpt2", "GPT2LMHeadModel"),
     "GPTNeoXForCausalLM": ("gpt_neox", "GPTNeoXForCausalLM"),

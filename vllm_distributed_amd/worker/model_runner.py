@@ -277,7 +277,7 @@ class ModelRunner:
         self.tp = get_tp_group()
         mode = envs.VDAMD_TP_OVERLAP
         if (self.is_gpu and self.pp.world_size == 1 and hasattr(self.model, "forward_overlapped")
-                and (mode == "force" or (mode == "auto" and self.tp.world_size > 1))):
+                and getattr(self.model, "tp_fusions", True) and (mode == "force" or (mode == "auto" and self.tp.world_size > 1))):
             self.comm_stream = torch.cuda.Stream(priority=-1)
         self.pp_link = None
         if self.pp.world_size > 1:
