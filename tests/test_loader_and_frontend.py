@@ -436,6 +436,47 @@ def test_sliding_window_is_resolved_per_layer():
     assert [layer_sliding_window(t, i) for i in range(4)] == [4096, None, 4096, None]
 
 
+def test_blocks_behind_the_sliding_window_return_to_the_pool():
+    """With every layer windowed, a sequence holds blocks for its window (plus the margin for steps in
+    flight), not for its length: four long generations fit a pool that their full lengths would
+    overflow, without a preemption and with the tokens of a roomy run."""
+    from vllm_distributed_amd.engine.kv_cache_manager import KVCacheManager
+    from vllm_distributed_amd.engine.request import Request
+    kv = KVCacheManager(num_blocks=64, block_size=16, max_model_len=1024, enable_caching=True, sliding_window=32)
+    req = Request("r", list(range(200)), SamplingParams(max_tokens=400), None)
+    assert kv.allocate_slots(req, 200) is not None
+    req.num_computed_tokens = 200
+    # keys below 200 - 32 - margin(128) = 40 are dead: blocks 0 and 1
+    assert kv.release_out_of_window(req) == 2 and kv.release_out_of_window(req) == 0
+    assert kv.get_block_ids("r")[:2] == [0, 0] and len(kv.get_block_ids("r")) == 13
+    assert kv.num_free_blocks == 64 - 11
+    kv.free(req)
+    assert kv.num_free_blocks == 64
+    kv_all = KVCacheManager(num_blocks=64, block_size=16, max_model_len=1024)      # a global-attention model
+    assert kv_all.allocate_slots(req, 200) is not None and kv_all.release_out_of_window(req) == 0
+
+    prompts = [[3 + (7 * i + j) % 400 for j in range(40)] for i in range(4)]
+    sp = SamplingParams(temperature=0.0, max_tokens=300, ignore_eos=True)
+    outs = {}
+    for blocks in (200, 56):        # 4 x 340 tokens = 88 blocks of 16 at full length; (32 + 128) / 16 + 2 each
+        llm = LLM(model="mistral-window-tiny", device="cpu", dtype="float32", max_model_len=512, block_size=16,
+                  num_gpu_blocks_override=blocks, max_num_seqs=4, load_format="dummy")
+        sched = llm.engine.core.scheduler
+        assert sched.kv.window == 32
+        outs[blocks] = [o.outputs[0].token_ids for o in llm.generate(prompts, sp)]
+        assert sched.num_preemptions == 0
+        assert sched.kv.num_free_blocks == blocks
+        llm.shutdown()
+        pstate.destroy_model_parallel()
+    assert outs[56] == outs[200]
+    # a model with global layers keeps everything
+    llm = LLM(model="llama-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,
+              num_gpu_blocks_override=32, load_format="dummy")
+    assert llm.engine.core.scheduler.kv.window is None
+    llm.shutdown()
+    pstate.destroy_model_parallel()
+
+
 def test_gptq_checkpoint_is_the_same_model_as_its_awq_twin(tmp_path):
     """A 4-bit GPTQ checkpoint holds the integers, zero points and scales of an AWQ one in another
     packing: writing the dummy AWQ model's tensors in GPTQ form (rows packed eight to a word, zero

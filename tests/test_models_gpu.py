@@ -48,6 +48,25 @@ def test_model_family_on_gpu_tracks_cpu_reference(model, tmp_path):
             assert max(abs(la[t] - lb[t]) for t in common) < 0.3, (model, step)
 
 
+def test_window_released_blocks_are_never_read_by_the_kernels():
+    """Sliding-window model on the HIP kernels with a pool that only fits because blocks behind the
+    window are recycled between the four sequences: tokens must equal a roomy run's (a kernel touching
+    a recycled block would read another sequence's keys)."""
+    prompts = [[3 + (7 * i + j) % 400 for j in range(40)] for i in range(4)]
+    sp = SamplingParams(temperature=0.0, max_tokens=300, ignore_eos=True)
+    outs = {}
+    for blocks in (64, 18):          # 4 x 340 tokens = 24 blocks of 64 at full length, 16 with recycling
+        llm = LLM(model="mistral-window-tiny", dtype="bfloat16", gpu_memory_utilization=0.3, max_model_len=512,
+                  block_size=64, num_gpu_blocks_override=blocks, max_num_seqs=4, load_format="dummy")
+        sched = llm.engine.core.scheduler
+        assert sched.kv.window == 32
+        outs[blocks] = [o.outputs[0].token_ids for o in llm.generate(prompts, sp)]
+        assert sched.num_preemptions == 0 and sched.kv.num_free_blocks == blocks
+        llm.shutdown()
+        pstate.destroy_model_parallel()
+    assert outs[18] == outs[64]
+
+
 def test_logit_edits_on_gpu_with_graph_decode():
     """logit_bias / allow list / bad words / min_tokens on bf16 device logits, in a batch
     that mixes edited and plain requests while decode runs from a captured graph."""

@@ -93,7 +93,8 @@ class EngineCore:
         self.scheduler = Scheduler(vllm_config.scheduler_config, vllm_config.cache_config, num_blocks,
                                    include_new_token_ids=pp > 1, kv_connector=kv_connector,
                                    max_loras=vllm_config.lora_config.max_loras if vllm_config.lora_config else 0,
-                                   speculative_config=vllm_config.speculative_config)
+                                   speculative_config=vllm_config.speculative_config,
+                                   sliding_window=None if kv_connector is not None else self.kv_window)
         self.max_concurrent = max(1, self.executor.max_concurrent_batches)
         self.batch_queue: Deque[Tuple[object, SchedulerOutput]] = deque()
         self.timer = StepTimer()
@@ -120,6 +121,9 @@ class EngineCore:
                 f"sequence of max_model_len={self.vllm_config.model_config.max_model_len} needs {need}; "
                 f"lower --max-model-len or raise --gpu-memory-utilization")
         cc.num_gpu_blocks = num_blocks
+        # every layer of every worker windowed: blocks that slid out of the widest window are dead
+        wins = [getattr(s, "sliding_window", None) for s in specs]
+        self.kv_window = max(wins) if wins and all(w is not None for w in wins) else None
         self.executor.initialize_from_config([KVCacheConfig(num_blocks=num_blocks)] * len(specs))
         return num_blocks
 

@@ -92,8 +92,17 @@ class BlockPool:
 
 
 class KVCacheManager:
+    # The window is treated as this much wider when blocks are released: the attention kernels fetch
+    # whole 64-key tiles (the one the window starts in is read and masked), a verification step may
+    # hand positions back (rejected speculative drafts, at most 16), and one step is in flight under
+    # async scheduling.
+    WINDOW_MARGIN = 128
+
     def __init__(self, num_blocks: int, block_size: int, max_model_len: int,
-                 enable_caching: bool = True):
+                 enable_caching: bool = True, sliding_window: Optional[int] = None):
+        # every attention layer sees at most this many most recent keys (None: some layer sees all)
+        self.window = int(sliding_window) if sliding_window else None
+        self.num_released: Dict[str, int] = {}       # leading blocks already given back, per request
         self.block_size = block_size
         self.max_model_len = max_model_len
         self.enable_caching = enable_caching
@@ -187,17 +196,45 @@ class KVCacheManager:
             return
         self._extend_hashes(request, n_full * self.block_size)
         for i in range(start, min(n_full, len(held))):
-            self.pool.set_hash(held[i], request.block_hashes[i])
+            if held[i] is not None:
+                self.pool.set_hash(held[i], request.block_hashes[i])
         self.num_cached_block[request.request_id] = n_full
+
+    def release_out_of_window(self, request: Request) -> int:
+        """Give back the leading blocks of a running request that no attention layer will read again:
+        with every layer windowed, the next query (position ``num_computed_tokens``) and all later ones
+        see keys from ``num_computed_tokens - window + 1`` on.  The request keeps its place in the
+        block table (workers hold the stale ids and never dereference them: the kernels skip whole
+        key tiles below the window); a released block that carries a prefix hash stays reusable
+        until it is evicted.  Returns the number of blocks released."""
+        if self.window is None:
+            return 0
+        held = self.req_blocks.get(request.request_id)
+        if not held:
+            return 0
+        dead = (request.num_computed_tokens - self.window - self.WINDOW_MARGIN) // self.block_size
+        done = self.num_released.get(request.request_id, 0)
+        dead = min(dead, len(held))
+        if dead <= done:
+            return 0
+        gone = [b for b in held[done:dead] if b is not None]
+        for i in range(done, dead):
+            held[i] = None
+        self.num_released[request.request_id] = dead
+        self.pool.release(gone)          # oldest first: evicted first
+        return len(gone)
 
     def free(self, request: Request) -> None:
         held = self.req_blocks.pop(request.request_id, None)
         self.num_cached_block.pop(request.request_id, None)
+        self.num_released.pop(request.request_id, None)
         if held:
-            self.pool.release(list(reversed(held)))
+            self.pool.release([b for b in reversed(held) if b is not None])
 
     def get_block_ids(self, request_id: str) -> List[int]:
-        return [b.block_id for b in self.req_blocks.get(request_id, [])]
+        """Block ids in sequence order; blocks released behind the window read as block 0 (a valid
+        index nobody dereferences)."""
+        return [0 if b is None else b.block_id for b in self.req_blocks.get(request_id, [])]
 
     def reset_prefix_cache(self) -> bool:
         return self.pool.reset_prefix_cache()

@@ -62,7 +62,8 @@ class Scheduler:
 
     def __init__(self, scheduler_config: SchedulerConfig, cache_config: CacheConfig,
                  num_blocks: int, include_new_token_ids: bool = True,
-                 kv_connector=None, max_loras: int = 0, speculative_config=None):
+                 kv_connector=None, max_loras: int = 0, speculative_config=None,
+                 sliding_window: Optional[int] = None):
         self.config = scheduler_config
         self.cache_config = cache_config
         self.max_num_seqs = scheduler_config.max_num_seqs
@@ -72,7 +73,7 @@ class Scheduler:
         # a request that will sample carries a placeholder for the unknown token
         self.async_scheduling = bool(scheduler_config.async_scheduling)
         self.kv = KVCacheManager(num_blocks, cache_config.block_size, self.max_model_len,
-                                 cache_config.enable_prefix_caching)
+                                 cache_config.enable_prefix_caching, sliding_window=sliding_window)
         self.requests: Dict[str, Request] = {}
         self.waiting: Deque[Request] = deque()
         self.running: List[Request] = []
@@ -378,6 +379,7 @@ class Scheduler:
                     for j, d in enumerate(entries):
                         req.prompt_logprobs.setdefault(first + j, d)
         caching = self.kv.enable_caching
+        windowed = self.kv.window is not None
         fwd_tokens = self.include_new_token_ids
         running_state = RequestStatus.RUNNING
         max_len = self.max_model_len
@@ -393,6 +395,8 @@ class Scheduler:
                 self.spec_stats["accepted"] += len(new_tokens) - 1
             if caching:              # blocks that are now full and fully known can be shared
                 self.kv.cache_blocks(req, req.num_computed_tokens)
+            if windowed:             # ... and blocks every layer's window has left go back to the pool
+                self.kv.release_out_of_window(req)
             if not new_tokens:
                 continue             # partial prefill: nothing sampled
             if req.num_output_placeholders:

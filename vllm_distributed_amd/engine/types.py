@@ -93,6 +93,9 @@ class KVCacheSpec:
     head_dim: int
     block_size: int
     dtype_bytes: int
+    # the largest attention window of this worker's layers when EVERY one of them has one (keys further
+    # back are never read again and their blocks can go back to the pool), else None
+    sliding_window: Optional[int] = None
 
     @property
     def bytes_per_block(self) -> int:

@@ -293,8 +293,10 @@ class ModelRunner:
         layers = self.model.attention_layers()
         a = layers[0]
         fp8 = self.vllm_config.cache_config.kv_fp8
+        windows = [int(getattr(l, "window", 0) or 0) for l in layers]
         return KVCacheSpec(num_layers=len(layers), num_kv_heads=a.num_kv_heads, head_dim=a.head_dim,
-                           block_size=self.block_size, dtype_bytes=1 if fp8 else self.model_config.dtype_bytes)
+                           block_size=self.block_size, dtype_bytes=1 if fp8 else self.model_config.dtype_bytes,
+                           sliding_window=max(windows) if windows and min(windows) > 0 else None)
 
     @torch.inference_mode()
     def profile_run(self) -> None:
