@@ -314,6 +314,50 @@ def test_ngram_speculative_decoding_reproduces_greedy_output():
         LLM(speculative_config={"method": "eagle"}, **kw)
 
 
+def test_draft_model_speculative_decoding_reproduces_greedy_output():
+    """A second model on the workers proposes, the target verifies: whatever the draft says, the text is
+    what one-token greedy decoding writes.  With the target as its own draft every proposal is accepted
+    (k + 1 tokens per step); with an unrelated draft nearly all are rejected and the text still holds."""
+    from vllm_distributed_amd import LLM, SamplingParams
+    kw = dict(model="llama-tiny", device="cpu", dtype="float32", max_model_len=256, num_gpu_blocks_override=128,
+              max_num_seqs=8, load_format="dummy")
+    prompts = [{"prompt_token_ids": [3, 9, 4, 7, 11, 5] * 6}, {"prompt_token_ids": list(range(20, 60))},
+               {"prompt_token_ids": [5, 6] * 20}, {"prompt_token_ids": list(range(100, 117))}]
+    sps = [SamplingParams(temperature=0.0, max_tokens=40, ignore_eos=True),
+           SamplingParams(temperature=0.0, max_tokens=23, ignore_eos=True),
+           SamplingParams(temperature=0.0, max_tokens=40, ignore_eos=True, logprobs=1),   # decoded one token at a time
+           SamplingParams(temperature=0.0, max_tokens=30, ignore_eos=True)]
+    ref = LLM(**kw)
+    want = [o.outputs[0].token_ids for o in ref.generate(prompts, sps)]
+    twin = LLM(speculative_config={"model": "llama-tiny", "num_speculative_tokens": 3}, **kw)
+    assert twin.engine.vllm_config.speculative_config.method == "draft_model"
+    runner = twin.engine.core.executor.driver.worker.model_runner
+    spec = runner.get_kv_cache_spec()
+    assert spec.extra_bytes_per_block == 2 * spec.num_layers * spec.block_size * spec.num_kv_heads * spec.head_dim * \
+        spec.dtype_bytes                                   # the draft's caches are budgeted next to the target's
+    got = [o.outputs[0].token_ids for o in twin.generate(prompts, sps)]
+    assert got == want
+    st = twin.engine.core.scheduler.spec_stats
+    assert st["drafted"] > 0 and st["accepted"] == st["drafted"]          # same weights: never wrong
+    assert st["accepted"] >= 0.6 * (40 + 23 + 30)            # ~3 of every 4 tokens of the three plain requests
+    solo = twin.generate(prompts[:1], sps[0])[0].outputs[0].token_ids
+    assert solo == want[0] and twin.engine.core.scheduler.step_id - 40 <= 14       # 40 tokens in ~11 steps
+    # an unrelated draft model (same vocabulary): rejections roll positions back, text unchanged;
+    # a prefix-cache hit on the second pass skips prompt blocks for both models alike
+    other = LLM(speculative_config={"method": "draft_model", "model": "phi-tiny", "num_speculative_tokens": 4}, **kw)
+    for _ in range(2):
+        got = [o.outputs[0].token_ids for o in other.generate(prompts, sps)]
+        assert got == want
+    st = other.engine.core.scheduler.spec_stats
+    assert st["drafted"] > 0 and st["accepted"] < st["drafted"]
+    hot = other.generate(prompts[:2], SamplingParams(temperature=0.8, max_tokens=30, ignore_eos=True))
+    assert [len(o.outputs[0].token_ids) for o in hot] == [30, 30]
+    with pytest.raises(ValueError):
+        LLM(speculative_config={"method": "draft_model"}, **kw)          # no model named
+    for llm in (ref, twin, other):
+        llm.shutdown()
+
+
 def test_offline_n_best_of_and_beam_search():
     """``LLM.generate`` fans ``n`` / ``best_of`` out into requests that share the prompt; beam search runs
     on one-token requests: width 1 is greedy decoding, beams come back best first and every beam's

@@ -67,6 +67,32 @@ def test_window_released_blocks_are_never_read_by_the_kernels():
     assert outs[18] == outs[64]
 
 
+def test_draft_model_speculation_on_gpu_with_graph_decode():
+    """Draft-model speculative decoding on the HIP kernels: the target as its own draft has every
+    proposal accepted and writes the text of plain greedy decoding (the target's one-token steps run
+    from the captured graph, the draft runs next to it on the same blocks)."""
+    kw = dict(model="llama-tiny", dtype="bfloat16", gpu_memory_utilization=0.3, max_model_len=256,
+              num_gpu_blocks_override=128, max_num_seqs=8, load_format="dummy")
+    prompts = [{"prompt_token_ids": [3, 9, 4, 7, 11, 5] * 6}, {"prompt_token_ids": list(range(20, 60))}]
+    sp = SamplingParams(temperature=0.0, max_tokens=32, ignore_eos=True)
+    ref = LLM(**kw)
+    want = [o.outputs[0].token_ids for o in ref.generate(prompts, sp)]
+    ref.shutdown()
+    pstate.destroy_model_parallel()
+    llm = LLM(speculative_config={"model": "llama-tiny", "num_speculative_tokens": 3}, **kw)
+    got = [o.outputs[0].token_ids for o in llm.generate(prompts, sp)]
+    st = llm.engine.core.scheduler.spec_stats
+    llm.shutdown()
+    pstate.destroy_model_parallel()
+    assert st["drafted"] > 0
+    # bf16: a verification step scores 4 positions in one prefill-shaped pass, a plain step one; near-ties
+    # may round differently, so demand agreement on a long common prefix rather than on every token
+    for a, b in zip(got, want):
+        same = next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), len(b))
+        assert same >= 8, (a, b)
+    assert st["accepted"] >= 0.5 * st["drafted"]
+
+
 def test_logit_edits_on_gpu_with_graph_decode():
     """logit_bias / allow list / bad words / min_tokens on bf16 device logits, in a batch
     that mixes edited and plain requests while decode runs from a captured graph."""

@@ -22,7 +22,8 @@ eng = LLMEngine.from_engine_args(EngineArgs(
     model=os.environ.get("MODEL") or "llama-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,
     num_gpu_blocks_override=64, max_num_seqs=8, tensor_parallel_size=tp,
     distributed_executor_backend="spmd" if tp > 1 else "uni",
-    async_scheduling=os.environ.get("ASYNC") == "1", quantization=os.environ.get("QUANT") or None))
+    async_scheduling=os.environ.get("ASYNC") == "1", quantization=os.environ.get("QUANT") or None,
+    speculative_config=json.loads(os.environ.get("SPEC") or "null")))
 sp = SamplingParams(temperature=0.8, top_p=0.9, seed=7, max_tokens=8, ignore_eos=True)
 g = SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True)
 ids = [eng.add_request(None, p, s) for p, s in (([5, 9, 200, 17], g), (list(range(10, 50)), sp), ([7, 7], g))]
@@ -36,14 +37,14 @@ eng.shutdown()
 """
 
 
-def _run(world, async_sched=False, sp="0", quant="", model=""):
+def _run(world, async_sched=False, sp="0", quant="", model="", spec=""):
     port = get_open_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VLLM_LOGGING_LEVEL="WARNING",
                    GLOO_SOCKET_IFNAME="lo", OMP_NUM_THREADS="2", ASYNC="1" if async_sched else "0",
-                   VDAMD_SEQUENCE_PARALLEL=sp, QUANT=quant, MODEL=model)
+                   VDAMD_SEQUENCE_PARALLEL=sp, QUANT=quant, MODEL=model, SPEC=spec)
         procs.append(subprocess.Popen([sys.executable, "-c", SCRIPT.format(root=ROOT)], env=env,
                                       stdout=subprocess.PIPE, text=True))
     outs = []
@@ -76,6 +77,15 @@ def test_spmd_tp2_other_families_match_single_process(model):
     ref = _run(1, model=model)[0]
     got = _run(2, model=model, sp="force")
     assert got[0] == ref and got[1] == ref
+
+
+@pytest.mark.slow
+def test_spmd_tp2_draft_model_speculation_matches_single_process():
+    """Target and draft model both sharded over the TP group: every rank proposes and verifies the
+    same tokens, and the greedy request reads as without speculation."""
+    ref = _run(1)[0]
+    got = _run(2, spec='{"model": "phi-tiny", "num_speculative_tokens": 3}')
+    assert got[0][0] == ref[0] and got[0][2] == ref[2] and got[1] == got[0]
 
 
 @pytest.mark.slow

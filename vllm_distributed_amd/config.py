@@ -351,18 +351,31 @@ class CacheConfig:
 
 @dataclass
 class SpeculativeConfig:
-    """Speculative decoding by prompt lookup: drafts are the tokens that followed the most recent
-    earlier occurrence of the text's current n-gram suffix; the model scores them all in one step
-    and keeps the prefix it agrees with (vLLM's ``--speculative-config '{"method": "ngram", ...}'``)."""
+    """Speculative decoding (vLLM's ``--speculative-config '{...}'``): the model scores a request's last
+    token and a few draft tokens in one step and keeps the drafts it reproduces, plus one token of its own.
+
+    ``method``
+      * ``ngram``: prompt lookup - drafts are the tokens that followed the most recent earlier
+        occurrence of the text's current n-gram suffix (``prompt_lookup_min`` .. ``prompt_lookup_max``);
+      * ``draft_model``: a smaller model with the same vocabulary (``model``) runs on the workers next
+        to the target, with its own KV cache over the same blocks, and proposes greedily."""
     method: str = "ngram"
     num_speculative_tokens: int = 4
     prompt_lookup_max: int = 4
     prompt_lookup_min: int = 2
+    model: Optional[str] = None              # draft model (a bundled name, a path or a hub id)
+    load_format: Optional[str] = None        # of the draft model; default: the target's
+    quantization: Optional[str] = None       # of the draft model
 
     def __post_init__(self) -> None:
-        if self.method not in ("ngram", "[ngram]"):
-            raise ValueError(f"speculative method {self.method!r} is not supported (ngram)")
-        self.method = "ngram"
+        if self.method in (None, "") or (self.method == "ngram" and self.model):
+            self.method = "draft_model" if self.model else "ngram"
+        if self.method not in ("ngram", "[ngram]", "draft_model"):
+            raise ValueError(f"speculative method {self.method!r} is not supported (ngram, draft_model)")
+        if self.method == "[ngram]":
+            self.method = "ngram"
+        if self.method == "draft_model" and not self.model:
+            raise ValueError("speculative method draft_model needs a \"model\"")
         if not 1 <= self.num_speculative_tokens <= 16:
             raise ValueError("num_speculative_tokens must be between 1 and 16")
         if not 1 <= self.prompt_lookup_min <= self.prompt_lookup_max:
@@ -375,8 +388,10 @@ class SpeculativeConfig:
             return None
         if isinstance(value, str):
             value = json.loads(value)
-        known = {k: value[k] for k in ("method", "num_speculative_tokens", "prompt_lookup_max", "prompt_lookup_min")
-                 if k in value}
+        known = {k: value[k] for k in ("method", "num_speculative_tokens", "prompt_lookup_max", "prompt_lookup_min",
+                                       "model", "load_format", "quantization") if k in value}
+        if "model" in known and "method" not in known:
+            known["method"] = "draft_model"
         return cls(**known)
 
 

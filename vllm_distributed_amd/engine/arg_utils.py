@@ -58,7 +58,7 @@ class EngineArgs:
     hip_graph_sizes: Optional[List[int]] = None
     max_capture_size: int = 512
     kv_transfer_config: Optional[Dict[str, Any]] = None
-    speculative_config: Optional[Any] = None          # dict or JSON text: {"method": "ngram", "num_speculative_tokens": 4, ...}
+    speculative_config: Optional[Any] = None          # dict or JSON text: {"method": "ngram", ...} or {"model": <draft>, ...}
     disable_log_stats: bool = False
     enable_lora: bool = False
     max_loras: int = 1
@@ -107,8 +107,9 @@ class EngineArgs:
         g.add_argument("--max-capture-size", type=int, default=512)
         g.add_argument("--kv-transfer-config", type=json.loads, default=None)
         g.add_argument("--speculative-config", type=json.loads, default=None,
-                       help='prompt-lookup speculative decoding, e.g. {"method": "ngram", "num_speculative_tokens": 4, '
-                            '"prompt_lookup_max": 4, "prompt_lookup_min": 2}')
+                       help='speculative decoding: prompt lookup, e.g. {"method": "ngram", "num_speculative_tokens": 4, '
+                            '"prompt_lookup_max": 4, "prompt_lookup_min": 2}, or a draft model with the target\'s '
+                            'vocabulary, e.g. {"model": "<name or path>", "num_speculative_tokens": 4}')
         g.add_argument("--disable-log-stats", action="store_true")
         g.add_argument("--enable-lora", action="store_true", help="serve LoRA adapters next to the base model")
         g.add_argument("--max-loras", type=int, default=1, help="adapters resident (and usable in one batch) at once")

@@ -32,7 +32,7 @@ class Request:
                  "arrival_time", "priority", "status", "output_token_ids", "all_token_ids",
                  "num_computed_tokens", "num_cached_tokens", "stop_reason", "metrics",
                  "block_hashes", "num_preemptions", "max_tokens", "prompt", "num_output_placeholders",
-                 "lora_request", "prompt_logprobs")
+                 "lora_request", "prompt_logprobs", "spec_token_ids")
 
     def __init__(self, request_id: str, prompt_token_ids: List[int],
                  sampling_params: SamplingParams, eos_token_id: Optional[int] = None,
@@ -58,6 +58,8 @@ class Request:
         self.prompt_logprobs: Optional[dict] = {} if sampling_params.prompt_logprobs is not None else None
         # tokens scheduled to be sampled whose values are not known yet (async scheduling)
         self.num_output_placeholders = 0
+        # what the workers' draft model proposed after this request's latest token (draft-model speculation)
+        self.spec_token_ids: List[int] = []
         self.max_tokens = sampling_params.max_tokens
         self.metrics = RequestMetrics(arrival_time=self.arrival_time,
                                       num_prompt_tokens=len(prompt_token_ids))

@@ -88,7 +88,11 @@ class Scheduler:
         self.spec = speculative_config
         self.spec_stats = {"drafted": 0, "accepted": 0}
         self._ngram = None
-        if self.spec is not None:
+        # draft-model speculation: the workers' proposal loop writes draft KV this many positions past
+        # the tokens a step schedules, so every allocation reaches that far
+        self.lookahead = (self.spec.num_speculative_tokens
+                          if self.spec is not None and self.spec.method == "draft_model" else 0)
+        if self.spec is not None and self.spec.method == "ngram":
             import ctypes
             from ..ops.grammar import load as load_core
             lib = load_core()
@@ -128,11 +132,13 @@ class Scheduler:
 
     # ------------------------------------------------------- speculative decoding
     def _propose_drafts(self, req: Request, budget: int) -> List[int]:
-        """Prompt-lookup drafts for a request in plain decode, or [].  Requests whose next-token
-        distribution depends on more than the text (penalties, logit edits, grammars, a seed's
-        draw order) or that report logprobs are decoded one token at a time."""
+        """Drafts for a request in plain decode (looked up in its own text, or what the workers' draft
+        model proposed after its newest token), or [].  Requests whose next-token distribution
+        depends on more than the text (penalties, logit edits, grammars, a seed's draw order) or
+        that report logprobs are decoded one token at a time."""
         sc = self.spec
         sp = req.sampling_params
+        proposed, req.spec_token_ids = req.spec_token_ids, []
         if (req.num_computed_tokens != req.num_tokens - 1 or req.num_output_placeholders
                 or sp.has_penalties or sp.has_logit_adjust or sp.logprobs is not None or sp.seed is not None
                 or sp.pooling is not None or req.lora_request is not None):
@@ -142,6 +148,8 @@ class Scheduler:
             room = min(room, req.max_tokens - len(req.output_token_ids) - 1)
         if room <= 0:
             return []
+        if sc.method == "draft_model":
+            return proposed[:room]
         ids = req.all_token_ids
         arr = np.asarray(ids[-self.SPEC_WINDOW:], dtype=np.int32)
         out = np.empty(room, dtype=np.int32)
@@ -207,10 +215,11 @@ class Scheduler:
             if drafts:
                 n = 1 + len(drafts)
             held = req_blocks.get(req.request_id)
-            if held is not None and req.num_computed_tokens + n <= len(held) * block_size:
+            reach = min(n + self.lookahead, self.max_model_len - req.num_computed_tokens)
+            if held is not None and req.num_computed_tokens + reach <= len(held) * block_size:
                 new_blocks = _NO_BLOCKS          # the common decode step: room left in the last block
             else:
-                new_blocks = self.kv.allocate_slots(req, n)
+                new_blocks = self.kv.allocate_slots(req, reach)
             while new_blocks is None:
                 victim = self._pick_victim(exclude_scheduled=num_scheduled)
                 if victim is None:
@@ -219,7 +228,7 @@ class Scheduler:
                 preempted.append(victim)
                 if victim is req:
                     break
-                new_blocks = self.kv.allocate_slots(req, n)
+                new_blocks = self.kv.allocate_slots(req, reach)
             if new_blocks is None or req.status != RequestStatus.RUNNING:
                 continue
             self._add_cached(cached, req, new_blocks)
@@ -258,7 +267,8 @@ class Scheduler:
                     n = min(n, self.config.long_prefill_token_threshold)
                 if n <= 0:
                     break
-                blocks = self.kv.allocate_slots(req, n + ext, computed_blocks)
+                blocks = self.kv.allocate_slots(
+                    req, min(n + ext + self.lookahead, self.max_model_len - num_cached), computed_blocks)
                 if blocks is None:
                     break
                 if ext:
@@ -379,6 +389,7 @@ class Scheduler:
                     for j, d in enumerate(entries):
                         req.prompt_logprobs.setdefault(first + j, d)
         caching = self.kv.enable_caching
+        proposed = runner_output.draft_token_ids
         windowed = self.kv.window is not None
         fwd_tokens = self.include_new_token_ids
         running_state = RequestStatus.RUNNING
@@ -446,6 +457,8 @@ class Scheduler:
                 m.finished_time = now
                 any_finished = True
                 self._free_request(req)
+            elif proposed is not None:
+                req.spec_token_ids = proposed.get(rid) or []
         if any_finished:             # one pass instead of a list.remove per request
             self.running = [r for r in self.running if r.status == running_state]
         return outputs

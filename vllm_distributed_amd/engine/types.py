@@ -80,6 +80,8 @@ class ModelRunnerOutput:
     finished_recving: Optional[Set[str]] = None
     # worker-side timing in seconds: prepare / forward / sample
     timing: Optional[Dict[str, float]] = None
+    # req_id -> tokens the workers' draft model proposes after the request's newest token
+    draft_token_ids: Optional[Dict[str, List[int]]] = None
 
 
 EMPTY_MODEL_RUNNER_OUTPUT = ModelRunnerOutput()
@@ -96,10 +98,13 @@ class KVCacheSpec:
     # the largest attention window of this worker's layers when EVERY one of them has one (keys further
     # back are never read again and their blocks can go back to the pool), else None
     sliding_window: Optional[int] = None
+    # bytes per block of further caches held over the same blocks (a draft model's layers)
+    extra_bytes_per_block: int = 0
 
     @property
     def bytes_per_block(self) -> int:
-        return 2 * self.num_layers * self.block_size * self.num_kv_heads * self.head_dim * self.dtype_bytes
+        return (2 * self.num_layers * self.block_size * self.num_kv_heads * self.head_dim * self.dtype_bytes
+                + self.extra_bytes_per_block)
 
     @property
     def bytes_per_token(self) -> int:

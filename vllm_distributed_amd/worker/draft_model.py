@@ -1,0 +1,148 @@
+"""Draft-model speculative decoding, worker side.
+
+A second, smaller model with the target's vocabulary lives on every worker next to the target.
+It keeps its own KV cache over the SAME blocks (one block table and one slot mapping serve both
+models), so the scheduler's paging decisions cover it for free.  Per step:
+
+1. *catch up*: the draft model runs the step's scheduled tokens under the target's attention
+   metadata, which writes its KV for exactly the positions the target wrote;
+2. *propose*: starting from the token the target just sampled for each request, it decodes
+   ``num_speculative_tokens`` tokens greedily, one batched decode step per token.  Those steps write
+   draft KV past the scheduled positions; the scheduler allocates that far ahead
+   (``Scheduler.lookahead``), and the next catch-up pass rewrites the same slots with the same
+   tokens (or, after a rejection, with the corrected ones).
+
+The proposals travel back in ``ModelRunnerOutput.draft_token_ids``; the scheduler hands them to the
+next step as ``scheduled_spec_decode_tokens`` and the target verifies them like prompt-lookup drafts
+(vLLM: ``--speculative-config '{"model": ..., "num_speculative_tokens": k}'``).
+"""
+from __future__ import annotations
+
+import copy
+import dataclasses
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..config import ModelConfig, VllmConfig
+from ..logger import init_logger
+from ..models.layers.attention import AttentionMetadata, set_forward_context
+from ..models.loader import load_model
+
+logger = init_logger(__name__)
+
+
+class DraftProposer:
+    def __init__(self, vllm_config: VllmConfig, device: torch.device):
+        sc, mc = vllm_config.speculative_config, vllm_config.model_config
+        fmt = sc.load_format or ("auto" if mc.load_format == "sharded_state" else mc.load_format)
+        dmc = ModelConfig(model=sc.model, dtype=mc.dtype, seed=mc.seed, max_model_len=mc.max_model_len,
+                          load_format=fmt, quantization=sc.quantization)
+        if int(dmc.hf_config["vocab_size"]) != int(mc.hf_config["vocab_size"]):
+            raise ValueError(f"draft model {sc.model!r} has vocabulary {dmc.hf_config['vocab_size']}, "
+                             f"the target {mc.hf_config['vocab_size']}: they must share a tokenizer")
+        cfg = copy.copy(vllm_config)            # no __post_init__: the target's checks do not apply twice
+        cfg.model_config, cfg.speculative_config, cfg.lora_config = dmc, None, None
+        self.model_config = dmc
+        self.model = load_model(cfg, device)
+        self.k = int(sc.num_speculative_tokens)
+        self.device = device
+        self.kv_caches: List[Tuple[torch.Tensor, torch.Tensor]] = []
+        logger.info("draft model %s loaded: %d tokens proposed per step", sc.model, self.k)
+
+    # ------------------------------------------------------------------ KV cache
+    def kv_bytes_per_block(self, block_size: int, dtype_bytes: int) -> int:
+        return sum(2 * block_size * a.num_kv_heads * a.head_dim * dtype_bytes for a in self.model.attention_layers())
+
+    def allocate_kv(self, num_blocks: int, block_size: int, dtype: torch.dtype, fp8: bool) -> None:
+        self.kv_caches = []
+        for attn in self.model.attention_layers():
+            dims = (num_blocks, attn.num_kv_heads, attn.head_dim, block_size)
+            k = torch.zeros(ops.k_cache_shape(*dims), dtype=dtype, device=self.device)
+            v = torch.zeros(ops.v_cache_shape(*dims), dtype=dtype, device=self.device)
+            scales = attn.kv_scales if fp8 else None
+            if scales is not None:
+                scales = tuple(t.to(self.device) for t in scales)
+            attn.bind_kv_cache(k, v, scales)
+            self.kv_caches.append((k, v))
+
+    def release_kv(self) -> None:
+        for attn in self.model.attention_layers():
+            attn.k_cache = attn.v_cache = None
+        self.kv_caches = []
+
+    # ------------------------------------------------------------------ per step
+    def catch_up(self, md: AttentionMetadata, input_ids: torch.Tensor, positions: torch.Tensor) -> None:
+        """Draft KV for the tokens this step ran (prompt chunks, decode tokens, drafts under
+        verification), at the slots the target used."""
+        md = dataclasses.replace(md, decode_workspace=None)     # sized for the target's heads
+        set_forward_context(md, positions)
+        try:
+            self.model(input_ids, positions, None)
+        finally:
+            set_forward_context(None)
+
+    def propose(self, last_tokens: torch.Tensor, start_pos: np.ndarray, block_table: np.ndarray,
+                num_blocks: np.ndarray, block_size: int, max_model_len: int, to_dev) -> List[List[int]]:
+        """``k`` greedy tokens after ``last_tokens[r]`` (which sits at position ``start_pos[r]``) for
+        every row ``r``.  A row stops early where its blocks or the model length end."""
+        r = int(start_pos.shape[0])
+        # positions a row may still write: inside its allocated blocks and below max_model_len - 1
+        # (the token proposed at the last step needs a position of its own)
+        limit = np.minimum(num_blocks.astype(np.int64) * block_size, max_model_len - 1)
+        room = np.clip(limit - start_pos, 0, self.k).astype(np.int64)
+        steps = int(room.max()) if r else 0
+        if steps <= 0:
+            return [[] for _ in range(r)]
+        width = int(min(block_table.shape[1], (int((start_pos + steps).max()) + block_size - 1) // block_size + 1))
+        bt = to_dev(block_table[:, :width])
+        qsl = to_dev(np.arange(r + 1, dtype=np.int32))
+        cur = last_tokens.to(torch.int32)
+        outs = []
+        for i in range(steps):
+            pos = start_pos.astype(np.int64) + i
+            live = i < room
+            safe = np.where(live, pos, 0)
+            slot = np.where(live, block_table[np.arange(r), safe // block_size].astype(np.int64) * block_size
+                            + safe % block_size, -1)
+            seq = (safe + 1).astype(np.int32)
+            md = AttentionMetadata(
+                num_decodes=r, num_decode_tokens=r, num_prefills=0, num_prefill_tokens=0,
+                slot_mapping=to_dev(slot.astype(np.int32)), block_table=bt, seq_lens=to_dev(seq),
+                query_start_loc=qsl, max_query_len=1, max_seq_len=int(seq.max()),
+                max_decode_seq_len=int(seq.max()), decode_workspace=None)
+            positions = to_dev(safe.astype(np.int32))
+            set_forward_context(md, positions)
+            try:
+                hidden = self.model(cur, positions, None)
+            finally:
+                set_forward_context(None)
+            logits = self.model.compute_logits(hidden)
+            cur = logits.float().argmax(dim=-1).to(torch.int32)
+            outs.append(cur)
+        toks = torch.stack(outs, dim=1).cpu().numpy()            # [r, steps]: the one host sync of the loop
+        return [toks[j, :int(room[j])].tolist() for j in range(r)]
+
+
+def accepted_tails(tokens: np.ndarray, counts: Optional[np.ndarray],
+                   drafts: Optional[List[Optional[List[int]]]]) -> Tuple[np.ndarray, np.ndarray]:
+    """Per sampled request: the index (into ``tokens``) of the last token the step keeps, and how many
+    drafts it accepted before it.  Without verification every request keeps its single token."""
+    if counts is None:
+        n = tokens.shape[0]
+        return np.arange(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
+    last, acc = [], []
+    off = 0
+    toks = tokens.tolist()
+    for j, c in enumerate(counts.tolist()):
+        d = drafts[j] if drafts is not None else None
+        n_acc = 0
+        if d:
+            while n_acc < len(d) and toks[off + n_acc] == d[n_acc]:
+                n_acc += 1
+        last.append(off + n_acc)
+        acc.append(n_acc)
+        off += c
+    return np.asarray(last, dtype=np.int64), np.asarray(acc, dtype=np.int64)

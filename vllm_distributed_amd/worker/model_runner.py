@@ -82,7 +82,7 @@ class PendingSample:
     lazy_step_result = True       # executors call .get() / .wait() on results carrying this mark
     __slots__ = ("runner", "step_id", "req_ids", "nreq", "sel", "rows", "gens", "pos", "tokens",
                  "event", "logprobs", "timing", "marks", "_result", "prompt_logprobs", "_lock", "_toks",
-                 "_published", "kv_sent", "kv_recv", "pooled", "counts", "drafts", "_accepted")
+                 "_published", "kv_sent", "kv_recv", "pooled", "counts", "drafts", "_accepted", "proposals")
 
     def __init__(self, runner: "ModelRunner", step_id: int, req_ids: List[str], sel: Optional[np.ndarray],
                  rows: Optional[np.ndarray], pos: Optional[np.ndarray], tokens: Optional[torch.Tensor],
@@ -98,6 +98,7 @@ class PendingSample:
         self.counts: Optional[np.ndarray] = None
         self.drafts: Optional[List[Optional[List[int]]]] = None
         self._accepted: Optional[List[List[int]]] = None
+        self.proposals: Optional[Dict[str, List[int]]] = None      # the draft model's tokens for the next step
         self.kv_sent = self.kv_recv = None
         self._result: Optional[ModelRunnerOutput] = None
         self._toks: Optional[np.ndarray] = None
@@ -157,7 +158,8 @@ class PendingSample:
                                              sampled_token_ids=out_tokens, logprobs=logprobs_out, timing=timing,
                                              prompt_logprobs=self.prompt_logprobs, pooled=pooled,
                                              finished_sending=self.kv_sent or None,
-                                             finished_recving=self.kv_recv or None)
+                                             finished_recving=self.kv_recv or None,
+                                             draft_token_ids=self.proposals)
             return self._result
 
     def publish(self) -> None:
@@ -245,6 +247,7 @@ class ModelRunner:
         self.graph_fallback_reason: Optional[str] = "not captured yet"
         self._static: Dict[str, torch.Tensor] = {}
         self.decode_workspace: Optional[torch.Tensor] = None
+        self.draft = None                 # worker.draft_model.DraftProposer (draft-model speculation)
         self.step_count = 0
         self.report_on_all_ranks = False
         self.comm_stream = None
@@ -283,6 +286,10 @@ class ModelRunner:
         if self.pp.world_size > 1:
             from ..parallel.pipeline import PipelineLink
             self.pp_link = PipelineLink(self.pp, self.device, use_rccl=envs.VDAMD_COMM_BACKEND in ("auto", "rccl"))
+        sc = self.vllm_config.speculative_config
+        if sc is not None and sc.method == "draft_model":
+            from .draft_model import DraftProposer
+            self.draft = DraftProposer(self.vllm_config, self.device)
         if self.vllm_config.lora_config is not None:
             from ..lora import LoRAManager
             self.lora_manager = LoRAManager(self.model, self.vllm_config.lora_config,
@@ -294,9 +301,14 @@ class ModelRunner:
         a = layers[0]
         fp8 = self.vllm_config.cache_config.kv_fp8
         windows = [int(getattr(l, "window", 0) or 0) for l in layers]
+        dtype_bytes = 1 if fp8 else self.model_config.dtype_bytes
+        if self.draft is not None:        # the draft reads every key it ever wrote unless it is windowed too
+            windows += [int(getattr(l, "window", 0) or 0) for l in self.draft.model.attention_layers()]
         return KVCacheSpec(num_layers=len(layers), num_kv_heads=a.num_kv_heads, head_dim=a.head_dim,
-                           block_size=self.block_size, dtype_bytes=1 if fp8 else self.model_config.dtype_bytes,
-                           sliding_window=max(windows) if windows and min(windows) > 0 else None)
+                           block_size=self.block_size, dtype_bytes=dtype_bytes,
+                           sliding_window=max(windows) if windows and min(windows) > 0 else None,
+                           extra_bytes_per_block=(self.draft.kv_bytes_per_block(self.block_size, dtype_bytes)
+                                                  if self.draft is not None else 0))
 
     @torch.inference_mode()
     def profile_run(self) -> None:
@@ -337,6 +349,8 @@ class ModelRunner:
                 scales = tuple(t.to(self.device) for t in scales)
             attn.bind_kv_cache(k, v, scales)
             self.kv_caches.append((k, v))
+        if self.draft is not None:
+            self.draft.allocate_kv(num_blocks, self.block_size, dtype, fp8)
         logger.info("KV cache: %d blocks x %d tokens (%.2f GiB)", num_blocks, self.block_size,
                     num_blocks * spec.bytes_per_block / 2**30)
 
@@ -507,6 +521,11 @@ class ModelRunner:
                     hidden = self._run_eager(md, input_ids, positions, total)
                 finally:
                     set_lora_step(None)
+        if self.draft is not None:
+            with trace_range("step.draft.catch_up"):
+                if graph is not None:                    # the graph ran from its own static inputs
+                    md, input_ids, positions = self._build_metadata(p)
+                self.draft.catch_up(md, input_ids, positions)
 
         # advance computed-token counts (the scheduler did the same when it scheduled)
         self.batch.num_computed[p["rows"]] += p["n_sched"]
@@ -567,6 +586,10 @@ class ModelRunner:
                 host_tokens.copy_(tokens, non_blocking=True)
             else:
                 host_tokens = tokens
+        proposals = None
+        if self.draft is not None and sel is not None:
+            with trace_range("step.draft.propose"):
+                proposals = self._propose_drafts(p, sel, rows_sel, pos_sel, tokens, counts, drafts_sel)
         self.tp.end_step()                # sampling may have gathered over the TP group
         if marks is not None:
             marks.stamp("end")
@@ -584,6 +607,7 @@ class ModelRunner:
                                 logprobs_sel, timing, marks)
         pending.prompt_logprobs = prompt_lps
         pending.counts, pending.drafts = counts, drafts_sel
+        pending.proposals = proposals
         pending.pooled = pooled
         pending.kv_sent, pending.kv_recv = kv_sent, kv_recv
         self._pending.append(pending)
@@ -592,6 +616,23 @@ class ModelRunner:
             return pending if (self._is_output_rank() or report_all) else _Discard(pending)
         out = pending.get()
         return out if (self._is_output_rank() or report_all) else None
+
+    def _propose_drafts(self, p: dict, sel: np.ndarray, rows_sel: np.ndarray, pos_sel: np.ndarray,
+                        tokens: torch.Tensor, counts: Optional[np.ndarray], drafts_sel) -> Dict[str, List[int]]:
+        """Run the draft model's proposal loop after this step's sampled tokens.  The values are read
+        back here (speculative decoding schedules one step at a time, so nothing runs ahead of
+        this sync): which of the step's drafts the target accepted decides where each request's
+        text now ends."""
+        from .draft_model import accepted_tails
+        toks = tokens.cpu().numpy()
+        last_idx, n_acc = accepted_tails(toks, counts, drafts_sel)
+        last = tokens.index_select(0, self._to_dev(last_idx, torch.int64))
+        b = self.batch
+        start = pos_sel.astype(np.int64) + n_acc          # position of the token each request ends on now
+        out = self.draft.propose(last, start, b.block_table[rows_sel], b.num_blocks[rows_sel], self.block_size,
+                                 self.max_model_len, self._to_dev)
+        ids = p["req_ids"]
+        return {ids[i]: d for i, d in zip(sel.tolist(), out) if d}
 
     def _overlap_bounds(self, nreq: int):
         """Micro-batch row ranges for all-reduce/compute overlap, or None."""

@@ -202,6 +202,8 @@ class Worker:
         for attn in self.model_runner.model.attention_layers():
             attn.k_cache = attn.v_cache = None
         self.model_runner.kv_caches = []
+        if self.model_runner.draft is not None:
+            self.model_runner.draft.release_kv()
         self.model_runner.graphs.clear()
         self.model_runner.graph_ctx.clear()
         self.model_runner.graph_sizes = []
