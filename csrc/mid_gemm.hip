@@ -28,129 +28,10 @@ constexpr int MG_BK = 64;            // K elements per tile = 128 bytes per row
 constexpr int MG_THREADS = 512;
 constexpr int MG_WAVES = 8;
 
-
-// ---------------------------------------------------------------------------------------------
-// Epilogue shared by both kernels.  Lane (r16, q) of fragment (j, i) holds
-// y[m0 + 16 i + r16][n0 + 16 j + 4 q .. +4].
-//   ksplit == 1            : convert and store.
-//   ksplit > 1, no counters: store the fp32 slab of this K slice; a reduce kernel follows.
-//   ksplit > 1, counters   : store the slab, then count this workgroup in on the tile's counter; the
-//     workgroup that arrives last adds all slabs of the tile in slice order (so the sum does not
-//     depend on who was last) and stores the result.  Nobody waits for anybody, so the scheme cannot
-//     deadlock whatever the dispatch order, and the second launch disappears.  The last arriver puts
-//     the counter back to zero: the buffer is zeroed once, when it is allocated.  Measured slower than
-//     the second kernel (the write-through slab stores below cost more than the launch they save), so
-//     callers leave it off unless asked.
-// ---------------------------------------------------------------------------------------------
-typedef unsigned int mg_u32x4 __attribute__((ext_vector_type(4)));
-
-template <typename T, int FN, int FM>
-__device__ __forceinline__ void mg_epilogue(f32x4 (&acc)[FN][FM], T* out, long out_stride, float* partial,
-                                            int* counters, int M, int N, int m0, int n0, int ks, int ksplit,
-                                            int tile_id, int r16, int q) {
-  if (ksplit == 1) {
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int m = m0 + 16 * i + r16;
-      if (m >= M) continue;
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int n = n0 + 16 * j + 4 * q;
-        if (n >= N) continue;                  // N % 16 == 0: a fragment column group is all in or all out
-        typename Vec4<T>::type o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (T)acc[j][i][r];
-        *reinterpret_cast<typename Vec4<T>::type*>(out + (long)m * out_stride + n) = o;
-      }
-    }
-    return;
-  }
-  if (counters == nullptr) {
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int m = m0 + 16 * i + r16;
-      if (m >= M) continue;
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int n = n0 + 16 * j + 4 * q;
-        if (n >= N) continue;
-        *reinterpret_cast<f32x4*>(partial + ((size_t)ks * M + m) * N + n) = acc[j][i];
-      }
-    }
-    return;
-  }
-  // Slab traffic of the in-launch reduction is device-scope (sc1) buffer stores and loads: the L2 of
-  // an XCD is not coherent with the other seven, and the alternative - release / acquire fences - would
-  // write back and invalidate whole caches once per workgroup.  Out-of-tile lanes aim past the end of
-  // the descriptor, where the hardware drops stores and returns zero for loads.
-  constexpr int SC1 = 16;
-  const unsigned pbytes = (unsigned)((size_t)ksplit * M * N * 4);      // < 4 GiB: checked by the host
-  const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(partial, 0, (int)pbytes, 0x00020000);
-  const unsigned slab = (unsigned)((size_t)M * N * 4);
-  unsigned off[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int m = m0 + 16 * i + r16, n = n0 + 16 * j + 4 * q;
-      off[i][j] = (m < M && n < N) ? (unsigned)(((size_t)m * N + n) * 4) : pbytes;
-    }
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mg_u32x4, acc[j][i]), prsrc,
-                                             off[i][j] == pbytes ? pbytes : off[i][j] + ks * slab, 0, SC1);
-  __shared__ int s_last;
-  __syncthreads();                             // every thread's slab stores have completed at device scope
-  if (threadIdx.x == 0) {
-    const int old = __hip_atomic_fetch_add(counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = old == ksplit - 1;
-    if (old == ksplit - 1) __hip_atomic_store(counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (!s_last) return;
-  // 8 fragments x 4 slices = 32 independent loads in flight per lane; slices past ksplit aim past the end
-  // of the descriptor and come back as zeros, so the adds need no branch and keep slice order
-  constexpr int FR = FM * FN, GROUP = FR < 8 ? FR : 8;
-#pragma unroll
-  for (int g0 = 0; g0 < FR; g0 += GROUP) {
-    f32x4 sum[GROUP];
-#pragma unroll
-    for (int f = 0; f < GROUP; ++f) sum[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < ksplit; k0 += 4) {
-      f32x4 v[GROUP][4];
-#pragma unroll
-      for (int f = 0; f < GROUP; ++f) {
-        const unsigned o = off[(g0 + f) / FN][(g0 + f) % FN];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-          v[f][kk] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                   prsrc, (o == pbytes || k0 + kk >= ksplit) ? pbytes : o + (k0 + kk) * slab,
-                                                   0, SC1));
-      }
-#pragma unroll
-      for (int f = 0; f < GROUP; ++f)
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) sum[f] += v[f][kk];
-    }
-#pragma unroll
-    for (int f = 0; f < GROUP; ++f) {
-      const int i = (g0 + f) / FN, j = (g0 + f) % FN;
-      const int m = m0 + 16 * i + r16, n = n0 + 16 * j + 4 * q;
-      if (m >= M || n >= N) continue;
-      typename Vec4<T>::type o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = (T)sum[f][r];
-      *reinterpret_cast<typename Vec4<T>::type*>(out + (long)m * out_stride + n) = o;
-    }
-  }
-}
-
 template <typename T, int BM, int FN>
 __global__ __launch_bounds__(MG_THREADS) void mid_gemm_kernel(
-    const T* x, long x_stride, const T* w, long w_stride, T* out, long out_stride, float* partial, int* counters,
-    int M, int N, int K, int ksplit) {
+    const T* x, long x_stride, const T* w, long w_stride, T* out, long out_stride, float* partial, int M, int N,
+    int K, int ksplit) {
   // x and w are deliberately not __restrict__: loads from provably unaliased read-only memory may be
   // moved across the barriers, and the pipeline below depends on WHEN each load is issued.
   using V8 = typename Vec8<T>::type;
@@ -265,8 +146,25 @@ __global__ __launch_bounds__(MG_THREADS) void mid_gemm_kernel(
     }
   }
 
-  mg_epilogue<T, FN, FM>(acc, out, out_stride, partial, counters, M, N, m0, n0, ks, ksplit,
-                         (int)blockIdx.y * ntn + tn, r16, q);
+  // ---- epilogue: lane (r16, q) of fragment (j, i) holds y[m0 + 16 i + r16][n0 + 16 j + 4 q .. +4]
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int m = m0 + 16 * i + r16;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int n = n0 + 16 * j + 4 * q;
+      if (n >= N) continue;                  // N % 16 == 0: a fragment column group is all in or all out
+      if (ksplit == 1) {
+        typename Vec4<T>::type o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (T)acc[j][i][r];
+        *reinterpret_cast<typename Vec4<T>::type*>(out + (long)m * out_stride + n) = o;
+      } else {
+        *reinterpret_cast<f32x4*>(partial + ((size_t)ks * M + m) * N + n) = acc[j][i];
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -294,8 +192,8 @@ __device__ __forceinline__ void asm_load2(V8& a, V8& b, const void* p) {
 
 template <typename T, int BM, int FN>
 __global__ __launch_bounds__(MG_THREADS) void mid_gemm_deep_kernel(
-    const T* x, long x_stride, const T* w, long w_stride, T* out, long out_stride, float* partial, int* counters,
-    int M, int N, int K, int ksplit) {
+    const T* x, long x_stride, const T* w, long w_stride, T* out, long out_stride, float* partial, int M, int N,
+    int K, int ksplit) {
   using V8 = typename Vec8<T>::type;
   constexpr int BN = MG_WAVES * 16 * FN;
   constexpr int FM = BM / 16;
@@ -403,8 +301,25 @@ __global__ __launch_bounds__(MG_THREADS) void mid_gemm_deep_kernel(
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stray tail prefetches must not outlive the registers / LDS
-  mg_epilogue<T, FN, FM>(acc, out, out_stride, partial, counters, M, N, m0, n0, ks, ksplit,
-                         (int)blockIdx.y * ntn + tn, r16, q);
+
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int m = m0 + 16 * i + r16;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int n = n0 + 16 * j + 4 * q;
+      if (n >= N) continue;
+      if (ksplit == 1) {
+        typename Vec4<T>::type o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (T)acc[j][i][r];
+        *reinterpret_cast<typename Vec4<T>::type*>(out + (long)m * out_stride + n) = o;
+      } else {
+        *reinterpret_cast<f32x4*>(partial + ((size_t)ks * M + m) * N + n) = acc[j][i];
+      }
+    }
+  }
 }
 
 template <typename T>
@@ -423,25 +338,25 @@ __global__ void mid_reduce_kernel(T* __restrict__ out, long out_stride, const fl
 }
 
 template <typename T, int BM, int FN>
-int launch(const void* x, long xs, const void* w, long ws, void* out, long os, void* partial, int* counters, int M,
-           int N, int K, int ksplit, int variant, hipStream_t st) {
+int launch(const void* x, long xs, const void* w, long ws, void* out, long os, void* partial, int M, int N, int K,
+           int ksplit, int variant, hipStream_t st) {
   constexpr int BN = MG_WAVES * 16 * FN;
   const int ntn = (N + BN - 1) / BN;
   dim3 grid(ntn * ksplit, (M + BM - 1) / BM);
   if constexpr (BM >= 64 && FN <= 2) {
     if (variant == 1) {
       mid_gemm_deep_kernel<T, BM, FN><<<grid, MG_THREADS, 0, st>>>((const T*)x, xs, (const T*)w, ws, (T*)out, os,
-                                                                   (float*)partial, counters, M, N, K, ksplit);
+                                                                   (float*)partial, M, N, K, ksplit);
     } else {
       mid_gemm_kernel<T, BM, FN><<<grid, MG_THREADS, 0, st>>>((const T*)x, xs, (const T*)w, ws, (T*)out, os,
-                                                              (float*)partial, counters, M, N, K, ksplit);
+                                                              (float*)partial, M, N, K, ksplit);
     }
   } else {
     mid_gemm_kernel<T, BM, FN><<<grid, MG_THREADS, 0, st>>>((const T*)x, xs, (const T*)w, ws, (T*)out, os,
-                                                            (float*)partial, counters, M, N, K, ksplit);
+                                                            (float*)partial, M, N, K, ksplit);
   }
   HIP_LAUNCH_CHECK();
-  if (ksplit > 1 && counters == nullptr) {
+  if (ksplit > 1) {
     const long n = (long)M * (N / 4);
     mid_reduce_kernel<T><<<(unsigned)((n + 255) / 256), 256, 0, st>>>((T*)out, os, (const float*)partial, M, N,
                                                                      ksplit);
@@ -451,11 +366,11 @@ int launch(const void* x, long xs, const void* w, long ws, void* out, long os, v
 }
 
 template <typename T>
-int dispatch(const void* x, long xs, const void* w, long ws, void* out, long os, void* partial, int* counters, int M,
-             int N, int K, int ksplit, int bm, int bn, int variant, hipStream_t st) {
+int dispatch(const void* x, long xs, const void* w, long ws, void* out, long os, void* partial, int M, int N, int K,
+             int ksplit, int bm, int bn, int variant, hipStream_t st) {
 #define MG_CASE(BM_, FN_)                                                                       \
   if (bm == BM_ && bn == MG_WAVES * 16 * FN_)                                                   \
-    return launch<T, BM_, FN_>(x, xs, w, ws, out, os, partial, counters, M, N, K, ksplit, variant, st);
+    return launch<T, BM_, FN_>(x, xs, w, ws, out, os, partial, M, N, K, ksplit, variant, st);
   MG_CASE(256, 2) MG_CASE(256, 1) MG_CASE(128, 2) MG_CASE(128, 1) MG_CASE(64, 2) MG_CASE(64, 4)
 #undef MG_CASE
   return -4;
@@ -465,27 +380,19 @@ int dispatch(const void* x, long xs, const void* w, long ws, void* out, long os,
 
 // out[M][N] = x[M][K] . w[N][K]^T.  K % 64 == 0, N % 16 == 0; strides in elements, multiples of 8;
 // pointers 16-byte aligned.  (bm, bn) is the workgroup tile: (256, 128|256), (128, 128|256), (64, 256|512).
-// partial holds ksplit * M * N floats when ksplit > 1.  counters (optional): num_counters zeroed ints, one per
-// output tile; with them the K slices are summed by the last workgroup of each tile inside the launch
-// (the kernel leaves them zeroed), without them by a second kernel.  variant 0: x staged through registers, W two tiles
+// partial holds ksplit * M * N floats when ksplit > 1.  variant 0: x staged through registers, W two tiles
 // ahead; variant 1: x by LDS-DMA, W four tiles ahead (tiles with bn <= 256).
 VDAMD_API int vdamd_mid_gemm(void* out, long out_stride, const void* x, long x_stride, const void* w, long w_stride,
-                             void* partial, int* counters, int num_counters, int M, int N, int K, int ksplit,
-                             int bm, int bn, int variant, int dtype, void* stream) {
+                             void* partial, int M, int N, int K, int ksplit, int bm, int bn, int variant, int dtype,
+                             void* stream) {
   if (M <= 0) return 0;
   if (K % MG_BK || N % 16 || ksplit < 1 || ksplit > K / MG_BK) return -1;
   if (ksplit > 1 && partial == nullptr) return -2;
   if ((x_stride | w_stride) % 8 || out_stride % 4) return -5;
-  if (bm <= 0 || bn <= 0) return -4;
-  if (ksplit == 1 || (long)((N + bn - 1) / bn) * ((M + bm - 1) / bm) > num_counters ||
-      (size_t)ksplit * M * N * 4 >= ((size_t)1 << 32) - 64)
-    counters = nullptr;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16)
-    return dispatch<bf16_t>(x, x_stride, w, w_stride, out, out_stride, partial, counters, M, N, K, ksplit, bm, bn,
-                            variant, st);
+    return dispatch<bf16_t>(x, x_stride, w, w_stride, out, out_stride, partial, M, N, K, ksplit, bm, bn, variant, st);
   if (dtype == DT_F16)
-    return dispatch<f16_t>(x, x_stride, w, w_stride, out, out_stride, partial, counters, M, N, K, ksplit, bm, bn,
-                           variant, st);
+    return dispatch<f16_t>(x, x_stride, w, w_stride, out, out_stride, partial, M, N, K, ksplit, bm, bn, variant, st);
   return -3;
 }

@@ -663,13 +663,6 @@ def test_mid_gemm_matches_fp32(dtype, m, n, k, pad):
             for variant in ((0, 1) if bn <= 256 else (0,)):      # register-staged x / LDS-DMA x with deep W prefetch
                 got = hip.mid_gemm(x, w, bm=bm, bn=bn, ksplit=ks, variant=variant)
                 torch.testing.assert_close(got.float(), ref, **tol)
-                if ks > 1:
-                    # K slices summed by the second kernel (the default) and by the last workgroup of each tile
-                    # inside the launch: both add the slabs in slice order, so they agree to the bit
-                    one = hip.mid_gemm(x, w, bm=bm, bn=bn, ksplit=ks, variant=variant, fused_reduce=True)
-                    assert torch.equal(got, one)
-    # every launch leaves the tile arrival counters at zero
-    assert int(hip._mid_counter_buffer(x.device).abs().sum()) == 0
     # strided output (a slice of a wider buffer), as the fused-collective path uses
     wide = torch.zeros(m, n + 64, device=DEV, dtype=dtype)
     hip.mid_gemm(x, w, out=wide[:, :n])

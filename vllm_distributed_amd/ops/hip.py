@@ -35,7 +35,7 @@ def load() -> ctypes.CDLL:
         "vdamd_layer_norm": [P, P, P, P, F, I, I, I, P],
         "vdamd_silu_and_mul": [P, P, L, I, I, P],
         "vdamd_embedding": [P, P, P, I, I, I, I, I, P],
-        "vdamd_mid_gemm": [P, L, P, L, P, L, P, P, I, I, I, I, I, I, I, I, I, P],
+        "vdamd_mid_gemm": [P, L, P, L, P, L, P, I, I, I, I, I, I, I, I, P],
         "vdamd_stream_gemm": [P, L, P, L, P, L, P, P, L, I, I, I, I, I, I, I, I, I, P],
         "vdamd_big_gemm": [P, L, P, L, P, L, P, L, I, I, I, I, I, I, P],
         "vdamd_rope_cache": [P, P, P, P, L, L, L, P, P, P, P, I, I, I, I, I, I, P, P, F, I, I, P, P, P],
@@ -659,31 +659,9 @@ def mid_profitable(m: int, n: int, k: int) -> bool:
     return m >= 48 and n <= 8192 and k >= 8192
 
 
-# Tile arrival counters of the in-launch split-K reduction: zeroed once, left zeroed by every launch.  One
-# buffer per (device, stream): launches on one stream run one after the other, two streams must not share.
-# Off by default: the slabs then have to move as device-scope write-through stores, which lose the L2's
-# write combining, and the launch comes out 10-20 % slower than with the second kernel
-# (profiles/r2_mid_gemm_fused_reduce.txt).
-MID_COUNTERS = 4096
-MID_FUSED_REDUCE = os.environ.get("VDAMD_MID_GEMM_FUSED_REDUCE", "0") == "1"
-_mid_counters: dict = {}
-
-
-def _mid_counter_buffer(device: torch.device) -> torch.Tensor:
-    key = (device.index, _stream())
-    buf = _mid_counters.get(key)
-    if buf is None:
-        buf = torch.zeros(MID_COUNTERS, dtype=torch.int32, device=device)
-        _mid_counters[key] = buf
-    return buf
-
-
 def mid_gemm(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, ksplit: Optional[int] = None,
-             bm: Optional[int] = None, bn: Optional[int] = None, variant: Optional[int] = None,
-             fused_reduce: Optional[bool] = None) -> torch.Tensor:
-    """``x [M<=512, K] @ w [N, K]^T`` with W streamed once and K split over the chip.  The K slices are
-    summed by a second kernel (the default) or, with ``fused_reduce``, inside the launch by the last
-    workgroup of each tile."""
+             bm: Optional[int] = None, bn: Optional[int] = None, variant: Optional[int] = None) -> torch.Tensor:
+    """``x [M<=512, K] @ w [N, K]^T`` with W streamed once and K split over the chip."""
     assert mid_supported(x, w), (x.shape, x.stride(), w.shape, w.stride(), x.dtype)
     m, k = x.shape
     n = w.shape[0]
@@ -700,13 +678,9 @@ def mid_gemm(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = Non
         out = torch.empty((m, n), dtype=x.dtype, device=x.device)
     assert out.shape == (m, n) and out.dtype == x.dtype and out.stride(1) == 1 and out.data_ptr() % 8 == 0
     partial = torch.empty(ksplit * m * n, dtype=torch.float32, device=x.device) if ksplit > 1 else None
-    if fused_reduce is None:
-        fused_reduce = MID_FUSED_REDUCE
-    counters = _mid_counter_buffer(x.device) if ksplit > 1 and fused_reduce else None
     _check(_LIB.vdamd_mid_gemm(out.data_ptr(), out.stride(0), x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
-                               None if partial is None else partial.data_ptr(),
-                               None if counters is None else counters.data_ptr(), MID_COUNTERS, m, n, k, ksplit,
-                               bm, bn, variant, _dt(x), _stream()), "mid_gemm")
+                               None if partial is None else partial.data_ptr(), m, n, k, ksplit, bm, bn,
+                               variant, _dt(x), _stream()), "mid_gemm")
     return out
 
 
