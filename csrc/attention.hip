@@ -698,8 +698,18 @@ VDAMD_API int vdamd_paged_attention_decode(void* out, float* workspace, const vo
                                         seq_lens, scale, B, Hq, Hkv, block_size, num_splits, out_stride, nullptr, \
                                         nullptr, window, s);                                                      \
   } while (0)
-  if (dtype == DT_BF16) { if (D == 128) CASE(bf16_t, 128); if (D == 64) CASE(bf16_t, 64); }
-  if (dtype == DT_F16) { if (D == 128) CASE(f16_t, 128); if (D == 64) CASE(f16_t, 64); }
+  if (dtype == DT_BF16) {
+    if (D == 128) CASE(bf16_t, 128);
+    if (D == 64) CASE(bf16_t, 64);
+    if (D == 96) CASE(bf16_t, 96);
+    if (D == 256) CASE(bf16_t, 256);
+  }
+  if (dtype == DT_F16) {
+    if (D == 128) CASE(f16_t, 128);
+    if (D == 64) CASE(f16_t, 64);
+    if (D == 96) CASE(f16_t, 96);
+    if (D == 256) CASE(f16_t, 256);
+  }
 #undef CASE
   return -2;
 }
@@ -722,8 +732,18 @@ VDAMD_API int vdamd_paged_attention_prefill(void* out, const void* q, long q_str
                                          query_start_loc, seq_lens, scale, num_seqs, max_q_len, Hq, Hkv,          \
                                          block_size, out_stride, nullptr, nullptr, window, s);                    \
   } while (0)
-  if (dtype == DT_BF16) { if (D == 128) CASE(bf16_t, 128); if (D == 64) CASE(bf16_t, 64); }
-  if (dtype == DT_F16) { if (D == 128) CASE(f16_t, 128); if (D == 64) CASE(f16_t, 64); }
+  if (dtype == DT_BF16) {
+    if (D == 128) CASE(bf16_t, 128);
+    if (D == 64) CASE(bf16_t, 64);
+    if (D == 96) CASE(bf16_t, 96);
+    if (D == 256) CASE(bf16_t, 256);
+  }
+  if (dtype == DT_F16) {
+    if (D == 128) CASE(f16_t, 128);
+    if (D == 64) CASE(f16_t, 64);
+    if (D == 96) CASE(f16_t, 96);
+    if (D == 256) CASE(f16_t, 256);
+  }
 #undef CASE
   return -2;
 }

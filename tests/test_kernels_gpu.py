@@ -70,7 +70,7 @@ def test_embedding_vocab_shard():
     assert got[0].abs().sum() == 0 and got[3].abs().sum() > 0
 
 
-@pytest.mark.parametrize("hq,hkv,d,bs", [(32, 8, 128, 64), (8, 8, 64, 16), (12, 2, 128, 32)])
+@pytest.mark.parametrize("hq,hkv,d,bs", [(32, 8, 128, 64), (8, 8, 64, 16), (12, 2, 128, 32), (32, 32, 96, 32), (8, 4, 256, 16)])
 def test_rope_and_cache_matches_reference(hq, hkv, d, bs):
     T, nb = 37, 12
     qkv = _rand(T, (hq + 2 * hkv) * d)
@@ -88,7 +88,7 @@ def test_rope_and_cache_matches_reference(hq, hkv, d, bs):
     torch.testing.assert_close(vc.float(), vc_ref, rtol=0, atol=0)
 
 
-@pytest.mark.parametrize("hq,hkv,d,bs", [(32, 8, 128, 64), (8, 8, 64, 16), (12, 1, 128, 32)])
+@pytest.mark.parametrize("hq,hkv,d,bs", [(32, 8, 128, 64), (8, 8, 64, 16), (12, 1, 128, 32), (8, 4, 256, 16)])
 def test_rope_and_cache_with_per_head_rms_norm(hq, hkv, d, bs):
     """Qwen3: q and k heads are RMS-normalised before the rotation, in the same kernel."""
     T, nb = 41, 12
@@ -145,7 +145,7 @@ def _make_paged(seq_lens, hkv, d, bs, dtype=torch.bfloat16, extra_blocks=3):
 
 
 @pytest.mark.parametrize("hq,hkv,d,bs", [(32, 8, 128, 64), (64, 8, 128, 64), (12, 12, 64, 16),
-                                         (24, 2, 128, 32), (4, 2, 64, 128)])
+                                         (24, 2, 128, 32), (4, 2, 64, 128), (32, 32, 96, 32), (8, 4, 256, 16)])
 @pytest.mark.parametrize("splits", [None, 0, 1, 4])          # 0 = the one-wave-per-sequence kernel
 def test_paged_attention_decode(hq, hkv, d, bs, splits):
     from vllm_distributed_amd.ops import hip
@@ -190,7 +190,7 @@ def test_decode_softmax_rescale_branch_with_spiked_key():
         torch.testing.assert_close(got.float(), ref, rtol=2e-2, atol=2e-2)
 
 
-@pytest.mark.parametrize("hq,hkv,d,bs", [(32, 8, 128, 64), (8, 8, 64, 16), (6, 2, 128, 32)])
+@pytest.mark.parametrize("hq,hkv,d,bs", [(32, 8, 128, 64), (8, 8, 64, 16), (6, 2, 128, 32), (32, 32, 96, 32), (8, 4, 256, 16)])
 def test_paged_attention_prefill_varlen_and_chunked(hq, hkv, d, bs):
     # (q_len, seq_len): full prompts, a chunk continuing a cached prefix, a single token
     cases = [(5, 5), (128, 128), (130, 130), (40, 300), (1, 77), (257, 600), (33, 33)]
@@ -499,7 +499,7 @@ def _fp8_caches(seq_lens, hkv, d, bs):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("hq,hkv,d,bs", [(32, 8, 128, 64), (64, 8, 128, 64), (12, 12, 64, 16), (24, 2, 128, 32)])
+@pytest.mark.parametrize("hq,hkv,d,bs", [(32, 8, 128, 64), (64, 8, 128, 64), (12, 12, 64, 16), (24, 2, 128, 32), (32, 32, 96, 32), (8, 4, 256, 16)])
 @pytest.mark.parametrize("splits", [None, 0, 1, 4])
 def test_paged_attention_decode_fp8_cache(dtype, hq, hkv, d, bs, splits):
     from vllm_distributed_amd.ops import hip
@@ -521,7 +521,7 @@ def test_paged_attention_decode_fp8_cache(dtype, hq, hkv, d, bs, splits):
     torch.testing.assert_close(got1.float(), ref1, rtol=2e-2, atol=2e-2)
 
 
-@pytest.mark.parametrize("hq,hkv,d,bs", [(32, 8, 128, 64), (8, 8, 64, 16), (6, 2, 128, 32)])
+@pytest.mark.parametrize("hq,hkv,d,bs", [(32, 8, 128, 64), (8, 8, 64, 16), (6, 2, 128, 32), (32, 32, 96, 32), (8, 4, 256, 16)])
 def test_paged_attention_prefill_fp8_cache(hq, hkv, d, bs):
     cases = [(5, 5), (128, 128), (130, 130), (40, 300), (1, 77), (257, 600), (33, 33)]
     seq_lens = [c[1] for c in cases]

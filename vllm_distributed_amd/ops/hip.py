@@ -85,7 +85,8 @@ def _dt(t: torch.Tensor) -> int:
 
 
 def supports_head_dim(d: int) -> bool:
-    return d in (64, 128)
+    """Head sizes the attention kernels are instantiated for (96: Phi-3-mini, 256: Gemma)."""
+    return d in (64, 96, 128, 256)
 
 
 def _half(t: torch.Tensor) -> bool:
@@ -195,7 +196,8 @@ def rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping
                    head_dim, q_norm_weight=None, k_norm_weight=None, norm_eps: float = 0.0,
                    kv_scales=None) -> torch.Tensor:
     """``q_norm_weight`` / ``k_norm_weight``: RMSNorm each q and k head before rotating (Qwen3)."""
-    if not _half(qkv):
+    lanes = head_dim // 16          # the fused q/k norm reduces over an aligned power-of-two lane group
+    if not _half(qkv) or head_dim % 16 or (q_norm_weight is not None and (lanes & (lanes - 1) or lanes > 64)):
         from . import torch_ref
         return torch_ref.rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping,
                                         num_heads, num_kv_heads, head_dim, q_norm_weight, k_norm_weight, norm_eps,
