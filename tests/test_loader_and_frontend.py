@@ -477,6 +477,57 @@ def test_blocks_behind_the_sliding_window_return_to_the_pool():
     pstate.destroy_model_parallel()
 
 
+def test_fp8_block_scaled_checkpoint_loads_as_its_dequantised_twin(tmp_path):
+    """An e4m3 checkpoint with 128 x 128 block scales (``weight_scale_inv``), per-channel and per-tensor
+    scales (``weight_scale``) loads to exactly the model its widened weights describe, and the config's
+    ``quant_method: fp8`` selects the W8A8 path on its own."""
+    import json
+    from safetensors.torch import save_file
+    from vllm_distributed_amd.models.loader import dummy_weights_iterator, fp8_checkpoint_dequantize
+    fp8 = torch.float8_e4m3fn
+    mc = ModelConfig(model="llama-tiny", dtype="float32", load_format="dummy")
+    q8, wide = {}, {}
+    for i, (name, w) in enumerate(dummy_weights_iterator(mc, torch.device("cpu"))):
+        if not (name.endswith("_proj.weight") and w.dim() == 2):
+            q8[name] = wide[name] = w.contiguous()
+            continue
+        n, k = w.shape
+        kind = i % 3
+        if kind == 0:        # blocks of 128 x 128 (ragged at the edges)
+            gn, gk = -(-n // 128), -(-k // 128)
+            pad = torch.zeros(gn * 128, gk * 128)
+            pad[:n, :k] = w
+            amax = pad.view(gn, 128, gk, 128).abs().amax(dim=(1, 3)).clamp(min=1e-8)
+            scale = amax / 448.0
+            full = scale.repeat_interleave(128, 0)[:n].repeat_interleave(128, 1)[:, :k]
+            sname = name + "_scale_inv"
+        elif kind == 1:      # one scale per output channel
+            scale = (w.abs().amax(dim=1, keepdim=True).clamp(min=1e-8) / 448.0)
+            full, sname = scale, name + "_scale"
+        else:                # one scale for the tensor
+            scale = (w.abs().amax().clamp(min=1e-8) / 448.0).reshape(1)
+            full, sname = scale, name + "_scale"
+        q = (w / full).clamp(-448, 448).to(fp8)
+        q8[name], q8[sname] = q, scale.float().contiguous()
+        wide[name] = fp8_checkpoint_dequantize(q, scale, torch.float32)
+        torch.testing.assert_close(wide[name], w, rtol=0.07, atol=1e-3)
+    outs = {}
+    for tag, tensors, extra in (("fp8", q8, {"quantization_config": {"quant_method": "fp8", "weight_block_size": [128, 128]}}),
+                                ("wide", wide, {})):
+        d = tmp_path / tag
+        d.mkdir()
+        save_file({k: v.contiguous() for k, v in tensors.items()}, str(d / "model.safetensors"))
+        (d / "config.json").write_text(json.dumps(dict(mc.hf_config, **extra)))
+        llm = LLM(model=str(d), device="cpu", dtype="float32", max_model_len=128, block_size=16,
+                  num_gpu_blocks_override=32, quantization=None if tag == "fp8" else "fp8")
+        assert llm.engine.vllm_config.model_config.quantization == "fp8"
+        outs[tag] = [o.outputs[0].token_ids for o in llm.generate(
+            [[5, 9, 200, 17, 33], list(range(10, 40))], SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True))]
+        llm.shutdown()
+        pstate.destroy_model_parallel()
+    assert outs["fp8"] == outs["wide"]
+
+
 def test_gptq_checkpoint_is_the_same_model_as_its_awq_twin(tmp_path):
     """A 4-bit GPTQ checkpoint holds the integers, zero points and scales of an AWQ one in another
     packing: writing the dummy AWQ model's tensors in GPTQ form (rows packed eight to a word, zero

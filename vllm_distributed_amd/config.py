@@ -200,6 +200,10 @@ class ModelConfig:
                 self.quantization = "awq"        # same integers, repacked at load (models/loader._gptq_as_awq)
             elif "nvfp4" in str(q.get("format", "")).lower() or str(q.get("quant_algo", "")).upper() == "NVFP4":
                 self.quantization = "nvfp4"      # compressed-tensors / modelopt exports
+            elif q.get("quant_method") == "fp8" or "float-quantized" in str(q.get("format", "")).lower():
+                # e4m3 weights with block / channel / tensor scales: widened by the loader, then
+                # quantised per output channel for the W8A8 kernels like any ``--quantization fp8`` model
+                self.quantization = "fp8"
         if self.load_format == "auto" and resolve_model_path(self.model) is None:
             if not is_bundled_architecture_name(self.model):
                 # a typo, an id that is not in the cache, an unmounted volume: serving random

@@ -313,8 +313,23 @@ def safetensors_weights_iterator(path: str, dtype: torch.dtype,
     for fn in files:
         with safe_open(fn, framework="pt", device="cpu") as f:
             keys = list(f.keys())
+            keyset = set(keys)
             awq_done = set()
             for k in keys:
+                # FP8 checkpoints (one e4m3 byte per weight + fp32 scales: per 128 x 128 block as
+                # ``weight_scale_inv``, or per tensor / per output channel as ``weight_scale``) are widened
+                # here; ``--quantization fp8`` then re-quantises per channel for the W8A8 kernels
+                if k.endswith((".weight_scale_inv", ".weight_scale", ".input_scale")) and \
+                        k[:k.rindex(".")] + ".weight" in keyset and not keep_quantized:
+                    continue
+                if k.endswith(".weight") and not keep_quantized and \
+                        (k + "_scale_inv" in keyset or k + "_scale" in keyset):
+                    if want is not None and not want(k):
+                        continue
+                    yield k, fp8_checkpoint_dequantize(
+                        f.get_tensor(k), f.get_tensor(k + "_scale_inv" if k + "_scale_inv" in keyset else k + "_scale"),
+                        dtype)
+                    continue
                 if keep_quantized:
                     if want is None or want(k):
                         if k.endswith(".scales"):
@@ -338,6 +353,28 @@ def safetensors_weights_iterator(path: str, dtype: torch.dtype,
                 # not read yet: the weight loaders narrow it to this rank's shard first, and only
                 # that hyper-rectangle is then read from the file
                 yield k, LazyTensor(f, k)
+
+
+def fp8_checkpoint_dequantize(w: torch.Tensor, scale: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """``w [N, K]`` e4m3 times its scales: a scalar, one per output row (``[N]`` / ``[N, 1]``), or one per
+    block of a regular grid (``[ceil(N / bn), ceil(K / bk)]``, block sizes inferred from the shapes:
+    128 x 128 in the published checkpoints)."""
+    wf = w.float()
+    s = scale.float()
+    if s.numel() == 1:
+        return (wf * s.reshape(())).to(dtype)
+    n, k = wf.shape
+    if s.dim() <= 1 or s.shape[-1] == 1:
+        if s.numel() != n:
+            raise ValueError(f"fp8 weight [{n}, {k}] with {s.numel()} scales")
+        return (wf * s.reshape(n, 1)).to(dtype)
+    gn, gk = s.shape
+    bn, bk = -(-n // gn), -(-k // gk)
+    for b in (bn, bk):          # block sizes are powers of two in every published layout: round up to one
+        if b & (b - 1):
+            raise ValueError(f"fp8 weight [{n}, {k}] with a [{gn}, {gk}] scale grid: blocks of {bn} x {bk}?")
+    full = s.repeat_interleave(bn, dim=0)[:n].repeat_interleave(bk, dim=1)[:, :k]
+    return (wf * full).to(dtype)
 
 
 def _gptq_as_awq(items: Iterable[Tuple[str, torch.Tensor]], mc: ModelConfig) -> Iterator[Tuple[str, torch.Tensor]]:
