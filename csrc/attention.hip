@@ -542,35 +542,53 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
           sc[u] = mfma32(a, qf[s], sc[u]);
         }
       }
-      // scale + causal mask (only tiles that straddle the diagonal need the compare)
+      // Only tiles that straddle the diagonal (or a window edge) need masking.  The others - nearly all
+      // of a long sequence - take the short path: the running max is found on the raw scores (the scale
+      // is positive) and the scale rides in the exponent's multiply-add, three VALU operations and one
+      // exponential per score instead of eight and one.
       const bool need_mask = base + KT - 1 > min(ctx + t_wave, seq_len - 1) || base < wave_lo_max;
-      float tmax = NEG_BIG;
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = sc[u][r] * sl2e;
-          if (need_mask) {
-            const int key = base + 32 * u + 16 * (r >> 3) + 8 * h + (r & 7);
-            v = (key <= q_hi && key >= q_lo) ? v : NEG_BIG;
-          }
-          sc[u][r] = v;
-          tmax = fmaxf(tmax, v);
-        }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float m_new = fmaxf(m_run, tmax);
-      const float alpha = exp2f(m_run - m_new);
-      float psum = 0.f;
+      float m_new, alpha, psum = 0.f;
       V pf[4];
+      if (!need_mask) {
+        float rmax = fmaxf(sc[0][0], sc[1][0]);
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+        for (int r = 1; r < 16; ++r) rmax = fmaxf(rmax, fmaxf(sc[0][r], sc[1][r]));
+        rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+        m_new = fmaxf(m_run, rmax * sl2e);
+        alpha = exp2f(m_run - m_new);
+        const float nm = -m_new;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          // (a query whose window starts above this tile has no visible key in it: see attend_loaded)
-          const float e = sc[u][r] <= 0.5f * NEG_BIG ? 0.f : exp2f(sc[u][r] - m_new);
-          psum += e;
-          pf[2 * u + (r >> 3)][r & 7] = (T)e;
-        }
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float e = exp2f(fmaf(sc[u][r], sl2e, nm));
+            psum += e;
+            pf[2 * u + (r >> 3)][r & 7] = (T)e;
+          }
+      } else {
+        float tmax = NEG_BIG;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = base + 32 * u + 16 * (r >> 3) + 8 * h + (r & 7);
+            const float v = (key <= q_hi && key >= q_lo) ? sc[u][r] * sl2e : NEG_BIG;
+            sc[u][r] = v;
+            tmax = fmaxf(tmax, v);
+          }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        m_new = fmaxf(m_run, tmax);
+        alpha = exp2f(m_run - m_new);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            // (a query whose window starts above this tile has no visible key in it: see attend_loaded)
+            const float e = sc[u][r] <= 0.5f * NEG_BIG ? 0.f : exp2f(sc[u][r] - m_new);
+            psum += e;
+            pf[2 * u + (r >> 3)][r & 7] = (T)e;
+          }
+      }
       l_run = l_run * alpha + psum;
       m_run = m_new;
       const bool rescale = __any(alpha != 1.f);     // the running max rarely moves after the first tiles
