@@ -253,6 +253,13 @@ def test_server_endpoints_end_to_end(frontend_mp):
                     assert rg.status_code == 200, rg.text
                     got = json.loads(rg.json()["choices"][0]["message"]["content"])
                     assert isinstance(got["a"], int) and got["b"] in ("x", "y") and set(got) <= {"a", "b", "c"}
+                gg = await c.post("/v1/completions", headers=hdr, json={
+                    "prompt": "x", "max_tokens": 24, "seed": 5,
+                    "guided_grammar": 'root ::= "<" [a-c]{2,4} ">" | "(" root ")"'})
+                assert gg.status_code == 200, gg.text
+                txt = gg.json()["choices"][0]["text"]
+                assert gg.json()["choices"][0]["finish_reason"] == "stop" and txt.count("(") == txt.count(")")
+                assert 4 <= len(txt.strip("()")) <= 6 and txt.strip("()")[0] == "<" and txt.strip("()")[-1] == ">"
                 for bad_body in ({"guided_regex": "(unclosed"}, {"guided_grammar": "root ::= x"},
                                  {"guided_regex": "a", "guided_choice": ["a"]},
                                  {"guided_json": {"type": "object", "properties": {"a": {"$ref": "http://x/y"}}}}):

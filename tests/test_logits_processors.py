@@ -332,3 +332,95 @@ def test_json_schema_lowering_accepts_and_rejects():
             SamplingParams(guided_json=broken)
     with pytest.raises(ValueError):
         SamplingParams(guided_regex="a", json_object=True)
+
+
+ARITH = r"""
+# sums of numbers and bracketed sums
+root ::= expr
+expr ::= term (("+" | "-") term)*
+term ::= [0-9]+ | "(" expr ")"
+"""
+JSON_GBNF = r"""
+root   ::= object
+value  ::= object | array | string | number | "true" | "false" | "null"
+object ::= "{" ws ( string ws ":" ws value ( ws "," ws string ws ":" ws value )* )? ws "}"
+array  ::= "[" ws ( value ( ws "," ws value )* )? ws "]"
+string ::= "\"" ( [^"\\\x00-\x1f] | "\\" ["\\/bfnrt] )* "\""
+number ::= "-"? ( "0" | [1-9] [0-9]* ) ( "." [0-9]+ )?
+ws     ::= [ \t\n]{0,4}
+"""
+
+
+def test_context_free_grammar_matcher_and_masks():
+    """The stack-set matcher of csrc/core/cfg_grammar.cpp: nesting a regular expression cannot count,
+    JSON against ``json.loads`` on random edits of valid documents, token masks through the vocabulary
+    trie, and the grammars it must refuse."""
+    import json
+    import random
+    from vllm_distributed_amd.ops.grammar import CfgGrammar, TokenTable, compile_grammar
+    g = CfgGrammar(ARITH)
+    assert not g.may_stop and not g.done
+    assert g.advance(b"12") and g.may_stop and not g.done
+    assert g.advance(b"+((3-4)") and not g.may_stop          # one bracket still open
+    assert not g.advance(b"+)") and g.advance(b")") and g.may_stop
+    assert not g.advance(b")") and not g.advance(b"x")       # rejected input leaves the position alone
+    toks = [b"1", b"23", b"+", b"+(", b"(", b")", b"a", b"", b"1+", b"))", b"-9"]
+    t = TokenTable(toks, len(toks))
+    assert dict(zip(toks, g.mask(t).tolist())) == {b"1": 0, b"23": 0, b"+": 1, b"+(": 1, b"(": 0, b")": 0, b"a": 0,
+                                                   b"": 0, b"1+": 0, b"))": 0, b"-9": 1}
+    assert dict(zip(toks, CfgGrammar(ARITH).mask(t).tolist())) == {
+        b"1": 1, b"23": 1, b"+": 0, b"+(": 0, b"(": 1, b")": 0, b"a": 0, b"": 0, b"1+": 1, b"))": 0, b"-9": 0}
+    # JSON objects: the grammar and json.loads agree on documents and on single-character corruptions of them
+    rng = random.Random(1)
+    docs = ['{"a": [1, 2.5, {"b": "x\\n\u00e9"}], "c": null}'.replace("\u00e9", "é"), '{}', '{"k":{"k":{"k":[[[-0.5]]]}}}',
+            '{"t": true, "f": false, "s": "a b"}']
+    for d in docs:
+        gj = CfgGrammar(JSON_GBNF)
+        assert gj.advance(d.encode()) and gj.may_stop and gj.done, d
+        for _ in range(60):
+            i = rng.randrange(len(d))
+            bad = d[:i] + rng.choice('{}[],:"x1 ') + d[i + 1:]
+            try:
+                ok = isinstance(json.loads(bad), dict)
+            except ValueError:
+                ok = False
+            gj = CfgGrammar(JSON_GBNF)
+            got = gj.advance(bad.encode()) and gj.may_stop
+            if ok != got:      # the grammar is stricter than json.loads only about whitespace runs and number forms
+                assert ok and not got and ("     " in bad or "e" in bad.lower() or "+" in bad), (bad, ok, got)
+    # repetition counts and the any-byte dot
+    gr = CfgGrammar('root ::= "a"{2,3} .{2} [^x]?')
+    assert not gr.advance(b"a\xff\xfe") and gr.advance(b"aa") and not gr.may_stop and gr.advance(b"a")
+    assert gr.advance(b"\xff\x00") and gr.may_stop and not gr.advance(b"x") and gr.advance(b"y") and gr.done
+    for bad in ['root ::= root "a" | "b"', 'root ::= "a', 'rot ::= "a"', 'root ::= x', 'root ::= [z-a]',
+                'root ::= ("a"', 'root ::= "a"{3,2}', 'root ::= a\na ::= b "x" | "y"\nb ::= a?  "z"',
+                'root ::= "a"\nroot ::= "b"']:
+        with pytest.raises(ValueError):
+            compile_grammar(bad)
+    from vllm_distributed_amd.sampling_params import SamplingParams
+    assert SamplingParams(guided_grammar=ARITH).has_logit_adjust
+    with pytest.raises(ValueError):
+        SamplingParams(guided_grammar=ARITH, guided_regex="a")
+    with pytest.raises(ValueError):
+        SamplingParams(guided_grammar="root ::= (")
+
+
+def test_guided_grammar_holds_generation_to_the_language():
+    """Random-weight model, temperature 1: whatever it prefers, the text is a sentence of the grammar
+    (balanced brackets) or a prefix of one when max_tokens cut it short."""
+    from vllm_distributed_amd import LLM, SamplingParams
+    from vllm_distributed_amd.ops.grammar import CfgGrammar
+    llm = LLM(**KW)
+    sps = [SamplingParams(temperature=1.0, seed=s, max_tokens=24, guided_grammar=ARITH,
+                          logit_bias={str(ord("(")): 3.0, str(ord(")")): 2.0}) for s in range(6)]
+    outs = llm.generate(["x"] * len(sps), sps)
+    finished = 0
+    for o in outs:
+        text = o.outputs[0].text.encode()
+        g = CfgGrammar(ARITH)
+        assert text and g.advance(text), text
+        if o.outputs[0].finish_reason == "stop":
+            finished += 1
+            assert g.may_stop and text.count(b"(") == text.count(b")"), text
+    assert finished >= 1
+    llm.shutdown()

@@ -325,15 +325,12 @@ def _sampling_params(req, default_max: Optional[int], max_model_len: int, logpro
 def _guided_options(req, extra: Dict[str, Any]) -> Dict[str, Any]:
     """The one output constraint a request asks for, as SamplingParams fields.  Accepted spellings:
     ``response_format`` (json_object, json_schema), vLLM's ``guided_json`` / ``guided_regex`` /
-    ``guided_choice`` and the ``structured_outputs`` object carrying ``json`` / ``regex`` /
-    ``choice`` / ``json_object``.  Context-free grammars are refused: refusing beats silently
-    generating unconstrained text."""
+    ``guided_choice`` / ``guided_grammar`` and the ``structured_outputs`` object carrying ``json`` /
+    ``regex`` / ``choice`` / ``grammar`` / ``json_object``.  Grammars are EBNF in the GBNF spelling
+    (``root ::= ...``)."""
     so = extra.get("structured_outputs") or {}
     if not isinstance(so, dict):
         raise ValueError("structured_outputs must be an object")
-    if extra.get("guided_grammar") is not None or so.get("grammar") is not None:
-        raise ValueError("guided_grammar: context-free grammars are not supported "
-                         "(use a JSON schema, a regular expression or a choice list)")
     out: Dict[str, Any] = {}
     rf = req.response_format or {}
     kind = rf.get("type", "text")
@@ -348,7 +345,8 @@ def _guided_options(req, extra: Dict[str, Any]) -> Dict[str, Any]:
     elif kind != "text":
         raise ValueError(f"response_format type {kind!r} is not supported (text, json_object, json_schema)")
     for field, keys in (("guided_json", ("guided_json", "json")), ("guided_regex", ("guided_regex", "regex")),
-                        ("guided_choice", ("guided_choice", "choice"))):
+                        ("guided_choice", ("guided_choice", "choice")),
+                        ("guided_grammar", ("guided_grammar", "grammar"))):
         val = extra.get(keys[0]) if extra.get(keys[0]) is not None else so.get(keys[1])
         if val is not None:
             out[field] = val
@@ -928,7 +926,7 @@ def _register_routes(app: FastAPI, dev_mode: bool = False) -> None:
 def _constrain(sp: SamplingParams, schema) -> SamplingParams:
     """``sp`` with its output held to ``schema`` (a plain JSON object when there is none)."""
     import dataclasses
-    if sp.guided_regex is not None or sp.guided_choice is not None:
+    if sp.guided_regex is not None or sp.guided_choice is not None or sp.guided_grammar is not None:
         raise ValueError("tool_choice cannot be combined with another output constraint")
     if sp.json_object and schema:
         raise ValueError("tool_choice cannot be combined with response_format json_object")

@@ -228,6 +228,121 @@ class RegexGrammar:
         return out
 
 
+# --------------------------------------------------------------------------- context-free grammars
+_CFG_CACHE: dict = {}
+
+
+class CompiledGrammar:
+    """An EBNF grammar (GBNF spelling, start rule ``root``) compiled by ``csrc/core/cfg_grammar.cpp``."""
+
+    def __init__(self, text: str):
+        lib = load()
+        P, L, I = ctypes.c_void_p, ctypes.c_long, ctypes.c_int
+        if not getattr(lib, "_cfg_bound", False):
+            lib.vdamd_cfg_compile.argtypes = [ctypes.c_char_p, L, ctypes.c_char_p, I]
+            lib.vdamd_cfg_compile.restype = P
+            lib.vdamd_cfg_free.argtypes = [P]
+            lib.vdamd_cfg_free.restype = None
+            lib.vdamd_cfg_state_new.argtypes = [P]
+            lib.vdamd_cfg_state_new.restype = P
+            lib.vdamd_cfg_state_free.argtypes = [P]
+            lib.vdamd_cfg_state_free.restype = None
+            lib.vdamd_cfg_advance.argtypes = [P, ctypes.c_char_p, L]
+            lib.vdamd_cfg_advance.restype = I
+            lib.vdamd_cfg_flags.argtypes = [P]
+            lib.vdamd_cfg_flags.restype = I
+            lib.vdamd_cfg_state_key.argtypes = [P, ctypes.c_char_p, L]
+            lib.vdamd_cfg_state_key.restype = L
+            lib.vdamd_trie_build.argtypes = [P, P, L]
+            lib.vdamd_trie_build.restype = P
+            lib.vdamd_trie_free.argtypes = [P]
+            lib.vdamd_trie_free.restype = None
+            lib.vdamd_cfg_mask.argtypes = [P, P, P]
+            lib.vdamd_cfg_mask.restype = L
+            lib._cfg_bound = True
+        self.lib = lib
+        raw = text.encode("utf-8")
+        err = ctypes.create_string_buffer(256)
+        self.handle = lib.vdamd_cfg_compile(raw, len(raw), err, len(err))
+        if not self.handle:
+            raise ValueError(f"cannot compile guided-decoding grammar: {err.value.decode('utf-8', 'replace')}")
+        self.text = text
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            self.lib.vdamd_cfg_free(h)
+
+
+def compile_grammar(text: str) -> CompiledGrammar:
+    c = _CFG_CACHE.get(text)
+    if c is None:
+        c = CompiledGrammar(text)
+        if len(_CFG_CACHE) >= 64:
+            _CFG_CACHE.pop(next(iter(_CFG_CACHE)))
+        _CFG_CACHE[text] = c
+    return c
+
+
+class _Trie:
+    """The vocabulary's byte strings as a trie (built once per token table, walked by every mask)."""
+
+    def __init__(self, lib, table: "TokenTable"):
+        self.lib = lib
+        self.handle = lib.vdamd_trie_build(table.blob.ctypes.data, table.offsets.ctypes.data, table.n)
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            self.lib.vdamd_trie_free(h)
+
+
+class CfgGrammar:
+    """One request's position in a context-free grammar (vLLM's ``guided_grammar``): the set of parse
+    stacks the text so far leaves open."""
+
+    def __init__(self, text: str) -> None:
+        self.cg = compile_grammar(text)
+        self.state = self.cg.lib.vdamd_cfg_state_new(self.cg.handle)
+
+    def __del__(self):
+        s, self.state = getattr(self, "state", None), None
+        if s:
+            self.cg.lib.vdamd_cfg_state_free(s)
+
+    def advance(self, data: bytes) -> bool:
+        return self.cg.lib.vdamd_cfg_advance(self.state, data, len(data)) == 0
+
+    @property
+    def may_stop(self) -> bool:
+        return bool(self.cg.lib.vdamd_cfg_flags(self.state) & 1)
+
+    @property
+    def done(self) -> bool:
+        return self.cg.lib.vdamd_cfg_flags(self.state) == 1
+
+    def _key(self) -> bytes:
+        lib = self.cg.lib
+        n = lib.vdamd_cfg_state_key(self.state, None, 0)
+        buf = ctypes.create_string_buffer(max(1, n))
+        lib.vdamd_cfg_state_key(self.state, buf, n)
+        return buf.raw[:n]
+
+    def mask(self, table: TokenTable) -> np.ndarray:
+        key = (id(self.cg), self._key())
+        out = table.mask_cache.get(key)
+        if out is None:
+            trie = getattr(table, "_trie", None)
+            if trie is None:
+                trie = table._trie = _Trie(self.cg.lib, table)
+            out = np.empty(table.n, dtype=np.uint8)
+            self.cg.lib.vdamd_cfg_mask(self.state, trie.handle, out.ctypes.data)
+            if len(table.mask_cache) >= 512:
+                table.mask_cache.clear()
+            table.mask_cache[key] = out
+        return out
+
+
 # --------------------------------------------------------------------------- JSON schema -> regex
 _WS = "[ ]?"
 _STR_CHAR = r'([^"\\\x00-\x1f]|\\["\\/bfnrt]|\\u[0-9a-fA-F]{4})'

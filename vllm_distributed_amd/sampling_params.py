@@ -39,6 +39,7 @@ class SamplingParams:
     pooling: Optional[str] = None
     guided_regex: Optional[str] = None                   # the output matches this regular expression
     guided_json: Optional[Any] = None                    # the output is JSON satisfying this schema (dict or str)
+    guided_grammar: Optional[str] = None                 # the output is a sentence of this EBNF grammar (start rule: root)
     # filled by the engine: the model's EOS id (the only token allowed once a constrained output is complete)
     eos_token_id: Optional[int] = None
     # filled by the engine: EOS + stop token ids, masked until ``min_tokens`` outputs exist
@@ -121,6 +122,13 @@ class SamplingParams:
                 raise ValueError("guided_regex must be a non-empty string")
             from .ops.grammar import compile_regex
             compile_regex(self.guided_regex)          # ValueError for what the automaton cannot express
+        if self.guided_grammar is not None:
+            if self.json_object or self.guided_choice is not None or self.guided_regex is not None:
+                raise ValueError("a request can carry one output constraint")
+            if not isinstance(self.guided_grammar, str) or not self.guided_grammar.strip():
+                raise ValueError("guided_grammar must be a non-empty string")
+            from .ops.grammar import compile_grammar
+            compile_grammar(self.guided_grammar)      # ValueError for syntax errors, left recursion, ...
         if self.truncate_prompt_tokens is not None and self.truncate_prompt_tokens < 1:
             raise ValueError("truncate_prompt_tokens must be >= 1")
         if self.prompt_logprobs is not None and self.prompt_logprobs < 0:
@@ -141,7 +149,7 @@ class SamplingParams:
     def has_logit_adjust(self) -> bool:
         """True when logits must be edited before sampling (bias, allow / ban lists, min_tokens)."""
         return bool(self.logit_bias or self.allowed_token_ids is not None or self.bad_words_token_ids
-                    or self.json_object or self.guided_choice or self.guided_regex
+                    or self.json_object or self.guided_choice or self.guided_regex or self.guided_grammar
                     or (self.min_tokens > 0 and self.min_tokens_ban_ids))
 
     def check_vocab(self, vocab_size: int) -> None:

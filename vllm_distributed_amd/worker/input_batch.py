@@ -104,6 +104,9 @@ class InputBatch:
         elif sp.guided_regex:
             from ..ops.grammar import RegexGrammar
             self.grammar[row] = RegexGrammar(sp.guided_regex)
+        elif sp.guided_grammar:
+            from ..ops.grammar import CfgGrammar
+            self.grammar[row] = CfgGrammar(sp.guided_grammar)
         self.num_logprobs[row] = -1 if sp.logprobs is None else sp.logprobs
         self.lora_id[row] = lora_id
         self.req_ids[row] = req_id
