@@ -21,7 +21,10 @@
 // compiled.
 //
 // The token mask walks a trie of the vocabulary's byte strings with the stack set, so tokens that share
-// a prefix share the work and a byte no stack accepts prunes its whole subtree.
+// a prefix share the work and a byte no stack accepts prunes its whole subtree.  Stack sets met on
+// the way are interned and their byte transitions remembered on the grammar (a DFA built lazily over
+// the sets actually reached): inside a string literal, say, every trie node after the first costs one
+// hash lookup.
 #include <algorithm>
 #include <array>
 #include <cstdint>
@@ -29,7 +32,9 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -433,8 +438,47 @@ struct Matcher {
   }
 };
 
+// Lazily built DFA over interned stack sets, shared by every request that uses the grammar.
+struct Lazy {
+  std::mutex mu;
+  std::map<StackSet, int> ids;
+  std::vector<const StackSet*> sets;                 // id -> key of `ids` (map nodes do not move)
+  std::unordered_map<uint64_t, int> trans;           // (id << 8 | byte) -> id, or -1: rejected
+  static constexpr size_t MAX_SETS = 50000;
+
+  int intern(const StackSet& s) {
+    auto it = ids.find(s);
+    if (it != ids.end()) return it->second;
+    const int id = (int)sets.size();
+    auto ins = ids.emplace(s, id);
+    sets.push_back(&ins.first->first);
+    return id;
+  }
+  int step(const Matcher& m, int id, unsigned c) {
+    const uint64_t key = ((uint64_t)id << 8) | c;
+    auto it = trans.find(key);
+    if (it != trans.end()) return it->second;
+    StackSet next;
+    int to = -1;
+    if (m.accept(*sets[id], c, next) && !next.empty()) to = intern(next);
+    trans.emplace(key, to);
+    return to;
+  }
+  void trim() {
+    if (sets.size() <= MAX_SETS) return;
+    ids.clear();
+    sets.clear();
+    trans.clear();
+  }
+};
+
+struct GrammarBox {
+  Grammar g;
+  Lazy lazy;
+};
+
 struct State {
-  std::shared_ptr<Grammar> g;
+  std::shared_ptr<GrammarBox> box;
   StackSet stacks;
 };
 
@@ -448,18 +492,16 @@ struct Trie {
   long n_tokens = 0;
 };
 
-void walk(const Matcher& m, const Trie& t, int node, const StackSet& set, uint8_t* out, long& allowed) {
-  const ByteSet first = m.first_bytes(set);
-  StackSet next;
+void walk(const Matcher& m, Lazy& lazy, const Trie& t, int node, int set_id, uint8_t* out, long& allowed) {
   for (const auto& kid : t.nodes[node].kids) {
-    if (!bs_has(first, kid.first)) continue;
-    if (!m.accept(set, kid.first, next) || next.empty()) continue;
+    const int to = lazy.step(m, set_id, kid.first);
+    if (to < 0) continue;
     const Trie::Node& child = t.nodes[kid.second];
     for (int id : child.tokens) {
       if (!out[id]) ++allowed;
       out[id] = 1;
     }
-    if (!child.kids.empty()) walk(m, t, kid.second, next, out, allowed);
+    if (!child.kids.empty()) walk(m, lazy, t, kid.second, to, out, allowed);
   }
 }
 
@@ -469,7 +511,8 @@ extern "C" {
 
 // Compiled grammar handle, or null with a message in `err`.
 void* vdamd_cfg_compile(const char* text, long n, char* err, int errlen) {
-  auto g = std::make_shared<Grammar>();
+  auto box = std::make_shared<GrammarBox>();
+  Grammar* g = &box->g;
   std::string src(text, (size_t)n);
   Parser ps(src, *g);
   std::string msg;
@@ -478,21 +521,21 @@ void* vdamd_cfg_compile(const char* text, long n, char* err, int errlen) {
   if (msg.empty() && left_recursive(*g, who)) msg = "rule " + who + " is left-recursive (rewrite it with a repetition)";
   if (msg.empty()) {
     StackSet s;
-    Matcher m{g.get()};
+    Matcher m{g};
     if (!m.start(s)) msg = "the grammar is too ambiguous to expand";
   }
   if (!msg.empty()) {
     if (err != nullptr && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", msg.c_str());
     return nullptr;
   }
-  return new std::shared_ptr<Grammar>(g);
+  return new std::shared_ptr<GrammarBox>(box);
 }
 
-void vdamd_cfg_free(void* h) { delete static_cast<std::shared_ptr<Grammar>*>(h); }
+void vdamd_cfg_free(void* h) { delete static_cast<std::shared_ptr<GrammarBox>*>(h); }
 
 void* vdamd_cfg_state_new(void* h) {
-  auto* st = new State{*static_cast<std::shared_ptr<Grammar>*>(h), {}};
-  Matcher m{st->g.get()};
+  auto* st = new State{*static_cast<std::shared_ptr<GrammarBox>*>(h), {}};
+  Matcher m{&st->box->g};
   m.start(st->stacks);
   return st;
 }
@@ -502,7 +545,7 @@ void vdamd_cfg_state_free(void* s) { delete static_cast<State*>(s); }
 // 0: consumed (state advanced); -1: the bytes do not continue any sentence (state unchanged)
 int vdamd_cfg_advance(void* s, const char* data, long n) {
   State* st = static_cast<State*>(s);
-  Matcher m{st->g.get()};
+  Matcher m{&st->box->g};
   StackSet cur = st->stacks, next;
   for (long i = 0; i < n; ++i) {
     if (!m.accept(cur, (unsigned char)data[i], next) || next.empty()) return -1;
@@ -578,8 +621,11 @@ long vdamd_cfg_mask(void* s, void* trie, uint8_t* out) {
   const Trie* t = static_cast<Trie*>(trie);
   std::memset(out, 0, (size_t)t->n_tokens);
   long allowed = 0;
-  Matcher m{st->g.get()};
-  walk(m, *t, 0, st->stacks, out, allowed);
+  Matcher m{&st->box->g};
+  Lazy& lazy = st->box->lazy;
+  std::lock_guard<std::mutex> hold(lazy.mu);
+  lazy.trim();
+  walk(m, lazy, *t, 0, lazy.intern(st->stacks), out, allowed);
   return allowed;
 }
 
