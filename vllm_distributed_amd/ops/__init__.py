@@ -238,7 +238,7 @@ def gate_up_silu(x, weight):
     """``silu(x @ Wg^T) * (x @ Wu^T)`` for ``weight = [Wg ; Wu]`` in one kernel (the large-batch GEMM
     forms the activation in its epilogue: the ``[M, 2F]`` intermediate is never written), or ``None``
     when that kernel does not take the shape - the caller then runs the two-step path."""
-    if (x.is_cuda and x.dim() == 2 and envs.VDAMD_BIG_GEMM and _use_hip(x) and x.shape[0] >= _hip.BIG_MIN_M
+    if (x.is_cuda and x.dim() == 2 and envs.VDAMD_BIG_GEMM and _use_hip(x) and x.shape[0] >= _hip.BIG_MIN_M_SILU
             and _hip.big_profitable(x.shape[0], weight.shape[0], weight.shape[1], True)
             and _hip.big_supported(x, weight, True)):
         return _hip.big_gemm(x, weight, silu_mul=True)

@@ -688,6 +688,9 @@ def mid_gemm(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = Non
 
 # ------------------------------------- 256 x 256 tile LDS-DMA GEMM, M >= 512
 BIG_MIN_M = 512
+# with the SiLU*mul epilogue a single full row of tiles already beats library GEMM + activation kernel
+# (70B gate_up at 256 rows: 216 us against 229 + 9; profiles/r2_big_gemm_vs_library.txt)
+BIG_MIN_M_SILU = 240
 BIG_VARIANT = int(os.environ.get("VDAMD_BIG_GEMM_VARIANT", "0"))
 
 
@@ -706,8 +709,10 @@ def big_profitable(m: int, n: int, k: int, silu_mul: bool = False) -> bool:
     chip's 256 CUs in whole rounds.  With the SiLU*mul epilogue it also saves the activation kernel
     and wins at every batch size measured (512 .. 16384 rows); without it the library is 1-4 % ahead
     from 4096 rows up and stays in charge there."""
-    if m < BIG_MIN_M or k < 1024:
+    if m < (BIG_MIN_M_SILU if silu_mul else BIG_MIN_M) or k < 1024:
         return False
+    if m < BIG_MIN_M and m > 256:
+        return False                  # between one and two full rows of tiles the second row is mostly padding
     tiles = -(-m // 256) * (-(-(n // 2) // 128) if silu_mul else -(-n // 256))
     rounds = -(-tiles // 256)
     eff = tiles / (rounds * 256.0)
