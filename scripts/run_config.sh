@@ -8,6 +8,7 @@
 #   scripts/run_config.sh 3   Llama-3-8B, head (1 GPU) + 7 single-GPU workers, TP=8
 #   scripts/run_config.sh 4   Llama-3-70B, TP=8 (head owns all 8 GPUs)
 #   scripts/run_config.sh 5   Llama-3-70B, TP=4 x PP=2 (head 4 GPUs + one 4-GPU worker node)
+#   scripts/run_config.sh 6   Llama-3-70B, TP=1: the headline model on one MI355X (bf16 weights fit in 288 GB)
 #
 # Environment: PORT (8000), NUM_PROMPTS (256), CONCURRENCY (64), INPUT_LEN (128), OUTPUT_LEN (64),
 # OUTPUT_JITTER (0: every request the same length; 0.5: lengths uniform in 32..96, requests desynchronised).
@@ -39,6 +40,8 @@ case "$cfg" in
   5) model=llama-3-70b; vocab=128256
      VLLM_HEAD_LOCAL_DEVICES=4 serve "$model" -tp 4 -pp 2 --max-model-len 4096
      remote --num-devices 4 --device-offset 4 ;;
+  6) model=llama-3-70b; vocab=128256
+     serve "$model" -tp 1 --max-model-len 4096 --max-num-seqs "${MAX_NUM_SEQS:-1024}" ;;
   *) echo "unknown config $cfg" >&2; exit 2 ;;
 esac
 
