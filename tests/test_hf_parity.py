@@ -48,6 +48,8 @@ CASES = {
                                         num_hidden_layers=3, final_logit_softcapping=20.0,
                                         layer_types=["sliding_attention", "full_attention", "sliding_attention"])),
     "phi": ("PhiConfig", dict(BASE, partial_rotary_factor=0.5, layer_norm_eps=1e-5)),
+    # Phi-2's head size of 80: padded to 96 for the cache and the attention kernels
+    "phi-head80": ("PhiConfig", dict(BASE, hidden_size=320, num_key_value_heads=4, partial_rotary_factor=0.4)),
     # routed experts + a sigmoid-gated shared expert; one dense layer in between (mlp_only_layers)
     "qwen2-moe": ("Qwen2MoeConfig", dict(BASE, moe_intermediate_size=64, shared_expert_intermediate_size=96,
                                          num_experts=8, num_experts_per_tok=2, norm_topk_prob=False,

@@ -57,9 +57,18 @@ def get_forward_context() -> ForwardContext:
 class Attention(nn.Module):
     """Owns one layer's slice of the KV cache (bound by the model runner)."""
 
+    KERNEL_HEAD_DIMS = (64, 96, 128, 256)
+
     def __init__(self, num_heads: int, head_dim: int, num_kv_heads: int, scale: float,
-                 layer_idx: int, sliding_window: Optional[int] = None):
+                 layer_idx: int, sliding_window: Optional[int] = None, pad_head_dim: bool = False):
         super().__init__()
+        # ``pad_head_dim`` (callers of ``forward`` only): a head size the attention kernels are not
+        # built for (Phi-2's 80) is zero-padded to the next one they are; ``head_dim`` is then the
+        # size q / k / v have in the cache and the kernels, ``model_head_dim`` the model's own.
+        # Zero columns change neither the scores nor (sliced off again) the output.
+        self.model_head_dim = head_dim
+        if pad_head_dim and head_dim not in self.KERNEL_HEAD_DIMS and head_dim < self.KERNEL_HEAD_DIMS[-1]:
+            head_dim = next(d for d in self.KERNEL_HEAD_DIMS if d > head_dim)
         self.num_heads, self.head_dim, self.num_kv_heads = num_heads, head_dim, num_kv_heads
         self.scale = scale
         # a query sees its last `window` keys only (0 = the whole context)
@@ -107,6 +116,18 @@ class Attention(nn.Module):
     def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
         """Unfused path: write k/v (``[T, Hkv*D]``) to the cache, then attend."""
         md = _CTX.attn_metadata
+        if self.head_dim != self.model_head_dim:
+            t, extra = q.shape[0], self.head_dim - self.model_head_dim
+            pad = torch.nn.functional.pad
+            if md is None:
+                return q
+            k = pad(k.reshape(t, self.num_kv_heads, self.model_head_dim), (0, extra))
+            v = pad(v.reshape(t, self.num_kv_heads, self.model_head_dim), (0, extra))
+            ops.reshape_and_cache(k, v, self.k_cache, self.v_cache, md.slot_mapping, self.kv_scales)
+            qp = pad(q.reshape(t, self.num_heads, self.model_head_dim), (0, extra))
+            out = self.forward_cached(qp.view(t, self.num_heads * self.head_dim))
+            return out.view(t, self.num_heads, self.head_dim)[..., :self.model_head_dim].reshape(
+                t, self.num_heads * self.model_head_dim)
         if md is not None:
             t = k.shape[0]
             ops.reshape_and_cache(k.reshape(t, self.num_kv_heads, self.head_dim),

@@ -29,7 +29,7 @@ class PhiLayer(nn.Module):
         self.qkv_proj = QKVParallelLinear(h, self.head_dim, heads, kv, True, dtype)
         self.dense = RowParallelLinear(h, h, True, dtype)
         self.attn = Attention(self.qkv_proj.num_heads, self.head_dim, self.qkv_proj.num_kv_heads,
-                              self.head_dim ** -0.5, layer_idx)
+                              self.head_dim ** -0.5, layer_idx, pad_head_dim=True)
         self.fc1 = ColumnParallelLinear(h, [cfg["intermediate_size"]], True, dtype)
         self.fc2 = RowParallelLinear(cfg["intermediate_size"], h, True, dtype)
         self.act = cfg.get("hidden_act", "gelu_new")
