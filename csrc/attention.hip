@@ -107,9 +107,16 @@ __device__ __forceinline__ void load_kv_group(KVFrag<T, D>& f, const void* __res
   for (int dt = 0; dt < D / 16; ++dt) f.vf[dt] = ld_kv<T, KV8>(v_cache, v_off + (long)dt * slab, v_scale);
 }
 
+// Score capping (Gemma-2): cap * tanh(score / cap) on the natural-log scale; `s2` and the result are
+// scores already multiplied by log2(e).
+__device__ __forceinline__ float soft_cap_log2(float s2, float cap) {
+  const float t = tanhf(s2 * (0.6931471805599453f / cap));
+  return t * (cap * 1.4426950408889634f);
+}
+
 template <typename T, int D, int NQ>
 __device__ __forceinline__ void attend_loaded(
-    const KVFrag<T, D>& f, int base, int seq_len, float scale_log2e,
+    const KVFrag<T, D>& f, int base, int seq_len, float scale_log2e, float softcap,
     const typename Vec8<T>::type (&qf)[NQ][D / 32], f32x4 (&acc)[NQ][D / 16], float (&m)[NQ], float (&l)[NQ],
     const int (&qpos_hi)[NQ], const int (&qpos_lo)[NQ]) {
   using V = typename Vec8<T>::type;
@@ -129,7 +136,8 @@ __device__ __forceinline__ void attend_loaded(
     float tmax = NEG_BIG;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float sv = (j < 4 ? s0[j & 3] : s1[j & 3]) * scale_log2e;
+      float sv = (j < 4 ? s0[j & 3] : s1[j & 3]) * scale_log2e;
+      if (softcap > 0.f) sv = soft_cap_log2(sv, softcap);
       p[j] = (kidx0 + j <= hi && kidx0 + j >= lo) ? sv : NEG_BIG;
       tmax = fmaxf(tmax, p[j]);
     }
@@ -160,12 +168,12 @@ __device__ __forceinline__ void attend_loaded(
 template <typename T, int D, int NQ, bool KV8>
 __device__ __forceinline__ void attend_group(
     const void* __restrict__ k_cache, const void* __restrict__ v_cache, const int* __restrict__ bt_row, int kvh,
-    int Hkv, int block_size, int base, int seq_len, float scale_log2e,
+    int Hkv, int block_size, int base, int seq_len, float scale_log2e, float softcap,
     const typename Vec8<T>::type (&qf)[NQ][D / 32], f32x4 (&acc)[NQ][D / 16], float (&m)[NQ], float (&l)[NQ],
     const int (&qpos_hi)[NQ], const int (&qpos_lo)[NQ], float k_scale, float v_scale) {
   KVFrag<T, D> f;
   load_kv_group<T, D, KV8>(f, k_cache, v_cache, bt_row, kvh, Hkv, block_size, base, seq_len, k_scale, v_scale);
-  attend_loaded<T, D, NQ>(f, base, seq_len, scale_log2e, qf, acc, m, l, qpos_hi, qpos_lo);
+  attend_loaded<T, D, NQ>(f, base, seq_len, scale_log2e, softcap, qf, acc, m, l, qpos_hi, qpos_lo);
 }
 
 // ---------------------------------------------------------------------------
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     long q_stride, const void* __restrict__ k_cache, const void* __restrict__ v_cache,
     const int* __restrict__ block_table, int bt_stride, const int* __restrict__ seq_lens, float scale_log2e,
     int Hq, int Hkv, int block_size, int num_splits, long out_stride, const float* __restrict__ k_scales,
-    const float* __restrict__ v_scales, int window) {
+    const float* __restrict__ v_scales, int window, float softcap) {
   using V = typename Vec8<T>::type;
   constexpr int LDS_ROW = D + 4;
   __shared__ float s_o[4][16][LDS_ROW];
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // measured 3-8% slower than letting 4 resident workgroups per CU hide the latency
   for (int g = g_begin + wid; g < g_end; g += 4)
     attend_group<T, D, 1, KV8>(k_cache, v_cache, bt_row, kvh, Hkv, block_size, g * 32, seq_len,
-                               scale_log2e * k_scale, qf, acc, m, l, qpos_hi, qpos_lo, 1.f, 1.f);
+                               scale_log2e * k_scale, softcap, qf, acc, m, l, qpos_hi, qpos_lo, 1.f, 1.f);
 
   float lsum = l[0];
   lsum += __shfl_xor(lsum, 16, 64);
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     T* __restrict__ out, const T* __restrict__ q, long q_stride, const void* __restrict__ k_cache,
     const void* __restrict__ v_cache, const int* __restrict__ block_table, int bt_stride,
     const int* __restrict__ seq_lens, float scale_log2e, int B, int Hq, int Hkv, int block_size, long out_stride,
-    const float* __restrict__ k_scales, const float* __restrict__ v_scales, int window) {
+    const float* __restrict__ k_scales, const float* __restrict__ v_scales, int window, float softcap) {
   using V = typename Vec8<T>::type;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int b = blockIdx.x * 4 + wid;
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int n_groups = (seq_len + 31) >> 5;
   for (int g = qpos_lo[0] >> 5; g < n_groups; ++g)
     attend_group<T, D, 1, KV8>(k_cache, v_cache, bt_row, kvh, Hkv, block_size, g * 32, seq_len,
-                               scale_log2e * k_scale, qf, acc, m, l, qpos_hi, qpos_lo, 1.f, 1.f);
+                               scale_log2e * k_scale, softcap, qf, acc, m, l, qpos_hi, qpos_lo, 1.f, 1.f);
   float lsum = l[0];
   lsum += __shfl_xor(lsum, 16, 64);
   lsum += __shfl_xor(lsum, 32, 64);
@@ -337,7 +345,7 @@ __global__ __launch_bounds__(256) void paged_prefill_kernel(
     const void* __restrict__ v_cache, const int* __restrict__ block_table, int bt_stride,
     const int* __restrict__ query_start_loc, const int* __restrict__ seq_lens, float scale_log2e, int Hq, int Hkv,
     int block_size, long out_stride, const float* __restrict__ k_scales, const float* __restrict__ v_scales,
-    int window) {
+    int window, float softcap) {
   using V = typename Vec8<T>::type;
   constexpr int NQ = 2;
   const int z = blockIdx.z, h = blockIdx.y;
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(256) void paged_prefill_kernel(
   const int g_first = window > 0 ? max(0, ctx + t_wave - window + 1) >> 5 : 0;     // the wave's earliest window edge
   for (int g = g_first; g < n_groups; ++g)
     attend_group<T, D, NQ, KV8>(k_cache, v_cache, bt_row, kvh, Hkv, block_size, g * 32, seq_len,
-                                scale_log2e * k_scale, qf, acc, m, l, qpos_hi, qpos_lo, 1.f, 1.f);
+                                scale_log2e * k_scale, softcap, qf, acc, m, l, qpos_hi, qpos_lo, 1.f, 1.f);
 #pragma unroll
   for (int n = 0; n < NQ; ++n) {
     float lsum = l[n];
@@ -427,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
     const void* __restrict__ v_cache, const int* __restrict__ block_table, int bt_stride,
     const int* __restrict__ query_start_loc, const int* __restrict__ seq_lens, float scale_log2e, int Hq, int Hkv,
     int block_size, long out_stride, int q_tiles, int total_wgs, int xcd_remap,
-    const float* __restrict__ k_scales, const float* __restrict__ v_scales, int window) {
+    const float* __restrict__ k_scales, const float* __restrict__ v_scales, int window, float softcap) {
   using V = typename Vec8<T>::type;
   constexpr int D = 128, KT = 64, TILE_BYTES = KT * D * 2;
   __shared__ __attribute__((aligned(16))) char smem[2][2][TILE_BYTES];     // [buffer][K | V^T]
@@ -546,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
       // of a long sequence - take the short path: the running max is found on the raw scores (the scale
       // is positive) and the scale rides in the exponent's multiply-add, three VALU operations and one
       // exponential per score instead of eight and one.
-      const bool need_mask = base + KT - 1 > min(ctx + t_wave, seq_len - 1) || base < wave_lo_max;
+      const bool need_mask = base + KT - 1 > min(ctx + t_wave, seq_len - 1) || base < wave_lo_max || softcap > 0.f;
       float m_new, alpha, psum = 0.f;
       V pf[4];
       if (!need_mask) {
@@ -572,7 +580,9 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int key = base + 32 * u + 16 * (r >> 3) + 8 * h + (r & 7);
-            const float v = (key <= q_hi && key >= q_lo) ? sc[u][r] * sl2e : NEG_BIG;
+            float sv = sc[u][r] * sl2e;
+            if (softcap > 0.f) sv = soft_cap_log2(sv, softcap);
+            const float v = (key <= q_hi && key >= q_lo) ? sv : NEG_BIG;
             sc[u][r] = v;
             tmax = fmaxf(tmax, v);
           }
@@ -630,7 +640,7 @@ template <typename T, int D, bool KV8>
 int launch_decode(void* out, float* ws, const void* q, long q_stride, const void* kc, const void* vc, const int* bt,
                   int bt_stride, const int* seq_lens, float scale, int B, int Hq, int Hkv, int block_size,
                   int num_splits, long out_stride, const float* k_scales, const float* v_scales, int window,
-                  hipStream_t s) {
+                  float softcap, hipStream_t s) {
   const int G = Hq / Hkv;
   const int q_tiles = (G + 15) / 16;
   float* part_o = ws;
@@ -639,13 +649,13 @@ int launch_decode(void* out, float* ws, const void* q, long q_stride, const void
   if (num_splits == 0) {      // one wave per sequence
     hipLaunchKernelGGL((paged_decode_wave_kernel<T, D, KV8>), dim3((B + 3) / 4, Hkv * q_tiles), dim3(256), 0, s,
                        (T*)out, (const T*)q, q_stride, kc, vc, bt, bt_stride, seq_lens, sl2, B, Hq, Hkv, block_size,
-                       out_stride, k_scales, v_scales, window);
+                       out_stride, k_scales, v_scales, window, softcap);
     HIP_LAUNCH_CHECK();
     return 0;
   }
   hipLaunchKernelGGL((paged_decode_kernel<T, D, KV8>), dim3(num_splits, Hkv * q_tiles, B), dim3(256), 0, s, (T*)out,
                      part_o, part_ml, (const T*)q, q_stride, kc, vc, bt, bt_stride, seq_lens,
-                     sl2, Hq, Hkv, block_size, num_splits, out_stride, k_scales, v_scales, window);
+                     sl2, Hq, Hkv, block_size, num_splits, out_stride, k_scales, v_scales, window, softcap);
   HIP_LAUNCH_CHECK();
   if (num_splits > 1) {
     hipLaunchKernelGGL((decode_reduce_kernel<T, D>), dim3(Hq, B), dim3(D), 0, s, (T*)out, part_o, part_ml, Hq,
@@ -659,7 +669,7 @@ template <typename T, int D, bool KV8>
 int launch_prefill(void* out, const void* q, long q_stride, const void* kc, const void* vc, const int* bt,
                    int bt_stride, const int* qsl, const int* seq_lens, float scale, int num_seqs, int max_q_len,
                    int Hq, int Hkv, int block_size, long out_stride, const float* k_scales, const float* v_scales,
-                   int window, hipStream_t s) {
+                   int window, float softcap, hipStream_t s) {
   const float sl2 = scale * 1.4426950408889634f;
   const int tiles = (max_q_len + 127) / 128;
   if constexpr (D == 128) {
@@ -673,14 +683,14 @@ int launch_prefill(void* out, const void* q, long q_stride, const void* kc, cons
       const int grid = remap ? (int)((total + 7) / 8 * 8) : (int)total;
       hipLaunchKernelGGL((paged_prefill_lds_kernel<T, KV8>), dim3(grid), dim3(256), 0, s, (T*)out,
                          (const T*)q, q_stride, kc, vc, bt, bt_stride, qsl, seq_lens, sl2, Hq,
-                         Hkv, block_size, out_stride, tiles, (int)total, remap, k_scales, v_scales, window);
+                         Hkv, block_size, out_stride, tiles, (int)total, remap, k_scales, v_scales, window, softcap);
       HIP_LAUNCH_CHECK();
       return 0;
     }
   }
   hipLaunchKernelGGL((paged_prefill_kernel<T, D, KV8>), dim3(tiles, Hq, num_seqs), dim3(256), 0, s, (T*)out,
                      (const T*)q, q_stride, kc, vc, bt, bt_stride, qsl, seq_lens, sl2, Hq, Hkv,
-                     block_size, out_stride, k_scales, v_scales, window);
+                     block_size, out_stride, k_scales, v_scales, window, softcap);
   HIP_LAUNCH_CHECK();
   return 0;
 }
@@ -701,7 +711,7 @@ VDAMD_API int vdamd_paged_attention_decode(void* out, float* workspace, const vo
                                            int bt_stride, const int* seq_lens, float scale, int B, int Hq, int Hkv,
                                            int D, int block_size, int num_splits, long out_stride, int dtype,
                                            int kv_fp8, const float* k_scales, const float* v_scales, int window,
-                                           hipStream_t s) {
+                                           float softcap, hipStream_t s) {
   if (B == 0) return 0;
   // num_splits == 0 selects the one-wave-per-sequence kernel (short contexts, large batches)
   if (Hq % Hkv != 0 || block_size % 8 != 0 || num_splits < 0 || num_splits > MAX_SPLITS) return -1;
@@ -711,10 +721,10 @@ VDAMD_API int vdamd_paged_attention_decode(void* out, float* workspace, const vo
     if (kv_fp8)                                                                                                  \
       return launch_decode<TY, DD, true>(out, workspace, q, q_stride, k_cache, v_cache, block_table, bt_stride,   \
                                          seq_lens, scale, B, Hq, Hkv, block_size, num_splits, out_stride,         \
-                                         k_scales, v_scales, window, s);                                          \
+                                         k_scales, v_scales, window, softcap, s);                                          \
     return launch_decode<TY, DD, false>(out, workspace, q, q_stride, k_cache, v_cache, block_table, bt_stride,    \
                                         seq_lens, scale, B, Hq, Hkv, block_size, num_splits, out_stride, nullptr, \
-                                        nullptr, window, s);                                                      \
+                                        nullptr, window, softcap, s);                                                    \
   } while (0)
   if (dtype == DT_BF16) {
     if (D == 128) CASE(bf16_t, 128);
@@ -737,7 +747,7 @@ VDAMD_API int vdamd_paged_attention_prefill(void* out, const void* q, long q_str
                                             const int* query_start_loc, const int* seq_lens, float scale,
                                             int num_seqs, int max_q_len, int Hq, int Hkv, int D, int block_size,
                                             long out_stride, int dtype, int kv_fp8, const float* k_scales,
-                                            const float* v_scales, int window, hipStream_t s) {
+                                            const float* v_scales, int window, float softcap, hipStream_t s) {
   if (num_seqs == 0 || max_q_len == 0) return 0;
   if (Hq % Hkv != 0 || block_size % 8 != 0) return -1;
 #define CASE(TY, DD)                                                                                             \
@@ -745,10 +755,10 @@ VDAMD_API int vdamd_paged_attention_prefill(void* out, const void* q, long q_str
     if (kv_fp8)                                                                                                  \
       return launch_prefill<TY, DD, true>(out, q, q_stride, k_cache, v_cache, block_table, bt_stride,             \
                                           query_start_loc, seq_lens, scale, num_seqs, max_q_len, Hq, Hkv,         \
-                                          block_size, out_stride, k_scales, v_scales, window, s);                 \
+                                          block_size, out_stride, k_scales, v_scales, window, softcap, s);                 \
     return launch_prefill<TY, DD, false>(out, q, q_stride, k_cache, v_cache, block_table, bt_stride,              \
                                          query_start_loc, seq_lens, scale, num_seqs, max_q_len, Hq, Hkv,          \
-                                         block_size, out_stride, nullptr, nullptr, window, s);                    \
+                                         block_size, out_stride, nullptr, nullptr, window, softcap, s);                  \
   } while (0)
   if (dtype == DT_BF16) {
     if (D == 128) CASE(bf16_t, 128);

@@ -275,6 +275,39 @@ def test_mfma_operand_maps_with_exact_integer_data():
         torch.testing.assert_close(got[0, h], vt[:, j].float(), rtol=0, atol=1e-2)
 
 
+@pytest.mark.parametrize("window", [0, 48])
+def test_attention_score_soft_cap(window):
+    """softcap * tanh(score / softcap) before the softmax (Gemma-2), with scores large enough for the cap
+    to bite: both decode kernels, every split count, both prefill kernels, with and without a window."""
+    from vllm_distributed_amd.ops import hip
+    hq, hkv, d, bs = 16, 4, 128, 32
+    scale, cap = 0.5, 6.0
+    seq_lens = [1, 31, 100, 517, 129]
+    kc, vc, bt = _make_paged(seq_lens, hkv, d, bs)
+    sl = torch.tensor(seq_lens, device=DEV, dtype=torch.int32)
+    q = _rand(len(seq_lens), hq, d)
+    ref = torch_ref.paged_attention_decode(q.float(), kc.float(), vc.float(), bt, sl, scale, None, window, cap)
+    plain = torch_ref.paged_attention_decode(q.float(), kc.float(), vc.float(), bt, sl, scale, None, window)
+    assert (ref - plain).abs().max() > 0.05              # the cap changes the answer
+    for splits in (None, 0, 1, 4):
+        got = hip.paged_attention_decode(q, kc, vc, bt, sl, scale, max_seq_len=max(seq_lens), num_splits=splits,
+                                         window=window, softcap=cap)
+        torch.testing.assert_close(got.float(), ref, rtol=3e-2, atol=3e-2)
+    for cases in ([(5, 5), (20, 300), (30, 30)], [(128, 128), (257, 600), (40, 300)]):
+        sls = [c[1] for c in cases]
+        kc2, vc2, bt2 = _make_paged(sls, hkv, d, bs)
+        qsl = [0]
+        for ql, _ in cases:
+            qsl.append(qsl[-1] + ql)
+        q2 = _rand(qsl[-1], hq, d)
+        qsl_t = torch.tensor(qsl, device=DEV, dtype=torch.int32)
+        sl2 = torch.tensor(sls, device=DEV, dtype=torch.int32)
+        ref2 = torch_ref.paged_attention(q2.float(), kc2.float(), vc2.float(), bt2, qsl_t, sl2, scale, None, window, cap)
+        got2 = ops.paged_attention(q2, kc2, vc2, bt2, qsl_t, sl2, scale, max(c[0] for c in cases), max(sls),
+                                   window=window, softcap=cap)
+        torch.testing.assert_close(got2.float(), ref2, rtol=3e-2, atol=3e-2)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_argmax(dtype):
     logits = _rand(9, 128256, dtype=dtype)

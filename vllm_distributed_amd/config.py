@@ -279,7 +279,7 @@ class ModelConfig:
         return {"llama": "LlamaForCausalLM", "opt": "OPTForCausalLM",
                 "qwen3_moe": "Qwen3MoeForCausalLM", "qwen2": "Qwen2ForCausalLM",
                 "qwen2_moe": "Qwen2MoeForCausalLM", "phi": "PhiForCausalLM",
-                "gemma3_text": "Gemma3ForCausalLM",
+                "gemma3_text": "Gemma3ForCausalLM", "gemma2": "Gemma2ForCausalLM",
                 "qwen3": "Qwen3ForCausalLM", "mistral": "MistralForCausalLM",
                 "mixtral": "MixtralForCausalLM", "phi3": "Phi3ForCausalLM"}.get(mt, mt)
 

@@ -60,7 +60,8 @@ class Attention(nn.Module):
     KERNEL_HEAD_DIMS = (64, 96, 128, 256)
 
     def __init__(self, num_heads: int, head_dim: int, num_kv_heads: int, scale: float,
-                 layer_idx: int, sliding_window: Optional[int] = None, pad_head_dim: bool = False):
+                 layer_idx: int, sliding_window: Optional[int] = None, pad_head_dim: bool = False,
+                 softcap: Optional[float] = None):
         super().__init__()
         # ``pad_head_dim`` (callers of ``forward`` only): a head size the attention kernels are not
         # built for (Phi-2's 80) is zero-padded to the next one they are; ``head_dim`` is then the
@@ -73,6 +74,8 @@ class Attention(nn.Module):
         self.scale = scale
         # a query sees its last `window` keys only (0 = the whole context)
         self.window = int(sliding_window or 0)
+        # scores squashed to softcap * tanh(score / softcap) before the softmax (Gemma-2); 0 = off
+        self.softcap = float(softcap or 0.0)
         self.layer_idx = layer_idx
         self.k_cache: Optional[torch.Tensor] = None
         self.v_cache: Optional[torch.Tensor] = None
@@ -104,13 +107,14 @@ class Attention(nn.Module):
             ops.paged_attention_decode(
                 qv[:nd], self.k_cache, self.v_cache, md.block_table[:md.num_decodes],
                 md.seq_lens[:md.num_decodes], self.scale, md.max_decode_seq_len,
-                out=out[:nd], workspace=md.decode_workspace, kv_scales=self.kv_scales, window=self.window)
+                out=out[:nd], workspace=md.decode_workspace, kv_scales=self.kv_scales, window=self.window,
+                softcap=self.softcap)
         if md.num_prefills > 0:
             ops.paged_attention(
                 qv[nd:], self.k_cache, self.v_cache, md.block_table[md.num_decodes:],
                 md.prefill_query_start_loc, md.seq_lens[md.num_decodes:], self.scale,
                 md.max_prefill_query_len, md.max_seq_len, out=out[nd:], kv_scales=self.kv_scales,
-                window=self.window)
+                window=self.window, softcap=self.softcap)
         return out.view(t, self.num_heads * self.head_dim)
 
     def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:

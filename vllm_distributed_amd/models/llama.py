@@ -67,7 +67,7 @@ class LlamaAttention(nn.Module):
         # Granite scales the scores by ``attention_multiplier`` instead of 1 / sqrt(head_dim)
         scale = cfg.get("attention_multiplier") or self.head_dim ** -0.5
         self.attn = Attention(self.num_heads, self.head_dim, self.num_kv_heads, float(scale), layer_idx,
-                              layer_sliding_window(cfg, layer_idx))
+                              layer_sliding_window(cfg, layer_idx), softcap=cfg.get("attn_logit_softcapping"))
 
     def forward(self, positions: torch.Tensor, hidden: torch.Tensor, reduce: bool = True,
                 staged: bool = False, residual: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:

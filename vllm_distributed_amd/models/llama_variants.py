@@ -5,6 +5,7 @@
 * Granite: four multipliers - on the embedding output, on each residual branch (folded into the
   ``o_proj`` / ``down_proj`` weights at load, so the fused add + norm kernels stay as they are), on the
   attention scores (``attention_multiplier`` replaces ``1 / sqrt(head_dim)``) and a divisor on the logits.
+* Gemma-2: Gemma-3's layer shape without the q/k norms and with tanh caps on attention scores and logits.
 * Gemma-3 (text): Gemma's constants plus per-head q/k RMSNorm, a norm on the OUTPUT of the attention and
   of the MLP branch as well as on their inputs, sliding-window layers with their own rotary base next to
   global ones, ``query_pre_attn_scalar ** -0.5`` as the score scale and an optional tanh cap on the logits.
@@ -79,6 +80,19 @@ class Gemma3DecoderLayer(nn.Module):
         stream = stream + self.post_attention_layernorm(a)
         m = self.mlp(self.pre_feedforward_layernorm(stream))
         return None, stream + self.post_feedforward_layernorm(m)
+
+
+class Gemma2ForCausalLM(GemmaForCausalLM):
+    """Gemma-2: norms on both sides of each branch like Gemma-3, no q/k norms, one rotary base for the
+    alternating sliding-window and global layers, tanh caps on the attention scores
+    (``attn_logit_softcapping``, applied inside the attention kernels) and on the logits."""
+    layer_cls = Gemma3DecoderLayer
+    tp_fusions = False
+
+    def compute_logits(self, hidden: torch.Tensor) -> torch.Tensor:
+        y = super().compute_logits(hidden)
+        cap = self.cfg.get("final_logit_softcapping")
+        return y if not cap else torch.tanh(y.float() / float(cap)).mul_(float(cap)).to(y.dtype)
 
 
 class Gemma3ForCausalLM(GemmaForCausalLM):

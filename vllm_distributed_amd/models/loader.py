@@ -158,7 +158,7 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
         if c.get("model_type") in ("qwen3", "qwen3_moe", "gemma3_text"):
             shapes[q + "self_attn.q_norm.weight"] = (hd,)
             shapes[q + "self_attn.k_norm.weight"] = (hd,)
-        if c.get("model_type") == "gemma3_text":
+        if c.get("model_type") in ("gemma3_text", "gemma2"):
             shapes[q + "pre_feedforward_layernorm.weight"] = (h,)
             shapes[q + "post_feedforward_layernorm.weight"] = (h,)
         shapes[q + "input_layernorm.weight"] = (h,)

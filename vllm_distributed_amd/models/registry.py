@@ -17,6 +17,7 @@ _MODELS: Dict[str, Tuple[str, str]] = {
     "PhiForCausalLM": ("phi", "PhiForCausalLM"),
     "OPTForCausalLM": ("opt", "OPTForCausalLM"),
     "GemmaForCausalLM": ("llama_variants", "GemmaForCausalLM"),
+    "Gemma2ForCausalLM": ("llama_variants", "Gemma2ForCausalLM"),
     "Gemma3ForCausalLM": ("llama_variants", "Gemma3ForCausalLM"),
     "GraniteForCausalLM": ("llama_variants", "GraniteForCausalLM"),
     "GPT2LMHeadModel": ("gpt2", "GPT2LMHeadModel"),

@@ -106,12 +106,14 @@ def rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping
 
 
 def paged_attention(q, k_cache, v_cache, block_table, query_start_loc, seq_lens, scale,
-                    max_query_len: int = 0, max_seq_len: int = 0, out=None, kv_scales=None, window: int = 0):
+                    max_query_len: int = 0, max_seq_len: int = 0, out=None, kv_scales=None, window: int = 0,
+                    softcap: float = 0.0):
     if _use_hip(q) and _hip.supports_head_dim(q.shape[-1]):
         return _hip.paged_attention_prefill(q, k_cache, v_cache, block_table, query_start_loc,
-                                            seq_lens, scale, max_query_len, max_seq_len, out, kv_scales, window)
+                                            seq_lens, scale, max_query_len, max_seq_len, out, kv_scales, window,
+                                            softcap)
     res = torch_ref.paged_attention(q, k_cache, v_cache, block_table, query_start_loc,
-                                    seq_lens, scale, kv_scales, window)
+                                    seq_lens, scale, kv_scales, window, softcap)
     if out is not None:
         out.copy_(res)
         return out
@@ -119,11 +121,14 @@ def paged_attention(q, k_cache, v_cache, block_table, query_start_loc, seq_lens,
 
 
 def paged_attention_decode(q, k_cache, v_cache, block_table, seq_lens, scale,
-                           max_seq_len: int = 0, out=None, workspace=None, kv_scales=None, window: int = 0):
+                           max_seq_len: int = 0, out=None, workspace=None, kv_scales=None, window: int = 0,
+                           softcap: float = 0.0):
     if _use_hip(q) and _hip.supports_head_dim(q.shape[-1]):
         return _hip.paged_attention_decode(q, k_cache, v_cache, block_table, seq_lens, scale,
-                                           max_seq_len, out, workspace, kv_scales=kv_scales, window=window)
-    res = torch_ref.paged_attention_decode(q, k_cache, v_cache, block_table, seq_lens, scale, kv_scales, window)
+                                           max_seq_len, out, workspace, kv_scales=kv_scales, window=window,
+                                           softcap=softcap)
+    res = torch_ref.paged_attention_decode(q, k_cache, v_cache, block_table, seq_lens, scale, kv_scales, window,
+                                           softcap)
     if out is not None:
         out.copy_(res)
         return out

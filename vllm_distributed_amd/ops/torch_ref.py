@@ -215,12 +215,14 @@ def _gather_kv(k_cache, v_cache, block_table_row, seq_len, kv_scales=None):
 
 def paged_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                     block_table: torch.Tensor, query_start_loc: torch.Tensor,
-                    seq_lens: torch.Tensor, scale: float, kv_scales=None, window: int = 0) -> torch.Tensor:
+                    seq_lens: torch.Tensor, scale: float, kv_scales=None, window: int = 0,
+                    softcap: float = 0.0) -> torch.Tensor:
     """Causal attention of each sequence's query chunk against its paged KV
     (which already contains the chunk).  ``q[T, Hq, D]``; sequence ``i`` owns
     query rows ``query_start_loc[i]:query_start_loc[i+1]`` which are the last
     ``q_len`` positions of its ``seq_lens[i]`` tokens.  ``window > 0``: a query at
-    position ``p`` sees keys ``p - window + 1 .. p`` only (sliding-window attention)."""
+    position ``p`` sees keys ``p - window + 1 .. p`` only (sliding-window attention).
+    ``softcap > 0``: scores are squashed to ``softcap * tanh(score / softcap)`` (Gemma-2)."""
     out = torch.empty_like(q)
     hq = q.shape[1]
     hkv = k_cache.shape[1]
@@ -237,6 +239,8 @@ def paged_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tenso
         v = v.float().repeat_interleave(g, dim=0)
         qi = q[s:e].float().transpose(0, 1)                     # [Hq, ql, D]
         scores = torch.matmul(qi, k.transpose(1, 2)) * scale    # [Hq, ql, sl]
+        if softcap > 0:
+            scores = torch.tanh(scores / softcap) * softcap
         qpos = torch.arange(sl - ql, sl, device=q.device).unsqueeze(1)
         kpos = torch.arange(sl, device=q.device).unsqueeze(0)
         scores = scores.masked_fill(kpos > qpos, float("-inf"))
@@ -248,10 +252,10 @@ def paged_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tenso
 
 def paged_attention_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                            block_table: torch.Tensor, seq_lens: torch.Tensor,
-                           scale: float, kv_scales=None, window: int = 0) -> torch.Tensor:
+                           scale: float, kv_scales=None, window: int = 0, softcap: float = 0.0) -> torch.Tensor:
     b = q.shape[0]
     qsl = torch.arange(b + 1, device=q.device, dtype=torch.int32)
-    return paged_attention(q, k_cache, v_cache, block_table, qsl, seq_lens, scale, kv_scales, window)
+    return paged_attention(q, k_cache, v_cache, block_table, qsl, seq_lens, scale, kv_scales, window, softcap)
 
 
 # ---------------------------------------------------------------- sampling
