@@ -50,6 +50,11 @@ CASES = {
     "gemma2": ("Gemma2Config", dict(BASE, head_dim=32, sliding_window=16, query_pre_attn_scalar=24,
                                     num_hidden_layers=3, attn_logit_softcapping=5.0, final_logit_softcapping=20.0,
                                     layer_types=["sliding_attention", "full_attention", "sliding_attention"])),
+    # rotary embedding over adjacent pairs (and, GLM, over half of every head, with q / k / v biases and a fused
+    # gate_up weight): folded into the row order of q_proj / k_proj at load
+    "helium": ("HeliumConfig", dict(BASE, head_dim=16)),
+    "ernie4_5": ("Ernie4_5Config", dict(BASE, use_bias=True)),
+    "glm": ("GlmConfig", dict(BASE, head_dim=16, pad_token_id=0)),
     "phi": ("PhiConfig", dict(BASE, partial_rotary_factor=0.5, layer_norm_eps=1e-5)),
     # Phi-2's head size of 80: padded to 96 for the cache and the attention kernels
     "phi-head80": ("PhiConfig", dict(BASE, hidden_size=320, num_key_value_heads=4, partial_rotary_factor=0.4)),

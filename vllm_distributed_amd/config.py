@@ -97,6 +97,9 @@ def normalize_hf_config(cfg: Dict[str, Any]) -> None:
         cfg["num_local_experts"] = cfg["num_experts"]
     if "torch_dtype" not in cfg and isinstance(cfg.get("dtype"), str):
         cfg["torch_dtype"] = cfg["dtype"]
+    if cfg.get("model_type") == "ernie4_5" and cfg.get("use_bias") is not None:
+        cfg.setdefault("attention_bias", bool(cfg["use_bias"]))      # one switch for every linear layer
+        cfg.setdefault("mlp_bias", bool(cfg["use_bias"]))
     rp = cfg.get("rope_parameters")
     if isinstance(rp, dict):
         if "rope_theta" in rp and cfg.get("rope_theta") is None:
@@ -280,6 +283,7 @@ class ModelConfig:
                 "qwen3_moe": "Qwen3MoeForCausalLM", "qwen2": "Qwen2ForCausalLM",
                 "qwen2_moe": "Qwen2MoeForCausalLM", "phi": "PhiForCausalLM",
                 "gemma3_text": "Gemma3ForCausalLM", "gemma2": "Gemma2ForCausalLM",
+                "helium": "HeliumForCausalLM", "ernie4_5": "Ernie4_5ForCausalLM", "glm": "GlmForCausalLM",
                 "qwen3": "Qwen3ForCausalLM", "mistral": "MistralForCausalLM",
                 "mixtral": "MixtralForCausalLM", "phi3": "Phi3ForCausalLM"}.get(mt, mt)
 

@@ -22,6 +22,38 @@ from .layers.linear import (ColumnParallelLinear, ParallelLMHead, QKVParallelLin
 from .utils import IntermediateTensors, get_pp_layer_range, materialize
 
 
+# families whose rotary embedding pairs ADJACENT dimensions (2i, 2i + 1) instead of (i, i + d/2)
+INTERLEAVED_ROPE_TYPES = ("helium", "ernie4_5", "glm")
+
+
+def rope_row_permutation(head_dim: int, rotary_dim: int, interleaved: bool) -> Optional[torch.Tensor]:
+    """Row order of one head of ``q_proj`` / ``k_proj`` under which a rotary embedding over the first
+    ``rotary_dim`` dimensions, pairing adjacent (``interleaved``) or half-apart dimensions, becomes the
+    full-width half-apart rotation the fused rotary kernel applies: new row ``j`` is old row
+    ``perm[j]``.  Scores ``q . k`` do not change when q and k are permuted alike, so this is a pure
+    change of basis done once, on the weights; the cos / sin table gets cos = 1, sin = 0 for the
+    pairs that are not rotated (``padded_cos_sin``).  None when nothing has to move."""
+    rd, d = rotary_dim, head_dim
+    if rd == d and not interleaved:
+        return None
+    first = [2 * i for i in range(rd // 2)] if interleaved else list(range(rd // 2))
+    second = [2 * i + 1 for i in range(rd // 2)] if interleaved else list(range(rd // 2, rd))
+    rest = list(range(rd, d))
+    keep = len(rest) // 2
+    return torch.tensor(first + rest[:keep] + second + rest[keep:], dtype=torch.long)
+
+
+def padded_cos_sin(table: torch.Tensor, head_dim: int) -> torch.Tensor:
+    """``[max_pos, rotary_dim]`` (cos | sin) -> ``[max_pos, head_dim]`` with identity rotations appended."""
+    rd = table.shape[1]
+    if rd == head_dim:
+        return table
+    extra = (head_dim - rd) // 2
+    cos, sin = table[:, :rd // 2], table[:, rd // 2:]
+    one, zero = torch.ones(table.shape[0], extra), torch.zeros(table.shape[0], extra)
+    return torch.cat([cos, one, sin, zero], dim=1).contiguous()
+
+
 class LlamaMLP(nn.Module):
     def __init__(self, hidden: int, inter: int, dtype: torch.dtype, bias: bool = False, act: str = "silu"):
         super().__init__()
@@ -53,8 +85,9 @@ class LlamaAttention(nn.Module):
         self.head_dim = cfg.get("head_dim") or hidden // heads
         bias = bool(cfg.get("attention_bias", False)) or cfg.get("model_type") in ("qwen2", "qwen2_moe")
         self.qkv_proj = QKVParallelLinear(hidden, self.head_dim, heads, kv_heads, bias, dtype)
+        # (GLM biases q / k / v only)
         self.o_proj = RowParallelLinear(heads * self.head_dim, hidden,
-                                        bool(cfg.get("attention_bias", False)), dtype)
+                                        bool(cfg.get("attention_bias", False)) and cfg.get("model_type") != "glm", dtype)
         self.num_heads = self.qkv_proj.num_heads
         self.num_kv_heads = self.qkv_proj.num_kv_heads
         self.q_size, self.kv_size = self.qkv_proj.q_size, self.qkv_proj.kv_size
@@ -172,9 +205,15 @@ class LlamaForCausalLM(nn.Module):
         self.start_layer, self.end_layer = get_pp_layer_range(
             n_layers, pp.rank_in_group, pp.world_size, vllm_config.parallel_config.pp_layer_partition)
         head_dim = cfg.get("head_dim") or cfg["hidden_size"] // cfg["num_attention_heads"]
+        rotary_dim = int(head_dim * float(cfg.get("partial_rotary_factor") or 1.0))
+        self.rope_perm = rope_row_permutation(head_dim, rotary_dim, cfg.get("model_type") in INTERLEAVED_ROPE_TYPES)
+        if self.rope_perm is not None and mc.quantization in ("awq", "nvfp4"):
+            raise NotImplementedError("packed 4-bit q/k projections of a model with an interleaved or partial rotary "
+                                      "embedding cannot be re-ordered at load")
+        self.head_dim = head_dim
         cos_sin = ops.build_cos_sin_cache(head_dim, mc.max_model_len, cfg.get("rope_theta", 10000.0),
-                                          cfg.get("rope_scaling"))
-        self.register_buffer("cos_sin_cache", cos_sin, persistent=False)
+                                          cfg.get("rope_scaling"), rotary_dim=rotary_dim)
+        self.register_buffer("cos_sin_cache", padded_cos_sin(cos_sin, head_dim), persistent=False)
         tie = bool(cfg.get("tie_word_embeddings", False))
         if self.is_first or (tie and self.is_last):
             self.embed_tokens = VocabParallelEmbedding(cfg["vocab_size"], cfg["hidden_size"], dtype,
@@ -472,6 +511,11 @@ class LlamaForCausalLM(nn.Module):
                 if renamed is None:
                     continue
                 name, w = renamed
+            if self.rope_perm is not None and (".q_proj." in name or ".k_proj." in name) \
+                    and name.endswith((".weight", ".bias")):
+                # re-order the rows of every head into the basis the rotary kernel works in
+                t = materialize(w)
+                w = t.reshape(-1, self.head_dim, *t.shape[1:]).index_select(1, self.rope_perm).reshape(t.shape)
             w = self.transform_weight(name, w)
             if name.endswith((".k_scale", ".v_scale")) and ".self_attn." in name:
                 # per-tensor scales of an fp8 KV cache (read only when the cache is e4m3)

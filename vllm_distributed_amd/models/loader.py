@@ -186,7 +186,7 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
                 shapes[q + f"block_sparse_moe.experts.{e}.w1.weight"] = (inter, h)
                 shapes[q + f"block_sparse_moe.experts.{e}.w3.weight"] = (inter, h)
                 shapes[q + f"block_sparse_moe.experts.{e}.w2.weight"] = (h, inter)
-        elif phi3:      # [gate | up] fused
+        elif phi3 or arch == "GlmForCausalLM":      # [gate | up] fused
             shapes[q + "mlp.gate_up_proj.weight"] = (2 * inter, h)
             shapes[q + "mlp.down_proj.weight"] = (h, inter)
         else:

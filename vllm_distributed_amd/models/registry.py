@@ -9,6 +9,11 @@ _MODELS: Dict[str, Tuple[str, str]] = {
     "MistralForCausalLM": ("llama", "LlamaForCausalLM"),
     "Qwen2ForCausalLM": ("llama", "LlamaForCausalLM"),
     "Qwen3ForCausalLM": ("llama", "LlamaForCausalLM"),
+    # Llama-shaped with a rotary embedding over adjacent pairs (and, GLM, over half of each head):
+    # folded into a row order of q_proj / k_proj at load (llama.rope_row_permutation)
+    "HeliumForCausalLM": ("llama", "LlamaForCausalLM"),
+    "Ernie4_5ForCausalLM": ("llama", "LlamaForCausalLM"),
+    "GlmForCausalLM": ("llama", "LlamaForCausalLM"),
     "Qwen3MoeForCausalLM": ("qwen3_moe", "Qwen3MoeForCausalLM"),
     "Qwen2MoeForCausalLM": ("qwen2_moe", "Qwen2MoeForCausalLM"),
     "MixtralForCausalLM": ("mixtral", "MixtralForCausalLM"),
