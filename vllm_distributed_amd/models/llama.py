@@ -50,7 +50,8 @@ def padded_cos_sin(table: torch.Tensor, head_dim: int) -> torch.Tensor:
         return table
     extra = (head_dim - rd) // 2
     cos, sin = table[:, :rd // 2], table[:, rd // 2:]
-    one, zero = torch.ones(table.shape[0], extra), torch.zeros(table.shape[0], extra)
+    one = torch.ones(table.shape[0], extra, dtype=table.dtype, device=table.device)
+    zero = torch.zeros_like(one)
     return torch.cat([cos, one, sin, zero], dim=1).contiguous()
 
 
@@ -515,7 +516,7 @@ class LlamaForCausalLM(nn.Module):
                     and name.endswith((".weight", ".bias")):
                 # re-order the rows of every head into the basis the rotary kernel works in
                 t = materialize(w)
-                w = t.reshape(-1, self.head_dim, *t.shape[1:]).index_select(1, self.rope_perm).reshape(t.shape)
+                w = t.reshape(-1, self.head_dim, *t.shape[1:]).index_select(1, self.rope_perm.to(t.device)).reshape(t.shape)
             w = self.transform_weight(name, w)
             if name.endswith((".k_scale", ".v_scale")) and ".self_attn." in name:
                 # per-tensor scales of an fp8 KV cache (read only when the cache is e4m3)
