@@ -589,3 +589,26 @@ def test_gptq_checkpoint_is_the_same_model_as_its_awq_twin(tmp_path):
     with pytest.raises(NotImplementedError, match="desc_act"):
         LLM(model=f"{bad}/gptq", device="cpu", dtype="float32", max_model_len=128, num_gpu_blocks_override=64)
     pstate.destroy_model_parallel()
+
+
+def test_a_checkpoint_that_lacks_a_parameter_is_refused(tmp_path):
+    """Every parameter must come from the checkpoint: a file without one layer's
+    norm weight must fail the load by name, not run on uninitialised memory."""
+    import json
+    from safetensors.torch import load_file, save_file
+    from vllm_distributed_amd.config import ModelConfig
+    from vllm_distributed_amd.models.loader import save_dummy_checkpoint
+    mc = ModelConfig(model="llama-tiny", dtype="float32", load_format="dummy")
+    src = tmp_path / "full"
+    save_dummy_checkpoint(mc, str(src))
+    sd = load_file(str(src / "model.safetensors"))
+    gone = "model.layers.1.post_attention_layernorm.weight"
+    assert gone in sd
+    dst = tmp_path / "holed"
+    dst.mkdir()
+    save_file({k: v.contiguous() for k, v in sd.items() if k != gone}, str(dst / "model.safetensors"))
+    (dst / "config.json").write_text(json.dumps(mc.hf_config))
+    with pytest.raises(Exception, match="post_attention_layernorm"):
+        LLM(model=str(dst), device="cpu", dtype="float32", max_model_len=128, block_size=16,
+            num_gpu_blocks_override=64, max_num_seqs=8)
+    pstate.destroy_model_parallel()

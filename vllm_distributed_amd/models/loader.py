@@ -414,6 +414,24 @@ def _with_progress(items: Iterable, what: str, every: float = 20.0) -> Iterator:
 
 
 # ------------------------------------------------------------------- entry
+_POISONABLE = (torch.float32, torch.float16, torch.bfloat16)
+
+
+def _poison(model: torch.nn.Module) -> None:
+    for p in model.parameters():
+        if p.dtype in _POISONABLE:
+            p.data.fill_(float("nan"))
+
+
+def _check_filled(model: torch.nn.Module, what: str) -> None:
+    missing = [n for n, p in model.named_parameters()
+               if p.dtype in _POISONABLE and p.numel() and bool(torch.isnan(p.data.view(-1)[:1]).item())
+               and bool(torch.isnan(p.data).all().item())]
+    if missing:
+        raise RuntimeError(f"{what}: {len(missing)} parameter(s) were not found in the checkpoint: "
+                           + ", ".join(missing[:8]) + (" ..." if len(missing) > 8 else ""))
+
+
 def load_model(vllm_config: VllmConfig, device: torch.device) -> torch.nn.Module:
     mc = vllm_config.model_config
     cls = get_model_class(mc.architecture)
@@ -421,6 +439,9 @@ def load_model(vllm_config: VllmConfig, device: torch.device) -> torch.nn.Module
         model = cls(vllm_config)
     model.rebind_buffers()
     model.eval()
+    # parameters are allocated uninitialised; mark them, so that one the checkpoint never fills
+    # (a bias the config promised, a norm with another name) is an error and not silent garbage
+    _poison(model)
 
     def want(name: str) -> bool:
         mapped = model.map_weight_name(name)
@@ -433,6 +454,7 @@ def load_model(vllm_config: VllmConfig, device: torch.device) -> torch.nn.Module
         from ..parallel.state import get_world_group
         n = load_sharded_state(model, path, get_world_group().rank, vllm_config)
         logger.info("loaded %d tensors of this rank's shard from %s", n, path)
+        _check_filled(model, mc.model)
         return model
     if mc.load_format == "dummy" or path is None:
         if mc.load_format != "dummy":       # "auto" without weights was settled (or refused) by ModelConfig
@@ -449,6 +471,7 @@ def load_model(vllm_config: VllmConfig, device: torch.device) -> torch.nn.Module
         mods = [m for m in model.modules() if getattr(m, "finalize_weights", None) is not None]
         for m in _with_progress(mods, "modules finalised"):      # repack quantised shards into the kernel layout
             m.finalize_weights()
+    _check_filled(model, mc.model)
     logger.info("loaded %d checkpoint tensors for %s (layers %d-%d, format=%s)", len(loaded),
                 mc.model, getattr(model, "start_layer", 0), getattr(model, "end_layer", 0),
                 mc.load_format if path is None else "safetensors")
