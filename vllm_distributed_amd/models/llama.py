@@ -23,7 +23,11 @@ from .utils import IntermediateTensors, get_pp_layer_range, materialize
 
 
 # families whose rotary embedding pairs ADJACENT dimensions (2i, 2i + 1) instead of (i, i + d/2)
-INTERLEAVED_ROPE_TYPES = ("helium", "ernie4_5", "glm")
+INTERLEAVED_ROPE_TYPES = ("helium", "ernie4_5", "glm", "glm4", "cohere")
+# families with an RMSNorm over each head of q and k before the rotation ...
+HEAD_QK_NORM_TYPES = ("qwen3", "qwen3_moe", "gemma3_text", "exaone4")
+# ... and with one over the whole width of the q and of the k projection
+FULL_QK_NORM_TYPES = ("olmo2", "olmo3")
 
 
 def rope_row_permutation(head_dim: int, rotary_dim: int, interleaved: bool) -> Optional[torch.Tensor]:
@@ -53,6 +57,37 @@ def padded_cos_sin(table: torch.Tensor, head_dim: int) -> torch.Tensor:
     one = torch.ones(table.shape[0], extra, dtype=table.dtype, device=table.device)
     zero = torch.zeros_like(one)
     return torch.cat([cos, one, sin, zero], dim=1).contiguous()
+
+
+def identity_cos_sin(table: torch.Tensor) -> torch.Tensor:
+    """A cos / sin table of ``table``'s shape that rotates nothing: what layers without a positional
+    embedding hand to the fused rotary + cache kernel."""
+    half = table.shape[1] // 2
+    out = torch.zeros_like(table)
+    out[:, :half] = 1
+    return out
+
+
+class FullWidthRMSNorm(nn.Module):
+    """RMSNorm over the whole q (or k) projection, all heads together (OLMo-2).  Under tensor
+    parallelism a rank holds ``width`` of the columns: the sum of squares is all-reduced, and counted
+    ``1 / replicas`` on each rank when KV heads are replicated."""
+
+    def __init__(self, width: int, total_width: int, shard_index: int, replicas: int, eps: float, dtype: torch.dtype):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(width, dtype=dtype), requires_grad=False)
+        self.weight.weight_loader = self._load
+        self.width, self.total, self.index, self.replicas, self.eps = width, total_width, shard_index, replicas, eps
+
+    def _load(self, param: nn.Parameter, w, shard_id=None) -> None:
+        param.data.copy_(materialize(w.narrow(0, self.index * self.width, self.width)))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        xf = x.float()
+        ss = xf.pow(2).sum(-1, keepdim=True)
+        if self.total != self.width:
+            ss = get_tp_group().all_reduce(ss / self.replicas)
+        return (xf * torch.rsqrt(ss / self.total + self.eps)).to(x.dtype) * self.weight
 
 
 class LlamaMLP(nn.Module):
@@ -86,18 +121,26 @@ class LlamaAttention(nn.Module):
         self.head_dim = cfg.get("head_dim") or hidden // heads
         bias = bool(cfg.get("attention_bias", False)) or cfg.get("model_type") in ("qwen2", "qwen2_moe")
         self.qkv_proj = QKVParallelLinear(hidden, self.head_dim, heads, kv_heads, bias, dtype)
-        # (GLM biases q / k / v only)
-        self.o_proj = RowParallelLinear(heads * self.head_dim, hidden,
-                                        bool(cfg.get("attention_bias", False)) and cfg.get("model_type") != "glm", dtype)
+        # (GLM biases q / k / v only; Seed-OSS says which in the config)
+        o_bias = cfg.get("attention_out_bias")
+        if o_bias is None:
+            o_bias = bool(cfg.get("attention_bias", False)) and cfg.get("model_type") not in ("glm", "glm4")
+        self.o_proj = RowParallelLinear(heads * self.head_dim, hidden, bool(o_bias), dtype)
         self.num_heads = self.qkv_proj.num_heads
         self.num_kv_heads = self.qkv_proj.num_kv_heads
         self.q_size, self.kv_size = self.qkv_proj.q_size, self.qkv_proj.kv_size
         self.cos_sin = cos_sin
-        self.qk_norm = cfg.get("model_type") in ("qwen3", "qwen3_moe", "gemma3_text")
+        self.qk_norm = cfg.get("model_type") in HEAD_QK_NORM_TYPES
+        self.qk_norm_full = cfg.get("model_type") in FULL_QK_NORM_TYPES
+        eps = cfg.get("rms_norm_eps", 1e-6)
         if self.qk_norm:
-            eps = cfg.get("rms_norm_eps", 1e-6)
             self.q_norm = RMSNorm(self.head_dim, eps, dtype)
             self.k_norm = RMSNorm(self.head_dim, eps, dtype)
+        elif self.qk_norm_full:
+            qp = self.qkv_proj
+            self.q_norm = FullWidthRMSNorm(qp.q_size, heads * self.head_dim, qp.tp_rank, 1, eps, dtype)
+            self.k_norm = FullWidthRMSNorm(qp.kv_size, kv_heads * self.head_dim, qp.tp_rank // qp.kv_replicas,
+                                           qp.kv_replicas, eps, dtype)
         # Granite scales the scores by ``attention_multiplier`` instead of 1 / sqrt(head_dim)
         scale = cfg.get("attention_multiplier") or self.head_dim ** -0.5
         self.attn = Attention(self.num_heads, self.head_dim, self.num_kv_heads, float(scale), layer_idx,
@@ -120,6 +163,11 @@ class LlamaAttention(nn.Module):
             q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
             q = self.q_norm(q.reshape(t * self.num_heads, self.head_dim)).view(t, self.q_size)
             k = self.k_norm(k.reshape(t * self.num_kv_heads, self.head_dim)).view(t, self.kv_size)
+            ops.rotary_embedding(positions, q, k, self.cos_sin, self.head_dim)
+            out = self.attn(q, k, v)
+        elif self.qk_norm_full:
+            q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+            q, k = self.q_norm(q).contiguous(), self.k_norm(k).contiguous()
             ops.rotary_embedding(positions, q, k, self.cos_sin, self.head_dim)
             out = self.attn(q, k, v)
         elif md is None:
@@ -227,7 +275,7 @@ class LlamaForCausalLM(nn.Module):
                 str(i): self.layer_cls(cfg, i, dtype, self.cos_sin_cache)
                 for i in range(self.start_layer, self.end_layer)})
         if self.is_last:
-            self.norm = RMSNorm(cfg["hidden_size"], cfg.get("rms_norm_eps", 1e-5), dtype)
+            self.norm = self.make_final_norm(cfg, dtype)
             if tie:
                 self.lm_head = None
             else:
@@ -242,6 +290,9 @@ class LlamaForCausalLM(nn.Module):
     def transform_weight(self, name: str, w):
         """Checkpoint tensor -> the tensor this implementation wants under the (mapped) ``name``."""
         return w
+
+    def make_final_norm(self, cfg: dict, dtype: torch.dtype) -> nn.Module:
+        return RMSNorm(cfg["hidden_size"], cfg.get("rms_norm_eps", 1e-5), dtype)
 
     def rebind_buffers(self) -> None:
         """After ``.to(device)`` the layers must see the moved cos/sin table."""
