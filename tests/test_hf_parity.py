@@ -62,6 +62,22 @@ CASES = {
     "qwen2-moe": ("Qwen2MoeConfig", dict(BASE, moe_intermediate_size=64, shared_expert_intermediate_size=96,
                                          num_experts=8, num_experts_per_tok=2, norm_topk_prob=False,
                                          decoder_sparse_step=1, mlp_only_layers=[1])),
+    # --- families that are Llama's layer with norms, biases, MLP or positional embedding changed
+    "smollm3": ("SmolLM3Config", dict(BASE, num_hidden_layers=3, no_rope_layers=[1, 0, 1], pad_token_id=0)),
+    "seed-oss": ("SeedOssConfig", dict(BASE, head_dim=32, attention_bias=True, attention_out_bias=False,
+                                       pad_token_id=0, bos_token_id=1, eos_token_id=2)),
+    "ministral": ("MinistralConfig", dict(BASE, head_dim=16, sliding_window=16,
+                                          layer_types=["sliding_attention", "full_attention"])),
+    "arcee": ("ArceeConfig", dict(BASE, mlp_bias=True)),
+    "glm4": ("Glm4Config", dict(BASE, head_dim=16, pad_token_id=0)),
+    "olmo2": ("Olmo2Config", dict(BASE, pad_token_id=0)),
+    "olmo3": ("Olmo3Config", dict(BASE, num_hidden_layers=3, sliding_window=16, pad_token_id=0,
+                                  layer_types=["sliding_attention", "full_attention", "sliding_attention"])),
+    "exaone4": ("Exaone4Config", dict(BASE, num_hidden_layers=3, sliding_window=16, pad_token_id=0,
+                                      layer_types=["sliding_attention", "full_attention", "sliding_attention"])),
+    "stablelm": ("StableLmConfig", dict(BASE, use_qkv_bias=True)),
+    "nemotron": ("NemotronConfig", dict(BASE, attention_bias=True, mlp_bias=True)),
+    "cohere": ("CohereConfig", dict(BASE, logit_scale=0.25, pad_token_id=0)),
 }
 PROMPTS = [[5, 9, 200, 17, 33, 2, 90], list(range(10, 60)), [7, 7, 300, 2, 2, 41, 8, 100, 101]]
 

@@ -284,6 +284,11 @@ class ModelConfig:
                 "qwen2_moe": "Qwen2MoeForCausalLM", "phi": "PhiForCausalLM",
                 "gemma3_text": "Gemma3ForCausalLM", "gemma2": "Gemma2ForCausalLM",
                 "helium": "HeliumForCausalLM", "ernie4_5": "Ernie4_5ForCausalLM", "glm": "GlmForCausalLM",
+                "seed_oss": "SeedOssForCausalLM", "ministral": "MinistralForCausalLM",
+                "smollm3": "SmolLM3ForCausalLM", "arcee": "ArceeForCausalLM", "glm4": "Glm4ForCausalLM",
+                "olmo2": "Olmo2ForCausalLM", "olmo3": "Olmo3ForCausalLM", "exaone4": "Exaone4ForCausalLM",
+                "stablelm": "StableLmForCausalLM", "nemotron": "NemotronForCausalLM",
+                "cohere": "CohereForCausalLM",
                 "qwen3": "Qwen3ForCausalLM", "mistral": "MistralForCausalLM",
                 "mixtral": "MixtralForCausalLM", "phi3": "Phi3ForCausalLM"}.get(mt, mt)
 

@@ -137,32 +137,54 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
     moe = arch in ("Qwen3MoeForCausalLM", "Qwen2MoeForCausalLM")
     mixtral = arch == "MixtralForCausalLM"
     phi3 = arch == "Phi3ForCausalLM"
-    qkv_bias = bool(c.get("attention_bias", False)) or c.get("model_type") in ("qwen2", "qwen2_moe")
+    mt = c.get("model_type")
+    qkv_bias = (bool(c.get("attention_bias", False)) or mt in ("qwen2", "qwen2_moe")
+                or (mt == "stablelm" and bool(c.get("use_qkv_bias", False))))
+    o_bias = c.get("attention_out_bias")
+    if o_bias is None:
+        o_bias = bool(c.get("attention_bias", False)) and mt not in ("glm", "glm4")
+    mlp_bias = bool(c.get("mlp_bias", False))
+    norm_bias = mt in ("stablelm", "nemotron")              # LayerNorm families
+    # which norms a layer has, by family
+    norms = {"gemma2": 4, "gemma3_text": 4}.get(mt) and (
+        "input_layernorm", "post_attention_layernorm", "pre_feedforward_layernorm", "post_feedforward_layernorm")
+    norms = norms or {"glm4": ("input_layernorm", "post_self_attn_layernorm", "post_attention_layernorm",
+                               "post_mlp_layernorm"),
+                      "olmo2": ("post_attention_layernorm", "post_feedforward_layernorm"),
+                      "olmo3": ("post_attention_layernorm", "post_feedforward_layernorm"),
+                      "exaone4": ("post_attention_layernorm", "post_feedforward_layernorm"),
+                      "cohere": ("input_layernorm",)}.get(mt, ("input_layernorm", "post_attention_layernorm"))
     shapes["model.embed_tokens.weight"] = (c["vocab_size"], h)
     shapes["model.norm.weight"] = (h,)
+    if norm_bias:
+        shapes["model.norm.bias"] = (h,)
     if not c.get("tie_word_embeddings", False):
         shapes["lm_head.weight"] = (c["vocab_size"], h)
+
+    def linear(name: str, out_f: int, in_f: int, bias: bool) -> None:
+        shapes[name + ".weight"] = (out_f, in_f)
+        if bias:
+            shapes[name + ".bias"] = (out_f,)
+
     for i in range(L):
         q = f"model.layers.{i}."
         if phi3:        # checkpoint stores [q | k | v] fused
             shapes[q + "self_attn.qkv_proj.weight"] = ((heads + 2 * kvh) * hd, h)
         else:
-            shapes[q + "self_attn.q_proj.weight"] = (heads * hd, h)
-            shapes[q + "self_attn.k_proj.weight"] = (kvh * hd, h)
-            shapes[q + "self_attn.v_proj.weight"] = (kvh * hd, h)
-        shapes[q + "self_attn.o_proj.weight"] = (h, heads * hd)
-        if qkv_bias:
-            shapes[q + "self_attn.q_proj.bias"] = (heads * hd,)
-            shapes[q + "self_attn.k_proj.bias"] = (kvh * hd,)
-            shapes[q + "self_attn.v_proj.bias"] = (kvh * hd,)
-        if c.get("model_type") in ("qwen3", "qwen3_moe", "gemma3_text"):
+            linear(q + "self_attn.q_proj", heads * hd, h, qkv_bias)
+            linear(q + "self_attn.k_proj", kvh * hd, h, qkv_bias)
+            linear(q + "self_attn.v_proj", kvh * hd, h, qkv_bias)
+        linear(q + "self_attn.o_proj", h, heads * hd, bool(o_bias))
+        if mt in ("qwen3", "qwen3_moe", "gemma3_text", "exaone4"):
             shapes[q + "self_attn.q_norm.weight"] = (hd,)
             shapes[q + "self_attn.k_norm.weight"] = (hd,)
-        if c.get("model_type") in ("gemma3_text", "gemma2"):
-            shapes[q + "pre_feedforward_layernorm.weight"] = (h,)
-            shapes[q + "post_feedforward_layernorm.weight"] = (h,)
-        shapes[q + "input_layernorm.weight"] = (h,)
-        shapes[q + "post_attention_layernorm.weight"] = (h,)
+        elif mt in ("olmo2", "olmo3"):
+            shapes[q + "self_attn.q_norm.weight"] = (heads * hd,)
+            shapes[q + "self_attn.k_norm.weight"] = (kvh * hd,)
+        for n in norms:
+            shapes[q + n + ".weight"] = (h,)
+            if norm_bias:
+                shapes[q + n + ".bias"] = (h,)
         step = c.get("decoder_sparse_step", 1)
         sparse = moe and c.get("num_experts", 0) > 0 and i not in c.get("mlp_only_layers", []) \
             and (i + 1) % step == 0
@@ -186,13 +208,14 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
                 shapes[q + f"block_sparse_moe.experts.{e}.w1.weight"] = (inter, h)
                 shapes[q + f"block_sparse_moe.experts.{e}.w3.weight"] = (inter, h)
                 shapes[q + f"block_sparse_moe.experts.{e}.w2.weight"] = (h, inter)
-        elif phi3 or arch == "GlmForCausalLM":      # [gate | up] fused
+        elif phi3 or mt in ("glm", "glm4"):      # [gate | up] fused
             shapes[q + "mlp.gate_up_proj.weight"] = (2 * inter, h)
             shapes[q + "mlp.down_proj.weight"] = (h, inter)
         else:
-            shapes[q + "mlp.gate_proj.weight"] = (inter, h)
-            shapes[q + "mlp.up_proj.weight"] = (inter, h)
-            shapes[q + "mlp.down_proj.weight"] = (h, inter)
+            if mt not in ("arcee", "nemotron"):  # (those: no gate)
+                linear(q + "mlp.gate_proj", inter, h, mlp_bias)
+            linear(q + "mlp.up_proj", inter, h, mlp_bias)
+            linear(q + "mlp.down_proj", h, inter, mlp_bias)
     return shapes
 
 

@@ -25,6 +25,18 @@ _MODELS: Dict[str, Tuple[str, str]] = {
     "Gemma2ForCausalLM": ("llama_variants", "Gemma2ForCausalLM"),
     "Gemma3ForCausalLM": ("llama_variants", "Gemma3ForCausalLM"),
     "GraniteForCausalLM": ("llama_variants", "GraniteForCausalLM"),
+    # Llama's layer with other bias switches (attention_out_bias) / a window per layer_types entry
+    "SeedOssForCausalLM": ("llama", "LlamaForCausalLM"),
+    "MinistralForCausalLM": ("llama", "LlamaForCausalLM"),
+    "SmolLM3ForCausalLM": ("llama_variants", "SmolLM3ForCausalLM"),
+    "ArceeForCausalLM": ("llama_variants", "ArceeForCausalLM"),
+    "Glm4ForCausalLM": ("llama_variants", "Glm4ForCausalLM"),
+    "Olmo2ForCausalLM": ("llama_variants", "Olmo2ForCausalLM"),
+    "Olmo3ForCausalLM": ("llama_variants", "Olmo3ForCausalLM"),
+    "Exaone4ForCausalLM": ("llama_variants", "Exaone4ForCausalLM"),
+    "StableLmForCausalLM": ("llama_variants", "StableLmForCausalLM"),
+    "NemotronForCausalLM": ("llama_variants", "NemotronForCausalLM"),
+    "CohereForCausalLM": ("llama_variants", "CohereForCausalLM"),
     "GPT2LMHeadModel": ("gpt2", "GPT2LMHeadModel"),
     "GPTNeoXForCausalLM": ("gpt_neox", "GPTNeoXForCausalLM"),
     "Starcoder2ForCausalLM": ("starcoder2", "Starcoder2ForCausalLM"),

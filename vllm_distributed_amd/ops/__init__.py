@@ -192,6 +192,8 @@ def activation(x, kind: str):
         return torch.nn.functional.silu(x)
     if kind == "relu":
         return torch.relu(x)
+    if kind == "relu2":
+        return torch.relu(x).square_()
     if kind in _GELU_KINDS:
         return torch.nn.functional.gelu(x, approximate=_GELU_KINDS[kind])
     raise ValueError(f"unsupported activation {kind!r}")
