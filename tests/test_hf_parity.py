@@ -70,6 +70,9 @@ CASES = {
                                           layer_types=["sliding_attention", "full_attention"])),
     "arcee": ("ArceeConfig", dict(BASE, mlp_bias=True)),
     "glm4": ("Glm4Config", dict(BASE, head_dim=16, pad_token_id=0)),
+    "olmo": ("OlmoConfig", dict(BASE, clip_qkv=0.6, pad_token_id=0)),
+    "olmoe": ("OlmoeConfig", dict(BASE, intermediate_size=64, num_experts=8, num_experts_per_tok=2, clip_qkv=1.5,
+                                  pad_token_id=0)),
     "olmo2": ("Olmo2Config", dict(BASE, pad_token_id=0)),
     "olmo3": ("Olmo3Config", dict(BASE, num_hidden_layers=3, sliding_window=16, pad_token_id=0,
                                   layer_types=["sliding_attention", "full_attention", "sliding_attention"])),

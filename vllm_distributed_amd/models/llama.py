@@ -27,7 +27,7 @@ INTERLEAVED_ROPE_TYPES = ("helium", "ernie4_5", "glm", "glm4", "cohere")
 # families with an RMSNorm over each head of q and k before the rotation ...
 HEAD_QK_NORM_TYPES = ("qwen3", "qwen3_moe", "gemma3_text", "exaone4")
 # ... and with one over the whole width of the q and of the k projection
-FULL_QK_NORM_TYPES = ("olmo2", "olmo3")
+FULL_QK_NORM_TYPES = ("olmo2", "olmo3", "olmoe")
 
 
 def rope_row_permutation(head_dim: int, rotary_dim: int, interleaved: bool) -> Optional[torch.Tensor]:
@@ -130,6 +130,7 @@ class LlamaAttention(nn.Module):
         self.num_kv_heads = self.qkv_proj.num_kv_heads
         self.q_size, self.kv_size = self.qkv_proj.q_size, self.qkv_proj.kv_size
         self.cos_sin = cos_sin
+        self.clip_qkv = float(cfg["clip_qkv"]) if cfg.get("clip_qkv") else None      # OLMo: clamp on q, k and v
         self.qk_norm = cfg.get("model_type") in HEAD_QK_NORM_TYPES
         self.qk_norm_full = cfg.get("model_type") in FULL_QK_NORM_TYPES
         eps = cfg.get("rms_norm_eps", 1e-6)
@@ -151,6 +152,8 @@ class LlamaAttention(nn.Module):
         """With ``residual``: None is returned when the output projection added its product into it."""
         qkv = self.qkv_proj(hidden)
         md = get_forward_context().attn_metadata
+        if self.clip_qkv is not None and not self.qk_norm_full:
+            qkv = qkv.clamp_(-self.clip_qkv, self.clip_qkv)
         if self.qk_norm and md is not None and self.attn.k_cache is not None:
             # per-head RMSNorm of q and k, rotation and the cache write in one kernel
             q = ops.rope_and_cache(positions, qkv, self.cos_sin, self.attn.k_cache, self.attn.v_cache,
@@ -168,6 +171,8 @@ class LlamaAttention(nn.Module):
         elif self.qk_norm_full:
             q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
             q, k = self.q_norm(q).contiguous(), self.k_norm(k).contiguous()
+            if self.clip_qkv is not None:
+                q, k, v = (t.clamp(-self.clip_qkv, self.clip_qkv) for t in (q, k, v))
             ops.rotary_embedding(positions, q, k, self.cos_sin, self.head_dim)
             out = self.attn(q, k, v)
         elif md is None:

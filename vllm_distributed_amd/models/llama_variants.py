@@ -15,6 +15,7 @@
 * GLM-4: GLM with a norm on the output of each branch as well.
 * OLMo-2 / OLMo-3: norms on the branch OUTPUTS only, RMSNorm over the whole q and k projections;
   OLMo-3's sliding-window layers use the unscaled rotary base.
+* OLMo: LayerNorms without parameters, optional clamp on q / k / v.
 * EXAONE-4: OLMo-2's layer shape with per-head q/k norms; with a sliding window configured, the global
   layers carry no positional embedding.
 * StableLM: LayerNorm (with bias) where Llama has RMSNorm, rotary embedding over a quarter of each head.
@@ -280,6 +281,31 @@ class Exaone4ForCausalLM(_PerLayerRope):
 
 
 # ------------------------------------------------------------------------------------ LayerNorm families
+class PlainLayerNorm(nn.Module):
+    """LayerNorm without weight or bias (OLMo)."""
+
+    def __init__(self, hidden: int, eps: float = 1e-5):
+        super().__init__()
+        self.hidden, self.eps = hidden, eps
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return torch.nn.functional.layer_norm(x.float(), (self.hidden,), None, None, self.eps).to(x.dtype)
+
+
+class OlmoDecoderLayer(BranchNormLayer):
+    def make_norm(self, cfg: dict, dtype: torch.dtype) -> nn.Module:
+        return PlainLayerNorm(cfg["hidden_size"])
+
+
+class OlmoForCausalLM(LlamaForCausalLM):
+    """OLMo (1): Llama with parameter-free LayerNorms and an optional clamp on q / k / v."""
+    layer_cls = OlmoDecoderLayer
+    tp_fusions = False
+
+    def make_final_norm(self, cfg: dict, dtype: torch.dtype) -> nn.Module:
+        return PlainLayerNorm(cfg["hidden_size"])
+
+
 class StableLmDecoderLayer(BranchNormLayer):
     def attention_config(self, cfg: dict) -> dict:
         if cfg.get("qk_layernorm") or cfg.get("use_parallel_residual"):

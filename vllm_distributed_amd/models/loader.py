@@ -134,7 +134,7 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
             shapes[q + "mlp.c_fc.weight"], shapes[q + "mlp.c_fc.bias"] = (inter, h), (inter,)
             shapes[q + "mlp.c_proj.weight"], shapes[q + "mlp.c_proj.bias"] = (h, inter), (h,)
         return shapes
-    moe = arch in ("Qwen3MoeForCausalLM", "Qwen2MoeForCausalLM")
+    moe = arch in ("Qwen3MoeForCausalLM", "Qwen2MoeForCausalLM", "OlmoeForCausalLM")
     mixtral = arch == "MixtralForCausalLM"
     phi3 = arch == "Phi3ForCausalLM"
     mt = c.get("model_type")
@@ -153,9 +153,10 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
                       "olmo2": ("post_attention_layernorm", "post_feedforward_layernorm"),
                       "olmo3": ("post_attention_layernorm", "post_feedforward_layernorm"),
                       "exaone4": ("post_attention_layernorm", "post_feedforward_layernorm"),
-                      "cohere": ("input_layernorm",)}.get(mt, ("input_layernorm", "post_attention_layernorm"))
+                      "cohere": ("input_layernorm",), "olmo": ()}.get(mt, ("input_layernorm", "post_attention_layernorm"))
     shapes["model.embed_tokens.weight"] = (c["vocab_size"], h)
-    shapes["model.norm.weight"] = (h,)
+    if mt != "olmo":
+        shapes["model.norm.weight"] = (h,)
     if norm_bias:
         shapes["model.norm.bias"] = (h,)
     if not c.get("tie_word_embeddings", False):
@@ -178,7 +179,7 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
         if mt in ("qwen3", "qwen3_moe", "gemma3_text", "exaone4"):
             shapes[q + "self_attn.q_norm.weight"] = (hd,)
             shapes[q + "self_attn.k_norm.weight"] = (hd,)
-        elif mt in ("olmo2", "olmo3"):
+        elif mt in ("olmo2", "olmo3", "olmoe"):
             shapes[q + "self_attn.q_norm.weight"] = (heads * hd,)
             shapes[q + "self_attn.k_norm.weight"] = (kvh * hd,)
         for n in norms:
@@ -189,7 +190,7 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
         sparse = moe and c.get("num_experts", 0) > 0 and i not in c.get("mlp_only_layers", []) \
             and (i + 1) % step == 0
         if sparse:
-            mi = c["moe_intermediate_size"]
+            mi = c.get("moe_intermediate_size") or inter
             shapes[q + "mlp.gate.weight"] = (c["num_experts"], h)
             for e in range(c["num_experts"]):
                 shapes[q + f"mlp.experts.{e}.gate_proj.weight"] = (mi, h)

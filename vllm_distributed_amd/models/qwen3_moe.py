@@ -73,3 +73,14 @@ class Qwen3MoeForCausalLM(LlamaForCausalLM):
                 loaded.append(mapped)
         dense = super().load_weights(others())
         return loaded + dense
+
+
+class OlmoeForCausalLM(Qwen3MoeForCausalLM):
+    """OLMoE: every layer sparse, experts of ``intermediate_size``, top-k weights not renormalised by
+    default, RMSNorm over the whole q and k projections (``llama.FullWidthRMSNorm``)."""
+
+    def __init__(self, vllm_config: VllmConfig):
+        cfg = vllm_config.model_config.hf_config
+        cfg.setdefault("moe_intermediate_size", cfg["intermediate_size"])
+        cfg.setdefault("norm_topk_prob", False)
+        super().__init__(vllm_config)

@@ -31,6 +31,8 @@ _MODELS: Dict[str, Tuple[str, str]] = {
     "SmolLM3ForCausalLM": ("llama_variants", "SmolLM3ForCausalLM"),
     "ArceeForCausalLM": ("llama_variants", "ArceeForCausalLM"),
     "Glm4ForCausalLM": ("llama_variants", "Glm4ForCausalLM"),
+    "OlmoForCausalLM": ("llama_variants", "OlmoForCausalLM"),
+    "OlmoeForCausalLM": ("qwen3_moe", "OlmoeForCausalLM"),
     "Olmo2ForCausalLM": ("llama_variants", "Olmo2ForCausalLM"),
     "Olmo3ForCausalLM": ("llama_variants", "Olmo3ForCausalLM"),
     "Exaone4ForCausalLM": ("llama_variants", "Exaone4ForCausalLM"),
