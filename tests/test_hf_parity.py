@@ -70,6 +70,19 @@ CASES = {
                                           layer_types=["sliding_attention", "full_attention"])),
     "arcee": ("ArceeConfig", dict(BASE, mlp_bias=True)),
     "glm4": ("Glm4Config", dict(BASE, head_dim=16, pad_token_id=0)),
+    # multi-head latent attention (low-rank q and kv, one shared rotated key part), a dense first layer, then
+    # routed experts (V3: sigmoid scores + choice bias, group-limited) + shared experts
+    "deepseek-v3": ("DeepseekV3Config", dict(BASE, num_hidden_layers=3, num_key_value_heads=4, q_lora_rank=24, kv_lora_rank=16,
+                                             qk_nope_head_dim=16, qk_rope_head_dim=8, v_head_dim=12,
+                                             moe_intermediate_size=32, n_routed_experts=8, n_shared_experts=2,
+                                             num_experts_per_tok=3, n_group=4, topk_group=2, first_k_dense_replace=1,
+                                             routed_scaling_factor=2.5, norm_topk_prob=True, pad_token_id=0)),
+    "deepseek-v2": ("DeepseekV2Config", dict(BASE, num_hidden_layers=3, q_lora_rank=None, kv_lora_rank=16,
+                                             qk_nope_head_dim=16, qk_rope_head_dim=8, v_head_dim=24,
+                                             moe_intermediate_size=32, n_routed_experts=8, n_shared_experts=1,
+                                             num_experts_per_tok=2, n_group=4, topk_group=2, first_k_dense_replace=1,
+                                             topk_method="group_limited_greedy", routed_scaling_factor=1.5,
+                                             pad_token_id=0)),
     "olmo": ("OlmoConfig", dict(BASE, clip_qkv=0.6, pad_token_id=0)),
     "olmoe": ("OlmoeConfig", dict(BASE, intermediate_size=64, num_experts=8, num_experts_per_tok=2, clip_qkv=1.5,
                                   pad_token_id=0)),
@@ -99,6 +112,9 @@ def _hf_model(name, tmp_path):
         for n, p in model.named_parameters():
             if p.dim() == 1:
                 p.add_(torch.randn_like(p) * 0.1)
+        for n, b in model.named_buffers():
+            if n.endswith("e_score_correction_bias"):       # DeepSeek-V3's choice bias is stored as a buffer
+                b.add_(torch.randn_like(b) * 0.2)
     model.save_pretrained(str(tmp_path), safe_serialization=True)
     return model
 

@@ -1,0 +1,192 @@
+"""DeepSeek-V2 / V3: multi-head latent attention (MLA) and a routed expert mixture with shared experts.
+
+Attention: queries come through an optional low-rank pair ``q_a_proj -> RMSNorm -> q_b_proj``; keys and
+values come from one latent ``kv_a_proj_with_mqa(x) = [c_kv (kv_lora_rank) | k_rope (qk_rope_head_dim)]``:
+``kv_b_proj(RMSNorm(c_kv))`` gives every head its ``k_nope`` and ``v``, and the single rotated ``k_rope``
+is shared by all heads.  This implementation expands the latent to per-head K / V before the cache
+(``[k_nope | k_rope]`` of ``qk_nope + qk_rope`` dims, V zero-padded to the same width, both padded to the
+next size the attention kernels are built for), so the paged attention kernels run unchanged; the price
+is a cache of ``heads x 256`` values per token where a latent cache would hold ``kv_lora_rank + rope``.
+The rotary pairs are adjacent dimensions in these checkpoints: the rope rows of ``q_b_proj`` / ``q_proj``
+and of ``kv_a_proj_with_mqa`` are re-ordered at load so that the half-apart rotation applies.
+
+Routing: V2 takes the top-k of a softmax (optionally within the best ``topk_group`` of ``n_group`` expert
+groups, a group scored by its best expert); V3 scores with a sigmoid, chooses with a per-expert bias
+added (``e_score_correction_bias``; a group scored by the sum of its two best), weights with the unbiased
+scores, renormalises and multiplies by ``routed_scaling_factor``.  ``n_shared_experts`` always-on experts
+are one dense MLP; the first ``first_k_dense_replace`` layers are dense.
+
+Parity is pinned against ``transformers``' DeepseekV2 / DeepseekV3 models (``tests/test_hf_parity.py``).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..config import VllmConfig
+from ..parallel.state import get_tensor_model_parallel_world_size, tensor_model_parallel_all_reduce
+from . import qwen3_moe
+from .layers.attention import Attention, RMSNorm, get_forward_context
+from .layers.linear import ColumnParallelLinear, ReplicatedLinear, RowParallelLinear, divide
+from .layers.moe import FusedMoE
+from .llama import LlamaMLP, rope_row_permutation
+from .qwen3_moe import Qwen3MoeDecoderLayer, Qwen3MoeForCausalLM
+from .utils import materialize
+
+
+def _yarn_mscale(scale: float, mscale: float) -> float:
+    return 1.0 if scale <= 1 else 0.1 * mscale * math.log(scale) + 1.0
+
+
+class MLAAttention(nn.Module):
+    def __init__(self, cfg: dict, layer_idx: int, dtype: torch.dtype, cos_sin: torch.Tensor):
+        super().__init__()
+        hidden, heads = cfg["hidden_size"], cfg["num_attention_heads"]
+        self.nope, self.rope, self.v_dim = cfg["qk_nope_head_dim"], cfg["qk_rope_head_dim"], cfg["v_head_dim"]
+        self.qk_dim = self.nope + self.rope
+        if self.v_dim > self.qk_dim:
+            raise NotImplementedError("value heads wider than the key heads")
+        self.kv_rank, q_rank = cfg["kv_lora_rank"], cfg.get("q_lora_rank")
+        bias = bool(cfg.get("attention_bias", False))
+        tp = get_tensor_model_parallel_world_size()
+        self.num_heads = divide(heads, tp)
+        if q_rank:
+            self.q_a_proj = ReplicatedLinear(hidden, q_rank, bias, dtype)
+            self.q_a_layernorm = RMSNorm(q_rank, 1e-6, dtype)
+            self.q_b_proj = ColumnParallelLinear(q_rank, [heads * self.qk_dim], False, dtype)
+        else:
+            self.q_a_proj = None
+            self.q_proj = ColumnParallelLinear(hidden, [heads * self.qk_dim], False, dtype)
+        self.kv_a_proj_with_mqa = ReplicatedLinear(hidden, self.kv_rank + self.rope, bias, dtype)
+        self.kv_a_layernorm = RMSNorm(self.kv_rank, 1e-6, dtype)
+        self.kv_b_proj = ColumnParallelLinear(self.kv_rank, [heads * (self.nope + self.v_dim)], False, dtype)
+        self.o_proj = RowParallelLinear(heads * self.v_dim, hidden, bias, dtype)
+        scale = self.qk_dim ** -0.5
+        rs = cfg.get("rope_scaling") or {}
+        if rs.get("rope_type", rs.get("type", "default")) != "default" and rs.get("mscale_all_dim"):
+            scale *= _yarn_mscale(float(rs["factor"]), float(rs["mscale_all_dim"])) ** 2
+        self.attn = Attention(self.num_heads, self.qk_dim, self.num_heads, float(scale), layer_idx, pad_head_dim=True)
+        self.cos_sin = cos_sin
+
+    def forward(self, positions: torch.Tensor, hidden: torch.Tensor, reduce: bool = True, staged: bool = False,
+                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        t, h = hidden.shape[0], self.num_heads
+        if self.q_a_proj is not None:
+            q = self.q_b_proj(self.q_a_layernorm(self.q_a_proj(hidden)))
+        else:
+            q = self.q_proj(hidden)
+        q = q.view(t, h, self.qk_dim)
+        latent = self.kv_a_proj_with_mqa(hidden)
+        kv = self.kv_b_proj(self.kv_a_layernorm(latent[:, :self.kv_rank].contiguous())).view(t, h, self.nope + self.v_dim)
+        q_rot = q[..., self.nope:].reshape(t, h * self.rope)
+        k_rot = latent[:, self.kv_rank:].contiguous()
+        ops.rotary_embedding(positions, q_rot, k_rot, self.cos_sin, self.rope)
+        q = torch.cat([q[..., :self.nope], q_rot.view(t, h, self.rope)], dim=-1)
+        k = torch.cat([kv[..., :self.nope], k_rot.view(t, 1, self.rope).expand(t, h, self.rope)], dim=-1)
+        v = F.pad(kv[..., self.nope:], (0, self.qk_dim - self.v_dim))
+        out = self.attn(q.reshape(t, -1), k.reshape(t, -1), v.reshape(t, -1))
+        out = out.view(t, h, self.qk_dim)[..., :self.v_dim].reshape(t, h * self.v_dim)
+        return self.o_proj(out, reduce, staged)
+
+
+class DeepseekMoE(FusedMoE):
+    """Routed experts + shared experts under one all-reduce; DeepSeek's routing rules."""
+    custom_routing = True
+
+    def __init__(self, cfg: dict, dtype: torch.dtype, expert_parallel: bool):
+        n = cfg.get("n_routed_experts") or cfg.get("num_experts") or cfg["num_local_experts"]
+        super().__init__(cfg["hidden_size"], cfg["moe_intermediate_size"], n, cfg["num_experts_per_tok"],
+                         bool(cfg.get("norm_topk_prob", False)), dtype, expert_parallel=expert_parallel)
+        self.v3 = cfg.get("model_type") == "deepseek_v3"
+        self.n_group, self.topk_group = int(cfg.get("n_group") or 1), int(cfg.get("topk_group") or 1)
+        self.grouped = self.v3 or cfg.get("topk_method") == "group_limited_greedy"
+        self.scaling = float(cfg.get("routed_scaling_factor") or 1.0)
+        if self.v3:
+            self.gate.e_score_correction_bias = nn.Parameter(torch.zeros(n, dtype=torch.float32), requires_grad=False)
+        shared = int(cfg.get("n_shared_experts") or 0)
+        self.shared_experts = LlamaMLP(cfg["hidden_size"], cfg["moe_intermediate_size"] * shared, dtype) if shared else None
+
+    def _group_mask(self, scores: torch.Tensor, group_scores: torch.Tensor) -> torch.Tensor:
+        idx = group_scores.topk(self.topk_group, dim=-1).indices
+        mask = torch.zeros_like(group_scores, dtype=torch.bool).scatter_(1, idx, True)
+        return mask.unsqueeze(-1).expand(-1, self.n_group, self.num_experts // self.n_group).reshape(scores.shape)
+
+    def route(self, logits: torch.Tensor):
+        if self.v3:
+            scores = logits.sigmoid()
+            choice = scores + self.gate.e_score_correction_bias
+            per_group = choice.view(-1, self.n_group, self.num_experts // self.n_group)
+            mask = self._group_mask(scores, per_group.topk(min(2, per_group.shape[-1]), dim=-1).values.sum(-1))
+            topi = choice.masked_fill(~mask, float("-inf")).topk(self.top_k, dim=-1).indices
+            topw = scores.gather(1, topi)
+            if self.renormalize:
+                topw = topw / (topw.sum(-1, keepdim=True) + 1e-20)
+        else:
+            scores = torch.softmax(logits, dim=-1)
+            if self.grouped:
+                per_group = scores.view(-1, self.n_group, self.num_experts // self.n_group)
+                scores = scores.masked_fill(~self._group_mask(scores, per_group.max(-1).values), 0.0)
+            topw, topi = scores.topk(self.top_k, dim=-1)
+        return topw * self.scaling, topi
+
+    def forward(self, x: torch.Tensor, reduce: bool = True, staged: bool = False) -> torch.Tensor:
+        out = super().forward(x, reduce=False)
+        if self.shared_experts is not None:
+            out = out + self.shared_experts(x, reduce=False)
+        if reduce and get_tensor_model_parallel_world_size() > 1:
+            out = tensor_model_parallel_all_reduce(out)
+        return out
+
+
+class DeepseekDecoderLayer(Qwen3MoeDecoderLayer):
+    def _make_attn(self, cfg: dict, layer_idx: int, dtype: torch.dtype, cos_sin: torch.Tensor) -> nn.Module:
+        return MLAAttention(cfg, layer_idx, dtype, cos_sin)
+
+    def _make_mlp(self, cfg: dict, dtype: torch.dtype) -> nn.Module:
+        n = cfg.get("n_routed_experts") or cfg.get("num_experts") or cfg.get("num_local_experts")
+        dense = (not n or self._layer_idx < int(cfg.get("first_k_dense_replace") or 0)
+                 or self._layer_idx % int(cfg.get("moe_layer_freq") or 1) != 0)
+        if dense:
+            return LlamaMLP(cfg["hidden_size"], cfg["intermediate_size"], dtype)
+        return DeepseekMoE(cfg, dtype, qwen3_moe._EP)
+
+
+class DeepseekV2ForCausalLM(Qwen3MoeForCausalLM):
+    layer_cls = DeepseekDecoderLayer
+    # the MLA block has its own projections: nothing of Llama's q / k / v stacking applies
+    stacked_params = [(".gate_proj", ".gate_up_proj", 0), (".up_proj", ".gate_up_proj", 1)]
+
+    def __init__(self, vllm_config: VllmConfig):
+        cfg = vllm_config.model_config.hf_config
+        cfg["head_dim"] = cfg["qk_rope_head_dim"]           # what the cos / sin table spans
+        if vllm_config.model_config.quantization in ("awq", "nvfp4"):
+            raise NotImplementedError("4-bit DeepSeek checkpoints (the rope rows of packed projections cannot be "
+                                      "re-ordered at load)")
+        super().__init__(vllm_config)
+        interleaved = cfg.get("model_type") == "deepseek_v2" or bool(cfg.get("rope_interleave", True))
+        self.mla_perm = rope_row_permutation(cfg["qk_rope_head_dim"], cfg["qk_rope_head_dim"], interleaved)
+
+    def transform_weight(self, name: str, w):
+        if self.mla_perm is None or not name.endswith((".weight", ".bias")):
+            return w
+        nope, rope = self.cfg["qk_nope_head_dim"], self.cfg["qk_rope_head_dim"]
+        if ".self_attn.q_b_proj." in name or ".self_attn.q_proj." in name:
+            t = materialize(w)
+            per_head = t.reshape(-1, nope + rope, *t.shape[1:])
+            perm = torch.cat([torch.arange(nope), nope + self.mla_perm]).to(t.device)
+            return per_head.index_select(1, perm).reshape(t.shape)
+        if ".self_attn.kv_a_proj_with_mqa." in name:
+            t = materialize(w)
+            rank = self.cfg["kv_lora_rank"]
+            perm = torch.cat([torch.arange(rank), rank + self.mla_perm]).to(t.device)
+            return t.index_select(0, perm)
+        return w
+
+
+class DeepseekV3ForCausalLM(DeepseekV2ForCausalLM):
+    pass

@@ -247,20 +247,28 @@ class FusedMoE(nn.Module):
         y = self._experts_grouped(x.index_select(0, src_row), tiles, tile_rows)
         return ops.moe_combine(y, topw, topi, inv, self.expert_start, local)
 
-    def forward(self, x: torch.Tensor, reduce: bool = True, staged: bool = False) -> torch.Tensor:
-        # `staged` (write the partial sums where the next direct all-reduce reads) is a hint only
-        logits = self.gate(x)
-        tile_rows = self._grouped_tile_rows(x)
-        if tile_rows and x.dim() == 2 and ops.moe_route_fused_ok(logits, self.num_experts, self.top_k):
-            out = self._forward_fused_routing(x, logits, tile_rows)
-            if reduce and self.tp > 1:
-                out = tensor_model_parallel_all_reduce(out)
-            return out
-        logits = logits.float()
+    # True in subclasses that override ``route``: the fused top-k kernel (softmax routing) is skipped
+    custom_routing = False
+
+    def route(self, logits: torch.Tensor):
+        """Router logits ``[T, E]`` (fp32) -> (weights ``[T, k]`` fp32, expert ids ``[T, k]``)."""
         probs = torch.softmax(logits, dim=-1)
         topw, topi = probs.topk(self.top_k, dim=-1)
         if self.renormalize:
             topw = topw / topw.sum(-1, keepdim=True)
+        return topw, topi
+
+    def forward(self, x: torch.Tensor, reduce: bool = True, staged: bool = False) -> torch.Tensor:
+        # `staged` (write the partial sums where the next direct all-reduce reads) is a hint only
+        logits = self.gate(x)
+        tile_rows = self._grouped_tile_rows(x)
+        if (tile_rows and x.dim() == 2 and not self.custom_routing
+                and ops.moe_route_fused_ok(logits, self.num_experts, self.top_k)):
+            out = self._forward_fused_routing(x, logits, tile_rows)
+            if reduce and self.tp > 1:
+                out = tensor_model_parallel_all_reduce(out)
+            return out
+        topw, topi = self.route(logits.float())
         topw = topw.to(x.dtype)
         if tile_rows:
             out = self._forward_grouped(x, topw, topi, tile_rows)

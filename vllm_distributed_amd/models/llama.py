@@ -192,10 +192,13 @@ class LlamaDecoderLayer(nn.Module):
     def __init__(self, cfg: dict, layer_idx: int, dtype: torch.dtype, cos_sin: torch.Tensor):
         super().__init__()
         eps = cfg.get("rms_norm_eps", 1e-5)
-        self.self_attn = LlamaAttention(cfg, layer_idx, dtype, cos_sin)
+        self.self_attn = self._make_attn(cfg, layer_idx, dtype, cos_sin)
         self.mlp = self._make_mlp(cfg, dtype)
         self.input_layernorm = RMSNorm(cfg["hidden_size"], eps, dtype)
         self.post_attention_layernorm = RMSNorm(cfg["hidden_size"], eps, dtype)
+
+    def _make_attn(self, cfg: dict, layer_idx: int, dtype: torch.dtype, cos_sin: torch.Tensor) -> nn.Module:
+        return LlamaAttention(cfg, layer_idx, dtype, cos_sin)
 
     def _make_mlp(self, cfg: dict, dtype: torch.dtype) -> nn.Module:
         act = cfg.get("hidden_activation") or cfg.get("hidden_act") or "silu"

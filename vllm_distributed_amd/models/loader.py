@@ -134,6 +134,53 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
             shapes[q + "mlp.c_fc.weight"], shapes[q + "mlp.c_fc.bias"] = (inter, h), (inter,)
             shapes[q + "mlp.c_proj.weight"], shapes[q + "mlp.c_proj.bias"] = (h, inter), (h,)
         return shapes
+    if arch in ("DeepseekV2ForCausalLM", "DeepseekV3ForCausalLM"):
+        nope, rope, vd, rank = c["qk_nope_head_dim"], c["qk_rope_head_dim"], c["v_head_dim"], c["kv_lora_rank"]
+        ab = bool(c.get("attention_bias", False))
+        ne = c.get("n_routed_experts") or c.get("num_experts") or c.get("num_local_experts") or 0
+        mi = c.get("moe_intermediate_size", 0)
+        shapes["model.embed_tokens.weight"] = (c["vocab_size"], h)
+        shapes["model.norm.weight"] = (h,)
+        if not c.get("tie_word_embeddings", False):
+            shapes["lm_head.weight"] = (c["vocab_size"], h)
+
+        def lin(name: str, out_f: int, in_f: int, bias: bool = False) -> None:
+            shapes[name + ".weight"] = (out_f, in_f)
+            if bias:
+                shapes[name + ".bias"] = (out_f,)
+
+        for i in range(L):
+            q = f"model.layers.{i}."
+            a = q + "self_attn."
+            if c.get("q_lora_rank"):
+                lin(a + "q_a_proj", c["q_lora_rank"], h, ab)
+                shapes[a + "q_a_layernorm.weight"] = (c["q_lora_rank"],)
+                lin(a + "q_b_proj", heads * (nope + rope), c["q_lora_rank"])
+            else:
+                lin(a + "q_proj", heads * (nope + rope), h)
+            lin(a + "kv_a_proj_with_mqa", rank + rope, h, ab)
+            shapes[a + "kv_a_layernorm.weight"] = (rank,)
+            lin(a + "kv_b_proj", heads * (nope + vd), rank)
+            lin(a + "o_proj", h, heads * vd, ab)
+            shapes[q + "input_layernorm.weight"] = shapes[q + "post_attention_layernorm.weight"] = (h,)
+            dense = not ne or i < int(c.get("first_k_dense_replace") or 0) or i % int(c.get("moe_layer_freq") or 1)
+            if dense:
+                for n, (o, k) in (("gate_proj", (inter, h)), ("up_proj", (inter, h)), ("down_proj", (h, inter))):
+                    lin(q + "mlp." + n, o, k)
+                continue
+            shapes[q + "mlp.gate.weight"] = (ne, h)
+            if c.get("model_type") == "deepseek_v3":
+                shapes[q + "mlp.gate.e_score_correction_bias"] = (ne,)
+            for e in range(ne):
+                lin(q + f"mlp.experts.{e}.gate_proj", mi, h)
+                lin(q + f"mlp.experts.{e}.up_proj", mi, h)
+                lin(q + f"mlp.experts.{e}.down_proj", h, mi)
+            ns = int(c.get("n_shared_experts") or 0)
+            if ns:
+                lin(q + "mlp.shared_experts.gate_proj", mi * ns, h)
+                lin(q + "mlp.shared_experts.up_proj", mi * ns, h)
+                lin(q + "mlp.shared_experts.down_proj", h, mi * ns)
+        return shapes
     moe = arch in ("Qwen3MoeForCausalLM", "Qwen2MoeForCausalLM", "OlmoeForCausalLM")
     mixtral = arch == "MixtralForCausalLM"
     phi3 = arch == "Phi3ForCausalLM"

@@ -16,6 +16,8 @@ _MODELS: Dict[str, Tuple[str, str]] = {
     "GlmForCausalLM": ("llama", "LlamaForCausalLM"),
     "Qwen3MoeForCausalLM": ("qwen3_moe", "Qwen3MoeForCausalLM"),
     "Qwen2MoeForCausalLM": ("qwen2_moe", "Qwen2MoeForCausalLM"),
+    "DeepseekV2ForCausalLM": ("deepseek", "DeepseekV2ForCausalLM"),
+    "DeepseekV3ForCausalLM": ("deepseek", "DeepseekV3ForCausalLM"),
     "MixtralForCausalLM": ("mixtral", "MixtralForCausalLM"),
     # Phi-3 checkpoints store qkv and gate/up already fused: the fused loaders take them whole
     "Phi3ForCausalLM": ("llama", "LlamaForCausalLM"),

@@ -1016,8 +1016,9 @@ class ModelRunner:
         if not (cc.use_hip_graph and envs.VDAMD_USE_HIP_GRAPH):
             self.graph_fallback_reason = "disabled (enforce_eager / VDAMD_USE_HIP_GRAPH=0)"
             return
-        if not ops.hip_supports_head_dim(self.model_config.head_dim):
-            self.graph_fallback_reason = f"no HIP attention kernel for head_dim {self.model_config.head_dim}"
+        kernel_head_dim = self.model.attention_layers()[0].head_dim      # (padded to a kernel size where needed)
+        if not ops.hip_supports_head_dim(kernel_head_dim):
+            self.graph_fallback_reason = f"no HIP attention kernel for head_dim {kernel_head_dim}"
             logger.info("hipGraph decode capture needs the HIP attention kernels (head_dim 64 or 128): "
                         "running eagerly")
             return
