@@ -83,6 +83,16 @@ CASES = {
                                              num_experts_per_tok=2, n_group=4, topk_group=2, first_k_dense_replace=1,
                                              topk_method="group_limited_greedy", routed_scaling_factor=1.5,
                                              pad_token_id=0)),
+    # V3's expert block behind grouped-query attention (GLM-4.5: half-rotated heads, q/k norms, q/k/v biases)
+    "glm4-moe": ("Glm4MoeConfig", dict(BASE, num_hidden_layers=3, head_dim=16, use_qk_norm=True, attention_bias=True,
+                                       moe_intermediate_size=32, n_routed_experts=8, n_shared_experts=1,
+                                       num_experts_per_tok=2, n_group=2, topk_group=1, first_k_dense_replace=1,
+                                       routed_scaling_factor=1.5, norm_topk_prob=True, pad_token_id=0)),
+    "dots1": ("Dots1Config", dict(BASE, num_hidden_layers=3, head_dim=16, moe_intermediate_size=32,
+                                  n_routed_experts=8, n_shared_experts=1, num_experts_per_tok=2, n_group=2,
+                                  topk_group=1, first_k_dense_replace=1, routed_scaling_factor=1.5,
+                                  norm_topk_prob=True, pad_token_id=0, sliding_window=16,
+                                  layer_types=["full_attention", "sliding_attention", "full_attention"])),
     "olmo": ("OlmoConfig", dict(BASE, clip_qkv=0.6, pad_token_id=0)),
     "olmoe": ("OlmoeConfig", dict(BASE, intermediate_size=64, num_experts=8, num_experts_per_tok=2, clip_qkv=1.5,
                                   pad_token_id=0)),

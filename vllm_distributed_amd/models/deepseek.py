@@ -16,6 +16,9 @@ added (``e_score_correction_bias``; a group scored by the sum of its two best), 
 scores, renormalises and multiplies by ``routed_scaling_factor``.  ``n_shared_experts`` always-on experts
 are one dense MLP; the first ``first_k_dense_replace`` layers are dense.
 
+GLM-4.5 (``Glm4MoeForCausalLM``) and dots.llm1 (``Dots1ForCausalLM``) put V3's expert block behind ordinary
+grouped-query attention.
+
 Parity is pinned against ``transformers``' DeepseekV2 / DeepseekV3 models (``tests/test_hf_parity.py``).
 """
 from __future__ import annotations
@@ -37,6 +40,10 @@ from .layers.moe import FusedMoE
 from .llama import LlamaMLP, rope_row_permutation
 from .qwen3_moe import Qwen3MoeDecoderLayer, Qwen3MoeForCausalLM
 from .utils import materialize
+
+
+# model types that route the way DeepSeek-V3 does
+V3_ROUTING_TYPES = ("deepseek_v3", "glm4_moe", "dots1")
 
 
 def _yarn_mscale(scale: float, mscale: float) -> float:
@@ -102,7 +109,7 @@ class DeepseekMoE(FusedMoE):
         n = cfg.get("n_routed_experts") or cfg.get("num_experts") or cfg["num_local_experts"]
         super().__init__(cfg["hidden_size"], cfg["moe_intermediate_size"], n, cfg["num_experts_per_tok"],
                          bool(cfg.get("norm_topk_prob", False)), dtype, expert_parallel=expert_parallel)
-        self.v3 = cfg.get("model_type") == "deepseek_v3"
+        self.v3 = cfg.get("model_type") in V3_ROUTING_TYPES
         self.n_group, self.topk_group = int(cfg.get("n_group") or 1), int(cfg.get("topk_group") or 1)
         self.grouped = self.v3 or cfg.get("topk_method") == "group_limited_greedy"
         self.scaling = float(cfg.get("routed_scaling_factor") or 1.0)
@@ -190,3 +197,18 @@ class DeepseekV2ForCausalLM(Qwen3MoeForCausalLM):
 
 class DeepseekV3ForCausalLM(DeepseekV2ForCausalLM):
     pass
+
+
+class V3RoutedDecoderLayer(Qwen3MoeDecoderLayer):
+    """Llama's attention (with the family's own switches) + DeepSeek-V3's expert block."""
+    _make_mlp = DeepseekDecoderLayer._make_mlp
+
+
+class Glm4MoeForCausalLM(Qwen3MoeForCausalLM):
+    """GLM-4.5: rotary embedding over half of each head, optional per-head q/k norms, q/k/v biases."""
+    layer_cls = V3RoutedDecoderLayer
+
+
+class Dots1ForCausalLM(Qwen3MoeForCausalLM):
+    """dots.llm1: Qwen3's attention (per-head q/k norms), windows per ``layer_types``."""
+    layer_cls = V3RoutedDecoderLayer

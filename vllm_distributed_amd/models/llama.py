@@ -24,10 +24,17 @@ from .utils import IntermediateTensors, get_pp_layer_range, materialize
 
 # families whose rotary embedding pairs ADJACENT dimensions (2i, 2i + 1) instead of (i, i + d/2)
 INTERLEAVED_ROPE_TYPES = ("helium", "ernie4_5", "glm", "glm4", "cohere")
+# families whose ``attention_bias`` means q / k / v only
+NO_O_BIAS_TYPES = ("glm", "glm4", "glm4_moe")
 # families with an RMSNorm over each head of q and k before the rotation ...
-HEAD_QK_NORM_TYPES = ("qwen3", "qwen3_moe", "gemma3_text", "exaone4")
+HEAD_QK_NORM_TYPES = ("qwen3", "qwen3_moe", "gemma3_text", "exaone4", "dots1")
 # ... and with one over the whole width of the q and of the k projection
 FULL_QK_NORM_TYPES = ("olmo2", "olmo3", "olmoe")
+
+
+def has_head_qk_norm(cfg: dict) -> bool:
+    return cfg.get("model_type") in HEAD_QK_NORM_TYPES or (cfg.get("model_type") == "glm4_moe"
+                                                             and bool(cfg.get("use_qk_norm")))
 
 
 def rope_row_permutation(head_dim: int, rotary_dim: int, interleaved: bool) -> Optional[torch.Tensor]:
@@ -124,14 +131,14 @@ class LlamaAttention(nn.Module):
         # (GLM biases q / k / v only; Seed-OSS says which in the config)
         o_bias = cfg.get("attention_out_bias")
         if o_bias is None:
-            o_bias = bool(cfg.get("attention_bias", False)) and cfg.get("model_type") not in ("glm", "glm4")
+            o_bias = bool(cfg.get("attention_bias", False)) and cfg.get("model_type") not in NO_O_BIAS_TYPES
         self.o_proj = RowParallelLinear(heads * self.head_dim, hidden, bool(o_bias), dtype)
         self.num_heads = self.qkv_proj.num_heads
         self.num_kv_heads = self.qkv_proj.num_kv_heads
         self.q_size, self.kv_size = self.qkv_proj.q_size, self.qkv_proj.kv_size
         self.cos_sin = cos_sin
         self.clip_qkv = float(cfg["clip_qkv"]) if cfg.get("clip_qkv") else None      # OLMo: clamp on q, k and v
-        self.qk_norm = cfg.get("model_type") in HEAD_QK_NORM_TYPES
+        self.qk_norm = has_head_qk_norm(cfg)
         self.qk_norm_full = cfg.get("model_type") in FULL_QK_NORM_TYPES
         eps = cfg.get("rms_norm_eps", 1e-6)
         if self.qk_norm:
@@ -571,9 +578,11 @@ class LlamaForCausalLM(nn.Module):
                 if renamed is None:
                     continue
                 name, w = renamed
-            if self.rope_perm is not None and (".q_proj." in name or ".k_proj." in name) \
-                    and name.endswith((".weight", ".bias")):
-                # re-order the rows of every head into the basis the rotary kernel works in
+            if self.rope_perm is not None and name.endswith((".weight", ".bias")) and (
+                    ".q_proj." in name or ".k_proj." in name
+                    or (name.endswith((".q_norm.weight", ".k_norm.weight")) and has_head_qk_norm(self.cfg))):
+                # re-order the rows of every head (and the per-head norm weights that act on them) into the
+                # basis the rotary kernel works in
                 t = materialize(w)
                 w = t.reshape(-1, self.head_dim, *t.shape[1:]).index_select(1, self.rope_perm.to(t.device)).reshape(t.shape)
             w = self.transform_weight(name, w)

@@ -223,7 +223,7 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
             linear(q + "self_attn.k_proj", kvh * hd, h, qkv_bias)
             linear(q + "self_attn.v_proj", kvh * hd, h, qkv_bias)
         linear(q + "self_attn.o_proj", h, heads * hd, bool(o_bias))
-        if mt in ("qwen3", "qwen3_moe", "gemma3_text", "exaone4"):
+        if mt in ("qwen3", "qwen3_moe", "gemma3_text", "exaone4", "dots1") or (mt == "glm4_moe" and c.get("use_qk_norm")):
             shapes[q + "self_attn.q_norm.weight"] = (hd,)
             shapes[q + "self_attn.k_norm.weight"] = (hd,)
         elif mt in ("olmo2", "olmo3", "olmoe"):
@@ -236,7 +236,18 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
         step = c.get("decoder_sparse_step", 1)
         sparse = moe and c.get("num_experts", 0) > 0 and i not in c.get("mlp_only_layers", []) \
             and (i + 1) % step == 0
-        if sparse:
+        v3_routed = mt in ("glm4_moe", "dots1") and i >= int(c.get("first_k_dense_replace") or 0)
+        if v3_routed:
+            mi, ne, ns = c["moe_intermediate_size"], c["n_routed_experts"], int(c.get("n_shared_experts") or 0)
+            shapes[q + "mlp.gate.weight"], shapes[q + "mlp.gate.e_score_correction_bias"] = (ne, h), (ne,)
+            for e in range(ne):
+                linear(q + f"mlp.experts.{e}.gate_proj", mi, h, False)
+                linear(q + f"mlp.experts.{e}.up_proj", mi, h, False)
+                linear(q + f"mlp.experts.{e}.down_proj", h, mi, False)
+            for n, (o, k) in (("gate_proj", (mi * ns, h)), ("up_proj", (mi * ns, h)), ("down_proj", (h, mi * ns))):
+                if ns:
+                    linear(q + "mlp.shared_experts." + n, o, k, False)
+        elif sparse:
             mi = c.get("moe_intermediate_size") or inter
             shapes[q + "mlp.gate.weight"] = (c["num_experts"], h)
             for e in range(c["num_experts"]):

@@ -18,6 +18,8 @@ _MODELS: Dict[str, Tuple[str, str]] = {
     "Qwen2MoeForCausalLM": ("qwen2_moe", "Qwen2MoeForCausalLM"),
     "DeepseekV2ForCausalLM": ("deepseek", "DeepseekV2ForCausalLM"),
     "DeepseekV3ForCausalLM": ("deepseek", "DeepseekV3ForCausalLM"),
+    "Glm4MoeForCausalLM": ("deepseek", "Glm4MoeForCausalLM"),
+    "Dots1ForCausalLM": ("deepseek", "Dots1ForCausalLM"),
     "MixtralForCausalLM": ("mixtral", "MixtralForCausalLM"),
     # Phi-3 checkpoints store qkv and gate/up already fused: the fused loaders take them whole
     "Phi3ForCausalLM": ("llama", "LlamaForCausalLM"),
