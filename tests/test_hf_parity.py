@@ -39,6 +39,14 @@ CASES = {
     "gpt-neox-serial": ("GPTNeoXConfig", dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2,
                                               num_attention_heads=4, vocab_size=320, max_position_embeddings=128,
                                               rotary_pct=0.25, use_parallel_residual=False)),
+    "gpt-bigcode": ("GPTBigCodeConfig", dict(n_embd=64, n_layer=2, n_head=4, vocab_size=320, n_positions=128,
+                                             multi_query=True)),
+    "gptj": ("GPTJConfig", dict(n_embd=64, n_layer=2, n_head=4, vocab_size=320, n_positions=128, rotary_dim=8)),
+    # the three Falcon block shapes: 40B (two norms, grouped KV), 7B (one norm, one KV head), sequential
+    "falcon-new": ("FalconConfig", dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, vocab_size=320, alibi=False, bias=False, new_decoder_architecture=True, num_kv_heads=2)),
+    "falcon-7b": ("FalconConfig", dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, vocab_size=320, alibi=False, bias=False, new_decoder_architecture=False, multi_query=True, parallel_attn=True)),
+    "falcon-seq": ("FalconConfig", dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, vocab_size=320, alibi=False, new_decoder_architecture=False, multi_query=False, parallel_attn=False,
+                                         bias=True)),
     "starcoder2": ("Starcoder2Config", dict(BASE, sliding_window=None, use_bias=True)),
     "qwen3-moe": ("Qwen3MoeConfig", dict(BASE, head_dim=32, moe_intermediate_size=64, num_experts=8,
                                          num_experts_per_tok=2, norm_topk_prob=True, decoder_sparse_step=1,

@@ -26,7 +26,8 @@ QWEN3_SMALL = dict(hidden_size=512, num_attention_heads=4, num_key_value_heads=2
                                    "phi-tiny", "gemma3-tiny", "phi2-tiny", "gemma2-tiny",
                                    "glm-tiny", "helium-tiny", "smollm3-tiny", "glm4-tiny", "olmo2-tiny",
                                    "exaone4-tiny", "nemotron-tiny", "stablelm-tiny", "cohere-tiny", "arcee-tiny",
-                                   "deepseek-v3-tiny", "glm4-moe-tiny"])
+                                   "deepseek-v3-tiny", "glm4-moe-tiny", "falcon-tiny", "gptj-tiny",
+                                   "gpt-bigcode-tiny"])
 def test_model_family_on_gpu_tracks_cpu_reference(model, tmp_path):
     overrides = QWEN3_SMALL if model == "qwen3-coder-480b-a35b" else {}
     mc = ModelConfig(model=model, dtype="float32", load_format="dummy", hf_overrides=overrides)

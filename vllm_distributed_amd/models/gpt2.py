@@ -24,14 +24,16 @@ class GPT2Block(nn.Module):
         eps = cfg.get("layer_norm_epsilon", 1e-5)
         self.head_dim = h // heads
         self.ln_1 = LayerNorm(h, eps, dtype)
-        self.c_attn = QKVParallelLinear(h, self.head_dim, heads, heads, True, dtype)
+        # GPT-BigCode (StarCoder): one K/V head shared by every query head
+        kv_heads = 1 if cfg.get("multi_query") else heads
+        self.c_attn = QKVParallelLinear(h, self.head_dim, heads, kv_heads, True, dtype)
         self.c_proj = RowParallelLinear(h, h, True, dtype)
         scale = self.head_dim ** -0.5 if cfg.get("scale_attn_weights", True) else 1.0
         self.attn = Attention(self.c_attn.num_heads, self.head_dim, self.c_attn.num_kv_heads, scale, layer_idx)
         self.ln_2 = LayerNorm(h, eps, dtype)
         self.c_fc = ColumnParallelLinear(h, [inner], True, dtype)
         self.mlp_c_proj = RowParallelLinear(inner, h, True, dtype)
-        self.act = cfg.get("activation_function", "gelu_new")
+        self.act = cfg.get("activation_function") or "gelu_new"
 
     def forward(self, hidden: torch.Tensor) -> torch.Tensor:
         qkv = self.c_attn(self.ln_1(hidden))
@@ -121,3 +123,17 @@ class GPT2LMHeadModel(nn.Module):
                 loader(p, w, None)
             loaded.append(name)
         return loaded
+
+
+class GPTBigCodeForCausalLM(GPT2LMHeadModel):
+    """GPT-2's block with multi-query attention and ``nn.Linear`` weights (stored ``[out, in]``)."""
+    _TRANSPOSED = ()
+
+    def __init__(self, vllm_config: VllmConfig):
+        cfg = vllm_config.model_config.hf_config
+        if not cfg.get("multi_query", True):
+            raise NotImplementedError("GPT-BigCode checkpoints without multi-query attention store q/k/v "
+                                      "interleaved per head; only multi_query=True is supported")
+        cfg["multi_query"] = True
+        cfg.setdefault("activation_function", "gelu_pytorch_tanh")
+        super().__init__(vllm_config)

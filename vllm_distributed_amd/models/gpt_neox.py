@@ -55,6 +55,8 @@ class GPTNeoXLayer(nn.Module):
 
 
 class GPTNeoXForCausalLM(nn.Module):
+    layer_cls = GPTNeoXLayer
+
     def __init__(self, vllm_config: VllmConfig):
         super().__init__()
         mc = vllm_config.model_config
@@ -75,7 +77,7 @@ class GPTNeoXForCausalLM(nn.Module):
         tie = bool(cfg.get("tie_word_embeddings", False))
         if self.is_first or (tie and self.is_last):
             self.embed_in = VocabParallelEmbedding(cfg["vocab_size"], h, dtype)
-        self.layers = nn.ModuleDict({str(i): GPTNeoXLayer(cfg, i, dtype, self.cos_sin_cache)
+        self.layers = nn.ModuleDict({str(i): self.layer_cls(cfg, i, dtype, self.cos_sin_cache)
                                      for i in range(self.start_layer, self.end_layer)})
         if self.is_last:
             self.final_layer_norm = LayerNorm(h, cfg.get("layer_norm_eps", 1e-5), dtype)

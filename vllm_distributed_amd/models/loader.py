@@ -87,6 +87,60 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
             shapes[q + "mlp.c_fc.weight"], shapes[q + "mlp.c_fc.bias"] = (h, inner), (inner,)
             shapes[q + "mlp.c_proj.weight"], shapes[q + "mlp.c_proj.bias"] = (inner, h), (h,)
         return shapes
+    if arch == "GPTBigCodeForCausalLM":
+        inner = c.get("n_inner") or 4 * h
+        hd = h // c["num_attention_heads"]
+        shapes["transformer.wte.weight"] = (c["vocab_size"], h)
+        shapes["transformer.wpe.weight"] = (c.get("n_positions", c.get("max_position_embeddings", 1024)), h)
+        shapes["transformer.ln_f.weight"] = shapes["transformer.ln_f.bias"] = (h,)
+        for i in range(L):
+            q = f"transformer.h.{i}."
+            for n in ("ln_1", "ln_2"):
+                shapes[q + n + ".weight"] = shapes[q + n + ".bias"] = (h,)
+            shapes[q + "attn.c_attn.weight"], shapes[q + "attn.c_attn.bias"] = (h + 2 * hd, h), (h + 2 * hd,)
+            shapes[q + "attn.c_proj.weight"], shapes[q + "attn.c_proj.bias"] = (h, h), (h,)
+            shapes[q + "mlp.c_fc.weight"], shapes[q + "mlp.c_fc.bias"] = (inner, h), (inner,)
+            shapes[q + "mlp.c_proj.weight"], shapes[q + "mlp.c_proj.bias"] = (h, inner), (h,)
+        return shapes
+    if arch == "GPTJForCausalLM":
+        inner = c.get("n_inner") or 4 * h
+        shapes["transformer.wte.weight"] = (c["vocab_size"], h)
+        shapes["transformer.ln_f.weight"] = shapes["transformer.ln_f.bias"] = (h,)
+        shapes["lm_head.weight"], shapes["lm_head.bias"] = (c["vocab_size"], h), (c["vocab_size"],)
+        for i in range(L):
+            q = f"transformer.h.{i}."
+            shapes[q + "ln_1.weight"] = shapes[q + "ln_1.bias"] = (h,)
+            for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                shapes[q + f"attn.{n}.weight"] = (h, h)
+            shapes[q + "mlp.fc_in.weight"], shapes[q + "mlp.fc_in.bias"] = (inner, h), (inner,)
+            shapes[q + "mlp.fc_out.weight"], shapes[q + "mlp.fc_out.bias"] = (h, inner), (h,)
+        return shapes
+    if arch in ("FalconForCausalLM", "RWForCausalLM"):
+        from .falcon import falcon_kv_heads
+        heads, kvh = c["num_attention_heads"], falcon_kv_heads(c)
+        hd, inner, bias = h // heads, c.get("ffn_hidden_size") or 4 * h, bool(c.get("bias", False))
+        new = bool(c.get("new_decoder_architecture"))
+        n_ln = c.get("num_ln_in_parallel_attn")
+        if new and (2 if n_ln is None else int(n_ln)) == 2:
+            lns = ("ln_attn", "ln_mlp")
+        else:
+            lns = ("input_layernorm",) if (new or c.get("parallel_attn", True)) else \
+                ("input_layernorm", "post_attention_layernorm")
+        shapes["transformer.word_embeddings.weight"] = (c["vocab_size"], h)
+        shapes["transformer.ln_f.weight"] = shapes["transformer.ln_f.bias"] = (h,)
+        if not c.get("tie_word_embeddings", True):
+            shapes["lm_head.weight"] = (c["vocab_size"], h)
+        for i in range(L):
+            q = f"transformer.h.{i}."
+            for n in lns:
+                shapes[q + n + ".weight"] = shapes[q + n + ".bias"] = (h,)
+            for n, (o, k) in (("self_attention.query_key_value", ((heads + 2 * kvh) * hd, h)),
+                              ("self_attention.dense", (h, h)), ("mlp.dense_h_to_4h", (inner, h)),
+                              ("mlp.dense_4h_to_h", (h, inner))):
+                shapes[q + n + ".weight"] = (o, k)
+                if bias:
+                    shapes[q + n + ".bias"] = (o,)
+        return shapes
     if arch == "GPTNeoXForCausalLM":
         inter = c["intermediate_size"]
         shapes["gpt_neox.embed_in.weight"] = (c["vocab_size"], h)

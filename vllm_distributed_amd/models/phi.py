@@ -26,8 +26,9 @@ class PhiLayer(nn.Module):
             raise ValueError("Phi checkpoints with qk_layernorm are not supported")
         self.head_dim = h // heads
         self.input_layernorm = LayerNorm(h, cfg.get("layer_norm_eps", 1e-5), dtype)
-        self.qkv_proj = QKVParallelLinear(h, self.head_dim, heads, kv, True, dtype)
-        self.dense = RowParallelLinear(h, h, True, dtype)
+        attn_bias = cfg.get("model_type") != "gptj"         # GPT-J: biases in the MLP only
+        self.qkv_proj = QKVParallelLinear(h, self.head_dim, heads, kv, attn_bias, dtype)
+        self.dense = RowParallelLinear(h, h, attn_bias, dtype)
         self.attn = Attention(self.qkv_proj.num_heads, self.head_dim, self.qkv_proj.num_kv_heads,
                               self.head_dim ** -0.5, layer_idx, pad_head_dim=True)
         self.fc1 = ColumnParallelLinear(h, [cfg["intermediate_size"]], True, dtype)
@@ -97,6 +98,9 @@ class PhiForCausalLM(nn.Module):
             return None
         return name.replace(".self_attn.", ".").replace(".mlp.", ".")
 
+    def transform_weight(self, name: str, w):
+        return w
+
     def _owns_layer(self, name: str) -> bool:
         if not name.startswith("layers."):
             return True
@@ -109,6 +113,7 @@ class PhiForCausalLM(nn.Module):
             name = self.map_weight_name(name)
             if name is None or not self._owns_layer(name):
                 continue
+            w = self.transform_weight(name, w)
             target, shard = name, None
             for frag, fused, sid in self.stacked_params:
                 if frag in name:
@@ -124,3 +129,41 @@ class PhiForCausalLM(nn.Module):
                 loader(p, w, shard)
             loaded.append(name)
         return loaded
+
+
+class GPTJForCausalLM(PhiForCausalLM):
+    """GPT-J: Phi's layer shape (one LayerNorm feeding attention and MLP side by side, LM head with a
+    bias) without attention biases, and a rotary embedding over ADJACENT pairs of the first
+    ``rotary_dim`` dimensions: the q / k rows of every head are de-interleaved at load, after which the
+    half-apart rotation of the first ``rotary_dim`` dimensions computes the same scores."""
+
+    def __init__(self, vllm_config: VllmConfig):
+        cfg = vllm_config.model_config.hf_config
+        h, heads = cfg["hidden_size"], cfg["num_attention_heads"]
+        self._head_dim = h // heads
+        self._rotary_dim = int(cfg.get("rotary_dim") or self._head_dim)
+        cfg["intermediate_size"] = cfg.get("n_inner") or 4 * h
+        cfg["partial_rotary_factor"] = self._rotary_dim / self._head_dim
+        cfg["layer_norm_eps"] = cfg.get("layer_norm_epsilon", 1e-5)
+        cfg["hidden_act"] = cfg.get("activation_function") or "gelu_new"
+        cfg["num_key_value_heads"] = heads
+        super().__init__(vllm_config)
+        rd, d = self._rotary_dim, self._head_dim
+        self._perm = torch.cat([torch.arange(0, rd, 2), torch.arange(1, rd, 2), torch.arange(rd, d)])
+
+    def map_weight_name(self, name: str) -> Optional[str]:
+        if name.startswith("transformer."):
+            name = name[len("transformer."):]
+        if name.endswith((".attn.bias", ".attn.masked_bias")):
+            return None                                     # causal-mask buffers of old checkpoints
+        if name.startswith("h."):
+            name = "layers." + name[2:]
+        return (name.replace("wte.", "embed_tokens.").replace("ln_f.", "final_layernorm.")
+                .replace(".ln_1.", ".input_layernorm.").replace(".attn.out_proj.", ".dense.")
+                .replace(".attn.", ".").replace(".mlp.fc_in.", ".fc1.").replace(".mlp.fc_out.", ".fc2."))
+
+    def transform_weight(self, name: str, w):
+        if ".q_proj." in name or ".k_proj." in name:
+            t = materialize(w)
+            return t.reshape(-1, self._head_dim, *t.shape[1:]).index_select(1, self._perm.to(t.device)).reshape(t.shape)
+        return w

@@ -44,7 +44,11 @@ _MODELS: Dict[str, Tuple[str, str]] = {
     "NemotronForCausalLM": ("llama_variants", "NemotronForCausalLM"),
     "CohereForCausalLM": ("llama_variants", "CohereForCausalLM"),
     "GPT2LMHeadModel": ("gpt2", "GPT2LMHeadModel"),
+    "GPTBigCodeForCausalLM": ("gpt2", "GPTBigCodeForCausalLM"),
+    "GPTJForCausalLM": ("phi", "GPTJForCausalLM"),
     "GPTNeoXForCausalLM": ("gpt_neox", "GPTNeoXForCausalLM"),
+    "FalconForCausalLM": ("falcon", "FalconForCausalLM"),
+    "RWForCausalLM": ("falcon", "FalconForCausalLM"),
     "Starcoder2ForCausalLM": ("starcoder2", "Starcoder2ForCausalLM"),
 }
 
