@@ -185,12 +185,12 @@ class DeepseekV2ForCausalLM(Qwen3MoeForCausalLM):
         if ".self_attn.q_b_proj." in name or ".self_attn.q_proj." in name:
             t = materialize(w)
             per_head = t.reshape(-1, nope + rope, *t.shape[1:])
-            perm = torch.cat([torch.arange(nope), nope + self.mla_perm]).to(t.device)
+            perm = torch.cat([torch.arange(nope, device=t.device), nope + self.mla_perm.to(t.device)])
             return per_head.index_select(1, perm).reshape(t.shape)
         if ".self_attn.kv_a_proj_with_mqa." in name:
             t = materialize(w)
             rank = self.cfg["kv_lora_rank"]
-            perm = torch.cat([torch.arange(rank), rank + self.mla_perm]).to(t.device)
+            perm = torch.cat([torch.arange(rank, device=t.device), rank + self.mla_perm.to(t.device)])
             return t.index_select(0, perm)
         return w
 
