@@ -70,7 +70,10 @@ def test_spmd_tp2_matches_single_process_on_every_rank():
 
 @pytest.mark.slow
 @pytest.mark.parametrize("model", ["qwen2-moe-tiny", "gemma3-tiny", "phi-tiny", "olmo2-tiny", "cohere-tiny",
-                                   "glm4-tiny", "nemotron-tiny", "deepseek-v3-tiny"])
+                                   "glm4-tiny", "nemotron-tiny", "deepseek-v3-tiny", "falcon-tiny", "gptj-tiny",
+                                   "gpt-bigcode-tiny", "smollm3-tiny", "exaone4-tiny", "stablelm-tiny", "arcee-tiny",
+                                   "glm4-moe-tiny", "helium-tiny", "gemma2-tiny", "starcoder2-tiny", "gpt-neox-tiny",
+                                   "gpt2-tiny", "opt-tiny", "granite-tiny", "mixtral-tiny"])
 def test_spmd_tp2_other_families_match_single_process(model):
     """Shared-expert MoE (routed and shared halves under one all-reduce), Gemma-3 (norms on the branch
     outputs: must stay on the plain layer loop even when the sharded residual stream is forced) and Phi
