@@ -114,7 +114,15 @@ def _reference(model):
 
 @pytest.mark.slow
 @pytest.mark.parametrize("model,tp,pp,async_sched", [("opt-tiny", 1, 2, False), ("llama-tiny", 2, 1, False),
-                                                     ("llama-tiny", 1, 2, False), ("llama-tiny", 2, 1, True)])
+                                                     ("llama-tiny", 1, 2, False), ("llama-tiny", 2, 1, True),
+                                                     # stage boundaries of the other layer shapes: the whole stream in
+                                                     # the residual slot, tied heads on the last stage, per-layer rope
+                                                     # tables, MLA + expert layers split across stages
+                                                     ("gemma3-tiny", 1, 2, False), ("cohere-tiny", 1, 2, False),
+                                                     ("smollm3-tiny", 1, 2, False), ("deepseek-v3-tiny", 1, 2, False),
+                                                     ("falcon-tiny", 1, 2, False), ("gptj-tiny", 1, 2, False),
+                                                     ("olmo2-tiny", 1, 2, False), ("qwen3-moe-tiny", 1, 2, False),
+                                                     ("mixtral-tiny", 1, 2, False)])
 def test_head_plus_remote_worker_matches_single_process(monkeypatch, model, tp, pp, async_sched):
     """OPT greedy with head + 1 worker on localhost is the plumbing configuration;
     the TP=2 case assembles one TP group from the head's device and a same-host worker."""

@@ -554,9 +554,11 @@ class LlamaForCausalLM(nn.Module):
 
     # ------------------------------------------------------------- weights
     def _owns_layer(self, name: str) -> bool:
-        if ".layers." not in name:
+        # (names arrive with or without the checkpoint's "model." prefix)
+        parts = name.split(".")
+        if "layers" not in parts[:-1]:
             return True
-        idx = int(name.split(".layers.")[1].split(".")[0])
+        idx = int(parts[parts.index("layers") + 1])
         return self.start_layer <= idx < self.end_layer
 
     def map_weight_name(self, name: str) -> Optional[str]:
