@@ -101,11 +101,11 @@ def _generate(engine, max_tokens=10):
     return [final[i] for i in ids]
 
 
-def _reference(model):
+def _reference(model, **kw):
     pstate.destroy_model_parallel()
     eng = LLMEngine.from_engine_args(EngineArgs(
         model=model, device="cpu", dtype="float32", max_model_len=128, block_size=16,
-        num_gpu_blocks_override=64, max_num_seqs=8))
+        num_gpu_blocks_override=64, max_num_seqs=8, **kw))
     out = _generate(eng)
     eng.shutdown()
     pstate.destroy_model_parallel()
@@ -457,6 +457,32 @@ def test_tp2_x_pp2_head_plus_three_remote_workers_two_batches_in_flight_then_a_k
         while not eng.core.executor.is_failed and time.time() < deadline:
             time.sleep(0.05)
         assert eng.core.executor.is_failed
+    finally:
+        if eng is not None:
+            eng.shutdown()
+        remote.terminate()
+        remote.wait(timeout=10)
+
+
+@pytest.mark.slow
+def test_awq_expert_model_at_tp2_x_pp2_matches_single_process(monkeypatch):
+    """The model of the reference's example deployment in miniature (``.env.server:11``: an AWQ
+    Qwen3-MoE checkpoint served with ``-tp 2 -pp 2``): packed 4-bit experts cut over the TP group,
+    expert layers spread over two stages, head + a three-device worker node."""
+    # groups of 32 input channels, so that an expert's half of the intermediate size still holds whole groups
+    over = {"quantization_config": {"quant_method": "awq", "bits": 4, "group_size": 32}}
+    ref = _reference("qwen3-moe-tiny", quantization="awq", hf_overrides=over)
+    port = get_open_port()
+    for k, v in _env(port, VLLM_HEAD_LOCAL_DEVICES="1").items():
+        monkeypatch.setenv(k, v)
+    remote = _start_remote(port, 3, 1)
+    eng = None
+    try:
+        eng = LLMEngine.from_engine_args(EngineArgs(
+            model="qwen3-moe-tiny", quantization="awq", hf_overrides=over, device="cpu", dtype="float32", max_model_len=128,
+            block_size=16, num_gpu_blocks_override=64, max_num_seqs=8, tensor_parallel_size=2,
+            pipeline_parallel_size=2, distributed_executor_backend="distributed"))
+        assert _generate(eng) == ref
     finally:
         if eng is not None:
             eng.shutdown()
