@@ -23,7 +23,8 @@ eng = LLMEngine.from_engine_args(EngineArgs(
     num_gpu_blocks_override=64, max_num_seqs=8, tensor_parallel_size=tp,
     distributed_executor_backend="spmd" if tp > 1 else "uni",
     async_scheduling=os.environ.get("ASYNC") == "1", quantization=os.environ.get("QUANT") or None,
-    speculative_config=json.loads(os.environ.get("SPEC") or "null")))
+    speculative_config=json.loads(os.environ.get("SPEC") or "null"),
+    enable_expert_parallel=os.environ.get("EP") == "1"))
 sp = SamplingParams(temperature=0.8, top_p=0.9, seed=7, max_tokens=8, ignore_eos=True)
 g = SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True)
 ids = [eng.add_request(None, p, s) for p, s in (([5, 9, 200, 17], g), (list(range(10, 50)), sp), ([7, 7], g))]
@@ -37,14 +38,14 @@ eng.shutdown()
 """
 
 
-def _run(world, async_sched=False, sp="0", quant="", model="", spec=""):
+def _run(world, async_sched=False, sp="0", quant="", model="", spec="", ep=False):
     port = get_open_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VLLM_LOGGING_LEVEL="WARNING",
                    GLOO_SOCKET_IFNAME="lo", OMP_NUM_THREADS="2", ASYNC="1" if async_sched else "0",
-                   VDAMD_SEQUENCE_PARALLEL=sp, QUANT=quant, MODEL=model, SPEC=spec)
+                   VDAMD_SEQUENCE_PARALLEL=sp, QUANT=quant, MODEL=model, SPEC=spec, EP="1" if ep else "0")
         procs.append(subprocess.Popen([sys.executable, "-c", SCRIPT.format(root=ROOT)], env=env,
                                       stdout=subprocess.PIPE, text=True))
     outs = []
@@ -80,6 +81,17 @@ def test_spmd_tp2_other_families_match_single_process(model):
     (parallel branches, biased vocab-parallel LM head) at TP=2 reproduce TP=1."""
     ref = _run(1, model=model)[0]
     got = _run(2, model=model, sp="force")
+    assert got[0] == ref and got[1] == ref
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("model", ["qwen3-moe-tiny", "qwen2-moe-tiny", "mixtral-tiny", "deepseek-v3-tiny",
+                                   "glm4-moe-tiny"])
+def test_spmd_tp2_expert_parallel_matches_single_process(model):
+    """Whole experts per rank (``enable_expert_parallel``) instead of column shards of every expert; shared
+    experts and attention stay tensor-parallel."""
+    ref = _run(1, model=model)[0]
+    got = _run(2, model=model, ep=True)
     assert got[0] == ref and got[1] == ref
 
 
