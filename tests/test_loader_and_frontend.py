@@ -612,3 +612,29 @@ def test_a_checkpoint_that_lacks_a_parameter_is_refused(tmp_path):
         LLM(model=str(dst), device="cpu", dtype="float32", max_model_len=128, block_size=16,
             num_gpu_blocks_override=64, max_num_seqs=8)
     pstate.destroy_model_parallel()
+
+
+def test_packed_quantisation_is_refused_for_families_without_packed_layers():
+    """OPT / Phi / StarCoder2 / GPT-2 style models build plain linear layers: asking for the AWQ kernels must
+    fail at load with the reason, not leave the packed tensors unplaced."""
+    with pytest.raises(Exception, match="no packed 4-bit linear layers"):
+        LLM(model="opt-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,
+            num_gpu_blocks_override=64, max_num_seqs=8, quantization="awq")
+    pstate.destroy_model_parallel()
+
+
+@pytest.mark.parametrize("model", ["glm-tiny", "helium-tiny", "stablelm-tiny"])
+def test_awq_q_k_projections_follow_the_rope_row_order(model):
+    """Families whose rotary embedding is folded into the row order of q_proj / k_proj: with packed AWQ weights
+    the same re-ordering is applied to the nibbles, zeros and scales, so the packed model generates what its
+    dequantised twin (dense rows re-ordered) does."""
+    outs = []
+    for q in ("awq-dequant", "awq"):
+        llm = LLM(model=model, device="cpu", dtype="float32", max_model_len=128, block_size=16,
+                  num_gpu_blocks_override=64, max_num_seqs=8, quantization=q)
+        o = llm.generate([[5, 9, 200, 17], list(range(10, 40))],
+                         SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True))
+        outs.append([x.outputs[0].token_ids for x in o])
+        llm.shutdown()
+        pstate.destroy_model_parallel()
+    assert outs[0] == outs[1]

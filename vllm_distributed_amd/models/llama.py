@@ -251,6 +251,8 @@ class LlamaDecoderLayer(nn.Module):
 
 class LlamaForCausalLM(nn.Module):
     layer_cls = LlamaDecoderLayer
+    # the linear layers are built under ``quantized_linears``: AWQ / NVFP4 / fp8 weights stay packed
+    packed_quantization = True
     # checkpoint name fragment -> (fused param fragment, shard id)
     stacked_params = [
         (".q_proj", ".qkv_proj", "q"), (".k_proj", ".qkv_proj", "k"), (".v_proj", ".qkv_proj", "v"),
@@ -271,9 +273,9 @@ class LlamaForCausalLM(nn.Module):
         head_dim = cfg.get("head_dim") or cfg["hidden_size"] // cfg["num_attention_heads"]
         rotary_dim = int(head_dim * float(cfg.get("partial_rotary_factor") or 1.0))
         self.rope_perm = rope_row_permutation(head_dim, rotary_dim, cfg.get("model_type") in INTERLEAVED_ROPE_TYPES)
-        if self.rope_perm is not None and mc.quantization in ("awq", "nvfp4"):
-            raise NotImplementedError("packed 4-bit q/k projections of a model with an interleaved or partial rotary "
-                                      "embedding cannot be re-ordered at load")
+        if self.rope_perm is not None and mc.quantization == "nvfp4":
+            raise NotImplementedError("NVFP4 q/k projections of a model with an interleaved or partial rotary "
+                                      "embedding are not re-ordered at load")
         self.head_dim = head_dim
         cos_sin = ops.build_cos_sin_cache(head_dim, mc.max_model_len, cfg.get("rope_theta", 10000.0),
                                           cfg.get("rope_scaling"), rotary_dim=rotary_dim)
@@ -587,6 +589,14 @@ class LlamaForCausalLM(nn.Module):
                 # basis the rotary kernel works in
                 t = materialize(w)
                 w = t.reshape(-1, self.head_dim, *t.shape[1:]).index_select(1, self.rope_perm.to(t.device)).reshape(t.shape)
+            elif self.rope_perm is not None and (".q_proj." in name or ".k_proj." in name) \
+                    and name.endswith((".qweight", ".qzeros", ".scales")):
+                # AWQ keeps output channels in the last dimension, eight to a word
+                from .loader import awq_reorder_out_columns
+                t = materialize(w)
+                out = t.shape[1] * (1 if name.endswith(".scales") else 8)
+                full = (torch.arange(out // self.head_dim).unsqueeze(1) * self.head_dim + self.rope_perm.cpu()).reshape(-1)
+                w = awq_reorder_out_columns(t, full, packed=not name.endswith(".scales"))
             w = self.transform_weight(name, w)
             if name.endswith((".k_scale", ".v_scale")) and ".self_attn." in name:
                 # per-tensor scales of an fp8 KV cache (read only when the cache is e4m3)

@@ -414,6 +414,19 @@ def awq_dequantize(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Te
     return ((w - z) * s).t().contiguous().to(dtype)
 
 
+def awq_reorder_out_columns(t: torch.Tensor, perm: torch.Tensor, packed: bool) -> torch.Tensor:
+    """Output channels of an AWQ tensor (the LAST dimension: ``qweight[in, out/8]``, ``qzeros[in/g, out/8]``
+    packed eight nibbles a word, ``scales[in/g, out]`` plain) taken in the order ``perm``."""
+    perm = perm.to(t.device)
+    if not packed:
+        return t.index_select(1, perm).contiguous()
+    shifts = torch.tensor([4 * _AWQ_ORDER.index(i) for i in range(8)], dtype=torch.int32, device=t.device)
+    u = ((t.unsqueeze(-1) >> shifts) & 0xF).reshape(t.shape[0], -1).index_select(1, perm)
+    u = u.reshape(t.shape[0], -1, 8).to(torch.int64) << shifts.to(torch.int64)
+    word = u.sum(-1)                                       # disjoint nibbles: a sum is an OR
+    return torch.where(word >= (1 << 31), word - (1 << 32), word).to(torch.int32)
+
+
 def _dequantize_stream(weights: Iterable[Tuple[str, torch.Tensor]], dtype: torch.dtype,
                        ) -> Iterator[Tuple[str, torch.Tensor]]:
     """Turn ``qweight/qzeros/scales`` triples of a weight stream into dense
@@ -571,6 +584,12 @@ def _check_filled(model: torch.nn.Module, what: str) -> None:
 def load_model(vllm_config: VllmConfig, device: torch.device) -> torch.nn.Module:
     mc = vllm_config.model_config
     cls = get_model_class(mc.architecture)
+    if mc.quantization in ("awq", "nvfp4") and not getattr(cls, "packed_quantization", False):
+        # (those checkpoints still load with ``--quantization awq-dequant``: 16-bit weights, dense kernels)
+        raise ValueError(f"{mc.architecture} has no packed 4-bit linear layers: quantization={mc.quantization!r} is "
+                         f"supported for the Llama-shaped and expert-mixture families only")
+    if mc.quantization == "fp8" and not getattr(cls, "packed_quantization", False):
+        logger.warning("%s has no fp8 linear layers: weights are kept in %s", mc.architecture, mc.dtype)
     with torch.device(device):
         model = cls(vllm_config)
     model.rebind_buffers()
