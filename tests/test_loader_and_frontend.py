@@ -638,3 +638,41 @@ def test_awq_q_k_projections_follow_the_rope_row_order(model):
         llm.shutdown()
         pstate.destroy_model_parallel()
     assert outs[0] == outs[1]
+
+
+def test_nvfp4_q_k_projections_follow_the_rope_row_order(tmp_path):
+    """GLM (adjacent-pair rotary over half of each head) with NVFP4 weights: packed bytes and block scales of
+    q_proj / k_proj are re-ordered row-wise like dense rows, so the packed model generates what the dense
+    checkpoint built from the dequantised tensors does."""
+    import json
+    from safetensors.torch import load_file, save_file
+    from vllm_distributed_amd.config import ModelConfig
+    from vllm_distributed_amd.models.layers.linear import nvfp4_dequantize
+    from vllm_distributed_amd.models.loader import save_dummy_checkpoint
+    mc = ModelConfig(model="glm-tiny", dtype="float32", load_format="dummy", quantization="nvfp4")
+    src = tmp_path / "packed"
+    save_dummy_checkpoint(mc, str(src))
+    sd = load_file(str(src / "model.safetensors"))
+    dense = {}
+    for k, v in sd.items():
+        if k.endswith(".weight_packed"):
+            base = k[:-len(".weight_packed")]
+            alpha = sd[base + ".weight_global_scale"].reciprocal()
+            dense[base + ".weight"] = nvfp4_dequantize(v, sd[base + ".weight_scale"], alpha.expand(v.shape[0]),
+                                                       torch.float32)
+        elif not k.endswith((".weight_global_scale", ".weight_scale")):
+            dense[k] = v
+    d = tmp_path / "dense"
+    d.mkdir()
+    save_file({k: v.contiguous() for k, v in dense.items()}, str(d / "model.safetensors"))
+    (d / "config.json").write_text(json.dumps(dict(mc.hf_config)))
+    outs = []
+    for kw in (dict(model="glm-tiny", quantization="nvfp4"), dict(model=str(d))):
+        llm = LLM(device="cpu", dtype="float32", max_model_len=128, block_size=16, num_gpu_blocks_override=64,
+                  max_num_seqs=8, **kw)
+        o = llm.generate([[5, 9, 200, 17], list(range(10, 50))],
+                         SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True))
+        outs.append([x.outputs[0].token_ids for x in o])
+        llm.shutdown()
+        pstate.destroy_model_parallel()
+    assert outs[0] == outs[1]

@@ -273,9 +273,6 @@ class LlamaForCausalLM(nn.Module):
         head_dim = cfg.get("head_dim") or cfg["hidden_size"] // cfg["num_attention_heads"]
         rotary_dim = int(head_dim * float(cfg.get("partial_rotary_factor") or 1.0))
         self.rope_perm = rope_row_permutation(head_dim, rotary_dim, cfg.get("model_type") in INTERLEAVED_ROPE_TYPES)
-        if self.rope_perm is not None and mc.quantization == "nvfp4":
-            raise NotImplementedError("NVFP4 q/k projections of a model with an interleaved or partial rotary "
-                                      "embedding are not re-ordered at load")
         self.head_dim = head_dim
         cos_sin = ops.build_cos_sin_cache(head_dim, mc.max_model_len, cfg.get("rope_theta", 10000.0),
                                           cfg.get("rope_scaling"), rotary_dim=rotary_dim)
@@ -582,11 +579,11 @@ class LlamaForCausalLM(nn.Module):
                 if renamed is None:
                     continue
                 name, w = renamed
-            if self.rope_perm is not None and name.endswith((".weight", ".bias")) and (
+            if self.rope_perm is not None and name.endswith((".weight", ".bias", ".weight_packed", ".weight_block_scale")) and (
                     ".q_proj." in name or ".k_proj." in name
                     or (name.endswith((".q_norm.weight", ".k_norm.weight")) and has_head_qk_norm(self.cfg))):
                 # re-order the rows of every head (and the per-head norm weights that act on them) into the
-                # basis the rotary kernel works in
+                # basis the rotary kernel works in; NVFP4 bytes and block scales are row-major like the dense weight
                 t = materialize(w)
                 w = t.reshape(-1, self.head_dim, *t.shape[1:]).index_select(1, self.rope_perm.to(t.device)).reshape(t.shape)
             elif self.rope_perm is not None and (".q_proj." in name or ".k_proj." in name) \
