@@ -624,3 +624,41 @@ def test_admin_endpoints_need_the_dev_flag_and_request_templates_need_trust():
                 assert bad.status_code == 400 and "template" in bad.text
     asyncio.run(main())
     pstate.destroy_model_parallel()
+
+
+def test_tool_parsers_of_the_other_model_families():
+    import json as _json
+    get = lambda n: ToolParserManager.get_tool_parser(n)()                       # noqa: E731
+    args = lambda c: _json.loads(c["function"]["arguments"])                      # noqa: E731
+    # Mistral: a JSON list after the marker, or NAME{json} per marker
+    content, calls = get("mistral").extract('Sure.[TOOL_CALLS][{"name": "add", "arguments": {"a": 1, "b": 2}}]')
+    assert content == "Sure." and calls[0]["function"]["name"] == "add" and args(calls[0]) == {"a": 1, "b": 2}
+    content, calls = get("mistral").extract('[TOOL_CALLS]get_weather{"city": "Paris"}[TOOL_CALLS]now{}')
+    assert content is None and [c["function"]["name"] for c in calls] == ["get_weather", "now"]
+    assert get("mistral").extract("no call here") == ("no call here", [])
+    # DeepSeek-V3
+    t = ("Let me check.<｜tool▁calls▁begin｜><｜tool▁call▁begin｜>function"
+         "<｜tool▁sep｜>get_weather\n```json\n{\"city\": \"Oslo\"}\n```<｜tool▁call▁end｜>"
+         "<｜tool▁calls▁end｜>")
+    content, calls = get("deepseek_v3").extract(t)
+    assert content == "Let me check." and calls[0]["function"]["name"] == "get_weather" and args(calls[0]) == {"city": "Oslo"}
+    # GLM-4.5: key / value tags, typed by the schema
+    tools = [{"type": "function", "function": {"name": "book", "parameters": {"type": "object", "properties": {
+        "nights": {"type": "integer"}, "city": {"type": "string"}, "late": {"type": "boolean"}}}}}]
+    t = ("<tool_call>book\n<arg_key>nights</arg_key>\n<arg_value>3</arg_value>\n<arg_key>city</arg_key>\n"
+         "<arg_value>Rome</arg_value>\n<arg_key>late</arg_key>\n<arg_value>true</arg_value>\n</tool_call>")
+    content, calls = get("glm45").extract(t, tools)
+    assert content is None and args(calls[0]) == {"nights": 3, "city": "Rome", "late": True}
+    # Granite, Phi-4-mini
+    _, calls = get("granite").extract('<|tool_call|>[{"name": "f", "arguments": {"x": 1}}]')
+    assert calls[0]["function"]["name"] == "f" and args(calls[0]) == {"x": 1}
+    _, calls = get("granite").extract('<tool_call>[{"name": "g", "arguments": {}}]')
+    assert calls[0]["function"]["name"] == "g"
+    content, calls = get("phi4_mini_json").extract('ok functools[{"name": "h", "arguments": {"q": "a b"}}]')
+    assert content == "ok" and args(calls[0]) == {"q": "a b"}
+    # pythonic: literals only; anything else is plain text
+    _, calls = get("pythonic").extract('[get_weather(city="Paris", days=3), tools.now()]')
+    assert [c["function"]["name"] for c in calls] == ["get_weather", "tools.now"] and args(calls[0]) == {"city": "Paris", "days": 3}
+    bad = '[get_weather(city=__import__("os").getcwd())]'
+    assert get("pythonic").extract(bad) == (bad, [])
+    assert get("pythonic").extract("[1, 2, 3]") == ("[1, 2, 3]", [])

@@ -161,5 +161,160 @@ class Llama3JsonToolParser(ToolParser):
         return None, calls
 
 
+def _json_call_list(parser: ToolParser, raw: str) -> List[dict]:
+    """``[{"name": .., "arguments" | "parameters": ..}, ...]`` (or one such object) -> calls; [] if it is not that."""
+    try:
+        obj = json.loads(raw)
+    except (ValueError, TypeError):
+        # the list may be followed by ordinary text: take the longest JSON prefix
+        try:
+            obj, _ = json.JSONDecoder().raw_decode(raw.lstrip())
+        except (ValueError, TypeError):
+            return []
+    items = obj if isinstance(obj, list) else [obj]
+    calls = []
+    for it in items:
+        if not isinstance(it, dict) or "name" not in it:
+            return []
+        calls.append(parser.make_call(it["name"], it.get("arguments", it.get("parameters", {}))))
+    return calls
+
+
+@ToolParserManager.register_module("mistral")
+class MistralToolParser(ToolParser):
+    """``[TOOL_CALLS][{"name": .., "arguments": {..}}, ...]``, or (newer tokenizers) one
+    ``[TOOL_CALLS]NAME{json arguments}`` per call."""
+
+    TOKEN = "[TOOL_CALLS]"
+    _named = re.compile(r"\s*([A-Za-z_][\w.\-]*)\s*(?:\[ARGS\])?\s*(\{.*)$", re.S)
+
+    def extract(self, text, tools=None):
+        if self.TOKEN not in text:
+            return text, []
+        content, _, rest = text.partition(self.TOKEN)
+        calls: List[dict] = []
+        for part in rest.split(self.TOKEN):
+            part = part.strip()
+            if part.startswith(("[", "{")):
+                calls.extend(_json_call_list(self, part))
+                continue
+            m = self._named.match(part)
+            if m:
+                try:
+                    args, _ = json.JSONDecoder().raw_decode(m.group(2))
+                    calls.append(self.make_call(m.group(1), args))
+                except (ValueError, TypeError):
+                    pass
+        if not calls:
+            return text, []
+        return (content.strip() or None), calls
+
+
+@ToolParserManager.register_module("deepseek_v3")
+class DeepSeekV3ToolParser(ToolParser):
+    """``<｜tool▁calls▁begin｜><｜tool▁call▁begin｜>function<｜tool▁sep｜>NAME\n```json\n{..}\n```<｜tool▁call▁end｜>...<｜tool▁calls▁end｜>``"""
+
+    BEGIN = "<\uff5ctool\u2581calls\u2581begin\uff5c>"
+    _call = re.compile("<\uff5ctool\u2581call\u2581begin\uff5c>(?:[^<]*?)<\uff5ctool\u2581sep\uff5c>([^\n<]+)\\s*"
+                       "(?:```json)?\\s*(.*?)\\s*(?:```)?\\s*<\uff5ctool\u2581call\u2581end\uff5c>", re.S)
+
+    def extract(self, text, tools=None):
+        if self.BEGIN not in text:
+            return text, []
+        content = text[:text.index(self.BEGIN)]
+        calls = []
+        for m in self._call.finditer(text):
+            try:
+                calls.append(self.make_call(m.group(1).strip(), json.loads(m.group(2))))
+            except (ValueError, TypeError):
+                continue
+        if not calls:
+            return text, []
+        return (content.strip() or None), calls
+
+
+@ToolParserManager.register_module("glm45")
+class Glm45ToolParser(ToolParser):
+    """``<tool_call>NAME\n<arg_key>K</arg_key>\n<arg_value>V</arg_value>...</tool_call>``; values are typed by the
+    tool's parameter schema."""
+
+    _call = re.compile(r"<tool_call>\s*([^\n<]+)\s*(.*?)</tool_call>", re.S)
+    _arg = re.compile(r"<arg_key>(.*?)</arg_key>\s*<arg_value>(.*?)</arg_value>", re.S)
+
+    def extract(self, text, tools=None):
+        calls = []
+        for m in self._call.finditer(text):
+            name = m.group(1).strip()
+            types = _param_types(tools, name)
+            calls.append(self.make_call(name, {k.strip(): _coerce(v, types.get(k.strip()))
+                                               for k, v in self._arg.findall(m.group(2))}))
+        if not calls:
+            return text, []
+        return (self._call.sub("", text).strip() or None), calls
+
+
+@ToolParserManager.register_module("granite")
+class GraniteToolParser(ToolParser):
+    """``<|tool_call|>[{"name": .., "arguments": {..}}, ...]`` (Granite 3.0) or ``<tool_call>[...]`` (3.1)."""
+
+    def extract(self, text, tools=None):
+        s = text.strip()
+        for tok in ("<|tool_call|>", "<tool_call>"):
+            if s.startswith(tok):
+                calls = _json_call_list(self, s[len(tok):].strip())
+                return (None, calls) if calls else (text, [])
+        return text, []
+
+
+@ToolParserManager.register_module("phi4_mini_json")
+class Phi4MiniJsonToolParser(ToolParser):
+    """``functools[{"name": .., "arguments": {..}}, ...]``"""
+
+    _call = re.compile(r"functools\s*(\[.*\])", re.S)
+
+    def extract(self, text, tools=None):
+        m = self._call.search(text)
+        calls = _json_call_list(self, m.group(1)) if m else []
+        if not calls:
+            return text, []
+        return (text[:m.start()].strip() or None), calls
+
+
+@ToolParserManager.register_module("pythonic")
+class PythonicToolParser(ToolParser):
+    """``[get_weather(city="Paris", days=3), other()]``: a Python list of calls with literal keyword
+    arguments (Llama-3.2 / Llama-4 "pythonic" prompts).  Parsed with ``ast``; nothing is evaluated
+    beyond literals."""
+
+    def extract(self, text, tools=None):
+        import ast
+        s = text.strip()
+        if s.startswith("<|python_start|>"):
+            s = s[len("<|python_start|>"):].split("<|python_end|>")[0].strip()
+        if not (s.startswith("[") and s.endswith("]")):
+            return text, []
+        try:
+            tree = ast.parse(s, mode="eval").body
+            if not isinstance(tree, ast.List) or not tree.elts:
+                return text, []
+            calls = []
+            for node in tree.elts:
+                if not isinstance(node, ast.Call) or node.args:
+                    return text, []
+                fn = node.func
+                parts = []
+                while isinstance(fn, ast.Attribute):
+                    parts.append(fn.attr)
+                    fn = fn.value
+                if not isinstance(fn, ast.Name):
+                    return text, []
+                name = ".".join([fn.id] + parts[::-1])
+                calls.append(self.make_call(name, {kw.arg: ast.literal_eval(kw.value) for kw in node.keywords}))
+        except (SyntaxError, ValueError, TypeError):
+            return text, []
+        return None, calls
+
+
 __all__ = ["ToolParser", "ToolParserManager", "Qwen3CoderToolParser", "HermesToolParser",
-           "Llama3JsonToolParser"]
+           "Llama3JsonToolParser", "MistralToolParser", "DeepSeekV3ToolParser", "Glm45ToolParser",
+           "GraniteToolParser", "Phi4MiniJsonToolParser", "PythonicToolParser"]
