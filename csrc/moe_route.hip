@@ -11,6 +11,12 @@
 // layer is eight launches: router GEMM, topk, align, row gather, two grouped
 // GEMMs, SiLU, combine.  Nothing here synchronises with the host, so the step
 // stays hipGraph-capturable.
+//
+//   moe_route_small   the first three steps (top-k, slot sort + tile table, gather of the
+//                 token rows into expert order) in ONE launch for decode batches of at most
+//                 16 tokens: every workgroup repeats the (tiny) routing computation in LDS, so
+//                 no workgroup waits for another, and then copies its share of the rows.
+//                 Positions within an expert follow slot order, so all workgroups agree.
 #include "common.h"
 
 namespace {
@@ -22,15 +28,10 @@ constexpr int ALIGN_THREADS = 1024;
 
 template <typename T> __device__ __forceinline__ float to_f(T v) { return (float)v; }
 
-// one wave per token
+// softmax + top-k of one token's logits by one wave: lane j (< k) returns the j-th pick
 template <typename T>
-__global__ __launch_bounds__(256) void moe_topk_kernel(const T* __restrict__ logits, long stride,
-                                                       float* __restrict__ topw, int* __restrict__ topi, int tokens,
-                                                       int E, int k, int renorm) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int t = blockIdx.x * 4 + wid;
-  if (t >= tokens) return;
-  const T* row = logits + (long)t * stride;
+__device__ __forceinline__ void wave_topk(const T* __restrict__ row, int E, int k, int renorm, int lane,
+                                          float& out_w, int& out_i) {
   float v[TOPK_MAX_VPL];
   float mx = -INFINITY;
 #pragma unroll
@@ -72,9 +73,24 @@ __global__ __launch_bounds__(256) void moe_topk_kernel(const T* __restrict__ log
     if (lane == j) { picked_w = best * inv_sum; picked_i = best_e; }
     wsum += best * inv_sum;
   }
+  out_w = renorm ? picked_w / wsum : picked_w;
+  out_i = picked_i;
+}
+
+// one wave per token
+template <typename T>
+__global__ __launch_bounds__(256) void moe_topk_kernel(const T* __restrict__ logits, long stride,
+                                                       float* __restrict__ topw, int* __restrict__ topi, int tokens,
+                                                       int E, int k, int renorm) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int t = blockIdx.x * 4 + wid;
+  if (t >= tokens) return;
+  float w;
+  int e;
+  wave_topk(logits + (long)t * stride, E, k, renorm, lane, w, e);
   if (lane < k) {
-    topw[(long)t * k + lane] = renorm ? picked_w / wsum : picked_w;
-    topi[(long)t * k + lane] = picked_i;
+    topw[(long)t * k + lane] = w;
+    topi[(long)t * k + lane] = e;
   }
 }
 
@@ -131,6 +147,115 @@ __global__ __launch_bounds__(ALIGN_THREADS) void moe_align_kernel(
     tiles[3 * j + 0] = 0;
     tiles[3 * j + 1] = 0;
     tiles[3 * j + 2] = 0;
+  }
+}
+
+constexpr int SMALL_MAX_TOKENS = 16;                              // one wave per token in a 1024-thread workgroup
+constexpr int SMALL_MAX_SLOTS = SMALL_MAX_TOKENS * TOPK_MAX_K;
+constexpr int SMALL_MAX_E = 64 * TOPK_MAX_VPL;
+
+// grid = any number of workgroups >= 1; workgroup 0 writes the routing tables, every workgroup
+// copies rows pos = blockIdx.x, blockIdx.x + gridDim.x, ... of the expert-sorted activations
+template <typename T, typename TX>
+__global__ __launch_bounds__(ALIGN_THREADS) void moe_route_small_kernel(
+    const T* __restrict__ logits, long lstride, int tokens, int E, int k, int renorm, int tile_rows, int expert_start,
+    int local_experts, float* __restrict__ topw, int* __restrict__ topi, int* __restrict__ src_row,
+    int* __restrict__ inv, int* __restrict__ tiles, int max_tiles, const TX* __restrict__ x, long xstride,
+    TX* __restrict__ xs, int H) {
+  __shared__ __attribute__((aligned(16))) int s_topi[SMALL_MAX_SLOTS];
+  __shared__ int s_src[SMALL_MAX_SLOTS];
+  __shared__ int counts[SMALL_MAX_E], row0[SMALL_MAX_E], tile0[SMALL_MAX_E];
+  __shared__ int total_tiles;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const bool writer = blockIdx.x == 0;
+  const int slots = tokens * k;
+  for (int e = tid; e < E; e += ALIGN_THREADS) counts[e] = 0;
+  if (wid < tokens) {
+    float w;
+    int e;
+    wave_topk(logits + (long)wid * lstride, E, k, renorm, lane, w, e);
+    if (lane < k) {
+      s_topi[wid * k + lane] = e;
+      if (writer) {
+        topw[(long)wid * k + lane] = w;
+        topi[(long)wid * k + lane] = e;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < slots) atomicAdd(&counts[s_topi[tid]], 1);
+  __syncthreads();
+  if (tid < 64) {
+    int rbase = 0, tbase = 0;
+    for (int e0 = 0; e0 < E; e0 += 64) {
+      const int e = e0 + tid;
+      const int c = e < E ? counts[e] : 0;
+      const int tl = (c + tile_rows - 1) / tile_rows;
+      int rs = c, ts = tl;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int r2 = __shfl_up(rs, o, 64), t2 = __shfl_up(ts, o, 64);
+        if (tid >= o) { rs += r2; ts += t2; }
+      }
+      if (e < E) { row0[e] = rbase + rs - c; tile0[e] = tbase + ts - tl; }
+      rbase += __shfl(rs, 63, 64);
+      tbase += __shfl(ts, 63, 64);
+    }
+    if (tid == 0) total_tiles = tbase;
+  }
+  __syncthreads();
+  {
+    // position within the expert = number of earlier slots routed to it: the same in every workgroup.
+    // Four threads per slot, each counting a quarter of the earlier slots, four at a time.
+    const int slot = tid >> 2, part = tid & 3;
+    int rank = 0, e = -1;
+    if (slot < slots) {
+      e = s_topi[slot];
+      const int quads = (slot + 3) >> 2;                          // int4 groups that hold slots < slot
+      for (int q = part; q < quads; q += 4) {
+        const int4 v = *reinterpret_cast<const int4*>(&s_topi[4 * q]);
+        const int base = 4 * q;
+        rank += (v.x == e && base < slot) + (v.y == e && base + 1 < slot) + (v.z == e && base + 2 < slot) +
+                (v.w == e && base + 3 < slot);
+      }
+    }
+    rank += __shfl_xor(rank, 1, 64);
+    rank += __shfl_xor(rank, 2, 64);
+    if (slot < slots && part == 0) {
+      const int pos = row0[e] + rank;
+      s_src[pos] = slot / k;
+      if (writer) {
+        inv[slot] = pos;
+        src_row[pos] = slot / k;
+      }
+    }
+  }
+  if (writer) {
+    for (int e = tid; e < E; e += ALIGN_THREADS) {
+      const int c = counts[e];
+      const bool local = local_experts < 0 || (e >= expert_start && e < expert_start + local_experts);
+      const int le = local_experts < 0 ? e : min(max(e - expert_start, 0), max(local_experts - 1, 0));
+      int j = tile0[e];
+      for (int r = 0; r < c; r += tile_rows, ++j) {
+        if (j >= max_tiles) break;
+        tiles[3 * j + 0] = le;
+        tiles[3 * j + 1] = row0[e] + r;
+        tiles[3 * j + 2] = local ? min(tile_rows, c - r) : 0;
+      }
+    }
+    for (int j = total_tiles + tid; j < max_tiles; j += ALIGN_THREADS) {
+      tiles[3 * j + 0] = 0;
+      tiles[3 * j + 1] = 0;
+      tiles[3 * j + 2] = 0;
+    }
+  }
+  __syncthreads();
+  using V = typename Vec8<TX>::type;
+  const int vecs = H >> 3;
+  for (int pos = blockIdx.x; pos < slots; pos += gridDim.x) {
+    const TX* src = x + (long)s_src[pos] * xstride;
+    TX* dst = xs + (long)pos * H;
+    for (int v = tid; v < vecs; v += ALIGN_THREADS) st8<TX>(dst + 8 * v, ld8<TX>(src + 8 * v));
   }
 }
 
@@ -215,6 +340,37 @@ VDAMD_API int vdamd_moe_combine(void* out, long out_stride, const void* y, long 
                        (const f16_t*)y, y_stride, topw, topi, inv, k, H, expert_start, local_experts);
   else
     return -2;
+  HIP_LAUNCH_CHECK();
+  return 0;
+}
+
+// top-k + slot sort + tile table + row gather for tokens <= 16 (see moe_route_small_kernel).  xs holds
+// tokens * k rows of H; tiles holds max_tiles >= tokens * k / tile_rows + E entries; x and xs are 16-bit.
+VDAMD_API int vdamd_moe_route_small(const void* logits, long lstride, int tokens, int E, int k, int renorm,
+                                    int tile_rows, int expert_start, int local_experts, float* topw, int* topi,
+                                    int* src_row, int* inv, int* tiles, int max_tiles, const void* x, long xstride,
+                                    void* xs, int H, int logits_dtype, int x_dtype, hipStream_t s) {
+  if (tokens <= 0) return 0;
+  if (tokens > SMALL_MAX_TOKENS || E < k || E > SMALL_MAX_E || k < 1 || k > TOPK_MAX_K || tile_rows < 1 || H % 8 ||
+      max_tiles < tokens * k / tile_rows + E)
+    return -1;
+  const dim3 grid((unsigned)(tokens * k)), block(ALIGN_THREADS);
+#define VDAMD_ROUTE_SMALL(TL, TXX)                                                                                  \
+  hipLaunchKernelGGL((moe_route_small_kernel<TL, TXX>), grid, block, 0, s, (const TL*)logits, lstride, tokens, E, k, \
+                     renorm, tile_rows, expert_start, local_experts, topw, topi, src_row, inv, tiles, max_tiles,    \
+                     (const TXX*)x, xstride, (TXX*)xs, H)
+  if (x_dtype == DT_BF16) {
+    if (logits_dtype == DT_BF16) VDAMD_ROUTE_SMALL(bf16_t, bf16_t);
+    else if (logits_dtype == DT_F32) VDAMD_ROUTE_SMALL(float, bf16_t);
+    else return -2;
+  } else if (x_dtype == DT_F16) {
+    if (logits_dtype == DT_F16) VDAMD_ROUTE_SMALL(f16_t, f16_t);
+    else if (logits_dtype == DT_F32) VDAMD_ROUTE_SMALL(float, f16_t);
+    else return -2;
+  } else {
+    return -2;
+  }
+#undef VDAMD_ROUTE_SMALL
   HIP_LAUNCH_CHECK();
   return 0;
 }

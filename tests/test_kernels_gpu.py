@@ -515,6 +515,36 @@ def test_moe_align_and_combine(tokens, experts, k, tile_rows, ep):
     assert (out.float() - want).abs().max().item() <= 2 ** -7 * want.abs().max().item() + 1e-6
 
 
+@pytest.mark.parametrize("ldtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("tokens,experts,k,tile_rows,renorm,ep", [(1, 160, 8, 16, True, None), (16, 160, 8, 16, True, None),
+                                                                   (7, 8, 2, 32, False, None), (16, 512, 16, 16, True, None),
+                                                                   (5, 16, 4, 16, True, (4, 8)), (3, 64, 1, 64, False, None)])
+def test_moe_route_small_is_topk_align_and_gather_in_one_launch(ldtype, tokens, experts, k, tile_rows, renorm, ep):
+    """The decode-batch routing kernel: the picks and weights of ``moe_topk``, the tile table of ``moe_align``
+    (it depends on the per-expert counts only), a slot sort that is a permutation grouped by expert with the
+    rows of one expert in slot order, and ``xs`` = the token rows in that order."""
+    from vllm_distributed_amd.ops import hip
+    ops.hip_available()
+    torch.manual_seed(tokens * 1000 + experts)
+    logits = (torch.randn(tokens, experts, device=DEV) * 2).to(ldtype)
+    x = torch.randn(tokens, 1032, device=DEV).to(torch.bfloat16)[:, :1024]       # strided rows
+    start, local = ep if ep else (0, -1)
+    topw, topi, inv, tiles, xs = hip.moe_route_small(logits, x, k, renorm, tile_rows, start, local)
+    rw, ri = hip.moe_topk(logits, k, renorm)
+    assert torch.equal(topi, ri) and torch.equal(topw, rw)
+    _, _, rtiles = hip.moe_align(ri, experts, tile_rows, start, local)
+    assert torch.equal(tiles, rtiles)
+    slots = tokens * k
+    flat = topi.reshape(-1).long()
+    assert torch.equal(inv.long().sort().values, torch.arange(slots, device=DEV))
+    sorted_experts = torch.empty(slots, dtype=torch.long, device=DEV)
+    sorted_experts[inv.long()] = flat
+    assert (sorted_experts[1:] >= sorted_experts[:-1]).all()
+    # slot order within an expert: the sort is the stable one
+    assert torch.equal(inv.long(), torch.argsort(torch.argsort(flat, stable=True), stable=True))
+    assert torch.equal(xs[inv.long()], x[torch.arange(slots, device=DEV) // k])
+
+
 # ---------------------------------------------------------------- e4m3 KV cache
 FP8 = torch.float8_e4m3fn
 

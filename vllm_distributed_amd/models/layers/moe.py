@@ -241,8 +241,14 @@ class FusedMoE(nn.Module):
         """Routing, expert GEMMs and the weighted sum in eight launches (router
         GEMM included): top-k, slot sort + tile table and the combine are one HIP
         kernel each."""
-        topw, topi = ops.moe_topk(logits, self.top_k, self.renormalize)
         local = self.local_experts if self.expert_parallel else -1
+        if ops.moe_route_small_ok(logits, x):
+            # decode-sized batch: top-k, slot sort, tile table and the row gather are one launch
+            topw, topi, inv, tiles, xs = ops.moe_route_small(logits, x, self.top_k, self.renormalize, tile_rows,
+                                                             self.expert_start, local)
+            return ops.moe_combine(self._experts_grouped(xs, tiles, tile_rows), topw, topi, inv,
+                                   self.expert_start, local)
+        topw, topi = ops.moe_topk(logits, self.top_k, self.renormalize)
         src_row, inv, tiles = ops.moe_align_fused(topi, self.num_experts, tile_rows, self.expert_start, local)
         y = self._experts_grouped(x.index_select(0, src_row), tiles, tile_rows)
         return ops.moe_combine(y, topw, topi, inv, self.expert_start, local)

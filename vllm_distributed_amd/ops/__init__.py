@@ -427,6 +427,18 @@ def moe_align_fused(topi, num_experts: int, tile_rows: int, expert_start: int = 
     return _hip.moe_align(topi, num_experts, tile_rows, expert_start, local_experts)
 
 
+def moe_route_small_ok(logits, x) -> bool:
+    """Whether the one-launch routing path takes this (decode-sized) batch."""
+    return (x.shape[0] <= _hip.MOE_SMALL_MAX_TOKENS and x.dtype in (torch.bfloat16, torch.float16)
+            and logits.dtype in (x.dtype, torch.float32) and x.stride(1) == 1 and x.stride(0) % 8 == 0
+            and x.shape[1] % 8 == 0 and x.data_ptr() % 16 == 0)
+
+
+def moe_route_small(logits, x, k: int, renormalize: bool, tile_rows: int, expert_start: int = 0,
+                    local_experts: int = -1):
+    return _hip.moe_route_small(logits, x, k, renormalize, tile_rows, expert_start, local_experts)
+
+
 def moe_combine(y, topw, topi, inv, expert_start: int = 0, local_experts: int = -1):
     return _hip.moe_combine(y, topw, topi, inv, expert_start, local_experts)
 

@@ -51,6 +51,7 @@ def load() -> ctypes.CDLL:
         "vdamd_w4a16_gemm_grouped": [P, L, P, L, P, P, L, L, P, I, I, I, I, I, I, P],
         "vdamd_moe_topk": [P, L, P, P, I, I, I, I, I, P],
         "vdamd_moe_align": [P, I, I, I, I, I, I, P, P, P, I, P],
+        "vdamd_moe_route_small": [P, L, I, I, I, I, I, I, I, P, P, P, P, P, I, P, L, P, I, I, I, P],
         "vdamd_moe_combine": [P, L, P, L, P, P, P, I, I, I, I, I, I, P],
         "vdamd_fp4a16_gemm": [P, L, P, L, P, P, P, P, I, I, I, I, I, I, P],
         "vdamd_fp4_dequant": [P, P, P, P, I, I, I, P],
@@ -843,6 +844,35 @@ def moe_align(topi: torch.Tensor, num_experts: int, tile_rows: int, expert_start
     _check(_LIB.vdamd_moe_align(topi.data_ptr(), slots, k, num_experts, tile_rows, expert_start, local_experts,
                                 src_row.data_ptr(), inv.data_ptr(), tiles.data_ptr(), n, _stream()), "moe_align")
     return src_row, inv, tiles
+
+
+MOE_SMALL_MAX_TOKENS = 16
+
+
+def moe_route_small(logits: torch.Tensor, x: torch.Tensor, k: int, renormalize: bool, tile_rows: int,
+                    expert_start: int = 0, local_experts: int = -1):
+    """``moe_topk`` + ``moe_align`` + the gather ``x[src_row]`` in one launch, for at most 16 tokens:
+    ``(topw, topi, inv, tiles, xs [T*k, H])``.  Rows of one expert keep slot order."""
+    t, e = logits.shape
+    h = x.shape[1]
+    assert logits.stride(1) == 1 and x.shape[0] == t and _half(x) and x.stride(1) == 1 and h % 8 == 0
+    assert x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
+    assert 1 <= t <= MOE_SMALL_MAX_TOKENS and k <= e <= MOE_MAX_EXPERTS and 1 <= k <= MOE_MAX_TOPK
+    assert logits.dtype in (x.dtype, torch.float32)
+    slots = t * k
+    n = slots // tile_rows + e
+    dev = x.device
+    topw = torch.empty((t, k), dtype=torch.float32, device=dev)
+    ints = torch.empty(3 * slots + 3 * n, dtype=torch.int32, device=dev)          # one allocation for the tables
+    topi, src_row, inv = ints[:slots].view(t, k), ints[slots:2 * slots], ints[2 * slots:3 * slots]
+    tiles = ints[3 * slots:].view(n, 3)
+    xs = torch.empty((slots, h), dtype=x.dtype, device=dev)
+    _check(_LIB.vdamd_moe_route_small(logits.data_ptr(), logits.stride(0), t, e, k, int(renormalize), tile_rows,
+                                      expert_start, local_experts, topw.data_ptr(), topi.data_ptr(),
+                                      src_row.data_ptr(), inv.data_ptr(), tiles.data_ptr(), n, x.data_ptr(),
+                                      x.stride(0), xs.data_ptr(), h, _dt(logits), _dt(x), _stream()),
+           "moe_route_small")
+    return topw, topi, inv, tiles, xs
 
 
 def moe_combine(y: torch.Tensor, topw: torch.Tensor, topi: torch.Tensor, inv: torch.Tensor, expert_start: int = 0,
