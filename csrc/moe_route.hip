@@ -161,19 +161,52 @@ __global__ __launch_bounds__(ALIGN_THREADS) void moe_route_small_kernel(
     const T* __restrict__ logits, long lstride, int tokens, int E, int k, int renorm, int tile_rows, int expert_start,
     int local_experts, float* __restrict__ topw, int* __restrict__ topi, int* __restrict__ src_row,
     int* __restrict__ inv, int* __restrict__ tiles, int max_tiles, const TX* __restrict__ x, long xstride,
-    TX* __restrict__ xs, int H) {
+    TX* __restrict__ xs, int H, int nsplit, long sstride) {
   __shared__ __attribute__((aligned(16))) int s_topi[SMALL_MAX_SLOTS];
   __shared__ int s_src[SMALL_MAX_SLOTS];
+  __shared__ float s_logit[SMALL_MAX_TOKENS * SMALL_MAX_E], s_part[ALIGN_THREADS];
   __shared__ int counts[SMALL_MAX_E], row0[SMALL_MAX_E], tile0[SMALL_MAX_E];
   __shared__ int total_tiles;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const bool writer = blockIdx.x == 0;
   const int slots = tokens * k;
   for (int e = tid; e < E; e += ALIGN_THREADS) counts[e] = 0;
+  if (nsplit > 1) {
+    // Add up the router GEMM's partial sums into LDS first, several threads per logit when there are few
+    // logits, each with independent loads in flight.  Fixed summation order: every workgroup gets the same
+    // bits, hence the same picks.
+    if constexpr (sizeof(T) == 4) {
+      const int total = tokens * E;
+      const int parts = max(1, min(nsplit, ALIGN_THREADS / total));
+      for (int wi = tid; wi < total * parts; wi += ALIGN_THREADS) {
+        const int el = wi % total, part = wi / total;
+        const float* p = (const float*)logits + (long)(el / E) * lstride + (el % E);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int sp = part;
+        for (; sp + 3 * parts < nsplit; sp += 4 * parts) {
+          a0 += p[(long)sp * sstride];
+          a1 += p[(long)(sp + parts) * sstride];
+          a2 += p[(long)(sp + 2 * parts) * sstride];
+          a3 += p[(long)(sp + 3 * parts) * sstride];
+        }
+        for (; sp < nsplit; sp += parts) a0 += p[(long)sp * sstride];
+        const float a = (a0 + a1) + (a2 + a3);
+        if (parts == 1) s_logit[el] = a; else s_part[part * total + el] = a;
+      }
+      __syncthreads();
+      if (parts > 1 && tid < total) {
+        float a = 0.f;
+        for (int q = 0; q < parts; ++q) a += s_part[q * total + tid];
+        s_logit[tid] = a;
+      }
+      __syncthreads();
+    }
+  }
   if (wid < tokens) {
     float w;
     int e;
-    wave_topk(logits + (long)wid * lstride, E, k, renorm, lane, w, e);
+    if (nsplit > 1) wave_topk(s_logit + wid * E, E, k, renorm, lane, w, e);
+    else wave_topk(logits + (long)wid * lstride, E, k, renorm, lane, w, e);
     if (lane < k) {
       s_topi[wid * k + lane] = e;
       if (writer) {
@@ -346,11 +379,14 @@ VDAMD_API int vdamd_moe_combine(void* out, long out_stride, const void* y, long 
 
 // top-k + slot sort + tile table + row gather for tokens <= 16 (see moe_route_small_kernel).  xs holds
 // tokens * k rows of H; tiles holds max_tiles >= tokens * k / tile_rows + E entries; x and xs are 16-bit.
+// nsplit > 1: logits are fp32 partial sums [nsplit][tokens][E] (sstride elements apart), added up here.
 VDAMD_API int vdamd_moe_route_small(const void* logits, long lstride, int tokens, int E, int k, int renorm,
                                     int tile_rows, int expert_start, int local_experts, float* topw, int* topi,
                                     int* src_row, int* inv, int* tiles, int max_tiles, const void* x, long xstride,
-                                    void* xs, int H, int logits_dtype, int x_dtype, hipStream_t s) {
+                                    void* xs, int H, int logits_dtype, int x_dtype, int nsplit, long sstride,
+                                    hipStream_t s) {
   if (tokens <= 0) return 0;
+  if (nsplit < 1 || (nsplit > 1 && logits_dtype != DT_F32)) return -3;
   if (tokens > SMALL_MAX_TOKENS || E < k || E > SMALL_MAX_E || k < 1 || k > TOPK_MAX_K || tile_rows < 1 || H % 8 ||
       max_tiles < tokens * k / tile_rows + E)
     return -1;
@@ -358,7 +394,7 @@ VDAMD_API int vdamd_moe_route_small(const void* logits, long lstride, int tokens
 #define VDAMD_ROUTE_SMALL(TL, TXX)                                                                                  \
   hipLaunchKernelGGL((moe_route_small_kernel<TL, TXX>), grid, block, 0, s, (const TL*)logits, lstride, tokens, E, k, \
                      renorm, tile_rows, expert_start, local_experts, topw, topi, src_row, inv, tiles, max_tiles,    \
-                     (const TXX*)x, xstride, (TXX*)xs, H)
+                     (const TXX*)x, xstride, (TXX*)xs, H, nsplit, sstride)
   if (x_dtype == DT_BF16) {
     if (logits_dtype == DT_BF16) VDAMD_ROUTE_SMALL(bf16_t, bf16_t);
     else if (logits_dtype == DT_F32) VDAMD_ROUTE_SMALL(float, bf16_t);

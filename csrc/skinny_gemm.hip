@@ -184,7 +184,7 @@ static int launch_skinny(const void* x, long xs, const void* w, long ws, void* o
   }
 #undef SG_CASE
   HIP_LAUNCH_CHECK();
-  if (ksplit > 1) {
+  if (ksplit > 1 && out != nullptr) {            // out == nullptr: the caller consumes the partial sums itself
     const long n = (long)M * (N / 4);
     skinny_reduce_kernel<T><<<(unsigned)((n + 255) / 256), 256, 0, st>>>((T*)out, os, (const float*)partial, M, N,
                                                                         ksplit);
@@ -206,6 +206,7 @@ VDAMD_API int vdamd_skinny_gemm(void* out, long out_stride, const void* x, long 
   if (M > 128 || K % 128 || N % 16 || ksplit < 1 || ksplit > K / 128) return -1;
   if (ntw != 1 && ntw != 2 && ntw != 4) return -4;
   if (ksplit > 1 && partial == nullptr) return -2;
+  if (out == nullptr && ksplit == 1) return -2;      // partial sums only: there must be a split to leave them in
   if ((x_stride | w_stride) % 8 || out_stride % 4) return -5;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16)

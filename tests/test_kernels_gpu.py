@@ -545,6 +545,25 @@ def test_moe_route_small_is_topk_align_and_gather_in_one_launch(ldtype, tokens, 
     assert torch.equal(xs[inv.long()], x[torch.arange(slots, device=DEV) // k])
 
 
+@pytest.mark.parametrize("tokens,experts,k", [(1, 160, 8), (16, 160, 8), (4, 64, 2)])
+def test_moe_route_small_adds_up_router_gemm_partial_sums(tokens, experts, k):
+    """The router GEMM's K-split partial sums go to the routing kernel unreduced: same picks as routing on
+    their sum, and ``skinny_gemm_partials`` really is the unreduced GEMM."""
+    from vllm_distributed_amd.ops import hip
+    ops.hip_available()
+    torch.manual_seed(tokens + experts)
+    x = torch.randn(tokens, 2048, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(experts, 2048, device=DEV) * 0.05).to(torch.bfloat16)
+    parts = hip.skinny_gemm_partials(x, w)
+    assert parts is not None and parts.dim() == 3 and parts.shape[1:] == (tokens, experts)
+    total = parts.sum(0)
+    assert (total - x.float() @ w.float().t()).abs().max().item() < 2e-2
+    topw, topi, inv, tiles, xs = hip.moe_route_small(parts, x, k, True, 16)
+    rw, ri = hip.moe_topk(total.contiguous(), k, True)
+    assert torch.equal(topi, ri) and torch.allclose(topw, rw, atol=1e-6)
+    assert torch.equal(xs[inv.long()], x[torch.arange(tokens * k, device=DEV) // k])
+
+
 # ---------------------------------------------------------------- e4m3 KV cache
 FP8 = torch.float8_e4m3fn
 

@@ -266,8 +266,18 @@ class FusedMoE(nn.Module):
 
     def forward(self, x: torch.Tensor, reduce: bool = True, staged: bool = False) -> torch.Tensor:
         # `staged` (write the partial sums where the next direct all-reduce reads) is a hint only
-        logits = self.gate(x)
         tile_rows = self._grouped_tile_rows(x)
+        logits = None
+        if (tile_rows and not self.custom_routing and self.gate.bias is None
+                and getattr(self.gate, "lora", None) is None and self.num_experts <= 512 and self.top_k <= 16):
+            # decode: the routing kernel adds up the router GEMM's K-split partial sums itself
+            logits = ops.router_logit_partials(x, self.gate.weight)
+            if logits is not None:
+                out = self._forward_fused_routing(x, logits, tile_rows)
+                if reduce and self.tp > 1:
+                    out = tensor_model_parallel_all_reduce(out)
+                return out
+        logits = self.gate(x)
         if (tile_rows and x.dim() == 2 and not self.custom_routing
                 and ops.moe_route_fused_ok(logits, self.num_experts, self.top_k)):
             out = self._forward_fused_routing(x, logits, tile_rows)

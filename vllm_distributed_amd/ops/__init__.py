@@ -428,10 +428,18 @@ def moe_align_fused(topi, num_experts: int, tile_rows: int, expert_start: int = 
 
 
 def moe_route_small_ok(logits, x) -> bool:
-    """Whether the one-launch routing path takes this (decode-sized) batch."""
-    return (x.shape[0] <= _hip.MOE_SMALL_MAX_TOKENS and x.dtype in (torch.bfloat16, torch.float16)
-            and logits.dtype in (x.dtype, torch.float32) and x.stride(1) == 1 and x.stride(0) % 8 == 0
-            and x.shape[1] % 8 == 0 and x.data_ptr() % 16 == 0)
+    """Whether the one-launch routing path takes this (decode-sized) batch (``logits`` None: not computed yet)."""
+    return (x.dim() == 2 and 0 < x.shape[0] <= _hip.MOE_SMALL_MAX_TOKENS and x.dtype in (torch.bfloat16, torch.float16)
+            and (logits is None or logits.dtype in (x.dtype, torch.float32)) and x.stride(1) == 1
+            and x.stride(0) % 8 == 0 and x.shape[1] % 8 == 0 and x.data_ptr() % 16 == 0)
+
+
+def router_logit_partials(x, weight):
+    """Router GEMM for a decode-sized batch with its K-split reduction left to the routing kernel: fp32
+    ``[splits, T, E]``, or None when the plain GEMM should run."""
+    if not (_use_hip(x) and weight.dtype == x.dtype and moe_route_small_ok(None, x)):
+        return None
+    return _hip.skinny_gemm_partials(x, weight)
 
 
 def moe_route_small(logits, x, k: int, renormalize: bool, tile_rows: int, expert_start: int = 0,

@@ -51,7 +51,7 @@ def load() -> ctypes.CDLL:
         "vdamd_w4a16_gemm_grouped": [P, L, P, L, P, P, L, L, P, I, I, I, I, I, I, P],
         "vdamd_moe_topk": [P, L, P, P, I, I, I, I, I, P],
         "vdamd_moe_align": [P, I, I, I, I, I, I, P, P, P, I, P],
-        "vdamd_moe_route_small": [P, L, I, I, I, I, I, I, I, P, P, P, P, P, I, P, L, P, I, I, I, P],
+        "vdamd_moe_route_small": [P, L, I, I, I, I, I, I, I, P, P, P, P, P, I, P, L, P, I, I, I, I, L, P],
         "vdamd_moe_combine": [P, L, P, L, P, P, P, I, I, I, I, I, I, P],
         "vdamd_fp4a16_gemm": [P, L, P, L, P, P, P, P, I, I, I, I, I, I, P],
         "vdamd_fp4_dequant": [P, P, P, P, I, I, I, P],
@@ -550,6 +550,23 @@ def skinny_gemm(x: torch.Tensor, w: torch.Tensor, ntw: Optional[int] = None, ksp
     return out
 
 
+def skinny_gemm_partials(x: torch.Tensor, w: torch.Tensor) -> Optional[torch.Tensor]:
+    """``skinny_gemm`` without its reduction: the fp32 partial sums ``[ksplit, M, N]`` of ``x @ w^T``, for a
+    consumer that adds them up while it loads them (the decode routing kernel).  None when the shape is
+    not split over K (there is then nothing to save) or not one the kernel takes."""
+    if not skinny_supported(x, w):
+        return None
+    m, k = x.shape
+    n = w.shape[0]
+    ntw, ksplit = skinny_choose(m, n, k)
+    if ksplit <= 1:
+        return None
+    partial = torch.empty((ksplit, m, n), dtype=torch.float32, device=x.device)
+    _check(_LIB.vdamd_skinny_gemm(None, n, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), partial.data_ptr(),
+                                  m, n, k, ksplit, ntw, _dt(x), 0, _stream()), "skinny_gemm (partial sums)")
+    return partial
+
+
 # ------------------------------------------- weight-streaming GEMM, M <= 16
 STREAM_MAX_M = 16
 EPI_NONE, EPI_RESIDUAL, EPI_SILU_MUL = 0, 1, 2
@@ -853,6 +870,11 @@ def moe_route_small(logits: torch.Tensor, x: torch.Tensor, k: int, renormalize: 
                     expert_start: int = 0, local_experts: int = -1):
     """``moe_topk`` + ``moe_align`` + the gather ``x[src_row]`` in one launch, for at most 16 tokens:
     ``(topw, topi, inv, tiles, xs [T*k, H])``.  Rows of one expert keep slot order."""
+    nsplit, sstride = 1, 0
+    if logits.dim() == 3:                       # fp32 partial sums of a K-split router GEMM, [splits, T, E]
+        assert logits.dtype == torch.float32 and logits.is_contiguous()
+        nsplit, sstride = logits.shape[0], logits.stride(0)
+        logits = logits[0]
     t, e = logits.shape
     h = x.shape[1]
     assert logits.stride(1) == 1 and x.shape[0] == t and _half(x) and x.stride(1) == 1 and h % 8 == 0
@@ -870,7 +892,7 @@ def moe_route_small(logits: torch.Tensor, x: torch.Tensor, k: int, renormalize: 
     _check(_LIB.vdamd_moe_route_small(logits.data_ptr(), logits.stride(0), t, e, k, int(renormalize), tile_rows,
                                       expert_start, local_experts, topw.data_ptr(), topi.data_ptr(),
                                       src_row.data_ptr(), inv.data_ptr(), tiles.data_ptr(), n, x.data_ptr(),
-                                      x.stride(0), xs.data_ptr(), h, _dt(logits), _dt(x), _stream()),
+                                      x.stride(0), xs.data_ptr(), h, _dt(logits), _dt(x), nsplit, sstride, _stream()),
            "moe_route_small")
     return topw, topi, inv, tiles, xs
 
