@@ -101,6 +101,10 @@ CASES = {
                                   topk_group=1, first_k_dense_replace=1, routed_scaling_factor=1.5,
                                   norm_topk_prob=True, pad_token_id=0, sliding_window=16,
                                   layer_types=["full_attention", "sliding_attention", "full_attention"])),
+    "granite-moe": ("GraniteMoeConfig", dict(BASE, intermediate_size=32, num_local_experts=4, num_experts_per_tok=2,
+                                             embedding_multiplier=6.0, residual_multiplier=0.4,
+                                             attention_multiplier=0.1, logits_scaling=4.0, tie_word_embeddings=True,
+                                             pad_token_id=0)),
     "olmo": ("OlmoConfig", dict(BASE, clip_qkv=0.6, pad_token_id=0)),
     "olmoe": ("OlmoeConfig", dict(BASE, intermediate_size=64, num_experts=8, num_experts_per_tok=2, clip_qkv=1.5,
                                   pad_token_id=0)),

@@ -20,6 +20,7 @@ _MODELS: Dict[str, Tuple[str, str]] = {
     "DeepseekV3ForCausalLM": ("deepseek", "DeepseekV3ForCausalLM"),
     "Glm4MoeForCausalLM": ("deepseek", "Glm4MoeForCausalLM"),
     "Dots1ForCausalLM": ("deepseek", "Dots1ForCausalLM"),
+    "GraniteMoeForCausalLM": ("mixtral", "GraniteMoeForCausalLM"),
     "MixtralForCausalLM": ("mixtral", "MixtralForCausalLM"),
     # Phi-3 checkpoints store qkv and gate/up already fused: the fused loaders take them whole
     "Phi3ForCausalLM": ("llama", "LlamaForCausalLM"),
