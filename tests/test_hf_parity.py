@@ -105,6 +105,9 @@ CASES = {
                                              embedding_multiplier=6.0, residual_multiplier=0.4,
                                              attention_multiplier=0.1, logits_scaling=4.0, tie_word_embeddings=True,
                                              pad_token_id=0)),
+    "ernie4_5-moe": ("Ernie4_5_MoeConfig", dict(BASE, num_hidden_layers=3, moe_intermediate_size=32, moe_num_experts=8,
+                                                moe_k=2, moe_num_shared_experts=1, moe_layer_start_index=1,
+                                                pad_token_id=0)),
     "olmo": ("OlmoConfig", dict(BASE, clip_qkv=0.6, pad_token_id=0)),
     "olmoe": ("OlmoeConfig", dict(BASE, intermediate_size=64, num_experts=8, num_experts_per_tok=2, clip_qkv=1.5,
                                   pad_token_id=0)),
@@ -137,6 +140,9 @@ def _hf_model(name, tmp_path):
         for n, b in model.named_buffers():
             if n.endswith("e_score_correction_bias"):       # DeepSeek-V3's choice bias is stored as a buffer
                 b.add_(torch.randn_like(b) * 0.2)
+        for n, p in model.named_parameters():
+            if n.endswith("e_score_correction_bias"):       # (ERNIE: a parameter of shape [1, E])
+                p.add_(torch.randn_like(p) * 0.2)
     model.save_pretrained(str(tmp_path), safe_serialization=True)
     return model
 

@@ -97,7 +97,7 @@ def normalize_hf_config(cfg: Dict[str, Any]) -> None:
         cfg["num_local_experts"] = cfg["num_experts"]
     if "torch_dtype" not in cfg and isinstance(cfg.get("dtype"), str):
         cfg["torch_dtype"] = cfg["dtype"]
-    if cfg.get("model_type") == "ernie4_5" and cfg.get("use_bias") is not None:
+    if cfg.get("model_type") in ("ernie4_5", "ernie4_5_moe") and cfg.get("use_bias") is not None:
         cfg.setdefault("attention_bias", bool(cfg["use_bias"]))      # one switch for every linear layer
         cfg.setdefault("mlp_bias", bool(cfg["use_bias"]))
     rp = cfg.get("rope_parameters")
@@ -286,7 +286,7 @@ class ModelConfig:
                 "helium": "HeliumForCausalLM", "ernie4_5": "Ernie4_5ForCausalLM", "glm": "GlmForCausalLM",
                 "seed_oss": "SeedOssForCausalLM", "ministral": "MinistralForCausalLM",
                 "smollm3": "SmolLM3ForCausalLM", "arcee": "ArceeForCausalLM", "glm4": "Glm4ForCausalLM",
-                "falcon": "FalconForCausalLM", "granitemoe": "GraniteMoeForCausalLM", "gpt_bigcode": "GPTBigCodeForCausalLM", "gptj": "GPTJForCausalLM", "glm4_moe": "Glm4MoeForCausalLM", "dots1": "Dots1ForCausalLM", "deepseek_v2": "DeepseekV2ForCausalLM", "deepseek_v3": "DeepseekV3ForCausalLM",
+                "falcon": "FalconForCausalLM", "ernie4_5_moe": "Ernie4_5_MoeForCausalLM", "granitemoe": "GraniteMoeForCausalLM", "gpt_bigcode": "GPTBigCodeForCausalLM", "gptj": "GPTJForCausalLM", "glm4_moe": "Glm4MoeForCausalLM", "dots1": "Dots1ForCausalLM", "deepseek_v2": "DeepseekV2ForCausalLM", "deepseek_v3": "DeepseekV3ForCausalLM",
                 "olmo2": "Olmo2ForCausalLM", "olmo": "OlmoForCausalLM", "olmoe": "OlmoeForCausalLM", "olmo3": "Olmo3ForCausalLM", "exaone4": "Exaone4ForCausalLM",
                 "stablelm": "StableLmForCausalLM", "nemotron": "NemotronForCausalLM",
                 "cohere": "CohereForCausalLM",

@@ -212,3 +212,66 @@ class Glm4MoeForCausalLM(Qwen3MoeForCausalLM):
 class Dots1ForCausalLM(Qwen3MoeForCausalLM):
     """dots.llm1: Qwen3's attention (per-head q/k norms), windows per ``layer_types``."""
     layer_cls = V3RoutedDecoderLayer
+
+
+class ErnieMoE(FusedMoE):
+    """ERNIE-4.5 MoE block: softmax scores; the top-k is taken on ``scores + bias`` (a stored per-expert
+    balance term), the weights are the unbiased scores of the picks, renormalised with a floor on the sum."""
+    custom_routing = True
+
+    def __init__(self, cfg: dict, dtype: torch.dtype, expert_parallel: bool):
+        n = int(cfg.get("moe_num_experts") or cfg["num_experts"])
+        super().__init__(cfg["hidden_size"], cfg["moe_intermediate_size"], n, cfg["moe_k"],
+                         True, dtype, expert_parallel=expert_parallel)
+        self.norm_min = float(cfg.get("moe_norm_min") or 1e-12)
+        self.gate.e_score_correction_bias = nn.Parameter(torch.zeros(n, dtype=torch.float32),
+                                                         requires_grad=False)
+        self.gate.e_score_correction_bias.weight_loader = \
+            lambda p, w, shard=None: p.data.copy_(materialize(w).reshape(-1))          # stored [1, E]
+        shared = int(cfg.get("moe_num_shared_experts") or 0)
+        self.shared_experts = LlamaMLP(cfg["hidden_size"], cfg["moe_intermediate_size"] * shared, dtype,
+                                       bool(cfg.get("mlp_bias", False))) if shared else None
+
+    def route(self, logits: torch.Tensor):
+        scores = torch.softmax(logits, dim=-1)
+        topi = (scores + self.gate.e_score_correction_bias).topk(self.top_k, dim=-1).indices
+        topw = scores.gather(1, topi)
+        return topw / topw.sum(-1, keepdim=True).clamp(min=self.norm_min), topi
+
+    def forward(self, x: torch.Tensor, reduce: bool = True, staged: bool = False) -> torch.Tensor:
+        out = FusedMoE.forward(self, x, reduce=False)
+        if self.shared_experts is not None:
+            out = out + self.shared_experts(x, reduce=False)
+        if reduce and get_tensor_model_parallel_world_size() > 1:
+            out = tensor_model_parallel_all_reduce(out)
+        return out
+
+
+class ErnieMoeDecoderLayer(Qwen3MoeDecoderLayer):
+    def _make_mlp(self, cfg: dict, dtype: torch.dtype) -> nn.Module:
+        i, last = self._layer_idx, cfg.get("moe_layer_end_index")
+        last = cfg["num_hidden_layers"] - 1 if last in (None, -1) else int(last)
+        sparse = ((i + 1) % int(cfg.get("moe_layer_interval") or 1) == 0
+                  and int(cfg.get("moe_layer_start_index") or 0) <= i <= last)
+        if sparse:
+            return ErnieMoE(cfg, dtype, qwen3_moe._EP)
+        return LlamaMLP(cfg["hidden_size"], cfg["intermediate_size"], dtype, bool(cfg.get("mlp_bias", False)))
+
+
+class Ernie4_5_MoeForCausalLM(Qwen3MoeForCausalLM):
+    """ERNIE-4.5 MoE (text): ERNIE-4.5's attention (rotary embedding over adjacent pairs) + ``ErnieMoE`` on the
+    layers ``moe_layer_start_index .. moe_layer_end_index`` (every ``moe_layer_interval``-th)."""
+    layer_cls = ErnieMoeDecoderLayer
+
+    def __init__(self, vllm_config: VllmConfig):
+        cfg = vllm_config.model_config.hf_config
+        if cfg.get("use_bias"):
+            raise NotImplementedError("ERNIE-4.5 MoE checkpoints with use_bias (biased experts and LM head)")
+        cfg.setdefault("moe_k", cfg.get("num_experts_per_tok") or 2)
+        cfg["num_experts_per_tok"] = cfg["moe_k"]
+        super().__init__(vllm_config)
+
+    def map_weight_name(self, name: str) -> Optional[str]:
+        name = super().map_weight_name(name)
+        # (the balance term sits under the router in newer checkpoints, next to it in the original ones)
+        return None if name is None else name.replace(".gate.moe_statics.", ".gate.").replace(".mlp.moe_statics.", ".mlp.gate.")

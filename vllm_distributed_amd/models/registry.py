@@ -18,6 +18,7 @@ _MODELS: Dict[str, Tuple[str, str]] = {
     "Qwen2MoeForCausalLM": ("qwen2_moe", "Qwen2MoeForCausalLM"),
     "DeepseekV2ForCausalLM": ("deepseek", "DeepseekV2ForCausalLM"),
     "DeepseekV3ForCausalLM": ("deepseek", "DeepseekV3ForCausalLM"),
+    "Ernie4_5_MoeForCausalLM": ("deepseek", "Ernie4_5_MoeForCausalLM"),
     "Glm4MoeForCausalLM": ("deepseek", "Glm4MoeForCausalLM"),
     "Dots1ForCausalLM": ("deepseek", "Dots1ForCausalLM"),
     "GraniteMoeForCausalLM": ("mixtral", "GraniteMoeForCausalLM"),
