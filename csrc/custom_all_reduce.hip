@@ -62,6 +62,8 @@ struct Signal {
 struct Peers {
   Signal* sig[CAR_MAX_RANKS];
   char* data[CAR_MAX_RANKS];
+  uint32_t* host_timeout;     // this rank's word in pinned host memory: the host polls it without touching a stream
+  unsigned long long timeout_ticks;   // bound of every spin, in ticks of the 100 MHz wall clock
 };
 
 struct Context {
@@ -73,6 +75,7 @@ struct Context {
   void* opened[2 * CAR_MAX_RANKS];
   int n_opened;
   int max_blocks;             // workgroups per kernel (<= CAR_MAX_BLOCKS); all ranks use the same value
+  uint32_t* host_flag;        // pinned, device-mapped: set by a kernel whose spin ran out
 };
 
 // Workgroup b of all ranks meet.  RELEASE: this kernel wrote data the peers read after the barrier.
@@ -93,8 +96,10 @@ __device__ __forceinline__ void cross_barrier(const Peers& peers, Signal* self, 
       uint32_t* mine = &self->flag[blockIdx.x][p];
       const unsigned long long t0 = wall_clock64();
       while ((int32_t)(__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
-        if (wall_clock64() - t0 > CAR_TIMEOUT_TICKS) {
+        if (wall_clock64() - t0 > peers.timeout_ticks) {
           __hip_atomic_store(&self->timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (peers.host_timeout != nullptr)
+            __hip_atomic_store(peers.host_timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           break;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -316,6 +321,14 @@ inline int flat_blocks(long packets, int max_blocks) {
 
 }  // namespace
 
+// Bound of every in-kernel spin (default 10 s).  A rank whose peer does not arrive within it sets the
+// timeout word and carries on with whatever it read.
+VDAMD_API void vdamd_car_set_timeout_ms(void* ctx, long ms) {
+  Context* c = (Context*)ctx;
+  if (ms < 1) ms = 1;
+  c->peers.timeout_ticks = (unsigned long long)ms * 100000ULL;
+}
+
 VDAMD_API int vdamd_car_handle_bytes() { return (int)sizeof(hipIpcMemHandle_t); }
 
 // Allocates the data region (4 areas of `cap` bytes) and the signal block.
@@ -337,6 +350,14 @@ VDAMD_API void* vdamd_car_create(int rank, int world, size_t cap, void* data_han
     (void)hipFree(c->self_data); (void)hipFree(c->self_sig); delete c; return nullptr;
   }
   for (int r = 0; r < CAR_MAX_RANKS; ++r) { c->peers.sig[r] = nullptr; c->peers.data[r] = nullptr; }
+  c->host_flag = nullptr;
+  c->peers.host_timeout = nullptr;
+  c->peers.timeout_ticks = CAR_TIMEOUT_TICKS;
+  if (hipHostMalloc((void**)&c->host_flag, 64, hipHostMallocMapped) == hipSuccess) {
+    *c->host_flag = 0;
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, c->host_flag, 0) == hipSuccess) c->peers.host_timeout = (uint32_t*)dp;
+  }
   c->peers.sig[rank] = c->self_sig;
   c->peers.data[rank] = c->self_data;
   return c;
@@ -374,8 +395,12 @@ VDAMD_API void vdamd_car_set_max_blocks(void* ctx, int n) {
   c->max_blocks = n < 1 ? 1 : (n > CAR_MAX_BLOCKS ? CAR_MAX_BLOCKS : n);
 }
 
+// Whether a bounded spin of any kernel of this rank has run out since creation.  Reads a word in
+// pinned host memory: no stream is touched, so the serving loop can ask after every step.
 VDAMD_API int vdamd_car_timed_out(void* ctx) {
   Context* c = (Context*)ctx;
+  if (c->host_flag != nullptr && c->peers.host_timeout != nullptr)
+    return (int)__atomic_load_n(c->host_flag, __ATOMIC_RELAXED);
   uint32_t v = 0;
   (void)hipMemcpy(&v, &c->self_sig->timeout_flag, sizeof(v), hipMemcpyDeviceToHost);
   return (int)v;
@@ -476,5 +501,6 @@ VDAMD_API void vdamd_car_destroy(void* ctx) {
   for (int i = 0; i < c->n_opened; ++i) (void)hipIpcCloseMemHandle(c->opened[i]);
   (void)hipFree(c->self_data);
   (void)hipFree(c->self_sig);
+  if (c->host_flag != nullptr) (void)hipHostFree(c->host_flag);
   delete c;
 }

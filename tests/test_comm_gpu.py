@@ -298,6 +298,7 @@ from vllm_distributed_amd.parallel import state as pstate
 runner = eng.core.executor.driver.worker.model_runner
 print("RESULT " + json.dumps(dict(tokens=[final[i] for i in ids], first_lp=[first_lp[i] for i in ids],
                                   direct_ar=pstate.get_tp_group().custom_ar is not None,
+                                  rccl=pstate.get_tp_group().rccl is not None,
                                   graphs=list(runner.graph_sizes), fallback=runner.graph_fallback_reason)), flush=True)
 eng.shutdown()
 """
@@ -318,13 +319,15 @@ def _assert_distributions_close(ref_lps, got_lps, atol=0.08, rtol=2e-2, min_entr
 
 
 def _run_spmd_shared(world, async_sched, sp="0", overrides=None, model="llama-tiny", ep=False, logprobs=8,
-                     extra_env=None):
+                     extra_env=None, share=True):
+    """``share``: every rank on GPU 0 (gloo, host-staged); otherwise rank r runs on GPU r over RCCL."""
     port = get_open_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), VLLM_LOGGING_LEVEL="WARNING", GLOO_SOCKET_IFNAME="lo",
-                   VDAMD_SHARE_DEVICE="1", ASYNC="1" if async_sched else "0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   VDAMD_SHARE_DEVICE="1" if share else "0", ASYNC="1" if async_sched else "0",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0",
                    VDAMD_SEQUENCE_PARALLEL=sp, OVERRIDES=json.dumps(overrides or {}), MODEL=model,
                    EP="1" if ep else "0", LOGPROBS=str(logprobs), **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, "-c", SPMD_SCRIPT.format(root=ROOT)], env=env,
@@ -448,3 +451,100 @@ def test_spmd_moe_tensor_and_expert_parallel_sharing_one_gpu(ep):
     for lp_ref, lp_tp, toks in zip(ref["first_lp"], got[0]["first_lp"], ref["tokens"]):
         top = str(toks[0])
         assert top in lp_tp and abs(lp_tp[top] - lp_ref[top]) < 0.15, (lp_ref, lp_tp)
+
+
+def _shared_gpu_env(monkeypatch, **extra):
+    env = dict(VLLM_SERVER_PORT=str(get_open_port()), VLLM_RPC_SECRET="test-secret", VLLM_HOST_IP="127.0.0.1",
+               VLLM_LOGGING_LEVEL="WARNING", GLOO_SOCKET_IFNAME="lo", PYTHONPATH=ROOT, VDAMD_SHARE_DEVICE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+
+
+def test_tp2_x_pp2_sharing_one_gpu_runs_the_fused_collectives_on_both_stages(monkeypatch):
+    """The reference's documented deployment shape (`-tp 2 -pp 2`, reference ``.env.server:11``) with the
+    peer-mapped fused all-reduce + add + RMSNorm inside BOTH pipeline stages, in both of its forms: the
+    replicated one (small messages) and the row-sharded one (the residual shards are gathered once at the
+    stage boundary).  Every rank must report the fused path and nothing else, decode must run from
+    graphs, and the first-token distributions must match the unsharded model."""
+    from vllm_distributed_amd import SamplingParams
+    from vllm_distributed_amd.engine.arg_utils import EngineArgs
+    from vllm_distributed_amd.engine.llm_engine import LLMEngine
+    from vllm_distributed_amd.parallel import state as pstate
+
+    prompts = [[5, 9, 200, 17, 3, 3, 8], list(range(10, 90)), [7, 7, 7], [11, 12, 13, 14]]
+
+    def generate(engine):
+        sp = SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True, logprobs=512)
+        ids = [engine.add_request(None, p, sp) for p in prompts]
+        final = {}
+        while engine.has_unfinished_requests():
+            for o in engine.step():
+                if o.finished:
+                    final[o.request_id] = o.outputs[0].logprobs[0]
+        return [final[i] for i in ids]
+
+    common = dict(model="llama-tiny", device="cuda", dtype="bfloat16", max_model_len=256,
+                  num_gpu_blocks_override=64, max_num_seqs=8, gpu_memory_utilization=0.15)
+    pstate.destroy_model_parallel()
+    eng = LLMEngine.from_engine_args(EngineArgs(**common))
+    ref = generate(eng)
+    eng.shutdown()
+    pstate.destroy_model_parallel()
+    for one_shot, want in (("0", "fused_sharded"), (str(1 << 30), "fused_replicated")):
+        _shared_gpu_env(monkeypatch, VLLM_HEAD_LOCAL_DEVICES="4", VDAMD_CUSTOM_ALL_REDUCE_ONE_SHOT_BYTES=one_shot)
+        eng = None
+        try:
+            eng = LLMEngine.from_engine_args(EngineArgs(
+                tensor_parallel_size=2, pipeline_parallel_size=2, distributed_executor_backend="distributed", **common))
+            got = generate(eng)
+            stats = eng.core.executor.collective_rpc("get_stats")
+            assert len(stats) == 4
+            for st in stats:
+                assert st["tp_direct_all_reduce"], st
+                assert set(st["tp_forward_paths"]) == {want}, st["tp_forward_paths"]
+                assert st["hip_graph_sizes"], st["hip_graph_fallback"]
+                assert st["tp_direct_timed_out"] is False
+            _assert_distributions_close(ref, got)
+        finally:
+            if eng is not None:
+                eng.shutdown()
+
+
+def test_peer_that_never_arrives_is_reported_and_fails_the_executor(monkeypatch):
+    """Rank 1 of a TP=2 group stops issuing work at its 6th step (a hung device).  Rank 0's fused
+    all-reduce gives up waiting after the configured bound and sets the timeout word in pinned host
+    memory; the worker reads it after the step and raises; the executor fails (a serving head then
+    exits non-zero), instead of serving sums that miss a rank."""
+    import time
+
+    from vllm_distributed_amd import SamplingParams
+    from vllm_distributed_amd.engine.arg_utils import EngineArgs
+    from vllm_distributed_amd.engine.llm_engine import LLMEngine
+    from vllm_distributed_amd.parallel import state as pstate
+    pstate.destroy_model_parallel()
+    _shared_gpu_env(monkeypatch, VLLM_HEAD_LOCAL_DEVICES="2", VDAMD_CUSTOM_ALL_REDUCE_TIMEOUT_MS="300",
+                    VDAMD_FAULT_STALL_AT="1:6", VLLM_EXECUTE_MODEL_TIMEOUT_SECONDS="60")
+    eng = None
+    try:
+        eng = LLMEngine.from_engine_args(EngineArgs(
+            model="llama-tiny", device="cuda", dtype="bfloat16", max_model_len=256, num_gpu_blocks_override=64,
+            max_num_seqs=8, gpu_memory_utilization=0.15, tensor_parallel_size=2,
+            distributed_executor_backend="distributed"))
+        ex = eng.core.executor
+        failed = []
+        ex.register_failure_callback(lambda: failed.append(True))
+        eng.add_request(None, [5, 9, 200, 17], SamplingParams(temperature=0.0, max_tokens=40, ignore_eos=True))
+        t0 = time.time()
+        with pytest.raises(Exception) as err:
+            while eng.has_unfinished_requests():
+                eng.step()
+        assert time.time() - t0 < 50, "the in-kernel bound, not the RPC timeout, must end the step"
+        deadline = time.time() + 10
+        while not ex.is_failed and time.time() < deadline:
+            time.sleep(0.05)
+        assert ex.is_failed and failed
+        assert "gave up waiting" in str(err.value) or "Executor failed" in str(err.value), str(err.value)
+    finally:
+        if eng is not None:
+            eng.shutdown()

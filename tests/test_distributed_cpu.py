@@ -465,6 +465,51 @@ def test_tp2_x_pp2_head_plus_three_remote_workers_two_batches_in_flight_then_a_k
 
 
 @pytest.mark.slow
+def test_stalled_rank_is_detected_and_the_serving_head_exits_nonzero(tmp_path):
+    """A rank that stops issuing work (a hung device: its process and its connection stay up, so no
+    socket closes) leaves its TP peer waiting inside the all-reduce.  The step's enforced timeout
+    fails the executor, and a serving head (``launch.py serve``) exits non-zero so that the
+    supervisor restarts the deployment (reference ``src/launch.py:142-144``, ``docker-compose.yml:8``)."""
+    port, http = get_open_port(), get_open_port()
+    env = _env(port, VLLM_HEAD_LOCAL_DEVICES="1", VLLM_EXECUTE_MODEL_TIMEOUT_SECONDS="4",
+               VDAMD_FAULT_STALL_AT="1:3", VLLM_LOGGING_LEVEL="INFO")
+    remote = _start_remote(port, 1, 1, VDAMD_FAULT_STALL_AT="1:3")
+    log = open(tmp_path / "head.log", "w")
+    head = subprocess.Popen([sys.executable, os.path.join(ROOT, "launch.py"), "serve", "llama-tiny", "--device", "cpu",
+                             "--dtype", "float32", "--max-model-len", "128", "--block-size", "16",
+                             "--num-gpu-blocks-override", "64", "--max-num-seqs", "4", "-tp", "2", "--host", "127.0.0.1",
+                             "--port", str(http), "--disable-frontend-multiprocessing"],
+                            env=env, stdout=log, stderr=subprocess.STDOUT)
+    try:
+        import urllib.request
+        deadline = time.time() + 120
+        up = False
+        while time.time() < deadline and head.poll() is None and not up:
+            try:
+                up = urllib.request.urlopen(f"http://127.0.0.1:{http}/health", timeout=2).status == 200
+            except Exception:  # noqa: BLE001
+                time.sleep(0.5)
+        assert up, open(tmp_path / "head.log").read()[-3000:]
+        req = urllib.request.Request(f"http://127.0.0.1:{http}/v1/completions", method="POST",
+                                     headers={"Content-Type": "application/json"},
+                                     data=b'{"model": "llama-tiny", "prompt": [5, 9, 200, 17], "max_tokens": 20}')
+        try:
+            urllib.request.urlopen(req, timeout=60).read()
+        except Exception:  # noqa: BLE001 - the request cannot complete: rank 1 never runs its third step
+            pass
+        rc = head.wait(timeout=60)
+        text = open(tmp_path / "head.log").read()
+        assert rc != 0, text[-3000:]
+        assert "execute_model failed on rank" in text, text[-3000:]
+    finally:
+        for p in (head, remote):
+            if p.poll() is None:
+                p.kill()
+            p.wait(timeout=10)
+        log.close()
+
+
+@pytest.mark.slow
 def test_awq_expert_model_at_tp2_x_pp2_matches_single_process(monkeypatch):
     """The model of the reference's example deployment in miniature (``.env.server:11``: an AWQ
     Qwen3-MoE checkpoint served with ``-tp 2 -pp 2``): packed 4-bit experts cut over the TP group,

@@ -85,7 +85,12 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     "VDAMD_CUSTOM_ALL_REDUCE_MAX_BYTES": _int("VDAMD_CUSTOM_ALL_REDUCE_MAX_BYTES", 16 << 20),
     # Messages up to this size are summed by every rank in one pass (one barrier, W x the
     # traffic); larger ones are reduce-scattered and gathered (two barriers, 2 x the traffic).
-    "VDAMD_CUSTOM_ALL_REDUCE_ONE_SHOT_BYTES": _int("VDAMD_CUSTOM_ALL_REDUCE_ONE_SHOT_BYTES", 256 << 10),
+    # "auto": both forms (and RCCL) are timed at bring-up on the machine's own links and the crossover
+    # sizes are taken from that; a number pins the threshold.
+    "VDAMD_CUSTOM_ALL_REDUCE_ONE_SHOT_BYTES": _str("VDAMD_CUSTOM_ALL_REDUCE_ONE_SHOT_BYTES", "auto"),
+    # Bound of every in-kernel wait for a peer (milliseconds).  A rank that gives up sets a flag the
+    # worker reads after every step and in check_health; the executor then fails the engine.
+    "VDAMD_CUSTOM_ALL_REDUCE_TIMEOUT_MS": _int("VDAMD_CUSTOM_ALL_REDUCE_TIMEOUT_MS", 10000),
     # System-scope release fence also in the barrier that opens a kernel (the data it
     # publishes was written by an earlier kernel into uncached memory): "0", "1", or
     # "auto" = turned on if the start-up self-check fails without it.
@@ -145,6 +150,8 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     "VDAMD_PROFILE_DIR": _str("VDAMD_PROFILE_DIR", "/tmp/vdamd_profile"),
     # Test-only fault hook: "rank:step" => that rank exits at that step.
     "VDAMD_FAULT_DIE_AT": _str("VDAMD_FAULT_DIE_AT", None),
+    # Test-only fault hook: "rank:step" => that rank stops issuing work at that step (a hung device).
+    "VDAMD_FAULT_STALL_AT": _str("VDAMD_FAULT_STALL_AT", None),
     # Data-plane NIC selection, honoured by RCCL / gloo.
     "NCCL_SOCKET_IFNAME": _str("NCCL_SOCKET_IFNAME", None),
     "GLOO_SOCKET_IFNAME": _str("GLOO_SOCKET_IFNAME", None),

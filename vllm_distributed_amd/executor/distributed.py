@@ -377,17 +377,20 @@ class DistributedExecutor(Executor):
         if not self.has_connector:
             (output,) = self.collective_rpc("execute_model", args=(scheduler_output,),
                                             unique_reply_rank=self.output_rank, non_block=non_block,
-                                            timeout=timeout)
+                                            timeout=timeout, fatal=True)
             return output
         outputs = self.collective_rpc("execute_model", args=(scheduler_output,), non_block=non_block,
-                                      timeout=timeout)
+                                      timeout=timeout, fatal=True)
         if non_block:
             return self.kv_output_aggregator.async_aggregate(outputs, self.output_rank)
         return self.kv_output_aggregator.aggregate(outputs, self.output_rank)
 
     def collective_rpc(self, method: Union[str, Callable], timeout: Optional[float] = None,
                        args: tuple = (), kwargs: Optional[dict] = None, non_block: bool = False,
-                       unique_reply_rank: Optional[int] = None) -> List[Any]:
+                       unique_reply_rank: Optional[int] = None, fatal: bool = False) -> List[Any]:
+        """``fatal``: an error or a timeout of this call on ANY rank (also one whose reply is not
+        wanted) fails the executor: a step that one rank did not finish leaves the data plane's
+        ranks out of step with each other, and nothing after it can be trusted."""
         if self.is_failed:
             raise RuntimeError("Executor failed.")
         if timeout is None:
@@ -397,8 +400,15 @@ class DistributedExecutor(Executor):
         payload = cloudpickle.dumps((method, unique_reply_rank, list(args), kwargs, time.time()))   # once
         reply_ranks = list(range(self.world_size)) if unique_reply_rank is None else [unique_reply_rank]
 
+        what = method if isinstance(method, str) else "call"
+
         async def call(rank: int, want_reply: bool) -> Any:
-            ret = await self.workers[rank](payload, timeout=timeout)
+            try:
+                ret = await self.workers[rank](payload, timeout=timeout)
+            except Exception as e:  # noqa: BLE001
+                if fatal and not self.shutdown_event.is_set():
+                    self._fail(f"{what} failed on rank {rank}: {e!r}")
+                raise
             if not want_reply or ret is None:
                 return None
             out = cloudpickle.loads(ret)

@@ -295,6 +295,9 @@ class LlamaForCausalLM(nn.Module):
             else:
                 self.lm_head = ParallelLMHead(cfg["vocab_size"], cfg["hidden_size"], dtype)
         self.tie = tie
+        # forwards (eager calls and graph captures) per form of the TP collectives: get_stats reports it
+        import collections
+        self.path_counts = collections.Counter()
 
     # ---- what differs between the Llama-shaped families (see llama_variants.py)
     def embedding_scale(self, cfg: dict) -> Optional[float]:
@@ -327,7 +330,9 @@ class LlamaForCausalLM(nn.Module):
         if fused is not None:
             return self.forward_fused_tp(input_ids, positions, intermediate, sharded=fused)
         if intermediate is None and self.sequence_parallel_ok(positions.shape[0]):
+            self.path_counts["sequence_parallel"] += 1
             return self.forward_sequence_parallel(input_ids, positions)
+        self.path_counts["plain"] += 1
         if self.is_first:
             hidden = self.embed_tokens(input_ids)
             residual = None
@@ -355,11 +360,9 @@ class LlamaForCausalLM(nn.Module):
         dtype = self.norm.weight.dtype if self.is_last else next(iter(self.parameters())).dtype
         if tp.world_size == 1 or num_tokens == 0 or not tp.fused_all_reduce_norm_ok(num_tokens, h, dtype):
             return None
-        small = num_tokens * h * 2 <= tp.custom_ar.one_shot_bytes
-        if small:
-            return False
-        # rows of the residual live on different ranks: only when one stage runs the whole model
-        return True if (self.is_first and self.is_last) else None
+        # larger messages: residual stream row-sharded inside the stage; at a stage boundary the
+        # shards are gathered once, so pipeline stages exchange the same replicated pair as ever
+        return not (num_tokens * h * 2 <= tp.custom_ar.one_shot_bytes)
 
     def forward_fused_tp(self, input_ids: Optional[torch.Tensor], positions: torch.Tensor,
                          intermediate: Optional[IntermediateTensors], sharded: bool):
@@ -371,11 +374,13 @@ class LlamaForCausalLM(nn.Module):
         tp = get_tp_group()
         layers = list(self.layers.values())
         t, h = positions.shape[0], self.cfg["hidden_size"]
+        self.path_counts["fused_sharded" if sharded else "fused_replicated"] += 1
+        per, mine = tp.custom_ar.shard_rows(t) if sharded else (t, t)
+        lo = min(tp.rank_in_group * per, t)
         if self.is_first:
             part = self.embed_tokens(input_ids, reduce=False, staged=True)
-            rows = tp.custom_ar.shard_rows(t)[0] if sharded else t
             # the residual starts at zero so that the embedding is reduced by the same fused kernel
-            res = torch.zeros((rows, h), dtype=part.dtype, device=part.device)
+            res = torch.zeros((per, h), dtype=part.dtype, device=part.device)
             reduced = False
         else:
             part, res = intermediate.hidden, intermediate.residual
@@ -385,7 +390,11 @@ class LlamaForCausalLM(nn.Module):
             nonlocal reduced, res
             if reduced:
                 reduced = False
-                normed, res = norm(x, res)
+                normed, res = norm(x, res)      # replicated inputs from the previous stage
+                if sharded:                     # from here on this rank keeps its rows of the residual only
+                    shard = torch.zeros((per, h), dtype=res.dtype, device=res.device)
+                    shard[:mine] = res[lo:lo + mine]
+                    res = shard
                 return normed
             return tp.all_reduce_add_rms_norm(x, res, norm.weight, norm.eps, sharded)
 
@@ -398,6 +407,8 @@ class LlamaForCausalLM(nn.Module):
             norm = layers[li + 1].input_layernorm if li + 1 < len(layers) else (self.norm if self.is_last else None)
         if not self.is_last:
             hidden = part if reduced else tp.all_reduce(part)
+            if sharded and not reduced:
+                res = tp.all_gather(res, dim=0)[:t]      # the next stage takes the pair replicated
             return IntermediateTensors(hidden, res)
         return add_norm(part, self.norm)
 

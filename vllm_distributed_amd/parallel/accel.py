@@ -43,40 +43,43 @@ def _verify_all_reduce(group: GroupCoordinator, fn, sizes=(4096, 1 << 19, 3 << 2
         return False
 
 
+def _exact(n: int, rank: int, salt: int, device, dtype=torch.bfloat16) -> torch.Tensor:
+    """Small integers (exact in bf16, sums over 8 ranks below 256) that differ by rank and by call."""
+    x = (torch.arange(n, device=device, dtype=torch.int64) * 7 + salt) % 13 + rank + 1 + salt % 5
+    return x.to(dtype)
+
+
 def _verify_direct(group: GroupCoordinator, car, rounds: int = 12) -> bool:
-    """Every form of the peer-mapped path against ``torch.distributed``, back to back and with
-    data that changes from call to call (a reader that sees a peer's previous message, or a
-    buffer overwritten while a peer still reads it, shows up as a wrong sum): one-shot and
-    two-shot all-reduce from the stage area and from ordinary memory, the fused
-    all-reduce + add + RMSNorm with replicated and with row-sharded residual, all-gather."""
+    """Every form of the peer-mapped path on exact-integer payloads, back to back and with data
+    that changes from call to call: a reader that sees a peer's previous message, or a buffer
+    overwritten while a peer still reads it, gives a sum that differs by at least one and cannot
+    hide inside a tolerance.  One-shot and two-shot all-reduce from the stage area and from ordinary
+    memory, the fused all-reduce + add + RMSNorm with replicated and with row-sharded residual
+    (residual compared exactly, normalised rows to bf16 rounding), all-gather.  The expected sums
+    are computed locally (every rank can form every rank's payload)."""
     try:
         dev, w, r = group.device, group.world_size, group.rank_in_group
-        gen = torch.Generator(device="cpu").manual_seed(1234)            # same stream of shapes on all ranks
         sizes = [n for n in (1024, 24 * 1024, 160 * 1024, 1 << 20) if 2 * n <= car.max_bytes]
         ok = True            # never leave early: every rank must issue the same sequence of collectives
         for it in range(rounds):
             n = sizes[it % len(sizes)]
-            base = torch.randn(n, generator=gen).to(dev)
-            x = (base * (r + 1) + it).to(torch.bfloat16)
-            ref = x.clone()
-            group._td_all_reduce(ref)
+            parts = [_exact(n, q, it, dev) for q in range(w)]
+            ref = torch.stack([p.float() for p in parts]).sum(0).to(torch.bfloat16)
             staged = car.stage_view((n,), torch.bfloat16)
-            src = x
+            src = parts[r]
             if it % 2 == 0 and staged is not None:
-                staged.copy_(x)
+                staged.copy_(parts[r])
                 src = staged
             out = car.all_reduce(src, two_shot=bool((it // 2) % 2))
-            if not torch.allclose(out.float(), ref.float(), rtol=2e-2, atol=2e-1):
+            if not torch.equal(out, ref):
                 logger.warning("direct all-reduce self-check: wrong sum (round %d, %d elements)", it, n)
                 ok = False
             # fused add + RMSNorm on [rows, 512]
             rows, h = (5, 512) if it % 3 else (64, 512)
-            xs = (torch.randn(rows, h, generator=gen).to(dev) * (r + 1)).to(torch.bfloat16)
-            res = torch.randn(rows, h, generator=gen).to(dev).to(torch.bfloat16)
-            wt = torch.randn(h, generator=gen).to(dev).to(torch.bfloat16)
-            tot = xs.clone()
-            group._td_all_reduce(tot)
-            want_res = (tot.float() + res.float()).to(torch.bfloat16)
+            xs = [_exact(rows * h, q, it + 17, dev).view(rows, h) for q in range(w)]
+            res = _exact(rows * h, 0, it + 3, dev).view(rows, h)
+            wt = (_exact(h, 0, it, dev).float() / 8).to(torch.bfloat16)
+            want_res = (torch.stack([x.float() for x in xs]).sum(0) + res.float()).to(torch.bfloat16)
             wf = want_res.float()
             want = wf * torch.rsqrt(wf.pow(2).mean(-1, keepdim=True) + 1e-5) * wt.float()
             sharded = bool(it % 2)
@@ -85,11 +88,10 @@ def _verify_direct(group: GroupCoordinator, car, rounds: int = 12) -> bool:
             my_res = res[lo:min(lo + per, rows)].clone() if sharded else res.clone()
             if sharded and my_res.shape[0] < per:
                 my_res = torch.cat([my_res, torch.zeros(per - my_res.shape[0], h, dtype=res.dtype, device=dev)])
-            got = car.all_reduce_add_rms_norm(xs, my_res, wt, 1e-5, sharded)
+            got = car.all_reduce_add_rms_norm(xs[r], my_res, wt, 1e-5, sharded)
             got_res = my_res[:min(lo + per, rows) - lo] if sharded else my_res
             want_r = want_res[lo:min(lo + per, rows)] if sharded else want_res
-            if not (torch.allclose(got.float(), want, rtol=3e-2, atol=3e-2)
-                    and torch.allclose(got_res.float(), want_r.float(), rtol=2e-2, atol=2e-1)):
+            if not (torch.allclose(got.float(), want, rtol=2e-2, atol=2e-2) and torch.equal(got_res, want_r)):
                 logger.warning("fused all-reduce + RMSNorm self-check failed (round %d, sharded=%s)", it, sharded)
                 ok = False
             piece = torch.full((3, 8), float(r * 100 + it), dtype=torch.float32, device=dev)
@@ -105,6 +107,65 @@ def _verify_direct(group: GroupCoordinator, car, rounds: int = 12) -> bool:
     except Exception as e:  # noqa: BLE001
         logger.warning("direct collective self-check raised %r", e)
         return False
+
+
+def _calibrate_direct(group: GroupCoordinator, car) -> None:
+    """Size thresholds of the peer-mapped path from this machine's own links: both forms of the
+    all-reduce (and RCCL's, where the direct binding is up) are timed at 32 KiB .. the path's
+    capacity; ``one_shot_bytes`` becomes the largest size up to which one pass over every peer's
+    partial sums is not slower than reduce-scatter + gather, ``use_bytes`` the largest size up to
+    which the path is not slower than RCCL.  Every rank issues the same calls and the decision is
+    taken on the slowest rank's times, so all ranks agree."""
+    if not getattr(car, "auto_thresholds", False):
+        return
+    try:
+        dev, w = group.device, group.world_size
+        sizes = [s for s in (32 << 10, 64 << 10, 128 << 10, 256 << 10, 512 << 10, 1 << 20, 2 << 20, 4 << 20,
+                             8 << 20, 16 << 20, 32 << 20, 64 << 20) if s <= car.max_bytes]
+
+        def timed(fn, iters: int) -> float:
+            for _ in range(2):
+                fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(iters):
+                fn()
+            b.record()
+            b.synchronize()
+            return a.elapsed_time(b) * 1e3 / iters
+
+        rows = []
+        for s in sizes:
+            n, iters = s // 2, (16 if s <= (1 << 20) else 6)
+            x = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+            one = timed(lambda: car.all_reduce(car.stage_view((n,), torch.bfloat16), two_shot=False), iters) \
+                if s * w <= (64 << 20) else float("inf")
+            two = timed(lambda: car.all_reduce(car.stage_view((n,), torch.bfloat16), two_shot=True), iters)
+            lib = timed(lambda: group.rccl.all_reduce(x), iters) if group.rccl is not None else float("inf")
+            rows.append((one, two, lib))
+        car.end_step()
+        torch.cuda.synchronize()
+        worst = [tuple(max(col) for col in zip(*per_size)) for per_size in zip(*group.all_gather_object(rows))]
+        one_shot, use, prefix_one, prefix_use = 0, 0, True, True
+        for s, (one, two, lib) in zip(sizes, worst):
+            if prefix_one and one <= two * 1.05:
+                one_shot = s
+            else:
+                prefix_one = False
+            if prefix_use and min(one, two) <= lib:
+                use = s
+            else:
+                prefix_use = False
+        car.one_shot_bytes = one_shot
+        car.use_bytes = use if group.rccl is not None else car.max_bytes
+        car.calibration = [dict(bytes=s, one_shot_us=round(o, 1) if o != float("inf") else None, two_shot_us=round(t, 1),
+                                rccl_us=round(l, 1) if l != float("inf") else None)
+                           for s, (o, t, l) in zip(sizes, worst)]
+        if group.rank_in_group == 0:
+            logger.info("tp group: direct collectives calibrated: one-shot up to %d KiB, used up to %d KiB %s",
+                        car.one_shot_bytes >> 10, car.use_bytes >> 10, car.calibration)
+    except Exception as e:  # noqa: BLE001 - the defaults stay
+        logger.warning("direct collective calibration raised %r; keeping the default thresholds", e)
 
 
 def _verify_gather_scatter(group: GroupCoordinator, comm) -> bool:
@@ -170,6 +231,9 @@ def attach_accelerated_collectives(pc: ParallelConfig) -> None:
                 ok = _all_agree(group, _verify_direct(group, car))
                 if ok:
                     logger.warning("tp group: direct collectives need the start-barrier release fence on this system")
+            if ok:
+                _calibrate_direct(group, car)
+                ok = _all_agree(group, not car.timed_out())
             if ok:
                 group.custom_ar = car
                 logger.info("tp group: direct (peer-mapped) collectives active (up to %d KiB, one-shot up to %d KiB)",

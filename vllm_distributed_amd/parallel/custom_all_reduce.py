@@ -47,8 +47,13 @@ class CustomAllReduce:
         if not 2 <= self.world <= 8:
             raise ValueError("direct all-reduce supports 2..8 ranks")
         self.max_bytes = (int(max_bytes) + 255) // 256 * 256
-        # messages up to this size are summed by every rank in one pass; larger ones in two
-        self.one_shot_bytes = int(envs.VDAMD_CUSTOM_ALL_REDUCE_ONE_SHOT_BYTES)
+        # messages up to this size are summed by every rank in one pass; larger ones in two.
+        # "auto": the bring-up times both forms on this machine's links (parallel/accel.py)
+        spec = str(envs.VDAMD_CUSTOM_ALL_REDUCE_ONE_SHOT_BYTES).strip().lower()
+        self.auto_thresholds = spec == "auto"
+        self.one_shot_bytes = (256 << 10) if self.auto_thresholds else int(spec)
+        # largest message the callers hand to this path (<= max_bytes, the capacity)
+        self.use_bytes = self.max_bytes
         self.fence_start = str(envs.VDAMD_CUSTOM_ALL_REDUCE_FENCE_START).strip().lower() in ("1", "true", "yes", "on")
         hb = int(self.lib.vdamd_car_handle_bytes())
         dh, sh = ctypes.create_string_buffer(hb), ctypes.create_string_buffer(hb)
@@ -62,6 +67,7 @@ class CustomAllReduce:
         if rc != 0:
             self.close()
             raise RuntimeError(f"hipIpcOpenMemHandle failed with {rc}")
+        self.lib.vdamd_car_set_timeout_ms(self.ctx, int(envs.VDAMD_CUSTOM_ALL_REDUCE_TIMEOUT_MS))
         if ranks_per_device > 1:
             # all grids must be resident together for the in-kernel barriers
             self.lib.vdamd_car_set_max_blocks(self.ctx, max(1, 512 // (4 * ranks_per_device)))
@@ -86,6 +92,8 @@ class CustomAllReduce:
         lib.vdamd_car_stage_ptr.restype = P
         lib.vdamd_car_set_max_blocks.argtypes = [P, I]
         lib.vdamd_car_set_max_blocks.restype = None
+        lib.vdamd_car_set_timeout_ms.argtypes = [P, ctypes.c_long]
+        lib.vdamd_car_set_timeout_ms.restype = None
         lib.vdamd_car_timed_out.argtypes = [P]
         lib.vdamd_car_timed_out.restype = I
         lib.vdamd_car_all_reduce.argtypes = [P, I, P, P, Z, I, I, I, P]
@@ -122,8 +130,9 @@ class CustomAllReduce:
         return not self.disabled and 0 < nbytes <= self.max_bytes and nbytes % 16 == 0
 
     def should_use(self, x: torch.Tensor) -> bool:
+        nbytes = x.numel() * x.element_size()
         return (x.is_cuda and x.dtype in _DT and x.is_contiguous() and x.data_ptr() % 16 == 0
-                and self.fits(x.numel() * x.element_size()))
+                and self.fits(nbytes) and nbytes <= self.use_bytes)
 
     def stage_view(self, shape: Tuple[int, ...], dtype: torch.dtype) -> Optional[torch.Tensor]:
         """A tensor of ``shape`` inside the stage area the NEXT call reads: a producer that
@@ -194,7 +203,9 @@ class CustomAllReduce:
                 and self.fits(x.numel() * x.element_size()))
 
     def timed_out(self) -> bool:
-        return bool(self.lib.vdamd_car_timed_out(self.ctx))
+        """Whether a peer failed to arrive at a barrier within the bound (the sums of that call
+        are then wrong).  A read of pinned host memory: cheap enough to ask after every step."""
+        return bool(self.ctx) and bool(self.lib.vdamd_car_timed_out(self.ctx))
 
     def close(self) -> None:
         if getattr(self, "ctx", None):

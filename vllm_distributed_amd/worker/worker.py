@@ -36,14 +36,14 @@ class Worker:
         self.device: Optional[torch.device] = None
         self.model_runner: Optional[ModelRunner] = None
         self._profiler = None
-        self._fault = self._parse_fault()
+        self._fault = self._parse_fault(envs.VDAMD_FAULT_DIE_AT)
+        self._stall = self._parse_fault(envs.VDAMD_FAULT_STALL_AT)
         self._steps = 0
         self._sleeping = False
 
     # ------------------------------------------------------------------ init
-    def _parse_fault(self) -> Optional[int]:
-        """Test-only fault hook: ``VDAMD_FAULT_DIE_AT=rank:step``."""
-        spec = envs.VDAMD_FAULT_DIE_AT
+    def _parse_fault(self, spec: Optional[str]) -> Optional[int]:
+        """Test-only fault hooks ``VDAMD_FAULT_DIE_AT`` / ``VDAMD_FAULT_STALL_AT`` = ``rank:step``."""
         if not spec:
             return None
         try:
@@ -143,12 +143,30 @@ class Worker:
         if self._fault is not None and self._steps >= self._fault:
             logger.error("fault injection: rank %d exiting at step %d", self.rank, self._steps)
             os._exit(17)
-        return self.model_runner.execute_model(scheduler_output)
+        if self._stall is not None and self._steps >= self._stall:
+            logger.error("fault injection: rank %d stops issuing work at step %d", self.rank, self._steps)
+            import time
+            while True:                 # a hung device: the peers' collectives never see this rank arrive
+                time.sleep(3600)
+        out = self.model_runner.execute_model(scheduler_output)
+        self._raise_if_collective_timed_out()
+        return out
+
+    def _raise_if_collective_timed_out(self) -> None:
+        """A peer-mapped collective whose wait for a peer ran out has summed whatever it found: the
+        step's tokens are wrong and every later one too.  The flag lives in pinned host memory, so
+        asking costs a load; raising here fails the step on the head, which stops the engine."""
+        for group in (pstate.get_tp_group(),) if pstate.model_parallel_is_initialized() else ():
+            car = group.custom_ar
+            if car is not None and car.timed_out():
+                raise RuntimeError(f"rank {self.rank}: a peer-mapped collective gave up waiting for a rank of the "
+                                   f"{group.name} group (VDAMD_CUSTOM_ALL_REDUCE_TIMEOUT_MS); results are invalid")
 
     def execute_dummy_batch(self) -> None:
         self.model_runner.profile_run()
 
     def check_health(self) -> bool:
+        self._raise_if_collective_timed_out()
         return True
 
     def synchronize(self) -> float:
@@ -166,9 +184,15 @@ class Worker:
         mr = self.model_runner
         if mr is not None:
             d.update(hip_graph_sizes=list(mr.graph_sizes), hip_graph_fallback=mr.graph_fallback_reason,
-                     block_size=mr.block_size)
+                     block_size=mr.block_size,
+                     tp_forward_paths=dict(getattr(getattr(mr, "model", None), "path_counts", None) or {}))
             tp = getattr(mr, "tp", None)
             if tp is not None:
+                car = tp.custom_ar
+                if car is not None:
+                    d.update(tp_direct_one_shot_bytes=car.one_shot_bytes, tp_direct_use_bytes=car.use_bytes,
+                             tp_direct_calibration=getattr(car, "calibration", None),
+                             tp_direct_timed_out=car.timed_out())
                 d.update(tp_rccl=tp.rccl is not None, tp_direct_all_reduce=tp.custom_ar is not None,
                          tp_backend=(None if tp.device_group is None else
                                      torch.distributed.get_backend(tp.device_group)))
