@@ -83,6 +83,10 @@ struct Parser {
   std::map<std::string, int> names;
   std::string err;
   int helper = 0;
+  int depth = 0;                 // open parentheses: parse_item / parse_alternates recurse once per level
+  static constexpr int MAX_NESTING = 256;
+  static constexpr size_t MAX_TEXT_BYTES = 64 * 1024;
+  static constexpr size_t MAX_RULES = 20000;
 
   Parser(const std::string& s, Grammar& gr) : src(s), g(gr) {}
 
@@ -204,8 +208,10 @@ struct Parser {
       prim.push_back(Sym{-1, add_set(s)});
     } else if (c == '(') {
       ++p;
+      if (++depth > MAX_NESTING) return fail("parentheses nested too deeply");
       int sub = new_helper(owner);
       if (!parse_alternates(owner, sub, true)) return false;
+      --depth;
       skip_ws(true);
       if (p >= src.size() || src[p] != ')') return fail("expected )");
       ++p;
@@ -241,6 +247,7 @@ struct Parser {
         ++p;
         if (hi > 256 || lo > 256) return fail("repetition count above 256");
       }
+      if (g.rules.size() > MAX_RULES) return fail("grammar too large");
       // unit ::= prim
       int unit = new_helper(owner);
       g.rules[unit].alts.push_back(prim);
@@ -302,6 +309,7 @@ struct Parser {
   }
 
   bool parse() {
+    if (src.size() > MAX_TEXT_BYTES) return fail("grammar longer than 64 KiB");
     std::vector<char> defined;
     while (true) {
       skip_ws(true);
@@ -316,7 +324,7 @@ struct Parser {
       if (defined[id]) return fail("rule " + n + " is defined twice");
       defined[id] = 1;
       if (!parse_alternates(n, id, false)) return false;
-      if (g.rules.size() > 20000) return fail("grammar too large");
+      if (g.rules.size() > MAX_RULES) return fail("grammar too large");
     }
     for (size_t i = 0; i < g.rules.size(); ++i)
       if (g.rules[i].alts.empty()) return fail("rule " + g.rules[i].name + " is used but never defined");

@@ -12,6 +12,7 @@
 // (...) and (?:...), alternation, quantifiers * + ? {m} {m,} {m,n}; ^ and $ are accepted and
 // ignored (the match is anchored anyway).  `.` and negated classes also admit bytes >= 0x80, so
 // non-ASCII text is allowed wherever an "anything but" is.
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -37,6 +38,9 @@ struct Parser {
   const unsigned char* p;
   const unsigned char* e;
   long budget = 400000;                 // NFA positions the expansion of counted repeats may create
+  int depth = 0;                        // open groups: the parser and the NFA builder recurse once per level
+  static constexpr int MAX_DEPTH = 256;
+  static constexpr int MAX_STACKED_QUANTIFIERS = 4;
 
   [[noreturn]] void fail(const std::string& what) const { throw std::runtime_error(what); }
   bool more() const { return p < e; }
@@ -150,7 +154,9 @@ struct Parser {
       case '(': {
         if (p + 1 < e && p[0] == '?' && p[1] == ':') p += 2;
         else if (more() && *p == '?') fail("only (?:...) groups are supported");
+        if (++depth > MAX_DEPTH) fail("groups nested too deeply");
         NodeP n = alt();
+        --depth;
         if (!more() || *p != ')') fail("missing )");
         ++p;
         return n;
@@ -174,17 +180,20 @@ struct Parser {
   }
   long size_of(const Node* n) const {
     switch (n->kind) {
+      // what Nfa::build allocates, roughly: an empty operand and every repetition's fork cost states too
       case Node::SET: return 1;
-      case Node::EMPTY: return 0;
+      case Node::EMPTY: return 1;
       case Node::REP: {
-        const long s = size_of(n->kids[0].get());
-        return s * (n->hi < 0 ? n->lo + 1 : n->hi);
+        const long s = size_of(n->kids[0].get()) + 1;
+        const long reps = n->hi < 0 ? n->lo + 1 : n->hi;
+        return s * (reps < 1 ? 1 : reps);
       }
       default: { long s = 0; for (auto& k : n->kids) s += size_of(k.get()); return s; }
     }
   }
   NodeP repeat() {
     NodeP a = atom();
+    int stacked = 0;
     while (more()) {
       int lo, hi;
       const unsigned char c = *p;
@@ -208,6 +217,7 @@ struct Parser {
         lo = (int)a1; hi = (int)b1; p = q + 1;
       } else break;
       if (more() && (*p == '?' || *p == '+')) ++p;   // lazy / possessive markers do not change the language
+      if (++stacked > MAX_STACKED_QUANTIFIERS) fail("too many quantifiers on one operand");
       NodeP r = mk(Node::REP);
       r->lo = lo; r->hi = hi;
       r->kids.push_back(std::move(a));
@@ -239,7 +249,11 @@ struct Nfa {
   struct St { int set = -1; int to = -1; int e1 = -1, e2 = -1; };
   std::vector<St> st;
   std::vector<ByteSet> sets;
-  int add() { st.emplace_back(); return (int)st.size() - 1; }
+  int add() {
+    if (st.size() >= 2000000) throw std::runtime_error("expression too large");
+    st.emplace_back();
+    return (int)st.size() - 1;
+  }
   // builds n between a fresh start and a fresh end; returns (start, end)
   std::pair<int, int> build(const Node* n) {
     switch (n->kind) {
@@ -306,16 +320,21 @@ struct Dfa {
   int n() const { return (int)accepting.size(); }
 };
 
-void closure(const Nfa& nfa, std::vector<int>& set, std::vector<char>& mark) {
+// `set` grows to its epsilon closure; stamp[s] == gen marks membership (no per-call clearing)
+void closure(const Nfa& nfa, std::vector<int>& set, std::vector<int>& stamp, int gen) {
   std::vector<int> stack(set);
   while (!stack.empty()) {
     const int s = stack.back(); stack.pop_back();
     for (int t : {nfa.st[s].e1, nfa.st[s].e2})
-      if (t >= 0 && !mark[t]) { mark[t] = 1; set.push_back(t); stack.push_back(t); }
+      if (t >= 0 && stamp[t] != gen) { stamp[t] = gen; set.push_back(t); stack.push_back(t); }
   }
 }
 
+constexpr long MAX_PATTERN_BYTES = 64 * 1024;
+constexpr long MAX_SUBSET_WORK = 400L * 1000 * 1000;   // NFA states visited while determinising
+
 Dfa* compile(const unsigned char* pat, long len, int max_states) {
+  if (len > MAX_PATTERN_BYTES) throw std::runtime_error("expression longer than 64 KiB");
   Parser ps{pat, pat + len};
   NodeP root = ps.alt();
   if (ps.more()) ps.fail(*ps.p == ')' ? "unbalanced )" : "trailing input");
@@ -325,13 +344,20 @@ Dfa* compile(const unsigned char* pat, long len, int max_states) {
   std::map<std::vector<int>, int> ids;
   std::vector<std::vector<int>> members;
   std::vector<int32_t> trans;
+  std::vector<int> stamp(nn, 0);
+  int gen = 0;
+  long work = 0;
   auto intern = [&](std::vector<int>& raw) -> int {
-    std::vector<char> mark(nn, 0);
-    for (int s : raw) mark[s] = 1;
-    closure(nfa, raw, mark);
+    ++gen;
+    for (int s : raw) stamp[s] = gen;
+    closure(nfa, raw, stamp, gen);
+    work += (long)raw.size();
+    if (work > MAX_SUBSET_WORK) throw std::runtime_error("expression too expensive to determinise");
     std::vector<int> key;
-    for (int s = 0; s < nn; ++s)
-      if (mark[s] && (nfa.st[s].set >= 0 || s == se.second)) key.push_back(s);   // only states that matter
+    for (int s : raw)
+      if (nfa.st[s].set >= 0 || s == se.second) key.push_back(s);   // only states that matter
+    std::sort(key.begin(), key.end());
+    key.erase(std::unique(key.begin(), key.end()), key.end());
     auto it = ids.find(key);
     if (it != ids.end()) return it->second;
     if ((int)members.size() >= max_states) throw std::runtime_error("expression needs too many DFA states");
@@ -347,6 +373,8 @@ Dfa* compile(const unsigned char* pat, long len, int max_states) {
     // group bytes by the set of NFA targets they reach
     std::map<std::vector<int>, std::vector<int>> by_target;
     const std::vector<int> mem = members[d];
+    work += 256L * (long)mem.size();
+    if (work > MAX_SUBSET_WORK) throw std::runtime_error("expression too expensive to determinise");
     for (int c = 0; c < 256; ++c) {
       std::vector<int> tg;
       for (int s : mem)

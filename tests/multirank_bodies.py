@@ -329,6 +329,38 @@ def body_car() -> dict:
     return dict(timed_out=timed_out, fence_start=car.fence_start)
 
 
+def body_car_timeout() -> dict:
+    """A peer that never issues its call: the other ranks' kernels must come back within the bound
+    (no GPU hang) and the host-visible timeout word must be set, readable without a stream sync."""
+    if MODE == "cpu":
+        return dict(skipped="peer-mapped collectives need device memory")
+    import time
+    os.environ["VDAMD_CUSTOM_ALL_REDUCE_TIMEOUT_MS"] = "200"
+    dev = setup(WORLD, 1)
+    from vllm_distributed_amd.parallel.custom_all_reduce import CustomAllReduce
+    g = pstate.get_tp_group()
+    car = CustomAllReduce(g, max_bytes=1 << 20, ranks_per_device=WORLD if MODE == "shared" else 1)
+    x = torch.ones(4096, dtype=torch.bfloat16, device=dev)
+    car.all_reduce(x)                     # everybody: a healthy call first
+    sync(dev)
+    if car.timed_out():
+        fail("timeout word set after a healthy call")
+    g.barrier()
+    waited = 0.0
+    if RANK != WORLD - 1:                 # the last rank plays the hung device
+        t0 = time.time()
+        car.all_reduce(x)
+        sync(dev)
+        waited = time.time() - t0
+        if not car.timed_out():
+            fail("timeout word not set although a peer never arrived")
+        if not 0.15 <= waited < 5.0:
+            fail(f"kernel returned after {waited:.2f}s for a 0.2 s bound")
+    g.barrier()
+    car.close()
+    return dict(waited=round(waited, 3))
+
+
 # ------------------------------------------------------------------- pipeline link
 def body_pipeline() -> dict:
     """``PipelineLink`` along a chain of WORLD stages with two batches in flight: stage 0 issues
@@ -374,7 +406,7 @@ def body_pipeline() -> dict:
     return dict(accelerated=accelerated, batches_checked=len(seen))
 
 
-BODIES = {"rccl": body_rccl, "car": body_car, "pipeline": body_pipeline}
+BODIES = {"rccl": body_rccl, "car": body_car, "car_timeout": body_car_timeout, "pipeline": body_pipeline}
 
 
 def main() -> None:

@@ -623,11 +623,12 @@ def test_packed_quantisation_is_refused_for_families_without_packed_layers():
     pstate.destroy_model_parallel()
 
 
-@pytest.mark.parametrize("model", ["glm-tiny", "helium-tiny", "stablelm-tiny"])
+@pytest.mark.parametrize("model", ["glm-tiny", "helium-tiny", "stablelm-tiny", "granite-tiny"])
 def test_awq_q_k_projections_follow_the_rope_row_order(model):
     """Families whose rotary embedding is folded into the row order of q_proj / k_proj: with packed AWQ weights
     the same re-ordering is applied to the nibbles, zeros and scales, so the packed model generates what its
-    dequantised twin (dense rows re-ordered) does."""
+    dequantised twin (dense rows re-ordered) does.  Granite: the residual multiplier folded into o_proj /
+    down_proj goes into the AWQ scales, never into the packed words."""
     outs = []
     for q in ("awq-dequant", "awq"):
         llm = LLM(model=model, device="cpu", dtype="float32", max_model_len=128, block_size=16,
@@ -640,16 +641,18 @@ def test_awq_q_k_projections_follow_the_rope_row_order(model):
     assert outs[0] == outs[1]
 
 
-def test_nvfp4_q_k_projections_follow_the_rope_row_order(tmp_path):
+@pytest.mark.parametrize("model", ["glm-tiny", "granite-tiny"])
+def test_nvfp4_q_k_projections_follow_the_rope_row_order(tmp_path, model):
     """GLM (adjacent-pair rotary over half of each head) with NVFP4 weights: packed bytes and block scales of
     q_proj / k_proj are re-ordered row-wise like dense rows, so the packed model generates what the dense
-    checkpoint built from the dequantised tensors does."""
+    checkpoint built from the dequantised tensors does.  Granite: the residual multiplier of o_proj / down_proj
+    goes into the per-matrix scale of the packed tensors."""
     import json
     from safetensors.torch import load_file, save_file
     from vllm_distributed_amd.config import ModelConfig
     from vllm_distributed_amd.models.layers.linear import nvfp4_dequantize
     from vllm_distributed_amd.models.loader import save_dummy_checkpoint
-    mc = ModelConfig(model="glm-tiny", dtype="float32", load_format="dummy", quantization="nvfp4")
+    mc = ModelConfig(model=model, dtype="float32", load_format="dummy", quantization="nvfp4")
     src = tmp_path / "packed"
     save_dummy_checkpoint(mc, str(src))
     sd = load_file(str(src / "model.safetensors"))
@@ -667,7 +670,7 @@ def test_nvfp4_q_k_projections_follow_the_rope_row_order(tmp_path):
     save_file({k: v.contiguous() for k, v in dense.items()}, str(d / "model.safetensors"))
     (d / "config.json").write_text(json.dumps(dict(mc.hf_config)))
     outs = []
-    for kw in (dict(model="glm-tiny", quantization="nvfp4"), dict(model=str(d))):
+    for kw in (dict(model=model, quantization="nvfp4"), dict(model=str(d))):
         llm = LLM(device="cpu", dtype="float32", max_model_len=128, block_size=16, num_gpu_blocks_override=64,
                   max_num_seqs=8, **kw)
         o = llm.generate([[5, 9, 200, 17], list(range(10, 50))],

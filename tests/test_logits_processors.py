@@ -424,3 +424,38 @@ def test_guided_grammar_holds_generation_to_the_language():
             assert g.may_stop and text.count(b"(") == text.count(b")"), text
     assert finished >= 1
     llm.shutdown()
+
+
+def test_constraint_compilers_refuse_hostile_inputs_instead_of_crashing():
+    """A request-supplied pattern or grammar reaches native recursive-descent parsers inside the serving
+    process: deep nesting, empty-operand repeats and oversize texts must come back as ValueError, quickly."""
+    import time
+
+    from vllm_distributed_amd.ops.grammar import compile_grammar, compile_regex
+    from vllm_distributed_amd.sampling_params import MAX_CONSTRAINT_BYTES
+    t0 = time.time()
+    for bad in ("(" * 300000, "(" * 300 + "a" + ")" * 300, "(){100000}" * 50, "a" * (MAX_CONSTRAINT_BYTES + 1),
+                "a****************", "(?:(?:a{1000}){1000}){1000}"):
+        with pytest.raises(ValueError):
+            compile_regex(bad)
+        with pytest.raises(ValueError):
+            SamplingParams(guided_regex=bad)
+    for bad in ("root ::= " + "(" * 300000, "root ::= " + "(" * 300 + '"a"' + ")" * 300,
+                "root ::= " + '"a" ' * (MAX_CONSTRAINT_BYTES // 4 + 1), 'root ::= ("a"{256}){256}' * 40):
+        with pytest.raises(ValueError):
+            compile_grammar(bad)
+        with pytest.raises(ValueError):
+            SamplingParams(guided_grammar=bad)
+    assert time.time() - t0 < 30
+    compile_regex("(" * 200 + "a" + ")" * 200)                         # deep, but within the limit
+    compile_grammar("root ::= " + "(" * 200 + '"a"' + ")" * 200)
+
+
+def test_pythonic_tool_parser_keeps_hostile_output_as_text():
+    from vllm_distributed_amd.entrypoints.openai.tool_parsers import PythonicToolParser
+    p = PythonicToolParser(None)
+    for text in ("[" + "f(a=" * 5000 + "1" + ")" * 5000 + "]", '[f(**{"a": 1})]', "[f(a=" + "[" * 100000 + "]" * 100000 + ")]"):
+        content, calls = p.extract(text)
+        assert calls == [] and content == text
+    content, calls = p.extract('[get_weather(city="Paris", days=3)]')
+    assert content is None and len(calls) == 1

@@ -74,7 +74,7 @@ def test_bodies_pipeline_link_over_gloo_on_cpu(world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("body,world", [("car", 2), ("car", 4), ("pipeline", 2), ("rccl", 2)])
+@pytest.mark.parametrize("body,world", [("car", 2), ("car", 4), ("car_timeout", 2), ("pipeline", 2), ("rccl", 2)])
 def test_bodies_on_ranks_sharing_one_gpu(body, world):
     run_body(body, world, "shared")
 
@@ -94,6 +94,13 @@ def test_rccl_communicator_across_devices_eager_and_in_a_graph(world):
 def test_peer_mapped_collectives_one_rank_per_device(world, fence_start):
     got = run_body("car", world, "devices", {"FENCE_START": "1" if fence_start else "0"}, timeout=280)
     assert all(r["timed_out"] is False and r["fence_start"] == fence_start for r in got)
+
+
+@pytest.mark.gpu
+@needs2
+def test_peer_mapped_collectives_bounded_wait_across_devices():
+    got = run_body("car_timeout", 2, "devices")
+    assert 0.15 <= got[0]["waited"] < 5.0
 
 
 @pytest.mark.gpu

@@ -322,6 +322,18 @@ def _sampling_params(req, default_max: Optional[int], max_model_len: int, logpro
                          logprobs if getattr(req, "echo", False) and not req.stream else None))
 
 
+async def _sampling_params_off_loop(req, *args) -> SamplingParams:
+    """``_sampling_params`` for a route handler.  A request that carries an output constraint has its
+    pattern / schema / grammar compiled to an automaton while the parameters are validated (up to
+    seconds for a large one): that runs on a worker thread, so the event loop keeps serving streams."""
+    extra = req.model_extra or {}
+    constrained = bool(req.response_format) or bool(extra.get("structured_outputs")) or any(
+        extra.get(k) is not None for k in ("guided_json", "guided_regex", "guided_choice", "guided_grammar"))
+    if not constrained:
+        return _sampling_params(req, *args)
+    return await asyncio.get_running_loop().run_in_executor(None, _sampling_params, req, *args)
+
+
 def _guided_options(req, extra: Dict[str, Any]) -> Dict[str, Any]:
     """The one output constraint a request asks for, as SamplingParams fields.  Accepted spellings:
     ``response_format`` (json_object, json_schema), vLLM's ``guided_json`` / ``guided_regex`` /
@@ -549,7 +561,8 @@ def _register_routes(app: FastAPI, dev_mode: bool = False) -> None:
         rid = "cmpl-" + uuid.uuid4().hex
         created = int(time.time())
         try:
-            sp = _sampling_params(req, 16, st.max_model_len, req.logprobs, st.default_sampling, st.max_logprobs)
+            sp = await _sampling_params_off_loop(req, 16, st.max_model_len, req.logprobs, st.default_sampling,
+                                                 st.max_logprobs)
         except ValueError as e:
             return _error(str(e))
         lora = st.loras.get(req.model) if req.model else None
@@ -713,7 +726,8 @@ def _register_routes(app: FastAPI, dev_mode: bool = False) -> None:
         prompt_ids = tok.encode(prompt, add_special_tokens=False)
         n_lp = (req.top_logprobs or 0) if req.logprobs else None
         try:
-            sp = _sampling_params(req, None, st.max_model_len, n_lp, st.default_sampling, st.max_logprobs)
+            sp = await _sampling_params_off_loop(req, None, st.max_model_len, n_lp, st.default_sampling,
+                                                 st.max_logprobs)
         except ValueError as e:
             return _error(str(e))
         required_tools = req.tool_choice == "required"

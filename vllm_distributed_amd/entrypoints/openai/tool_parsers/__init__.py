@@ -309,8 +309,11 @@ class PythonicToolParser(ToolParser):
                 if not isinstance(fn, ast.Name):
                     return text, []
                 name = ".".join([fn.id] + parts[::-1])
+                if any(kw.arg is None for kw in node.keywords):      # f(**{...}): not a literal keyword
+                    return text, []
                 calls.append(self.make_call(name, {kw.arg: ast.literal_eval(kw.value) for kw in node.keywords}))
-        except (SyntaxError, ValueError, TypeError):
+        except (SyntaxError, ValueError, TypeError, RecursionError, MemoryError):
+            # model output is untrusted text: whatever the parser cannot take stays plain content
             return text, []
         return None, calls
 

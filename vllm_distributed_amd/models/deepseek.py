@@ -139,6 +139,9 @@ class DeepseekMoE(FusedMoE):
                 per_group = scores.view(-1, self.n_group, self.num_experts // self.n_group)
                 scores = scores.masked_fill(~self._group_mask(scores, per_group.max(-1).values), 0.0)
             topw, topi = scores.topk(self.top_k, dim=-1)
+            if self.renormalize and self.top_k > 1:
+                # DeepSeek-V2's own gate: the picks' scores are renormalised INSTEAD of being scaled
+                return topw / (topw.sum(-1, keepdim=True) + 1e-20), topi
         return topw * self.scaling, topi
 
     def forward(self, x: torch.Tensor, reduce: bool = True, staged: bool = False) -> torch.Tensor:
@@ -224,6 +227,9 @@ class ErnieMoE(FusedMoE):
         super().__init__(cfg["hidden_size"], cfg["moe_intermediate_size"], n, cfg["moe_k"],
                          True, dtype, expert_parallel=expert_parallel)
         self.norm_min = float(cfg.get("moe_norm_min") or 1e-12)
+        # the router runs in fp32 (weights stored and multiplied in fp32): the biased top-k over near-tied
+        # softmax scores picks other experts at bf16 resolution
+        self.gate.weight.data = self.gate.weight.data.float()
         self.gate.e_score_correction_bias = nn.Parameter(torch.zeros(n, dtype=torch.float32),
                                                          requires_grad=False)
         self.gate.e_score_correction_bias.weight_loader = \
@@ -232,8 +238,11 @@ class ErnieMoE(FusedMoE):
         self.shared_experts = LlamaMLP(cfg["hidden_size"], cfg["moe_intermediate_size"] * shared, dtype,
                                        bool(cfg.get("mlp_bias", False))) if shared else None
 
+    def router_logits(self, x: torch.Tensor) -> torch.Tensor:
+        return torch.nn.functional.linear(x.float(), self.gate.weight.float())
+
     def route(self, logits: torch.Tensor):
-        scores = torch.softmax(logits, dim=-1)
+        scores = torch.softmax(logits.float(), dim=-1)
         topi = (scores + self.gate.e_score_correction_bias).topk(self.top_k, dim=-1).indices
         topw = scores.gather(1, topi)
         return topw / topw.sum(-1, keepdim=True).clamp(min=self.norm_min), topi

@@ -256,6 +256,10 @@ class FusedMoE(nn.Module):
     # True in subclasses that override ``route``: the fused top-k kernel (softmax routing) is skipped
     custom_routing = False
 
+    def router_logits(self, x: torch.Tensor) -> torch.Tensor:
+        """``[T, E]`` scores of the router (families that keep the router in fp32 override this)."""
+        return self.gate(x)
+
     def route(self, logits: torch.Tensor):
         """Router logits ``[T, E]`` (fp32) -> (weights ``[T, k]`` fp32, expert ids ``[T, k]``)."""
         probs = torch.softmax(logits, dim=-1)
@@ -277,7 +281,7 @@ class FusedMoE(nn.Module):
                 if reduce and self.tp > 1:
                     out = tensor_model_parallel_all_reduce(out)
                 return out
-        logits = self.gate(x)
+        logits = self.router_logits(x)
         if (tile_rows and x.dim() == 2 and not self.custom_routing
                 and ops.moe_route_fused_ok(logits, self.num_experts, self.top_k)):
             out = self._forward_fused_routing(x, logits, tile_rows)

@@ -61,8 +61,15 @@ class GraniteForCausalLM(LlamaForCausalLM):
         return float(m) if m not in (None, 1.0) else None
 
     def transform_weight(self, name: str, w):
+        """``residual_multiplier`` folded into the two projections that feed the residual stream.  For a
+        dense tensor that is the weight (and bias) itself; a packed 4-bit tensor must not be touched -
+        there the factor goes into what the kernels multiply the integers with: the per-group ``scales``
+        of AWQ (zero points are subtracted before the scale, so they stay), the per-matrix
+        ``weight_alpha`` of NVFP4 (names as ``nvfp4_rename`` leaves them)."""
         m = self.cfg.get("residual_multiplier")
-        if m not in (None, 1.0) and (".o_proj." in name or ".down_proj." in name) and name.endswith(("weight", "bias")):
+        if m in (None, 1.0) or not (".o_proj." in name or ".down_proj." in name):
+            return w
+        if name.endswith((".weight", ".bias", ".scales", ".weight_alpha")):
             # the whole tensor is read here; a row-parallel loader then narrows it to its shard
             return materialize(w).float().mul(float(m))
         return w

@@ -573,12 +573,25 @@ def _poison(model: torch.nn.Module) -> None:
 
 
 def _check_filled(model: torch.nn.Module, what: str) -> None:
-    missing = [n for n, p in model.named_parameters()
-               if p.dtype in _POISONABLE and p.numel() and bool(torch.isnan(p.data.view(-1)[:1]).item())
-               and bool(torch.isnan(p.data).all().item())]
-    if missing:
-        raise RuntimeError(f"{what}: {len(missing)} parameter(s) were not found in the checkpoint: "
-                           + ", ".join(missing[:8]) + (" ..." if len(missing) > 8 else ""))
+    """Every element of every parameter must have come from the checkpoint.  A fused parameter can be
+    filled in part (qkv_proj without k_proj, gate_up_proj without one half, an expert stack with
+    experts absent from the file): any element still carrying the poison value counts."""
+    missing, partial = [], []
+    for n, p in model.named_parameters():
+        if p.dtype not in _POISONABLE or not p.numel():
+            continue
+        nan = torch.isnan(p.data)
+        if bool(nan.any().item()):
+            (missing if bool(nan.all().item()) else partial).append(n)
+    if missing or partial:
+        msg = []
+        if missing:
+            msg.append(f"{len(missing)} parameter(s) were not found in the checkpoint: "
+                       + ", ".join(missing[:8]) + (" ..." if len(missing) > 8 else ""))
+        if partial:
+            msg.append(f"{len(partial)} fused parameter(s) were only partly filled (a shard of each is missing "
+                       f"from the checkpoint): " + ", ".join(partial[:8]) + (" ..." if len(partial) > 8 else ""))
+        raise RuntimeError(f"{what}: " + "; ".join(msg))
 
 
 def load_model(vllm_config: VllmConfig, device: torch.device) -> torch.nn.Module:

@@ -110,7 +110,7 @@ class GraniteMoeForCausalLM(MixtralForCausalLM):
                 mapped = self.map_weight_name(name)
                 kind = next((v for k, v in self._STACKED.items() if mapped and mapped.endswith(".mlp." + k)), None)
                 if kind is None:
-                    if mapped and mapped.endswith(".o_proj.weight") and mult != 1.0:
+                    if mapped and mapped.endswith((".o_proj.weight", ".o_proj.bias")) and mult != 1.0:
                         w = materialize(w).float().mul(mult)
                     yield name, w
                     continue

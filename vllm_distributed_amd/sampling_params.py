@@ -4,6 +4,10 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Union
 
+# A request-supplied pattern or grammar is compiled by native recursive-descent parsers in the serving
+# process: its size is bounded here, its nesting and automaton size inside the compilers.
+MAX_CONSTRAINT_BYTES = 64 * 1024
+
 
 @dataclass
 class SamplingParams:
@@ -120,6 +124,8 @@ class SamplingParams:
                 raise ValueError("a request can carry one output constraint")
             if not isinstance(self.guided_regex, str) or not self.guided_regex:
                 raise ValueError("guided_regex must be a non-empty string")
+            if len(self.guided_regex.encode("utf-8", "surrogatepass")) > MAX_CONSTRAINT_BYTES:
+                raise ValueError(f"guided_regex is longer than {MAX_CONSTRAINT_BYTES} bytes")
             from .ops.grammar import compile_regex
             compile_regex(self.guided_regex)          # ValueError for what the automaton cannot express
         if self.guided_grammar is not None:
@@ -127,6 +133,8 @@ class SamplingParams:
                 raise ValueError("a request can carry one output constraint")
             if not isinstance(self.guided_grammar, str) or not self.guided_grammar.strip():
                 raise ValueError("guided_grammar must be a non-empty string")
+            if len(self.guided_grammar.encode("utf-8", "surrogatepass")) > MAX_CONSTRAINT_BYTES:
+                raise ValueError(f"guided_grammar is longer than {MAX_CONSTRAINT_BYTES} bytes")
             from .ops.grammar import compile_grammar
             compile_grammar(self.guided_grammar)      # ValueError for syntax errors, left recursion, ...
         if self.truncate_prompt_tokens is not None and self.truncate_prompt_tokens < 1:
