@@ -26,6 +26,13 @@ are warm-up; exactly K decode steps are timed between two "every worker has
 drained its device" barriers.  The same run then measures a fixed global batch
 of 256 sequences (strong scaling: the latency regime) and reports it next to
 the headline.
+
+The headline layout is tensor parallelism over all N GPUs (the named configuration).  ``--parallelism``
+selects another split of the same N GPUs (``pp``: N pipeline stages, ``tpAxppB``), and for N > 1 the
+run ends by measuring the pipeline-parallel layout in a child process and reporting it next to the
+headline as ``alt_parallelism``: on a point-to-point xGMI mesh a weak-scaled decode batch moves
+``2 * layers`` all-reduces of ``[2048 N, hidden]`` under TP and one ``[2048, hidden]`` pair per stage
+boundary under PP.
 """
 from __future__ import annotations
 
@@ -127,9 +134,62 @@ def _parse():
     ap.add_argument("--simulate-tp", type=int, default=1,
                     help="one GPU stands in for one rank of a TP group of this size (per-rank compute proxy; "
                          "collectives move no data and the result is NOT a benchmark number)")
+    ap.add_argument("--parallelism", type=str, default="tp",
+                    help="tp (default: TP = N), pp (PP = N), or tpAxppB with A * B = N")
+    ap.add_argument("--alt-parallelism", type=str, default="pp",
+                    help="second layout measured in a child process after the headline when N > 1 ('none' = skip)")
+    ap.add_argument("--alt-timeout", type=float, default=900.0)
     ap.add_argument("--device", type=str, default="cuda", choices=["cuda", "cpu"],
                     help="cpu = gloo rehearsal of the multi-rank path with a tiny model (not a measurement)")
     return ap.parse_args()
+
+
+def _split(spec: str, n: int) -> tuple:
+    """``(tp, pp)`` of a ``--parallelism`` value for N GPUs."""
+    spec = spec.strip().lower()
+    if spec == "tp":
+        return n, 1
+    if spec == "pp":
+        return 1, n
+    import re
+    m = re.fullmatch(r"tp(\d+)xpp(\d+)", spec)
+    if not m or int(m.group(1)) * int(m.group(2)) != n:
+        raise SystemExit(f"--parallelism {spec!r}: expected tp, pp or tpAxppB with A * B = {n}")
+    return int(m.group(1)), int(m.group(2))
+
+
+def _measure_alt_layout(args, n: int) -> dict:
+    """The same weak point under ``--alt-parallelism``, in a child process started bare (its head spawns
+    all N workers) once this process's workers have gone.  A failure there never costs the headline."""
+    import subprocess
+    tp, pp = _split(args.alt_parallelism, n)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_") and k not in (
+        "RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR",
+        "MASTER_PORT", "VLLM_SERVER_PORT", "VLLM_RPC_SECRET", "VLLM_HEAD_LOCAL_DEVICES")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n), "--steps", str(args.steps), "--warmup",
+           str(args.warmup), "--model", args.model, "--batch-per-gpu", str(args.batch_per_gpu), "--strong-batch", "0",
+           "--prompt-len", str(args.prompt_len), "--ttft-requests", "1", "--dtype", args.dtype, "--parallelism",
+           args.alt_parallelism, "--alt-parallelism", "none", "--device", args.device,
+           "--gpu-memory-utilization", str(args.gpu_memory_utilization),
+           "--prefill-budget-per-gpu", str(args.prefill_budget_per_gpu)]
+    if args.num_gpu_blocks_override is not None:
+        cmd += ["--num-gpu-blocks-override", str(args.num_gpu_blocks_override)]
+    if args.enforce_eager:
+        cmd.append("--enforce-eager")
+    if args.sync_scheduling:
+        cmd.append("--sync-scheduling")
+    try:
+        time.sleep(3.0)                    # the previous engine's workers release their devices as they exit
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.alt_timeout)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"parallelism": f"tp{tp}xpp{pp}", "error": (r.stderr or r.stdout)[-600:]}
+        j = json.loads(lines[-1])
+        return {"parallelism": j["config"]["parallelism"], "tokens_per_s": j["value"], "ms_per_step": j["ms_per_step"],
+                "global_batch": j["config"]["global_batch"], "ttft_p50_ms": j.get("ttft_p50_ms"),
+                "hip_graph": j["config"]["hip_graph"], "step_breakdown_ms": j["config"]["step_breakdown_ms"]}
+    except Exception as e:  # noqa: BLE001
+        return {"parallelism": f"tp{tp}xpp{pp}", "error": repr(e)[-600:]}
 
 
 def main() -> None:
@@ -191,12 +251,16 @@ def run_head(args, n: int, rank: int, backend: str, launched: bool) -> None:
 
     spmd = backend == "spmd" and n > 1
     on_gpu = args.device == "cuda"
+    tp, pp = _split(args.parallelism, n)
+    if spmd and pp > 1:
+        raise SystemExit("--executor spmd runs tensor parallelism only")
     if n > 1 and not spmd:
         os.environ.setdefault("VDAMD_TIME_COLLECTIVES", "0")
 
     # prefill budget scales with N so the batch is prefilled in the same number of steps at every N
     shards = n * args.simulate_tp
-    prefill_budget = args.prefill_budget_per_gpu * shards
+    # (a pipeline stage is not sharded by PP: its prefill chunk is sized by the TP degree alone)
+    prefill_budget = args.prefill_budget_per_gpu * (shards if args.parallelism == "tp" else _split(args.parallelism, n)[0])
     per_gpu = _fit_batch_per_gpu(args, query_device=backend != "distributed")
     batch = per_gpu * shards
     strong = min(args.strong_batch, batch) if args.strong_batch > 0 else 0
@@ -204,13 +268,15 @@ def run_head(args, n: int, rank: int, backend: str, launched: bool) -> None:
     prefill_steps = -(-batch * args.prompt_len // max(prefill_budget, batch))
     total_new = args.warmup + args.steps + prefill_steps + 10
     max_len = args.prompt_len + total_new + 16
-    sizes = sorted({s for s in (strong, batch) if s > 0})
+    # under PP the running sequences are dealt out over PP micro-batches: those are the sizes decode runs at
+    sizes = sorted({-(-s // pp) for s in (strong, batch) if s > 0} | ({s for s in (strong, batch) if s > 0} if pp == 1 else set()))
     engine = LLMEngine.from_engine_args(EngineArgs(
-        model=args.model, dtype=args.dtype, load_format="dummy", tensor_parallel_size=n, device=args.device,
+        model=args.model, dtype=args.dtype, load_format="dummy", tensor_parallel_size=tp, pipeline_parallel_size=pp,
+        device=args.device,
         quantization=args.quantization, kv_cache_dtype=args.kv_cache_dtype,
         distributed_executor_backend=backend, max_model_len=max_len, max_num_seqs=batch,
         max_num_batched_tokens=max(prefill_budget, batch), enable_prefix_caching=False,
-        enforce_eager=args.enforce_eager, max_capture_size=batch, hip_graph_sizes=sizes,
+        enforce_eager=args.enforce_eager, max_capture_size=max(sizes), hip_graph_sizes=sizes,
         gpu_memory_utilization=args.gpu_memory_utilization,
         num_gpu_blocks_override=args.num_gpu_blocks_override, seed=0, async_scheduling=not args.sync_scheduling))
     executor = engine.core.executor
@@ -261,20 +327,27 @@ def run_head(args, n: int, rank: int, backend: str, launched: bool) -> None:
             engine.step()
         sync()
         prefill_s = time.perf_counter() - t_prefill0
-        if not args.sync_scheduling:
-            engine.step()          # fill the one-step-ahead pipeline: from here every call returns one full step
+        if not args.sync_scheduling or pp > 1:
+            for _ in range(max(1, pp - 1) if pp > 1 else 1):
+                engine.step()      # fill the pipeline: from here every call returns one batch's tokens
         for _ in range(args.warmup):
             engine.step()
         produced = 0
         sync()
         engine.core.timer.reset()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            outs = engine.step()
-            produced += sum(len(o.new_token_ids) for o in outs)
+        if pp == 1:
+            for _ in range(args.steps):
+                outs = engine.step()
+                produced += sum(len(o.new_token_ids) for o in outs)
+        else:
+            # one "step" = every sequence gains one token = PP micro-batches through the pipeline
+            while produced < nseq * args.steps:
+                produced += sum(len(o.new_token_ids) for o in engine.step())
         sync()
         elapsed = time.perf_counter() - t0
-        assert produced == nseq * args.steps, (produced, nseq, args.steps)
+        assert produced >= nseq * args.steps, (produced, nseq, args.steps)
+        steps_done = produced / nseq
         if spmd:                   # every rank timed its own copy of the loop: report the slowest
             import torch
             import torch.distributed as dist
@@ -287,16 +360,21 @@ def run_head(args, n: int, rank: int, backend: str, launched: bool) -> None:
         while engine.has_unfinished_requests():
             engine.step()
         sync()
-        return {"global_batch": nseq, "tokens_per_s": round(nseq * args.steps / elapsed, 2),
-                "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        return {"global_batch": nseq, "tokens_per_s": round(produced / elapsed, 2),
+                "ms_per_step": round(1e3 * elapsed / steps_done, 3),
                 "prefill_tokens_per_s": round(nseq * args.prompt_len / prefill_s, 1),
                 "step_breakdown_ms": breakdown}
 
     weak = measure(batch, "b")
     strong_res = measure(strong, "s") if strong and strong != batch else None
 
+    stats = executor.collective_rpc("get_stats") if rank == 0 else []
+    engine.shutdown()
     if rank == 0:
-        stats = executor.collective_rpc("get_stats")
+        alt = None
+        if n > 1 and not spmd and args.alt_parallelism.lower() not in ("none", args.parallelism.lower()) \
+                and args.simulate_tp == 1:
+            alt = _measure_alt_layout(args, n)
         s0 = stats[0] if stats else {}
         dt = {"bfloat16": "bf16", "float16": "fp16", "float32": "fp32"}[args.dtype]
         if args.quantization:
@@ -306,7 +384,8 @@ def run_head(args, n: int, rank: int, backend: str, launched: bool) -> None:
         pretty = {"llama-3-70b": "Llama-3-70B", "llama-3-8b": "Llama-3-8B"}.get(args.model, args.model)
         bd = weak["step_breakdown_ms"]
         config = {"model": args.model, "global_batch": batch, "seq_len": args.prompt_len,
-                  "parallelism": f"tp{n}", "executor": backend,
+                  "parallelism": f"tp{tp}" if pp == 1 else (f"pp{pp}" if tp == 1 else f"tp{tp}xpp{pp}"),
+                  "executor": backend,
                   "launch": ("torch.distributed.run: head + %d registered workers" % (n - 1)
                              if backend == "distributed" and launched
                              else "head spawns every worker" if backend == "distributed" else backend),
@@ -317,7 +396,8 @@ def run_head(args, n: int, rank: int, backend: str, launched: bool) -> None:
                                      "direct_all_reduce": s0.get("tp_direct_all_reduce")},
                   "block_size": s0.get("block_size"), "step_breakdown_ms": bd}
         print(json.dumps({
-            "metric": (f"output tokens/sec (whole node), {pretty} {dt} TP over N GPUs, decode"
+            "metric": (f"output tokens/sec (whole node), {pretty} {dt} "
+                       f"{'TP' if pp == 1 else ('PP' if tp == 1 else 'TPxPP')} over N GPUs, decode"
                        if args.simulate_tp == 1 else
                        f"NOT A BENCHMARK: per-rank compute proxy, one GPU simulating rank 0 of TP={args.simulate_tp}"),
             "value": weak["tokens_per_s"], "unit": "tokens/s", "n_gpus": n, "steps": args.steps,
@@ -328,9 +408,9 @@ def run_head(args, n: int, rank: int, backend: str, launched: bool) -> None:
             "prefill_tokens_per_s": weak["prefill_tokens_per_s"],
             "rpc_overhead_ms": bd.get("rpc_overhead_ms"),
             "strong_scaling": None if strong_res is None else dict(strong_res, scaling="strong"),
+            "alt_parallelism": alt,
             "config": config,
         }), flush=True)
-    engine.shutdown()
 
 
 if __name__ == "__main__":

@@ -393,3 +393,25 @@ def test_offline_n_best_of_and_beam_search():
     finally:
         llm.shutdown()
         pstate.destroy_model_parallel()
+
+
+def test_pipeline_depth_deals_running_requests_over_micro_batches():
+    """With PP batches in flight the scheduler hands each schedule() call 1/PP of the running requests:
+    all of them in the first batch would leave the other stages idle until it has passed through."""
+    from vllm_distributed_amd.config import CacheConfig, SchedulerConfig
+    from vllm_distributed_amd.engine.request import Request
+    from vllm_distributed_amd.engine.scheduler import Scheduler
+    from vllm_distributed_amd.engine.types import ModelRunnerOutput
+    sc = SchedulerConfig(max_num_seqs=16, max_num_batched_tokens=256, max_model_len=64)
+    sched = Scheduler(sc, CacheConfig(block_size=16), num_blocks=64, pipeline_depth=4)
+    for i in range(8):
+        sched.add_request(Request(f"r{i}", [1, 2, 3], SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True)))
+    so = sched.schedule()                          # prefill of all eight (waiting requests are not capped)
+    assert len(so.num_scheduled_tokens) == 8
+    out = ModelRunnerOutput(req_ids=list(so.num_scheduled_tokens), sampled_token_ids=[[5]] * 8)
+    sched.update_from_output(so, out)
+    batches = [sched.schedule() for _ in range(4)]  # four micro-batches in flight, nothing returned yet
+    sizes = [len(b.num_scheduled_tokens) for b in batches]
+    assert sizes == [2, 2, 2, 2]
+    assert len(set().union(*[set(b.num_scheduled_tokens) for b in batches])) == 8
+    assert sched.schedule().is_empty               # everything is in flight

@@ -165,3 +165,23 @@ def test_bench_script_without_a_launcher_spawns_its_workers():
     assert j["strong_scaling"]["tokens_per_s"] > 0
     bd = j["config"]["step_breakdown_ms"]
     assert bd["steps"] == 3 and bd["rpc_overhead_ms"] == pytest.approx(bd["rpc_in_ms"] + bd["rpc_out_ms"], abs=0.01)
+
+
+@pytest.mark.slow
+def test_bench_reports_the_pipeline_layout_next_to_the_headline():
+    """``bench.py --gpus 2`` measures TP = 2 (the headline layout) and then, in a child process, PP = 2
+    with the running sequences dealt out over two micro-batches; the child's numbers arrive as
+    ``alt_parallelism`` and a failure there would only leave an ``error`` field."""
+    env = dict(os.environ, VLLM_LOGGING_LEVEL="ERROR", GLOO_SOCKET_IFNAME="lo", OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    j = _bench_json([sys.executable, os.path.join(ROOT, "bench.py"), *BENCH_ARGS[:-2], "--strong-batch", "0",
+                     "--alt-parallelism", "pp"], env)
+    assert j["config"]["parallelism"] == "tp2" and "TP over N GPUs" in j["metric"]
+    alt = j["alt_parallelism"]
+    assert alt is not None and "error" not in alt, alt
+    assert alt["parallelism"] == "pp2" and alt["tokens_per_s"] > 0 and alt["global_batch"] == 8
+    # asked for directly, the pipeline layout is the reported one and no second run happens
+    j = _bench_json([sys.executable, os.path.join(ROOT, "bench.py"), *BENCH_ARGS[:-2], "--strong-batch", "0",
+                     "--parallelism", "pp"], env)
+    assert j["config"]["parallelism"] == "pp2" and j["alt_parallelism"] is None and "PP over N GPUs" in j["metric"]

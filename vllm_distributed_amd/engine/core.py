@@ -94,7 +94,8 @@ class EngineCore:
                                    include_new_token_ids=pp > 1, kv_connector=kv_connector,
                                    max_loras=vllm_config.lora_config.max_loras if vllm_config.lora_config else 0,
                                    speculative_config=vllm_config.speculative_config,
-                                   sliding_window=None if kv_connector is not None else self.kv_window)
+                                   sliding_window=None if kv_connector is not None else self.kv_window,
+                                   pipeline_depth=pp)
         self.max_concurrent = max(1, self.executor.max_concurrent_batches)
         self.batch_queue: Deque[Tuple[object, SchedulerOutput]] = deque()
         self.timer = StepTimer()

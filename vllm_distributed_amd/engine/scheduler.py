@@ -63,8 +63,12 @@ class Scheduler:
     def __init__(self, scheduler_config: SchedulerConfig, cache_config: CacheConfig,
                  num_blocks: int, include_new_token_ids: bool = True,
                  kv_connector=None, max_loras: int = 0, speculative_config=None,
-                 sliding_window: Optional[int] = None):
+                 sliding_window: Optional[int] = None, pipeline_depth: int = 1):
         self.config = scheduler_config
+        # pipeline parallelism keeps `pipeline_depth` batches in flight, and a stage only has work
+        # while a batch is at it: the running requests are dealt out over that many micro-batches
+        # instead of all going into the first one (which would leave every other stage idle)
+        self.pipeline_depth = max(1, int(pipeline_depth))
         self.cache_config = cache_config
         self.max_num_seqs = scheduler_config.max_num_seqs
         self.max_num_batched_tokens = scheduler_config.max_num_batched_tokens
@@ -195,8 +199,9 @@ class Scheduler:
         req_blocks, block_size = self.kv.req_blocks, self.kv.block_size
 
         # 1. running requests
+        seq_cap = -(-len(self.running) // self.pipeline_depth) if self.pipeline_depth > 1 else len(self.running)
         for req in list(self.running):
-            if budget <= 0:
+            if budget <= 0 or len(num_scheduled) >= seq_cap:
                 break
             if req.status != RequestStatus.RUNNING:
                 continue             # preempted earlier in this loop
