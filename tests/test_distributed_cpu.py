@@ -676,3 +676,21 @@ def test_head_spawns_eight_workers_tp8_matches_single_process(monkeypatch):
     finally:
         if eng is not None:
             eng.shutdown()
+
+
+@pytest.mark.slow
+def test_control_plane_round_trip_and_head_cost_at_world_8():
+    """``benchmarks/rpc_fanout_bench.py``: eight stub workers behind the real executor, 2048 sequences.
+    The bounds are loose (a shared CI box): what they pin is the order of magnitude - a step's fan-out
+    and reply in a few milliseconds, the head's own scheduling code in microseconds per sequence."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "benchmarks", "rpc_fanout_bench.py"), "--world", "8",
+                        "--batches", "2048", "--steps", "10", "--sync-scheduling"], capture_output=True, text=True,
+                       timeout=280, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    row = j["results"][0]
+    assert j["world"] == 8 and row["batch"] == 2048 and row["tokens_per_step_call"] == 2048
+    assert j["noop_one_reply_ms_p50"] < 15.0, j
+    assert row["execute_rtt_ms_p50"] < 40.0, row
+    assert row["schedule_ms"] + row["update_ms"] < 2048 * 0.02, row          # < 20 us per sequence

@@ -29,7 +29,7 @@ logger = init_logger(__name__)
 
 class _ReqState:
     __slots__ = ("request", "detok", "prompt", "cumulative_logprob", "logprobs", "finish_reason",
-                 "stop_reason", "prompt_logprobs", "pooled")
+                 "stop_reason", "prompt_logprobs", "pooled", "live")
 
     def __init__(self, request: Request, detok: Optional[IncrementalDetokenizer], prompt: Optional[str]):
         self.request = request
@@ -41,6 +41,9 @@ class _ReqState:
         self.stop_reason = None
         self.prompt_logprobs = None
         self.pooled = None
+        # the completion object of a running request that is not detokenised: it shows the request's own
+        # (live) token list, so one object serves every step until the request finishes
+        self.live: Optional[List[CompletionOutput]] = None
 
 
 class LLMEngine:
@@ -160,11 +163,23 @@ class LLMEngine:
     def _process(self, core_outputs: List[EngineCoreOutput]) -> List[RequestOutput]:
         outs: List[RequestOutput] = []
         stop_hits: List[str] = []
+        states, remote = self.states, self.remote_core
         for co in core_outputs:
-            st = self.states.get(co.request_id)
+            st = states.get(co.request_id)
             if st is None:
                 continue
             req = st.request
+            if (st.detok is None and co.finish_reason is None and not remote and co.logprobs is None
+                    and co.prompt_logprobs is None and co.pooled is None and st.logprobs is None):
+                # a plain decode step of a request nobody detokenises: no text, nothing accumulated
+                live = st.live
+                if live is None:
+                    live = st.live = [CompletionOutput(index=0, text="", token_ids=req.output_token_ids,
+                                                       cumulative_logprob=st.cumulative_logprob, logprobs=None,
+                                                       finish_reason=None, stop_reason=co.stop_reason)]
+                outs.append(RequestOutput(co.request_id, st.prompt, req.prompt_token_ids, live, False, req.metrics,
+                                          co.new_token_ids, "", st.prompt_logprobs, st.pooled))
+                continue
             finish_reason, stop_reason = co.finish_reason, co.stop_reason
             if self.remote_core:        # the scheduler's Request lives in the core process: mirror it
                 for t in co.new_token_ids:

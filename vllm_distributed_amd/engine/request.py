@@ -32,7 +32,7 @@ class Request:
                  "arrival_time", "priority", "status", "output_token_ids", "all_token_ids",
                  "num_computed_tokens", "num_cached_tokens", "stop_reason", "metrics",
                  "block_hashes", "num_preemptions", "max_tokens", "prompt", "num_output_placeholders",
-                 "lora_request", "prompt_logprobs", "spec_token_ids")
+                 "lora_request", "prompt_logprobs", "spec_token_ids", "plain_stop")
 
     def __init__(self, request_id: str, prompt_token_ids: List[int],
                  sampling_params: SamplingParams, eos_token_id: Optional[int] = None,
@@ -61,6 +61,10 @@ class Request:
         # what the workers' draft model proposed after this request's latest token (draft-model speculation)
         self.spec_token_ids: List[int] = []
         self.max_tokens = sampling_params.max_tokens
+        # the only ways this request can end are its length limits: no end-of-sequence or stop-token test per
+        # sampled token (the scheduler's per-step loops take a short path for such requests)
+        self.plain_stop = bool((sampling_params.ignore_eos or eos_token_id is None)
+                               and not sampling_params.stop_token_ids)
         self.metrics = RequestMetrics(arrival_time=self.arrival_time,
                                       num_prompt_tokens=len(prompt_token_ids))
 

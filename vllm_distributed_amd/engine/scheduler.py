@@ -200,11 +200,35 @@ class Scheduler:
 
         # 1. running requests
         seq_cap = -(-len(self.running) // self.pipeline_depth) if self.pipeline_depth > 1 else len(self.running)
+        # the plain decode step of a request (one token, room left in its last block, nothing that
+        # needs bookkeeping) is most of a large batch: it is handled in a dozen statements up front
+        quick = (self.spec is None and self.kv_connector is None and self.lookahead == 0
+                 and self.config.long_prefill_token_threshold <= 0)
+        pending_new = self._pending_new_tokens
+        running_state = RequestStatus.RUNNING
+        max_model_len, async_mode = self.max_model_len, self.async_scheduling
         for req in list(self.running):
             if budget <= 0 or len(num_scheduled) >= seq_cap:
                 break
-            if req.status != RequestStatus.RUNNING:
+            if req.status != running_state:
                 continue             # preempted earlier in this loop
+            if quick:
+                ph, comp, have = req.num_output_placeholders, req.num_computed_tokens, len(req.all_token_ids)
+                if have + ph - comp == 1 and comp + 1 < max_model_len:
+                    mt = req.max_tokens
+                    if ph and ((mt is not None and len(req.output_token_ids) + ph >= mt) or have + ph >= max_model_len):
+                        continue     # would overshoot max_tokens / max_model_len: wait for the token
+                    rid = req.request_id
+                    held = req_blocks.get(rid)
+                    if held is not None and comp + 1 <= len(held) * block_size:
+                        if pending_new and rid in pending_new:
+                            self._add_cached(cached, req, _NO_BLOCKS)
+                        num_scheduled[rid] = 1
+                        req.num_computed_tokens = comp + 1
+                        if async_mode and comp + 1 >= have + ph:
+                            req.num_output_placeholders = ph + 1
+                        budget -= 1
+                        continue
             n = req.num_tokens + req.num_output_placeholders - req.num_computed_tokens
             if n <= 0:               # its next token is still in flight
                 continue
@@ -400,10 +424,35 @@ class Scheduler:
         running_state = RequestStatus.RUNNING
         max_len = self.max_model_len
         any_finished = False
+        # one token for a request that can only end by length, with nothing else to record: most of a
+        # large decode batch, and the reason this loop has a short path
+        quick = (not spec and not caching and not windowed and lps is None and proposed is None
+                 and not runner_output.pooled)
+        pending_new = self._pending_new_tokens
         for rid, new_tokens in zip(runner_output.req_ids, runner_output.sampled_token_ids):
             req = requests.get(rid)
             if req is None or req.status != running_state or rid not in scheduled:
                 continue             # aborted / preempted / finished while in flight
+            if quick and req.plain_stop and len(new_tokens) == 1:
+                out_ids, all_ids, mt = req.output_token_ids, req.all_token_ids, req.max_tokens
+                n_out = len(out_ids) + 1
+                if (n_out > 1 and (mt is None or n_out < mt) and len(all_ids) + 1 < max_len
+                        and req.prompt_logprobs is None):
+                    tok = new_tokens[0]
+                    out_ids.append(tok)
+                    all_ids.append(tok)
+                    if req.num_output_placeholders:
+                        req.num_output_placeholders -= 1
+                    req.metrics.num_generation_tokens = n_out
+                    if fwd_tokens:
+                        got = pending_new.get(rid)
+                        if got is None:
+                            pending_new[rid] = list(new_tokens)
+                        else:
+                            got.extend(new_tokens)
+                    nc = req.num_cached_tokens
+                    outputs.append(EngineCoreOutput(rid, new_tokens, None, req.stop_reason, None, nc if nc > 0 else 0))
+                    continue
             if spec and new_tokens and rid in spec:
                 # 1 + len(drafts) positions ran; the accepted drafts and one more token came back:
                 # the positions of the rejected drafts count as not computed (their KV is overwritten)

@@ -50,6 +50,9 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     # Address the head's RPC server binds to.  Unset: every interface when a real shared
     # secret is configured, loopback only (workers on this host) when it is not.
     "VLLM_RPC_BIND": _str("VLLM_RPC_BIND", None),
+    # How the head talks to the workers it spawns itself: "socket" (a Unix socket pair on the event
+    # loops of both sides) or "pipe" (multiprocessing.Pipe with helper threads, the reference's choice).
+    "VLLM_LOCAL_WORKER_TRANSPORT": _str("VLLM_LOCAL_WORKER_TRANSPORT", "socket"),
     # Seconds a remote worker waits between reconnect attempts.
     "VLLM_REMOTE_RETRY_SECONDS": _float("VLLM_REMOTE_RETRY_SECONDS", 10.0),
     # Cap on GPUs the head uses for its own (forked) workers; -1 = all.

@@ -27,7 +27,10 @@ from __future__ import annotations
 import asyncio
 import concurrent.futures
 import multiprocessing
+import functools
 import os
+import socket
+import sys
 import threading
 import time
 import traceback
@@ -146,6 +149,9 @@ class DistributedExecutor(Executor):
                 except Exception:
                     pass
 
+        # the RPC thread must get the interpreter promptly while the engine thread runs long pure-Python
+        # loops (scheduling a 16k-sequence batch): hand-over within 0.5 ms instead of the default 5
+        sys.setswitchinterval(0.0005)
         self._thread = threading.Thread(target=rpc_thread, name="executor-rpc", daemon=True)
         self._thread.start()
         self.loop = loop_ready.result()
@@ -306,7 +312,21 @@ class DistributedExecutor(Executor):
     async def _spawn_local_worker(self, a: Assignment) -> Any:
         from ..launch import worker_main
         ctx = multiprocessing.get_context("spawn")
-        parent_conn, child_conn = ctx.Pipe()
+        loop = asyncio.get_running_loop()
+        if envs.VLLM_LOCAL_WORKER_TRANSPORT == "pipe":
+            # the reference's transport for its own workers (src/launch.py:157): every frame crosses
+            # two helper threads per direction (blocking Connection.send / recv)
+            parent_conn, child_conn = ctx.Pipe()
+        else:
+            # a Unix socket pair driven by the event loops of both processes: no helper threads on the
+            # step's path (a thread hand-off costs 50-300 us, and a step made 4 of them per worker)
+            parent_conn, child_conn = socket.socketpair(socket.AF_UNIX, socket.SOCK_STREAM)
+            for sk in (parent_conn, child_conn):
+                for opt in (socket.SO_SNDBUF, socket.SO_RCVBUF):
+                    try:
+                        sk.setsockopt(socket.SOL_SOCKET, opt, 4 << 20)
+                    except OSError:
+                        pass
         proc = ctx.Process(target=worker_main, args=(child_conn,),
                            kwargs=dict(vllm_config_blob=cloudpickle.dumps(self.vllm_config),
                                        rank=a.rank, local_rank=a.local_rank),
@@ -314,8 +334,11 @@ class DistributedExecutor(Executor):
         proc.start()
         child_conn.close()
         self._local_procs.append(proc)
-        transport = ConnectionTransport(parent_conn)
-        loop = asyncio.get_running_loop()
+        if isinstance(parent_conn, socket.socket):
+            reader, writer = await asyncio.open_connection(sock=parent_conn)
+            transport = StreamTransport(reader, writer)
+        else:
+            transport = ConnectionTransport(parent_conn)
         peer, read_loop = await prepare_peer_readloop(loop, transport, "head", f"local-worker-{a.rank}")
         peer.params["bootstrap_exchange"] = self.rendezvous.exchange
         self._peers[a.rank] = peer
@@ -417,13 +440,32 @@ class DistributedExecutor(Executor):
                 timing["rpc_out"] = max(0.0, time.time() - timing.pop("t_reply"))
             return out
 
-        futures: List[concurrent.futures.Future] = []
-        for rank in range(self.world_size):
-            fut = asyncio.run_coroutine_threadsafe(call(rank, rank in reply_ranks), self.loop)
-            if rank in reply_ranks:
-                futures.append(fut)
+        # one hand-off to the RPC thread for the whole fan-out (not one per worker): the coroutine
+        # starts every rank's call back to back on the loop and wires each result to its future
+        futures: List[concurrent.futures.Future] = [concurrent.futures.Future() for _ in reply_ranks]
+        slot = {rank: i for i, rank in enumerate(reply_ranks)}
+
+        def settle(rank: int, task: "asyncio.Future") -> None:
+            out = futures[slot[rank]] if rank in slot else None
+            if task.cancelled():
+                if out is not None:
+                    out.cancel()
+                return
+            e = task.exception()
+            if out is None:
+                if e is not None and not self.shutdown_event.is_set():
+                    logger.error("worker call failed on a non-reply rank: %r", e)
+            elif e is not None:
+                out.set_exception(e)
             else:
-                fut.add_done_callback(self._log_background_error)
+                out.set_result(task.result())
+
+        def fan_out() -> None:
+            for rank in range(self.world_size):
+                task = asyncio.ensure_future(call(rank, rank in slot))
+                task.add_done_callback(functools.partial(settle, rank))
+
+        self.loop.call_soon_threadsafe(fan_out)
         if non_block:
             return futures
         try:

@@ -35,6 +35,14 @@ logger = init_logger(__name__)
 # --------------------------------------------------------------------------
 # worker-side RPC endpoint
 # --------------------------------------------------------------------------
+class _Finished:
+    """A call whose reply was already pickled on the worker thread."""
+    __slots__ = ("reply",)
+
+    def __init__(self, reply: Optional[bytes]):
+        self.reply = reply
+
+
 def set_peer_run_worker(peer: RpcPeer, wrapper: Any, rank: int, local_rank: int):
     """Publish ``run_worker(pickled)`` on ``peer``.
 
@@ -66,6 +74,9 @@ def set_peer_run_worker(peer: RpcPeer, wrapper: Any, rank: int, local_rank: int)
             runner = getattr(getattr(wrapper, "worker", None), "model_runner", None)
             if runner is not None:
                 runner.defer_output = True      # the reply thread waits for the device, not this one
+        if not getattr(result, "lazy_step_result", False):
+            # nothing to wait for: the reply is pickled here, without a hand-off to the reply thread
+            return _Finished(_finish(result, unique_reply_rank, t_send, t_arrive, t_dequeue))
         return result, unique_reply_rank, t_send, t_arrive, t_dequeue
 
     def _finish(result: Any, unique_reply_rank: Optional[int], t_send: Optional[float], t_arrive: float,
@@ -85,6 +96,8 @@ def set_peer_run_worker(peer: RpcPeer, wrapper: Any, rank: int, local_rank: int)
     async def run_worker(pickled: bytes):
         loop = asyncio.get_running_loop()
         done = await loop.run_in_executor(executor, _run, pickled, time.time())
+        if isinstance(done, _Finished):
+            return done.reply
         return await loop.run_in_executor(replier, _finish, *done)
 
     peer.params["run_worker"] = run_worker
@@ -120,15 +133,26 @@ async def worker_async_main(transport, vllm_config, rank: int, local_rank: int) 
         os._exit(0)        # the pipe is gone: nothing to clean up that the OS will not
 
 
-def worker_main(conn: multiprocessing.connection.Connection, vllm_config_blob: bytes, rank: int,
-                local_rank: int) -> None:
+def worker_main(conn, vllm_config_blob: bytes, rank: int, local_rank: int) -> None:
+    """``conn``: the worker's end of a Unix socket pair (served by the event loop itself) or of a
+    ``multiprocessing.Pipe`` (reference ``src/launch.py:655-665``)."""
+    import socket as _socket
     _die_with_parent()
+    sys.setswitchinterval(0.0005)      # a thread that got a frame takes the interpreter within 0.5 ms, not 5
     vllm_config = cloudpickle.loads(vllm_config_blob)
-    transport = ConnectionTransport(conn)
     loop = asyncio.new_event_loop()
     asyncio.set_event_loop(loop)
     gc_runner_loop(loop)
-    loop.run_until_complete(worker_async_main(transport, vllm_config, rank, local_rank))
+
+    async def main() -> None:
+        if isinstance(conn, _socket.socket):
+            reader, writer = await asyncio.open_connection(sock=conn)
+            transport = StreamTransport(reader, writer)
+        else:
+            transport = ConnectionTransport(conn)
+        await worker_async_main(transport, vllm_config, rank, local_rank)
+
+    loop.run_until_complete(main())
     loop.close()
 
 

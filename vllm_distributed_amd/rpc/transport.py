@@ -136,6 +136,7 @@ class StreamTransport(RpcTransport):
         self.reader = reader
         self.writer = writer
         self.codec = codec
+        self._pending: list = []        # frames written since the last flush: they leave in one send
 
     async def read(self) -> Tuple[int, bytes]:
         try:
@@ -149,11 +150,17 @@ class StreamTransport(RpcTransport):
         return ftype, payload
 
     async def write(self, ftype: int, payload: bytes) -> None:
-        self.writer.write(_HEADER.pack(len(payload) + 1, ftype))
+        self._pending.append(_HEADER.pack(len(payload) + 1, ftype))
         if payload:
-            self.writer.write(payload)
+            self._pending.append(payload)
 
     async def flush(self) -> None:
+        if self._pending:
+            frames, self._pending = self._pending, []
+            # a call's sideband buffer and its message: one system call, not four
+            self.writer.write(b"".join(frames) if sum(map(len, frames)) <= 65536 else frames[0])
+            if sum(map(len, frames)) > 65536:
+                self.writer.writelines(frames[1:])
         await self.writer.drain()
 
     def close(self) -> None:
