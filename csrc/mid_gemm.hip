@@ -356,7 +356,7 @@ int launch(const void* x, long xs, const void* w, long ws, void* out, long os, v
                                                             (float*)partial, M, N, K, ksplit);
   }
   HIP_LAUNCH_CHECK();
-  if (ksplit > 1) {
+  if (ksplit > 1 && out != nullptr) {            // out == nullptr: the caller consumes the K-split slabs itself
     const long n = (long)M * (N / 4);
     mid_reduce_kernel<T><<<(unsigned)((n + 255) / 256), 256, 0, st>>>((T*)out, os, (const float*)partial, M, N,
                                                                      ksplit);
@@ -388,6 +388,7 @@ VDAMD_API int vdamd_mid_gemm(void* out, long out_stride, const void* x, long x_s
   if (M <= 0) return 0;
   if (K % MG_BK || N % 16 || ksplit < 1 || ksplit > K / MG_BK) return -1;
   if (ksplit > 1 && partial == nullptr) return -2;
+  if (out == nullptr && ksplit == 1) return -2;
   if ((x_stride | w_stride) % 8 || out_stride % 4) return -5;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16)

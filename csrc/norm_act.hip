@@ -52,6 +52,70 @@ __global__ void rms_norm_kernel(T* __restrict__ out, const T* __restrict__ x, T*
   }
 }
 
+// The same with the row arriving as `ks` fp32 partial sums (the K-split slabs of the GEMM that produced it,
+// [ks][rows][H]): v = sum of the slabs + residual; residual = v; out = v * rsqrt(mean(v^2) + eps) * w.
+// One kernel where the split GEMM's own reduction, a bf16 round trip and the add + norm kernel ran before.
+template <typename T>
+__global__ void reduce_add_rms_norm_kernel(T* __restrict__ out, const float* __restrict__ partial, int ks,
+                                           long slab_stride, T* __restrict__ residual, const T* __restrict__ w,
+                                           float eps, int H, long out_stride) {
+  __shared__ float red[17];
+  const long row = blockIdx.x;
+  const float* pr = partial + row * (long)H;
+  T* rr = residual + row * (long)H;
+  T* orow = out + row * out_stride;
+  using V = typename Vec8<T>::type;
+  V vals[NORM_MAX_ITERS];
+  float ss = 0.f;
+  const int nvec = H >> 3;
+#pragma unroll
+  for (int it = 0; it < NORM_MAX_ITERS; ++it) {
+    const int i = threadIdx.x + it * blockDim.x;
+    if (i < nvec) {
+      const V r = ld8<T>(rr + 8 * i);
+      f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = a;
+      // four slabs' loads in flight at a time (a plain loop over a run-time ks waits for each in turn)
+      int k = 0;
+      for (; k + 4 <= ks; k += 4) {
+        f32x4 la[4], lb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          la[u] = *reinterpret_cast<const f32x4*>(pr + (k + u) * slab_stride + 8 * i);
+          lb[u] = *reinterpret_cast<const f32x4*>(pr + (k + u) * slab_stride + 8 * i + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a += la[u]; b += lb[u]; }
+      }
+      for (; k < ks; ++k) {
+        a += *reinterpret_cast<const f32x4*>(pr + k * slab_stride + 8 * i);
+        b += *reinterpret_cast<const f32x4*>(pr + k * slab_stride + 8 * i + 4);
+      }
+      V v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = (T)(a[j] + (float)r[j]);
+        v[j + 4] = (T)(b[j] + (float)r[j + 4]);
+      }
+      st8<T>(rr + 8 * i, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float f = (float)v[j]; ss += f * f; }
+      vals[it] = v;
+    }
+  }
+  ss = block_sum(ss, red);
+  const float inv = rsqrtf(ss / (float)H + eps);
+#pragma unroll
+  for (int it = 0; it < NORM_MAX_ITERS; ++it) {
+    const int i = threadIdx.x + it * blockDim.x;
+    if (i < nvec) {
+      V g = ld8<T>(w + 8 * i), o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (T)((float)vals[it][j] * inv * (float)g[j]);
+      st8<T>(orow + 8 * i, o);
+    }
+  }
+}
+
 template <typename T>
 __global__ void layer_norm_kernel(T* __restrict__ out, const T* __restrict__ x, const T* __restrict__ w,
                                   const T* __restrict__ b, float eps, int H) {
@@ -162,6 +226,28 @@ VDAMD_API int vdamd_rms_norm(void* out, const void* x, void* residual, const voi
   else if (dtype == DT_F16) { if (residual) LAUNCH(f16_t, true); else LAUNCH(f16_t, false); }
   else return -2;
 #undef LAUNCH
+  HIP_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[T][H] = RMSNorm(sum_k partial[k][T][H] + residual) * w; residual is updated in place to the sum.
+VDAMD_API int vdamd_reduce_add_rms_norm(void* out, const float* partial, int ks, void* residual, const void* w,
+                                        float eps, int T, int H, long out_stride, int dtype, hipStream_t s) {
+  if (T == 0) return 0;
+  if (H % 8 != 0 || H > 8 * 1024 * NORM_MAX_ITERS || ks < 1 || residual == nullptr) return -1;
+  int threads = norm_threads(H);
+  if (T <= 64) {               // a few rows: one pass of a wider workgroup, the launch is latency-bound
+    threads = ((H >> 3) + 63) / 64 * 64;
+    if (threads > 1024) threads = 1024;
+  }
+  const long slab = (long)T * H;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(reduce_add_rms_norm_kernel<bf16_t>, dim3(T), dim3(threads), 0, s, (bf16_t*)out, partial, ks,
+                       slab, (bf16_t*)residual, (const bf16_t*)w, eps, H, out_stride);
+  else if (dtype == DT_F16)
+    hipLaunchKernelGGL(reduce_add_rms_norm_kernel<f16_t>, dim3(T), dim3(threads), 0, s, (f16_t*)out, partial, ks,
+                       slab, (f16_t*)residual, (const f16_t*)w, eps, H, out_stride);
+  else return -2;
   HIP_LAUNCH_CHECK();
   return 0;
 }

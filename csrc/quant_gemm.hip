@@ -549,7 +549,7 @@ static int launch_w4a16(void* out, long out_stride, const void* x, long x_stride
 #undef W4_LAUNCH
 #undef W4_LDS
   HIP_LAUNCH_CHECK();
-  if (ksplit > 1) {
+  if (ksplit > 1 && out != nullptr) {            // out == nullptr: the caller consumes the K-split slabs itself
     const long n = (long)M * (N / 4);
     w4a16_reduce_kernel<T><<<(unsigned)((n + 255) / 256), 256, 0, st>>>((T*)out, out_stride,
                                                                         (const float*)partial, M, N, ksplit);

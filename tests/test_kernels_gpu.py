@@ -872,3 +872,26 @@ def test_skinny_gemm_with_silu_mul_operand(m):
     a = ops.silu_mul_linear(gu, w2)
     b = ops.linear(ops.silu_and_mul(gu), w2)
     torch.testing.assert_close(a.float(), b.float(), rtol=3e-2, atol=0.3)
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 8192, 8192), (64, 8192, 28672), (1, 8192, 28672), (200, 4096, 14336)])
+def test_k_split_partial_sums_reduced_by_the_following_norm(m, n, k):
+    """A projection left as fp32 K-split slabs + the kernel that sums them, adds the residual and
+    normalises, against the fp32 definition; and against the reduce -> add + norm pair it replaces."""
+    torch.manual_seed(m + n)
+    x = (torch.randn(m, k, device="cuda") * 0.5).to(torch.bfloat16)
+    w = (torch.randn(n, k, device="cuda") * 0.02).to(torch.bfloat16)
+    res = torch.randn(m, n, device="cuda").to(torch.bfloat16)
+    g = (torch.rand(n, device="cuda") + 0.5).to(torch.bfloat16)
+    slabs = ops.linear_partials(x, w)
+    assert slabs is not None and slabs.dim() == 3 and slabs.shape[1:] == (m, n) and slabs.dtype == torch.float32
+    r1 = res.clone()
+    normed, r1 = ops.reduce_add_rms_norm(slabs, r1, g, 1e-5)
+    y = x.float() @ w.float().t()
+    tot = (y + res.float()).to(torch.bfloat16).float()
+    want = tot * torch.rsqrt(tot.pow(2).mean(-1, keepdim=True) + 1e-5) * g.float()
+    assert (r1.float() - (y + res.float())).abs().max().item() < 0.06
+    assert (normed.float() - want).abs().max().item() < 0.06
+    r2 = res.clone()
+    n2, r2 = ops.fused_add_rms_norm(ops.linear(x, w), r2, g, 1e-5)
+    assert (normed.float() - n2.float()).abs().max().item() < 0.13      # two bf16 roundings of values up to ~8

@@ -122,6 +122,9 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     # Large-batch (M >= 512) 256 x 256-tile LDS-DMA GEMM with fused SiLU*mul / residual epilogues
     # (0 = library GEMM + separate activation kernel).
     "VDAMD_BIG_GEMM": _bool("VDAMD_BIG_GEMM", True),
+    # The K-split slabs of a row-parallel projection (TP = 1) are summed by the add + RMSNorm that follows it
+    # instead of by a reduction kernel of their own (one launch and a 16-bit round trip fewer per projection).
+    "VDAMD_FUSED_REDUCE_NORM": _bool("VDAMD_FUSED_REDUCE_NORM", True),
     # Form silu(gate) * up inside the weight-streaming down projection instead of a separate activation
     # kernel.  Off by default: at 70B batch 1 the two dependent loads in front of the LDS store cost the
     # GEMM more (about 7 us) than the 4.8 us activation kernel they replace (26.05 vs 25.85 ms per token).

@@ -146,7 +146,13 @@ class RMSNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(hidden_size, dtype=dtype), requires_grad=False)
         self.eps = eps
 
-    def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None):
+    def forward(self, x, residual: Optional[torch.Tensor] = None):
+        """``x`` may be a projection's K-split partial sums (``layers.linear.PartialSums``): with a
+        residual they are summed by the same kernel that adds and normalises."""
+        if not isinstance(x, torch.Tensor):
+            if residual is not None:
+                return ops.reduce_add_rms_norm(x.slabs, residual, self.weight, self.eps)
+            x = x.materialize()
         if residual is None:
             return ops.rms_norm(x, self.weight, self.eps)
         return ops.fused_add_rms_norm(x, residual, self.weight, self.eps)

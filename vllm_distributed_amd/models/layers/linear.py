@@ -434,6 +434,16 @@ class RowParallelLinear(_LinearBase):
             y = tensor_model_parallel_all_reduce(y)
         return y
 
+    def forward_partials(self, x: torch.Tensor) -> Optional["PartialSums"]:
+        """The product left as the fp32 K-split slabs of the short-batch kernels (an unsharded dense
+        16-bit or AWQ layer, no bias, no adapter) for the add + RMSNorm that follows to sum; None when
+        the shape does not run split or the layer is not of that kind."""
+        if (self.tp > 1 or self.weight_scale is not None or self.lora is not None or self.bias is not None
+                or self.alpha is not None or x.dim() != 2 or not x.is_cuda):
+            return None
+        slabs = ops.w4a16_partials(x, self.qw, self.sz) if self.qw is not None else ops.linear_partials(x, self.weight)
+        return None if slabs is None else PartialSums(slabs, x.dtype)
+
     def forward_add(self, x: torch.Tensor, residual: torch.Tensor) -> bool:
         """``residual += x W^T`` in the GEMM's epilogue, for an unsharded dense 16-bit layer and a
         batch the large-batch kernel takes; False (nothing done) otherwise.  The add + RMSNorm that
@@ -457,6 +467,22 @@ class RowParallelLinear(_LinearBase):
         if reduce and self.reduce_results and self.tp > 1:
             y = tensor_model_parallel_all_reduce(y)
         return y
+
+
+class PartialSums:
+    """A projection's output as fp32 slabs ``[ks, T, H]`` whose sum over ``ks`` is the value.  Only an
+    ``RMSNorm`` called with a residual consumes it as is; everybody else asks for ``materialize()``."""
+    __slots__ = ("slabs", "dtype")
+
+    def __init__(self, slabs: torch.Tensor, dtype: torch.dtype):
+        self.slabs, self.dtype = slabs, dtype
+
+    @property
+    def shape(self):
+        return self.slabs.shape[1:]
+
+    def materialize(self) -> torch.Tensor:
+        return self.slabs.sum(0).to(self.dtype)
 
 
 def pad_vocab(vocab_size: int, tp: int, multiple: int = 64) -> int:

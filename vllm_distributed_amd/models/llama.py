@@ -107,16 +107,28 @@ class LlamaMLP(nn.Module):
     supports_residual = True
 
     def forward(self, x: torch.Tensor, reduce: bool = True, staged: bool = False,
-                residual: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
-        """With ``residual``: None is returned when the down projection added its product into it."""
+                residual: Optional[torch.Tensor] = None, partials: bool = False):
+        """With ``residual``: None is returned when the down projection added its product into it.
+        ``partials``: the caller's next step is an RMSNorm with a residual, which also takes the
+        projection's K-split partial sums (``PartialSums``)."""
         if self.act != "silu":
             return self.down_proj(ops.act_and_mul(self.gate_up_proj(x), self.act), reduce, staged)
         act = self.gate_up_proj.forward_silu(x)       # large batches: activation formed in the GEMM epilogue
         if act is not None:
             if residual is not None and self.down_proj.forward_add(act, residual):
                 return None
+            if partials and act.shape[0] <= 256:
+                part = self.down_proj.forward_partials(act)
+                if part is not None:
+                    return part
             return self.down_proj(act, reduce, staged)
-        return self.down_proj.forward_gated(self.gate_up_proj(x), reduce, staged)
+        gate_up = self.gate_up_proj(x)
+        if partials and gate_up.dim() == 2 and gate_up.shape[0] <= 256:
+            # short batches: the K-split slabs go to the next add + RMSNorm unreduced
+            act = ops.silu_and_mul(gate_up)
+            part = self.down_proj.forward_partials(act)
+            return part if part is not None else self.down_proj(act, reduce, staged)
+        return self.down_proj.forward_gated(gate_up, reduce, staged)
 
 
 class LlamaAttention(nn.Module):
@@ -155,8 +167,9 @@ class LlamaAttention(nn.Module):
                               layer_sliding_window(cfg, layer_idx), softcap=cfg.get("attn_logit_softcapping"))
 
     def forward(self, positions: torch.Tensor, hidden: torch.Tensor, reduce: bool = True,
-                staged: bool = False, residual: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
-        """With ``residual``: None is returned when the output projection added its product into it."""
+                staged: bool = False, residual: Optional[torch.Tensor] = None, partials: bool = False):
+        """With ``residual``: None is returned when the output projection added its product into it.
+        ``partials``: the output projection may return its K-split partial sums (``PartialSums``)."""
         qkv = self.qkv_proj(hidden)
         md = get_forward_context().attn_metadata
         if self.clip_qkv is not None and not self.qk_norm_full:
@@ -192,6 +205,10 @@ class LlamaAttention(nn.Module):
             out = self.attn.forward_cached(q)
         if residual is not None and self.o_proj.forward_add(out, residual):
             return None
+        if partials:
+            part = self.o_proj.forward_partials(out)
+            if part is not None:
+                return part
         return self.o_proj(out, reduce, staged)
 
 
@@ -203,6 +220,10 @@ class LlamaDecoderLayer(nn.Module):
         self.mlp = self._make_mlp(cfg, dtype)
         self.input_layernorm = RMSNorm(cfg["hidden_size"], eps, dtype)
         self.post_attention_layernorm = RMSNorm(cfg["hidden_size"], eps, dtype)
+        # both branches end in a projection whose output goes straight into an RMSNorm with the residual:
+        # they may hand over K-split partial sums (unsharded layers; see RowParallelLinear.forward_partials)
+        self._attn_partials = type(self.self_attn) is LlamaAttention
+        self._mlp_partials = type(self.mlp) is LlamaMLP
 
     def _make_attn(self, cfg: dict, layer_idx: int, dtype: torch.dtype, cos_sin: torch.Tensor) -> nn.Module:
         return LlamaAttention(cfg, layer_idx, dtype, cos_sin)
@@ -237,12 +258,17 @@ class LlamaDecoderLayer(nn.Module):
             hidden = self.input_layernorm(residual)
         else:
             hidden, residual = self.input_layernorm(hidden, residual)
-        hidden = self.self_attn(positions, hidden, residual=residual)
+        if self._attn_partials:
+            hidden = self.self_attn(positions, hidden, residual=residual, partials=True)
+        else:
+            hidden = self.self_attn(positions, hidden, residual=residual)
         if hidden is None:
             hidden = self.post_attention_layernorm(residual)
         else:
             hidden, residual = self.post_attention_layernorm(hidden, residual)
-        if getattr(self.mlp, "supports_residual", False):
+        if self._mlp_partials:
+            hidden = self.mlp(hidden, residual=residual, partials=True)
+        elif getattr(self.mlp, "supports_residual", False):
             hidden = self.mlp(hidden, residual=residual)
         else:
             hidden = self.mlp(hidden)
@@ -343,6 +369,8 @@ class LlamaForCausalLM(nn.Module):
         if not self.is_last:
             if hidden is None:                  # the last GEMM already added its product into the residual
                 hidden = torch.zeros_like(residual)
+            elif not isinstance(hidden, torch.Tensor):
+                hidden = hidden.materialize()   # K-split partial sums do not cross a stage boundary
             return IntermediateTensors(hidden, residual)
         if hidden is None:
             return self.norm(residual)

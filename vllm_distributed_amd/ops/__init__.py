@@ -67,6 +67,38 @@ def fused_add_rms_norm(x, residual, weight, eps) -> Tuple[torch.Tensor, torch.Te
     return torch_ref.fused_add_rms_norm(x, residual, weight, eps)
 
 
+def reduce_add_rms_norm(partial, residual, weight, eps) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``fused_add_rms_norm`` whose first operand arrives as fp32 K-split slabs ``[ks, T, H]``."""
+    if _use_hip(residual):
+        return _hip.reduce_add_rms_norm(partial, residual, weight, eps)
+    return torch_ref.fused_add_rms_norm(partial.sum(0).to(residual.dtype), residual, weight, eps)
+
+
+def linear_partials(x, weight):
+    """``x @ weight^T`` left as the fp32 K-split slabs ``[ks, M, N]`` of the short-batch kernels, for a
+    consumer that reduces them itself (the add + RMSNorm that follows a row-parallel projection); None
+    where the shape runs unsplit or on another kernel."""
+    if not (x.is_cuda and x.dim() == 2 and 0 < x.shape[0] <= 256 and envs.VDAMD_SKINNY_GEMM
+            and envs.VDAMD_FUSED_REDUCE_NORM and _use_hip(x)):
+        return None
+    m, n, k = x.shape[0], weight.shape[0], weight.shape[1]
+    if _hip.mid_profitable(m, n, k) and _hip.mid_supported(x, weight):
+        return _hip.mid_gemm(x, weight, partials=True)
+    if m <= 128 and _hip.skinny_profitable(m, n, k) and _hip.skinny_supported(x, weight):
+        return _hip.skinny_gemm_partials(x, weight)
+    return None
+
+
+def w4a16_partials(x, qw, sz):
+    """The fused 4-bit GEMM left as its fp32 K-split slabs (None: unsplit shape or a batch it does not take)."""
+    if not (x.dim() == 2 and _use_hip(x) and x.dtype in (torch.bfloat16, torch.float16)
+            and 0 < x.shape[0] <= _hip.W4_MAX_FUSED_M and envs.VDAMD_FUSED_REDUCE_NORM):
+        return None
+    if x.stride(1) != 1 or x.stride(0) % 8 or x.data_ptr() % 16:
+        x = x.contiguous()
+    return _hip.w4a16_gemm(x, qw, sz, partials=True)
+
+
 def layer_norm(x, weight, bias, eps):
     if _use_hip(x):
         return _hip.layer_norm(x, weight, bias, eps)

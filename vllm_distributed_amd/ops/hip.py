@@ -33,6 +33,7 @@ def load() -> ctypes.CDLL:
     sigs = {
         "vdamd_rms_norm": [P, P, P, P, F, I, I, L, L, I, P],
         "vdamd_layer_norm": [P, P, P, P, F, I, I, I, P],
+        "vdamd_reduce_add_rms_norm": [P, P, I, P, P, F, I, I, L, I, P],
         "vdamd_silu_and_mul": [P, P, L, I, I, P],
         "vdamd_embedding": [P, P, P, I, I, I, I, I, P],
         "vdamd_mid_gemm": [P, L, P, L, P, L, P, I, I, I, I, I, I, I, I, P],
@@ -122,6 +123,20 @@ def fused_add_rms_norm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Te
     _check(_LIB.vdamd_rms_norm(x.data_ptr(), x.data_ptr(), residual.data_ptr(), weight.data_ptr(), eps,
                                x.shape[0], h, h, h, _dt(x), _stream()), "fused_add_rms_norm")
     return x, residual
+
+
+def reduce_add_rms_norm(partial: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor,
+                        eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``normed = RMSNorm(sum_k partial[k] + residual) * weight`` with ``residual`` updated in place to the
+    sum: the K-split slabs ``[ks, T, H]`` (fp32) of the GEMM that fed the norm are reduced by the norm."""
+    ks, t, h = partial.shape
+    assert partial.dtype == torch.float32 and partial.is_contiguous() and residual.shape == (t, h)
+    assert residual.is_contiguous() and _half(residual) and weight.dtype == residual.dtype
+    out = torch.empty_like(residual)
+    _check(_LIB.vdamd_reduce_add_rms_norm(out.data_ptr(), partial.data_ptr(), ks, residual.data_ptr(),
+                                          weight.data_ptr(), float(eps), t, h, h, _dt(residual), _stream()),
+           "reduce_add_rms_norm")
+    return out, residual
 
 
 def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], eps: float) -> torch.Tensor:
@@ -407,25 +422,29 @@ def w4_dequant(qw: torch.Tensor, sz: torch.Tensor, out: Optional[torch.Tensor] =
 
 
 def w4a16_gemm(x: torch.Tensor, qw: torch.Tensor, sz: torch.Tensor, variant: Optional[int] = None,
-               ksplit: Optional[int] = None) -> torch.Tensor:
-    """``x [M, K]`` (bf16/fp16, rows 16-byte aligned) times the packed weights."""
+               ksplit: Optional[int] = None, partials: bool = False) -> Optional[torch.Tensor]:
+    """``x [M, K]`` (bf16/fp16, rows 16-byte aligned) times the packed weights.  ``partials``: the fp32
+    K-split slabs ``[ksplit, M, N]`` instead of their sum, for a consumer that adds them up while it
+    reads them; None when the shape runs unsplit."""
     n, k, g = _w4_dims(qw, sz)
     assert x.dim() == 2 and x.shape[1] == k and x.dtype == sz.dtype and x.stride(1) == 1
     assert x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
     m = x.shape[0]
-    out = torch.empty((m, n), dtype=x.dtype, device=x.device)
-    if m == 0:
-        return out
     if variant is None:
         variant = w4_choose_variant(m, n, k)
     if ksplit is None:
         ksplit = w4_choose_ksplit(m, n, k, variant)
+    if partials and (ksplit <= 1 or m == 0):
+        return None
+    out = None if partials else torch.empty((m, n), dtype=x.dtype, device=x.device)
+    if m == 0:
+        return out
     assert 1 <= ksplit <= k // 128
-    partial = torch.empty(ksplit * m * n, dtype=torch.float32, device=x.device) if ksplit > 1 else None
-    _check(_LIB.vdamd_w4a16_gemm(out.data_ptr(), n, x.data_ptr(), x.stride(0), qw.data_ptr(), sz.data_ptr(),
-                                 None if partial is None else partial.data_ptr(), m, n, k, g, ksplit,
+    partial = torch.empty((ksplit, m, n), dtype=torch.float32, device=x.device) if ksplit > 1 else None
+    _check(_LIB.vdamd_w4a16_gemm(None if out is None else out.data_ptr(), n, x.data_ptr(), x.stride(0), qw.data_ptr(),
+                                 sz.data_ptr(), None if partial is None else partial.data_ptr(), m, n, k, g, ksplit,
                                  variant, _dt(x), _stream()), "w4a16_gemm")
-    return out
+    return partial if partials else out
 
 
 # ------------------------------------------------------------ NVFP4 linears
@@ -682,8 +701,10 @@ def mid_profitable(m: int, n: int, k: int) -> bool:
 
 
 def mid_gemm(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, ksplit: Optional[int] = None,
-             bm: Optional[int] = None, bn: Optional[int] = None, variant: Optional[int] = None) -> torch.Tensor:
-    """``x [M<=512, K] @ w [N, K]^T`` with W streamed once and K split over the chip."""
+             bm: Optional[int] = None, bn: Optional[int] = None, variant: Optional[int] = None,
+             partials: bool = False) -> Optional[torch.Tensor]:
+    """``x [M<=512, K] @ w [N, K]^T`` with W streamed once and K split over the chip.  ``partials``: the
+    fp32 K-split slabs ``[ksplit, M, N]`` instead of their sum (None when the shape runs unsplit)."""
     assert mid_supported(x, w), (x.shape, x.stride(), w.shape, w.stride(), x.dtype)
     m, k = x.shape
     n = w.shape[0]
@@ -696,6 +717,13 @@ def mid_gemm(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = Non
         variant = MID_VARIANT
     if variant < 0:
         variant = 1 if bm == 256 and bn <= 256 else 0
+    if partials:
+        if ksplit <= 1:
+            return None
+        partial = torch.empty((ksplit, m, n), dtype=torch.float32, device=x.device)
+        _check(_LIB.vdamd_mid_gemm(None, n, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), partial.data_ptr(),
+                                   m, n, k, ksplit, bm, bn, variant, _dt(x), _stream()), "mid_gemm (partial sums)")
+        return partial
     if out is None:
         out = torch.empty((m, n), dtype=x.dtype, device=x.device)
     assert out.shape == (m, n) and out.dtype == x.dtype and out.stride(1) == 1 and out.data_ptr() % 8 == 0
