@@ -20,6 +20,15 @@ QWEN3_SMALL = dict(hidden_size=512, num_attention_heads=4, num_key_value_heads=2
                    vocab_size=1024, max_position_embeddings=512)
 
 
+# multi-head latent attention is served by expanding the latent to a padded per-head size: whatever that is
+MLA_EXPANDED = {"deepseek-v3-tiny"}
+# dense families (no router whose near-ties bf16 can flip): the GPU run must track the fp32 reference closely
+TIGHT = {"llama-tiny", "opt-tiny", "phi3-tiny", "gemma-tiny", "granite-tiny", "gpt2-tiny", "gpt-neox-tiny",
+         "starcoder2-tiny", "mistral-window-tiny", "phi-tiny", "phi2-tiny", "glm-tiny", "helium-tiny", "smollm3-tiny",
+         "glm4-tiny", "olmo2-tiny", "exaone4-tiny", "nemotron-tiny", "stablelm-tiny", "arcee-tiny", "falcon-tiny",
+         "gptj-tiny", "gpt-bigcode-tiny"}
+
+
 @pytest.mark.parametrize("model", ["llama-tiny", "opt-tiny", "qwen3-moe-tiny", "mixtral-tiny", "phi3-tiny",
                                    "qwen3-coder-480b-a35b", "gemma-tiny", "granite-tiny", "gpt2-tiny",
                                    "gpt-neox-tiny", "starcoder2-tiny", "mistral-window-tiny", "qwen2-moe-tiny",
@@ -33,14 +42,26 @@ def test_model_family_on_gpu_tracks_cpu_reference(model, tmp_path):
     mc = ModelConfig(model=model, dtype="float32", load_format="dummy", hf_overrides=overrides)
     save_dummy_checkpoint(mc, str(tmp_path))
     (tmp_path / "config.json").write_text(json.dumps(mc.hf_config))
+    from vllm_distributed_amd import ops
     outs = {}
+    head_dim = mc.head_dim
     for dev in ("cuda", "cpu"):
         kw = dict(dtype="bfloat16", gpu_memory_utilization=0.3) if dev == "cuda" else dict(dtype="float32", device="cpu")
+        before = dict(ops.attention_calls)
         llm = LLM(model=str(tmp_path), max_model_len=256, num_gpu_blocks_override=64, max_num_seqs=8, **kw)
         if dev == "cuda" and overrides:
             runner = llm.engine.core.executor.driver.worker.model_runner
             assert runner.graphs, "decode steps of the cut-down Qwen3-Coder must be hipGraph-captured"
         outs[dev] = llm.generate(PROMPTS, SamplingParams(temperature=0.0, max_tokens=3, ignore_eos=True, logprobs=20))
+        if dev == "cuda":
+            # the comparison below must be about the HIP attention kernels wherever they take the head size;
+            # a family that silently ran the PyTorch reference on the GPU would pass it for the wrong reason
+            ran_hip = ops.attention_calls["hip"] - before["hip"]
+            ran_ref = ops.attention_calls["reference_on_gpu"] - before["reference_on_gpu"]
+            if ops.hip_supports_head_dim(head_dim) and model not in MLA_EXPANDED:
+                assert ran_hip > 0 and ran_ref == 0, (model, head_dim, ran_hip, ran_ref)
+            else:
+                assert ran_ref > 0 or ran_hip > 0
         llm.shutdown()
         pstate.destroy_model_parallel()
     for a, b in zip(outs["cuda"], outs["cpu"]):
@@ -49,7 +70,7 @@ def test_model_family_on_gpu_tracks_cpu_reference(model, tmp_path):
             common = set(la) & set(lb)
             assert len(common) >= 8, (model, step, sorted(la), sorted(lb))
             # bf16 router logits can flip a near-tied expert choice on the MoE models: allow for it
-            assert max(abs(la[t] - lb[t]) for t in common) < 0.3, (model, step)
+            assert max(abs(la[t] - lb[t]) for t in common) < (0.15 if model in TIGHT else 0.3), (model, step)
 
 
 def test_window_released_blocks_are_never_read_by_the_kernels():

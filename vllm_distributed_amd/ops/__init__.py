@@ -40,6 +40,29 @@ def hip_supports_head_dim(d: int) -> bool:
     return hip_available() and _hip.supports_head_dim(d)
 
 
+# How often attention ran on the HIP kernels and how often a GPU tensor took the PyTorch reference instead
+# (a head size the kernels are not built for).  Workers report it in ``get_stats``; the reference path is
+# announced once per head size, loudly: numbers measured on it say nothing about the kernels.
+attention_calls = {"hip": 0, "reference_on_gpu": 0}
+_announced_fallbacks = set()
+
+
+def _note_attention(q, on_hip: bool) -> None:
+    if on_hip:
+        attention_calls["hip"] += 1
+        return
+    if not q.is_cuda:
+        return
+    attention_calls["reference_on_gpu"] += 1
+    d = int(q.shape[-1])
+    if d not in _announced_fallbacks:
+        _announced_fallbacks.add(d)
+        from ..logger import init_logger
+        init_logger(__name__).warning(
+            "attention with head size %d runs on the PyTorch REFERENCE path on the GPU (the HIP kernels are built for "
+            "%s): correct, but slow and not hipGraph-friendly", d, sorted(_hip.HEAD_DIMS) if _hip is not None else "?")
+
+
 def _use_hip(t: torch.Tensor) -> bool:
     if not t.is_cuda:
         return False
@@ -140,7 +163,9 @@ def rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping
 def paged_attention(q, k_cache, v_cache, block_table, query_start_loc, seq_lens, scale,
                     max_query_len: int = 0, max_seq_len: int = 0, out=None, kv_scales=None, window: int = 0,
                     softcap: float = 0.0):
-    if _use_hip(q) and _hip.supports_head_dim(q.shape[-1]):
+    on_hip = _use_hip(q) and _hip.supports_head_dim(q.shape[-1])
+    _note_attention(q, on_hip)
+    if on_hip:
         return _hip.paged_attention_prefill(q, k_cache, v_cache, block_table, query_start_loc,
                                             seq_lens, scale, max_query_len, max_seq_len, out, kv_scales, window,
                                             softcap)
@@ -155,7 +180,9 @@ def paged_attention(q, k_cache, v_cache, block_table, query_start_loc, seq_lens,
 def paged_attention_decode(q, k_cache, v_cache, block_table, seq_lens, scale,
                            max_seq_len: int = 0, out=None, workspace=None, kv_scales=None, window: int = 0,
                            softcap: float = 0.0):
-    if _use_hip(q) and _hip.supports_head_dim(q.shape[-1]):
+    on_hip = _use_hip(q) and _hip.supports_head_dim(q.shape[-1])
+    _note_attention(q, on_hip)
+    if on_hip:
         return _hip.paged_attention_decode(q, k_cache, v_cache, block_table, seq_lens, scale,
                                            max_seq_len, out, workspace, kv_scales=kv_scales, window=window,
                                            softcap=softcap)

@@ -86,9 +86,12 @@ def _dt(t: torch.Tensor) -> int:
         raise TypeError(f"unsupported dtype {t.dtype}") from None
 
 
+HEAD_DIMS = (64, 96, 128, 256)
+
+
 def supports_head_dim(d: int) -> bool:
     """Head sizes the attention kernels are instantiated for (96: Phi-3-mini, 256: Gemma)."""
-    return d in (64, 96, 128, 256)
+    return d in HEAD_DIMS
 
 
 def _half(t: torch.Tensor) -> bool:

@@ -181,6 +181,8 @@ class Worker:
         if self.device is not None and self.device.type == "cuda":
             free, total = torch.cuda.mem_get_info()
             d.update(mem_free=free, mem_total=total, mem_torch=torch.cuda.memory_allocated())
+        from .. import ops
+        d["attention_calls"] = dict(ops.attention_calls)
         mr = self.model_runner
         if mr is not None:
             d.update(hip_graph_sizes=list(mr.graph_sizes), hip_graph_fallback=mr.graph_fallback_reason,
