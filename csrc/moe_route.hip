@@ -327,6 +327,70 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(T* __restrict__ out, l
   }
 }
 
+// One workgroup per token: the weighted sum of its k expert rows (rounded to T, as moe_combine writes it),
+// plus the residual (updated in place), then RMSNorm of the sum.  COMBINE_NORM_ITERS * 8 * blockDim >= H.
+constexpr int COMBINE_NORM_ITERS = 4;
+template <typename T>
+__global__ void moe_combine_add_rms_norm_kernel(T* __restrict__ out, long out_stride, const T* __restrict__ y,
+                                                long y_stride, const float* __restrict__ topw,
+                                                const int* __restrict__ topi, const int* __restrict__ inv, int k, int H,
+                                                int expert_start, int local_experts, T* __restrict__ residual,
+                                                const T* __restrict__ gamma, float eps) {
+  using V = typename Vec8<T>::type;
+  const int t = blockIdx.x;
+  __shared__ float w[TOPK_MAX_K];
+  __shared__ int pos[TOPK_MAX_K];
+  __shared__ float red[17];
+  if (threadIdx.x < k) {
+    const int e = topi[(long)t * k + threadIdx.x];
+    const bool local = local_experts < 0 || (e >= expert_start && e < expert_start + local_experts);
+    w[threadIdx.x] = local ? topw[(long)t * k + threadIdx.x] : 0.f;
+    pos[threadIdx.x] = local ? inv[(long)t * k + threadIdx.x] : -1;
+  }
+  __syncthreads();
+  T* rr = residual + (long)t * H;
+  V vals[COMBINE_NORM_ITERS];
+  float ss = 0.f;
+  const int nvec = H >> 3;
+#pragma unroll
+  for (int it = 0; it < COMBINE_NORM_ITERS; ++it) {
+    const int i = threadIdx.x + it * blockDim.x;
+    if (i < nvec) {
+      const V r = ld8<T>(rr + 8 * i);
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < k; ++j) {
+        if (pos[j] < 0) continue;
+        const V v = ld8<T>(y + (long)pos[j] * y_stride + 8 * i);
+        const float wj = w[j];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] += wj * (float)v[c];
+      }
+      V v;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        v[c] = (T)((float)(T)acc[c] + (float)r[c]);
+        const float f = (float)v[c];
+        ss += f * f;
+      }
+      st8<T>(rr + 8 * i, v);
+      vals[it] = v;
+    }
+  }
+  ss = block_sum(ss, red);
+  const float rinv = rsqrtf(ss / (float)H + eps);
+#pragma unroll
+  for (int it = 0; it < COMBINE_NORM_ITERS; ++it) {
+    const int i = threadIdx.x + it * blockDim.x;
+    if (i < nvec) {
+      const V g = ld8<T>(gamma + 8 * i);
+      V o;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) o[c] = (T)((float)vals[it][c] * rinv * (float)g[c]);
+      st8<T>(out + (long)t * out_stride + 8 * i, o);
+    }
+  }
+}
+
 }  // namespace
 
 VDAMD_API int vdamd_moe_topk(const void* logits, long stride, float* topw, int* topi, int tokens, int E, int k,
@@ -407,6 +471,31 @@ VDAMD_API int vdamd_moe_route_small(const void* logits, long lstride, int tokens
     return -2;
   }
 #undef VDAMD_ROUTE_SMALL
+  HIP_LAUNCH_CHECK();
+  return 0;
+}
+
+// residual[t] += sum_j w[t][j] * y[slot (t, j)] (in place), out[t] = RMSNorm(residual[t]) * gamma
+VDAMD_API int vdamd_moe_combine_add_rms_norm(void* out, long out_stride, const void* y, long y_stride,
+                                             const float* topw, const int* topi, const int* inv, int tokens, int k,
+                                             int H, int expert_start, int local_experts, void* residual,
+                                             const void* gamma, float eps, int dtype, hipStream_t s) {
+  if (tokens <= 0) return 0;
+  if (H % 8 || H > 8 * 1024 * COMBINE_NORM_ITERS || k < 1 || k > TOPK_MAX_K || residual == nullptr) return -1;
+  int threads = ((H >> 3) + 63) / 64 * 64;            // one pass where the row fits: these launches are latency-bound
+  if (tokens > 64) threads = (threads / COMBINE_NORM_ITERS + 63) / 64 * 64;
+  if (threads > 1024) threads = 1024;
+  if (threads < 64) threads = 64;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL((moe_combine_add_rms_norm_kernel<bf16_t>), dim3(tokens), dim3(threads), 0, s, (bf16_t*)out,
+                       out_stride, (const bf16_t*)y, y_stride, topw, topi, inv, k, H, expert_start, local_experts,
+                       (bf16_t*)residual, (const bf16_t*)gamma, eps);
+  else if (dtype == DT_F16)
+    hipLaunchKernelGGL((moe_combine_add_rms_norm_kernel<f16_t>), dim3(tokens), dim3(threads), 0, s, (f16_t*)out,
+                       out_stride, (const f16_t*)y, y_stride, topw, topi, inv, k, H, expert_start, local_experts,
+                       (f16_t*)residual, (const f16_t*)gamma, eps);
+  else
+    return -2;
   HIP_LAUNCH_CHECK();
   return 0;
 }

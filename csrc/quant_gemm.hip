@@ -79,7 +79,9 @@ __global__ __launch_bounds__(256) void w4a16_gemm_kernel(
     const T* __restrict__ x, long x_stride, const uint32_t* __restrict__ qw, const T* __restrict__ sz,
     T* __restrict__ out, long out_stride, float* __restrict__ partial, int M, int N, int K,
     int kb_per_group, int ksplit, const float* __restrict__ alpha, const int* __restrict__ tiles,
-    long qw_group_stride, long sz_group_stride) {
+    long qw_group_stride, long sz_group_stride, int up_off = 0) {
+  // up_off > 0: x is [M][2K'] = [gate | up] with the up half `up_off` elements further on, and the left
+  // operand is silu(gate) * up, formed as the fragments are loaded (no activation kernel in between)
   using V8 = typename Vec8<T>::type;
   constexpr bool PREFETCH_X = MT <= 2;
   int m_base = blockIdx.z * (16 * MT);
@@ -143,6 +145,21 @@ __global__ __launch_bounds__(256) void w4a16_gemm_kernel(
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int s = 0; s < 4; ++s) bx[mt][s] = ld8(xrow[mt] + (kb << 7) + 8 * s);
+    if (up_off > 0) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const V8 up = ld8(xrow[mt] + up_off + (kb << 7) + 8 * s);
+          V8 a;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float gt = (float)bx[mt][s][j];
+            a[j] = (T)(gt / (1.f + __expf(-gt)) * (float)up[j]);
+          }
+          bx[mt][s] = a;
+        }
+    }
   };
 
   u32x4 wc[W4_NTW], wn[W4_NTW];
@@ -639,13 +656,15 @@ VDAMD_API int vdamd_w4_dequant(void* out, const void* qw, const void* sz, int N,
 template <typename T, int FMT>
 static int launch_w4_grouped(void* out, long os, const void* x, long xs, const void* qw, const void* sz, long qgs,
                              long sgs, const float* alpha, const int* tiles, int num_tiles, int tile_rows, int N,
-                             int K, int G, hipStream_t st) {
+                             int K, int G, hipStream_t st, int up_off = 0) {
+  if (up_off > 0 && tile_rows > 32) return -6;      // only the register-operand variant forms the activation
   if (tile_rows <= 32) {
     // few rows per group: 64 output rows per workgroup, the four waves split K
     dim3 grid((N / 16 + W4_NTW - 1) / W4_NTW, 1, num_tiles);
 #define W4G0(MT_)                                                                                               \
   w4a16_gemm_kernel<T, MT_, FMT><<<grid, 256, 0, st>>>((const T*)x, xs, (const uint32_t*)qw, (const T*)sz, (T*)out, \
-                                                    os, nullptr, tile_rows, N, K, G / 128, 1, alpha, tiles, qgs, sgs)
+                                                    os, nullptr, tile_rows, N, K, G / 128, 1, alpha, tiles, qgs, sgs, \
+                                                    up_off)
     if (tile_rows <= 16) W4G0(1); else W4G0(2);
 #undef W4G0
     HIP_LAUNCH_CHECK();
@@ -668,20 +687,22 @@ static int launch_w4_grouped(void* out, long os, const void* x, long xs, const v
 // Grouped form for mixture-of-experts (see vdamd_skinny_gemm_grouped): group g's
 // packed weights start at qw + g * qw_group_stride words, sz + g * sz_group_stride
 // elements; tile_rows is 16, 32, 48 or 64.
+// up_off > 0 (tile_rows <= 32 only): x rows are [gate | up] with the up half up_off elements after the
+// gate half, and the product is taken with silu(gate) * up.
 VDAMD_API int vdamd_w4a16_gemm_grouped(void* out, long out_stride, const void* x, long x_stride, const void* qw,
                                        const void* sz, long qw_group_stride, long sz_group_stride,
                                        const int* tiles, int num_tiles, int tile_rows, int N, int K, int G,
-                                       int dtype, void* stream) {
+                                       int dtype, int up_off, void* stream) {
   if (num_tiles <= 0) return 0;
   if (tile_rows <= 0 || tile_rows > 64 || tile_rows % 16 || tiles == nullptr) return -1;
-  if (K % 128 || N % 16 || G % 128 || K % G) return -1;
+  if (K % 128 || N % 16 || G % 128 || K % G || up_off < 0 || up_off % 8) return -1;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16)
     return launch_w4_grouped<bf16_t, W4_INT>(out, out_stride, x, x_stride, qw, sz, qw_group_stride, sz_group_stride,
-                                             nullptr, tiles, num_tiles, tile_rows, N, K, G, st);
+                                             nullptr, tiles, num_tiles, tile_rows, N, K, G, st, up_off);
   if (dtype == DT_F16)
     return launch_w4_grouped<f16_t, W4_INT>(out, out_stride, x, x_stride, qw, sz, qw_group_stride, sz_group_stride,
-                                            nullptr, tiles, num_tiles, tile_rows, N, K, G, st);
+                                            nullptr, tiles, num_tiles, tile_rows, N, K, G, st, up_off);
   return -3;
 }
 

@@ -34,16 +34,45 @@ __device__ __forceinline__ uint2 pack_fp8x8(const float (&f)[8]) {
   return make_uint2((unsigned)lo, (unsigned)hi);
 }
 
+// sum over the slabs of 8 consecutive fp32 partial sums, rounded to T as the GEMM's own reduction would
+template <typename T>
+__device__ __forceinline__ typename Vec8<T>::type sum8(const float* __restrict__ p, int nslabs, long slab_stride) {
+  f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = a;
+  int s = 0;
+  for (; s + 4 <= nslabs; s += 4) {               // four slabs' loads in flight at a time
+    f32x4 la[4], lb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      la[u] = *reinterpret_cast<const f32x4*>(p + (s + u) * slab_stride);
+      lb[u] = *reinterpret_cast<const f32x4*>(p + (s + u) * slab_stride + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a += la[u]; b += lb[u]; }
+  }
+  for (; s < nslabs; ++s) {
+    a += *reinterpret_cast<const f32x4*>(p + s * slab_stride);
+    b += *reinterpret_cast<const f32x4*>(p + s * slab_stride + 4);
+  }
+  typename Vec8<T>::type v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { v[j] = (T)a[j]; v[j + 4] = (T)b[j]; }
+  return v;
+}
+
 // KV8: the cache holds one e4m3 byte per element (same layouts); values are divided by the
 // KV head's scale before they are narrowed.
-template <typename T, bool WRITE_CACHE, bool ROTATE, bool KV8>
+// SLABS (with WRITE_CACHE and ROTATE): q, k and v arrive as the fp32 K-split partial sums
+// part[nslabs][T][(Hq + 2 Hkv) D] of the projection that produced them; the rotated q goes to `q`
+// (a buffer of its own), k and v only to the cache.
+template <typename T, bool WRITE_CACHE, bool ROTATE, bool KV8, bool SLABS = false>
 __global__ void rope_cache_kernel(const int* __restrict__ positions, T* __restrict__ q, T* __restrict__ k,
                                   const T* __restrict__ v, long q_stride, long k_stride, long v_stride,
                                   const float* __restrict__ cos_sin, void* __restrict__ k_cache_v,
                                   void* __restrict__ v_cache_v, const int* __restrict__ slot_mapping, int Hq, int Hkv,
                                   int D, int block_size, int T_tokens, const T* __restrict__ q_norm_w,
                                   const T* __restrict__ k_norm_w, float norm_eps,
-                                  const float* __restrict__ k_scales, const float* __restrict__ v_scales) {
+                                  const float* __restrict__ k_scales, const float* __restrict__ v_scales,
+                                  const float* __restrict__ part = nullptr, int nslabs = 0, long slab_stride = 0) {
   T* k_cache = reinterpret_cast<T*>(k_cache_v);
   T* v_cache = reinterpret_cast<T*>(v_cache_v);
   using V = typename Vec8<T>::type;
@@ -68,8 +97,15 @@ __global__ void rope_cache_kernel(const int* __restrict__ positions, T* __restri
       const int it = is_q ? item : item - q_items;
       const int h = it / cpp, c = it - h * cpp;
       T* base = is_q ? q + t * q_stride + (long)h * D : k + t * k_stride + (long)h * D;
-      V x1 = ld8<T>(base + 8 * c);
-      V x2 = ld8<T>(base + half + 8 * c);
+      V x1, x2;
+      if constexpr (SLABS) {
+        const float* pb = part + t * (long)(Hq + 2 * Hkv) * D + (long)(is_q ? h : Hq + h) * D;
+        x1 = sum8<T>(pb + 8 * c, nslabs, slab_stride);
+        x2 = sum8<T>(pb + half + 8 * c, nslabs, slab_stride);
+      } else {
+        x1 = ld8<T>(base + 8 * c);
+        x2 = ld8<T>(base + half + 8 * c);
+      }
       V o1 = x1, o2 = x2;
       float f1[8], f2[8];
 #pragma unroll
@@ -125,10 +161,19 @@ __global__ void rope_cache_kernel(const int* __restrict__ positions, T* __restri
       const int cpd = D >> 3;
       const int h = it / cpd, c = it - h * cpd;
       // this thread's head-dim indices are c + cpd*j: the head's cpd lanes store adjacent 16-byte groups
-      const T* src = v + t * v_stride + (long)h * D + c;
+      // (from slabs: 8c + j, so that the partial sums are read as two 16-byte vectors per slab)
       T x[8];
+      const int d0 = SLABS ? 8 * c : c, dstep = SLABS ? 1 : cpd;
+      if constexpr (SLABS) {
+        const V xv = sum8<T>(part + t * (long)(Hq + 2 * Hkv) * D + (long)(Hq + Hkv + h) * D + 8 * c, nslabs,
+                             slab_stride);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) x[j] = src[j * cpd];
+        for (int j = 0; j < 8; ++j) x[j] = xv[j];
+      } else {
+        const T* src = v + t * v_stride + (long)h * D + c;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = src[j * cpd];
+      }
       // element index of head-dim row d: 16-row slab d/16, key group off/8, row d%16, key off%8
       const long head0 = (blk * Hkv + h) * (long)D * block_size + (off >> 3) * 128 + (off & 7);
       auto at = [&](int d) { return head0 + (long)(d >> 4) * (block_size * 16) + (d & 15) * 8; };
@@ -141,10 +186,10 @@ __global__ void rope_cache_kernel(const int* __restrict__ positions, T* __restri
         uint8_t* dst = reinterpret_cast<uint8_t*>(v_cache_v);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          dst[at(c + j * cpd)] = (uint8_t)(((j < 4 ? pk.x : pk.y) >> (8 * (j & 3))) & 0xFF);
+          dst[at(d0 + j * dstep)] = (uint8_t)(((j < 4 ? pk.x : pk.y) >> (8 * (j & 3))) & 0xFF);
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v_cache[at(c + j * cpd)] = x[j];
+        for (int j = 0; j < 8; ++j) v_cache[at(d0 + j * dstep)] = x[j];
       }
     }
   }
@@ -154,7 +199,8 @@ template <typename T>
 int launch(const int* positions, void* q, void* k, const void* v, long qs, long ks, long vs, const float* cos_sin,
            void* k_cache, void* v_cache, const int* slot_mapping, int T_tokens, int Hq, int Hkv, int D,
            int block_size, int mode, const void* qnw, const void* knw, float eps, int kv_fp8,
-           const float* k_scales, const float* v_scales, hipStream_t s) {
+           const float* k_scales, const float* v_scales, hipStream_t s, const float* part = nullptr,
+           int nslabs = 0) {
   // mode 0 and 2 write the cache (v items exist), mode 1 rotates only
   const long items = Hq * (D >> 4) + Hkv * (D >> 4) + (mode == 1 ? 0 : Hkv * (D >> 3));
   const long total = items * T_tokens;
@@ -164,7 +210,16 @@ int launch(const int* positions, void* q, void* k, const void* v, long qs, long 
   hipLaunchKernelGGL((rope_cache_kernel<T, WC, ROT, K8>), dim3(blocks), dim3(threads), 0, s, positions, (T*)q,  \
                      (T*)k, (const T*)v, qs, ks, vs, cos_sin, k_cache, v_cache, slot_mapping, Hq, Hkv,          \
                      D, block_size, T_tokens, (const T*)qnw, (const T*)knw, eps, k_scales, v_scales)
-  if (mode == 1) L(false, true, false);  // rotate q,k in place only
+  if (part != nullptr) {                 // rotate + cache from K-split partial sums
+    const long slab_stride = (long)T_tokens * (Hq + 2 * Hkv) * D;
+#define LS(K8)                                                                                                  \
+  hipLaunchKernelGGL((rope_cache_kernel<T, true, true, K8, true>), dim3(blocks), dim3(threads), 0, s, positions, \
+                     (T*)q, (T*)nullptr, (const T*)nullptr, qs, 0L, 0L, cos_sin, k_cache, v_cache, slot_mapping, \
+                     Hq, Hkv, D, block_size, T_tokens, (const T*)qnw, (const T*)knw, eps, k_scales, v_scales,    \
+                     part, nslabs, slab_stride)
+    if (kv_fp8) LS(true); else LS(false);
+#undef LS
+  } else if (mode == 1) L(false, true, false);  // rotate q,k in place only
   else if (mode == 0) {                  // rotate q,k + write k,v to cache
     if (kv_fp8) L(true, true, true); else L(true, true, false);
   } else {                               // cache write only (k,v already final)
@@ -197,5 +252,27 @@ VDAMD_API int vdamd_rope_cache(const int* positions, void* q, void* k, const voi
     return launch<f16_t>(positions, q, k, v, q_stride, k_stride, v_stride, cos_sin, k_cache, v_cache,
                          slot_mapping, T, Hq, Hkv, D, block_size, mode, q_norm_w, k_norm_w, norm_eps, kv_fp8,
                          k_scales, v_scales, s);
+  return -2;
+}
+
+// vdamd_rope_cache (mode 0) reading q, k and v as fp32 K-split partial sums part[nslabs][T][(Hq + 2 Hkv) D]
+// (contiguous) and writing the rotated q to q_out[T][q_stride]; k and v go to the cache only.
+VDAMD_API int vdamd_rope_cache_slabs(const int* positions, const float* part, int nslabs, void* q_out, long q_stride,
+                                     const float* cos_sin, void* k_cache, void* v_cache, const int* slot_mapping,
+                                     int T, int Hq, int Hkv, int D, int block_size, const void* q_norm_w,
+                                     const void* k_norm_w, float norm_eps, int dtype, int kv_fp8,
+                                     const float* k_scales, const float* v_scales, hipStream_t s) {
+  if (T == 0) return 0;
+  if (D % 16 != 0 || nslabs < 1 || part == nullptr || q_out == nullptr) return -1;
+  if ((q_norm_w == nullptr) != (k_norm_w == nullptr)) return -1;
+  if (q_norm_w != nullptr && (((D / 16) & (D / 16 - 1)) != 0 || D / 16 > 64)) return -1;
+  if (dtype == DT_BF16)
+    return launch<bf16_t>(positions, q_out, nullptr, nullptr, q_stride, 0, 0, cos_sin, k_cache, v_cache, slot_mapping,
+                          T, Hq, Hkv, D, block_size, 0, q_norm_w, k_norm_w, norm_eps, kv_fp8, k_scales, v_scales, s,
+                          part, nslabs);
+  if (dtype == DT_F16)
+    return launch<f16_t>(positions, q_out, nullptr, nullptr, q_stride, 0, 0, cos_sin, k_cache, v_cache, slot_mapping,
+                         T, Hq, Hkv, D, block_size, 0, q_norm_w, k_norm_w, norm_eps, kv_fp8, k_scales, v_scales, s,
+                         part, nslabs);
   return -2;
 }

@@ -109,6 +109,47 @@ def test_rope_and_cache_with_per_head_rms_norm(hq, hkv, d, bs):
     torch.testing.assert_close(vc.float(), vc_ref, rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("dtype,kv8", [(torch.bfloat16, False), (torch.float16, False), (torch.bfloat16, True)])
+@pytest.mark.parametrize("hq,hkv,d,bs,ks,norm", [(32, 8, 128, 64, 4, False), (12, 1, 128, 32, 7, True),
+                                                 (8, 4, 256, 16, 1, True), (8, 8, 64, 16, 9, False)])
+def test_rope_and_cache_from_k_split_partial_sums(dtype, kv8, hq, hkv, d, bs, ks, norm):
+    """The rotary + cache kernel adding up the projection's fp32 K-split slabs itself: the rotated q and
+    both caches against the same kernel fed the summed, rounded qkv (and through it against the fp32
+    reference the tests above pin that kernel to)."""
+    from vllm_distributed_amd.ops import hip
+    T, nb = 19, 12
+    n = (hq + 2 * hkv) * d
+    slabs = torch.randn(ks, T, n, device=DEV) / math.sqrt(ks)
+    qkv = slabs.sum(0).to(dtype)
+    qw = kw = None
+    if norm:
+        qw, kw = (1.0 + 0.2 * torch.randn(d, device=DEV)).to(dtype), (1.0 + 0.2 * torch.randn(d, device=DEV)).to(dtype)
+    cos_sin = torch_ref.build_cos_sin_cache(d, 4096, 1e6).to(DEV)
+    pos = torch.randint(0, 4096, (T,), device=DEV, dtype=torch.int32)
+    slots = torch.randperm(nb * bs, device=DEV)[:T].to(torch.int32)
+    slots[3] = -1
+    cdt = torch.float8_e4m3fn if kv8 else dtype
+    scales = (torch.rand(2, hkv, device=DEV) + 0.5) if kv8 else None
+
+    def caches():
+        return (torch.zeros(nb, hkv, bs, d, device=DEV, dtype=torch.float32).to(cdt),
+                torch.zeros(nb, hkv, d // 16, bs // 8, 16, 8, device=DEV, dtype=torch.float32).to(cdt))
+    kc0, vc0 = caches()
+    q0 = hip.rope_and_cache(pos, qkv.clone(), cos_sin, kc0, vc0, slots, hq, hkv, d, qw, kw, 1e-6, scales).clone()
+    kc1, vc1 = caches()
+    q1 = hip.rope_and_cache_partials(pos, slabs, dtype, cos_sin, kc1, vc1, slots, hq, hkv, d, qw, kw, 1e-6, scales)
+    torch.cuda.synchronize()
+    assert q1.shape == (T, hq * d) and q1.dtype == dtype
+    tol = dict(rtol=2e-2, atol=2e-2) if not kv8 else dict(rtol=0.13, atol=0.07)
+    torch.testing.assert_close(q1.float(), q0.float(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(kc1.float(), kc0.float(), **tol)
+    torch.testing.assert_close(vc1.float(), vc0.float(), **tol)
+    # nearly every element is bit-identical (a different order of the fp32 additions flips a rounding now and then)
+    assert (q1 == q0).float().mean().item() > 0.99
+    assert (vc1.float() == vc0.float()).float().mean().item() > 0.99
+    assert kc0.float().abs().sum().item() > 0 and vc0.float().abs().sum().item() > 0
+
+
 def test_rotary_and_reshape_unfused():
     T, hq, hkv, d, bs, nb = 19, 4, 2, 64, 16, 8
     q, k, v = _rand(T, hq * d), _rand(T, hkv * d), _rand(T, hkv * d)
@@ -513,6 +554,19 @@ def test_moe_align_and_combine(tokens, experts, k, tile_rows, ep):
         w = torch.where((topi >= start) & (topi < start + local), w, torch.zeros_like(w))
     want = (rows * w.unsqueeze(-1)).sum(1)
     assert (out.float() - want).abs().max().item() <= 2 ** -7 * want.abs().max().item() + 1e-6
+    # combine + residual add + RMSNorm in one launch: the same sum (rounded to 16 bits as above) added into
+    # the residual, then normalised, against fp32 arithmetic on the separate kernel's output
+    for hh in (256, 6144):
+        y = torch.randn(slots, hh, device=DEV, generator=gen).to(torch.bfloat16)
+        res = torch.randn(tokens, hh, device=DEV, generator=gen).to(torch.bfloat16)
+        gamma = (1 + 0.1 * torch.randn(hh, device=DEV, generator=gen)).to(torch.bfloat16)
+        summed = hip.moe_combine(y, topw, topi, inv, start, local)
+        want_res = (summed.float() + res.float()).to(torch.bfloat16)
+        want_out = want_res.float() * torch.rsqrt(want_res.float().pow(2).mean(-1, keepdim=True) + 1e-6) * gamma.float()
+        got_out, got_res = hip.moe_combine_add_rms_norm(y, topw, topi, inv, start, local, res, gamma, 1e-6)
+        assert got_res.data_ptr() == res.data_ptr()
+        assert (got_res.float() - want_res.float()).abs().max().item() <= 2 ** -7 * want_res.abs().max().item()
+        assert (got_out.float() - want_out).abs().max().item() <= 2 ** -7 * want_out.abs().max().item()
 
 
 @pytest.mark.parametrize("ldtype", [torch.bfloat16, torch.float32])

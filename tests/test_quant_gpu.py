@@ -148,6 +148,42 @@ def test_fused_moe_grouped_gemm_path_matches_per_expert_loop(quantized, tokens, 
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("tile_rows,tokens", [(16, 1), (16, 9), (32, 40)])
+def test_grouped_w4a16_gemm_forms_silu_mul_while_loading(dtype, tile_rows, tokens):
+    """The second expert GEMM of a decode step reads ``[gate | up]`` and multiplies by
+    ``silu(gate) * up`` formed in registers: against the activation kernel followed by the same GEMM
+    (same rounding of the activation to 16 bits, so the products agree to accumulation order) and against
+    an fp32 reference over the dequantised weights."""
+    from vllm_distributed_amd.ops import hip
+    experts, top_k, inter, hidden = 8, 2, 384, 256        # second GEMM: [rows, inter] x [hidden, inter]^T
+    gen = torch.Generator(device=DEV).manual_seed(tile_rows * 100 + tokens)
+    qws, szs, deq = [], [], []
+    for _ in range(experts):
+        w = torch.randn(hidden, inter, device=DEV, generator=gen) * 0.05
+        q, z, sc = quant.quantize_w4(w, 128)
+        qw, sz = quant.pack_w4(q, z, sc, dtype)
+        qws.append(qw), szs.append(sz)
+        deq.append(quant.w4_dequant(qw, sz).t().contiguous())                         # [inter, hidden]
+    qw, sz = torch.stack(qws).contiguous(), torch.stack(szs).contiguous()
+    logits = torch.randn(tokens, experts, device=DEV, generator=gen)
+    topi = logits.topk(top_k, dim=-1).indices.to(torch.int32)
+    src_row, inv, tiles = hip.moe_align(topi, experts, tile_rows, 0, -1)
+    h = (torch.randn(src_row.numel(), 2 * inter, device=DEV, generator=gen) * 2).to(dtype)
+    fused = hip.grouped_w4a16_gemm(h, qw, sz, tiles, tile_rows, silu_mul=True)
+    act = ops.silu_and_mul(h)
+    plain = hip.grouped_w4a16_gemm(act, qw, sz, tiles, tile_rows)
+    torch.cuda.synchronize()
+    flat = topi.reshape(-1).long()
+    for slot in range(flat.numel()):
+        row = int(inv[slot])
+        a32 = torch.nn.functional.silu(h[row, :inter].float()) * h[row, inter:].float()
+        want = a32 @ deq[int(flat[slot])]
+        scale = want.abs().max().item() + 1e-3
+        assert (fused[row].float() - want).abs().max().item() <= 0.02 * scale, (slot, row)
+        assert (fused[row].float() - plain[row].float()).abs().max().item() <= 0.01 * scale, (slot, row)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("m,k", [(1, 512), (7, 4096), (300, 8192), (16, 28672), (5, 1000)])
 def test_dynamic_fp8_quant_matches_torch_conversion(dtype, m, k):
     from vllm_distributed_amd.ops import hip

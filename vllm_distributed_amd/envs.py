@@ -125,6 +125,8 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     # The K-split slabs of a row-parallel projection (TP = 1) are summed by the add + RMSNorm that follows it
     # instead of by a reduction kernel of their own (one launch and a 16-bit round trip fewer per projection).
     "VDAMD_FUSED_REDUCE_NORM": _bool("VDAMD_FUSED_REDUCE_NORM", True),
+    # The rotary + KV-cache kernel sums the K-split partial sums of the q/k/v projection itself (decode-sized batches).
+    "VDAMD_FUSED_REDUCE_ROPE": _bool("VDAMD_FUSED_REDUCE_ROPE", True),
     # Form silu(gate) * up inside the weight-streaming down projection instead of a separate activation
     # kernel.  Off by default: at 70B batch 1 the two dependent loads in front of the LDS store cost the
     # GEMM more (about 7 us) than the 4.8 us activation kernel they replace (26.05 vs 25.85 ms per token).
@@ -142,6 +144,10 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     # Time the library's candidate kernels for every decode GEMM shape at warm-up.
     "VDAMD_TUNE_GEMM": _bool("VDAMD_TUNE_GEMM", False),
     "VDAMD_TUNE_GEMM_FILE": _str("VDAMD_TUNE_GEMM_FILE", os.path.expanduser("~/.cache/vllm_distributed_amd/gemm_tuning.csv")),
+    # MoE decode: the second expert GEMM forms silu(gate) * up while it loads its operand (no activation launch).
+    # Off by default: every workgroup of the GEMM repeats the activation of its rows, which costs more than
+    # the launch it saves (Qwen3-Coder-480B AWQ on one MI355X: batch 1 8.07 -> 8.47 ms, batch 16 28.4 -> 34.4 ms).
+    "VDAMD_MOE_FUSED_SILU": _bool("VDAMD_MOE_FUSED_SILU", False),
     # MoE: average rows per expert (4-bit experts; twice that for 16-bit ones) up to which a step
     # runs the grouped HIP GEMMs; above it each expert gets its own library GEMM.
     "VDAMD_MOE_GROUPED_MAX_ROWS": _int("VDAMD_MOE_GROUPED_MAX_ROWS", 512),

@@ -147,11 +147,12 @@ class RMSNorm(nn.Module):
         self.eps = eps
 
     def forward(self, x, residual: Optional[torch.Tensor] = None):
-        """``x`` may be a projection's K-split partial sums (``layers.linear.PartialSums``): with a
-        residual they are summed by the same kernel that adds and normalises."""
+        """``x`` may be a value its producer left unfinished - a projection's K-split partial sums
+        (``layers.linear.PartialSums``) or the expert rows of a sparse block before their weighted sum
+        (``layers.moe.ExpertRows``): with a residual, the kernel that adds and normalises finishes it."""
         if not isinstance(x, torch.Tensor):
             if residual is not None:
-                return ops.reduce_add_rms_norm(x.slabs, residual, self.weight, self.eps)
+                return x.add_rms_norm(residual, self.weight, self.eps)
             x = x.materialize()
         if residual is None:
             return ops.rms_norm(x, self.weight, self.eps)

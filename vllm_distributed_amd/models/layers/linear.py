@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ... import ops
+from ... import envs, ops
 from ..utils import materialize
 from ...parallel.state import (get_tp_group, get_tensor_model_parallel_rank,
                                get_tensor_model_parallel_world_size,
@@ -394,6 +394,16 @@ class QKVParallelLinear(_LinearBase):
         size, dst = size // pack, dst // pack
         param.data.narrow(od, dst, size).copy_(materialize(w.narrow(od, src_idx * size, size)))
 
+    def forward_partials(self, x: torch.Tensor) -> Optional["PartialSums"]:
+        """The packed ``[q | k | v]`` left as the fp32 K-split slabs of the short-batch kernels (dense
+        16-bit or AWQ weights, no bias, no adapter) for the rotary + cache kernel to sum; None when the
+        shape does not run split or the layer is not of that kind."""
+        if (self.weight_scale is not None or self.lora is not None or self.bias is not None
+                or self.alpha is not None or x.dim() != 2 or not x.is_cuda or not envs.VDAMD_FUSED_REDUCE_ROPE):
+            return None
+        slabs = ops.w4a16_partials(x, self.qw, self.sz) if self.qw is not None else ops.linear_partials(x, self.weight)
+        return None if slabs is None else PartialSums(slabs, x.dtype)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.qw is None and self.weight_scale is None and self.lora is None and x.dim() == 2:
             # large batches: the q columns alone tile the chip exactly, the k/v columns follow separately
@@ -483,6 +493,9 @@ class PartialSums:
 
     def materialize(self) -> torch.Tensor:
         return self.slabs.sum(0).to(self.dtype)
+
+    def add_rms_norm(self, residual: torch.Tensor, weight: torch.Tensor, eps: float):
+        return ops.reduce_add_rms_norm(self.slabs, residual, weight, eps)
 
 
 def pad_vocab(vocab_size: int, tp: int, multiple: int = 64) -> int:

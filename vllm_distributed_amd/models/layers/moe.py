@@ -28,6 +28,27 @@ from .linear import (ReplicatedLinear, _fill_scalar, active_quant, awq_to_native
                      nvfp4_dequantize, w4_layout_ok)
 
 
+class ExpertRows:
+    """A sparse block's output before the weighted sum over each token's experts: rows ``y`` in
+    expert-sorted order plus the routing tables.  An ``RMSNorm`` called with a residual sums, adds and
+    normalises in one launch; everybody else asks for ``materialize()``."""
+    __slots__ = ("y", "topw", "topi", "inv", "expert_start", "local")
+
+    def __init__(self, y, topw, topi, inv, expert_start, local):
+        self.y, self.topw, self.topi, self.inv, self.expert_start, self.local = y, topw, topi, inv, expert_start, local
+
+    @property
+    def shape(self):
+        return (self.topi.shape[0], self.y.shape[1])
+
+    def materialize(self) -> torch.Tensor:
+        return ops.moe_combine(self.y, self.topw, self.topi, self.inv, self.expert_start, self.local)
+
+    def add_rms_norm(self, residual: torch.Tensor, weight: torch.Tensor, eps: float):
+        return ops.moe_combine_add_rms_norm(self.y, self.topw, self.topi, self.inv, self.expert_start, self.local,
+                                            residual, weight, eps)
+
+
 class FusedMoE(nn.Module):
     def __init__(self, hidden: int, inter: int, num_experts: int, top_k: int,
                  renormalize: bool, dtype: torch.dtype, expert_parallel: bool = False):
@@ -232,22 +253,25 @@ class FusedMoE(nn.Module):
     def _experts_grouped(self, xs: torch.Tensor, tiles: torch.Tensor, tile_rows: int) -> torch.Tensor:
         if self.qw13 is not None:
             h = ops.grouped_linear(xs, tiles, tile_rows, qw=self.qw13, sz=self.sz13, alpha=self.alpha13)
-            return ops.grouped_linear(ops.silu_and_mul(h), tiles, tile_rows, qw=self.qw2, sz=self.sz2,
-                                      alpha=self.alpha2)
+            return ops.grouped_linear(h, tiles, tile_rows, qw=self.qw2, sz=self.sz2, alpha=self.alpha2,
+                                      silu_mul=True)
         h = ops.grouped_linear(xs, tiles, tile_rows, weight=self.w13)
         return ops.grouped_linear(ops.silu_and_mul(h), tiles, tile_rows, weight=self.w2)
 
-    def _forward_fused_routing(self, x: torch.Tensor, logits: torch.Tensor, tile_rows: int) -> torch.Tensor:
+    def _forward_fused_routing(self, x: torch.Tensor, logits: torch.Tensor, tile_rows: int, deferred: bool = False):
         """Routing, expert GEMMs and the weighted sum in eight launches (router
         GEMM included): top-k, slot sort + tile table and the combine are one HIP
-        kernel each."""
+        kernel each.  ``deferred`` (decode-sized batches): the weighted sum is left to the add + RMSNorm
+        that follows (``ExpertRows``)."""
         local = self.local_experts if self.expert_parallel else -1
         if ops.moe_route_small_ok(logits, x):
             # decode-sized batch: top-k, slot sort, tile table and the row gather are one launch
             topw, topi, inv, tiles, xs = ops.moe_route_small(logits, x, self.top_k, self.renormalize, tile_rows,
                                                              self.expert_start, local)
-            return ops.moe_combine(self._experts_grouped(xs, tiles, tile_rows), topw, topi, inv,
-                                   self.expert_start, local)
+            y = self._experts_grouped(xs, tiles, tile_rows)
+            if deferred:
+                return ExpertRows(y, topw, topi, inv, self.expert_start, local)
+            return ops.moe_combine(y, topw, topi, inv, self.expert_start, local)
         topw, topi = ops.moe_topk(logits, self.top_k, self.renormalize)
         src_row, inv, tiles = ops.moe_align_fused(topi, self.num_experts, tile_rows, self.expert_start, local)
         y = self._experts_grouped(x.index_select(0, src_row), tiles, tile_rows)
@@ -268,7 +292,8 @@ class FusedMoE(nn.Module):
             topw = topw / topw.sum(-1, keepdim=True)
         return topw, topi
 
-    def forward(self, x: torch.Tensor, reduce: bool = True, staged: bool = False) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, reduce: bool = True, staged: bool = False, deferred: bool = False):
+        # `deferred`: the caller feeds the result to an add + RMSNorm and accepts ``ExpertRows``
         # `staged` (write the partial sums where the next direct all-reduce reads) is a hint only
         tile_rows = self._grouped_tile_rows(x)
         logits = None
@@ -277,7 +302,9 @@ class FusedMoE(nn.Module):
             # decode: the routing kernel adds up the router GEMM's K-split partial sums itself
             logits = ops.router_logit_partials(x, self.gate.weight)
             if logits is not None:
-                out = self._forward_fused_routing(x, logits, tile_rows)
+                # unsharded experts only: a sharded block's sum still has to cross the TP group
+                defer = deferred and self.tp == 1 and envs.VDAMD_FUSED_REDUCE_NORM
+                out = self._forward_fused_routing(x, logits, tile_rows, defer)
                 if reduce and self.tp > 1:
                     out = tensor_model_parallel_all_reduce(out)
                 return out

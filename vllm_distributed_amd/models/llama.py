@@ -17,6 +17,7 @@ from .. import envs, ops
 from ..config import VllmConfig, layer_sliding_window
 from ..parallel.state import get_pp_group, get_tp_group
 from .layers.attention import Attention, RMSNorm, get_forward_context
+from .layers.moe import FusedMoE
 from .layers.linear import (ColumnParallelLinear, ParallelLMHead, QKVParallelLinear, QuantSpec,
                             RowParallelLinear, VocabParallelEmbedding, nvfp4_rename, quantized_linears)
 from .utils import IntermediateTensors, get_pp_layer_range, materialize
@@ -170,8 +171,19 @@ class LlamaAttention(nn.Module):
                 staged: bool = False, residual: Optional[torch.Tensor] = None, partials: bool = False):
         """With ``residual``: None is returned when the output projection added its product into it.
         ``partials``: the output projection may return its K-split partial sums (``PartialSums``)."""
-        qkv = self.qkv_proj(hidden)
         md = get_forward_context().attn_metadata
+        if (md is not None and self.attn.k_cache is not None and self.clip_qkv is None and not self.qk_norm_full
+                and ops.rope_cache_fused_ok(self.head_dim)):
+            # decode-sized batches: the projection's K-split partial sums are added up by the kernel that
+            # normalises, rotates and writes the cache
+            part = self.qkv_proj.forward_partials(hidden)
+            if part is not None:
+                nw = (self.q_norm.weight, self.k_norm.weight, self.q_norm.eps) if self.qk_norm else (None, None, 0.0)
+                q = ops.rope_and_cache_partials(positions, part.slabs, part.dtype, self.cos_sin, self.attn.k_cache,
+                                                self.attn.v_cache, md.slot_mapping, self.num_heads,
+                                                self.num_kv_heads, self.head_dim, *nw, kv_scales=self.attn.kv_scales)
+                return self._project_out(self.attn.forward_cached(q), reduce, staged, residual, partials)
+        qkv = self.qkv_proj(hidden)
         if self.clip_qkv is not None and not self.qk_norm_full:
             qkv = qkv.clamp_(-self.clip_qkv, self.clip_qkv)
         if self.qk_norm and md is not None and self.attn.k_cache is not None:
@@ -203,6 +215,10 @@ class LlamaAttention(nn.Module):
                                    self.attn.v_cache, md.slot_mapping, self.num_heads,
                                    self.num_kv_heads, self.head_dim, kv_scales=self.attn.kv_scales)
             out = self.attn.forward_cached(q)
+        return self._project_out(out, reduce, staged, residual, partials)
+
+    def _project_out(self, out: torch.Tensor, reduce: bool, staged: bool, residual: Optional[torch.Tensor],
+                     partials: bool):
         if residual is not None and self.o_proj.forward_add(out, residual):
             return None
         if partials:
@@ -224,6 +240,7 @@ class LlamaDecoderLayer(nn.Module):
         # they may hand over K-split partial sums (unsharded layers; see RowParallelLinear.forward_partials)
         self._attn_partials = type(self.self_attn) is LlamaAttention
         self._mlp_partials = type(self.mlp) is LlamaMLP
+        self._mlp_deferred = type(self.mlp) is FusedMoE     # may leave its weighted sum to the next norm
 
     def _make_attn(self, cfg: dict, layer_idx: int, dtype: torch.dtype, cos_sin: torch.Tensor) -> nn.Module:
         return LlamaAttention(cfg, layer_idx, dtype, cos_sin)
@@ -268,6 +285,8 @@ class LlamaDecoderLayer(nn.Module):
             hidden, residual = self.post_attention_layernorm(hidden, residual)
         if self._mlp_partials:
             hidden = self.mlp(hidden, residual=residual, partials=True)
+        elif self._mlp_deferred:
+            hidden = self.mlp(hidden, deferred=True)
         elif getattr(self.mlp, "supports_residual", False):
             hidden = self.mlp(hidden, residual=residual)
         else:

@@ -160,6 +160,22 @@ def rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping
                                     kv_scales)
 
 
+def rope_cache_fused_ok(head_dim: int) -> bool:
+    """Whether the HIP rotary + cache kernel takes this head size (per-head norm included)."""
+    lanes = head_dim // 16
+    return head_dim % 16 == 0 and lanes & (lanes - 1) == 0 and lanes <= 64 and hip_available()
+
+
+def rope_and_cache_partials(positions, slabs, dtype, cos_sin_cache, k_cache, v_cache, slot_mapping,
+                            num_heads, num_kv_heads, head_dim, q_norm_weight=None, k_norm_weight=None, norm_eps=0.0,
+                            kv_scales=None):
+    """``rope_and_cache`` on a projection left as K-split slabs (``linear_partials`` / ``w4a16_partials``;
+    HIP only): returns the rotated ``q``."""
+    return _hip.rope_and_cache_partials(positions, slabs, dtype, cos_sin_cache, k_cache, v_cache, slot_mapping,
+                                        num_heads, num_kv_heads, head_dim, q_norm_weight, k_norm_weight, norm_eps,
+                                        kv_scales)
+
+
 def paged_attention(q, k_cache, v_cache, block_table, query_start_loc, seq_lens, scale,
                     max_query_len: int = 0, max_seq_len: int = 0, out=None, kv_scales=None, window: int = 0,
                     softcap: float = 0.0):
@@ -510,16 +526,32 @@ def moe_combine(y, topw, topi, inv, expert_start: int = 0, local_experts: int = 
     return _hip.moe_combine(y, topw, topi, inv, expert_start, local_experts)
 
 
-def grouped_linear(x, tiles, tile_rows: int, weight=None, qw=None, sz=None, alpha=None):
+def moe_combine_add_rms_norm(y, topw, topi, inv, expert_start, local_experts, residual, weight, eps):
+    """``fused_add_rms_norm(moe_combine(...), residual, weight, eps)`` in one launch (HIP only)."""
+    return _hip.moe_combine_add_rms_norm(y, topw, topi, inv, expert_start, local_experts, residual, weight, eps)
+
+
+def grouped_linear(x, tiles, tile_rows: int, weight=None, qw=None, sz=None, alpha=None, silu_mul: bool = False):
     """Row-grouped ``x @ W[g]^T`` (dense ``weight [G, N, K]``, packed 4-bit
     integer ``qw/sz``, or NVFP4 ``qw`` + int32 ``sz`` + ``alpha [G, N]``) for rows
-    sorted by group - see ``moe_align``.  HIP only."""
+    sorted by group - see ``moe_align``.  HIP only.  ``silu_mul``: ``x`` is ``[rows, 2K] = [gate | up]``
+    and the product is taken with ``silu(gate) * up`` (inside the kernel where ``grouped_silu_fused`` says
+    so, through the activation kernel otherwise)."""
     assert _use_hip(x)
+    if silu_mul and not grouped_silu_fused(tile_rows, qw, sz):
+        x, silu_mul = silu_and_mul(x), False
     if qw is not None:
         if sz.dtype == torch.int32:
             return _hip.grouped_fp4a16_gemm(x, qw, sz, alpha, tiles, tile_rows)
-        return _hip.grouped_w4a16_gemm(x, qw, sz, tiles, tile_rows)
+        return _hip.grouped_w4a16_gemm(x, qw, sz, tiles, tile_rows, silu_mul=silu_mul)
     return _hip.grouped_gemm(x, weight, tiles, tile_rows)
+
+
+def grouped_silu_fused(tile_rows: int, qw, sz) -> bool:
+    """Whether the grouped GEMM of these weights forms ``silu(gate) * up`` itself at this tile size
+    (integer 4-bit experts, few rows per expert: decode)."""
+    return (qw is not None and sz.dtype != torch.int32 and tile_rows <= _hip.W4_GROUPED_SILU_MAX_ROWS
+            and envs.VDAMD_MOE_FUSED_SILU)
 
 
 apply_penalties = torch_ref.apply_penalties

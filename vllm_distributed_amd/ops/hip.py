@@ -40,6 +40,7 @@ def load() -> ctypes.CDLL:
         "vdamd_stream_gemm": [P, L, P, L, P, L, P, P, L, I, I, I, I, I, I, I, I, I, P],
         "vdamd_big_gemm": [P, L, P, L, P, L, P, L, I, I, I, I, I, I, P],
         "vdamd_rope_cache": [P, P, P, P, L, L, L, P, P, P, P, I, I, I, I, I, I, P, P, F, I, I, P, P, P],
+        "vdamd_rope_cache_slabs": [P, P, I, P, L, P, P, P, P, I, I, I, I, I, P, P, F, I, I, P, P, P],
         "vdamd_paged_attention_decode": [P, P, P, L, P, P, P, I, P, F, I, I, I, I, I, I, L, I, I, P, P, I, F, P],
         "vdamd_paged_attention_prefill": [P, P, L, P, P, P, I, P, P, F, I, I, I, I, I, I, L, I, I, P, P, I, F, P],
         "vdamd_argmax": [P, P, I, I, L, I, P],
@@ -49,11 +50,12 @@ def load() -> ctypes.CDLL:
         "vdamd_skinny_gemm": [P, L, P, L, P, L, P, I, I, I, I, I, I, L, P],
         "vdamd_dynamic_fp8_quant": [P, P, P, I, I, L, I, P],
         "vdamd_skinny_gemm_grouped": [P, L, P, L, P, L, L, P, I, I, I, I, I, I, P],
-        "vdamd_w4a16_gemm_grouped": [P, L, P, L, P, P, L, L, P, I, I, I, I, I, I, P],
+        "vdamd_w4a16_gemm_grouped": [P, L, P, L, P, P, L, L, P, I, I, I, I, I, I, I, P],
         "vdamd_moe_topk": [P, L, P, P, I, I, I, I, I, P],
         "vdamd_moe_align": [P, I, I, I, I, I, I, P, P, P, I, P],
         "vdamd_moe_route_small": [P, L, I, I, I, I, I, I, I, P, P, P, P, P, I, P, L, P, I, I, I, I, L, P],
         "vdamd_moe_combine": [P, L, P, L, P, P, P, I, I, I, I, I, I, P],
+        "vdamd_moe_combine_add_rms_norm": [P, L, P, L, P, P, P, I, I, I, I, I, P, P, F, I, P],
         "vdamd_fp4a16_gemm": [P, L, P, L, P, P, P, P, I, I, I, I, I, I, P],
         "vdamd_fp4_dequant": [P, P, P, P, I, I, I, P],
         "vdamd_fp4a16_gemm_grouped": [P, L, P, L, P, P, L, L, P, P, I, I, I, I, I, P],
@@ -243,6 +245,37 @@ def rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping
     return qkv[:, :qs]
 
 
+def rope_and_cache_partials(positions, slabs, dtype, cos_sin_cache, k_cache, v_cache, slot_mapping, num_heads,
+                            num_kv_heads, head_dim, q_norm_weight=None, k_norm_weight=None, norm_eps: float = 0.0,
+                            kv_scales=None) -> torch.Tensor:
+    """``rope_and_cache`` whose packed ``qkv`` arrives as the fp32 K-split slabs ``[ks, T, (Hq + 2 Hkv) D]`` of
+    the projection (summed here, rounded to ``dtype`` first as the GEMM's own reduction would); returns the
+    rotated ``q [T, Hq D]`` in a buffer of its own."""
+    ks, t, n = slabs.shape
+    qs = num_heads * head_dim
+    lanes = head_dim // 16
+    assert slabs.dtype == torch.float32 and slabs.is_contiguous() and n == qs + 2 * num_kv_heads * head_dim
+    assert head_dim % 16 == 0 and dtype in (torch.bfloat16, torch.float16)
+    assert q_norm_weight is None or (lanes & (lanes - 1) == 0 and lanes <= 64)
+    if q_norm_weight is not None:
+        for w in (q_norm_weight, k_norm_weight):
+            assert w.dtype == dtype and w.numel() == head_dim and w.is_contiguous()
+    assert cos_sin_cache.dtype == torch.float32 and cos_sin_cache.shape[1] == head_dim
+    assert positions.dtype == torch.int32 and slot_mapping.dtype == torch.int32
+    assert positions.numel() >= t and slot_mapping.numel() >= t
+    bs = _check_cache(k_cache, v_cache, num_kv_heads, head_dim)
+    q = torch.empty((t, qs), dtype=dtype, device=slabs.device)
+    _check(_LIB.vdamd_rope_cache_slabs(positions.data_ptr(), slabs.data_ptr(), ks, q.data_ptr(), qs,
+                                       cos_sin_cache.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+                                       slot_mapping.data_ptr(), t, num_heads, num_kv_heads, head_dim, bs,
+                                       None if q_norm_weight is None else q_norm_weight.data_ptr(),
+                                       None if k_norm_weight is None else k_norm_weight.data_ptr(), norm_eps,
+                                       _DT[dtype],
+                                       *_kv_args(k_cache, kv_scales, num_kv_heads), _stream()),
+           "rope_and_cache_partials")
+    return q
+
+
 def rotary_embedding(positions, q, k, cos_sin_cache, head_dim) -> None:
     if not _half(q):
         from . import torch_ref
@@ -280,10 +313,11 @@ def decode_workspace_floats(max_bs: int, num_heads: int, head_dim: int, num_kv_h
 
 
 def choose_num_splits(batch: int, num_kv_heads: int, max_seq_len: int) -> int:
-    """Enough workgroups to fill 256 CUs twice over, each split >= 256 keys."""
+    """Enough workgroups to fill 256 CUs twice over, each split >= 512 keys: up to 512 keys one
+    workgroup per (sequence, KV head) finishes in the time the merge kernel of a split takes to launch."""
     wgs = max(1, batch * num_kv_heads)
     want = (512 + wgs - 1) // wgs
-    by_len = max(1, (max_seq_len + 255) // 256)
+    by_len = max(1, max_seq_len // 512)
     return max(1, min(MAX_SPLITS, want, by_len))
 
 
@@ -825,18 +859,29 @@ def grouped_gemm(x: torch.Tensor, w: torch.Tensor, tiles: torch.Tensor, tile_row
     return out
 
 
+W4_GROUPED_SILU_MAX_ROWS = 32      # tile sizes whose kernel forms silu(gate) * up while loading its operand
+
+
 def grouped_w4a16_gemm(x: torch.Tensor, qw: torch.Tensor, sz: torch.Tensor, tiles: torch.Tensor,
-                       tile_rows: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Grouped form of ``w4a16_gemm``: ``qw [G, N/16, K/128, 64, 4]``, ``sz [G, N/16, K/g, 16, 2]``."""
+                       tile_rows: int, out: Optional[torch.Tensor] = None, silu_mul: bool = False) -> torch.Tensor:
+    """Grouped form of ``w4a16_gemm``: ``qw [G, N/16, K/128, 64, 4]``, ``sz [G, N/16, K/g, 16, 2]``.
+    ``silu_mul`` (``tile_rows <= 32``): ``x`` is ``[rows, 2K] = [gate | up]`` and the left operand is
+    ``silu(gate) * up``, formed inside the kernel."""
     nt = _check_tiles(tiles, x, tile_rows)
     assert qw.dim() == 5 and sz.dim() == 5 and qw.shape[0] == sz.shape[0] and tile_rows <= 64
     n, k, grp = _w4_dims(qw[0], sz[0])
-    assert qw.is_contiguous() and sz.is_contiguous() and x.shape[1] == k and x.dtype == sz.dtype
+    up_off = 0
+    if silu_mul:
+        assert tile_rows <= W4_GROUPED_SILU_MAX_ROWS and x.shape[1] == 2 * k
+        up_off = k
+    else:
+        assert x.shape[1] == k
+    assert qw.is_contiguous() and sz.is_contiguous() and x.dtype == sz.dtype
     if out is None:
         out = torch.empty((x.shape[0], n), dtype=x.dtype, device=x.device)
     _check(_LIB.vdamd_w4a16_gemm_grouped(out.data_ptr(), out.stride(0), x.data_ptr(), x.stride(0), qw.data_ptr(),
                                          sz.data_ptr(), qw[0].numel(), sz[0].numel(), tiles.data_ptr(), nt,
-                                         tile_rows, n, k, grp, _dt(x), _stream()), "w4a16_gemm_grouped")
+                                         tile_rows, n, k, grp, _dt(x), up_off, _stream()), "w4a16_gemm_grouped")
     return out
 
 
@@ -940,6 +985,24 @@ def moe_combine(y: torch.Tensor, topw: torch.Tensor, topi: torch.Tensor, inv: to
                                   inv.data_ptr(), t, k, h, expert_start, local_experts, _dt(y), _stream()),
            "moe_combine")
     return out
+
+
+def moe_combine_add_rms_norm(y: torch.Tensor, topw: torch.Tensor, topi: torch.Tensor, inv: torch.Tensor,
+                             expert_start: int, local_experts: int, residual: torch.Tensor, weight: torch.Tensor,
+                             eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``moe_combine`` followed by ``fused_add_rms_norm`` in one launch: ``residual`` (in place) gains the
+    weighted sum of each token's expert rows, and its RMSNorm is returned next to it."""
+    t, k = topi.shape
+    h = y.shape[1]
+    assert y.stride(1) == 1 and h % 8 == 0 and h <= 32768 and k <= 16 and _half(y)
+    assert residual.shape == (t, h) and residual.is_contiguous() and residual.dtype == y.dtype == weight.dtype
+    assert topw.dtype == torch.float32 and topw.is_contiguous() and topi.is_contiguous() and inv.is_contiguous()
+    out = torch.empty_like(residual)
+    _check(_LIB.vdamd_moe_combine_add_rms_norm(out.data_ptr(), h, y.data_ptr(), y.stride(0), topw.data_ptr(),
+                                               topi.data_ptr(), inv.data_ptr(), t, k, h, expert_start, local_experts,
+                                               residual.data_ptr(), weight.data_ptr(), float(eps), _dt(y), _stream()),
+           "moe_combine_add_rms_norm")
+    return out, residual
 
 
 # ------------------------------------------------------------------ FP8 W8A8
