@@ -752,6 +752,31 @@ def _padded_weight(n, k, pad, dtype=torch.bfloat16):
     return buf[:, :k]
 
 
+@pytest.mark.parametrize("m", [1, 3, 8])
+def test_wide_outputs_at_a_few_rows_take_the_weight_streaming_kernel(m, monkeypatch):
+    """``ops.gate_up_silu`` and ``ops.linear`` hand up to 8 rows into a very wide output to
+    ``stream_gemm`` (activation in its epilogue): results against fp32, and the routing itself."""
+    from vllm_distributed_amd.ops import hip
+    n, k = 28672, 1024 * 2
+    x = _rand(m, k)
+    buf = _rand(n, k + 128, scale=0.03)
+    w = buf[:, :k]                                      # padded rows, as the runner lays dense weights out
+    calls = []
+    real = hip.stream_gemm
+    monkeypatch.setattr(hip, "stream_gemm", lambda *a, **kw: (calls.append(kw.get("silu_mul", False)), real(*a, **kw))[1])
+    got = ops.gate_up_silu(x, w)
+    assert calls == [True] and got.shape == (m, n // 2)
+    y = torch.nn.functional.linear(x.float(), w.float())
+    want = torch.nn.functional.silu(y[:, :n // 2]) * y[:, n // 2:]
+    assert (got.float() - want).abs().max().item() <= 0.02 * want.abs().max().item() + 1e-3
+    got = ops.linear(x, w)
+    assert calls == [True, False]
+    assert (got.float() - y).abs().max().item() <= 0.02 * y.abs().max().item() + 1e-3
+    assert ops.gate_up_silu(_rand(9, k), w) is None                      # beyond 8 rows: not this kernel
+    assert not hip.stream_profitable(4, 7168, 8192)                       # a TP=8 shard: the library is ahead
+
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("m,n,k,pad", [(1, 4096, 4096, 0), (3, 1024, 8192, 128), (16, 6144, 4096, 128),
                                        (7, 48, 256, 0), (16, 2064, 1152, 8), (2, 28672, 1024, 128)])

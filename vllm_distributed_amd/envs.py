@@ -124,6 +124,9 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     "VDAMD_BIG_GEMM": _bool("VDAMD_BIG_GEMM", True),
     # The K-split slabs of a row-parallel projection (TP = 1) are summed by the add + RMSNorm that follows it
     # instead of by a reduction kernel of their own (one launch and a 16-bit round trip fewer per projection).
+    # Up to 8 rows into a very wide output (gate_up with the SiLU epilogue, LM head): the barrier-free
+    # weight-streaming GEMM instead of the library.
+    "VDAMD_STREAM_GEMM": _bool("VDAMD_STREAM_GEMM", True),
     "VDAMD_FUSED_REDUCE_NORM": _bool("VDAMD_FUSED_REDUCE_NORM", True),
     # The rotary + KV-cache kernel sums the K-split partial sums of the q/k/v projection itself (decode-sized batches).
     "VDAMD_FUSED_REDUCE_ROPE": _bool("VDAMD_FUSED_REDUCE_ROPE", True),

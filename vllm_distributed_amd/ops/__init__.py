@@ -239,6 +239,10 @@ def linear(x, weight, bias=None, out=None):
     buffer the following all-reduce reads)."""
     if x.is_cuda and x.dim() == 2 and x.shape[0] <= 256 and envs.VDAMD_SKINNY_GEMM and _use_hip(x):
         m, n, k = x.shape[0], weight.shape[0], weight.shape[1]
+        if (envs.VDAMD_STREAM_GEMM and _hip.stream_profitable(m, n, k) and _hip.stream_supported(x, weight)
+                and (out is None or out.stride(0) == n)):
+            y = _hip.stream_gemm(x, weight, out=out)
+            return y if bias is None else y.add_(bias)
         if _hip.mid_profitable(m, n, k) and _hip.mid_supported(x, weight):
             y = _hip.mid_gemm(x, weight, out=out)
             return y if bias is None else y.add_(bias)
@@ -319,7 +323,12 @@ def linear_add(x, weight, residual) -> bool:
 def gate_up_silu(x, weight):
     """``silu(x @ Wg^T) * (x @ Wu^T)`` for ``weight = [Wg ; Wu]`` in one kernel (the large-batch GEMM
     forms the activation in its epilogue: the ``[M, 2F]`` intermediate is never written), or ``None``
-    when that kernel does not take the shape - the caller then runs the two-step path."""
+    when that kernel does not take the shape - the caller then runs the two-step path.  A handful of rows
+    take the barrier-free weight-streaming kernel, which has the same epilogue."""
+    if (x.is_cuda and x.dim() == 2 and envs.VDAMD_STREAM_GEMM and envs.VDAMD_SKINNY_GEMM and _use_hip(x)
+            and _hip.stream_profitable(x.shape[0], weight.shape[0], weight.shape[1])
+            and _hip.stream_supported(x, weight) and weight.shape[0] % 64 == 0):
+        return _hip.stream_gemm(x, weight, silu_mul=True)
     if (x.is_cuda and x.dim() == 2 and envs.VDAMD_BIG_GEMM and _use_hip(x) and x.shape[0] >= _hip.BIG_MIN_M_SILU
             and _hip.big_profitable(x.shape[0], weight.shape[0], weight.shape[1], True)
             and _hip.big_supported(x, weight, True)):

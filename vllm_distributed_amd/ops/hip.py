@@ -636,6 +636,17 @@ def stream_supported(x: torch.Tensor, w: torch.Tensor) -> bool:
             and w.data_ptr() % 16 == 0)
 
 
+STREAM_WIRED_MAX_M = 8
+
+
+def stream_profitable(m: int, n: int, k: int) -> bool:
+    """Where this kernel beats the library GEMM on MI355X (benchmarks/stream_silu_probe.py and
+    stream_gemm_sweep.py, padded weight rows, inside graphs): up to 8 rows into a very wide output - a gate_up
+    projection (8B-class: 48 us with the activation in the epilogue against 67 us for library + activation
+    kernel; 70B: 164 against 166 us) or an LM head (356 against 369 us).  Narrow outputs (a TP=8 shard) lose."""
+    return 0 < m <= STREAM_WIRED_MAX_M and n >= 24576 and k >= 2048
+
+
 def stream_choose(n: int, k: int, silu: bool = False) -> Tuple[int, int, int]:
     """``(ntw, ksplit, depth)``.  One output tile per workgroup until N alone gives several
     workgroups per CU; K is split across workgroups only when even that leaves CUs idle."""
