@@ -210,6 +210,80 @@ def test_shared_storage_kv_connector_moves_prefill_between_engines(tmp_path):
     pstate.destroy_model_parallel()
 
 
+def test_kv_transfers_run_beside_the_steps_and_an_aborted_load_keeps_its_blocks(tmp_path, monkeypatch):
+    """The connector's file I/O and copies happen on a side thread: with a load slowed to 0.4 s another
+    request keeps generating (steps are not held up), the parked request is scheduled only once the load
+    has been reported, and a request aborted mid-load gives its blocks back only after the copy has ended."""
+    import time
+    from vllm_distributed_amd import SamplingParams
+    from vllm_distributed_amd.engine.arg_utils import EngineArgs
+    from vllm_distributed_amd.engine.llm_engine import LLMEngine
+    from vllm_distributed_amd.executor.kv_transfer import WorkerKVConnector
+    from vllm_distributed_amd.parallel import state as pstate
+    long_a, long_b, other = list(range(3, 3 + 70)), list(range(100, 100 + 50)), [9, 8, 7, 6, 5]
+
+    def make(role):
+        pstate.destroy_model_parallel()
+        kv = {"kv_connector": "SharedStorageConnector", "kv_role": role,
+              "kv_connector_extra_config": {"shared_storage_path": str(tmp_path)}}
+        return LLMEngine.from_engine_args(EngineArgs(
+            model="llama-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,
+            num_gpu_blocks_override=64, max_num_seqs=8, kv_transfer_config=kv, enable_prefix_caching=False))
+
+    def drain(eng):
+        final = {}
+        while eng.has_unfinished_requests():
+            for o in eng.step():
+                if o.finished:
+                    final[o.request_id] = o.outputs[0].token_ids
+        return final
+
+    prod = make("kv_producer")
+    sp1 = SamplingParams(temperature=0.0, max_tokens=1, ignore_eos=True)
+    ids = [prod.add_request(None, p, sp1) for p in (long_a, long_b)]
+    first = drain(prod)
+    wconn = prod.core.executor.driver.worker.model_runner.kv_connector
+    assert wconn.transfers_started == 2 and wconn.idle() and wconn.max_step_block_s < 0.05
+    prod.shutdown()
+
+    real_load = WorkerKVConnector._load
+
+    def slow_load(self, op, path, kv_caches):
+        time.sleep(0.4)
+        real_load(self, op, path, kv_caches)
+    monkeypatch.setattr(WorkerKVConnector, "_load", slow_load)
+    cons = make("kv_consumer")
+    sched = cons.core.scheduler
+    free0 = sched.kv.pool.num_free_blocks
+    sp = SamplingParams(temperature=0.0, max_tokens=40, ignore_eos=True)
+    rid_other = cons.add_request(None, other, sp)
+    rid_a = cons.add_request(None, long_a, SamplingParams(temperature=0.0, max_tokens=3, ignore_eos=True))
+    rid_b = cons.add_request(None, long_b, sp)
+    tokens_while_loading = 0
+    t0 = time.time()
+    final = {}
+    aborted = False
+    while cons.has_unfinished_requests():
+        for o in cons.step():
+            if o.request_id == rid_other and sched.kv_loading:
+                tokens_while_loading += 1
+            if o.finished:
+                final[o.request_id] = o.outputs[0].token_ids
+        if not aborted and rid_b in sched.kv_loading:
+            held = len(sched.kv.req_blocks[rid_b])
+            cons.abort_request(rid_b)                         # mid-copy: blocks must stay allocated
+            assert rid_b in sched._kv_load_orphans and len(sched.kv.req_blocks[rid_b]) == held
+            aborted = True
+    assert aborted and time.time() - t0 >= 0.4
+    assert tokens_while_loading >= 5, tokens_while_loading      # the slowed copies did not stall decoding
+    assert final[rid_a][0] == first[ids[0]][0] and len(final[rid_a]) == 3 and len(final[rid_other]) == 40
+    assert not sched.kv_loading and not sched._kv_load_orphans and rid_b not in sched.kv.req_blocks
+    assert sched.kv.pool.num_free_blocks == free0
+    assert sched.kv_connector.num_loaded_tokens == 64 + 48
+    cons.shutdown()
+    pstate.destroy_model_parallel()
+
+
 def test_fp8_kv_cache_reference_ops_and_engine_cpu():
     """The e4m3 KV cache on the CPU reference path: write / read round trip with per-head scales,
     half the bytes per block, and an engine that generates with it."""

@@ -173,7 +173,7 @@ class EngineCore:
         t0 = time.perf_counter()
         so = self.scheduler.schedule()
         t1 = time.perf_counter()
-        if so.is_empty and not so.finished_req_ids and not so.preempted_req_ids:
+        if not self._worth_running(so):
             return []
         out = self.executor.execute_model(so)
         t2 = time.perf_counter()
@@ -183,6 +183,19 @@ class EngineCore:
         self.timer.add_step(out)
         return res
 
+    @staticmethod
+    def _worth_running(so: SchedulerOutput) -> bool:
+        """A step with nothing scheduled still goes to the workers when it carries news for them (finished or
+        preempted requests) or when KV transfers are in flight: the workers report a finished transfer with
+        the output of the next step they run, so an otherwise idle engine polls (a couple of ms apart)."""
+        if not so.is_empty or so.finished_req_ids or so.preempted_req_ids:
+            return True
+        meta = so.kv_connector_metadata
+        if meta and (meta.get("pending") or meta.get("load") or meta.get("save")):
+            time.sleep(0.002)
+            return True
+        return False
+
     def _step_with_batch_queue(self) -> List[EngineCoreOutput]:
         """Fill the pipeline before draining it: schedule a new batch whenever
         a slot is free and something is schedulable; otherwise wait for the
@@ -191,7 +204,7 @@ class EngineCore:
             t0 = time.perf_counter()
             so = self.scheduler.schedule()
             t1 = time.perf_counter()
-            if not so.is_empty or so.finished_req_ids or so.preempted_req_ids:
+            if self._worth_running(so):
                 fut = self.executor.execute_model(so, non_block=True)
                 self.batch_queue.append((fut, so))
                 self.timer.add_head(schedule=t1 - t0, launch=time.perf_counter() - t1)

@@ -89,6 +89,12 @@ class Scheduler:
         self._pending_new_tokens: Dict[str, List[int]] = {}
         self.include_new_token_ids = include_new_token_ids
         self.kv_connector = kv_connector
+        # requests whose prompt KV the workers are copying in from another engine (not schedulable until every
+        # rank has reported the copy), those whose copy has landed and that wait at the head of the queue, and
+        # those that were aborted mid-copy (their blocks are only freed once nobody writes to them any more)
+        self.kv_loading: Dict[str, Request] = {}
+        self._kv_loaded: Set[str] = set()
+        self._kv_load_orphans: Dict[str, Request] = {}
         self.spec = speculative_config
         self.spec_stats = {"drafted": 0, "accepted": 0}
         self._ngram = None
@@ -166,6 +172,9 @@ class Scheduler:
             req = self.requests.get(rid)
             if req is None or req.finished:
                 continue
+            if self._orphan_if_loading(req, RequestStatus.FINISHED_ABORTED):
+                aborted.append(rid)
+                continue
             if req.status == RequestStatus.RUNNING:
                 self.running.remove(req)
             else:
@@ -179,7 +188,11 @@ class Scheduler:
         return aborted
 
     def has_unfinished_requests(self) -> bool:
-        return bool(self.waiting or self.running)
+        if self.waiting or self.running:
+            return True
+        # KV transfers in flight keep the engine stepping: their completion arrives with a step's output
+        return self.kv_connector is not None and bool(self.kv_loading or self._kv_load_orphans
+                                                      or self.kv_connector.sending)
 
     def has_requests(self) -> bool:
         return self.has_unfinished_requests() or bool(self._finished_since_last)
@@ -274,20 +287,36 @@ class Scheduler:
 
         # 2. waiting requests (not while we are under memory pressure)
         if not preempted:
-            while self.waiting and budget > 0 and len(self.running) < self.max_num_seqs:
+            while self.waiting and budget > 0 and len(self.running) + len(self.kv_loading) < self.max_num_seqs:
                 req = self.waiting[0]
                 if req.lora_request is not None:
                     active = {r.lora_request.lora_int_id for r in self.running if r.lora_request is not None}
                     if req.lora_request.lora_int_id not in active and len(active) >= self.max_loras:
                         break            # every adapter slot is busy with running requests
                 computed_blocks, num_cached = ([], 0)
-                if req.num_computed_tokens == 0:
+                loaded = req.request_id in self._kv_loaded          # back from a load: its blocks are in place
+                if loaded:
+                    num_cached = req.num_computed_tokens
+                elif req.num_computed_tokens == 0:
                     computed_blocks, num_cached = self.kv.get_computed_blocks(req)
-                # prompt KV another engine left in the shared storage: loaded by the workers into
-                # fresh blocks before this step runs, so it counts as computed like a cache hit
-                ext = 0
-                if self.kv_connector is not None and req.num_computed_tokens == 0:
+                # prompt KV another engine left in the shared storage: the workers copy it into fresh
+                # blocks on a side thread while steps go on; the request is parked (``kv_loading``) and
+                # comes back to the head of the queue once every rank has reported the copy done, with
+                # the loaded tokens counted as computed like a cache hit
+                if self.kv_connector is not None and not loaded and req.num_computed_tokens == 0:
                     ext = self.kv_connector.get_num_new_matched_tokens(req, num_cached)
+                    if ext:
+                        if self.kv.allocate_slots(req, ext, computed_blocks) is None:
+                            break
+                        self.kv_connector.note_load(req, num_cached, ext, self.kv.get_block_ids(req.request_id))
+                        self.waiting.popleft()
+                        req.num_computed_tokens = num_cached + ext
+                        if req.num_cached_tokens < 0:
+                            req.num_cached_tokens = num_cached + ext
+                            req.metrics.num_cached_tokens = num_cached + ext
+                        self.kv_loading[req.request_id] = req
+                        continue
+                ext = 0
                 n = req.num_tokens - num_cached - ext
                 if not self.config.enable_chunked_prefill and n > budget:
                     break
@@ -300,9 +329,9 @@ class Scheduler:
                     req, min(n + ext + self.lookahead, self.max_model_len - num_cached), computed_blocks)
                 if blocks is None:
                     break
-                if ext:
-                    self.kv_connector.note_load(req, num_cached, ext, self.kv.get_block_ids(req.request_id))
-                    num_cached += ext
+                if loaded:
+                    self._kv_loaded.discard(req.request_id)
+                    blocks = self.kv.get_block_ids(req.request_id)      # the workers meet this request for the first time
                 self.waiting.popleft()
                 resumed = req.status == RequestStatus.PREEMPTED
                 req.status = RequestStatus.RUNNING
@@ -340,7 +369,8 @@ class Scheduler:
         self._finished_since_last = set()
         self._preempted_since_last = set()
         if self.kv_connector is not None:
-            out.kv_connector_metadata = self.kv_connector.build_connector_meta(out)
+            out.kv_connector_metadata = self.kv_connector.build_connector_meta(
+                out, pending=bool(self.kv_loading or self._kv_load_orphans or self.kv_connector.sending))
         self.step_id += 1
         return out
 
@@ -406,6 +436,15 @@ class Scheduler:
         if self.kv_connector is not None:
             for held in self.kv_connector.update_from_output(runner_output):
                 self.kv.free(held)                 # its save has been confirmed by every rank
+            for rid in (runner_output.finished_recving or ()):
+                req = self.kv_loading.pop(rid, None)
+                if req is not None:                # every rank holds the loaded blocks: schedulable, ahead of newcomers
+                    self._kv_loaded.add(rid)
+                    self._enqueue_waiting(req, front=True)
+                    continue
+                req = self._kv_load_orphans.pop(rid, None)
+                if req is not None:
+                    self.kv.free(req)
         lps = dict(zip(runner_output.req_ids, runner_output.logprobs)) if runner_output.logprobs else None
         now = time.time()
         requests = self.requests
@@ -540,6 +579,8 @@ class Scheduler:
             req = self.requests.get(rid)
             if req is None or req.finished:
                 continue
+            if self._orphan_if_loading(req, status):
+                continue
             if req.status == RequestStatus.RUNNING:
                 self.running.remove(req)
             else:
@@ -549,6 +590,18 @@ class Scheduler:
                     pass
             req.status = status
             self._free_request(req)
+
+    def _orphan_if_loading(self, req: Request, status: RequestStatus) -> bool:
+        """A request that ends while the workers are still copying its KV in: it leaves the books now,
+        its blocks stay allocated until the copy has been reported finished."""
+        if self.kv_loading.pop(req.request_id, None) is None:
+            self._kv_loaded.discard(req.request_id)
+            return False
+        req.status = status
+        self._kv_load_orphans[req.request_id] = req
+        self._pending_new_tokens.pop(req.request_id, None)
+        self.requests.pop(req.request_id, None)
+        return True
 
     def _free_request(self, req: Request) -> None:
         if self.kv_connector is None or not self.kv_connector.request_finished(req):

@@ -156,11 +156,13 @@ class SchedulerKVConnector:
         self.sending.add(request.request_id)
         self.num_saved_requests += 1
 
-    def build_connector_meta(self, scheduler_output) -> dict:
+    def build_connector_meta(self, scheduler_output, pending: bool = False) -> dict:
+        """``pending``: transfers started by earlier steps are still in flight (an otherwise empty step is
+        then worth running: its output carries the workers' completion reports)."""
         loads, self._loads = self._loads, []
         saves, self._saves = self._saves, []
         return {"role": self.config.kv_role, "step": scheduler_output.step_id, "path": self.path,
-                "load": loads, "save": saves}
+                "load": loads, "save": saves, "pending": bool(pending or loads or saves)}
 
     def update_from_output(self, runner_output) -> List[object]:
         """Fold the aggregated worker reports in; returns the requests whose blocks were being
@@ -182,58 +184,145 @@ class SchedulerKVConnector:
 
 
 class WorkerKVConnector:
-    """Worker side: copies KV blocks between this rank's cache and the shared storage.
+    """Worker side: copies KV blocks between this rank's cache and the shared storage, off the step.
 
     One file per (prompt prefix, rank): ``<path>/<key>/rank<r>.safetensors`` with ``k.<i>`` /
     ``v.<i>`` = the blocks of the rank's i-th attention layer in cache layout.  ``meta.json``
-    appears once every rank's file is in place (the last writer renames it in)."""
+    appears once every rank's file is in place (the last writer renames it in).
+
+    ``execute_model`` only queues the transfers a step asks for (``start``) and collects the names of
+    those that have finished since it last asked (``poll``); file I/O and the copies between host and
+    device run on one side thread, on a stream of its own.  That is safe without further ordering
+    because the scheduler keeps everybody else off the blocks involved: blocks being loaded belong to a
+    parked request that is scheduled only after every rank has reported the load, and blocks being
+    saved are whole prompt blocks, never rewritten, held until every rank has reported the save (the
+    side thread waits for the event that marks the end of the step that wrote them)."""
 
     def __init__(self, vllm_config: VllmConfig, rank: int, world_size: int):
+        import queue
+        import threading
         self.rank, self.world_size = rank, world_size
+        self._jobs: "queue.Queue" = queue.Queue()
+        self._lock = threading.Lock()
+        self._sent: Set[str] = set()
+        self._recvd: Set[str] = set()
+        self._error: Optional[BaseException] = None
+        self._inflight = 0
+        self._thread: Optional[threading.Thread] = None
+        self.transfers_started = 0
+        self.max_step_block_s = 0.0          # longest time one start() / poll() call held the step thread
 
-    def load(self, meta: dict, kv_caches) -> Set[str]:
+    # -- step thread ---------------------------------------------------------------------
+    def start(self, meta: dict, kv_caches, kind: str, after=None) -> None:
+        """Queue the ``kind`` (``"load"`` / ``"save"``) operations of a step's connector metadata.
+        ``after``: a device event the side thread waits for first (the step that fills the blocks)."""
+        import time
+        ops = meta.get(kind) or ()
+        if not ops:
+            return
+        t0 = time.perf_counter()
+        self._ensure_thread(kv_caches[0][0].device)
+        with self._lock:
+            self._inflight += len(ops)
+        self.transfers_started += len(ops)
+        for op in ops:
+            self._jobs.put((kind, op, meta["path"], kv_caches, after))
+        self.max_step_block_s = max(self.max_step_block_s, time.perf_counter() - t0)
+
+    def poll(self):
+        """``(finished_sending, finished_recving)`` since the last call (None when empty).  A transfer that
+        failed fails the step: the engine must not go on believing in blocks that never arrived."""
+        with self._lock:
+            if self._error is not None:
+                err, self._error = self._error, None
+                raise RuntimeError(f"KV transfer failed on rank {self.rank}: {err!r}") from err
+            sent, self._sent = self._sent, set()
+            recvd, self._recvd = self._recvd, set()
+        return sent or None, recvd or None
+
+    def idle(self) -> bool:
+        with self._lock:
+            return self._inflight == 0
+
+    def shutdown(self) -> None:
+        if self._thread is not None:
+            self._jobs.put(None)
+            self._thread.join(timeout=30)
+            self._thread = None
+
+    # -- side thread ---------------------------------------------------------------------
+    def _ensure_thread(self, device) -> None:
+        import threading
+        if self._thread is None or not self._thread.is_alive():
+            self._thread = threading.Thread(target=self._run, args=(device,), name=f"kv-transfer-{self.rank}",
+                                            daemon=True)
+            self._thread.start()
+
+    def _run(self, device) -> None:
+        import contextlib
+
+        import torch
+        stream = None
+        if device.type == "cuda":
+            torch.cuda.set_device(device)
+            stream = torch.cuda.Stream(device)
+        with torch.inference_mode():
+            while True:
+                job = self._jobs.get()
+                if job is None:
+                    return
+                kind, op, path, kv_caches, after = job
+                try:
+                    if after is not None:
+                        after.synchronize()
+                    with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+                        (self._load if kind == "load" else self._save)(op, path, kv_caches)
+                        if stream is not None:
+                            stream.synchronize()
+                    with self._lock:
+                        (self._recvd if kind == "load" else self._sent).add(op["req_id"])
+                        self._inflight -= 1
+                except BaseException as e:  # noqa: BLE001 - reported by the next poll()
+                    with self._lock:
+                        self._error = e
+                        self._inflight -= 1
+
+    def _load(self, op: dict, path: str, kv_caches) -> None:
         import os
 
         import torch
         from safetensors import safe_open
-        done: Set[str] = set()
-        for op in meta.get("load", ()):
-            fn = os.path.join(meta["path"], op["key"], f"rank{self.rank}.safetensors")
-            fb, nb = op["first_block"], op["num_blocks"]
-            dst = torch.as_tensor(op["block_ids"][fb:fb + nb], dtype=torch.int64, device=kv_caches[0][0].device)
-            with safe_open(fn, framework="pt", device="cpu") as f:
-                for i, (k, v) in enumerate(kv_caches):
-                    k.index_copy_(0, dst, f.get_slice(f"k.{i}")[fb:fb + nb].to(k.device))
-                    v.index_copy_(0, dst, f.get_slice(f"v.{i}")[fb:fb + nb].to(v.device))
-            done.add(op["req_id"])
-        return done
+        fn = os.path.join(path, op["key"], f"rank{self.rank}.safetensors")
+        fb, nb = op["first_block"], op["num_blocks"]
+        dev = kv_caches[0][0].device
+        dst = torch.as_tensor(op["block_ids"][fb:fb + nb], dtype=torch.int64, device=dev)
+        with safe_open(fn, framework="pt", device="cpu") as f:
+            for i, (k, v) in enumerate(kv_caches):
+                k.index_copy_(0, dst, f.get_slice(f"k.{i}")[fb:fb + nb].to(dev))
+                v.index_copy_(0, dst, f.get_slice(f"v.{i}")[fb:fb + nb].to(dev))
 
-    def save(self, meta: dict, kv_caches) -> Set[str]:
+    def _save(self, op: dict, path: str, kv_caches) -> None:
         import json
         import os
 
         import torch
         from safetensors.torch import save_file
-        done: Set[str] = set()
-        for op in meta.get("save", ()):
-            d = os.path.join(meta["path"], op["key"])
-            os.makedirs(d, exist_ok=True)
-            src = torch.as_tensor(op["block_ids"], dtype=torch.int64, device=kv_caches[0][0].device)
-            tensors = {}
-            for i, (k, v) in enumerate(kv_caches):
-                tensors[f"k.{i}"] = k.index_select(0, src).cpu().contiguous()
-                tensors[f"v.{i}"] = v.index_select(0, src).cpu().contiguous()
-            tmp = os.path.join(d, f".rank{self.rank}.tmp")
-            save_file(tensors, tmp)
-            os.replace(tmp, os.path.join(d, f"rank{self.rank}.safetensors"))
-            have = [f for f in os.listdir(d) if f.startswith("rank") and f.endswith(".safetensors")]
-            if len(have) == self.world_size:           # every rank's part is there: commit
-                tmpm = os.path.join(d, f".meta.{self.rank}.tmp")
-                with open(tmpm, "w") as f:
-                    json.dump({"num_blocks": op["num_blocks"], "world_size": self.world_size}, f)
-                os.replace(tmpm, os.path.join(d, "meta.json"))
-            done.add(op["req_id"])
-        return done
+        d = os.path.join(path, op["key"])
+        os.makedirs(d, exist_ok=True)
+        src = torch.as_tensor(op["block_ids"], dtype=torch.int64, device=kv_caches[0][0].device)
+        tensors = {}
+        for i, (k, v) in enumerate(kv_caches):
+            tensors[f"k.{i}"] = k.index_select(0, src).cpu().contiguous()
+            tensors[f"v.{i}"] = v.index_select(0, src).cpu().contiguous()
+        tmp = os.path.join(d, f".rank{self.rank}.tmp")
+        save_file(tensors, tmp)
+        os.replace(tmp, os.path.join(d, f"rank{self.rank}.safetensors"))
+        have = [f for f in os.listdir(d) if f.startswith("rank") and f.endswith(".safetensors")]
+        if len(have) == self.world_size:           # every rank's part is there: commit
+            tmpm = os.path.join(d, f".meta.{self.rank}.tmp")
+            with open(tmpm, "w") as f:
+                json.dump({"num_blocks": op["num_blocks"], "world_size": self.world_size}, f)
+            os.replace(tmpm, os.path.join(d, "meta.json"))
 
 
 def make_scheduler_connector(vllm_config: VllmConfig) -> SchedulerKVConnector:

@@ -493,8 +493,12 @@ class ModelRunner:
             self._update_states(so)
             self.step_count += 1
             kv_meta = so.kv_connector_metadata if self.kv_connector is not None else None
-            kv_recv = self.kv_connector.load(kv_meta, self.kv_caches) if kv_meta else None
+            if kv_meta:
+                self.kv_connector.start(kv_meta, self.kv_caches, "load")     # copied in by a side thread
             if so.total_num_scheduled_tokens == 0:
+                if self.kv_connector is not None:         # every rank reports its finished transfers
+                    kv_sent, kv_recv = self.kv_connector.poll()
+                    return ModelRunnerOutput(step_id=so.step_id, finished_sending=kv_sent, finished_recving=kv_recv)
                 return ModelRunnerOutput(step_id=so.step_id) if self._is_output_rank() else None   # nothing to wait for
             p = self._prepare_inputs(so)
         nreq, nd, total = len(p["req_ids"]), p["num_decodes"], p["total"]
@@ -529,9 +533,16 @@ class ModelRunner:
 
         # advance computed-token counts (the scheduler did the same when it scheduled)
         self.batch.num_computed[p["rows"]] += p["n_sched"]
-        kv_sent = None
-        if kv_meta and kv_meta.get("save"):
-            kv_sent = self.kv_connector.save(kv_meta, self.kv_caches)     # this step wrote the last prompt blocks
+        kv_sent = kv_recv = None
+        if self.kv_connector is not None:
+            if kv_meta and kv_meta.get("save"):
+                # this step wrote the last prompt blocks: the side thread copies them out once it has run
+                done = None
+                if self.is_gpu:
+                    done = torch.cuda.Event()
+                    done.record()
+                self.kv_connector.start(kv_meta, self.kv_caches, "save", after=done)
+            kv_sent, kv_recv = self.kv_connector.poll()       # whatever has finished since the last step
 
         if not self.pp.is_last_rank:
             if marks is not None:
