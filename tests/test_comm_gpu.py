@@ -549,3 +549,53 @@ def test_peer_that_never_arrives_is_reported_and_fails_the_executor(monkeypatch)
     finally:
         if eng is not None:
             eng.shutdown()
+
+
+def test_device_to_device_kv_hand_over_between_two_engines(tmp_path):
+    """Disaggregated prefill on one machine: a producer engine (its own process) prefills and hands the
+    prompts' KV blocks over as hipIpc device buffers, a consumer engine (another process) maps them and
+    copies device to device, and generates what an engine that computed everything itself generates.
+    No KV byte is written to the mailbox directory, and the producer frees each buffer once the consumer
+    has acknowledged it."""
+    import json
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kv_handover_proc.py")
+    env = dict(os.environ, VLLM_LOGGING_LEVEL="WARNING", HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+    def result(line_source):
+        for line in line_source:
+            if line.startswith("RESULT "):
+                return json.loads(line[7:])
+        raise AssertionError("child ended without a result")
+
+    def run(role):
+        r = subprocess.run([sys.executable, script, role, str(tmp_path)], env=env, capture_output=True, text=True,
+                           timeout=170)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        return result(r.stdout.splitlines())
+
+    ref = run("reference")
+    prod = subprocess.Popen([sys.executable, script, "producer", str(tmp_path)], env=env, stdin=subprocess.PIPE,
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        first = result(iter(prod.stdout.readline, ""))
+        assert [t[0] for t in first["tokens"]] == [t[0] for t in ref["tokens"]]
+        assert first["num_saved_requests"] == 2 and first["device_bytes_sent"] > 0
+        assert first["exported_bytes"] == first["device_bytes_sent"]
+        files = [f for _, _, fs in os.walk(str(tmp_path)) for f in fs]
+        assert files and not [f for f in files if f.endswith(".safetensors")], files
+        got = run("consumer")
+        assert got["tokens"] == ref["tokens"]
+        assert got["num_loaded_tokens"] == 64 + 32 and got["device_bytes_received"] == first["device_bytes_sent"]
+        prod.stdin.write("reap\n")
+        prod.stdin.flush()
+        after = result(iter(prod.stdout.readline, ""))
+        assert after["exported_bytes"] == 0                        # acknowledged buffers were freed
+        assert not [f for _, _, fs in os.walk(str(tmp_path)) for f in fs]
+        prod.stdin.write("exit\n")
+        prod.stdin.flush()
+        assert prod.wait(timeout=60) == 0, prod.stderr.read()[-3000:]
+    finally:
+        if prod.poll() is None:
+            prod.kill()

@@ -163,11 +163,13 @@ def test_async_scheduling_with_preemption_and_chunked_prefill():
     assert got == ref
 
 
-def test_shared_storage_kv_connector_moves_prefill_between_engines(tmp_path):
+@pytest.mark.parametrize("connector", ["SharedStorageConnector", "DeviceIpcConnector"])
+def test_shared_storage_kv_connector_moves_prefill_between_engines(tmp_path, connector):
     """Disaggregated prefill: a producer engine prefills and writes each prompt's KV blocks to
     shared storage, a consumer engine loads them instead of computing them, and generates what
     an engine that computed everything itself generates.  The producer frees a finished
-    request's blocks only once its save has been confirmed."""
+    request's blocks only once its save has been confirmed.  (The device-buffer connector has no
+    device here and falls back to files.)"""
     from vllm_distributed_amd import SamplingParams
     from vllm_distributed_amd.engine.arg_utils import EngineArgs
     from vllm_distributed_amd.engine.llm_engine import LLMEngine
@@ -176,7 +178,7 @@ def test_shared_storage_kv_connector_moves_prefill_between_engines(tmp_path):
 
     def make(role):
         pstate.destroy_model_parallel()
-        kv = None if role is None else {"kv_connector": "SharedStorageConnector", "kv_role": role,
+        kv = None if role is None else {"kv_connector": connector, "kv_role": role,
                                         "kv_connector_extra_config": {"shared_storage_path": str(tmp_path)}}
         return LLMEngine.from_engine_args(EngineArgs(
             model="llama-tiny", device="cpu", dtype="float32", max_model_len=128, block_size=16,

@@ -5,6 +5,17 @@ sending / receiving KV blocks; a request only counts as finished once *all*
 workers have reported it.  ``KVOutputAggregator`` folds the per-worker
 ``ModelRunnerOutput``s into the output rank's (reference ``src/launch.py:28,
 295-296,338-349``).
+
+Two connectors share the scheduler / worker halves below:
+
+* ``SharedStorageConnector`` - KV blocks travel as safetensors files under ``shared_storage_path``.
+* ``DeviceIpcConnector`` - producer and consumer on one machine: the producer gathers a prompt's blocks
+  into a device buffer and publishes its hipIpc handle (a small JSON file under ``shared_storage_path``,
+  which only serves as the mailbox); the consumer maps the buffer and copies device to device (over
+  xGMI when the engines sit on different GPUs), then acknowledges, and the producer frees the buffer.
+  The bytes never touch the host.  Buffers nobody claimed are dropped after ``device_buffer_ttl_s``; a
+  hand-over is single-use.  Without a GPU (or beyond ``device_buffer_bytes`` of unclaimed buffers) a
+  save falls back to the file form, which every consumer also reads.
 """
 from __future__ import annotations
 
@@ -14,6 +25,19 @@ from typing import Dict, List, Optional, Sequence, Set
 
 from ..config import VllmConfig
 from ..engine.types import ModelRunnerOutput
+
+DEVICE_CONNECTORS = ("DeviceIpcConnector",)
+
+
+def _pid_alive(pid: int) -> bool:
+    import os
+    try:
+        os.kill(int(pid), 0)
+    except ProcessLookupError:
+        return False
+    except PermissionError:
+        return True
+    return True
 
 
 class KVOutputAggregator:
@@ -129,9 +153,25 @@ class SchedulerKVConnector:
         if n <= num_local_tokens:
             return 0
         key = kv_prefix_key(request.prompt_token_ids, n, self.salt)
-        if not os.path.isfile(os.path.join(self.path, key, "meta.json")):      # written last: the commit mark
+        if not self._committed(os.path.join(self.path, key)):
             return 0
         return n - num_local_tokens
+
+    @staticmethod
+    def _committed(d: str) -> bool:
+        """``meta.json`` is written last: the commit mark.  A device-buffer hand-over is only usable while
+        the process that owns the buffer lives, and only on its machine."""
+        import json
+        import os
+        import socket
+        try:
+            with open(os.path.join(d, "meta.json")) as f:
+                meta = json.load(f)
+        except (OSError, ValueError):
+            return False
+        if meta.get("mode") != "ipc":
+            return True
+        return meta.get("host") == socket.gethostname() and _pid_alive(meta.get("pid", -1))
 
     def note_load(self, request, first_token: int, num_tokens: int, block_ids: List[int]) -> None:
         key = kv_prefix_key(request.prompt_token_ids, first_token + num_tokens, self.salt)
@@ -149,7 +189,7 @@ class SchedulerKVConnector:
         if n == 0:
             return
         key = kv_prefix_key(request.prompt_token_ids, n, self.salt)
-        if os.path.isfile(os.path.join(self.path, key, "meta.json")):
+        if self._committed(os.path.join(self.path, key)):
             return
         self._saves.append({"req_id": request.request_id, "key": key, "num_blocks": n // self.block_size,
                             "block_ids": list(block_ids[:n // self.block_size])})
@@ -202,6 +242,17 @@ class WorkerKVConnector:
         import queue
         import threading
         self.rank, self.world_size = rank, world_size
+        cfg = vllm_config.kv_transfer_config
+        extra = (cfg.kv_connector_extra_config or {}) if cfg is not None else {}
+        self.device_mode = cfg is not None and cfg.kv_connector in DEVICE_CONNECTORS
+        self.device_buffer_bytes = int(extra.get("device_buffer_bytes", 8 << 30))
+        self.device_buffer_ttl_s = float(extra.get("device_buffer_ttl_s", 600.0))
+        self._exports: Dict[str, dict] = {}          # side thread only: key -> device buffer handed out
+        self._exported_bytes = 0
+        self._last_reap = 0.0
+        self._ipc = None
+        self.device_bytes_sent = 0
+        self.device_bytes_received = 0
         self._jobs: "queue.Queue" = queue.Queue()
         self._lock = threading.Lock()
         self._sent: Set[str] = set()
@@ -238,6 +289,12 @@ class WorkerKVConnector:
                 raise RuntimeError(f"KV transfer failed on rank {self.rank}: {err!r}") from err
             sent, self._sent = self._sent, set()
             recvd, self._recvd = self._recvd, set()
+        if self._exports and self._thread is not None:
+            import time
+            now = time.monotonic()
+            if now - self._last_reap > 0.5:          # claimed or expired device buffers go back to the pool
+                self._last_reap = now
+                self._jobs.put(("reap", None, None, None, None))
         return sent or None, recvd or None
 
     def idle(self) -> bool:
@@ -249,6 +306,8 @@ class WorkerKVConnector:
             self._jobs.put(None)
             self._thread.join(timeout=30)
             self._thread = None
+        for key in list(self._exports):                  # nobody can map these once this process is gone
+            self._drop_export(key)
 
     # -- side thread ---------------------------------------------------------------------
     def _ensure_thread(self, device) -> None:
@@ -272,6 +331,12 @@ class WorkerKVConnector:
                 if job is None:
                     return
                 kind, op, path, kv_caches, after = job
+                if kind == "reap":
+                    try:
+                        self._reap()
+                    except Exception:  # noqa: BLE001 - housekeeping only
+                        pass
+                    continue
                 try:
                     if after is not None:
                         after.synchronize()
@@ -296,6 +361,9 @@ class WorkerKVConnector:
         fb, nb = op["first_block"], op["num_blocks"]
         dev = kv_caches[0][0].device
         dst = torch.as_tensor(op["block_ids"][fb:fb + nb], dtype=torch.int64, device=dev)
+        desc = os.path.join(path, op["key"], f"rank{self.rank}.ipc.json")
+        if os.path.isfile(desc):
+            return self._load_device(desc, op["key"], fb, nb, dst, kv_caches)
         with safe_open(fn, framework="pt", device="cpu") as f:
             for i, (k, v) in enumerate(kv_caches):
                 k.index_copy_(0, dst, f.get_slice(f"k.{i}")[fb:fb + nb].to(dev))
@@ -310,6 +378,8 @@ class WorkerKVConnector:
         d = os.path.join(path, op["key"])
         os.makedirs(d, exist_ok=True)
         src = torch.as_tensor(op["block_ids"], dtype=torch.int64, device=kv_caches[0][0].device)
+        if self.device_mode and src.is_cuda and self._save_device(op, d, src, kv_caches):
+            return
         tensors = {}
         for i, (k, v) in enumerate(kv_caches):
             tensors[f"k.{i}"] = k.index_select(0, src).cpu().contiguous()
@@ -321,8 +391,165 @@ class WorkerKVConnector:
         if len(have) == self.world_size:           # every rank's part is there: commit
             tmpm = os.path.join(d, f".meta.{self.rank}.tmp")
             with open(tmpm, "w") as f:
-                json.dump({"num_blocks": op["num_blocks"], "world_size": self.world_size}, f)
+                json.dump({"num_blocks": op["num_blocks"], "world_size": self.world_size, "mode": "file"}, f)
             os.replace(tmpm, os.path.join(d, "meta.json"))
+
+    # -- device-to-device hand-over -----------------------------------------------------
+    def _ipc_lib(self):
+        if self._ipc is None:
+            import ctypes
+
+            from ..ops import hip
+            lib = hip.load()
+            lib.vdamd_ipc_handle_bytes.restype = ctypes.c_int
+            lib.vdamd_ipc_alloc.argtypes = [ctypes.c_size_t, ctypes.c_void_p]
+            lib.vdamd_ipc_alloc.restype = ctypes.c_void_p
+            lib.vdamd_ipc_free.argtypes = [ctypes.c_void_p]
+            lib.vdamd_ipc_free.restype = ctypes.c_int
+            lib.vdamd_ipc_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+            lib.vdamd_ipc_open.restype = ctypes.c_void_p
+            lib.vdamd_ipc_close.argtypes = [ctypes.c_void_p]
+            lib.vdamd_ipc_close.restype = ctypes.c_int
+            self._ipc = lib
+        return self._ipc
+
+    @staticmethod
+    def _view(buf, entry: dict):
+        """The tensor an entry of a hand-over descriptor names inside the mapped byte buffer."""
+        import torch
+        dtype = getattr(torch, entry["dtype"])
+        n = 1
+        for x in entry["shape"]:
+            n *= x
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        return buf[entry["offset"]:entry["offset"] + nbytes].view(dtype).view(entry["shape"])
+
+    @staticmethod
+    def _raw(t):
+        """One-byte element types as plain bytes (gather / scatter kernels exist for those everywhere)."""
+        import torch
+        return t.view(torch.uint8) if t.element_size() == 1 else t
+
+    def _save_device(self, op: dict, d: str, src, kv_caches) -> bool:
+        """Gather the blocks into a fresh exportable device buffer and publish its handle.  False: no room
+        (or no buffer to be had): the caller writes files instead."""
+        import ctypes
+        import json
+        import os
+        import socket
+        import time
+
+        import torch
+
+        from ..parallel.custom_all_reduce import _DevicePointer
+        self._reap()
+        entries, off = [], 0
+        nb = src.numel()
+        for i, (k, v) in enumerate(kv_caches):
+            for name, t in (("k", k), ("v", v)):
+                shape = [nb] + list(t.shape[1:])
+                nbytes = nb * t[0].numel() * t.element_size()
+                entries.append({"name": f"{name}.{i}", "offset": off, "shape": shape,
+                                "dtype": str(t.dtype).split(".")[1]})
+                off += (nbytes + 255) // 256 * 256
+        total = off
+        if total == 0 or self._exported_bytes + total > self.device_buffer_bytes:
+            return False
+        lib = self._ipc_lib()
+        handle = ctypes.create_string_buffer(int(lib.vdamd_ipc_handle_bytes()))
+        ptr = lib.vdamd_ipc_alloc(total, handle)
+        if not ptr:
+            return False
+        buf = torch.as_tensor(_DevicePointer(ptr, total), device=src.device)
+        for e in entries:
+            kind, layer = e["name"].split(".")
+            t = kv_caches[int(layer)][0 if kind == "k" else 1]
+            torch.index_select(self._raw(t), 0, src, out=self._raw(self._view(buf, e)))
+        torch.cuda.current_stream().synchronize()        # the bytes are in place before anybody can find them
+        del buf
+        key = os.path.basename(d)
+        self._exports[key] = {"ptr": ptr, "nbytes": total, "dir": d, "born": time.monotonic()}
+        self._exported_bytes += total
+        self.device_bytes_sent += total
+        tmp = os.path.join(d, f".rank{self.rank}.ipc.tmp")
+        with open(tmp, "w") as f:
+            json.dump({"handle": handle.raw.hex(), "nbytes": total, "entries": entries, "pid": os.getpid(),
+                       "host": socket.gethostname(), "num_blocks": nb}, f)
+        os.replace(tmp, os.path.join(d, f"rank{self.rank}.ipc.json"))
+        have = [f for f in os.listdir(d) if f.startswith("rank") and f.endswith((".ipc.json", ".safetensors"))]
+        if len(have) == self.world_size:
+            tmpm = os.path.join(d, f".meta.{self.rank}.tmp")
+            with open(tmpm, "w") as f:
+                json.dump({"num_blocks": op["num_blocks"], "world_size": self.world_size, "mode": "ipc",
+                           "pid": os.getpid(), "host": socket.gethostname()}, f)
+            os.replace(tmpm, os.path.join(d, "meta.json"))
+        return True
+
+    def _load_device(self, desc_path: str, key: str, fb: int, nb: int, dst, kv_caches) -> None:
+        import ctypes
+        import json
+        import os
+
+        import torch
+
+        from ..parallel.custom_all_reduce import _DevicePointer
+        with open(desc_path) as f:
+            desc = json.load(f)
+        lib = self._ipc_lib()
+        own = self._exports.get(key) if desc.get("pid") == os.getpid() else None
+        mapped = None
+        if own is not None:                  # this very process handed it out (kv_both): no mapping needed
+            ptr = own["ptr"]
+        else:
+            err = ctypes.c_int(0)
+            mapped = ptr = lib.vdamd_ipc_open(bytes.fromhex(desc["handle"]), ctypes.byref(err))
+            if not ptr:
+                raise RuntimeError(f"hipIpcOpenMemHandle failed with {err.value} for {desc_path}")
+        try:
+            buf = torch.as_tensor(_DevicePointer(ptr, desc["nbytes"]), device=dst.device)
+            for e in desc["entries"]:
+                kind, layer = e["name"].split(".")
+                t = kv_caches[int(layer)][0 if kind == "k" else 1]
+                self._raw(t).index_copy_(0, dst, self._raw(self._view(buf, e)[fb:fb + nb]))
+            torch.cuda.current_stream().synchronize()
+            del buf
+        finally:
+            if mapped is not None:
+                lib.vdamd_ipc_close(mapped)
+        self.device_bytes_received += desc["nbytes"]
+        ack = os.path.join(os.path.dirname(desc_path), f"rank{self.rank}.ack")
+        with open(ack + ".tmp", "w") as f:
+            f.write("ok")
+        os.replace(ack + ".tmp", ack)
+
+    def _reap(self) -> None:
+        """Free the device buffers whose hand-over has been acknowledged, or that nobody came for."""
+        import os
+        import time
+        now = time.monotonic()
+        for key, ex in list(self._exports.items()):
+            if os.path.isfile(os.path.join(ex["dir"], f"rank{self.rank}.ack")) \
+                    or now - ex["born"] > self.device_buffer_ttl_s:
+                self._drop_export(key)
+
+    def _drop_export(self, key: str) -> None:
+        import os
+        ex = self._exports.pop(key, None)
+        if ex is None:
+            return
+        d = ex["dir"]
+        # the commit mark goes first: nobody new may pick this hand-over up
+        for name in ("meta.json", f"rank{self.rank}.ipc.json", f"rank{self.rank}.ack"):
+            try:
+                os.remove(os.path.join(d, name))
+            except OSError:
+                pass
+        try:
+            os.rmdir(d)
+        except OSError:
+            pass
+        self._ipc_lib().vdamd_ipc_free(ex["ptr"])
+        self._exported_bytes -= ex["nbytes"]
 
 
 def make_scheduler_connector(vllm_config: VllmConfig) -> SchedulerKVConnector:

@@ -274,6 +274,9 @@ class Worker:
         return self._lora().pin_lora(lora_id)
 
     def shutdown(self) -> None:
+        conn = getattr(self.model_runner, "kv_connector", None)
+        if conn is not None:
+            conn.shutdown()                 # joins the transfer thread, frees device buffers handed out
         self.model_runner = None
         # only the groups this worker set up: an engine built later in the same process owns newer ones
         pstate.destroy_model_parallel(getattr(self, "_pstate_generation", None))
