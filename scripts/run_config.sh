@@ -11,7 +11,8 @@
 #   scripts/run_config.sh 6   Llama-3-70B, TP=1: the headline model on one MI355X (bf16 weights fit in 288 GB)
 #
 # Environment: PORT (8000), NUM_PROMPTS (256), CONCURRENCY (64), INPUT_LEN (128), OUTPUT_LEN (64),
-# OUTPUT_JITTER (0: every request the same length; 0.5: lengths uniform in 32..96, requests desynchronised).
+# OUTPUT_JITTER (0: every request the same length; 0.5: lengths uniform in 32..96, requests desynchronised),
+# REQUEST_RATE (0: all requests released at once; > 0: Poisson arrivals per second).
 set -euo pipefail
 cfg="${1:?config number 1-5}"
 here="$(cd "$(dirname "$0")/.." && pwd)"
@@ -60,4 +61,4 @@ done
 
 python "$here/benchmarks/serve_bench.py" --base-url "http://127.0.0.1:$port" --model "$model" \
   --vocab-size "$vocab" --num-prompts "${NUM_PROMPTS:-256}" --concurrency "${CONCURRENCY:-64}" \
-  --input-len "${INPUT_LEN:-128}" --output-len "${OUTPUT_LEN:-64}" --output-len-jitter "${OUTPUT_JITTER:-0}"
+  --input-len "${INPUT_LEN:-128}" --output-len "${OUTPUT_LEN:-64}" --output-len-jitter "${OUTPUT_JITTER:-0}" --request-rate "${REQUEST_RATE:-0}"

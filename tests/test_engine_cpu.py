@@ -525,3 +525,63 @@ def test_scheduler_step_cost_at_16384_sequences():
             best = cost if best is None else min(best, cost)
     assert all(len(r.output_token_ids) == 8 for r in sched.running)
     assert best < n * 14e-6, f"{best * 1e3:.1f} ms for {n} sequences"
+
+
+def _drive(sched, steps, arrivals=None):
+    """Run ``steps`` schedule/update rounds with a stub model; ``arrivals``: step -> requests added before it.
+    Returns, per request, the step in which its first token was sampled."""
+    from vllm_distributed_amd.engine.types import ModelRunnerOutput
+    first = {}
+    for step in range(steps):
+        for req in (arrivals or {}).get(step, ()):
+            sched.add_request(req)
+        so = sched.schedule()
+        ids = list(so.num_scheduled_tokens)
+        toks = []
+        for rid in ids:
+            req = sched.requests[rid]
+            toks.append([7] if req.num_computed_tokens >= req.num_tokens else [])     # a chunk that ends mid-prompt samples nothing
+        for o in sched.update_from_output(so, ModelRunnerOutput(step_id=so.step_id, req_ids=ids, sampled_token_ids=toks)):
+            first.setdefault(o.request_id, step)
+    return first
+
+
+def test_prefill_admission_next_to_a_full_decode_batch_and_the_long_prompt_cap():
+    """What decides time to first token under load.  (a) A request that arrives while a large decode batch
+    runs is admitted by the very next schedule() call, in the same step as the decodes (the token budget is
+    shared, decodes first).  (b) A burst larger than the budget is admitted in arrival order, budget tokens
+    per step: the last request of a burst waits for the burst's prefill, no longer.  (c) Without
+    ``long_prefill_token_threshold`` a long prompt at the head of the queue takes the whole budget of every
+    step until it is done and short prompts behind it wait; with it the long prompt advances by that many
+    tokens per step and the short ones get in beside it."""
+    from vllm_distributed_amd.config import CacheConfig, SchedulerConfig
+    from vllm_distributed_amd.engine.request import Request
+    from vllm_distributed_amd.engine.scheduler import Scheduler
+    sp = SamplingParams(temperature=0.0, max_tokens=64, ignore_eos=True)
+
+    def make(threshold=0, budget=1024):
+        sc = SchedulerConfig(max_num_seqs=512, max_num_batched_tokens=budget, max_model_len=8192,
+                             enable_chunked_prefill=True, long_prefill_token_threshold=threshold,
+                             async_scheduling=False)
+        return Scheduler(sc, CacheConfig(block_size=16, enable_prefix_caching=False), num_blocks=4096)
+
+    # (a) 256 decodes running; a newcomer gets its whole 128-token prompt in with the next step
+    sched = make()
+    base = {0: [Request(f"d{i}", [1, 2, 3], sp) for i in range(256)],
+            5: [Request("new", list(range(3, 131)), sp)]}
+    first = _drive(sched, 8, base)
+    assert first["new"] == 5 and all(first[f"d{i}"] == 0 for i in range(256))
+
+    # (b) a burst of 64 x 128-token prompts against a 1024-token budget: eight per step, in order
+    sched = make()
+    first = _drive(sched, 12, {0: [Request(f"b{i}", list(range(3, 131)), sp) for i in range(64)]})
+    assert [first[f"b{i}"] for i in (0, 7, 8, 63)] == [0, 0, 1, 8]     # (decodes of the admitted eat into later budgets)
+
+    # (c) a 4000-token prompt followed by three short ones
+    def long_then_short(threshold):
+        sched = make(threshold)
+        reqs = [Request("long", list(range(3, 4003)), sp)] + [Request(f"s{i}", [5, 6, 7, 8], sp) for i in range(3)]
+        return _drive(sched, 12, {0: reqs})
+    plain, capped = long_then_short(0), long_then_short(512)
+    assert plain["long"] == 3 and all(plain[f"s{i}"] == 3 for i in range(3))        # head-of-line: 4 steps of 1024
+    assert all(capped[f"s{i}"] == 0 for i in range(3)) and capped["long"] == 7       # 8 steps of 512 for the long one

@@ -5,8 +5,12 @@ instance (the reference's CLI registers vLLM's benchmark sub-commands next to
 Sends ``--num-prompts`` streaming ``/v1/completions`` requests with at most
 ``--concurrency`` in flight, synthetic prompts of ``--input-len`` token ids,
 ``--output-len`` new tokens each (``ignore_eos``), and reports the metrics the
-deployment is judged by: output tokens/s over the whole run, p50/p99 time to
-first token, p50 inter-token latency.
+deployment is judged by: output tokens/s over the whole run, p50/p90/p99 time to
+first token, p50 inter-token latency.  By default all requests are released at
+once (a closed loop of ``--concurrency`` clients: time to first token then
+mostly measures how long the initial burst's prefill takes); ``--request-rate``
+releases them as a Poisson process instead, which is what shows whether a newly
+arrived request gets in next to a full decode batch.
 
     python launch.py bench serve --base-url http://127.0.0.1:8000 --served-model llama-3-8b \
         --num-prompts 256 --concurrency 64 --input-len 128 --output-len 64
@@ -67,8 +71,17 @@ async def run(args) -> dict:
                 out_len = max(1, round(args.output_len * (1.0 + rng.uniform(-jitter, jitter))))
             payload = {"model": args.model, "prompt": prompt, "max_tokens": out_len, "temperature": 0.0,
                        "ignore_eos": True, "stream": True, "stream_options": {"include_usage": True}}
+            if arrivals is not None:
+                await asyncio.sleep(max(0.0, t0 + arrivals[i] - time.perf_counter()))
             async with sem:
                 await _one(session, url, headers, payload, result)
+        arrivals = None
+        rate = float(getattr(args, "request_rate", 0.0) or 0.0)
+        if rate > 0:
+            t, arrivals = 0.0, []
+            for _ in range(args.num_prompts):
+                arrivals.append(t)
+                t += rng.expovariate(rate)
         t0 = time.perf_counter()
         await asyncio.gather(*(guarded(i) for i in range(args.num_prompts)))
         elapsed = time.perf_counter() - t0
@@ -78,10 +91,12 @@ async def run(args) -> dict:
         return round(1e3 * xs[min(len(xs) - 1, int(p * len(xs)))], 2) if xs else None
     return {"num_prompts": args.num_prompts, "concurrency": args.concurrency, "input_len": args.input_len,
             "output_len": args.output_len, "output_len_jitter": float(getattr(args, "output_len_jitter", 0.0) or 0.0),
+            "request_rate": float(getattr(args, "request_rate", 0.0) or 0.0),
             "elapsed_s": round(elapsed, 3),
             "output_tokens_per_s": round(result["tokens"] / elapsed, 1),
             "requests_per_s": round(args.num_prompts / elapsed, 2),
-            "ttft_p50_ms": pct(result["ttft"], 0.5), "ttft_p99_ms": pct(result["ttft"], 0.99),
+            "ttft_p50_ms": pct(result["ttft"], 0.5), "ttft_p90_ms": pct(result["ttft"], 0.9),
+            "ttft_p99_ms": pct(result["ttft"], 0.99),
             "itl_p50_ms": pct(result["itl"], 0.5)}
 
 
@@ -92,6 +107,8 @@ def add_args(ap: argparse.ArgumentParser) -> None:
     ap.add_argument("--concurrency", type=int, default=16)
     ap.add_argument("--vocab-size", type=int, default=32000)
     ap.add_argument("--timeout", type=float, default=1800.0)
+    ap.add_argument("--request-rate", type=float, default=0.0,
+                    help="release requests as a Poisson process of this many per second (0: all at once)")
     ap.add_argument("--output-len-jitter", type=float, default=0.0,
                     help="draw each request's output length uniformly from output-len x (1 +- this fraction)")
 
