@@ -459,7 +459,13 @@ VDAMD_API int vdamd_car_fused_norm(void* ctx, int parity, const void* in, void* 
   const int per = (rows + c->world - 1) / c->world;
   int blocks = two_shot ? per : rows;
   if (blocks > c->max_blocks) blocks = c->max_blocks;
-  const int threads = row_threads(H);
+  int threads = row_threads(H);
+  if (blocks <= 64) {
+    // few rows per rank (a decode batch split over the group): one pass of a wider workgroup, so that every
+    // 16-byte piece of the row is requested from every peer at once instead of a quarter of them at a time
+    threads = ((H >> 3) + 63) / 64 * 64;
+    if (threads > 1024) threads = 1024;
+  }
 #define RUN(TY, FS)                                                                                              \
   if (two_shot)                                                                                                  \
     hipLaunchKernelGGL((twoshot_norm_kernel<TY, FS>), dim3(blocks), dim3(threads), 0, s, c->peers, c->self_sig,  \
