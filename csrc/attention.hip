@@ -25,6 +25,7 @@
 namespace {
 
 constexpr float NEG_BIG = -1.0e30f;
+constexpr float LOG2E_F = 1.4426950408889634f;
 constexpr int MAX_SPLITS = 64;
 
 template <typename T>
@@ -53,6 +54,12 @@ __device__ __forceinline__ typename Vec8<T>::type fp8x8_to(uint2 w, float scale)
     r.u[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.y, scale, false));
     r.u[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.y, scale, true));
   }
+  // Two wait states between the packed converts and whatever reads their results.  Without them some
+  // instantiations (D = 96 prefill over an e4m3 cache, after an unrelated change of the surrounding
+  // schedule) produced wrong products for a few percent of the outputs, deterministically: the same
+  // result-forwarding behaviour the NVFP4 GEMM met with v_cvt_pk_f32_fp8, which the compiler's hazard
+  // table does not cover.
+  asm volatile("s_nop 1" : "+v"(r.u[0]), "+v"(r.u[1]), "+v"(r.u[2]), "+v"(r.u[3]));
   return r.v;
 }
 
@@ -118,7 +125,9 @@ template <typename T, int D, int NQ>
 __device__ __forceinline__ void attend_loaded(
     const KVFrag<T, D>& f, int base, int seq_len, float scale_log2e, float softcap,
     const typename Vec8<T>::type (&qf)[NQ][D / 32], f32x4 (&acc)[NQ][D / 16], float (&m)[NQ], float (&l)[NQ],
-    const int (&qpos_hi)[NQ], const int (&qpos_lo)[NQ]) {
+    const int (&qpos_hi)[NQ], const int (&qpos_lo)[NQ], float alibi_l2 = 0.f) {
+  // alibi_l2: this lane's query head's ALiBi slope times log2(e) (0: none); the bias of key k for the
+  // query at position p is slope * (k - p)
   using V = typename Vec8<T>::type;
   const int g4 = (threadIdx.x & 63) >> 4;
   const int kidx0 = base + 8 * g4;     // key index of P element j is kidx0 + j
@@ -138,6 +147,7 @@ __device__ __forceinline__ void attend_loaded(
     for (int j = 0; j < 8; ++j) {
       float sv = (j < 4 ? s0[j & 3] : s1[j & 3]) * scale_log2e;
       if (softcap > 0.f) sv = soft_cap_log2(sv, softcap);
+      sv = fmaf(alibi_l2, (float)(kidx0 + j - qpos_hi[n]), sv);
       p[j] = (kidx0 + j <= hi && kidx0 + j >= lo) ? sv : NEG_BIG;
       tmax = fmaxf(tmax, p[j]);
     }
@@ -170,10 +180,10 @@ __device__ __forceinline__ void attend_group(
     const void* __restrict__ k_cache, const void* __restrict__ v_cache, const int* __restrict__ bt_row, int kvh,
     int Hkv, int block_size, int base, int seq_len, float scale_log2e, float softcap,
     const typename Vec8<T>::type (&qf)[NQ][D / 32], f32x4 (&acc)[NQ][D / 16], float (&m)[NQ], float (&l)[NQ],
-    const int (&qpos_hi)[NQ], const int (&qpos_lo)[NQ], float k_scale, float v_scale) {
+    const int (&qpos_hi)[NQ], const int (&qpos_lo)[NQ], float k_scale, float v_scale, float alibi_l2 = 0.f) {
   KVFrag<T, D> f;
   load_kv_group<T, D, KV8>(f, k_cache, v_cache, bt_row, kvh, Hkv, block_size, base, seq_len, k_scale, v_scale);
-  attend_loaded<T, D, NQ>(f, base, seq_len, scale_log2e, softcap, qf, acc, m, l, qpos_hi, qpos_lo);
+  attend_loaded<T, D, NQ>(f, base, seq_len, scale_log2e, softcap, qf, acc, m, l, qpos_hi, qpos_lo, alibi_l2);
 }
 
 // ---------------------------------------------------------------------------
@@ -187,7 +197,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     long q_stride, const void* __restrict__ k_cache, const void* __restrict__ v_cache,
     const int* __restrict__ block_table, int bt_stride, const int* __restrict__ seq_lens, float scale_log2e,
     int Hq, int Hkv, int block_size, int num_splits, long out_stride, const float* __restrict__ k_scales,
-    const float* __restrict__ v_scales, int window, float softcap) {
+    const float* __restrict__ v_scales, int window, float softcap, const float* __restrict__ sinks,
+    const float* __restrict__ alibi) {
+  // sinks[Hq] (natural-log units): an extra score per query head that takes part in the softmax's
+  // denominator only (attention sinks); alibi[Hq]: slopes of a linear position bias.  Either may be null.
   using V = typename Vec8<T>::type;
   constexpr int LDS_ROW = D + 4;
   __shared__ float s_o[4][16][LDS_ROW];
@@ -226,12 +239,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int qpos_hi[1] = {seq_len - 1};
   const int qpos_lo[1] = {key_lo};
   const int* bt_row = block_table + (long)b * bt_stride;
+  const float alibi_l2 = (alibi != nullptr && r16 < nq) ? alibi[qh0 + r16] * LOG2E_F : 0.f;
 
   // no register double-buffering here: it halves the occupancy (202 VGPRs) and
   // measured 3-8% slower than letting 4 resident workgroups per CU hide the latency
   for (int g = g_begin + wid; g < g_end; g += 4)
     attend_group<T, D, 1, KV8>(k_cache, v_cache, bt_row, kvh, Hkv, block_size, g * 32, seq_len,
-                               scale_log2e * k_scale, softcap, qf, acc, m, l, qpos_hi, qpos_lo, 1.f, 1.f);
+                               scale_log2e * k_scale, softcap, qf, acc, m, l, qpos_hi, qpos_lo, 1.f, 1.f, alibi_l2);
 
   float lsum = l[0];
   lsum += __shfl_xor(lsum, 16, 64);
@@ -249,9 +263,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const float mm = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
     const float a0 = exp2f(m0 - mm), a1 = exp2f(m1 - mm), a2 = exp2f(m2 - mm), a3 = exp2f(m3 - mm);
     const float o = (s_o[0][qi][d] * a0 + s_o[1][qi][d] * a1 + s_o[2][qi][d] * a2 + s_o[3][qi][d] * a3) * v_scale;
-    const float lt = s_l[0][qi] * a0 + s_l[1][qi] * a1 + s_l[2][qi] * a2 + s_l[3][qi] * a3;
+    float lt = s_l[0][qi] * a0 + s_l[1][qi] * a1 + s_l[2][qi] * a2 + s_l[3][qi] * a3;
     const int qh = qh0 + qi;
     if (num_splits == 1) {
+      if (sinks != nullptr) lt += exp2f(sinks[qh] * LOG2E_F - mm);       // (with splits: added by the merge kernel)
       out[b * out_stride + (long)qh * D + d] = (T)(lt > 0.f ? o / lt : 0.f);
     } else {
       const long pidx = ((long)b * Hq + qh) * num_splits + split;
@@ -271,7 +286,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     T* __restrict__ out, const T* __restrict__ q, long q_stride, const void* __restrict__ k_cache,
     const void* __restrict__ v_cache, const int* __restrict__ block_table, int bt_stride,
     const int* __restrict__ seq_lens, float scale_log2e, int B, int Hq, int Hkv, int block_size, long out_stride,
-    const float* __restrict__ k_scales, const float* __restrict__ v_scales, int window, float softcap) {
+    const float* __restrict__ k_scales, const float* __restrict__ v_scales, int window, float softcap,
+    const float* __restrict__ sinks, const float* __restrict__ alibi) {
   using V = typename Vec8<T>::type;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int b = blockIdx.x * 4 + wid;
@@ -298,13 +314,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int qpos_lo[1] = {window > 0 ? max(0, seq_len - window) : 0};
   const int* bt_row = block_table + (long)b * bt_stride;
   const int n_groups = (seq_len + 31) >> 5;
+  const float alibi_l2 = (alibi != nullptr && r16 < nq) ? alibi[qh0 + r16] * LOG2E_F : 0.f;
   for (int g = qpos_lo[0] >> 5; g < n_groups; ++g)
     attend_group<T, D, 1, KV8>(k_cache, v_cache, bt_row, kvh, Hkv, block_size, g * 32, seq_len,
-                               scale_log2e * k_scale, softcap, qf, acc, m, l, qpos_hi, qpos_lo, 1.f, 1.f);
+                               scale_log2e * k_scale, softcap, qf, acc, m, l, qpos_hi, qpos_lo, 1.f, 1.f, alibi_l2);
   float lsum = l[0];
   lsum += __shfl_xor(lsum, 16, 64);
   lsum += __shfl_xor(lsum, 32, 64);
   if (r16 >= nq) return;
+  if (sinks != nullptr) lsum += exp2f(sinks[qh0 + r16] * LOG2E_F - m[0]);
   const float inv = lsum > 0.f ? v_scale / lsum : 0.f;
   T* orow = out + b * out_stride + (long)(qh0 + r16) * D + 4 * g4;
 #pragma unroll
@@ -318,7 +336,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 template <typename T, int D>
 __global__ void decode_reduce_kernel(T* __restrict__ out, const float* __restrict__ part_o,
-                                     const float* __restrict__ part_ml, int Hq, int num_splits, long out_stride) {
+                                     const float* __restrict__ part_ml, int Hq, int num_splits, long out_stride,
+                                     const float* __restrict__ sinks) {
   const int qh = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
   const long base = ((long)b * Hq + qh) * num_splits;
   float mm = NEG_BIG;
@@ -329,6 +348,7 @@ __global__ void decode_reduce_kernel(T* __restrict__ out, const float* __restric
     lt += part_ml[2 * (base + s) + 1] * a;
     o += part_o[(base + s) * D + d] * a;
   }
+  if (sinks != nullptr) lt += exp2f(sinks[qh] * LOG2E_F - mm);
   out[b * out_stride + (long)qh * D + d] = (T)(lt > 0.f ? o / lt : 0.f);
 }
 
@@ -345,7 +365,7 @@ __global__ __launch_bounds__(256) void paged_prefill_kernel(
     const void* __restrict__ v_cache, const int* __restrict__ block_table, int bt_stride,
     const int* __restrict__ query_start_loc, const int* __restrict__ seq_lens, float scale_log2e, int Hq, int Hkv,
     int block_size, long out_stride, const float* __restrict__ k_scales, const float* __restrict__ v_scales,
-    int window, float softcap) {
+    int window, float softcap, const float* __restrict__ sinks, const float* __restrict__ alibi) {
   using V = typename Vec8<T>::type;
   constexpr int NQ = 2;
   const int z = blockIdx.z, h = blockIdx.y;
@@ -385,14 +405,16 @@ __global__ __launch_bounds__(256) void paged_prefill_kernel(
   const int last_key = min(seq_len - 1, ctx + min(t_wave + 31, q_len - 1));
   const int n_groups = (last_key >> 5) + 1;
   const int g_first = window > 0 ? max(0, ctx + t_wave - window + 1) >> 5 : 0;     // the wave's earliest window edge
+  const float alibi_l2 = alibi != nullptr ? alibi[h] * LOG2E_F : 0.f;
   for (int g = g_first; g < n_groups; ++g)
     attend_group<T, D, NQ, KV8>(k_cache, v_cache, bt_row, kvh, Hkv, block_size, g * 32, seq_len,
-                                scale_log2e * k_scale, softcap, qf, acc, m, l, qpos_hi, qpos_lo, 1.f, 1.f);
+                                scale_log2e * k_scale, softcap, qf, acc, m, l, qpos_hi, qpos_lo, 1.f, 1.f, alibi_l2);
 #pragma unroll
   for (int n = 0; n < NQ; ++n) {
     float lsum = l[n];
     lsum += __shfl_xor(lsum, 16, 64);
     lsum += __shfl_xor(lsum, 32, 64);
+    if (sinks != nullptr) lsum += exp2f(sinks[h] * LOG2E_F - m[n]);
     const float inv = lsum > 0.f ? v_scale / lsum : 0.f;
     const int tok = t_wave + 16 * n + r16;
     if (tok < q_len) {
@@ -435,7 +457,8 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
     const void* __restrict__ v_cache, const int* __restrict__ block_table, int bt_stride,
     const int* __restrict__ query_start_loc, const int* __restrict__ seq_lens, float scale_log2e, int Hq, int Hkv,
     int block_size, long out_stride, int q_tiles, int total_wgs, int xcd_remap,
-    const float* __restrict__ k_scales, const float* __restrict__ v_scales, int window, float softcap) {
+    const float* __restrict__ k_scales, const float* __restrict__ v_scales, int window, float softcap,
+    const float* __restrict__ sinks, const float* __restrict__ alibi) {
   using V = typename Vec8<T>::type;
   constexpr int D = 128, KT = 64, TILE_BYTES = KT * D * 2;
   __shared__ __attribute__((aligned(16))) char smem[2][2][TILE_BYTES];     // [buffer][K | V^T]
@@ -465,6 +488,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
   const float k_scale = (KV8 && k_scales != nullptr) ? k_scales[kvh] : 1.f;
   const float v_scale = (KV8 && v_scales != nullptr) ? v_scales[kvh] : 1.f;
   const float sl2e = scale_log2e * k_scale;
+  const float alibi_l2 = alibi != nullptr ? alibi[head] * LOG2E_F : 0.f;
   const int t_wave = t_blk + wid * 32;
   const int tok = t_wave + l32;
   const bool wave_active = t_wave < q_len;
@@ -554,7 +578,8 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
       // of a long sequence - take the short path: the running max is found on the raw scores (the scale
       // is positive) and the scale rides in the exponent's multiply-add, three VALU operations and one
       // exponential per score instead of eight and one.
-      const bool need_mask = base + KT - 1 > min(ctx + t_wave, seq_len - 1) || base < wave_lo_max || softcap > 0.f;
+      const bool need_mask = base + KT - 1 > min(ctx + t_wave, seq_len - 1) || base < wave_lo_max || softcap > 0.f ||
+                             alibi_l2 != 0.f;
       float m_new, alpha, psum = 0.f;
       V pf[4];
       if (!need_mask) {
@@ -582,6 +607,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
             const int key = base + 32 * u + 16 * (r >> 3) + 8 * h + (r & 7);
             float sv = sc[u][r] * sl2e;
             if (softcap > 0.f) sv = soft_cap_log2(sv, softcap);
+            sv = fmaf(alibi_l2, (float)(key - (ctx + tok)), sv);
             const float v = (key <= q_hi && key >= q_lo) ? sv : NEG_BIG;
             sc[u][r] = v;
             tmax = fmaxf(tmax, v);
@@ -620,6 +646,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
 
   if (tok < q_len) {
     float lsum = l_run + __shfl_xor(l_run, 32, 64);
+    if (sinks != nullptr) lsum += exp2f(sinks[head] * LOG2E_F - m_run);
     const float inv = lsum > 0.f ? v_scale / lsum : 0.f;
     T* orow = out + (long)(q0 + tok) * out_stride + (long)head * D + 4 * h;
 #pragma unroll
@@ -640,7 +667,7 @@ template <typename T, int D, bool KV8>
 int launch_decode(void* out, float* ws, const void* q, long q_stride, const void* kc, const void* vc, const int* bt,
                   int bt_stride, const int* seq_lens, float scale, int B, int Hq, int Hkv, int block_size,
                   int num_splits, long out_stride, const float* k_scales, const float* v_scales, int window,
-                  float softcap, hipStream_t s) {
+                  float softcap, const float* sinks, const float* alibi, hipStream_t s) {
   const int G = Hq / Hkv;
   const int q_tiles = (G + 15) / 16;
   float* part_o = ws;
@@ -649,17 +676,18 @@ int launch_decode(void* out, float* ws, const void* q, long q_stride, const void
   if (num_splits == 0) {      // one wave per sequence
     hipLaunchKernelGGL((paged_decode_wave_kernel<T, D, KV8>), dim3((B + 3) / 4, Hkv * q_tiles), dim3(256), 0, s,
                        (T*)out, (const T*)q, q_stride, kc, vc, bt, bt_stride, seq_lens, sl2, B, Hq, Hkv, block_size,
-                       out_stride, k_scales, v_scales, window, softcap);
+                       out_stride, k_scales, v_scales, window, softcap, sinks, alibi);
     HIP_LAUNCH_CHECK();
     return 0;
   }
   hipLaunchKernelGGL((paged_decode_kernel<T, D, KV8>), dim3(num_splits, Hkv * q_tiles, B), dim3(256), 0, s, (T*)out,
                      part_o, part_ml, (const T*)q, q_stride, kc, vc, bt, bt_stride, seq_lens,
-                     sl2, Hq, Hkv, block_size, num_splits, out_stride, k_scales, v_scales, window, softcap);
+                     sl2, Hq, Hkv, block_size, num_splits, out_stride, k_scales, v_scales, window, softcap, sinks,
+                     alibi);
   HIP_LAUNCH_CHECK();
   if (num_splits > 1) {
     hipLaunchKernelGGL((decode_reduce_kernel<T, D>), dim3(Hq, B), dim3(D), 0, s, (T*)out, part_o, part_ml, Hq,
-                       num_splits, out_stride);
+                       num_splits, out_stride, sinks);
     HIP_LAUNCH_CHECK();
   }
   return 0;
@@ -669,7 +697,7 @@ template <typename T, int D, bool KV8>
 int launch_prefill(void* out, const void* q, long q_stride, const void* kc, const void* vc, const int* bt,
                    int bt_stride, const int* qsl, const int* seq_lens, float scale, int num_seqs, int max_q_len,
                    int Hq, int Hkv, int block_size, long out_stride, const float* k_scales, const float* v_scales,
-                   int window, float softcap, hipStream_t s) {
+                   int window, float softcap, const float* sinks, const float* alibi, hipStream_t s) {
   const float sl2 = scale * 1.4426950408889634f;
   const int tiles = (max_q_len + 127) / 128;
   if constexpr (D == 128) {
@@ -683,14 +711,15 @@ int launch_prefill(void* out, const void* q, long q_stride, const void* kc, cons
       const int grid = remap ? (int)((total + 7) / 8 * 8) : (int)total;
       hipLaunchKernelGGL((paged_prefill_lds_kernel<T, KV8>), dim3(grid), dim3(256), 0, s, (T*)out,
                          (const T*)q, q_stride, kc, vc, bt, bt_stride, qsl, seq_lens, sl2, Hq,
-                         Hkv, block_size, out_stride, tiles, (int)total, remap, k_scales, v_scales, window, softcap);
+                         Hkv, block_size, out_stride, tiles, (int)total, remap, k_scales, v_scales, window, softcap,
+                         sinks, alibi);
       HIP_LAUNCH_CHECK();
       return 0;
     }
   }
   hipLaunchKernelGGL((paged_prefill_kernel<T, D, KV8>), dim3(tiles, Hq, num_seqs), dim3(256), 0, s, (T*)out,
                      (const T*)q, q_stride, kc, vc, bt, bt_stride, qsl, seq_lens, sl2, Hq, Hkv,
-                     block_size, out_stride, k_scales, v_scales, window, softcap);
+                     block_size, out_stride, k_scales, v_scales, window, softcap, sinks, alibi);
   HIP_LAUNCH_CHECK();
   return 0;
 }
@@ -711,7 +740,7 @@ VDAMD_API int vdamd_paged_attention_decode(void* out, float* workspace, const vo
                                            int bt_stride, const int* seq_lens, float scale, int B, int Hq, int Hkv,
                                            int D, int block_size, int num_splits, long out_stride, int dtype,
                                            int kv_fp8, const float* k_scales, const float* v_scales, int window,
-                                           float softcap, hipStream_t s) {
+                                           float softcap, const float* sinks, const float* alibi, hipStream_t s) {
   if (B == 0) return 0;
   // num_splits == 0 selects the one-wave-per-sequence kernel (short contexts, large batches)
   if (Hq % Hkv != 0 || block_size % 8 != 0 || num_splits < 0 || num_splits > MAX_SPLITS) return -1;
@@ -721,10 +750,10 @@ VDAMD_API int vdamd_paged_attention_decode(void* out, float* workspace, const vo
     if (kv_fp8)                                                                                                  \
       return launch_decode<TY, DD, true>(out, workspace, q, q_stride, k_cache, v_cache, block_table, bt_stride,   \
                                          seq_lens, scale, B, Hq, Hkv, block_size, num_splits, out_stride,         \
-                                         k_scales, v_scales, window, softcap, s);                                          \
+                                         k_scales, v_scales, window, softcap, sinks, alibi, s);                            \
     return launch_decode<TY, DD, false>(out, workspace, q, q_stride, k_cache, v_cache, block_table, bt_stride,    \
                                         seq_lens, scale, B, Hq, Hkv, block_size, num_splits, out_stride, nullptr, \
-                                        nullptr, window, softcap, s);                                                    \
+                                        nullptr, window, softcap, sinks, alibi, s);                                      \
   } while (0)
   if (dtype == DT_BF16) {
     if (D == 128) CASE(bf16_t, 128);
@@ -747,7 +776,8 @@ VDAMD_API int vdamd_paged_attention_prefill(void* out, const void* q, long q_str
                                             const int* query_start_loc, const int* seq_lens, float scale,
                                             int num_seqs, int max_q_len, int Hq, int Hkv, int D, int block_size,
                                             long out_stride, int dtype, int kv_fp8, const float* k_scales,
-                                            const float* v_scales, int window, float softcap, hipStream_t s) {
+                                            const float* v_scales, int window, float softcap, const float* sinks,
+                                            const float* alibi, hipStream_t s) {
   if (num_seqs == 0 || max_q_len == 0) return 0;
   if (Hq % Hkv != 0 || block_size % 8 != 0) return -1;
 #define CASE(TY, DD)                                                                                             \
@@ -755,10 +785,10 @@ VDAMD_API int vdamd_paged_attention_prefill(void* out, const void* q, long q_str
     if (kv_fp8)                                                                                                  \
       return launch_prefill<TY, DD, true>(out, q, q_stride, k_cache, v_cache, block_table, bt_stride,             \
                                           query_start_loc, seq_lens, scale, num_seqs, max_q_len, Hq, Hkv,         \
-                                          block_size, out_stride, k_scales, v_scales, window, softcap, s);                 \
+                                          block_size, out_stride, k_scales, v_scales, window, softcap, sinks, alibi, s);   \
     return launch_prefill<TY, DD, false>(out, q, q_stride, k_cache, v_cache, block_table, bt_stride,              \
                                          query_start_loc, seq_lens, scale, num_seqs, max_q_len, Hq, Hkv,          \
-                                         block_size, out_stride, nullptr, nullptr, window, softcap, s);                  \
+                                         block_size, out_stride, nullptr, nullptr, window, softcap, sinks, alibi, s);    \
   } while (0)
   if (dtype == DT_BF16) {
     if (D == 128) CASE(bf16_t, 128);

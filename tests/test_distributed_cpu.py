@@ -122,7 +122,10 @@ def _reference(model, **kw):
                                                      ("smollm3-tiny", 1, 2, False), ("deepseek-v3-tiny", 1, 2, False),
                                                      ("falcon-tiny", 1, 2, False), ("gptj-tiny", 1, 2, False),
                                                      ("olmo2-tiny", 1, 2, False), ("qwen3-moe-tiny", 1, 2, False),
-                                                     ("mixtral-tiny", 1, 2, False)])
+                                                     ("mixtral-tiny", 1, 2, False),
+                                                     # expert biases added once across a sharded expert block,
+                                                     # attention sinks cut to each rank's heads
+                                                     ("gpt-oss-tiny", 2, 1, False)])
 def test_head_plus_remote_worker_matches_single_process(monkeypatch, model, tp, pp, async_sched):
     """OPT greedy with head + 1 worker on localhost is the plumbing configuration;
     the TP=2 case assembles one TP group from the head's device and a same-host worker."""

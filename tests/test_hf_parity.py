@@ -119,6 +119,13 @@ CASES = {
     "stablelm": ("StableLmConfig", dict(BASE, use_qkv_bias=True)),
     "nemotron": ("NemotronConfig", dict(BASE, attention_bias=True, mlp_bias=True)),
     "cohere": ("CohereConfig", dict(BASE, logit_scale=0.25, pad_token_id=0)),
+    # attention sinks, q/k/v/o biases, a window on every other layer, YaRN; experts with biases and the clamped
+    # SwiGLU, stacked and column-interleaved in the checkpoint; router with a bias, softmax over the chosen logits
+    "gpt-oss": ("GptOssConfig", dict(BASE, head_dim=16, num_hidden_layers=3, intermediate_size=48, num_local_experts=6,
+                                     num_experts_per_tok=2, sliding_window=16, pad_token_id=0,
+                                     layer_types=["sliding_attention", "full_attention", "sliding_attention"],
+                                     rope_scaling=dict(rope_type="yarn", factor=4.0, beta_fast=32.0, beta_slow=1.0,
+                                                       original_max_position_embeddings=32, truncate=False))),
 }
 PROMPTS = [[5, 9, 200, 17, 33, 2, 90], list(range(10, 60)), [7, 7, 300, 2, 2, 41, 8, 100, 101]]
 
@@ -135,7 +142,7 @@ def _hf_model(name, tmp_path):
     # bias, a swapped norm or an unapplied scale shows
     with torch.no_grad():
         for n, p in model.named_parameters():
-            if p.dim() == 1:
+            if p.dim() == 1 or (p.dim() == 2 and n.endswith("_proj_bias")):      # (gpt-oss: one bias row per expert)
                 p.add_(torch.randn_like(p) * 0.1)
         for n, b in model.named_buffers():
             if n.endswith("e_score_correction_bias"):       # DeepSeek-V3's choice bias is stored as a buffer

@@ -290,6 +290,52 @@ def test_sliding_window_attention_decode_and_prefill(window, kv8):
         torch.testing.assert_close(got2.float(), ref2, rtol=3e-2, atol=3e-2)
 
 
+@pytest.mark.parametrize("hq,hkv,d,bs", [(32, 8, 128, 64), (64, 8, 64, 16), (8, 8, 64, 16)])
+@pytest.mark.parametrize("which", ["sinks", "alibi", "both+window"])
+def test_attention_sinks_and_alibi_bias_decode_and_prefill(hq, hkv, d, bs, which):
+    """Attention sinks (an extra per-head score in the softmax's denominator, large ones taking most of
+    the mass) and ALiBi (``slope * (key - query)`` on the scores): both decode kernels at every split
+    count and both prefill kernels against the fp32 reference."""
+    from vllm_distributed_amd.ops import hip
+    scale = 1.0 / math.sqrt(d)
+    sinks = alibi = None
+    window = 0
+    if which != "alibi":
+        sinks = torch.randn(hq, device=DEV) * 2
+        sinks[0], sinks[-1] = 9.0, -30.0               # nearly all of the mass / no visible effect
+    if which != "sinks":
+        alibi = torch.tensor([2.0 ** (-8.0 * (i + 1) / hq) for i in range(hq)], device=DEV)
+    if which == "both+window":
+        window = 100
+    seq_lens = [1, 31, 33, 64, 100, 517, 1000, 129]
+    kc, vc, bt = _make_paged(seq_lens, hkv, d, bs)
+    sl = torch.tensor(seq_lens, device=DEV, dtype=torch.int32)
+    q = _rand(len(seq_lens), hq, d)
+    ref = torch_ref.paged_attention_decode(q.float(), kc.float(), vc.float(), bt, sl, scale, None, window, 0.0,
+                                           sinks, alibi)
+    plain = torch_ref.paged_attention_decode(q.float(), kc.float(), vc.float(), bt, sl, scale, None, window)
+    assert (ref - plain).abs().max().item() > 0.05           # the feature under test changes the result
+    for splits in (None, 0, 1, 4):
+        got = hip.paged_attention_decode(q, kc, vc, bt, sl, scale, max_seq_len=max(seq_lens), num_splits=splits,
+                                         window=window, sinks=sinks, alibi_slopes=alibi)
+        torch.testing.assert_close(got.float(), ref, rtol=3e-2, atol=3e-2)
+    for cases in ([(5, 5), (20, 300), (1, 77), (30, 30)],                   # every chunk <= 32 rows: fragment-direct
+                  [(128, 128), (130, 130), (40, 300), (257, 600), (33, 33)]):    # LDS-staged kernel where D = 128
+        sls = [c[1] for c in cases]
+        kc2, vc2, bt2 = _make_paged(sls, hkv, d, bs)
+        qsl = [0]
+        for ql, _ in cases:
+            qsl.append(qsl[-1] + ql)
+        q2 = _rand(qsl[-1], hq, d)
+        qsl_t = torch.tensor(qsl, device=DEV, dtype=torch.int32)
+        sl2 = torch.tensor(sls, device=DEV, dtype=torch.int32)
+        ref2 = torch_ref.paged_attention(q2.float(), kc2.float(), vc2.float(), bt2, qsl_t, sl2, scale, None, window,
+                                         0.0, sinks, alibi)
+        got2 = ops.paged_attention(q2, kc2, vc2, bt2, qsl_t, sl2, scale, max(c[0] for c in cases), max(sls),
+                                   window=window, sinks=sinks, alibi_slopes=alibi)
+        torch.testing.assert_close(got2.float(), ref2, rtol=3e-2, atol=3e-2)
+
+
 def test_mfma_operand_maps_with_exact_integer_data():
     """A = I style check with asymmetric data: one-hot queries pick out single
     K dimensions, V holds distinct small integers, so any swapped lane/row map

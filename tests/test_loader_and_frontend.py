@@ -679,3 +679,52 @@ def test_nvfp4_q_k_projections_follow_the_rope_row_order(tmp_path, model):
         llm.shutdown()
         pstate.destroy_model_parallel()
     assert outs[0] == outs[1]
+
+
+def test_gpt_oss_mxfp4_checkpoint_equals_its_widened_twin(tmp_path):
+    """The original gpt-oss release stores the expert matrices as MXFP4 (``*_blocks`` / ``*_scales``, output
+    channels in rows, gate and up interleaved).  A checkpoint written that way from quantised values must load
+    to the model its widened (dense ``[E, in, out]``) twin loads to; encoder and decoder follow the format's
+    definition (E2M1 values, one power-of-two scale per 32; parity with a released file is unpinned)."""
+    from safetensors.torch import load_file, save_file
+    from vllm_distributed_amd.config import ModelConfig
+    from vllm_distributed_amd.models.gpt_oss import mxfp4_dequantize, mxfp4_quantize
+    from vllm_distributed_amd.models.loader import save_dummy_checkpoint
+    w = torch.randn(6, 64) * torch.logspace(-3, 2, 6).unsqueeze(1)
+    blocks, scales = mxfp4_quantize(w)
+    back = mxfp4_dequantize(blocks, scales, torch.float32)
+    assert blocks.shape == (6, 2, 16) and scales.shape == (6, 2)
+    assert ((back - w).abs() <= 0.26 * w.abs().reshape(6, 2, 32).amax(-1).repeat_interleave(32, 1) + 1e-9).all()
+    b2, s2 = mxfp4_quantize(back)
+    assert torch.equal(mxfp4_dequantize(b2, s2, torch.float32), back)            # a fixed point
+
+    mc = ModelConfig(model="gpt-oss-tiny", dtype="float32", load_format="dummy")
+    dense_dir, mx_dir = tmp_path / "dense", tmp_path / "mxfp4"
+    save_dummy_checkpoint(mc, str(dense_dir))
+    tensors = load_file(str(dense_dir / "model.safetensors"))
+    dense, packed = {}, {}
+    for name, t in tensors.items():
+        if name.endswith((".experts.gate_up_proj", ".experts.down_proj")):
+            rows = t.transpose(1, 2).contiguous()                     # [E, out, in]: the release's orientation
+            blk, sc = mxfp4_quantize(rows)
+            packed[name + "_blocks"], packed[name + "_scales"] = blk, sc
+            dense[name] = mxfp4_dequantize(blk, sc, torch.float32).transpose(1, 2).contiguous()
+        else:
+            dense[name] = packed[name] = t
+    save_file(dense, str(dense_dir / "model.safetensors"))
+    mx_dir.mkdir()
+    save_file(packed, str(mx_dir / "model.safetensors"))
+    cfg = dict(mc.hf_config, quantization_config={"quant_method": "mxfp4"})
+    import json
+    (mx_dir / "config.json").write_text(json.dumps(cfg))
+    outs = {}
+    for tag, d in (("dense", dense_dir), ("mxfp4", mx_dir)):
+        llm = LLM(model=str(d), device="cpu", dtype="float32", max_model_len=128, block_size=16,
+                  num_gpu_blocks_override=64, max_num_seqs=8)
+        o = llm.generate([[5, 9, 200, 17], list(range(10, 50))],
+                         SamplingParams(temperature=0.0, max_tokens=5, ignore_eos=True, logprobs=3))
+        outs[tag] = [(x.outputs[0].token_ids, x.outputs[0].logprobs[0]) for x in o]
+        llm.shutdown()
+        pstate.destroy_model_parallel()
+    for (ta, la), (tb, lb) in zip(outs["dense"], outs["mxfp4"]):
+        assert ta == tb and all(abs(la[t] - lb[t]) < 1e-5 for t in la)

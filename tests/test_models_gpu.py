@@ -36,7 +36,7 @@ TIGHT = {"llama-tiny", "opt-tiny", "phi3-tiny", "gemma-tiny", "granite-tiny", "g
                                    "glm-tiny", "helium-tiny", "smollm3-tiny", "glm4-tiny", "olmo2-tiny",
                                    "exaone4-tiny", "nemotron-tiny", "stablelm-tiny", "cohere-tiny", "arcee-tiny",
                                    "deepseek-v3-tiny", "glm4-moe-tiny", "falcon-tiny", "gptj-tiny",
-                                   "gpt-bigcode-tiny"])
+                                   "gpt-bigcode-tiny", "gpt-oss-tiny"])
 def test_model_family_on_gpu_tracks_cpu_reference(model, tmp_path):
     overrides = QWEN3_SMALL if model == "qwen3-coder-480b-a35b" else {}
     mc = ModelConfig(model=model, dtype="float32", load_format="dummy", hf_overrides=overrides)
@@ -70,7 +70,10 @@ def test_model_family_on_gpu_tracks_cpu_reference(model, tmp_path):
             common = set(la) & set(lb)
             assert len(common) >= 8, (model, step, sorted(la), sorted(lb))
             # bf16 router logits can flip a near-tied expert choice on the MoE models: allow for it
-            assert max(abs(la[t] - lb[t]) for t in common) < (0.15 if model in TIGHT else 0.3), (model, step)
+            # (gpt-oss: top-2 of 8 experts behind a router with a bias, plus sinks; its expert block is pinned
+            # against the per-expert loop on the same device in tests/test_quant_gpu.py)
+            tol = 0.15 if model in TIGHT else (0.4 if model == "gpt-oss-tiny" else 0.3)
+            assert max(abs(la[t] - lb[t]) for t in common) < tol, (model, step)
 
 
 def test_window_released_blocks_are_never_read_by_the_kernels():

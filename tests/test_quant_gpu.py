@@ -424,3 +424,49 @@ def test_dense_shadow_serves_large_batches(method, monkeypatch):
         outs[shadow] = (lin(xs).float(), lin(xl).float())
     assert torch.equal(outs["0"][0], outs["1"][0])
     assert (outs["0"][1] - outs["1"][1]).abs().max() <= 1e-6 * outs["0"][1].abs().max() + 1e-6
+
+
+@pytest.mark.parametrize("tokens", [1, 7, 64, 300])
+def test_gpt_oss_expert_block_grouped_path_matches_per_expert_loop(tokens, monkeypatch):
+    """gpt-oss experts (biases, clamped SwiGLU, reduction dimensions zero-padded to the GEMM's K tile) as
+    grouped HIP GEMMs with the per-row expert biases added on the device, against the per-expert loop of
+    library GEMMs on the same weights and the same router logits; and captured in a hipGraph."""
+    from vllm_distributed_amd.models.gpt_oss import GptOssMoE
+    from vllm_distributed_amd.models.layers.moe import FusedMoE
+    from vllm_distributed_amd.parallel import state as pstate
+    pstate.destroy_model_parallel()
+    pstate.ensure_single_process_groups(torch.device(DEV))
+    cfg = dict(hidden_size=192, intermediate_size=160, num_local_experts=8, num_experts_per_tok=4, swiglu_limit=7.0)
+    torch.manual_seed(tokens)
+    with torch.device(DEV):
+        moe = GptOssMoE(cfg, torch.bfloat16, False)
+    assert (moe.h_pad, moe.i_pad) == (256, 256)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    E, I, H = 8, 160, 192
+    moe.load_stacked("gate_up_proj", (torch.randn(E, H, 2 * I, device=DEV, generator=gen) * 0.08).to(torch.bfloat16))
+    moe.load_stacked("gate_up_proj_bias", (torch.randn(E, 2 * I, device=DEV, generator=gen) * 0.5).to(torch.bfloat16))
+    moe.load_stacked("down_proj", (torch.randn(E, I, H, device=DEV, generator=gen) * 0.08).to(torch.bfloat16))
+    moe.load_stacked("down_proj_bias", (torch.randn(E, H, device=DEV, generator=gen) * 0.5).to(torch.bfloat16))
+    moe.gate.weight.data.copy_((torch.randn(E, H, device=DEV, generator=gen) * 0.1).to(torch.bfloat16))
+    moe.gate.bias.data.copy_((torch.randn(E, device=DEV, generator=gen) * 0.5).to(torch.bfloat16))
+    x = (torch.randn(tokens, H, device=DEV, generator=gen) * 2).to(torch.bfloat16)     # large enough to hit the clamp
+    with torch.inference_mode():
+        rows = moe._grouped_tile_rows(x)
+        assert rows in (16, 32, 64, 128)
+        got = moe(x).float()
+        monkeypatch.setattr(GptOssMoE, "_grouped_tile_rows", lambda self, x: 0)
+        ref = moe(x).float()
+        monkeypatch.undo()
+        torch.cuda.synchronize()
+        err = (got - ref).abs().max().item()
+        assert err <= 0.03 * ref.abs().max().item() + 1e-3, err
+        if tokens == 64:
+            g = torch.cuda.CUDAGraph()
+            moe(x)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                y = moe(x)
+            g.replay()
+            torch.cuda.synchronize()
+            assert (y.float() - ref).abs().max().item() <= 0.03 * ref.abs().max().item() + 1e-3
+    pstate.destroy_model_parallel()

@@ -291,7 +291,7 @@ class ModelConfig:
                 "stablelm": "StableLmForCausalLM", "nemotron": "NemotronForCausalLM",
                 "cohere": "CohereForCausalLM",
                 "qwen3": "Qwen3ForCausalLM", "mistral": "MistralForCausalLM",
-                "mixtral": "MixtralForCausalLM", "phi3": "Phi3ForCausalLM"}.get(mt, mt)
+                "mixtral": "MixtralForCausalLM", "phi3": "Phi3ForCausalLM", "gpt_oss": "GptOssForCausalLM"}.get(mt, mt)
 
     @property
     def hidden_size(self) -> int:

@@ -81,6 +81,10 @@ class Attention(nn.Module):
         self.v_cache: Optional[torch.Tensor] = None
         # e4m3 cache only: (k_scale[Hkv], v_scale[Hkv]) fp32; stored = value / scale.  None = 1.0
         self.kv_scales: Optional[tuple] = None
+        # fp32 [num_heads] each, or None: an extra softmax column per head that is dropped after the softmax
+        # (attention sinks: gpt-oss), and the slopes of a linear position bias (ALiBi: Bloom, MPT, Falcon-RW)
+        self.sinks: Optional[torch.Tensor] = None
+        self.alibi_slopes: Optional[torch.Tensor] = None
 
     def bind_kv_cache(self, k_cache: torch.Tensor, v_cache: torch.Tensor, kv_scales: Optional[tuple] = None) -> None:
         self.k_cache, self.v_cache, self.kv_scales = k_cache, v_cache, kv_scales
@@ -108,13 +112,13 @@ class Attention(nn.Module):
                 qv[:nd], self.k_cache, self.v_cache, md.block_table[:md.num_decodes],
                 md.seq_lens[:md.num_decodes], self.scale, md.max_decode_seq_len,
                 out=out[:nd], workspace=md.decode_workspace, kv_scales=self.kv_scales, window=self.window,
-                softcap=self.softcap)
+                softcap=self.softcap, sinks=self.sinks, alibi_slopes=self.alibi_slopes)
         if md.num_prefills > 0:
             ops.paged_attention(
                 qv[nd:], self.k_cache, self.v_cache, md.block_table[md.num_decodes:],
                 md.prefill_query_start_loc, md.seq_lens[md.num_decodes:], self.scale,
                 md.max_prefill_query_len, md.max_seq_len, out=out[nd:], kv_scales=self.kv_scales,
-                window=self.window, softcap=self.softcap)
+                window=self.window, softcap=self.softcap, sinks=self.sinks, alibi_slopes=self.alibi_slopes)
         return out.view(t, self.num_heads * self.head_dim)
 
     def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:

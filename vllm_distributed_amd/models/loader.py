@@ -315,6 +315,12 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
                     shapes[q + "mlp.shared_expert.gate_proj.weight"] = (si, h)
                     shapes[q + "mlp.shared_expert.up_proj.weight"] = (si, h)
                     shapes[q + "mlp.shared_expert.down_proj.weight"] = (h, si)
+        elif mt == "gpt_oss":        # experts stacked, [in, out] with gate / up columns interleaved; biases everywhere
+            ne = c["num_local_experts"]
+            shapes[q + "self_attn.sinks"] = (heads,)
+            shapes[q + "mlp.router.weight"], shapes[q + "mlp.router.bias"] = (ne, h), (ne,)
+            shapes[q + "mlp.experts.gate_up_proj"], shapes[q + "mlp.experts.gate_up_proj_bias"] = (ne, h, 2 * inter), (ne, 2 * inter)
+            shapes[q + "mlp.experts.down_proj"], shapes[q + "mlp.experts.down_proj_bias"] = (ne, inter, h), (ne, h)
         elif mixtral:
             shapes[q + "block_sparse_moe.gate.weight"] = (c["num_local_experts"], h)
             for e in range(c["num_local_experts"]):
@@ -379,8 +385,14 @@ def dummy_weights_iterator(mc: ModelConfig, device: torch.device,
         if re.search(r"(layernorm|layer_norm|norm)\.weight$", name):
             w = 1.0 + 0.05 * (torch.rand(shape, generator=gen, device=device, dtype=torch.float32) - 0.5)
             w = w.to(dtype)
-        elif name.endswith(".bias"):
+        elif name.endswith((".bias", "_proj_bias")):
             w = (0.02 * (torch.rand(shape, generator=gen, device=device, dtype=torch.float32) - 0.5)).to(dtype)
+        elif name.endswith(".sinks"):
+            w = (2.0 * (torch.rand(shape, generator=gen, device=device, dtype=torch.float32) - 0.5)).to(dtype)
+        elif name.endswith((".experts.gate_up_proj", ".experts.down_proj")):        # stored [E, in, out]
+            scale = (3.0 / shape[-2]) ** 0.5
+            w = torch.empty(shape, device=device, dtype=dtype)
+            w.uniform_(-scale, scale, generator=gen)
         else:
             fan_in = shape[-1]
             scale = (3.0 / fan_in) ** 0.5      # unit-variance-preserving uniform

@@ -23,6 +23,7 @@ _MODELS: Dict[str, Tuple[str, str]] = {
     "Dots1ForCausalLM": ("deepseek", "Dots1ForCausalLM"),
     "GraniteMoeForCausalLM": ("mixtral", "GraniteMoeForCausalLM"),
     "MixtralForCausalLM": ("mixtral", "MixtralForCausalLM"),
+    "GptOssForCausalLM": ("gpt_oss", "GptOssForCausalLM"),
     # Phi-3 checkpoints store qkv and gate/up already fused: the fused loaders take them whole
     "Phi3ForCausalLM": ("llama", "LlamaForCausalLM"),
     "PhiForCausalLM": ("phi", "PhiForCausalLM"),

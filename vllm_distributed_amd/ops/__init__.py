@@ -178,15 +178,15 @@ def rope_and_cache_partials(positions, slabs, dtype, cos_sin_cache, k_cache, v_c
 
 def paged_attention(q, k_cache, v_cache, block_table, query_start_loc, seq_lens, scale,
                     max_query_len: int = 0, max_seq_len: int = 0, out=None, kv_scales=None, window: int = 0,
-                    softcap: float = 0.0):
+                    softcap: float = 0.0, sinks=None, alibi_slopes=None):
     on_hip = _use_hip(q) and _hip.supports_head_dim(q.shape[-1])
     _note_attention(q, on_hip)
     if on_hip:
         return _hip.paged_attention_prefill(q, k_cache, v_cache, block_table, query_start_loc,
                                             seq_lens, scale, max_query_len, max_seq_len, out, kv_scales, window,
-                                            softcap)
+                                            softcap, sinks, alibi_slopes)
     res = torch_ref.paged_attention(q, k_cache, v_cache, block_table, query_start_loc,
-                                    seq_lens, scale, kv_scales, window, softcap)
+                                    seq_lens, scale, kv_scales, window, softcap, sinks, alibi_slopes)
     if out is not None:
         out.copy_(res)
         return out
@@ -195,15 +195,15 @@ def paged_attention(q, k_cache, v_cache, block_table, query_start_loc, seq_lens,
 
 def paged_attention_decode(q, k_cache, v_cache, block_table, seq_lens, scale,
                            max_seq_len: int = 0, out=None, workspace=None, kv_scales=None, window: int = 0,
-                           softcap: float = 0.0):
+                           softcap: float = 0.0, sinks=None, alibi_slopes=None):
     on_hip = _use_hip(q) and _hip.supports_head_dim(q.shape[-1])
     _note_attention(q, on_hip)
     if on_hip:
         return _hip.paged_attention_decode(q, k_cache, v_cache, block_table, seq_lens, scale,
                                            max_seq_len, out, workspace, kv_scales=kv_scales, window=window,
-                                           softcap=softcap)
+                                           softcap=softcap, sinks=sinks, alibi_slopes=alibi_slopes)
     res = torch_ref.paged_attention_decode(q, k_cache, v_cache, block_table, seq_lens, scale, kv_scales, window,
-                                           softcap)
+                                           softcap, sinks, alibi_slopes)
     if out is not None:
         out.copy_(res)
         return out

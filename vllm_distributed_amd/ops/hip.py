@@ -41,8 +41,8 @@ def load() -> ctypes.CDLL:
         "vdamd_big_gemm": [P, L, P, L, P, L, P, L, I, I, I, I, I, I, P],
         "vdamd_rope_cache": [P, P, P, P, L, L, L, P, P, P, P, I, I, I, I, I, I, P, P, F, I, I, P, P, P],
         "vdamd_rope_cache_slabs": [P, P, I, P, L, P, P, P, P, I, I, I, I, I, P, P, F, I, I, P, P, P],
-        "vdamd_paged_attention_decode": [P, P, P, L, P, P, P, I, P, F, I, I, I, I, I, I, L, I, I, P, P, I, F, P],
-        "vdamd_paged_attention_prefill": [P, P, L, P, P, P, I, P, P, F, I, I, I, I, I, I, L, I, I, P, P, I, F, P],
+        "vdamd_paged_attention_decode": [P, P, P, L, P, P, P, I, P, F, I, I, I, I, I, I, L, I, I, P, P, I, F, P, P, P],
+        "vdamd_paged_attention_prefill": [P, P, L, P, P, P, I, P, P, F, I, I, I, I, I, I, L, I, I, P, P, I, F, P, P, P],
         "vdamd_argmax": [P, P, I, I, L, I, P],
         "vdamd_sample": [P, P, I, I, L, P, P, P, P, P, I, P],
         "vdamd_w4a16_gemm": [P, L, P, L, P, P, P, I, I, I, I, I, I, I, P],
@@ -321,11 +321,21 @@ def choose_num_splits(batch: int, num_kv_heads: int, max_seq_len: int) -> int:
     return max(1, min(MAX_SPLITS, want, by_len))
 
 
+def _per_head(t: Optional[torch.Tensor], hq: int, q: torch.Tensor):
+    """Pointer of an optional fp32 ``[Hq]`` vector (attention sinks, ALiBi slopes)."""
+    if t is None:
+        return None
+    assert t.dtype == torch.float32 and t.numel() == hq and t.is_contiguous() and t.device == q.device
+    return t.data_ptr()
+
+
 def paged_attention_decode(q, k_cache, v_cache, block_table, seq_lens, scale, max_seq_len=0, out=None,
                            workspace=None, num_splits: Optional[int] = None, kv_scales=None,
-                           window: int = 0, softcap: float = 0.0) -> torch.Tensor:
+                           window: int = 0, softcap: float = 0.0, sinks=None, alibi_slopes=None) -> torch.Tensor:
     """``window > 0``: sliding-window attention, the query sees its last ``window`` keys only.
-    ``softcap > 0``: scores become ``softcap * tanh(score / softcap)`` before the softmax (Gemma-2)."""
+    ``softcap > 0``: scores become ``softcap * tanh(score / softcap)`` before the softmax (Gemma-2).
+    ``sinks [Hq]`` (fp32): one extra score per query head that only enters the softmax's denominator
+    (attention sinks).  ``alibi_slopes [Hq]`` (fp32): key ``k`` gets ``slope * (k - query position)`` added."""
     b, hq, d = q.shape
     hkv = k_cache.shape[1]
     bs = _check_cache(k_cache, v_cache, hkv, d)
@@ -350,14 +360,14 @@ def paged_attention_decode(q, k_cache, v_cache, block_table, seq_lens, scale, ma
     _check(_LIB.vdamd_paged_attention_decode(
         out.data_ptr(), ws_ptr, q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(),
         block_table.data_ptr(), block_table.stride(0), seq_lens.data_ptr(), float(scale), b, hq, hkv, d, bs,
-        num_splits, hq * d, _dt(q), *_kv_args(k_cache, kv_scales, hkv), int(window), float(softcap), _stream()),
-        "paged_attention_decode")
+        num_splits, hq * d, _dt(q), *_kv_args(k_cache, kv_scales, hkv), int(window), float(softcap),
+        _per_head(sinks, hq, q), _per_head(alibi_slopes, hq, q), _stream()), "paged_attention_decode")
     return out
 
 
 def paged_attention_prefill(q, k_cache, v_cache, block_table, query_start_loc, seq_lens, scale,
                             max_query_len=0, max_seq_len=0, out=None, kv_scales=None, window: int = 0,
-                            softcap: float = 0.0) -> torch.Tensor:
+                            softcap: float = 0.0, sinks=None, alibi_slopes=None) -> torch.Tensor:
     t, hq, d = q.shape
     hkv = k_cache.shape[1]
     bs = _check_cache(k_cache, v_cache, hkv, d)
@@ -377,7 +387,8 @@ def paged_attention_prefill(q, k_cache, v_cache, block_table, query_start_loc, s
         out.data_ptr(), q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(),
         block_table.data_ptr(), block_table.stride(0), query_start_loc.data_ptr(), seq_lens.data_ptr(),
         float(scale), nseq, max_query_len, hq, hkv, d, bs, hq * d, _dt(q), *_kv_args(k_cache, kv_scales, hkv),
-        int(window), float(softcap), _stream()), "paged_attention_prefill")
+        int(window), float(softcap), _per_head(sinks, hq, q), _per_head(alibi_slopes, hq, q), _stream()),
+        "paged_attention_prefill")
     return out
 
 

@@ -216,13 +216,15 @@ def _gather_kv(k_cache, v_cache, block_table_row, seq_len, kv_scales=None):
 def paged_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                     block_table: torch.Tensor, query_start_loc: torch.Tensor,
                     seq_lens: torch.Tensor, scale: float, kv_scales=None, window: int = 0,
-                    softcap: float = 0.0) -> torch.Tensor:
+                    softcap: float = 0.0, sinks=None, alibi_slopes=None) -> torch.Tensor:
     """Causal attention of each sequence's query chunk against its paged KV
     (which already contains the chunk).  ``q[T, Hq, D]``; sequence ``i`` owns
     query rows ``query_start_loc[i]:query_start_loc[i+1]`` which are the last
     ``q_len`` positions of its ``seq_lens[i]`` tokens.  ``window > 0``: a query at
     position ``p`` sees keys ``p - window + 1 .. p`` only (sliding-window attention).
-    ``softcap > 0``: scores are squashed to ``softcap * tanh(score / softcap)`` (Gemma-2)."""
+    ``softcap > 0``: scores are squashed to ``softcap * tanh(score / softcap)`` (Gemma-2).
+    ``sinks [Hq]``: one extra score per head that joins the softmax and is then dropped (attention sinks).
+    ``alibi_slopes [Hq]``: ``slope * (key position - query position)`` is added to the scores."""
     out = torch.empty_like(q)
     hq = q.shape[1]
     hkv = k_cache.shape[1]
@@ -243,19 +245,28 @@ def paged_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tenso
             scores = torch.tanh(scores / softcap) * softcap
         qpos = torch.arange(sl - ql, sl, device=q.device).unsqueeze(1)
         kpos = torch.arange(sl, device=q.device).unsqueeze(0)
+        if alibi_slopes is not None:
+            scores = scores + alibi_slopes.float().view(-1, 1, 1) * (kpos - qpos).float()
         scores = scores.masked_fill(kpos > qpos, float("-inf"))
         if window > 0:
             scores = scores.masked_fill(kpos <= qpos - window, float("-inf"))
-        out[s:e] = torch.matmul(torch.softmax(scores, -1), v).transpose(0, 1).to(q.dtype)
+        if sinks is not None:
+            col = sinks.float().view(-1, 1, 1).expand(hq, ql, 1)
+            probs = torch.softmax(torch.cat([scores, col], dim=-1), -1)[..., :-1]
+        else:
+            probs = torch.softmax(scores, -1)
+        out[s:e] = torch.matmul(probs, v).transpose(0, 1).to(q.dtype)
     return out
 
 
 def paged_attention_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                            block_table: torch.Tensor, seq_lens: torch.Tensor,
-                           scale: float, kv_scales=None, window: int = 0, softcap: float = 0.0) -> torch.Tensor:
+                           scale: float, kv_scales=None, window: int = 0, softcap: float = 0.0,
+                           sinks=None, alibi_slopes=None) -> torch.Tensor:
     b = q.shape[0]
     qsl = torch.arange(b + 1, device=q.device, dtype=torch.int32)
-    return paged_attention(q, k_cache, v_cache, block_table, qsl, seq_lens, scale, kv_scales, window, softcap)
+    return paged_attention(q, k_cache, v_cache, block_table, qsl, seq_lens, scale, kv_scales, window, softcap,
+                           sinks, alibi_slopes)
 
 
 # ---------------------------------------------------------------- sampling
