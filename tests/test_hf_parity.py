@@ -47,6 +47,15 @@ CASES = {
     "falcon-7b": ("FalconConfig", dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, vocab_size=320, alibi=False, bias=False, new_decoder_architecture=False, multi_query=True, parallel_attn=True)),
     "falcon-seq": ("FalconConfig", dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, vocab_size=320, alibi=False, new_decoder_architecture=False, multi_query=False, parallel_attn=False,
                                          bias=True)),
+    # ALiBi instead of rotary embeddings: Falcon-RW (bias scaled with the scores), Bloom (both residual forms,
+    # a head count that is not a power of two), MPT (its own slope sequence, no biases anywhere, q/k/v clamp)
+    "falcon-rw": ("FalconConfig", dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, vocab_size=320, alibi=True,
+                                       new_decoder_architecture=False, multi_query=False, parallel_attn=False, bias=True)),
+    "bloom": ("BloomConfig", dict(hidden_size=96, n_layer=2, n_head=6, vocab_size=320)),
+    "bloom-post-ln": ("BloomConfig", dict(hidden_size=64, n_layer=2, n_head=4, vocab_size=320,
+                                          apply_residual_connection_post_layernorm=True)),
+    "mpt": ("MptConfig", dict(d_model=96, n_heads=6, n_layers=2, vocab_size=320, max_seq_len=128,
+                              attn_config=dict(alibi=True, alibi_bias_max=8, clip_qkv=0.8))),
     "starcoder2": ("Starcoder2Config", dict(BASE, sliding_window=None, use_bias=True)),
     "qwen3-moe": ("Qwen3MoeConfig", dict(BASE, head_dim=32, moe_intermediate_size=64, num_experts=8,
                                          num_experts_per_tok=2, norm_topk_prob=True, decoder_sparse_step=1,

@@ -26,7 +26,7 @@ MLA_EXPANDED = {"deepseek-v3-tiny"}
 TIGHT = {"llama-tiny", "opt-tiny", "phi3-tiny", "gemma-tiny", "granite-tiny", "gpt2-tiny", "gpt-neox-tiny",
          "starcoder2-tiny", "mistral-window-tiny", "phi-tiny", "phi2-tiny", "glm-tiny", "helium-tiny", "smollm3-tiny",
          "glm4-tiny", "olmo2-tiny", "exaone4-tiny", "nemotron-tiny", "stablelm-tiny", "arcee-tiny", "falcon-tiny",
-         "gptj-tiny", "gpt-bigcode-tiny"}
+         "gptj-tiny", "gpt-bigcode-tiny", "bloom-tiny", "mpt-tiny", "falcon-rw-tiny"}
 
 
 @pytest.mark.parametrize("model", ["llama-tiny", "opt-tiny", "qwen3-moe-tiny", "mixtral-tiny", "phi3-tiny",
@@ -36,7 +36,8 @@ TIGHT = {"llama-tiny", "opt-tiny", "phi3-tiny", "gemma-tiny", "granite-tiny", "g
                                    "glm-tiny", "helium-tiny", "smollm3-tiny", "glm4-tiny", "olmo2-tiny",
                                    "exaone4-tiny", "nemotron-tiny", "stablelm-tiny", "cohere-tiny", "arcee-tiny",
                                    "deepseek-v3-tiny", "glm4-moe-tiny", "falcon-tiny", "gptj-tiny",
-                                   "gpt-bigcode-tiny", "gpt-oss-tiny"])
+                                   "gpt-bigcode-tiny", "gpt-oss-tiny",
+                                   "bloom-tiny", "mpt-tiny", "falcon-rw-tiny"])
 def test_model_family_on_gpu_tracks_cpu_reference(model, tmp_path):
     overrides = QWEN3_SMALL if model == "qwen3-coder-480b-a35b" else {}
     mc = ModelConfig(model=model, dtype="float32", load_format="dummy", hf_overrides=overrides)

@@ -88,7 +88,10 @@ def normalize_hf_config(cfg: Dict[str, Any]) -> None:
     block where older checkpoints have ``num_experts`` / ``torch_dtype`` / ``rope_theta`` + ``rope_scaling``."""
     # GPT-2 era spellings
     for old, new in (("n_embd", "hidden_size"), ("n_head", "num_attention_heads"), ("n_layer", "num_hidden_layers"),
-                     ("n_positions", "max_position_embeddings")):
+                     ("n_positions", "max_position_embeddings"),
+                     # MPT
+                     ("d_model", "hidden_size"), ("n_heads", "num_attention_heads"), ("n_layers", "num_hidden_layers"),
+                     ("max_seq_len", "max_position_embeddings")):
         if cfg.get(new) is None and cfg.get(old) is not None:
             cfg[new] = cfg[old]
     if cfg.get("num_experts") is None and cfg.get("num_local_experts") is not None:
@@ -291,7 +294,8 @@ class ModelConfig:
                 "stablelm": "StableLmForCausalLM", "nemotron": "NemotronForCausalLM",
                 "cohere": "CohereForCausalLM",
                 "qwen3": "Qwen3ForCausalLM", "mistral": "MistralForCausalLM",
-                "mixtral": "MixtralForCausalLM", "phi3": "Phi3ForCausalLM", "gpt_oss": "GptOssForCausalLM"}.get(mt, mt)
+                "mixtral": "MixtralForCausalLM", "phi3": "Phi3ForCausalLM", "gpt_oss": "GptOssForCausalLM",
+                "bloom": "BloomForCausalLM", "mpt": "MptForCausalLM"}.get(mt, mt)
 
     @property
     def hidden_size(self) -> int:

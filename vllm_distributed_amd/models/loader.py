@@ -115,6 +115,29 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
             shapes[q + "mlp.fc_in.weight"], shapes[q + "mlp.fc_in.bias"] = (inner, h), (inner,)
             shapes[q + "mlp.fc_out.weight"], shapes[q + "mlp.fc_out.bias"] = (h, inner), (h,)
         return shapes
+    if arch == "BloomForCausalLM":
+        heads = c["num_attention_heads"]
+        shapes["transformer.word_embeddings.weight"] = (c["vocab_size"], h)
+        for n in ("word_embeddings_layernorm", "ln_f"):
+            shapes[f"transformer.{n}.weight"] = shapes[f"transformer.{n}.bias"] = (h,)
+        for i in range(L):
+            q = f"transformer.h.{i}."
+            for n in ("input_layernorm", "post_attention_layernorm"):
+                shapes[q + n + ".weight"] = shapes[q + n + ".bias"] = (h,)
+            for n, (o, k) in (("self_attention.query_key_value", (3 * h, h)), ("self_attention.dense", (h, h)),
+                              ("mlp.dense_h_to_4h", (4 * h, h)), ("mlp.dense_4h_to_h", (h, 4 * h))):
+                shapes[q + n + ".weight"], shapes[q + n + ".bias"] = (o, k), (o,)
+        return shapes
+    if arch in ("MptForCausalLM", "MPTForCausalLM"):
+        inner = int(c.get("expansion_ratio", 4)) * h
+        shapes["transformer.wte.weight"] = (c["vocab_size"], h)
+        shapes["transformer.norm_f.weight"] = (h,)
+        for i in range(L):
+            q = f"transformer.blocks.{i}."
+            shapes[q + "norm_1.weight"] = shapes[q + "norm_2.weight"] = (h,)
+            shapes[q + "attn.Wqkv.weight"], shapes[q + "attn.out_proj.weight"] = (3 * h, h), (h, h)
+            shapes[q + "ffn.up_proj.weight"], shapes[q + "ffn.down_proj.weight"] = (inner, h), (h, inner)
+        return shapes
     if arch in ("FalconForCausalLM", "RWForCausalLM"):
         from .falcon import falcon_kv_heads
         heads, kvh = c["num_attention_heads"], falcon_kv_heads(c)

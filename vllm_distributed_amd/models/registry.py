@@ -52,6 +52,10 @@ _MODELS: Dict[str, Tuple[str, str]] = {
     "GPTNeoXForCausalLM": ("gpt_neox", "GPTNeoXForCausalLM"),
     "FalconForCausalLM": ("falcon", "FalconForCausalLM"),
     "RWForCausalLM": ("falcon", "FalconForCausalLM"),
+    # the same block with ALiBi position biases and other bias / norm / activation switches
+    "BloomForCausalLM": ("bloom", "BloomForCausalLM"),
+    "MptForCausalLM": ("mpt", "MptForCausalLM"),
+    "MPTForCausalLM": ("mpt", "MptForCausalLM"),
     "Starcoder2ForCausalLM": ("starcoder2", "Starcoder2ForCausalLM"),
 }
 

@@ -195,6 +195,29 @@ def rope_and_cache(positions: torch.Tensor, qkv: torch.Tensor, cos_sin_cache: to
     return q
 
 
+def alibi_slopes(num_heads: int, kind: str = "bloom", bias_max: float = 8.0) -> torch.Tensor:
+    """Per-head slopes of the linear position bias (fp32 ``[num_heads]``).  ``bloom`` (also Falcon-RW):
+    a geometric sequence over the largest power of two not above the head count, the remaining heads
+    taking every other step of the next finer sequence.  ``mpt``: the sequence over the next power of
+    two at or above the head count with exponent step ``bias_max / n``, odd entries first when the
+    count is not a power of two."""
+    if kind == "mpt":
+        n = 2 ** math.ceil(math.log2(num_heads))
+        s = 1.0 / torch.pow(2.0, torch.arange(1, n + 1, dtype=torch.float32) * (bias_max / n))
+        if n != num_heads:
+            s = torch.cat([s[1::2], s[::2]])[:num_heads]
+        return s.contiguous()
+    n = 2 ** math.floor(math.log2(num_heads))
+    base = 2.0 ** (-(2.0 ** -(math.log2(n) - 3)))
+    s = torch.pow(torch.tensor(base, dtype=torch.float32), torch.arange(1, n + 1, dtype=torch.float32))
+    if n != num_heads:
+        extra = 2.0 ** (-(2.0 ** -(math.log2(2 * n) - 3)))
+        rest = min(n, num_heads - n)
+        s = torch.cat([s, torch.pow(torch.tensor(extra, dtype=torch.float32),
+                                    torch.arange(1, 1 + 2 * rest, 2, dtype=torch.float32))])
+    return s.contiguous()
+
+
 def _gather_kv(k_cache, v_cache, block_table_row, seq_len, kv_scales=None):
     bs = k_cache.shape[2]
     nb = (seq_len + bs - 1) // bs
