@@ -4,6 +4,9 @@ packed experts plus a KV cache.  Random weights of the real shapes; reports load
 time, memory and decode speed.
 
     python benchmarks/qwen480b_single_gpu.py [--layers 62] [--batch 16] [--steps 32] [--quantization awq|nvfp4]
+
+``--model gpt-oss-120b --quantization none`` runs another bundled sparse architecture the same way (gpt-oss:
+experts widened to bf16, 36 layers = 218 GiB of weights).
 """
 import argparse
 import json
@@ -20,7 +23,8 @@ from vllm_distributed_amd.engine.llm_engine import LLMEngine       # noqa: E402
 from vllm_distributed_amd.sampling_params import SamplingParams    # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--layers", type=int, default=62)
+ap.add_argument("--model", default="qwen3-coder-480b-a35b")
+ap.add_argument("--layers", type=int, default=0, help="0: as many as the architecture has")
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--prompt-len", type=int, default=128)
 ap.add_argument("--steps", type=int, default=32)
@@ -31,8 +35,8 @@ args = ap.parse_args()
 
 t0 = time.time()
 eng = LLMEngine.from_engine_args(EngineArgs(
-    model="qwen3-coder-480b-a35b", load_format="dummy", quantization=args.quantization,
-    hf_overrides={"num_hidden_layers": args.layers}, max_model_len=4096, max_num_seqs=max(args.batch, 8),
+    model=args.model, load_format="dummy", quantization=None if args.quantization == "none" else args.quantization,
+    hf_overrides={"num_hidden_layers": args.layers} if args.layers else {}, max_model_len=4096, max_num_seqs=max(args.batch, 8),
     max_num_batched_tokens=args.max_batched_tokens, gpu_memory_utilization=args.gpu_memory_utilization, enable_prefix_caching=False,
     hip_graph_sizes=[args.batch], max_capture_size=args.batch, async_scheduling=True))
 load_s = time.time() - t0
@@ -55,7 +59,7 @@ for _ in range(args.steps):
     eng.step()
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t2) / args.steps * 1e3
-print(json.dumps({"model": "qwen3-coder-480b-a35b", "layers": args.layers, "quantization": args.quantization,
+print(json.dumps({"model": args.model, "layers": eng.core.vllm_config.model_config.num_hidden_layers, "quantization": args.quantization,
                   "gpus": 1, "batch": args.batch, "prompt_len": args.prompt_len, "load_s": round(load_s, 1),
                   "prefill_s": round(prefill_s, 2), "decode_ms_per_step": round(ms, 2),
                   "decode_tokens_per_s": round(args.batch / ms * 1e3, 1),

@@ -298,16 +298,20 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(T* __restrict__ out, l
                                                           const T* __restrict__ y, long y_stride,
                                                           const float* __restrict__ topw, const int* __restrict__ topi,
                                                           const int* __restrict__ inv, int k, int H, int expert_start,
-                                                          int local_experts) {
+                                                          int local_experts, const T* __restrict__ bias) {
+  // bias (nullable): [local experts][H], added to an expert's row (and rounded to T, as a biased linear
+  // layer would) before the row is weighed
   using V = typename Vec8<T>::type;
   const int t = blockIdx.x;
   __shared__ float w[TOPK_MAX_K];
   __shared__ int pos[TOPK_MAX_K];
+  __shared__ int loc[TOPK_MAX_K];
   if (threadIdx.x < k) {
     const int e = topi[(long)t * k + threadIdx.x];
     const bool local = local_experts < 0 || (e >= expert_start && e < expert_start + local_experts);
     w[threadIdx.x] = local ? topw[(long)t * k + threadIdx.x] : 0.f;
     pos[threadIdx.x] = local ? inv[(long)t * k + threadIdx.x] : -1;
+    loc[threadIdx.x] = e - expert_start;
   }
   __syncthreads();
   const int h = blockIdx.y * 2048 + threadIdx.x * 8;
@@ -315,7 +319,12 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(T* __restrict__ out, l
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int j = 0; j < k; ++j) {
       if (pos[j] < 0) continue;          // an expert another rank holds: its row was never computed here
-      const V v = ld8<T>(y + (long)pos[j] * y_stride + h);
+      V v = ld8<T>(y + (long)pos[j] * y_stride + h);
+      if (bias != nullptr) {
+        const V b = ld8<T>(bias + (long)loc[j] * H + h);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (T)((float)v[i] + (float)b[i]);
+      }
       const float wj = w[j];
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i] += wj * (float)v[i];
@@ -325,6 +334,34 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(T* __restrict__ out, l
     for (int i = 0; i < 8; ++i) o[i] = (T)acc[i];
     st8<T>(out + (long)t * out_stride + h, o);
   }
+}
+
+// gpt-oss experts: out[row][c] = (up + 1) * gate * sigmoid(alpha * gate) with gate = min(h[row][c] + b[e][c], limit)
+// and up = clamp(h[row][ip + c] + b[e][ip + c], -limit, limit), for the sorted row of every (token, choice) slot
+// whose expert e is held here.  grid (slots, ceil(ip / 2048)).
+template <typename T>
+__global__ __launch_bounds__(256) void bias_clamped_glu_kernel(T* __restrict__ out, long out_stride,
+                                                               const T* __restrict__ h, long h_stride,
+                                                               const T* __restrict__ bias, const int* __restrict__ topi,
+                                                               const int* __restrict__ inv, int ip, int expert_start,
+                                                               int local_experts, float limit, float alpha) {
+  using V = typename Vec8<T>::type;
+  const int slot = blockIdx.x;
+  const int le = topi[slot] - expert_start;
+  if (local_experts >= 0 && (le < 0 || le >= local_experts)) return;
+  const long row = inv[slot];
+  const int c = blockIdx.y * 2048 + threadIdx.x * 8;
+  if (c >= ip) return;
+  const V g = ld8<T>(h + row * h_stride + c), u = ld8<T>(h + row * h_stride + ip + c);
+  const V bg = ld8<T>(bias + (long)le * 2 * ip + c), bu = ld8<T>(bias + (long)le * 2 * ip + ip + c);
+  V o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float gate = fminf((float)(T)((float)g[i] + (float)bg[i]), limit);
+    const float up = fminf(fmaxf((float)(T)((float)u[i] + (float)bu[i]), -limit), limit);
+    o[i] = (T)((up + 1.f) * gate / (1.f + __expf(-alpha * gate)));
+  }
+  st8<T>(out + row * out_stride + c, o);
 }
 
 // One workgroup per token: the weighted sum of its k expert rows (rounded to T, as moe_combine writes it),
@@ -426,15 +463,17 @@ VDAMD_API int vdamd_moe_align(const int* topi, int slots, int k, int E, int tile
 
 VDAMD_API int vdamd_moe_combine(void* out, long out_stride, const void* y, long y_stride, const float* topw,
                                 const int* topi, const int* inv, int tokens, int k, int H, int expert_start,
-                                int local_experts, int dtype, hipStream_t s) {
+                                int local_experts, const void* bias, int dtype, hipStream_t s) {
   if (tokens <= 0) return 0;
   if (H % 8 || k < 1 || k > TOPK_MAX_K) return -1;
   if (dtype == DT_BF16)
     hipLaunchKernelGGL((moe_combine_kernel<bf16_t>), dim3(tokens, (H + 2047) / 2048), dim3(256), 0, s, (bf16_t*)out, out_stride,
-                       (const bf16_t*)y, y_stride, topw, topi, inv, k, H, expert_start, local_experts);
+                       (const bf16_t*)y, y_stride, topw, topi, inv, k, H, expert_start, local_experts,
+                       (const bf16_t*)bias);
   else if (dtype == DT_F16)
     hipLaunchKernelGGL((moe_combine_kernel<f16_t>), dim3(tokens, (H + 2047) / 2048), dim3(256), 0, s, (f16_t*)out, out_stride,
-                       (const f16_t*)y, y_stride, topw, topi, inv, k, H, expert_start, local_experts);
+                       (const f16_t*)y, y_stride, topw, topi, inv, k, H, expert_start, local_experts,
+                       (const f16_t*)bias);
   else
     return -2;
   HIP_LAUNCH_CHECK();
@@ -494,6 +533,28 @@ VDAMD_API int vdamd_moe_combine_add_rms_norm(void* out, long out_stride, const v
     hipLaunchKernelGGL((moe_combine_add_rms_norm_kernel<f16_t>), dim3(tokens), dim3(threads), 0, s, (f16_t*)out,
                        out_stride, (const f16_t*)y, y_stride, topw, topi, inv, k, H, expert_start, local_experts,
                        (f16_t*)residual, (const f16_t*)gamma, eps);
+  else
+    return -2;
+  HIP_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[row] = clamped GLU of h[row] + bias[expert of row] for the sorted rows of all `slots` (token, choice) pairs;
+// h is [rows][2 ip] = [gate | up], bias [local experts][2 ip], out [rows][out_stride >= ip].
+VDAMD_API int vdamd_bias_clamped_glu(void* out, long out_stride, const void* h, long h_stride, const void* bias,
+                                     const int* topi, const int* inv, int slots, int ip, int expert_start,
+                                     int local_experts, float limit, float alpha, int dtype, hipStream_t s) {
+  if (slots <= 0) return 0;
+  if (ip % 8 || h_stride % 8 || out_stride % 8) return -1;
+  const dim3 grid(slots, (ip + 2047) / 2048);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL((bias_clamped_glu_kernel<bf16_t>), grid, dim3(256), 0, s, (bf16_t*)out, out_stride,
+                       (const bf16_t*)h, h_stride, (const bf16_t*)bias, topi, inv, ip, expert_start, local_experts,
+                       limit, alpha);
+  else if (dtype == DT_F16)
+    hipLaunchKernelGGL((bias_clamped_glu_kernel<f16_t>), grid, dim3(256), 0, s, (f16_t*)out, out_stride,
+                       (const f16_t*)h, h_stride, (const f16_t*)bias, topi, inv, ip, expert_start, local_experts,
+                       limit, alpha);
   else
     return -2;
   HIP_LAUNCH_CHECK();

@@ -67,7 +67,8 @@ class GptOssMoE(FusedMoE):
 
     def __init__(self, cfg: dict, dtype: torch.dtype, expert_parallel: bool):
         super().__init__(cfg["hidden_size"], cfg["intermediate_size"], cfg["num_local_experts"],
-                         cfg["num_experts_per_tok"], True, dtype, expert_parallel=expert_parallel)
+                         cfg["num_experts_per_tok"], True, dtype, expert_parallel=expert_parallel,
+                         allocate_experts=False)
         if self.quant is not None:
             raise NotImplementedError("packed 4-bit gpt-oss experts (AWQ / NVFP4); MXFP4 checkpoints are widened at load")
         self.gate = ReplicatedLinear(self.hidden, self.num_experts, True, dtype, quant=False)
@@ -145,14 +146,11 @@ class GptOssMoE(FusedMoE):
         local = self.local_experts if self.expert_parallel else -1
         topw, topi = ops.moe_topk(logits, self.top_k, True)
         src_row, inv, tiles = ops.moe_align_fused(topi, self.num_experts, tile_rows, self.expert_start, local)
-        flat = topi.reshape(-1).long()
-        row_e = torch.empty_like(flat)
-        row_e[inv.long()] = flat                                  # expert of every sorted row
-        row_e = (row_e - self.expert_start).clamp_(0, self.local_experts - 1)
         xs = self._pad(x).index_select(0, src_row)
-        h = ops.grouped_linear(xs, tiles, tile_rows, weight=self.w13) + self.b13.index_select(0, row_e)
-        y = ops.grouped_linear(self._act(h), tiles, tile_rows, weight=self.w2) + self.b2.index_select(0, row_e)
-        return ops.moe_combine(y, topw, topi, inv, self.expert_start, local)
+        h = ops.grouped_linear(xs, tiles, tile_rows, weight=self.w13)
+        a = ops.bias_clamped_glu(h, self.b13, topi, inv, self.expert_start, local, self.limit, self.ALPHA)
+        y = ops.grouped_linear(a, tiles, tile_rows, weight=self.w2)
+        return ops.moe_combine(y, topw, topi, inv, self.expert_start, local, bias=self.b2)
 
     def forward(self, x: torch.Tensor, reduce: bool = True, staged: bool = False, deferred: bool = False):
         logits = self.gate(x)

@@ -51,7 +51,9 @@ class ExpertRows:
 
 class FusedMoE(nn.Module):
     def __init__(self, hidden: int, inter: int, num_experts: int, top_k: int,
-                 renormalize: bool, dtype: torch.dtype, expert_parallel: bool = False):
+                 renormalize: bool, dtype: torch.dtype, expert_parallel: bool = False,
+                 allocate_experts: bool = True):
+        # allocate_experts = False: a subclass lays out its own (dense) expert tensors
         super().__init__()
         self.tp = get_tensor_model_parallel_world_size()
         self.tp_rank = get_tensor_model_parallel_rank()
@@ -82,6 +84,8 @@ class FusedMoE(nn.Module):
             p = nn.Parameter(torch.empty(*shape, dtype=dt), requires_grad=False)
             p.out_dim, p.pack, p.in_div, p.weight_loader = out_dim, pack, in_div, loader
             return p
+        if not allocate_experts:
+            return
         if self.quant is None:
             self.w13 = param(E, 2 * I, hidden, loader=self._load_w13)
             self.w2 = param(E, hidden, I, loader=self._load_w2)

@@ -531,8 +531,13 @@ def moe_route_small(logits, x, k: int, renormalize: bool, tile_rows: int, expert
     return _hip.moe_route_small(logits, x, k, renormalize, tile_rows, expert_start, local_experts)
 
 
-def moe_combine(y, topw, topi, inv, expert_start: int = 0, local_experts: int = -1):
-    return _hip.moe_combine(y, topw, topi, inv, expert_start, local_experts)
+def moe_combine(y, topw, topi, inv, expert_start: int = 0, local_experts: int = -1, bias=None):
+    return _hip.moe_combine(y, topw, topi, inv, expert_start, local_experts, bias)
+
+
+def bias_clamped_glu(h, bias, topi, inv, expert_start: int, local_experts: int, limit: float, alpha: float):
+    """gpt-oss expert activation with the per-expert bias, on expert-sorted rows (HIP only)."""
+    return _hip.bias_clamped_glu(h, bias, topi, inv, expert_start, local_experts, limit, alpha)
 
 
 def moe_combine_add_rms_norm(y, topw, topi, inv, expert_start, local_experts, residual, weight, eps):

@@ -54,7 +54,8 @@ def load() -> ctypes.CDLL:
         "vdamd_moe_topk": [P, L, P, P, I, I, I, I, I, P],
         "vdamd_moe_align": [P, I, I, I, I, I, I, P, P, P, I, P],
         "vdamd_moe_route_small": [P, L, I, I, I, I, I, I, I, P, P, P, P, P, I, P, L, P, I, I, I, I, L, P],
-        "vdamd_moe_combine": [P, L, P, L, P, P, P, I, I, I, I, I, I, P],
+        "vdamd_moe_combine": [P, L, P, L, P, P, P, I, I, I, I, I, P, I, P],
+        "vdamd_bias_clamped_glu": [P, L, P, L, P, P, P, I, I, I, I, F, F, I, P],
         "vdamd_moe_combine_add_rms_norm": [P, L, P, L, P, P, P, I, I, I, I, I, P, P, F, I, P],
         "vdamd_fp4a16_gemm": [P, L, P, L, P, P, P, P, I, I, I, I, I, I, P],
         "vdamd_fp4_dequant": [P, P, P, P, I, I, I, P],
@@ -996,16 +997,40 @@ def moe_route_small(logits: torch.Tensor, x: torch.Tensor, k: int, renormalize: 
 
 
 def moe_combine(y: torch.Tensor, topw: torch.Tensor, topi: torch.Tensor, inv: torch.Tensor, expert_start: int = 0,
-                local_experts: int = -1) -> torch.Tensor:
-    """``out[t] = sum_j topw[t, j] * y[inv[t*k + j]]`` in fp32 (slots of experts this rank does not hold are skipped)."""
+                local_experts: int = -1, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``out[t] = sum_j topw[t, j] * y[inv[t*k + j]]`` in fp32 (slots of experts this rank does not hold are skipped).
+    ``bias [local experts, H]``: each row first gains its expert's bias (rounded to the row's dtype)."""
     t, k = topi.shape
     h = y.shape[1]
+    if bias is not None:
+        assert bias.dtype == y.dtype and bias.dim() == 2 and bias.shape[1] == h and bias.is_contiguous()
+        assert bias.shape[0] >= (local_experts if local_experts >= 0 else 1)
     assert _half(y) and y.stride(1) == 1 and y.stride(0) % 8 == 0 and h % 8 == 0 and y.data_ptr() % 16 == 0
     assert topw.dtype == torch.float32 and topw.is_contiguous() and topi.is_contiguous() and inv.numel() == t * k
     out = torch.empty((t, h), dtype=y.dtype, device=y.device)
     _check(_LIB.vdamd_moe_combine(out.data_ptr(), h, y.data_ptr(), y.stride(0), topw.data_ptr(), topi.data_ptr(),
-                                  inv.data_ptr(), t, k, h, expert_start, local_experts, _dt(y), _stream()),
+                                  inv.data_ptr(), t, k, h, expert_start, local_experts,
+                                  None if bias is None else bias.data_ptr(), _dt(y), _stream()),
            "moe_combine")
+    return out
+
+
+def bias_clamped_glu(h: torch.Tensor, bias: torch.Tensor, topi: torch.Tensor, inv: torch.Tensor, expert_start: int,
+                     local_experts: int, limit: float, alpha: float) -> torch.Tensor:
+    """gpt-oss expert activation on expert-sorted rows ``h [rows, 2 ip] = [gate | up]``: every row gains the
+    ``[2 ip]`` bias of its expert, then ``(up + 1) * gate * sigmoid(alpha * gate)`` with ``gate`` clamped from
+    above and ``up`` on both sides; returns ``[rows, ip]``.  Rows of slots whose expert lives elsewhere are
+    left unwritten (their weights are zero in the combine)."""
+    rows, two_ip = h.shape
+    ip = two_ip // 2
+    slots = topi.numel()
+    assert _half(h) and h.stride(1) == 1 and ip % 8 == 0 and inv.numel() == slots and rows >= slots
+    assert bias.dtype == h.dtype and bias.shape[1] == two_ip and bias.is_contiguous()
+    assert topi.dtype == torch.int32 and inv.dtype == torch.int32 and topi.is_contiguous() and inv.is_contiguous()
+    out = torch.empty((rows, ip), dtype=h.dtype, device=h.device)
+    _check(_LIB.vdamd_bias_clamped_glu(out.data_ptr(), ip, h.data_ptr(), h.stride(0), bias.data_ptr(), topi.data_ptr(),
+                                       inv.data_ptr(), slots, ip, expert_start, local_experts, float(limit),
+                                       float(alpha), _dt(h), _stream()), "bias_clamped_glu")
     return out
 
 
