@@ -134,7 +134,7 @@ class SchedulerKVConnector:
                                               pc.tensor_parallel_size, pc.pipeline_parallel_size,
                                               getattr(vllm_config.cache_config, "cache_dtype", "auto")))
         if self.path:
-            os.makedirs(self.path, exist_ok=True)
+            os.makedirs(self.path, mode=0o700, exist_ok=True)      # hand-over descriptors name mappable device memory
         self._loads: List[dict] = []              # decided while scheduling, shipped with the step
         self._saves: List[dict] = []
         self.sending: Set[str] = set()            # saves asked for and not yet confirmed by every rank
