@@ -281,8 +281,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // most of them one group each and then pays an LDS exchange, a barrier and a cross-wave combine
 // per sequence.  Here a wave walks all groups of its sequence and writes its rows itself: no LDS,
 // no barrier, and consecutive sequences of a workgroup keep the load queues of the CU busy.
+// (three waves per SIMD: at four, 128 registers, the q fragments spill and are reloaded inside the key loop)
 template <typename T, int D, bool KV8>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void paged_decode_wave_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void paged_decode_wave_kernel(
     T* __restrict__ out, const T* __restrict__ q, long q_stride, const void* __restrict__ k_cache,
     const void* __restrict__ v_cache, const int* __restrict__ block_table, int bt_stride,
     const int* __restrict__ seq_lens, float scale_log2e, int B, int Hq, int Hkv, int block_size, long out_stride,
@@ -451,217 +452,20 @@ __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-template <typename T, bool KV8>
-__global__ __launch_bounds__(256, 2) void paged_prefill_lds_kernel(
-    T* __restrict__ out, const T* __restrict__ q, long q_stride, const void* __restrict__ k_cache,
-    const void* __restrict__ v_cache, const int* __restrict__ block_table, int bt_stride,
-    const int* __restrict__ query_start_loc, const int* __restrict__ seq_lens, float scale_log2e, int Hq, int Hkv,
-    int block_size, long out_stride, int q_tiles, int total_wgs, int xcd_remap,
-    const float* __restrict__ k_scales, const float* __restrict__ v_scales, int window, float softcap,
-    const float* __restrict__ sinks, const float* __restrict__ alibi) {
-  using V = typename Vec8<T>::type;
-  constexpr int D = 128, KT = 64, TILE_BYTES = KT * D * 2;
-  __shared__ __attribute__((aligned(16))) char smem[2][2][TILE_BYTES];     // [buffer][K | V^T]
-
-  // Workgroups are handed to the 8 XCDs round-robin by their linear id, and each
-  // XCD has its own L2.  Remapping id -> (id % 8) * (n / 8) + id / 8 gives every
-  // XCD one contiguous run of (sequence, head, query tile) triples, i.e. the query
-  // tiles and the GQA group of *one* KV head, so a K/V tile is fetched into one L2
-  // instead of eight.
-  int wg = blockIdx.x;
-  if (xcd_remap) {
-    wg = (wg & 7) * ((int)gridDim.x >> 3) + (wg >> 3);
-    if (wg >= total_wgs) return;
-  }
-  const int qt = wg % q_tiles, head = (wg / q_tiles) % Hq, z = wg / (q_tiles * Hq);
-  const int q0 = query_start_loc[z];
-  const int q_len = query_start_loc[z + 1] - q0;
-  // heaviest (latest, longest causal span) query tiles are dispatched first
-  const int t_blk = (q_tiles - 1 - qt) * 128;
-  if (t_blk >= q_len) return;                       // uniform for the workgroup
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int l32 = lane & 31, h = lane >> 5;
-  const int seq_len = seq_lens[z];
-  const int ctx = seq_len - q_len;
-  const int kvh = head / (Hq / Hkv);
-  // an e4m3 cache is widened on its way into LDS: the tiles the MFMAs read are T either way
-  const float k_scale = (KV8 && k_scales != nullptr) ? k_scales[kvh] : 1.f;
-  const float v_scale = (KV8 && v_scales != nullptr) ? v_scales[kvh] : 1.f;
-  const float sl2e = scale_log2e * k_scale;
-  const float alibi_l2 = alibi != nullptr ? alibi[head] * LOG2E_F : 0.f;
-  const int t_wave = t_blk + wid * 32;
-  const int tok = t_wave + l32;
-  const bool wave_active = t_wave < q_len;
-  const int* bt_row = block_table + (long)z * bt_stride;
-
-  // Q^T B-operand fragments: 8 k-steps of 16 dims
-  V qf[8];
-#pragma unroll
-  for (int s = 0; s < 8; ++s)
-    qf[s] = (tok < q_len) ? ld8<T>(q + (long)(q0 + tok) * q_stride + (long)head * D + 16 * s + 8 * h) : zero8<T>();
-
-  f32x16 acc[4];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
-  float m_run = NEG_BIG, l_run = 0.f;
-  const int q_hi = min(ctx + tok, seq_len - 1);                    // last key this lane's query sees
-  const int q_lo = window > 0 ? max(0, ctx + tok - window + 1) : 0;  // first one, under a sliding window
-  const int wave_last_key = min(seq_len - 1, ctx + min(t_wave + 31, q_len - 1));
-  const int n_tiles = (min(seq_len - 1, ctx + min(t_blk + 127, q_len - 1)) >> 6) + 1;
-  // tiles wholly below the window of the workgroup's first query are skipped; the largest window edge
-  // of this wave decides which tiles need the lower compare
-  const int t_first = window > 0 ? max(0, ctx + t_blk - window + 1) >> 6 : 0;
-  const int wave_lo_max = window > 0 ? max(0, ctx + min(t_wave + 31, q_len - 1) - window + 1) : 0;
-
-  // per-thread staging coordinates: 4 K chunks + 4 V^T chunks of 16 bytes
-  V stage_k[4], stage_v[4];
-  auto load_tile = [&](int tile) {
-    const int base = tile * KT;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + 256 * i;
-      const int row = c >> 4, cc = c & 15;
-      const int key = min(base + row, seq_len - 1);
-      const long blk = bt_row[key / block_size];
-      stage_k[i] = ld_kv<T, KV8>(k_cache, ((blk * Hkv + kvh) * block_size + (key % block_size)) * (long)D + 8 * cc,
-                                 1.f);
-      const int d = ((c >> 7) << 4) | (c & 15), kc = (c >> 4) & 7;    // lanes walk the cache's chunk order
-      const int vkey = min(base + 8 * kc, seq_len - 1) & ~7;
-      const long blkv = bt_row[vkey / block_size];
-      stage_v[i] = ld_kv<T, KV8>(
-          v_cache, ((blkv * Hkv + kvh) * (long)(D / 16) + (d >> 4)) * (block_size * 16) +
-                       ((vkey % block_size) >> 3) * 128 + 8 * (d & 15), 1.f);
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + 256 * i;
-      const int row = c >> 4, cc = c & 15;
-      *reinterpret_cast<V*>(&smem[buf][0][row * 256 + ((cc ^ (row & 15)) << 4)]) = stage_k[i];
-      const int d = ((c >> 7) << 4) | (c & 15), kc = (c >> 4) & 7;
-      *reinterpret_cast<V*>(&smem[buf][1][d * 128 + ((kc ^ ((d >> 1) & 7)) << 4)]) = stage_v[i];
-    }
-  };
-
-  // MFMA row rho of a 32-key sub-tile reads LDS key row kappa(rho): bits 2 and 3 swapped
-  const int kappa = (l32 & ~12) | ((l32 & 4) << 1) | ((l32 & 8) >> 1);
-
-  load_tile(t_first);
-  store_tile(t_first & 1);
-  __syncthreads();
-
-  for (int t = t_first; t < n_tiles; ++t) {
-    const int buf = t & 1;
-    const bool more = t + 1 < n_tiles;
-    if (more) load_tile(t + 1);
-    const int base = t * KT;
-    if (wave_active && base <= wave_last_key) {
-      const char* ks = smem[buf][0];
-      const char* vs = smem[buf][1];
-      f32x16 sc[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sc[u][r] = 0.f;
-        const int row = 32 * u + kappa;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          const int chunk = 2 * s + h;
-          const V a = *reinterpret_cast<const V*>(ks + row * 256 + ((chunk ^ (row & 15)) << 4));
-          sc[u] = mfma32(a, qf[s], sc[u]);
-        }
-      }
-      // Only tiles that straddle the diagonal (or a window edge) need masking.  The others - nearly all
-      // of a long sequence - take the short path: the running max is found on the raw scores (the scale
-      // is positive) and the scale rides in the exponent's multiply-add, three VALU operations and one
-      // exponential per score instead of eight and one.
-      const bool need_mask = base + KT - 1 > min(ctx + t_wave, seq_len - 1) || base < wave_lo_max || softcap > 0.f ||
-                             alibi_l2 != 0.f;
-      float m_new, alpha, psum = 0.f;
-      V pf[4];
-      if (!need_mask) {
-        float rmax = fmaxf(sc[0][0], sc[1][0]);
-#pragma unroll
-        for (int r = 1; r < 16; ++r) rmax = fmaxf(rmax, fmaxf(sc[0][r], sc[1][r]));
-        rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
-        m_new = fmaxf(m_run, rmax * sl2e);
-        alpha = exp2f(m_run - m_new);
-        const float nm = -m_new;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float e = exp2f(fmaf(sc[u][r], sl2e, nm));
-            psum += e;
-            pf[2 * u + (r >> 3)][r & 7] = (T)e;
-          }
-      } else {
-        float tmax = NEG_BIG;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = base + 32 * u + 16 * (r >> 3) + 8 * h + (r & 7);
-            float sv = sc[u][r] * sl2e;
-            if (softcap > 0.f) sv = soft_cap_log2(sv, softcap);
-            sv = fmaf(alibi_l2, (float)(key - (ctx + tok)), sv);
-            const float v = (key <= q_hi && key >= q_lo) ? sv : NEG_BIG;
-            sc[u][r] = v;
-            tmax = fmaxf(tmax, v);
-          }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        m_new = fmaxf(m_run, tmax);
-        alpha = exp2f(m_run - m_new);
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            // (a query whose window starts above this tile has no visible key in it: see attend_loaded)
-            const float e = sc[u][r] <= 0.5f * NEG_BIG ? 0.f : exp2f(sc[u][r] - m_new);
-            psum += e;
-            pf[2 * u + (r >> 3)][r & 7] = (T)e;
-          }
-      }
-      l_run = l_run * alpha + psum;
-      m_run = m_new;
-      const bool rescale = __any(alpha != 1.f);     // the running max rarely moves after the first tiles
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        if (rescale) acc[dt] *= alpha;
-        const int d = 32 * dt + l32;
-#pragma unroll
-        for (int ks4 = 0; ks4 < 4; ++ks4) {
-          const int kc = 2 * ks4 + h;
-          const V a = *reinterpret_cast<const V*>(vs + d * 128 + ((kc ^ ((d >> 1) & 7)) << 4));
-          acc[dt] = mfma32(a, pf[ks4], acc[dt]);
-        }
-      }
-    }
-    if (more) store_tile(buf ^ 1);
-    __syncthreads();
-  }
-
-  if (tok < q_len) {
-    float lsum = l_run + __shfl_xor(l_run, 32, 64);
-    if (sinks != nullptr) lsum += exp2f(sinks[head] * LOG2E_F - m_run);
-    const float inv = lsum > 0.f ? v_scale / lsum : 0.f;
-    T* orow = out + (long)(q0 + tok) * out_stride + (long)head * D + 4 * h;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        typename Vec4<T>::type o4;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) o4[b] = (T)(acc[dt][4 * g + b] * inv);
-        *reinterpret_cast<typename Vec4<T>::type*>(orow + 32 * dt + 8 * g) = o4;
-      }
-  } else {
-    (void)__shfl_xor(l_run, 32, 64);
-  }
-}
+#define PREFILL_LDS_NAME paged_prefill_lds_kernel
+#define PREFILL_LDS_BIAS 0
+#define PREFILL_LDS_EXTRA_PARAMS
+#include "attention_prefill_lds.inc"
+#undef PREFILL_LDS_NAME
+#undef PREFILL_LDS_BIAS
+#undef PREFILL_LDS_EXTRA_PARAMS
+#define PREFILL_LDS_NAME paged_prefill_lds_bias_kernel
+#define PREFILL_LDS_BIAS 1
+#define PREFILL_LDS_EXTRA_PARAMS , const float *__restrict__ sinks, const float *__restrict__ alibi
+#include "attention_prefill_lds.inc"
+#undef PREFILL_LDS_NAME
+#undef PREFILL_LDS_BIAS
+#undef PREFILL_LDS_EXTRA_PARAMS
 
 template <typename T, int D, bool KV8>
 int launch_decode(void* out, float* ws, const void* q, long q_stride, const void* kc, const void* vc, const int* bt,
@@ -709,10 +513,15 @@ int launch_prefill(void* out, const void* q, long q_stride, const void* kc, cons
       const long total = (long)tiles * Hq * num_seqs;
       if (total > (1L << 30)) return -3;
       const int grid = remap ? (int)((total + 7) / 8 * 8) : (int)total;
-      hipLaunchKernelGGL((paged_prefill_lds_kernel<T, KV8>), dim3(grid), dim3(256), 0, s, (T*)out,
-                         (const T*)q, q_stride, kc, vc, bt, bt_stride, qsl, seq_lens, sl2, Hq,
-                         Hkv, block_size, out_stride, tiles, (int)total, remap, k_scales, v_scales, window, softcap,
-                         sinks, alibi);
+      if (sinks != nullptr || alibi != nullptr)
+        hipLaunchKernelGGL((paged_prefill_lds_bias_kernel<T, KV8>), dim3(grid), dim3(256), 0, s, (T*)out,
+                           (const T*)q, q_stride, kc, vc, bt, bt_stride, qsl, seq_lens, sl2, Hq,
+                           Hkv, block_size, out_stride, tiles, (int)total, remap, k_scales, v_scales, window, softcap,
+                           sinks, alibi);
+      else
+        hipLaunchKernelGGL((paged_prefill_lds_kernel<T, KV8>), dim3(grid), dim3(256), 0, s, (T*)out,
+                           (const T*)q, q_stride, kc, vc, bt, bt_stride, qsl, seq_lens, sl2, Hq,
+                           Hkv, block_size, out_stride, tiles, (int)total, remap, k_scales, v_scales, window, softcap);
       HIP_LAUNCH_CHECK();
       return 0;
     }

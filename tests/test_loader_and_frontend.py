@@ -728,3 +728,32 @@ def test_gpt_oss_mxfp4_checkpoint_equals_its_widened_twin(tmp_path):
         pstate.destroy_model_parallel()
     for (ta, la), (tb, lb) in zip(outs["dense"], outs["mxfp4"]):
         assert ta == tb and all(abs(la[t] - lb[t]) < 1e-5 for t in la)
+
+
+def test_hot_attention_kernels_fit_the_register_file(tmp_path):
+    """The attention kernels are written against exact register budgets (four waves per SIMD = 128 registers
+    in decode, the whole file in the LDS-staged prefill kernel).  A few spilled registers - reloaded inside the
+    key loop - halve their bandwidth, and any change near them can tip the allocator: the compiled kernels the
+    serving paths use must have no scratch segment."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    asm = tmp_path / "attention.s"
+    subprocess.run([hipcc, "-S", "--offload-arch=gfx950", "--cuda-device-only", "-O3", "-std=c++17",
+                    "-I" + os.path.join(root, "csrc"), os.path.join(root, "csrc", "attention.hip"), "-o", str(asm)],
+                   check=True, capture_output=True, timeout=600)
+    spilled = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", asm.read_text(), re.S):
+        scratch = int(re.search(r"private_segment_fixed_size (\d+)", m.group(2)).group(1))
+        if scratch:
+            spilled[m.group(1)] = scratch
+    hot = [k for k in spilled if ("paged_decode_kernel" in k or "paged_prefill_kernel" in k
+                                  or ("paged_prefill_lds_kernel" in k))]
+    assert not hot, {k: spilled[k] for k in hot}
+    # known and accepted: the one-wave decode kernel at head size 256 (not a default path) and the LDS prefill
+    # kernel's sinks / ALiBi instantiation
+    assert all("wave_kernel" in k and "Li256E" in k or "lds_bias_kernel" in k for k in spilled), spilled

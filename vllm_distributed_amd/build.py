@@ -78,7 +78,7 @@ def build_sanitized(verbose: bool = True) -> str:
     sanitizers are not available for gfx950 here.  Load the result with
     ``VDAMD_OPS_LIB=<path> LD_PRELOAD=$(clang -print-file-name=libclang_rt.asan-x86_64.so)``."""
     hip_src = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
-    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc")))
     flags = ["-O1", "-g", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wno-unused-result",
              "-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined",
              "-Xarch_host", "-fno-omit-frame-pointer"]
@@ -97,7 +97,7 @@ def build_sanitized(verbose: bool = True) -> str:
 def build(force: bool = False, verbose: bool = True) -> List[str]:
     built = []
     hip_src = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
-    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc")))
     if hip_src:
         built.append(_build_lib("libvdamd_ops.so", hip_src, headers, _hipcc(), HIP_FLAGS, [], force))
     core_dir = os.path.join(CSRC, "core")
