@@ -434,6 +434,131 @@ def test_draft_model_speculative_decoding_reproduces_greedy_output():
         llm.shutdown()
 
 
+def _record_head_proposals(llm):
+    """(request id, position of the request's newest token) -> the head's drafts, for every proposal made."""
+    runner = llm.engine.core.executor.driver.worker.model_runner
+    seen, last = {}, {}
+    inner_propose, inner_step = runner.draft.propose, runner._propose_from_hidden
+
+    def propose(feats, start_pos, *a, **k):
+        out = inner_propose(feats, start_pos, *a, **k)
+        last["start"], last["out"] = start_pos.copy(), out
+        return out
+
+    def step(p, md, input_ids, positions, hidden, sel, *a, **k):
+        last.clear()
+        res = inner_step(p, md, input_ids, positions, hidden, sel, *a, **k)
+        if sel is not None and last:
+            for j, i in enumerate(sel.tolist()):
+                seen[(p["req_ids"][i], int(last["start"][j]))] = list(last["out"][j])
+        return res
+
+    runner.draft.propose, runner._propose_from_hidden = propose, step
+    return seen
+
+
+def test_eagle_and_mtp_heads_draft_from_the_targets_hidden_states():
+    """Heads that read (next token, target hidden state) pairs.  Whatever they propose, the text is greedy
+    decoding's.  The wiring is pinned with heads whose layer is silenced (zero output projections), so the
+    feature is ``fc([embed(next token) ; hidden])`` alone:
+      * embedding half only -> the drafts after a token ``s`` are ``f(s), f(f(s)), ...`` for a host-computable ``f``
+        (the token paired with the last kept position is the one the target has just sampled);
+      * hidden half only, as the identity -> the feature at the last kept position is the target's own hidden
+        state there, whose best token is the one just sampled: every draft repeats it.
+    The head's KV follows the target's slots: the drafts do not depend on how the prompt was chunked.
+    No EAGLE / MTP fixtures ship with the reference: parity with other implementations is unpinned."""
+    import torch
+    from vllm_distributed_amd import LLM, SamplingParams
+    kw = dict(model="llama-tiny", device="cpu", dtype="float32", max_model_len=256, num_gpu_blocks_override=128,
+              max_num_seqs=8, load_format="dummy")
+    prompts = [{"prompt_token_ids": [3, 9, 4, 7, 11, 5] * 6}, {"prompt_token_ids": list(range(20, 60))},
+               {"prompt_token_ids": [5, 6] * 20}, {"prompt_token_ids": list(range(100, 117))}]
+    sps = [SamplingParams(temperature=0.0, max_tokens=40, ignore_eos=True),
+           SamplingParams(temperature=0.0, max_tokens=23, ignore_eos=True),
+           SamplingParams(temperature=0.0, max_tokens=40, ignore_eos=True, logprobs=1),   # decoded one token at a time
+           SamplingParams(temperature=0.0, max_tokens=30, ignore_eos=True)]
+    ref = LLM(**kw)
+    want = [o.outputs[0].token_ids for o in ref.generate(prompts, sps)]
+    spec_cfg = {"method": "eagle", "model": "eagle-llama-tiny", "num_speculative_tokens": 3}
+
+    # ---- a random head: lossless, and the same drafts whether the prompts ran whole or in 16-token chunks
+    logs = []
+    for extra in ({}, {"max_num_batched_tokens": 16}):
+        llm = LLM(speculative_config=spec_cfg, **kw, **extra)
+        assert llm.engine.vllm_config.speculative_config.reads_target_hidden
+        runner = llm.engine.core.executor.driver.worker.model_runner
+        assert runner.draft.model.embed_tokens is runner.model.embed_tokens          # shared, not copied
+        assert runner.get_kv_cache_spec().extra_bytes_per_block > 0                  # the head's cache is budgeted
+        seen = _record_head_proposals(llm)
+        outs = llm.generate(prompts, sps)
+        assert [o.outputs[0].token_ids for o in outs] == want
+        st = llm.engine.core.scheduler.spec_stats
+        assert st["drafted"] > 0 and st["accepted"] < st["drafted"]
+        order = {o.request_id: i for i, o in enumerate(outs)}
+        logs.append({(order[r], pos): d for (r, pos), d in seen.items()})
+        if extra:       # again over cached prefixes: the head's KV of the cached blocks is reused as well
+            assert [o.outputs[0].token_ids for o in llm.generate(prompts, sps)] == want
+        llm.shutdown()
+    assert len(logs[0]) > 60 and logs[0] == logs[1]
+    assert all(len(d) == 3 for (i, pos), d in logs[0].items() if pos + 4 < len(prompts[i]["prompt_token_ids"]) + sps[i].max_tokens)
+
+    # ---- silenced layer: the two halves of fc, one at a time
+    for half in ("embedding", "hidden"):
+        llm = LLM(speculative_config=spec_cfg, **kw)
+        runner = llm.engine.core.executor.driver.worker.model_runner
+        head, target = runner.draft.model, runner.model
+        h = head.cfg["hidden_size"]
+        gen = torch.Generator().manual_seed(5)
+        a = torch.randn(h, h, generator=gen) / h ** 0.5
+        with torch.no_grad():
+            layer = head.layers["0"]
+            layer.self_attn.o_proj.weight.zero_()
+            layer.mlp.down_proj.weight.zero_()
+            head.fc.weight.zero_()
+            head.fc.bias.zero_()
+            if half == "embedding":
+                head.fc.weight[:, :h] = a
+            else:
+                head.fc.weight[:, h:] = torch.eye(h)
+        emb, lm = target.embed_tokens.weight.float(), target.lm_head.weight.float()
+        f = ((emb @ a.T) @ lm.T).argmax(-1).tolist()
+        seen = _record_head_proposals(llm)
+        outs = llm.generate(prompts, sps)
+        assert [o.outputs[0].token_ids for o in outs] == want
+        full = {o.request_id: list(o.prompt_token_ids) + list(o.outputs[0].token_ids) for o in outs}
+        checked = 0
+        for (rid, pos), drafts in seen.items():
+            if pos >= len(full[rid]):
+                continue                       # (the step that produced the request's final token)
+            s = full[rid][pos]
+            if half == "embedding":
+                expect, t = [], s
+                for _ in drafts:
+                    t = f[t]
+                    expect.append(t)
+            else:
+                expect = [s] * len(drafts)
+            assert drafts == expect, (half, rid, pos, s, drafts, expect)
+            checked += 1
+        assert checked > 60
+        llm.shutdown()
+
+    # ---- DeepSeek-V3's multi-token-prediction module, loaded from the target's own checkpoint
+    kw["model"] = "deepseek-v3-mtp-tiny"
+    ref2 = LLM(**kw)
+    want2 = [o.outputs[0].token_ids for o in ref2.generate(prompts[:2], sps[:2])]
+    mtp = LLM(speculative_config={"method": "deepseek_mtp", "num_speculative_tokens": 2}, **kw)
+    assert mtp.engine.vllm_config.speculative_config.method == "mtp"
+    runner = mtp.engine.core.executor.driver.worker.model_runner
+    assert list(runner.draft.model.layers) == ["3"] and runner.draft.model.lm_head is runner.model.lm_head
+    assert [o.outputs[0].token_ids for o in mtp.generate(prompts[:2], sps[:2])] == want2
+    assert mtp.engine.core.scheduler.spec_stats["drafted"] > 0
+    with pytest.raises(ValueError):
+        LLM(speculative_config={"method": "mtp"}, **dict(kw, model="deepseek-v3-tiny"))     # no such module inside
+    for llm in (ref, ref2, mtp):
+        llm.shutdown()
+
+
 def test_offline_n_best_of_and_beam_search():
     """``LLM.generate`` fans ``n`` / ``best_of`` out into requests that share the prompt; beam search runs
     on one-token requests: width 1 is greedy decoding, beams come back best first and every beam's

@@ -757,3 +757,42 @@ def test_hot_attention_kernels_fit_the_register_file(tmp_path):
     # known and accepted: the one-wave decode kernel at head size 256 (not a default path) and the LDS prefill
     # kernel's sinks / ALiBi instantiation
     assert all("wave_kernel" in k and "Li256E" in k or "lds_bias_kernel" in k for k in spilled), spilled
+
+
+def test_eagle_head_checkpoint_in_the_authors_layout(tmp_path):
+    """EAGLE's published head checkpoints name their tensors without a ``model.`` prefix, carry a copy of the
+    embedding, ``fc`` with a bias, one decoder layer without an input norm, and no LM head: the file loads, the
+    embedding in it is used, the LM head is the target's.  (Synthetic tensors of those names and shapes: no
+    EAGLE checkpoint ships with the reference.)"""
+    import json
+    import torch
+    from safetensors.torch import save_file
+    from vllm_distributed_amd import LLM, SamplingParams
+    from vllm_distributed_amd.config import ModelConfig
+    from vllm_distributed_amd.models.loader import dummy_weights_iterator, save_dummy_checkpoint
+    target_dir, head_dir = str(tmp_path / "target"), tmp_path / "head"
+    save_dummy_checkpoint(ModelConfig(model="llama-tiny", dtype="float32", load_format="dummy"), target_dir)
+    hmc = ModelConfig(model="eagle-llama-tiny", dtype="float32", load_format="dummy")
+    hmc.hf_config = dict(hmc.hf_config, architectures=["EagleLlamaForCausalLM"])
+    tensors = {n[len("model."):]: w.contiguous() for n, w in dummy_weights_iterator(hmc, torch.device("cpu"))}
+    assert "fc.bias" in tensors and "layers.0.input_layernorm.weight" not in tensors and "lm_head.weight" not in tensors
+    tensors["embed_tokens.weight"] = torch.randn(512, 256) * 0.05
+    head_dir.mkdir()
+    save_file(tensors, str(head_dir / "model.safetensors"))
+    (head_dir / "config.json").write_text(json.dumps(dict(hmc.hf_config, architectures=["LlamaForCausalLM"])))
+    kw = dict(model=target_dir, device="cpu", dtype="float32", max_model_len=128, num_gpu_blocks_override=64,
+              max_num_seqs=4)
+    prompts = [{"prompt_token_ids": list(range(30, 50))}, {"prompt_token_ids": [7, 8, 9] * 5}]
+    sp = SamplingParams(temperature=0.0, max_tokens=24, ignore_eos=True)
+    ref = LLM(**kw)
+    want = [o.outputs[0].token_ids for o in ref.generate(prompts, sp)]
+    llm = LLM(speculative_config={"method": "eagle", "model": str(head_dir), "num_speculative_tokens": 2}, **kw)
+    runner = llm.engine.core.executor.driver.worker.model_runner
+    head = runner.draft.model
+    assert head.embed_tokens is not runner.model.embed_tokens and head.lm_head is runner.model.lm_head
+    assert torch.equal(head.embed_tokens.weight[:512], tensors["embed_tokens.weight"])
+    assert head.layers["0"].input_layernorm is None and head.norm is None
+    assert [o.outputs[0].token_ids for o in llm.generate(prompts, sp)] == want
+    assert llm.engine.core.scheduler.spec_stats["drafted"] > 0
+    ref.shutdown()
+    llm.shutdown()

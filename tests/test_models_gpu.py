@@ -122,6 +122,33 @@ def test_draft_model_speculation_on_gpu_with_graph_decode():
     assert st["accepted"] >= 0.5 * st["drafted"]
 
 
+@pytest.mark.parametrize("target,spec", [
+    ("llama-tiny", {"method": "eagle", "model": "eagle-llama-tiny", "num_speculative_tokens": 3}),
+    ("deepseek-v3-mtp-tiny", {"method": "mtp", "num_speculative_tokens": 2})])
+def test_hidden_state_heads_on_gpu(target, spec):
+    """EAGLE head / DeepSeek multi-token-prediction module on the HIP kernels, next to a target whose
+    one-token steps run from the captured graph (the head then reads the graph's output buffer): random
+    heads, so nearly every draft is rejected and rolled back, and the text stays greedy decoding's."""
+    kw = dict(model=target, dtype="bfloat16", gpu_memory_utilization=0.3, max_model_len=256,
+              num_gpu_blocks_override=128, max_num_seqs=8, load_format="dummy")
+    prompts = [{"prompt_token_ids": [3, 9, 4, 7, 11, 5] * 6}, {"prompt_token_ids": list(range(20, 60))}]
+    sp = SamplingParams(temperature=0.0, max_tokens=32, ignore_eos=True)
+    pstate.destroy_model_parallel()
+    ref = LLM(**kw)
+    want = [o.outputs[0].token_ids for o in ref.generate(prompts, sp)]
+    ref.shutdown()
+    pstate.destroy_model_parallel()
+    llm = LLM(speculative_config=spec, **kw)
+    got = [o.outputs[0].token_ids for o in llm.generate(prompts, sp)]
+    st = llm.engine.core.scheduler.spec_stats
+    llm.shutdown()
+    pstate.destroy_model_parallel()
+    assert st["drafted"] > 0 and [len(g) for g in got] == [32, 32]
+    for a, b in zip(got, want):           # (bf16 near-ties: see the draft-model test above)
+        same = next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), len(b))
+        assert same >= 8, (a, b)
+
+
 def test_logit_edits_on_gpu_with_graph_decode():
     """logit_bias / allow list / bad words / min_tokens on bf16 device logits, in a batch
     that mixes edited and plain requests while decode runs from a captured graph."""

@@ -105,6 +105,14 @@ def test_spmd_tp2_draft_model_speculation_matches_single_process():
 
 
 @pytest.mark.slow
+def test_spmd_tp2_eagle_head_speculation_matches_single_process():
+    """An EAGLE head sharded like the target, sharing its vocabulary-parallel embedding and LM head."""
+    ref = _run(1)[0]
+    got = _run(2, spec='{"method": "eagle", "model": "eagle-llama-tiny", "num_speculative_tokens": 3}')
+    assert got[0][0] == ref[0] and got[0][2] == ref[2] and got[1] == got[0]
+
+
+@pytest.mark.slow
 @pytest.mark.parametrize("quant", ["awq", "nvfp4"])
 def test_spmd_tp2_quantised_shards_match_single_process(quant):
     """Packed 4-bit tensors (integer groups / fp4 blocks with per-matrix

@@ -376,7 +376,10 @@ class SpeculativeConfig:
       * ``ngram``: prompt lookup - drafts are the tokens that followed the most recent earlier
         occurrence of the text's current n-gram suffix (``prompt_lookup_min`` .. ``prompt_lookup_max``);
       * ``draft_model``: a smaller model with the same vocabulary (``model``) runs on the workers next
-        to the target, with its own KV cache over the same blocks, and proposes greedily."""
+        to the target, with its own KV cache over the same blocks, and proposes greedily;
+      * ``eagle``: an EAGLE head (``model``: its checkpoint) drafts from the target's hidden states;
+      * ``mtp`` (``deepseek_mtp``): the multi-token-prediction module inside a DeepSeek-V3 checkpoint does
+        the same (``model`` defaults to the target's checkpoint)."""
     method: str = "ngram"
     num_speculative_tokens: int = 4
     prompt_lookup_max: int = 4
@@ -385,19 +388,29 @@ class SpeculativeConfig:
     load_format: Optional[str] = None        # of the draft model; default: the target's
     quantization: Optional[str] = None       # of the draft model
 
+    METHODS = ("ngram", "draft_model", "eagle", "mtp")
+
     def __post_init__(self) -> None:
         if self.method in (None, "") or (self.method == "ngram" and self.model):
             self.method = "draft_model" if self.model else "ngram"
-        if self.method not in ("ngram", "[ngram]", "draft_model"):
-            raise ValueError(f"speculative method {self.method!r} is not supported (ngram, draft_model)")
-        if self.method == "[ngram]":
-            self.method = "ngram"
-        if self.method == "draft_model" and not self.model:
-            raise ValueError("speculative method draft_model needs a \"model\"")
+        self.method = {"[ngram]": "ngram", "deepseek_mtp": "mtp"}.get(self.method, self.method)
+        if self.method not in self.METHODS:
+            raise ValueError(f"speculative method {self.method!r} is not supported ({', '.join(self.METHODS)})")
+        if self.method in ("draft_model", "eagle") and not self.model:
+            raise ValueError(f"speculative method {self.method} needs a \"model\"")
         if not 1 <= self.num_speculative_tokens <= 16:
             raise ValueError("num_speculative_tokens must be between 1 and 16")
         if not 1 <= self.prompt_lookup_min <= self.prompt_lookup_max:
             raise ValueError("need 1 <= prompt_lookup_min <= prompt_lookup_max")
+
+    @property
+    def worker_side(self) -> bool:
+        """Drafts come from a model on the workers (and travel back with each step's output)."""
+        return self.method != "ngram"
+
+    @property
+    def reads_target_hidden(self) -> bool:
+        return self.method in ("eagle", "mtp")
 
     @classmethod
     def from_value(cls, value) -> Optional["SpeculativeConfig"]:

@@ -101,7 +101,7 @@ class Scheduler:
         # draft-model speculation: the workers' proposal loop writes draft KV this many positions past
         # the tokens a step schedules, so every allocation reaches that far
         self.lookahead = (self.spec.num_speculative_tokens
-                          if self.spec is not None and self.spec.method == "draft_model" else 0)
+                          if self.spec is not None and self.spec.worker_side else 0)
         if self.spec is not None and self.spec.method == "ngram":
             import ctypes
             from ..ops.grammar import load as load_core
@@ -158,7 +158,7 @@ class Scheduler:
             room = min(room, req.max_tokens - len(req.output_token_ids) - 1)
         if room <= 0:
             return []
-        if sc.method == "draft_model":
+        if sc.worker_side:
             return proposed[:room]
         ids = req.all_token_ids
         arr = np.asarray(ids[-self.SPEC_WINDOW:], dtype=np.int32)

@@ -312,9 +312,7 @@ class LlamaForCausalLM(nn.Module):
         self.cfg = cfg
         pp = get_pp_group()
         self.is_first, self.is_last = pp.is_first_rank, pp.is_last_rank
-        n_layers = cfg["num_hidden_layers"]
-        self.start_layer, self.end_layer = get_pp_layer_range(
-            n_layers, pp.rank_in_group, pp.world_size, vllm_config.parallel_config.pp_layer_partition)
+        self.start_layer, self.end_layer = self.layer_range(cfg, vllm_config)
         head_dim = cfg.get("head_dim") or cfg["hidden_size"] // cfg["num_attention_heads"]
         rotary_dim = int(head_dim * float(cfg.get("partial_rotary_factor") or 1.0))
         self.rope_perm = rope_row_permutation(head_dim, rotary_dim, cfg.get("model_type") in INTERLEAVED_ROPE_TYPES)
@@ -345,6 +343,12 @@ class LlamaForCausalLM(nn.Module):
         self.path_counts = collections.Counter()
 
     # ---- what differs between the Llama-shaped families (see llama_variants.py)
+    def layer_range(self, cfg: dict, vllm_config: VllmConfig) -> Tuple[int, int]:
+        """The decoder layers this instance builds: its pipeline stage's slice."""
+        pp = get_pp_group()
+        return get_pp_layer_range(cfg["num_hidden_layers"], pp.rank_in_group, pp.world_size,
+                                  vllm_config.parallel_config.pp_layer_partition)
+
     def embedding_scale(self, cfg: dict) -> Optional[float]:
         """Factor applied to the embedding output (Gemma: sqrt(hidden), Granite: a config value)."""
         return None

@@ -211,7 +211,7 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
             shapes[q + "mlp.c_fc.weight"], shapes[q + "mlp.c_fc.bias"] = (inter, h), (inter,)
             shapes[q + "mlp.c_proj.weight"], shapes[q + "mlp.c_proj.bias"] = (h, inter), (h,)
         return shapes
-    if arch in ("DeepseekV2ForCausalLM", "DeepseekV3ForCausalLM"):
+    if arch in ("DeepseekV2ForCausalLM", "DeepseekV3ForCausalLM", "DeepSeekMTP"):
         nope, rope, vd, rank = c["qk_nope_head_dim"], c["qk_rope_head_dim"], c["v_head_dim"], c["kv_lora_rank"]
         ab = bool(c.get("attention_bias", False))
         ne = c.get("n_routed_experts") or c.get("num_experts") or c.get("num_local_experts") or 0
@@ -226,9 +226,13 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
             if bias:
                 shapes[name + ".bias"] = (out_f,)
 
-        for i in range(L):
+        nextn = int(c.get("num_nextn_predict_layers") or 0) if arch in ("DeepseekV3ForCausalLM", "DeepSeekMTP") else 0
+        for i in range(L + nextn):
             q = f"model.layers.{i}."
             a = q + "self_attn."
+            if i >= L:            # a multi-token-prediction module: a decoder layer plus its own glue
+                shapes[q + "enorm.weight"] = shapes[q + "hnorm.weight"] = shapes[q + "shared_head.norm.weight"] = (h,)
+                shapes[q + "eh_proj.weight"] = (h, 2 * h)
             if c.get("q_lora_rank"):
                 lin(a + "q_a_proj", c["q_lora_rank"], h, ab)
                 shapes[a + "q_a_layernorm.weight"] = (c["q_lora_rank"],)
@@ -278,12 +282,19 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
                       "olmo3": ("post_attention_layernorm", "post_feedforward_layernorm"),
                       "exaone4": ("post_attention_layernorm", "post_feedforward_layernorm"),
                       "cohere": ("input_layernorm",), "olmo": ()}.get(mt, ("input_layernorm", "post_attention_layernorm"))
-    shapes["model.embed_tokens.weight"] = (c["vocab_size"], h)
-    if mt != "olmo":
+    eagle = arch == "EagleLlamaForCausalLM"       # a draft head: no embedding / head / final norm of its own
+    if eagle:
+        norms = ("input_layernorm", "post_attention_layernorm")
+        shapes["model.fc.weight"] = (h, 2 * h)
+        if c.get("bias", True):
+            shapes["model.fc.bias"] = (h,)
+    else:
+        shapes["model.embed_tokens.weight"] = (c["vocab_size"], h)
+    if mt != "olmo" and not eagle:
         shapes["model.norm.weight"] = (h,)
     if norm_bias:
         shapes["model.norm.bias"] = (h,)
-    if not c.get("tie_word_embeddings", False):
+    if not c.get("tie_word_embeddings", False) and not eagle:
         shapes["lm_head.weight"] = (c["vocab_size"], h)
 
     def linear(name: str, out_f: int, in_f: int, bias: bool) -> None:
@@ -307,6 +318,8 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
             shapes[q + "self_attn.q_norm.weight"] = (heads * hd,)
             shapes[q + "self_attn.k_norm.weight"] = (kvh * hd,)
         for n in norms:
+            if eagle and i == 0 and n == "input_layernorm":
+                continue
             shapes[q + n + ".weight"] = (h,)
             if norm_bias:
                 shapes[q + n + ".bias"] = (h,)
@@ -618,6 +631,11 @@ def _check_filled(model: torch.nn.Module, what: str) -> None:
         nan = torch.isnan(p.data)
         if bool(nan.any().item()):
             (missing if bool(nan.all().item()) else partial).append(n)
+    optional = getattr(model, "optional_parameters", ())
+    if optional:
+        # modules a draft head may share with its target instead of carrying a copy: reported, not refused
+        model.missing_optional = [n for n in missing if n in optional]
+        missing = [n for n in missing if n not in optional]
     if missing or partial:
         msg = []
         if missing:

@@ -57,6 +57,9 @@ _MODELS: Dict[str, Tuple[str, str]] = {
     "MptForCausalLM": ("mpt", "MptForCausalLM"),
     "MPTForCausalLM": ("mpt", "MptForCausalLM"),
     "Starcoder2ForCausalLM": ("starcoder2", "Starcoder2ForCausalLM"),
+    # draft heads of speculative decoding (never a served model by themselves; worker/draft_model.py)
+    "EagleLlamaForCausalLM": ("spec_heads", "EagleLlamaForCausalLM"),
+    "DeepSeekMTP": ("spec_heads", "DeepSeekMTP"),
 }
 
 

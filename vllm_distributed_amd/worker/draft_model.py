@@ -35,11 +35,17 @@ logger = init_logger(__name__)
 
 
 class DraftProposer:
-    def __init__(self, vllm_config: VllmConfig, device: torch.device):
+    needs_hidden = False          # True: drafts from the target's hidden states, after the step has sampled
+
+    def _draft_model_config(self, vllm_config: VllmConfig) -> ModelConfig:
         sc, mc = vllm_config.speculative_config, vllm_config.model_config
         fmt = sc.load_format or ("auto" if mc.load_format == "sharded_state" else mc.load_format)
-        dmc = ModelConfig(model=sc.model, dtype=mc.dtype, seed=mc.seed, max_model_len=mc.max_model_len,
-                          load_format=fmt, quantization=sc.quantization)
+        return ModelConfig(model=sc.model, dtype=mc.dtype, seed=mc.seed, max_model_len=mc.max_model_len,
+                           load_format=fmt, quantization=sc.quantization)
+
+    def __init__(self, vllm_config: VllmConfig, device: torch.device):
+        sc, mc = vllm_config.speculative_config, vllm_config.model_config
+        dmc = self._draft_model_config(vllm_config)
         if int(dmc.hf_config["vocab_size"]) != int(mc.hf_config["vocab_size"]):
             raise ValueError(f"draft model {sc.model!r} has vocabulary {dmc.hf_config['vocab_size']}, "
                              f"the target {mc.hf_config['vocab_size']}: they must share a tokenizer")
@@ -50,7 +56,7 @@ class DraftProposer:
         self.k = int(sc.num_speculative_tokens)
         self.device = device
         self.kv_caches: List[Tuple[torch.Tensor, torch.Tensor]] = []
-        logger.info("draft model %s loaded: %d tokens proposed per step", sc.model, self.k)
+        logger.info("draft model %s loaded: %d tokens proposed per step", dmc.model, self.k)
 
     # ------------------------------------------------------------------ KV cache
     def kv_bytes_per_block(self, block_size: int, dtype_bytes: int) -> int:
@@ -124,6 +130,101 @@ class DraftProposer:
             outs.append(cur)
         toks = torch.stack(outs, dim=1).cpu().numpy()            # [r, steps]: the one host sync of the loop
         return [toks[j, :int(room[j])].tolist() for j in range(r)]
+
+
+class HiddenStateProposer(DraftProposer):
+    """EAGLE heads and DeepSeek's multi-token-prediction module (``models/spec_heads.py``): the head reads
+    (token ``i + 1``, target hidden state ``i``) at position ``i`` and its output there predicts token ``i + 2``.
+
+    Per step, AFTER the target has sampled: one pass over the step's tokens - each paired with its successor,
+    which for a sampled position is the token the target just produced there - writes the head's KV at the
+    target's slots and leaves, at every request's last kept position, the feature that predicts the first draft.
+    ``k - 1`` single-token passes follow, each fed the previous draft and the head's own previous feature.
+    Embedding and LM head are the target's unless the head's checkpoint brings its own."""
+    needs_hidden = True
+
+    def _draft_model_config(self, vllm_config: VllmConfig) -> ModelConfig:
+        sc, mc = vllm_config.speculative_config, vllm_config.model_config
+        if sc.method == "mtp":
+            if int(mc.hf_config.get("num_nextn_predict_layers") or 0) < 1:
+                raise ValueError(f"{mc.model} has no multi-token-prediction module (num_nextn_predict_layers)")
+            dmc = ModelConfig(model=sc.model or mc.model, dtype=mc.dtype, seed=mc.seed, max_model_len=mc.max_model_len,
+                              load_format=sc.load_format or mc.load_format, quantization=sc.quantization)
+            dmc.hf_config = dict(dmc.hf_config, architectures=["DeepSeekMTP"])
+            return dmc
+        dmc = super()._draft_model_config(vllm_config)
+        if dmc.hf_config.get("model_type") not in ("llama", "mistral", "qwen2", "qwen3"):
+            raise ValueError(f"EAGLE head {sc.model!r}: model_type {dmc.hf_config.get('model_type')!r} is not one "
+                             f"of the Llama-shaped families this head is written for")
+        dmc.hf_config = dict(dmc.hf_config, architectures=["EagleLlamaForCausalLM"])
+        return dmc
+
+    def bind_target(self, target: torch.nn.Module) -> None:
+        """Share what the head's checkpoint did not bring."""
+        head = self.model
+        if int(head.cfg["hidden_size"]) != int(target.cfg["hidden_size"]):
+            raise ValueError(f"draft head width {head.cfg['hidden_size']} != target width {target.cfg['hidden_size']}")
+        missing = set(getattr(head, "missing_optional", ()))
+        if "embed_tokens.weight" in missing:
+            head.embed_tokens = target.embed_tokens
+        if "lm_head.weight" in missing or getattr(head, "lm_head", None) is None:
+            head.lm_head, head.tie = target.lm_head, target.tie
+            if target.lm_head is None and "embed_tokens.weight" not in missing:
+                logger.info("draft head: logits through its own embedding (the target ties embedding and head)")
+        logger.info("draft head shares with the target: %s", ", ".join(sorted(missing)) or "nothing")
+
+    def catch_up(self, md: AttentionMetadata, input_ids: torch.Tensor, positions: torch.Tensor) -> None:
+        raise RuntimeError("a hidden-state head catches up in propose_after")
+
+    def run_step_tokens(self, md: AttentionMetadata, shifted_ids: torch.Tensor, positions: torch.Tensor,
+                        hidden: torch.Tensor) -> torch.Tensor:
+        """The head over a step's tokens (``shifted_ids[i]`` = the token after position ``i``): KV written at the
+        target's slots, features ``[T, H]`` returned."""
+        md = dataclasses.replace(md, decode_workspace=None)
+        set_forward_context(md, positions)
+        try:
+            return self.model(shifted_ids, positions, hidden)
+        finally:
+            set_forward_context(None)
+
+    def propose(self, feats: torch.Tensor, start_pos: np.ndarray, block_table: np.ndarray,
+                num_blocks: np.ndarray, block_size: int, max_model_len: int, to_dev) -> List[List[int]]:
+        """``feats[r]``: the head's feature at row ``r``'s last kept position (``start_pos[r] - 1``).  It predicts
+        the token after the one at ``start_pos[r]``; every further draft costs one pass at the next position."""
+        r = int(start_pos.shape[0])
+        if r == 0:
+            return []
+        limit = np.minimum(num_blocks.astype(np.int64) * block_size, max_model_len - 1)
+        room = np.clip(limit - start_pos, 0, self.k - 1).astype(np.int64)       # passes a row may still run
+        steps = int(room.max())
+        cur = self.model.compute_logits(feats).float().argmax(dim=-1).to(torch.int32)
+        outs = [cur]
+        if steps > 0:
+            width = int(min(block_table.shape[1], (int((start_pos + steps).max()) + block_size - 1) // block_size + 1))
+            bt = to_dev(block_table[:, :width])
+            qsl = to_dev(np.arange(r + 1, dtype=np.int32))
+        for i in range(steps):
+            pos = start_pos.astype(np.int64) + i
+            live = i < room
+            safe = np.where(live, pos, 0)
+            slot = np.where(live, block_table[np.arange(r), safe // block_size].astype(np.int64) * block_size
+                            + safe % block_size, -1)
+            seq = (safe + 1).astype(np.int32)
+            md = AttentionMetadata(
+                num_decodes=r, num_decode_tokens=r, num_prefills=0, num_prefill_tokens=0,
+                slot_mapping=to_dev(slot.astype(np.int32)), block_table=bt, seq_lens=to_dev(seq),
+                query_start_loc=qsl, max_query_len=1, max_seq_len=int(seq.max()),
+                max_decode_seq_len=int(seq.max()), decode_workspace=None)
+            positions = to_dev(safe.astype(np.int32))
+            set_forward_context(md, positions)
+            try:
+                feats = self.model(cur, positions, feats)
+            finally:
+                set_forward_context(None)
+            cur = self.model.compute_logits(feats).float().argmax(dim=-1).to(torch.int32)
+            outs.append(cur)
+        toks = torch.stack(outs, dim=1).cpu().numpy()            # [r, 1 + steps]: the one host sync of the loop
+        return [toks[j, :1 + int(room[j])].tolist() for j in range(r)]
 
 
 def accepted_tails(tokens: np.ndarray, counts: Optional[np.ndarray],

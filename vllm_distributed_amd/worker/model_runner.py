@@ -287,9 +287,13 @@ class ModelRunner:
             from ..parallel.pipeline import PipelineLink
             self.pp_link = PipelineLink(self.pp, self.device, use_rccl=envs.VDAMD_COMM_BACKEND in ("auto", "rccl"))
         sc = self.vllm_config.speculative_config
-        if sc is not None and sc.method == "draft_model":
-            from .draft_model import DraftProposer
-            self.draft = DraftProposer(self.vllm_config, self.device)
+        if sc is not None and sc.worker_side:
+            from .draft_model import DraftProposer, HiddenStateProposer
+            if sc.reads_target_hidden:
+                self.draft = HiddenStateProposer(self.vllm_config, self.device)
+                self.draft.bind_target(self.model)
+            else:
+                self.draft = DraftProposer(self.vllm_config, self.device)
         if self.vllm_config.lora_config is not None:
             from ..lora import LoRAManager
             self.lora_manager = LoRAManager(self.model, self.vllm_config.lora_config,
@@ -529,7 +533,8 @@ class ModelRunner:
             with trace_range("step.draft.catch_up"):
                 if graph is not None:                    # the graph ran from its own static inputs
                     md, input_ids, positions = self._build_metadata(p)
-                self.draft.catch_up(md, input_ids, positions)
+                if not self.draft.needs_hidden:          # (a hidden-state head runs once the step has sampled)
+                    self.draft.catch_up(md, input_ids, positions)
 
         # advance computed-token counts (the scheduler did the same when it scheduled)
         self.batch.num_computed[p["rows"]] += p["n_sched"]
@@ -576,10 +581,13 @@ class ModelRunner:
                 within = np.arange(int(ends[-1])) - np.repeat(ends - counts, counts)
                 idx = np.repeat(last_idx - (counts - 1), counts) + within
                 rows_smp = np.repeat(rows_sel, counts)
+                smp_idx = idx
                 hs = hidden.index_select(0, self._to_dev(idx, torch.int64))
             elif len(sel) == total:        # every token is a sampling position (pure decode)
+                smp_idx = np.arange(total)
                 hs = hidden[:total]
             else:
+                smp_idx = last_idx
                 hs = hidden.index_select(0, self._to_dev(last_idx, torch.int64))
             with trace_range("step.sample"):
                 tokens, logprobs_sel = self._sample(hs, rows_smp)
@@ -598,7 +606,12 @@ class ModelRunner:
             else:
                 host_tokens = tokens
         proposals = None
-        if self.draft is not None and sel is not None:
+        if self.draft is not None and self.draft.needs_hidden:
+            with trace_range("step.draft.propose"):
+                proposals = self._propose_from_hidden(p, md, input_ids, positions, hidden, sel, rows_sel, pos_sel,
+                                                      tokens if sel is not None else None,
+                                                      smp_idx if sel is not None else None, counts, drafts_sel)
+        elif self.draft is not None and sel is not None:
             with trace_range("step.draft.propose"):
                 proposals = self._propose_drafts(p, sel, rows_sel, pos_sel, tokens, counts, drafts_sel)
         self.tp.end_step()                # sampling may have gathered over the TP group
@@ -644,6 +657,42 @@ class ModelRunner:
                                  self.max_model_len, self._to_dev)
         ids = p["req_ids"]
         return {ids[i]: d for i, d in zip(sel.tolist(), out) if d}
+
+    def _propose_from_hidden(self, p: dict, md, input_ids: torch.Tensor, positions: torch.Tensor,
+                             hidden: torch.Tensor, sel, rows_sel, pos_sel, tokens: Optional[torch.Tensor],
+                             smp_idx, counts, drafts_sel) -> Optional[Dict[str, List[int]]]:
+        """EAGLE / multi-token-prediction heads.  The head pairs the target's hidden state at every position
+        of this step with the token that FOLLOWS it: the next input token inside a request, the next prompt
+        token at the end of an unfinished prompt chunk, and at a sampled position the token the target has
+        just produced there (for a draft under verification that is the draft itself when it was accepted;
+        positions behind a rejected draft get a wrong pair, are not counted as computed, and are run again
+        by the next step)."""
+        from .draft_model import accepted_tails
+        b, total = self.batch, p["total"]
+        ids = input_ids[:total]
+        shifted = torch.empty_like(ids)
+        shifted[:-1] = ids[1:]
+        ends = p["qsl"][1:] - 1                            # flat index of every request's last scheduled token
+        nxt = b.num_computed[p["rows"]]                    # (already advanced: the position after that token)
+        known = nxt < b.num_known[p["rows"]]
+        follow = np.where(known, b.token_ids[p["rows"], np.minimum(nxt, b.token_ids.shape[1] - 1)], 0)
+        shifted.index_copy_(0, self._to_dev(ends, torch.int64), self._to_dev(follow.astype(np.int32)).to(shifted.dtype))
+        if sel is not None:
+            shifted.index_copy_(0, self._to_dev(smp_idx, torch.int64), tokens.to(shifted.dtype))
+        feats = self.draft.run_step_tokens(md, shifted, positions[:total], hidden[:total])
+        if sel is None:
+            return None
+        toks = tokens.cpu().numpy()
+        last_idx, n_acc = accepted_tails(toks, counts, drafts_sel)
+        # flat position of each sampled request's last kept token: its first sampled position + accepted drafts
+        first = (p["qsl"][1:][sel] - 1) - ((counts - 1) if counts is not None else 0)
+        keep = first + n_acc
+        start = pos_sel.astype(np.int64) + n_acc          # position of the token each request ends on now
+        out = self.draft.propose(feats.index_select(0, self._to_dev(keep, torch.int64)), start,
+                                 b.block_table[rows_sel], b.num_blocks[rows_sel], self.block_size,
+                                 self.max_model_len, self._to_dev)
+        ids_ = p["req_ids"]
+        return {ids_[i]: d for i, d in zip(sel.tolist(), out) if d}
 
     def _overlap_bounds(self, nreq: int):
         """Micro-batch row ranges for all-reduce/compute overlap, or None."""
