@@ -584,6 +584,64 @@ def test_reasoning_parser_routes_chat_output_to_reasoning_content():
     pstate.destroy_model_parallel()
 
 
+def test_chat_completions_with_image_parts():
+    """``image_url`` content parts of a chat request reach a vision-language model as images: a base64 data URL
+    is decoded, its placeholder is widened to the tower's 16 embeddings (usage counts them), two different
+    pictures give two different replies and the same picture the same reply; remote URLs and models without a
+    vision tower answer 400."""
+    import base64
+    import io
+    import numpy as np
+    from PIL import Image
+    pstate.destroy_model_parallel()
+
+    def data_url(seed):
+        img = Image.fromarray((np.random.default_rng(seed).random((40, 50, 3)) * 255).astype("uint8"))
+        buf = io.BytesIO()
+        img.save(buf, format="PNG")
+        return "data:image/png;base64," + base64.b64encode(buf.getvalue()).decode()
+
+    def body(url, text="what is this?"):
+        return {"messages": [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": url}},
+                                                          {"type": "text", "text": text}]}],
+                "max_tokens": 8, "temperature": 0, "ignore_eos": True}
+
+    async def main(model, expect_images):
+        args = build_parser().parse_args(
+            (f"serve {model} --device cpu --dtype float32 --max-model-len 256 --block-size 16 "
+             "--num-gpu-blocks-override 64 --port 0 --disable-frontend-multiprocessing").split())
+        args.model = args.model_tag
+        async with api_server.build_async_engine_client(args) as engine:
+            app = api_server.build_app(args)
+            await api_server.init_app_state(engine, await engine.get_vllm_config(), app.state, args)
+            async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://t") as c:
+                if not expect_images:
+                    r = await c.post("/v1/chat/completions", json=body(data_url(1)))
+                    assert r.status_code == 400 and "does not take images" in r.text
+                    return
+                assert app.state.image_placeholder == "<511>"
+                a = (await c.post("/v1/chat/completions", json=body(data_url(1)))).json()
+                b = (await c.post("/v1/chat/completions", json=body(data_url(2)))).json()
+                a2 = (await c.post("/v1/chat/completions", json=body(data_url(1)))).json()
+                plain = (await c.post("/v1/chat/completions", json={
+                    "messages": [{"role": "user", "content": "what is this?"}], "max_tokens": 8, "temperature": 0,
+                    "ignore_eos": True})).json()
+                text = [x["choices"][0]["message"]["content"] for x in (a, b, a2)]
+                assert text[0] == text[2] and text[0] != text[1]
+                # one placeholder line ("<511>" + newline) became 16 image positions + the newline
+                assert a["usage"]["prompt_tokens"] == plain["usage"]["prompt_tokens"] + 16 + 1
+                r = await c.post("/v1/chat/completions", json=body("https://example.com/cat.png"))
+                assert r.status_code == 400 and "data: URL" in r.text
+                r = await c.post("/v1/chat/completions", json=body("data:image/png;base64,AAAA"))
+                assert r.status_code == 400 and "undecodable" in r.text
+                t = (await c.post("/tokenize", json={"messages": body(data_url(1))["messages"]})).json()
+                assert t["tokens"].count(511) == 1
+    asyncio.run(main("llava-tiny", True))
+    pstate.destroy_model_parallel()
+    asyncio.run(main("llama-tiny", False))
+    pstate.destroy_model_parallel()
+
+
 def test_chat_templates_render_in_a_sandbox():
     """Templates come from model repositories and, with --trust-request-chat-template, from
     request bodies: attribute walks into Python internals must fail, ordinary templates work."""

@@ -559,6 +559,56 @@ def test_eagle_and_mtp_heads_draft_from_the_targets_hidden_states():
         llm.shutdown()
 
 
+def test_image_prompts_prefix_cache_preemption_and_refusals():
+    """Requests with images next to text requests: blocks over an image are cached under the image's content
+    (same picture: hit, other picture behind the same tokens: no hit), a preempted request brings its image
+    back with it, a pre-expanded prompt is taken as it is, and malformed inputs are refused at the door."""
+    import numpy as np
+    from PIL import Image
+    from vllm_distributed_amd import LLM, SamplingParams
+    rng = np.random.default_rng(5)
+    pics = [Image.fromarray((rng.random((36, 48, 3)) * 255).astype("uint8")) for _ in range(4)]
+    kw = dict(model="llava-tiny", device="cpu", dtype="float32", max_model_len=256, load_format="dummy", max_num_seqs=8)
+    sp = SamplingParams(temperature=0.0, max_tokens=24, ignore_eos=True)
+    text = list(range(30, 60))
+
+    def prompt(k, tail=()):
+        return {"prompt_token_ids": text + [511] + list(tail), "multi_modal_data": {"image": pics[k]}}
+
+    roomy = LLM(num_gpu_blocks_override=128, **kw)
+    want = [o.outputs[0].token_ids for o in roomy.generate([prompt(0), prompt(1), prompt(2, (7, 8))], sp)]
+    assert want[0] != want[1]
+    kv = roomy.engine.core.scheduler.kv
+    hits = kv.prefix_hits
+    again = roomy.generate([prompt(1)], sp)[0]                    # 30 text + 16 image tokens: two full blocks cached
+    assert again.outputs[0].token_ids == want[1] and kv.prefix_hits - hits >= 32
+    hits = kv.prefix_hits
+    other = roomy.generate([{"prompt_token_ids": text + [511], "multi_modal_data": {"image": pics[3]}}], sp)[0]
+    assert kv.prefix_hits - hits == 16                            # the text-only first block, nothing over the image
+    assert other.outputs[0].token_ids not in (want[0], want[1])
+    expanded = roomy.generate([{"prompt_token_ids": text + [511] * 16, "multi_modal_data": {"image": pics[0]}}], sp)[0]
+    assert expanded.outputs[0].token_ids == want[0]
+    with pytest.raises(ValueError, match="placeholder"):
+        roomy.generate([{"prompt_token_ids": text, "multi_modal_data": {"image": pics[0]}}], sp)
+    with pytest.raises(ValueError, match="placeholder"):
+        roomy.generate([{"prompt_token_ids": text + [511, 511], "multi_modal_data": {"image": pics[0]}}], sp)
+    with pytest.raises(ValueError, match="cut through"):
+        roomy.generate([prompt(0)], SamplingParams(max_tokens=4, truncate_prompt_tokens=20))
+    roomy.shutdown()
+    # a pool too small for three 70-token sequences: one is preempted and recomputed, image included
+    tight = LLM(num_gpu_blocks_override=11, enable_prefix_caching=False, **dict(kw, max_model_len=128))
+    got = [o.outputs[0].token_ids for o in tight.generate([prompt(0), prompt(1), prompt(2, (7, 8))], sp)]
+    assert tight.engine.core.scheduler.num_preemptions > 0 and got == want
+    runner = tight.engine.core.executor.driver.worker.model_runner
+    tight.generate([{"prompt_token_ids": [1, 2, 3]}], SamplingParams(max_tokens=2))     # (finished ids travel with the next step)
+    assert not runner._mm_inputs and not runner._mm_embeds       # nothing kept once the requests are gone
+    tight.shutdown()
+    plain = LLM(model="llama-tiny", device="cpu", dtype="float32", max_model_len=128, load_format="dummy")
+    with pytest.raises(ValueError, match="does not take images"):
+        plain.generate([{"prompt_token_ids": [1, 2, 3], "multi_modal_data": {"image": pics[0]}}], sp)
+    plain.shutdown()
+
+
 def test_offline_n_best_of_and_beam_search():
     """``LLM.generate`` fans ``n`` / ``best_of`` out into requests that share the prompt; beam search runs
     on one-token requests: width 1 is greedy decoding, beams come back best first and every beam's

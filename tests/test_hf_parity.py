@@ -187,3 +187,63 @@ def test_family_matches_transformers(name, tmp_path):
         for t in top:
             assert abs(got[t] - lp[t].item()) < 2e-3, (name, t, got[t], lp[t].item())
         assert list(out.outputs[0].token_ids) == toks, (name, out.outputs[0].token_ids, toks)
+
+
+def test_llava_matches_transformers_with_images(tmp_path):
+    """A small random LLaVA (CLIP tower, tapped at the second-to-last layer, two-layer projector, Llama decoder)
+    against ``transformers.LlavaForConditionalGeneration`` on the same weights: pixels from this package's own
+    preprocessing, one and two images per prompt, next to a text-only prompt; then the same prompts prefilled in
+    8-token chunks, which cut through the images."""
+    import numpy as np
+    from PIL import Image
+    if not hasattr(transformers, "LlavaForConditionalGeneration"):
+        pytest.skip("transformers has no LLaVA")
+    text = transformers.LlamaConfig(**dict(BASE, rope_theta=10000.0))
+    vision = transformers.CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=3, num_attention_heads=4,
+                                           image_size=28, patch_size=7, projection_dim=16)
+    cfg = transformers.LlavaConfig(vision_config=vision, text_config=text, image_token_index=319,
+                                   vision_feature_layer=-2, vision_feature_select_strategy="default")
+    torch.manual_seed(77)
+    model = transformers.LlavaForConditionalGeneration(cfg).eval().float()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    model.save_pretrained(str(tmp_path), safe_serialization=True)
+    rng = np.random.default_rng(3)
+    imgs = [Image.fromarray((rng.random(s) * 255).astype("uint8")) for s in ((40, 60, 3), (30, 29, 3), (64, 64, 3))]
+    cases = [([5, 9, 319, 17, 33, 2, 90], [imgs[0]]), ([7, 319, 300, 2, 319, 41, 8], [imgs[1], imgs[2]]),
+             (list(range(10, 40)), [])]
+    from vllm_distributed_amd.multimodal import ClipImageProcessor
+    proc = ClipImageProcessor(28, 28)
+    ref_lp, ref_tokens = [], []
+    with torch.no_grad():
+        for ids, pics in cases:
+            full = []
+            for t in ids:
+                full += [319] * 16 if t == 319 else [t]
+            kw = {}
+            if pics:
+                kw["pixel_values"] = torch.from_numpy(np.stack([proc(im).astype(np.float32) for im in pics]))
+            x = torch.tensor([full])
+            ref_lp.append(model(input_ids=x, **kw).logits[0, -1].float().log_softmax(-1))
+            gen = model.generate(input_ids=x, max_new_tokens=4, do_sample=False, pad_token_id=0, **kw)
+            ref_tokens.append(gen[0, len(full):].tolist())
+    prompts = [{"prompt_token_ids": ids, **({"multi_modal_data": {"image": pics}} if pics else {})} for ids, pics in cases]
+    sp = SamplingParams(temperature=0.0, max_tokens=4, ignore_eos=True, logprobs=10)
+    for extra in ({}, {"max_num_batched_tokens": 8}):
+        llm = LLM(model=str(tmp_path), dtype="float32", device="cpu", max_model_len=128, num_gpu_blocks_override=64,
+                  max_num_seqs=8, **extra)
+        try:
+            outs = llm.generate(prompts, sp)
+        finally:
+            llm.shutdown()
+            pstate.destroy_model_parallel()
+        for out, lp, toks in zip(outs, ref_lp, ref_tokens):
+            got = out.outputs[0].logprobs[0]
+            top = torch.topk(lp, 5).indices.tolist()
+            assert set(top) <= set(got), (top, sorted(got))
+            for t in top:
+                assert abs(got[t] - lp[t].item()) < 3e-3, (t, got[t], lp[t].item())
+            assert list(out.outputs[0].token_ids) == toks
+        assert len(outs[0].prompt_token_ids) == 6 + 16 and len(outs[1].prompt_token_ids) == 5 + 32

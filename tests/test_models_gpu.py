@@ -77,6 +77,34 @@ def test_model_family_on_gpu_tracks_cpu_reference(model, tmp_path):
             assert max(abs(la[t] - lb[t]) for t in common) < tol, (model, step)
 
 
+def test_llava_with_images_on_gpu_tracks_cpu_reference(tmp_path):
+    """Vision tower + projector + decoder in bf16 on the GPU (the decoder on the HIP kernels, prompts chunked at
+    32 tokens so that a chunk boundary falls inside each image) against the fp32 CPU run of the same checkpoint."""
+    import numpy as np
+    from PIL import Image
+    mc = ModelConfig(model="llava-tiny", dtype="float32", load_format="dummy")
+    save_dummy_checkpoint(mc, str(tmp_path))
+    rng = np.random.default_rng(11)
+    pics = [Image.fromarray((rng.random(s) * 255).astype("uint8")) for s in ((40, 60, 3), (31, 28, 3))]
+    prompts = [{"prompt_token_ids": list(range(20, 45)) + [511] + list(range(60, 70)), "multi_modal_data": {"image": pics[0]}},
+               {"prompt_token_ids": [511, 5, 6, 7, 511, 9], "multi_modal_data": {"image": pics}},
+               {"prompt_token_ids": list(range(100, 140))}]
+    sp = SamplingParams(temperature=0.0, max_tokens=3, ignore_eos=True, logprobs=20)
+    outs = {}
+    for dev in ("cuda", "cpu"):
+        kw = dict(dtype="bfloat16", gpu_memory_utilization=0.3, max_num_batched_tokens=32) if dev == "cuda" \
+            else dict(dtype="float32", device="cpu")
+        llm = LLM(model=str(tmp_path), max_model_len=256, num_gpu_blocks_override=64, max_num_seqs=8, **kw)
+        outs[dev] = llm.generate(prompts, sp)
+        llm.shutdown()
+        pstate.destroy_model_parallel()
+    for a, b in zip(outs["cuda"], outs["cpu"]):
+        la, lb = a.outputs[0].logprobs[0], b.outputs[0].logprobs[0]
+        common = set(la) & set(lb)
+        assert len(common) >= 8 and max(abs(la[t] - lb[t]) for t in common) < 0.15
+    assert len(outs["cuda"][1].prompt_token_ids) == 4 + 32
+
+
 def test_window_released_blocks_are_never_read_by_the_kernels():
     """Sliding-window model on the HIP kernels with a pool that only fits because blocks behind the
     window are recycled between the four sequences: tokens must equal a roomy run's (a kernel touching

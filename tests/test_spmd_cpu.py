@@ -27,7 +27,14 @@ eng = LLMEngine.from_engine_args(EngineArgs(
     enable_expert_parallel=os.environ.get("EP") == "1"))
 sp = SamplingParams(temperature=0.8, top_p=0.9, seed=7, max_tokens=8, ignore_eos=True)
 g = SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True)
-ids = [eng.add_request(None, p, s) for p, s in (([5, 9, 200, 17], g), (list(range(10, 50)), sp), ([7, 7], g))]
+prompts = [([5, 9, 200, 17], g), (list(range(10, 50)), sp), ([7, 7], g)]
+if os.environ.get("IMAGES") == "1":        # an image in front of the first two prompts (placeholder id 511)
+    import numpy as np
+    from PIL import Image
+    pics = [Image.fromarray((np.random.default_rng(k).random((32, 40, 3)) * 255).astype("uint8")) for k in (1, 2)]
+    prompts = [({{"prompt_token_ids": [511] + prompts[k][0], "multi_modal_data": {{"image": pics[k]}}}}, prompts[k][1])
+               for k in (0, 1)] + prompts[2:]
+ids = [eng.add_request(None, p, s) for p, s in prompts]
 final = {{}}
 while eng.has_unfinished_requests():
     for o in eng.step():
@@ -38,14 +45,15 @@ eng.shutdown()
 """
 
 
-def _run(world, async_sched=False, sp="0", quant="", model="", spec="", ep=False):
+def _run(world, async_sched=False, sp="0", quant="", model="", spec="", ep=False, images=False):
     port = get_open_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VLLM_LOGGING_LEVEL="WARNING",
                    GLOO_SOCKET_IFNAME="lo", OMP_NUM_THREADS="2", ASYNC="1" if async_sched else "0",
-                   VDAMD_SEQUENCE_PARALLEL=sp, QUANT=quant, MODEL=model, SPEC=spec, EP="1" if ep else "0")
+                   VDAMD_SEQUENCE_PARALLEL=sp, QUANT=quant, MODEL=model, SPEC=spec, EP="1" if ep else "0",
+                   IMAGES="1" if images else "0")
         procs.append(subprocess.Popen([sys.executable, "-c", SCRIPT.format(root=ROOT)], env=env,
                                       stdout=subprocess.PIPE, text=True))
     outs = []
@@ -102,6 +110,17 @@ def test_spmd_tp2_draft_model_speculation_matches_single_process():
     ref = _run(1)[0]
     got = _run(2, spec='{"model": "phi-tiny", "num_speculative_tokens": 3}')
     assert got[0][0] == ref[0] and got[0][2] == ref[2] and got[1] == got[0]
+
+
+@pytest.mark.slow
+def test_spmd_tp2_llava_with_images_matches_single_process():
+    """The vision tower is replicated, the decoder sharded: steps that carry image rows leave the fused /
+    sequence-parallel forms of the embedding (forced here) for the plain one, and TP=2 reproduces TP=1."""
+    ref = _run(1, model="llava-tiny", images=True)[0]
+    plain = _run(1, model="llava-tiny")[0]
+    assert ref[2] == plain[2] and ref[0] != plain[0]
+    got = _run(2, model="llava-tiny", images=True, sp="force")
+    assert got[0] == ref and got[1] == ref
 
 
 @pytest.mark.slow

@@ -132,7 +132,14 @@ class KVCacheManager:
         # KV produced under an adapter is only reusable under the same adapter
         lora = getattr(request, "lora_request", None)
         parent = hashes[-1] if hashes else (None if lora is None else hash(("lora", lora.lora_int_id)))
+        mm = getattr(request, "mm_inputs", None)
         for i in range(len(hashes), n_full):
+            if mm:
+                # image placeholders read the same for every image: a block over one also hashes its pixels
+                from ..multimodal import block_mm_salt
+                salt = block_mm_salt(mm, i * bs, (i + 1) * bs)
+                if salt is not None:
+                    parent = hash((parent, "mm") + salt)
             parent = hash_block_tokens(parent, toks[i * bs:(i + 1) * bs])
             hashes.append(parent)
 

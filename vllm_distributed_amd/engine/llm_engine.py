@@ -79,9 +79,11 @@ class LLMEngine:
         if request_id is None:
             request_id = f"req-{next(self._counter)}"
         text: Optional[str] = None
+        mm_data = None
         if isinstance(prompt, dict):
             text = prompt.get("prompt")
             ids = prompt.get("prompt_token_ids")
+            mm_data = prompt.get("multi_modal_data")
             if ids is None:
                 ids = self.tokenizer.encode(text)
         elif isinstance(prompt, str):
@@ -91,6 +93,11 @@ class LLMEngine:
         ids = list(ids)
         max_len = self.model_config.max_model_len
         params = params.clone()          # the fields filled below are per request
+        mm_inputs = self._process_images(ids, mm_data) if mm_data else None
+        if mm_inputs is not None:
+            ids, mm_inputs = mm_inputs
+            if params.truncate_prompt_tokens is not None and params.truncate_prompt_tokens < len(ids):
+                raise ValueError("truncate_prompt_tokens would cut through the image of a multimodal prompt")
         if params.truncate_prompt_tokens is not None:
             ids = ids[-params.truncate_prompt_tokens:]
         if params.max_tokens is None:
@@ -113,11 +120,32 @@ class LLMEngine:
             raise ValueError(f"duplicate request id {request_id}")
         if lora_request is not None and self.vllm_config.lora_config is None:
             raise ValueError("the engine was started without --enable-lora")
-        req = Request(request_id, ids, params, self.eos_token_id, arrival_time, priority, text, lora_request)
+        req = Request(request_id, ids, params, self.eos_token_id, arrival_time, priority, text, lora_request,
+                      mm_inputs)
         detok = IncrementalDetokenizer(self.tokenizer, ids, params) if params.detokenize else None
         self.core.add_request(req)
         self.states[request_id] = _ReqState(req, detok, text)
         return request_id
+
+    def _process_images(self, ids: List[int], mm_data: dict):
+        """Pixels for the vision tower and the prompt with every image placeholder widened to the number of
+        embeddings one image yields (``multimodal.py``)."""
+        from .. import multimodal as mm
+        cfg = self.model_config.hf_config
+        if cfg.get("mm_model_type") is None:
+            raise ValueError(f"{self.model_config.model} does not take images")
+        images = mm_data.get("image") if isinstance(mm_data, dict) else None
+        if images is None:
+            raise ValueError("multi_modal_data: only {\"image\": ...} is supported")
+        if not isinstance(images, (list, tuple)):
+            images = [images]
+        if getattr(self, "_image_processor", None) is None:
+            from ..config import resolve_model_path
+            self._image_processor = mm.ClipImageProcessor.from_model(resolve_model_path(self.model_config.model),
+                                                                     cfg["vision_config"])
+        pixels = [self._image_processor(mm.load_image(im)) for im in images]
+        token = int(cfg.get("image_token_index", cfg.get("image_token_id", 32000)))
+        return mm.expand_image_placeholders(ids, pixels, token, mm.tokens_per_image(cfg))
 
     def _resolve_token_lists(self, params: SamplingParams) -> None:
         """Fill the token-id forms of ``bad_words`` and of the tokens ``min_tokens`` holds back."""

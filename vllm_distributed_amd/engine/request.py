@@ -32,14 +32,16 @@ class Request:
                  "arrival_time", "priority", "status", "output_token_ids", "all_token_ids",
                  "num_computed_tokens", "num_cached_tokens", "stop_reason", "metrics",
                  "block_hashes", "num_preemptions", "max_tokens", "prompt", "num_output_placeholders",
-                 "lora_request", "prompt_logprobs", "spec_token_ids", "plain_stop")
+                 "lora_request", "prompt_logprobs", "spec_token_ids", "plain_stop", "mm_inputs")
 
     def __init__(self, request_id: str, prompt_token_ids: List[int],
                  sampling_params: SamplingParams, eos_token_id: Optional[int] = None,
                  arrival_time: Optional[float] = None, priority: int = 0,
-                 prompt: Optional[str] = None, lora_request=None):
+                 prompt: Optional[str] = None, lora_request=None, mm_inputs=None):
         self.request_id = request_id
         self.lora_request = lora_request
+        # images of a vision-language request (multimodal.MultiModalInput: placeholder span + pixels), or None
+        self.mm_inputs = mm_inputs or None
         self.prompt_token_ids = list(prompt_token_ids)
         self.sampling_params = sampling_params
         self.eos_token_id = eos_token_id

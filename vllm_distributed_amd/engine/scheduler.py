@@ -349,7 +349,7 @@ class Scheduler:
                     sampling_params=req.sampling_params, block_ids=blocks,
                     num_computed_tokens=num_cached,
                     output_token_ids=list(req.output_token_ids) if resumed else [],
-                    lora_request=req.lora_request))
+                    lora_request=req.lora_request, mm_inputs=req.mm_inputs))
                 self._known_to_workers.add(req.request_id)
                 self._pending_new_tokens.pop(req.request_id, None)
                 num_scheduled[req.request_id] = n

@@ -26,6 +26,7 @@ class NewRequestData:
     # tokens generated before a preemption (recompute path) - part of the prompt now
     output_token_ids: List[int] = field(default_factory=list)
     lora_request: Optional[Any] = None
+    mm_inputs: Optional[List[Any]] = None     # multimodal.MultiModalInput per image of the prompt
 
 
 @dataclass

@@ -279,6 +279,20 @@ async def init_app_state(engine: AsyncLLM, vllm_config, state, args: argparse.Na
                 state.chat_template = f.read()
         except OSError:
             state.chat_template = ct
+    # vision-language models: image_url content parts become images of the request; each leaves the
+    # tokenizer's spelling of the placeholder token in the prompt text
+    hf = vllm_config.model_config.hf_config
+    state.takes_images = hf.get("mm_model_type") is not None
+    state.image_placeholder = "<image>"
+    if state.takes_images:
+        from ...multimodal import tokens_per_image
+        state.tokens_per_image = tokens_per_image(hf)
+        try:
+            spelled = engine.tokenizer.convert_ids_to_tokens([int(hf.get("image_token_index", hf.get("image_token_id")))])
+            if spelled and isinstance(spelled[0], str) and spelled[0]:
+                state.image_placeholder = spelled[0]
+        except Exception:  # noqa: BLE001 - a tokenizer without that table keeps the conventional spelling
+            pass
     state.start_time = time.time()
     # served LoRA adapters: name -> LoRARequest (``--lora-modules name=path ...`` and /v1/load_lora_adapter)
     state.loras = {}
@@ -383,13 +397,25 @@ def _sse(obj: Any) -> str:
     return "data: " + (obj if isinstance(obj, str) else json.dumps(obj, ensure_ascii=False)) + "\n\n"
 
 
-def _messages_to_dicts(messages: List[ChatMessage]) -> List[dict]:
+def _messages_to_dicts(messages: List[ChatMessage], images: Optional[list] = None,
+                       image_placeholder: str = "<image>") -> List[dict]:
+    """Content parts -> text.  ``image_url`` parts are collected into ``images`` (in order of appearance) and
+    leave one placeholder line each at the head of their message, the form LLaVA-style prompts take."""
     out = []
     for m in messages:
         d = m.model_dump(exclude_none=True)
         c = d.get("content")
-        if isinstance(c, list):     # content parts -> text
-            d["content"] = "".join(p.get("text", "") for p in c if isinstance(p, dict))
+        if isinstance(c, list):
+            n_img = 0
+            for part in c:
+                if isinstance(part, dict) and part.get("type") in ("image_url", "image", "input_image"):
+                    if images is None:
+                        raise ValueError("this model does not take images")
+                    src = part.get("image_url") or part.get("image") or part.get("url")
+                    images.append(src.get("url") if isinstance(src, dict) else src)
+                    n_img += 1
+            text = "".join(p.get("text", "") for p in c if isinstance(p, dict))
+            d["content"] = (image_placeholder + "\n") * n_img + text
         out.append(d)
     return out
 
@@ -430,7 +456,8 @@ def _register_routes(app: FastAPI, dev_mode: bool = False) -> None:
     async def tokenize(req: TokenizeRequest, request: Request):
         tok = request.app.state.engine.tokenizer
         if req.messages is not None:
-            text = tok.apply_chat_template(_messages_to_dicts(req.messages), tokenize=False,
+            st = request.app.state
+            text = tok.apply_chat_template(_messages_to_dicts(req.messages, [], st.image_placeholder), tokenize=False,
                                            add_generation_prompt=req.add_generation_prompt)
             ids = tok.encode(text, add_special_tokens=False)
         else:
@@ -697,7 +724,14 @@ def _register_routes(app: FastAPI, dev_mode: bool = False) -> None:
             return err
         n = max(1, int(req.n or 1))
         tok = engine.tokenizer
-        messages = _messages_to_dicts(req.messages)
+        images: Optional[list] = [] if st.takes_images else None
+        try:
+            messages = _messages_to_dicts(req.messages, images, st.image_placeholder)
+            if images:
+                from ...multimodal import load_image
+                images = [load_image(src) for src in images]
+        except ValueError as e:
+            return _error(str(e))
         tools = req.tools if req.tool_choice != "none" else None
         # a named tool: the reply *is* that call, its arguments constrained to one JSON object
         forced_tool: Optional[str] = None
@@ -773,7 +807,14 @@ def _register_routes(app: FastAPI, dev_mode: bool = False) -> None:
             return {"id": rid, "object": "chat.completion", "created": created, "model": model, "choices": choices,
                     "usage": _usage(len(prompt_ids), sum(len(b.tokens) for b in beams))}
         from .tool_parsers import _call_id
-        gens = [engine.generate({"prompt": prompt, "prompt_token_ids": prompt_ids}, _nth_params(sp, j),
+        if images and req.use_beam_search:
+            return _error("beam search over prompts with images is not supported")
+        full_prompt: Dict[str, Any] = {"prompt": prompt, "prompt_token_ids": prompt_ids}
+        n_prompt = len(prompt_ids)
+        if images:
+            full_prompt["multi_modal_data"] = {"image": images}
+            n_prompt += len(images) * (st.tokens_per_image - 1)     # each placeholder widens to one image's embeddings
+        gens = [engine.generate(full_prompt, _nth_params(sp, j),
                                 rid if n == 1 else f"{rid}-{j}", req.priority,
                                 st.loras.get(req.model) if req.model else None) for j in range(n)]
         gen = gens[0]
@@ -884,7 +925,7 @@ def _register_routes(app: FastAPI, dev_mode: bool = False) -> None:
                     if req.stream_options and req.stream_options.include_usage:
                         yield _sse({"id": rid, "object": "chat.completion.chunk", "created": created,
                                     "model": model, "choices": [],
-                                    "usage": _usage(len(prompt_ids), sum(counts))})
+                                    "usage": _usage(n_prompt, sum(counts))})
                 except Exception as e:  # noqa: BLE001
                     yield _sse({"error": {"message": str(e), "type": type(e).__name__}})
                 yield _sse("[DONE]")
@@ -926,7 +967,7 @@ def _register_routes(app: FastAPI, dev_mode: bool = False) -> None:
                             "finish_reason": finish, "stop_reason": c.stop_reason})
             n_out += len(c.token_ids)
         body = {"id": rid, "object": "chat.completion", "created": created, "model": model,
-                "choices": choices, "usage": _usage(len(prompt_ids), n_out)}
+                "choices": choices, "usage": _usage(n_prompt, n_out)}
         if req.prompt_logprobs is not None and finals:
             body["prompt_logprobs"] = _prompt_logprobs_json(tok, finals[0].prompt_logprobs)
         return body

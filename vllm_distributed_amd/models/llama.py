@@ -353,6 +353,10 @@ class LlamaForCausalLM(nn.Module):
         """Factor applied to the embedding output (Gemma: sqrt(hidden), Granite: a config value)."""
         return None
 
+    def embed_input(self, input_ids: torch.Tensor) -> torch.Tensor:
+        """Embeddings of a step's tokens (vision-language models overwrite the image rows here)."""
+        return self.embed_tokens(input_ids)
+
     def transform_weight(self, name: str, w):
         """Checkpoint tensor -> the tensor this implementation wants under the (mapped) ``name``."""
         return w
@@ -383,7 +387,7 @@ class LlamaForCausalLM(nn.Module):
             return self.forward_sequence_parallel(input_ids, positions)
         self.path_counts["plain"] += 1
         if self.is_first:
-            hidden = self.embed_tokens(input_ids)
+            hidden = self.embed_input(input_ids)
             residual = None
         else:
             hidden, residual = intermediate.hidden, intermediate.residual
@@ -564,7 +568,7 @@ class LlamaForCausalLM(nn.Module):
         from .layers.attention import set_forward_context
         tp = get_tp_group()
         main = torch.cuda.current_stream()
-        hidden = self.embed_tokens(input_ids)
+        hidden = self.embed_input(input_ids)
         n = len(bounds)
         h = [hidden[s:e] for s, e in bounds]
         pos = [positions[s:e] for s, e in bounds]

@@ -44,8 +44,34 @@ def _seed_for(name: str, base_seed: int) -> int:
 
 def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
     """Checkpoint tensor names and shapes for the supported architectures."""
-    c = mc.hf_config
-    arch = mc.architecture
+    return _weight_shapes(mc.hf_config, mc.architecture)
+
+
+def _weight_shapes(c: dict, arch: str) -> Dict[str, Tuple[int, ...]]:
+    if arch == "LlavaForConditionalGeneration":
+        # the decoder's tensors under "language_model.", a CLIP vision tower and the two-layer projector
+        text_arch = {"mistral": "MistralForCausalLM", "qwen2": "Qwen2ForCausalLM"}.get(c.get("model_type"), "LlamaForCausalLM")
+        out = {"language_model." + n: s for n, s in _weight_shapes(c, text_arch).items()}
+        v = c["vision_config"]
+        vh, vi, ps = int(v["hidden_size"]), int(v["intermediate_size"]), int(v["patch_size"])
+        p = "vision_tower.vision_model."
+        out[p + "embeddings.class_embedding"] = (vh,)
+        out[p + "embeddings.patch_embedding.weight"] = (vh, 3, ps, ps)
+        out[p + "embeddings.position_embedding.weight"] = ((int(v["image_size"]) // ps) ** 2 + 1, vh)
+        for n in ("pre_layrnorm", "post_layernorm"):
+            out[p + n + ".weight"] = out[p + n + ".bias"] = (vh,)
+        for i in range(int(v["num_hidden_layers"])):
+            q = f"{p}encoder.layers.{i}."
+            for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                out[q + f"self_attn.{n}.weight"], out[q + f"self_attn.{n}.bias"] = (vh, vh), (vh,)
+            for n in ("layer_norm1", "layer_norm2"):
+                out[q + n + ".weight"] = out[q + n + ".bias"] = (vh,)
+            out[q + "mlp.fc1.weight"], out[q + "mlp.fc1.bias"] = (vi, vh), (vi,)
+            out[q + "mlp.fc2.weight"], out[q + "mlp.fc2.bias"] = (vh, vi), (vh,)
+        th = c["hidden_size"]
+        out["multi_modal_projector.linear_1.weight"], out["multi_modal_projector.linear_1.bias"] = (th, vh), (th,)
+        out["multi_modal_projector.linear_2.weight"], out["multi_modal_projector.linear_2.bias"] = (th, th), (th,)
+        return out
     h = c["hidden_size"]
     L = c.get("num_hidden_layers", 0)
     shapes: Dict[str, Tuple[int, ...]] = {}

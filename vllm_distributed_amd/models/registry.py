@@ -57,6 +57,8 @@ _MODELS: Dict[str, Tuple[str, str]] = {
     "MptForCausalLM": ("mpt", "MptForCausalLM"),
     "MPTForCausalLM": ("mpt", "MptForCausalLM"),
     "Starcoder2ForCausalLM": ("starcoder2", "Starcoder2ForCausalLM"),
+    # vision-language: CLIP tower + projector in front of the Llama decoder
+    "LlavaForConditionalGeneration": ("llava", "LlavaForConditionalGeneration"),
     # draft heads of speculative decoding (never a served model by themselves; worker/draft_model.py)
     "EagleLlamaForCausalLM": ("spec_heads", "EagleLlamaForCausalLM"),
     "DeepSeekMTP": ("spec_heads", "DeepSeekMTP"),

@@ -4,6 +4,7 @@ so benchmark/test configurations must not depend on the hub)."""
 from __future__ import annotations
 
 import json
+import re
 import os
 from typing import Any, Dict, List, Optional, Sequence
 
@@ -32,8 +33,19 @@ class ByteTokenizer:
         self.is_fast = True
         self.all_special_ids = [i for i in (bos_token_id, eos_token_id) if i is not None]
 
+    _SPELLED = re.compile(r"<(\d{3,7})>")
+
     def encode(self, text: str, add_special_tokens: bool = True) -> List[int]:
-        ids = [b % self.vocab_size for b in text.encode("utf-8")]
+        # ids past the bytes read back from the spelling convert_ids_to_tokens gives them ("<511>"): the way a
+        # synthetic prompt names a special token (an image placeholder) in text
+        ids: List[int] = []
+        at = 0
+        for m in self._SPELLED.finditer(text):
+            if 256 <= int(m.group(1)) < self.vocab_size:
+                ids += list(text[at:m.start()].encode("utf-8")) + [int(m.group(1))]
+                at = m.end()
+        ids += list(text[at:].encode("utf-8"))
+        ids = [b % self.vocab_size for b in ids]
         if add_special_tokens and self.bos_token_id is not None:
             ids = [self.bos_token_id] + ids
         return ids

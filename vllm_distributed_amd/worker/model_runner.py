@@ -248,6 +248,10 @@ class ModelRunner:
         self._static: Dict[str, torch.Tensor] = {}
         self.decode_workspace: Optional[torch.Tensor] = None
         self.draft = None                 # worker.draft_model.DraftProposer (draft-model speculation)
+        # vision-language requests: their images (multimodal.MultiModalInput) and the projected features of
+        # each, computed when the first prompt chunk over the image runs and kept until the request leaves
+        self._mm_inputs: Dict[str, list] = {}
+        self._mm_embeds: Dict[Tuple[str, int], torch.Tensor] = {}
         self.step_count = 0
         self.report_on_all_ranks = False
         self.comm_stream = None
@@ -363,9 +367,13 @@ class ModelRunner:
         b = self.batch
         for rid in so.finished_req_ids:
             b.remove_request(rid)
+            self._drop_mm(rid)
         for rid in so.preempted_req_ids:
             b.remove_request(rid)
+            self._drop_mm(rid)
         for nr in so.scheduled_new_reqs:
+            if getattr(nr, "mm_inputs", None):
+                self._mm_inputs[nr.req_id] = nr.mm_inputs
             lora_id = 0
             if nr.lora_request is not None:
                 if self.lora_manager is None:
@@ -395,6 +403,40 @@ class ModelRunner:
                 nt = int(b.num_tokens[row])
                 b.token_ids[row, nt:nt + len(drafts)] = drafts
                 b.num_known[row] = nt + len(drafts)
+
+    def _drop_mm(self, rid: str) -> None:
+        if self._mm_inputs.pop(rid, None) is not None:
+            for key in [k for k in self._mm_embeds if k[0] == rid]:
+                del self._mm_embeds[key]
+
+    def _image_rows(self, p: dict) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
+        """Rows of this step's flat token list that sit on image placeholders, and the image features that
+        belong there.  A prompt may be prefilled in several chunks, and a chunk may start or end inside an
+        image: each chunk takes the slice of the image's features its positions cover."""
+        if not self._mm_inputs or not hasattr(self.model, "encode_images") or not getattr(self.model, "is_first", True):
+            return None
+        rows, feats = [], []
+        starts = p["seq_lens"] - p["n_sched"]
+        for i, rid in enumerate(p["req_ids"]):
+            items = self._mm_inputs.get(rid)
+            if not items:
+                continue
+            lo, hi = int(starts[i]), int(p["seq_lens"][i])
+            for k, m in enumerate(items):
+                a, z = max(lo, m.offset), min(hi, m.offset + m.length)
+                if a >= z:
+                    continue
+                emb = self._mm_embeds.get((rid, k))
+                if emb is None:
+                    px = torch.from_numpy(np.ascontiguousarray(m.pixel_values)).unsqueeze(0)
+                    emb = self._mm_embeds[(rid, k)] = self.model.encode_images(px.to(self.device))[0]
+                    if emb.shape[0] != m.length:
+                        raise RuntimeError(f"image of {rid}: {emb.shape[0]} features for {m.length} placeholder tokens")
+                rows.append(np.arange(a - lo, z - lo, dtype=np.int64) + int(p["qsl"][i]))
+                feats.append(emb[a - m.offset:z - m.offset])
+        if not rows:
+            return None
+        return self._to_dev(np.concatenate(rows), torch.int64), torch.cat(feats)
 
     def loras_in_batch(self):
         b = self.batch
@@ -516,8 +558,13 @@ class ModelRunner:
         lora_step = None
         if self.lora_manager is not None:
             lora_step = self.lora_manager.make_step(self.batch.lora_id[p["tok_rows"]], self._to_dev)
+        # (a one-token prompt chunk counts as a decode row and may sit on an image placeholder: look at every step
+        # while a request with images is resident)
+        image_rows = self._image_rows(p) if self._mm_inputs else None
+        if image_rows is not None:
+            self.model.set_mm_step(*image_rows)
         graph = None
-        if self.graphs and nd == nreq and lora_step is None:       # captured graphs hold the base model only
+        if self.graphs and nd == nreq and lora_step is None and image_rows is None:   # graphs hold the text model only
             graph = self._pick_graph(nreq, p["max_blocks"])
         with trace_range("step.forward.graph" if graph is not None else "step.forward.eager"):
             if graph is not None:
@@ -529,6 +576,8 @@ class ModelRunner:
                     hidden = self._run_eager(md, input_ids, positions, total)
                 finally:
                     set_lora_step(None)
+                    if image_rows is not None:
+                        self.model.set_mm_step(None)
         if self.draft is not None:
             with trace_range("step.draft.catch_up"):
                 if graph is not None:                    # the graph ran from its own static inputs
