@@ -1,0 +1,293 @@
+// Multi-head latent attention (DeepSeek-V2 / V3) over a LATENT paged cache, gfx950.
+//
+// With the up-projections absorbed into the query and the output (q_lat = q_nope . W_UK, out = o_lat . W_UV^T),
+// every query head of a token attends over ONE shared key per position,
+//     key   = [ RMSNorm(c_kv) (RANK values) | rotated k_rope (ROPE values) ]      DK = RANK + ROPE
+//     value =   RMSNorm(c_kv)                                                      DV = RANK
+// so the cache holds DK + DV values per token and layer instead of heads x (DK' + DV') expanded ones
+// (DeepSeek-V3: 1088 against 49152).  The two forms of the latent are stored in the layouts the other
+// attention kernels use, which make them direct MFMA operands from global memory:
+//     k_cache[num_blocks][block_size][DK]                    key rows
+//     v_cache[num_blocks][DV/16][block_size/8][16][8]        V^T in fragment order
+//
+// One workgroup = one token's tile of 16 query heads (x one KV split).  What makes this shape different from
+// grouped-query attention is the width: a wave that held all of Q (DK/32 fragments), all of a 32-key K group
+// and the whole O^T accumulator (DV/16 tiles) would need ~500 registers.  The four waves of a workgroup split
+// BOTH reductions instead:
+//   * wave w multiplies its quarter of the DK dimension (Q and K fragments of its k-steps only) and leaves a
+//     partial S^T tile pair in LDS; after one barrier every wave adds the four partials - 8 floats per lane,
+//     same lane in every wave, conflict-free - and all four run the identical online softmax on the sum;
+//   * wave w owns DV/4 columns of the output: its V^T fragments and accumulators are a quarter as well.
+// No byte of the cache is read twice by a workgroup, 2 waves per SIMD fit (<= 256 registers), and the exchange
+// (2 KiB per group, double-buffered so one barrier per 32 keys suffices) is small next to the 70 KB of cache a
+// group streams.  The next group's fragments are requested before the current group is multiplied.
+//
+// Rows are tokens, not sequences: a prefill chunk, a decode batch and a speculative verification are the same
+// launch with `token_seq[t]` naming the block-table row and `seq_lens[t]` = position + 1 the causal limit of
+// token t.  (A long prompt therefore streams its keys once per query token - from L2 for the most part, since
+// neighbouring tokens run side by side; the expanded-cache prefill kernel reads them once per 128 tokens.)
+//
+// FlashMLA / vLLM's MLA backends are the CUDA counterparts; the reference framework reaches them through the
+// vLLM image it runs (/root/reference/Dockerfile:1).
+#include "common.h"
+
+namespace {
+
+constexpr float MLA_NEG_BIG = -1.0e30f;
+constexpr int MLA_MAX_SPLITS = 64;
+
+template <typename T, int DK, int DV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void mla_attention_kernel(
+    T* __restrict__ out, long out_stride, float* __restrict__ part_o, float* __restrict__ part_ml,
+    const T* __restrict__ q, long q_stride, const T* __restrict__ k_cache, const T* __restrict__ v_cache,
+    const int* __restrict__ block_table, int bt_stride, const int* __restrict__ token_seq,
+    const int* __restrict__ seq_lens, float scale_log2e, int Hq, int block_size, int num_splits) {
+  using V = typename Vec8<T>::type;
+  constexpr int KSTEPS = DK / 32;              // 32-wide steps of the QK^T reduction
+  constexpr int KS = (KSTEPS + 3) / 4;         // ... per wave (the last waves may run short: zero Q there)
+  constexpr int VT = DV / 64;                  // 16-row tiles of O^T per wave
+  static_assert(DK % 32 == 0 && DV % 64 == 0, "unsupported latent width");
+  __shared__ float s_part[2][4][64][8];
+
+  const int split = blockIdx.x, qt = blockIdx.y, t = blockIdx.z;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int qh0 = qt * 16;
+  const int nq = min(16, Hq - qh0);
+  const int seq_len = seq_lens[t];
+  const int* bt_row = block_table + (long)(token_seq != nullptr ? token_seq[t] : t) * bt_stride;
+
+  const int n_groups = (seq_len + 31) >> 5;
+  const int gps = (n_groups + num_splits - 1) / num_splits;
+  const int g_begin = split * gps;
+  const int g_end = min(g_begin + gps, n_groups);
+
+  // this wave's k-steps: global step wid * KS + s, clamped for the address and zeroed in Q when past the end
+  V qf[KS];
+  int kstep_off[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int sg = wid * KS + s;
+    kstep_off[s] = 32 * min(sg, KSTEPS - 1) + 8 * g4;
+    V z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (T)0.f;
+    qf[s] = (sg < KSTEPS && r16 < nq) ? ld8<T>(q + t * q_stride + (long)(qh0 + r16) * DK + kstep_off[s]) : z;
+  }
+  f32x4 acc[VT];
+#pragma unroll
+  for (int i = 0; i < VT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = MLA_NEG_BIG, l = 0.f;
+
+  const int slab = block_size * 16;            // elements of one 16-row slab of a V^T block
+  struct Frag { V ka[KS], kb[KS], vf[VT]; };
+  auto load = [&](Frag& f, int g) {
+    const int base = g * 32;
+    // K rows of the two interleaved S^T tiles: tile 0 row i <-> key 8 (i >> 2) + (i & 3), tile 1 the same + 4
+    const int key0 = base + 8 * (r16 >> 2) + (r16 & 3);
+    const int ka = min(key0, seq_len - 1), kb = min(key0 + 4, seq_len - 1);
+    const long ra = ((long)bt_row[ka / block_size] * block_size + (ka % block_size)) * DK;
+    const long rb = ((long)bt_row[kb / block_size] * block_size + (kb % block_size)) * DK;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      f.ka[s] = ld8<T>(k_cache + ra + kstep_off[s]);
+      f.kb[s] = ld8<T>(k_cache + rb + kstep_off[s]);
+    }
+    // V^T: this lane's 8 keys are base + 8 g4 .. + 7 (inside one block: block_size % 8 == 0)
+    const int vkey = min(base + 8 * g4, seq_len - 1) & ~7;
+    const long vo = (long)bt_row[vkey / block_size] * (DV / 16) * slab + ((vkey % block_size) >> 3) * 128 + 8 * r16;
+#pragma unroll
+    for (int i = 0; i < VT; ++i) f.vf[i] = ld8<T>(v_cache + vo + (long)(wid * VT + i) * slab);
+  };
+
+  Frag cur, nxt;
+  if (g_begin < g_end) load(cur, g_begin);
+  for (int g = g_begin; g < g_end; ++g) {
+    load(nxt, min(g + 1, g_end - 1));          // (past the end: the last group again, never used)
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      s0 = mfma16(cur.ka[s], qf[s], s0);
+      s1 = mfma16(cur.kb[s], qf[s], s1);
+    }
+    float* mine = &s_part[g & 1][wid][lane][0];
+    *reinterpret_cast<f32x4*>(mine) = s0;
+    *reinterpret_cast<f32x4*>(mine + 4) = s1;
+    __syncthreads();
+    // (every wave adds the four partials in the same order, its own included: the softmax state that follows is
+    // then bit-identical in all four, which the split-KV merge relies on - only wave 0 reports m and l)
+    s0 = *reinterpret_cast<const f32x4*>(&s_part[g & 1][0][lane][0]);
+    s1 = *reinterpret_cast<const f32x4*>(&s_part[g & 1][0][lane][4]);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      s0 += *reinterpret_cast<const f32x4*>(&s_part[g & 1][w][lane][0]);
+      s1 += *reinterpret_cast<const f32x4*>(&s_part[g & 1][w][lane][4]);
+    }
+    // online softmax; key index of element j is base + 8 g4 + j
+    const int kidx0 = g * 32 + 8 * g4;
+    float p[8];
+    float tmax = MLA_NEG_BIG;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float sv = (j < 4 ? s0[j & 3] : s1[j & 3]) * scale_log2e;
+      p[j] = (kidx0 + j < seq_len) ? sv : MLA_NEG_BIG;
+      tmax = fmaxf(tmax, p[j]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m, tmax);
+    const float alpha = exp2f(m - m_new);
+    float psum = 0.f;
+    V pf;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float e = p[j] <= 0.5f * MLA_NEG_BIG ? 0.f : exp2f(p[j] - m_new);
+      psum += e;
+      pf[j] = (T)e;
+    }
+    l = l * alpha + psum;
+    m = m_new;
+#pragma unroll
+    for (int i = 0; i < VT; ++i) {
+      acc[i] *= alpha;
+      acc[i] = mfma16(cur.vf[i], pf, acc[i]);
+    }
+    cur = nxt;
+  }
+
+  float lsum = l;
+  lsum += __shfl_xor(lsum, 16, 64);
+  lsum += __shfl_xor(lsum, 32, 64);
+  if (r16 >= nq) return;
+  const int qh = qh0 + r16;
+  if (num_splits == 1) {
+    const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+    T* orow = out + t * out_stride + (long)qh * DV + 4 * g4;
+#pragma unroll
+    for (int i = 0; i < VT; ++i) {
+      typename Vec4<T>::type o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (T)(acc[i][r] * inv);
+      *reinterpret_cast<typename Vec4<T>::type*>(orow + 16 * (wid * VT + i)) = o;
+    }
+  } else {
+    const long pidx = ((long)t * Hq + qh) * num_splits + split;
+#pragma unroll
+    for (int i = 0; i < VT; ++i)
+      *reinterpret_cast<f32x4*>(part_o + pidx * DV + 16 * (wid * VT + i) + 4 * g4) = acc[i];
+    if (wid == 0 && g4 == 0) { part_ml[2 * pidx] = m; part_ml[2 * pidx + 1] = lsum; }
+  }
+}
+
+// Merge of the KV splits: out = sum_s o_s 2^(m_s - M) / sum_s l_s 2^(m_s - M).
+template <typename T, int DV>
+__global__ void mla_reduce_kernel(T* __restrict__ out, long out_stride, const float* __restrict__ part_o,
+                                  const float* __restrict__ part_ml, int Hq, int num_splits) {
+  const int t = blockIdx.y, qh = blockIdx.x;
+  const long p0 = ((long)t * Hq + qh) * num_splits;
+  float mm = MLA_NEG_BIG;
+  for (int s = 0; s < num_splits; ++s) mm = fmaxf(mm, part_ml[2 * (p0 + s)]);
+  float lt = 0.f;
+  for (int s = 0; s < num_splits; ++s) lt += part_ml[2 * (p0 + s) + 1] * exp2f(part_ml[2 * (p0 + s)] - mm);
+  const float inv = lt > 0.f ? 1.f / lt : 0.f;
+  for (int d = threadIdx.x; d < DV; d += blockDim.x) {
+    float o = 0.f;
+    for (int s = 0; s < num_splits; ++s) o += part_o[(p0 + s) * DV + d] * exp2f(part_ml[2 * (p0 + s)] - mm);
+    out[t * out_stride + (long)qh * DV + d] = (T)(o * inv);
+  }
+}
+
+// One token's latent row into both cache forms.  x[T][DK] (row stride in elements); slot < 0: skipped.
+template <typename T>
+__global__ void mla_cache_write_kernel(const T* __restrict__ x, long x_stride, T* __restrict__ k_cache,
+                                       T* __restrict__ v_cache, const int* __restrict__ slot_mapping, int DK, int DV,
+                                       int block_size) {
+  const int t = blockIdx.x;
+  const int slot = slot_mapping[t];
+  if (slot < 0) return;
+  const long blk = slot / block_size;
+  const int off = slot % block_size;
+  const T* row = x + t * x_stride;
+  T* krow = k_cache + ((long)blk * block_size + off) * DK;
+  const long slab = (long)block_size * 16;
+  T* vblk = v_cache + blk * (DV / 16) * slab + (off >> 3) * 128 + (off & 7);
+  for (int d = threadIdx.x; d < DK; d += blockDim.x) {
+    const T v = row[d];
+    krow[d] = v;
+    if (d < DV) vblk[(d >> 4) * slab + (d & 15) * 8] = v;
+  }
+}
+
+template <typename T, int DK, int DV>
+int launch_mla(void* out, long out_stride, void* part_o, void* part_ml, const void* q, long q_stride,
+               const void* k_cache, const void* v_cache, const int* block_table, int bt_stride, const int* token_seq,
+               const int* seq_lens, float scale, int T_, int Hq, int block_size, int num_splits, hipStream_t st) {
+  dim3 grid(num_splits, (Hq + 15) / 16, T_);
+  mla_attention_kernel<T, DK, DV><<<grid, 256, 0, st>>>(
+      (T*)out, out_stride, (float*)part_o, (float*)part_ml, (const T*)q, q_stride, (const T*)k_cache,
+      (const T*)v_cache, block_table, bt_stride, token_seq, seq_lens, scale * 1.4426950408889634f, Hq, block_size,
+      num_splits);
+  HIP_LAUNCH_CHECK();
+  if (num_splits > 1) {
+    mla_reduce_kernel<T, DV><<<dim3(Hq, T_), 128, 0, st>>>((T*)out, out_stride, (const float*)part_o,
+                                                          (const float*)part_ml, Hq, num_splits);
+    HIP_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+template <typename T>
+int dispatch_mla(int DK, int DV, void* out, long out_stride, void* part_o, void* part_ml, const void* q, long q_stride,
+                 const void* k_cache, const void* v_cache, const int* block_table, int bt_stride,
+                 const int* token_seq, const int* seq_lens, float scale, int T_, int Hq, int block_size,
+                 int num_splits, hipStream_t st) {
+#define MLA_CASE(DK_, DV_)                                                                                     \
+  if (DK == DK_ && DV == DV_)                                                                                  \
+    return launch_mla<T, DK_, DV_>(out, out_stride, part_o, part_ml, q, q_stride, k_cache, v_cache, block_table, \
+                                   bt_stride, token_seq, seq_lens, scale, T_, Hq, block_size, num_splits, st);
+  MLA_CASE(576, 512) MLA_CASE(96, 64) MLA_CASE(320, 256)
+#undef MLA_CASE
+  return -4;
+}
+
+}  // namespace
+
+// out[T][Hq][DV] = softmax(scale * q[T][Hq][DK] . K^T) . V over the latent cache.  token_seq[T] (may be null:
+// token t uses block-table row t) and seq_lens[T] (keys 0 .. seq_lens[t] - 1 are visible to token t).
+// part_o / part_ml: num_splits * T * Hq * (DV | 2) floats when num_splits > 1.
+// Supported (DK, DV): (576, 512) DeepSeek-V2 / V3, (320, 256), (96, 64).
+VDAMD_API int vdamd_mla_attention(void* out, long out_stride, void* part_o, void* part_ml, const void* q,
+                                  long q_stride, const void* k_cache, const void* v_cache, const int* block_table,
+                                  int bt_stride, const int* token_seq, const int* seq_lens, float scale, int T_,
+                                  int Hq, int DK, int DV, int block_size, int num_splits, int dtype, void* stream) {
+  if (T_ <= 0) return 0;
+  if (block_size % 8 || num_splits < 1 || num_splits > MLA_MAX_SPLITS) return -1;
+  if (num_splits > 1 && (part_o == nullptr || part_ml == nullptr)) return -2;
+  if (q_stride % 8 || out_stride % 4) return -5;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16)
+    return dispatch_mla<bf16_t>(DK, DV, out, out_stride, part_o, part_ml, q, q_stride, k_cache, v_cache, block_table,
+                                bt_stride, token_seq, seq_lens, scale, T_, Hq, block_size, num_splits, st);
+  if (dtype == DT_F16)
+    return dispatch_mla<f16_t>(DK, DV, out, out_stride, part_o, part_ml, q, q_stride, k_cache, v_cache, block_table,
+                               bt_stride, token_seq, seq_lens, scale, T_, Hq, block_size, num_splits, st);
+  return -3;
+}
+
+VDAMD_API int vdamd_mla_cache_write(const void* x, long x_stride, void* k_cache, void* v_cache,
+                                    const int* slot_mapping, int T_, int DK, int DV, int block_size, int dtype,
+                                    void* stream) {
+  if (T_ <= 0) return 0;
+  if (block_size % 8 || DV % 16 || DV > DK) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16)
+    mla_cache_write_kernel<bf16_t><<<T_, 256, 0, st>>>((const bf16_t*)x, x_stride, (bf16_t*)k_cache,
+                                                     (bf16_t*)v_cache, slot_mapping, DK, DV, block_size);
+  else if (dtype == DT_F16)
+    mla_cache_write_kernel<f16_t><<<T_, 256, 0, st>>>((const f16_t*)x, x_stride, (f16_t*)k_cache, (f16_t*)v_cache,
+                                                    slot_mapping, DK, DV, block_size);
+  else
+    return -3;
+  HIP_LAUNCH_CHECK();
+  return 0;
+}

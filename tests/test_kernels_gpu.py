@@ -1020,3 +1020,54 @@ def test_k_split_partial_sums_reduced_by_the_following_norm(m, n, k):
     r2 = res.clone()
     n2, r2 = ops.fused_add_rms_norm(ops.linear(x, w), r2, g, 1e-5)
     assert (normed.float() - n2.float()).abs().max().item() < 0.13      # two bf16 roundings of values up to ~8
+
+
+@pytest.mark.parametrize("dk,dv,hq,bs", [(576, 512, 16, 64), (576, 512, 128, 16), (576, 512, 8, 64), (96, 64, 4, 16),
+                                         (96, 64, 48, 32)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_latent_attention_decode_prefill_and_cache_write(dk, dv, hq, bs, dtype):
+    """Multi-head latent attention over the latent cache against an fp32 PyTorch statement of the same sum:
+    the cache-write kernel against index assignment, then a decode batch (lengths around the 32-key group
+    boundaries, one long enough for several KV splits) and a prefill chunk behind a cached context (rows are
+    tokens: each sees keys up to its own position)."""
+    from vllm_distributed_amd.ops import hip as _hip
+    torch.manual_seed(dk + hq)
+    lens = [1, 31, 32, 33, 200, 1500]
+    nblk = sum(-(-n // bs) for n in lens) + 4
+    kc = torch.zeros(torch_ref.k_cache_shape(nblk, 1, dk, bs), dtype=dtype, device=DEV)
+    vc = torch.zeros(torch_ref.v_cache_shape(nblk, 1, dv, bs), dtype=dtype, device=DEV)
+    kc_ref, vc_ref = kc.clone(), vc.clone()
+    order = torch.randperm(nblk - 1)[:nblk - 4] + 1           # block 0 stays empty: a clamped read must not matter
+    table = torch.zeros((len(lens), -(-max(lens) // bs)), dtype=torch.int32)
+    slots, at = [], 0
+    for b, n in enumerate(lens):
+        nb = -(-n // bs)
+        table[b, :nb] = order[at:at + nb].int()
+        at += nb
+        slots += [int(table[b, i // bs]) * bs + i % bs for i in range(n)]
+    latent = (torch.randn(len(slots), dk, device=DEV) * 0.5).to(dtype)
+    slot_t = torch.tensor(slots + [-1], dtype=torch.int32, device=DEV)
+    extra = torch.cat([latent, latent[:1]])                    # a row with slot -1 is skipped
+    _hip.mla_cache_write(extra, kc, vc, slot_t)
+    torch_ref.mla_cache_write(extra, kc_ref, vc_ref, slot_t)
+    assert torch.equal(kc, kc_ref) and torch.equal(vc, vc_ref)
+    table = table.to(DEV)
+    scale = dk ** -0.5
+    # ---- decode: one query per sequence
+    q = torch.randn(len(lens), hq, dk, device=DEV).to(dtype)
+    sl = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    got = _hip.mla_attention(q, kc, vc, table, None, sl, scale, max(lens))
+    ref = torch_ref.mla_attention(q.float(), kc.float(), vc.float(), table, None, sl, scale)
+    torch.testing.assert_close(got.float(), ref, rtol=2e-2, atol=2e-2)
+    assert _hip.mla_num_splits(len(lens), -(-hq // 16), max(lens)) > 1 or hq > 64
+    # ---- prefill: the last 40 tokens of sequence 4 and the last 70 of sequence 5, causal
+    tok_seq, tok_len = [], []
+    for b, n_q in ((4, 40), (5, 70)):
+        tok_seq += [b] * n_q
+        tok_len += list(range(lens[b] - n_q + 1, lens[b] + 1))
+    ts = torch.tensor(tok_seq, dtype=torch.int32, device=DEV)
+    tl = torch.tensor(tok_len, dtype=torch.int32, device=DEV)
+    q = torch.randn(len(tok_seq), hq, dk, device=DEV).to(dtype)
+    got = _hip.mla_attention(q, kc, vc, table, ts, tl, scale, max(lens))
+    ref = torch_ref.mla_attention(q.float(), kc.float(), vc.float(), table, ts, tl, scale)
+    torch.testing.assert_close(got.float(), ref, rtol=2e-2, atol=2e-2)

@@ -571,3 +571,23 @@ def grouped_silu_fused(tile_rows: int, qw, sz) -> bool:
 apply_penalties = torch_ref.apply_penalties
 compute_logprobs = torch_ref.compute_logprobs
 build_cos_sin_cache = torch_ref.build_cos_sin_cache
+
+
+# ------------------------------------------------ multi-head latent attention over a latent cache (DeepSeek)
+def mla_kernel_ok(dk: int, dv: int, dtype: torch.dtype) -> bool:
+    """Whether the HIP latent-attention kernel is built for this key / value width."""
+    return hip_available() and _hip.mla_supported(dk, dv, dtype)
+
+
+def mla_cache_write(latent, k_cache, v_cache, slot_mapping):
+    if _use_hip(latent) and latent.dtype in (torch.bfloat16, torch.float16):
+        return _hip.mla_cache_write(latent, k_cache, v_cache, slot_mapping)
+    return torch_ref.mla_cache_write(latent, k_cache, v_cache, slot_mapping)
+
+
+def mla_attention(q, k_cache, v_cache, block_table, token_seq, seq_lens, scale, max_seq_len, out=None):
+    on_hip = _use_hip(q) and _hip.mla_supported(q.shape[2], v_cache.shape[2] * v_cache.shape[4], q.dtype)
+    _note_attention(q, on_hip)
+    if on_hip:
+        return _hip.mla_attention(q, k_cache, v_cache, block_table, token_seq, seq_lens, scale, max_seq_len, out)
+    return torch_ref.mla_attention(q, k_cache, v_cache, block_table, token_seq, seq_lens, scale, max_seq_len, out)

@@ -56,6 +56,8 @@ def load() -> ctypes.CDLL:
         "vdamd_moe_route_small": [P, L, I, I, I, I, I, I, I, P, P, P, P, P, I, P, L, P, I, I, I, I, L, P],
         "vdamd_moe_combine": [P, L, P, L, P, P, P, I, I, I, I, I, P, I, P],
         "vdamd_bias_clamped_glu": [P, L, P, L, P, P, P, I, I, I, I, F, F, I, P],
+        "vdamd_mla_attention": [P, L, P, P, P, L, P, P, P, I, P, P, F, I, I, I, I, I, I, I, P],
+        "vdamd_mla_cache_write": [P, L, P, P, P, I, I, I, I, I, P],
         "vdamd_moe_combine_add_rms_norm": [P, L, P, L, P, P, P, I, I, I, I, I, P, P, F, I, P],
         "vdamd_fp4a16_gemm": [P, L, P, L, P, P, P, P, I, I, I, I, I, I, P],
         "vdamd_fp4_dequant": [P, P, P, P, I, I, I, P],
@@ -1063,3 +1065,61 @@ def dynamic_fp8_quant(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     _check(_LIB.vdamd_dynamic_fp8_quant(out.data_ptr(), scale.data_ptr(), x.data_ptr(), m, k, x.stride(0),
                                         _dt(x), _stream()), "dynamic_fp8_quant")
     return out, scale
+
+
+# ------------------------------------------------ multi-head latent attention (DeepSeek) over a latent cache
+MLA_KERNEL_DIMS = ((576, 512), (320, 256), (96, 64))
+
+
+def mla_supported(dk: int, dv: int, dtype: torch.dtype) -> bool:
+    return (dk, dv) in MLA_KERNEL_DIMS and dtype in (torch.bfloat16, torch.float16)
+
+
+def mla_cache_write(latent: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                    slot_mapping: torch.Tensor) -> None:
+    """``latent[T, DK]`` (normalised c_kv | rotated k_rope) into the key-row cache and, its first DV values,
+    into the V^T fragment cache."""
+    t, dk = latent.shape
+    dv = v_cache.shape[2] * v_cache.shape[4]
+    bs = k_cache.shape[2]
+    assert latent.stride(1) == 1 and k_cache.shape[1] == 1 and k_cache.shape[3] == dk and k_cache.is_contiguous()
+    assert v_cache.is_contiguous() and v_cache.shape[3] * v_cache.shape[5] == bs and k_cache.dtype == latent.dtype
+    assert slot_mapping.dtype == torch.int32 and slot_mapping.numel() >= t
+    _check(_LIB.vdamd_mla_cache_write(latent.data_ptr(), latent.stride(0), k_cache.data_ptr(), v_cache.data_ptr(),
+                                      slot_mapping.data_ptr(), t, dk, dv, bs, _dt(latent), _stream()), "mla_cache_write")
+
+
+def mla_num_splits(tokens: int, q_tiles: int, max_seq_len: int) -> int:
+    """KV splits so that the launch has a few workgroups per CU, none shorter than 128 keys."""
+    want = -(-1024 // max(1, tokens * q_tiles))
+    return int(max(1, min(want, max_seq_len // 128, 64)))
+
+
+def mla_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_table: torch.Tensor,
+                  token_seq: Optional[torch.Tensor], seq_lens: torch.Tensor, scale: float, max_seq_len: int,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``q[T, Hq, DK]`` against the latent cache -> ``[T, Hq, DV]``; token ``t`` reads block-table row
+    ``token_seq[t]`` (``t`` itself when None) and sees keys ``0 .. seq_lens[t] - 1``."""
+    t, hq, dk = q.shape
+    dv = v_cache.shape[2] * v_cache.shape[4]
+    bs = k_cache.shape[2]
+    assert mla_supported(dk, dv, q.dtype), (dk, dv, q.dtype)
+    assert q.stride(2) == 1 and q.stride(1) == dk and k_cache.is_contiguous() and v_cache.is_contiguous()
+    assert block_table.dtype == torch.int32 and block_table.stride(1) == 1 and seq_lens.dtype == torch.int32
+    assert seq_lens.numel() >= t and (token_seq is None or (token_seq.dtype == torch.int32 and token_seq.numel() >= t))
+    assert token_seq is not None or block_table.shape[0] >= t
+    if out is None:
+        out = torch.empty((t, hq, dv), dtype=q.dtype, device=q.device)
+    assert out.stride(2) == 1 and out.stride(1) == dv
+    splits = mla_num_splits(t, -(-hq // 16), max_seq_len)
+    part_o = part_ml = None
+    if splits > 1:
+        part_o = torch.empty((t * hq * splits, dv), dtype=torch.float32, device=q.device)
+        part_ml = torch.empty((t * hq * splits, 2), dtype=torch.float32, device=q.device)
+    _check(_LIB.vdamd_mla_attention(
+        out.data_ptr(), out.stride(0), None if part_o is None else part_o.data_ptr(),
+        None if part_ml is None else part_ml.data_ptr(), q.data_ptr(), q.stride(0), k_cache.data_ptr(),
+        v_cache.data_ptr(), block_table.data_ptr(), block_table.stride(0),
+        None if token_seq is None else token_seq.data_ptr(), seq_lens.data_ptr(), float(scale), t, hq, dk, dv, bs,
+        splits, _dt(q), _stream()), "mla_attention")
+    return out

@@ -357,3 +357,46 @@ def embedding(ids: torch.Tensor, weight: torch.Tensor, vocab_start: int = 0,
     if masked or vocab_start != 0:
         out = out * mask.unsqueeze(-1).to(out.dtype)
     return out
+
+
+# ------------------------------------------------ multi-head latent attention over a latent cache (DeepSeek)
+def mla_cache_write(latent: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                    slot_mapping: torch.Tensor) -> None:
+    """``latent[T, DK]`` into ``k_cache[blocks, 1, bs, DK]``; its first DV values into the V^T fragment cache."""
+    bs = k_cache.shape[2]
+    dv = v_cache.shape[2] * V_ROWS
+    valid = slot_mapping[:latent.shape[0]] >= 0
+    slots = slot_mapping[:latent.shape[0]][valid].long()
+    blk, off = slots // bs, slots % bs
+    x = latent[valid].to(k_cache.dtype)
+    k_cache[blk, 0, off, :] = x
+    v_cache[blk, 0, :, off // V_GROUP, :, off % V_GROUP] = x[:, :dv].unflatten(-1, (-1, V_ROWS))
+
+
+def mla_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_table: torch.Tensor,
+                  token_seq: Optional[torch.Tensor], seq_lens: torch.Tensor, scale: float, max_seq_len: int = 0,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``q[T, Hq, DK]`` against the latent cache -> ``[T, Hq, DV]`` in fp32 arithmetic.  Keys come from the
+    key-row cache, values from the V^T fragment cache (so a test of a kernel against this checks both)."""
+    t, hq, dk = q.shape
+    bs = k_cache.shape[2]
+    dv = v_cache.shape[2] * V_ROWS
+    res = torch.zeros((t, hq, dv), dtype=torch.float32, device=q.device)
+    rows = token_seq.long() if token_seq is not None else torch.arange(t, device=q.device)
+    lens = seq_lens[:t].long()
+    for b in torch.unique(rows).tolist():
+        mine = torch.nonzero(rows == b).flatten()
+        n = int(lens[mine].max())
+        blocks = block_table[b, :(n + bs - 1) // bs].long()
+        keys = k_cache[blocks, 0].reshape(-1, dk)[:n].float()
+        # [blocks, DV/16, bs/8, 16, 8] -> [blocks, bs/8, 8, DV/16, 16] -> [n, DV]
+        vals = v_cache[blocks, 0].permute(0, 2, 4, 1, 3).reshape(-1, dv)[:n].float()
+        s = torch.einsum("thd,nd->thn", q[mine].float(), keys) * scale
+        mask = torch.arange(n, device=q.device)[None, None, :] >= lens[mine][:, None, None]
+        p = torch.softmax(s.masked_fill(mask, float("-inf")), dim=-1)
+        res[mine] = torch.einsum("thn,nd->thd", p, vals)
+    res = res.to(q.dtype)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
