@@ -247,3 +247,38 @@ def test_llava_matches_transformers_with_images(tmp_path):
                 assert abs(got[t] - lp[t].item()) < 3e-3, (t, got[t], lp[t].item())
             assert list(out.outputs[0].token_ids) == toks
         assert len(outs[0].prompt_token_ids) == 6 + 16 and len(outs[1].prompt_token_ids) == 5 + 32
+
+
+@pytest.mark.parametrize("name", ["deepseek-v3", "deepseek-v2"])
+@pytest.mark.parametrize("latent", [True, False])
+def test_deepseek_latent_and_expanded_caches_match_transformers(name, latent, tmp_path, monkeypatch):
+    """Multi-head latent attention served both ways: the latent row in the cache with the up-projections
+    absorbed into the query and the output (kv_lora_rank + rope + kv_lora_rank values per token), and per-head
+    keys / values expanded in front of an ordinary cache.  Both against transformers, prompts whole and in
+    16-token chunks (a chunk's rows attend over the cached latent of the chunks before it)."""
+    monkeypatch.setenv("VDAMD_MLA_LATENT", "1" if latent else "0")
+    model = _hf_model(name, tmp_path)
+    ref_tokens = []
+    with torch.no_grad():
+        for p in PROMPTS:
+            gen = model.generate(torch.tensor([p]), max_new_tokens=6, do_sample=False, pad_token_id=0)
+            ref_tokens.append(gen[0, len(p):].tolist())
+    for extra in ({}, {"max_num_batched_tokens": 16}):
+        llm = LLM(model=str(tmp_path), dtype="float32", device="cpu", max_model_len=128, num_gpu_blocks_override=64,
+                  max_num_seqs=8, **extra)
+        try:
+            runner = llm.engine.core.executor.driver.worker.model_runner
+            attn = runner.model.attention_layers()[0]
+            assert bool(getattr(attn, "latent", False)) == latent
+            k, v = runner.kv_caches[0]
+            rank, rope = CASES[name][1]["kv_lora_rank"], CASES[name][1]["qk_rope_head_dim"]
+            if latent:
+                assert k.shape[1] == 1 and k.shape[-1] == rank + rope and v.shape[2] * v.shape[4] == rank
+                assert runner.get_kv_cache_spec().bytes_per_token == 3 * (2 * rank + rope) * 4      # 3 layers, fp32
+            else:
+                assert k.shape[1] == 4
+            outs = llm.generate(PROMPTS, SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True))
+        finally:
+            llm.shutdown()
+            pstate.destroy_model_parallel()
+        assert [list(o.outputs[0].token_ids) for o in outs] == ref_tokens

@@ -1059,7 +1059,7 @@ def test_latent_attention_decode_prefill_and_cache_write(dk, dv, hq, bs, dtype):
     got = _hip.mla_attention(q, kc, vc, table, None, sl, scale, max(lens))
     ref = torch_ref.mla_attention(q.float(), kc.float(), vc.float(), table, None, sl, scale)
     torch.testing.assert_close(got.float(), ref, rtol=2e-2, atol=2e-2)
-    assert _hip.mla_num_splits(len(lens), -(-hq // 16), max(lens)) > 1 or hq > 64
+    assert _hip.mla_num_splits(len(lens), -(-hq // 16), max(lens)) > 1
     # ---- prefill: the last 40 tokens of sequence 4 and the last 70 of sequence 5, causal
     tok_seq, tok_len = [], []
     for b, n_q in ((4, 40), (5, 70)):

@@ -20,8 +20,9 @@ QWEN3_SMALL = dict(hidden_size=512, num_attention_heads=4, num_key_value_heads=2
                    vocab_size=1024, max_position_embeddings=512)
 
 
-# multi-head latent attention is served by expanding the latent to a padded per-head size: whatever that is
-MLA_EXPANDED = {"deepseek-v3-tiny"}
+# (families whose attention may run outside the HIP kernels: none - DeepSeek's latent width 64 + 32 is one
+# the latent-cache kernel is built for)
+MLA_EXPANDED = set()
 # dense families (no router whose near-ties bf16 can flip): the GPU run must track the fp32 reference closely
 TIGHT = {"llama-tiny", "opt-tiny", "phi3-tiny", "gemma-tiny", "granite-tiny", "gpt2-tiny", "gpt-neox-tiny",
          "starcoder2-tiny", "mistral-window-tiny", "phi-tiny", "phi2-tiny", "glm-tiny", "helium-tiny", "smollm3-tiny",

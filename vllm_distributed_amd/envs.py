@@ -127,6 +127,11 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     # Up to 8 rows into a very wide output (gate_up with the SiLU epilogue, LM head): the barrier-free
     # weight-streaming GEMM instead of the library.
     "VDAMD_STREAM_GEMM": _bool("VDAMD_STREAM_GEMM", True),
+    # DeepSeek's multi-head latent attention keeps the latent (kv_lora_rank + rope values per token) in the
+    # cache and attends with the up-projections absorbed into q and the output; 0 = expand to per-head
+    # keys and values in front of an ordinary paged cache (the only form for latent widths the kernel
+    # is not built for on the GPU).
+    "VDAMD_MLA_LATENT": _bool("VDAMD_MLA_LATENT", True),
     "VDAMD_FUSED_REDUCE_NORM": _bool("VDAMD_FUSED_REDUCE_NORM", True),
     # The rotary + KV-cache kernel sums the K-split partial sums of the q/k/v projection itself (decode-sized batches).
     "VDAMD_FUSED_REDUCE_ROPE": _bool("VDAMD_FUSED_REDUCE_ROPE", True),

@@ -3,10 +3,13 @@
 Attention: queries come through an optional low-rank pair ``q_a_proj -> RMSNorm -> q_b_proj``; keys and
 values come from one latent ``kv_a_proj_with_mqa(x) = [c_kv (kv_lora_rank) | k_rope (qk_rope_head_dim)]``:
 ``kv_b_proj(RMSNorm(c_kv))`` gives every head its ``k_nope`` and ``v``, and the single rotated ``k_rope``
-is shared by all heads.  This implementation expands the latent to per-head K / V before the cache
-(``[k_nope | k_rope]`` of ``qk_nope + qk_rope`` dims, V zero-padded to the same width, both padded to the
-next size the attention kernels are built for), so the paged attention kernels run unchanged; the price
-is a cache of ``heads x 256`` values per token where a latent cache would hold ``kv_lora_rank + rope``.
+is shared by all heads.  Two forms are served.  *Latent cache* (default): the cache holds the normalised
+``c_kv`` and the rotated ``k_rope`` of a token - once as a key row, once as V^T fragments - and ``kv_b_proj`` is
+absorbed: its key half is folded into the query (``q_nope . W_UK``), its value half applied to the attention
+output, so every head attends over one shared ``rank + rope``-wide key (``layers.attention.LatentAttention``,
+``csrc/mla_attention.hip``).  *Expanded* (``VDAMD_MLA_LATENT=0``, or a latent width the kernel is not built for):
+per-head K / V (``[k_nope | k_rope]``, V zero-padded to the same width, both padded to the next size the attention
+kernels take) in front of the ordinary paged cache, at ``heads x 2 x 256`` values per token.
 The rotary pairs are adjacent dimensions in these checkpoints: the rope rows of ``q_b_proj`` / ``q_proj``
 and of ``kv_a_proj_with_mqa`` are re-ordered at load so that the half-apart rotation applies.
 
@@ -30,11 +33,11 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops
+from .. import envs, ops
 from ..config import VllmConfig
 from ..parallel.state import get_tensor_model_parallel_world_size, tensor_model_parallel_all_reduce
 from . import qwen3_moe
-from .layers.attention import Attention, RMSNorm, get_forward_context
+from .layers.attention import Attention, LatentAttention, RMSNorm, get_forward_context
 from .layers.linear import ColumnParallelLinear, ReplicatedLinear, RowParallelLinear, divide
 from .layers.moe import FusedMoE
 from .llama import LlamaMLP, rope_row_permutation
@@ -77,8 +80,39 @@ class MLAAttention(nn.Module):
         rs = cfg.get("rope_scaling") or {}
         if rs.get("rope_type", rs.get("type", "default")) != "default" and rs.get("mscale_all_dim"):
             scale *= _yarn_mscale(float(rs["factor"]), float(rs["mscale_all_dim"])) ** 2
-        self.attn = Attention(self.num_heads, self.qk_dim, self.num_heads, float(scale), layer_idx, pad_head_dim=True)
+        # latent cache (absorbed projections) wherever the kernel for this latent width exists - always on the
+        # CPU, where the PyTorch reference serves any width - else per-head keys / values in an ordinary cache
+        dk, dv = self.kv_rank + self.rope, self.kv_rank
+        on_gpu = torch.empty(0).device.type != "cpu"       # (modules are built under the target device)
+        self.latent = bool(envs.VDAMD_MLA_LATENT) and dv % 16 == 0 and (
+            not on_gpu or ops.mla_kernel_ok(dk, dv, dtype))
+        if self.latent:
+            self.attn = LatentAttention(self.num_heads, self.kv_rank, self.rope, float(scale), layer_idx)
+        else:
+            self.attn = Attention(self.num_heads, self.qk_dim, self.num_heads, float(scale), layer_idx, pad_head_dim=True)
+        self._absorbed = None
         self.cos_sin = cos_sin
+
+    def _absorbed_weights(self):
+        """``kv_b_proj`` per local head, split into the part that makes keys (folded into the query:
+        ``w_uk[h]`` is ``[nope, rank]``) and the part that makes values (applied to the attention output:
+        ``w_uv_t[h]`` is ``[rank, v_dim]``)."""
+        if self._absorbed is None:
+            w = self.kv_b_proj.weight.view(self.num_heads, self.nope + self.v_dim, self.kv_rank)
+            self._absorbed = (w[:, :self.nope, :].contiguous(), w[:, self.nope:, :].transpose(1, 2).contiguous())
+        return self._absorbed
+
+    def _forward_latent(self, positions: torch.Tensor, q: torch.Tensor, latent: torch.Tensor) -> torch.Tensor:
+        t, h = q.shape[0], self.num_heads
+        c = self.kv_a_layernorm(latent[:, :self.kv_rank].contiguous())
+        q_rot = q[..., self.nope:].reshape(t, h * self.rope)
+        k_rot = latent[:, self.kv_rank:].contiguous()
+        ops.rotary_embedding(positions, q_rot, k_rot, self.cos_sin, self.rope)
+        w_uk, w_uv_t = self._absorbed_weights()
+        q_lat = torch.bmm(q[..., :self.nope].transpose(0, 1), w_uk)                  # [h, t, rank]
+        q_full = torch.cat([q_lat.transpose(0, 1), q_rot.view(t, h, self.rope)], dim=-1)
+        o_lat = self.attn.forward_latent(q_full, torch.cat([c, k_rot], dim=-1))      # [t, h, rank]
+        return torch.bmm(o_lat.transpose(0, 1), w_uv_t).transpose(0, 1).reshape(t, h * self.v_dim)
 
     def forward(self, positions: torch.Tensor, hidden: torch.Tensor, reduce: bool = True, staged: bool = False,
                 residual: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -89,6 +123,8 @@ class MLAAttention(nn.Module):
             q = self.q_proj(hidden)
         q = q.view(t, h, self.qk_dim)
         latent = self.kv_a_proj_with_mqa(hidden)
+        if self.latent:
+            return self.o_proj(self._forward_latent(positions, q, latent), reduce, staged)
         kv = self.kv_b_proj(self.kv_a_layernorm(latent[:, :self.kv_rank].contiguous())).view(t, h, self.nope + self.v_dim)
         q_rot = q[..., self.nope:].reshape(t, h * self.rope)
         k_rot = latent[:, self.kv_rank:].contiguous()

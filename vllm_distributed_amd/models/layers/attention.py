@@ -35,6 +35,20 @@ class AttentionMetadata:
     max_decode_seq_len: int = 0
     decode_workspace: Optional[torch.Tensor] = None
 
+    def token_rows(self, positions: torch.Tensor):
+        """Per token of the step: the block-table row it reads (None = its own index: a pure decode batch)
+        and the number of keys it sees (its position + 1).  For kernels whose rows are tokens
+        (``LatentAttention``); computed once per step and kept."""
+        if self.num_prefills == 0:
+            return None, self.seq_lens
+        cached = getattr(self, "_token_rows", None)
+        if cached is None:
+            t = positions.shape[0]
+            idx = torch.arange(t, dtype=self.query_start_loc.dtype, device=positions.device)
+            rows = torch.bucketize(idx, self.query_start_loc[1:], right=True).to(torch.int32)
+            cached = self._token_rows = (rows, (positions + 1).to(torch.int32))
+        return cached
+
 
 class ForwardContext:
     attn_metadata: Optional[AttentionMetadata] = None
@@ -89,6 +103,14 @@ class Attention(nn.Module):
     def bind_kv_cache(self, k_cache: torch.Tensor, v_cache: torch.Tensor, kv_scales: Optional[tuple] = None) -> None:
         self.k_cache, self.v_cache, self.kv_scales = k_cache, v_cache, kv_scales
 
+    def kv_cache_shapes(self, num_blocks: int, block_size: int):
+        """Shapes of this layer's two cache tensors."""
+        dims = (num_blocks, self.num_kv_heads, self.head_dim, block_size)
+        return ops.k_cache_shape(*dims), ops.v_cache_shape(*dims)
+
+    def kv_values_per_token(self) -> int:
+        return 2 * self.num_kv_heads * self.head_dim
+
     def set_kv_scale(self, which: str, value: torch.Tensor) -> None:
         """Checkpoint ``k_scale`` / ``v_scale`` (a scalar, or one value per local KV head)."""
         ks, vs = self.kv_scales or (None, None)
@@ -142,6 +164,35 @@ class Attention(nn.Module):
                                   v.reshape(t, self.num_kv_heads, self.head_dim),
                                   self.k_cache, self.v_cache, md.slot_mapping, self.kv_scales)
         return self.forward_cached(q)
+
+
+class LatentAttention(Attention):
+    """Multi-head latent attention with the up-projections absorbed into the query and the output: every head
+    attends over ONE shared key ``[normalised c_kv | rotated k_rope]`` (``rank + rope`` wide) whose first ``rank``
+    values are also the value.  The cache holds that row twice - as a key row and in the V^T fragment layout - so
+    ``rank + rope + rank`` values per token where per-head keys and values would take ``heads * 2 * head_dim``."""
+    latent = True
+
+    def __init__(self, num_heads: int, rank: int, rope: int, scale: float, layer_idx: int):
+        super().__init__(num_heads, rank + rope, 1, scale, layer_idx)
+        self.v_dim = rank
+
+    def kv_cache_shapes(self, num_blocks: int, block_size: int):
+        return (ops.k_cache_shape(num_blocks, 1, self.head_dim, block_size),
+                ops.v_cache_shape(num_blocks, 1, self.v_dim, block_size))
+
+    def kv_values_per_token(self) -> int:
+        return self.head_dim + self.v_dim
+
+    def forward_latent(self, q: torch.Tensor, latent: torch.Tensor) -> torch.Tensor:
+        """``q[T, H, rank + rope]`` (absorbed, rotated), ``latent[T, rank + rope]`` of this step's tokens:
+        writes the cache, returns ``[T, H, rank]``."""
+        md = _CTX.attn_metadata
+        if md is None:                          # memory-profiling pass: no cache bound
+            return q[..., :self.v_dim].contiguous()
+        ops.mla_cache_write(latent, self.k_cache, self.v_cache, md.slot_mapping)
+        rows, lens = md.token_rows(_CTX.positions)
+        return ops.mla_attention(q, self.k_cache, self.v_cache, md.block_table, rows, lens, self.scale, md.max_seq_len)
 
 
 class RMSNorm(nn.Module):

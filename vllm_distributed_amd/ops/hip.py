@@ -1090,14 +1090,17 @@ def mla_cache_write(latent: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.
 
 
 def mla_num_splits(tokens: int, q_tiles: int, max_seq_len: int) -> int:
-    """KV splits so that the launch has a few workgroups per CU, none shorter than 128 keys."""
-    want = -(-1024 // max(1, tokens * q_tiles))
-    return int(max(1, min(want, max_seq_len // 128, 64)))
+    """KV splits: about one workgroup per CU in total and no split shorter than ~192 keys.  A workgroup
+    streams ~36 GB/s by itself (one group of 32 keys in flight ahead of the one being multiplied), so the
+    chip's bandwidth needs a few hundred of them; beyond that, more splits only add partial sums to write and
+    merge (scripts/dev/mla_split_sweep.py: the fastest count is within ~5 % of this rule from batch 1 to 256)."""
+    want = -(-256 // max(1, tokens * q_tiles))
+    return int(max(1, min(want, max_seq_len // 192, 64)))
 
 
 def mla_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_table: torch.Tensor,
                   token_seq: Optional[torch.Tensor], seq_lens: torch.Tensor, scale: float, max_seq_len: int,
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  out: Optional[torch.Tensor] = None, splits: Optional[int] = None) -> torch.Tensor:
     """``q[T, Hq, DK]`` against the latent cache -> ``[T, Hq, DV]``; token ``t`` reads block-table row
     ``token_seq[t]`` (``t`` itself when None) and sees keys ``0 .. seq_lens[t] - 1``."""
     t, hq, dk = q.shape
@@ -1111,7 +1114,8 @@ def mla_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
     if out is None:
         out = torch.empty((t, hq, dv), dtype=q.dtype, device=q.device)
     assert out.stride(2) == 1 and out.stride(1) == dv
-    splits = mla_num_splits(t, -(-hq // 16), max_seq_len)
+    if splits is None:
+        splits = mla_num_splits(t, -(-hq // 16), max_seq_len)
     part_o = part_ml = None
     if splits > 1:
         part_o = torch.empty((t * hq * splits, dv), dtype=torch.float32, device=q.device)

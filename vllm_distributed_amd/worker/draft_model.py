@@ -60,14 +60,14 @@ class DraftProposer:
 
     # ------------------------------------------------------------------ KV cache
     def kv_bytes_per_block(self, block_size: int, dtype_bytes: int) -> int:
-        return sum(2 * block_size * a.num_kv_heads * a.head_dim * dtype_bytes for a in self.model.attention_layers())
+        return sum(block_size * a.kv_values_per_token() * dtype_bytes for a in self.model.attention_layers())
 
     def allocate_kv(self, num_blocks: int, block_size: int, dtype: torch.dtype, fp8: bool) -> None:
         self.kv_caches = []
         for attn in self.model.attention_layers():
-            dims = (num_blocks, attn.num_kv_heads, attn.head_dim, block_size)
-            k = torch.zeros(ops.k_cache_shape(*dims), dtype=dtype, device=self.device)
-            v = torch.zeros(ops.v_cache_shape(*dims), dtype=dtype, device=self.device)
+            k_shape, v_shape = attn.kv_cache_shapes(num_blocks, block_size)
+            k = torch.zeros(k_shape, dtype=dtype, device=self.device)
+            v = torch.zeros(v_shape, dtype=dtype, device=self.device)
             scales = attn.kv_scales if fp8 else None
             if scales is not None:
                 scales = tuple(t.to(self.device) for t in scales)

@@ -312,7 +312,15 @@ class ModelRunner:
         dtype_bytes = 1 if fp8 else self.model_config.dtype_bytes
         if self.draft is not None:        # the draft reads every key it ever wrote unless it is windowed too
             windows += [int(getattr(l, "window", 0) or 0) for l in self.draft.model.attention_layers()]
-        return KVCacheSpec(num_layers=len(layers), num_kv_heads=a.num_kv_heads, head_dim=a.head_dim,
+        heads, width = a.num_kv_heads, a.head_dim
+        if getattr(a, "latent", False):
+            # one shared latent row per token, held in two layouts: (rank + rope) + rank values, which the
+            # spec's "2 x heads x head_dim" states as one head of half that sum
+            heads, width = 1, a.kv_values_per_token() // 2
+            if fp8:
+                raise NotImplementedError("an fp8 KV cache for the latent cache of multi-head latent attention "
+                                          "(VDAMD_MLA_LATENT=0 serves it with per-head keys and values)")
+        return KVCacheSpec(num_layers=len(layers), num_kv_heads=heads, head_dim=width,
                            block_size=self.block_size, dtype_bytes=dtype_bytes,
                            sliding_window=max(windows) if windows and min(windows) > 0 else None,
                            extra_bytes_per_block=(self.draft.kv_bytes_per_block(self.block_size, dtype_bytes)
@@ -349,9 +357,9 @@ class ModelRunner:
         self.num_blocks = num_blocks
         self.kv_caches = []
         for attn in self.model.attention_layers():
-            dims = (num_blocks, spec.num_kv_heads, spec.head_dim, self.block_size)
-            k = torch.zeros(ops.k_cache_shape(*dims), dtype=dtype, device=self.device)
-            v = torch.zeros(ops.v_cache_shape(*dims), dtype=dtype, device=self.device)
+            k_shape, v_shape = attn.kv_cache_shapes(num_blocks, self.block_size)
+            k = torch.zeros(k_shape, dtype=dtype, device=self.device)
+            v = torch.zeros(v_shape, dtype=dtype, device=self.device)
             scales = attn.kv_scales if fp8 else None
             if scales is not None:
                 scales = tuple(t.to(self.device) for t in scales)
@@ -1125,8 +1133,13 @@ class ModelRunner:
         if not (cc.use_hip_graph and envs.VDAMD_USE_HIP_GRAPH):
             self.graph_fallback_reason = "disabled (enforce_eager / VDAMD_USE_HIP_GRAPH=0)"
             return
-        kernel_head_dim = self.model.attention_layers()[0].head_dim      # (padded to a kernel size where needed)
-        if not ops.hip_supports_head_dim(kernel_head_dim):
+        first = self.model.attention_layers()[0]
+        kernel_head_dim = first.head_dim      # (padded to a kernel size where needed)
+        if getattr(first, "latent", False):
+            kernel_ok = ops.mla_kernel_ok(first.head_dim, first.v_dim, self.model_config.torch_dtype)
+        else:
+            kernel_ok = ops.hip_supports_head_dim(kernel_head_dim)
+        if not kernel_ok:
             self.graph_fallback_reason = f"no HIP attention kernel for head_dim {kernel_head_dim}"
             logger.info("hipGraph decode capture needs the HIP attention kernels (head_dim 64 or 128): "
                         "running eagerly")
