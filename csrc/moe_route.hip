@@ -94,6 +94,114 @@ __global__ __launch_bounds__(256) void moe_topk_kernel(const T* __restrict__ log
   }
 }
 
+// DeepSeek routing, one wave per token.  Scores: sigmoid of the logits (V3) or their softmax (V2); the CHOICE is
+// made on `score + bias[e]` (bias may be null), optionally inside the `topk_group` best of `n_group` equal groups
+// of experts - a group scored by the sum of its two best choice values (`group_top2` != 0, V3) or by its best one
+// (V2) -; the WEIGHTS are the unbiased scores of the chosen experts, renormalised on request, times `scale`.
+// Ties go to the lowest expert (and group) id.
+template <typename T>
+__global__ __launch_bounds__(256) void moe_topk_grouped_kernel(
+    const T* __restrict__ logits, long stride, const float* __restrict__ bias, float* __restrict__ topw,
+    int* __restrict__ topi, int tokens, int E, int k, int n_group, int topk_group, int sigmoid, int group_top2,
+    int renorm, float scale) {
+  __shared__ float s_choice[4][64 * TOPK_MAX_VPL];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int t = blockIdx.x * 4 + wid;
+  if (t >= tokens) return;                       // (waves of a workgroup share nothing: no barrier below)
+  const T* row = logits + (long)t * stride;
+  float sc[TOPK_MAX_VPL], ch[TOPK_MAX_VPL];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < TOPK_MAX_VPL; ++i) {
+    const int e = lane + 64 * i;
+    sc[i] = e < E ? to_f(row[e]) : -INFINITY;
+    mx = fmaxf(mx, sc[i]);
+  }
+  if (sigmoid) {
+#pragma unroll
+    for (int i = 0; i < TOPK_MAX_VPL; ++i) sc[i] = 1.f / (1.f + __expf(-sc[i]));
+  } else {
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < TOPK_MAX_VPL; ++i) {
+      sc[i] = (lane + 64 * i) < E ? __expf(sc[i] - mx) : 0.f;
+      sum += sc[i];
+    }
+    const float inv_sum = 1.f / wave_sum(sum);
+#pragma unroll
+    for (int i = 0; i < TOPK_MAX_VPL; ++i) sc[i] *= inv_sum;
+  }
+#pragma unroll
+  for (int i = 0; i < TOPK_MAX_VPL; ++i) {
+    const int e = lane + 64 * i;
+    ch[i] = e < E ? sc[i] + (bias != nullptr ? bias[e] : 0.f) : -INFINITY;
+  }
+  if (n_group > 1 && topk_group < n_group) {
+    float* mine = s_choice[wid];
+#pragma unroll
+    for (int i = 0; i < TOPK_MAX_VPL; ++i)
+      if (lane + 64 * i < E) mine[lane + 64 * i] = ch[i];
+    __builtin_amdgcn_wave_barrier();               // (one wave's LDS instructions execute in order: its reads below
+                                                   // see the writes above; the barrier only pins the compiler's order)
+    const int gsize = E / n_group;
+    float gscore = -INFINITY;                      // lane g scores group g
+    if (lane < n_group) {
+      float b1 = -INFINITY, b2 = -INFINITY;
+      for (int j = 0; j < gsize; ++j) {
+        const float v = mine[lane * gsize + j];
+        if (v > b1) { b2 = b1; b1 = v; } else if (v > b2) { b2 = v; }
+      }
+      gscore = group_top2 ? (gsize > 1 ? b1 + b2 : b1) : b1;
+    }
+    unsigned long long keep = 0ull;
+    for (int j = 0; j < topk_group; ++j) {
+      float best = gscore;
+      int best_g = lane < n_group ? lane : 0x7fffffff;
+      if (lane >= n_group || ((keep >> lane) & 1ull)) { best = -INFINITY; best_g = 0x7fffffff; }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int og = __shfl_xor(best_g, o, 64);
+        if (ob > best || (ob == best && og < best_g)) { best = ob; best_g = og; }
+      }
+      if (best_g < 64) keep |= 1ull << best_g;
+    }
+#pragma unroll
+    for (int i = 0; i < TOPK_MAX_VPL; ++i) {
+      const int e = lane + 64 * i;
+      if (e < E && !((keep >> (e / gsize)) & 1ull)) ch[i] = -INFINITY;
+    }
+  }
+  float picked_w = 0.f, wsum = 0.f;
+  int picked_i = 0;
+  for (int j = 0; j < k; ++j) {
+    float best = -INFINITY, best_s = 0.f;
+    int best_e = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < TOPK_MAX_VPL; ++i)
+      if (ch[i] > best) { best = ch[i]; best_s = sc[i]; best_e = lane + 64 * i; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64), os = __shfl_xor(best_s, o, 64);
+      const int oe = __shfl_xor(best_e, o, 64);
+      if (ob > best || (ob == best && oe < best_e)) { best = ob; best_s = os; best_e = oe; }
+    }
+    if (best_e == 0x7fffffff) { best_e = 0; best_s = 0.f; }     // fewer than k eligible experts: weight 0
+    else if ((best_e & 63) == lane) {
+#pragma unroll
+      for (int i = 0; i < TOPK_MAX_VPL; ++i)
+        if (i == (best_e >> 6)) ch[i] = -INFINITY;
+    }
+    if (lane == j) { picked_w = best_s; picked_i = best_e; }
+    wsum += best_s;
+  }
+  if (lane < k) {
+    topw[(long)t * k + lane] = (renorm ? picked_w / (wsum + 1e-20f) : picked_w) * scale;
+    topi[(long)t * k + lane] = picked_i;
+  }
+}
+
 // single workgroup; slots = tokens * k
 __global__ __launch_bounds__(ALIGN_THREADS) void moe_align_kernel(
     const int* __restrict__ topi, int slots, int k, int E, int tile_rows, int expert_start, int local_experts,
@@ -429,6 +537,25 @@ __global__ void moe_combine_add_rms_norm_kernel(T* __restrict__ out, long out_st
 }
 
 }  // namespace
+
+VDAMD_API int vdamd_moe_topk_grouped(const void* logits, long stride, const float* bias, float* topw, int* topi,
+                                     int tokens, int E, int k, int n_group, int topk_group, int sigmoid,
+                                     int group_top2, int renorm, float scale, int dtype, hipStream_t s) {
+  if (tokens <= 0) return 0;
+  if (E < k || E > 64 * TOPK_MAX_VPL || k < 1 || k > TOPK_MAX_K) return -1;
+  if (n_group < 1 || n_group > 64 || E % n_group || topk_group < 1) return -1;
+  const unsigned blocks = (unsigned)((tokens + 3) / 4);
+#define TOPKG(T_)                                                                                              \
+  hipLaunchKernelGGL((moe_topk_grouped_kernel<T_>), dim3(blocks), dim3(256), 0, s, (const T_*)logits, stride, bias, \
+                     topw, topi, tokens, E, k, n_group, topk_group, sigmoid, group_top2, renorm, scale)
+  if (dtype == DT_BF16) TOPKG(bf16_t);
+  else if (dtype == DT_F16) TOPKG(f16_t);
+  else if (dtype == DT_F32) TOPKG(float);
+  else return -2;
+#undef TOPKG
+  HIP_LAUNCH_CHECK();
+  return 0;
+}
 
 VDAMD_API int vdamd_moe_topk(const void* logits, long stride, float* topw, int* topi, int tokens, int E, int k,
                              int renorm, int dtype, hipStream_t s) {

@@ -1071,3 +1071,38 @@ def test_latent_attention_decode_prefill_and_cache_write(dk, dv, hq, bs, dtype):
     got = _hip.mla_attention(q, kc, vc, table, ts, tl, scale, max(lens))
     ref = torch_ref.mla_attention(q.float(), kc.float(), vc.float(), table, ts, tl, scale)
     torch.testing.assert_close(got.float(), ref, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("e,k,n_group,topk_group,v3,renorm", [
+    (256, 8, 8, 4, True, True), (256, 8, 1, 1, True, True), (160, 6, 8, 3, False, False), (64, 6, 1, 1, False, False),
+    (64, 6, 1, 1, False, True), (8, 2, 4, 2, True, True), (128, 1, 1, 1, True, True), (72, 4, 8, 8, False, True)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_grouped_routing_kernel_matches_the_deepseek_formulas(e, k, n_group, topk_group, v3, renorm, dtype):
+    """DeepSeek's routing as one kernel against the same rules written with PyTorch ops: V3 = sigmoid scores,
+    choice on score + bias, groups ranked by the sum of their two best, weights renormalised and scaled; V2 =
+    softmax scores, groups ranked by their best, weights renormalised OR scaled."""
+    from vllm_distributed_amd.ops import hip as _hip
+    torch.manual_seed(e + k)
+    tokens, scale = 37, 2.5
+    logits = (torch.randn(tokens, e, device=DEV) * 2).to(dtype)
+    bias = (torch.randn(e, device=DEV) * 0.3) if v3 else None
+    x = logits.float()
+    scores = x.sigmoid() if v3 else torch.softmax(x, dim=-1)
+    choice = scores + bias if v3 else scores
+    if n_group > 1 and topk_group < n_group:
+        per_group = choice.view(tokens, n_group, e // n_group)
+        gs = per_group.topk(min(2, e // n_group), dim=-1).values.sum(-1) if v3 else per_group.max(-1).values
+        keep = torch.zeros_like(gs, dtype=torch.bool).scatter_(1, gs.topk(topk_group, dim=-1).indices, True)
+        choice = choice.masked_fill(~keep.unsqueeze(-1).expand(-1, -1, e // n_group).reshape(tokens, e), float("-inf"))
+    want_i = choice.topk(k, dim=-1).indices
+    want_w = scores.gather(1, want_i)
+    if renorm:
+        want_w = want_w / (want_w.sum(-1, keepdim=True) + 1e-20)
+    if v3 or not renorm:
+        want_w = want_w * scale
+    got_w, got_i = _hip.moe_topk_grouped(logits, bias, k, n_group, topk_group, v3, v3, renorm,
+                                         scale if (v3 or not renorm) else 1.0)
+    assert got_i.dtype == torch.int32 and got_w.dtype == torch.float32
+    assert torch.equal(got_i.long().sort(-1).values, want_i.sort(-1).values)
+    order_g, order_w = got_i.long().argsort(-1), want_i.argsort(-1)
+    torch.testing.assert_close(got_w.gather(1, order_g), want_w.gather(1, order_w), rtol=1e-4, atol=1e-6)

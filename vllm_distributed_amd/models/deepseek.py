@@ -180,8 +180,32 @@ class DeepseekMoE(FusedMoE):
                 return topw / (topw.sum(-1, keepdim=True) + 1e-20), topi
         return topw * self.scaling, topi
 
+    def _route_hip(self, logits: torch.Tensor):
+        """``route`` as one kernel (``csrc/moe_route.hip:moe_topk_grouped_kernel``): (weights fp32, experts int32)."""
+        grouped = self.grouped and self.n_group > 1
+        if self.v3:
+            scale, renorm = self.scaling, self.renormalize
+        else:       # V2's own gate renormalises INSTEAD of scaling
+            renorm = self.renormalize and self.top_k > 1
+            scale = 1.0 if renorm else self.scaling
+        bias = self.gate.e_score_correction_bias if self.v3 else None
+        return ops.moe_topk_grouped(logits, bias, self.top_k, self.n_group if grouped else 1,
+                                    self.topk_group if grouped else 1, self.v3, self.v3, renorm, scale)
+
+    def _forward_routed(self, x: torch.Tensor) -> torch.Tensor:
+        """The routed experts' weighted sum (unreduced).  On the GPU: router GEMM, one routing kernel, slot sort +
+        tile table, row gather, two grouped GEMMs with the activation between them, weighted combine."""
+        tile_rows = self._grouped_tile_rows(x) if x.dim() == 2 else 0
+        if not tile_rows or self.num_experts > 512 or self.top_k > 16 or self.n_group > 64:
+            return super().forward(x, reduce=False)
+        topw, topi = self._route_hip(self.router_logits(x))
+        local = self.local_experts if self.expert_parallel else -1
+        src_row, inv, tiles = ops.moe_align_fused(topi, self.num_experts, tile_rows, self.expert_start, local)
+        y = self._experts_grouped(x.index_select(0, src_row), tiles, tile_rows)
+        return ops.moe_combine(y, topw, topi, inv, self.expert_start, local)
+
     def forward(self, x: torch.Tensor, reduce: bool = True, staged: bool = False) -> torch.Tensor:
-        out = super().forward(x, reduce=False)
+        out = self._forward_routed(x)
         if self.shared_experts is not None:
             out = out + self.shared_experts(x, reduce=False)
         if reduce and get_tensor_model_parallel_world_size() > 1:

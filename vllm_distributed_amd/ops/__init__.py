@@ -507,6 +507,11 @@ def moe_topk(logits, k: int, renormalize: bool):
     return _hip.moe_topk(logits, k, renormalize)
 
 
+def moe_topk_grouped(logits, bias, k: int, n_group: int, topk_group: int, sigmoid: bool, group_top2: bool,
+                     renormalize: bool, scale: float):
+    return _hip.moe_topk_grouped(logits, bias, k, n_group, topk_group, sigmoid, group_top2, renormalize, scale)
+
+
 def moe_align_fused(topi, num_experts: int, tile_rows: int, expert_start: int = 0, local_experts: int = -1):
     return _hip.moe_align(topi, num_experts, tile_rows, expert_start, local_experts)
 

@@ -56,6 +56,7 @@ def load() -> ctypes.CDLL:
         "vdamd_moe_route_small": [P, L, I, I, I, I, I, I, I, P, P, P, P, P, I, P, L, P, I, I, I, I, L, P],
         "vdamd_moe_combine": [P, L, P, L, P, P, P, I, I, I, I, I, P, I, P],
         "vdamd_bias_clamped_glu": [P, L, P, L, P, P, P, I, I, I, I, F, F, I, P],
+        "vdamd_moe_topk_grouped": [P, L, P, P, P, I, I, I, I, I, I, I, I, F, I, P],
         "vdamd_mla_attention": [P, L, P, P, P, L, P, P, P, I, P, P, F, I, I, I, I, I, I, I, P],
         "vdamd_mla_cache_write": [P, L, P, P, P, I, I, I, I, I, P],
         "vdamd_moe_combine_add_rms_norm": [P, L, P, L, P, P, P, I, I, I, I, I, P, P, F, I, P],
@@ -944,6 +945,25 @@ def moe_topk(logits: torch.Tensor, k: int, renormalize: bool) -> Tuple[torch.Ten
     topi = torch.empty((t, k), dtype=torch.int32, device=logits.device)
     _check(_LIB.vdamd_moe_topk(logits.data_ptr(), logits.stride(0), topw.data_ptr(), topi.data_ptr(), t, e, k,
                                int(renormalize), _dt(logits), _stream()), "moe_topk")
+    return topw, topi
+
+
+def moe_topk_grouped(logits: torch.Tensor, bias: Optional[torch.Tensor], k: int, n_group: int, topk_group: int,
+                     sigmoid: bool, group_top2: bool, renormalize: bool, scale: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """DeepSeek routing in one launch: scores = sigmoid (V3) or softmax (V2) of ``logits [T, E]``; experts chosen
+    by ``score + bias`` inside the ``topk_group`` best of ``n_group`` groups (a group scored by its two best
+    choices' sum, or by its best); weights = the chosen experts' unbiased scores, renormalised on request, times
+    ``scale``.  Returns ``(weights [T, k] fp32, experts [T, k] int32)``."""
+    assert logits.dim() == 2 and logits.stride(1) == 1 and logits.dtype in _DT
+    t, e = logits.shape
+    assert k <= e <= MOE_MAX_EXPERTS and 1 <= k <= MOE_MAX_TOPK and 1 <= n_group <= 64 and e % n_group == 0
+    assert bias is None or (bias.dtype == torch.float32 and bias.numel() == e and bias.is_contiguous())
+    topw = torch.empty((t, k), dtype=torch.float32, device=logits.device)
+    topi = torch.empty((t, k), dtype=torch.int32, device=logits.device)
+    _check(_LIB.vdamd_moe_topk_grouped(logits.data_ptr(), logits.stride(0), None if bias is None else bias.data_ptr(),
+                                       topw.data_ptr(), topi.data_ptr(), t, e, k, n_group, max(1, topk_group),
+                                       int(sigmoid), int(group_top2), int(renormalize), float(scale), _dt(logits),
+                                       _stream()), "moe_topk_grouped")
     return topw, topi
 
 
