@@ -218,6 +218,58 @@ __global__ void mla_cache_write_kernel(const T* __restrict__ x, long x_stride, T
   }
 }
 
+// Everything between the projections and the attention of one token, in one launch (one workgroup per token):
+//   * RMSNorm of the latent's first RANK values, rotation of its last ROPE values (half-apart pairs, fp32
+//     [cos | sin] table row of the token's position), and the resulting row written into both cache forms;
+//   * the absorbed query assembled per head: q_full[t][h] = [ q_lat[h][t] (RANK) | rotated q[t][h][nope:] (ROPE) ].
+// Replaces a norm, two slice copies, the rotary kernel, two concatenations and the cache write.
+template <typename T>
+__global__ __launch_bounds__(256) void mla_prep_kernel(
+    T* __restrict__ q_full, const T* __restrict__ q, long q_tok_stride, int q_head_stride, int nope,
+    const T* __restrict__ q_lat, long q_lat_head_stride, long q_lat_tok_stride, const T* __restrict__ latent,
+    long latent_stride, const T* __restrict__ norm_w, float eps, const float* __restrict__ cos_sin,
+    const int* __restrict__ positions, T* __restrict__ k_cache, T* __restrict__ v_cache,
+    const int* __restrict__ slot_mapping, int H, int RANK, int ROPE, int block_size) {
+  __shared__ float red[17];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int DK = RANK + ROPE, half = ROPE / 2;
+  const float* cs = cos_sin + (long)positions[t] * ROPE;
+  const T* lat = latent + t * latent_stride;
+  float ss = 0.f;
+  for (int d = tid; d < RANK; d += 256) { const float v = (float)lat[d]; ss += v * v; }
+  const float rinv = rsqrtf(block_sum(ss, red) / (float)RANK + eps);
+  const int slot = slot_mapping != nullptr ? slot_mapping[t] : -1;
+  if (slot >= 0) {
+    const long blk = slot / block_size;
+    const int off = slot % block_size;
+    T* krow = k_cache + (blk * block_size + off) * DK;
+    const long slab = (long)block_size * 16;
+    T* vblk = v_cache + blk * (RANK / 16) * slab + (off >> 3) * 128 + (off & 7);
+    for (int d = tid; d < RANK; d += 256) {
+      const T v = (T)((float)lat[d] * rinv * (float)norm_w[d]);
+      krow[d] = v;
+      vblk[(d >> 4) * slab + (d & 15) * 8] = v;
+    }
+    for (int i = tid; i < half; i += 256) {
+      const float x1 = (float)lat[RANK + i], x2 = (float)lat[RANK + half + i];
+      krow[RANK + i] = (T)(x1 * cs[i] - x2 * cs[half + i]);
+      krow[RANK + half + i] = (T)(x2 * cs[i] + x1 * cs[half + i]);
+    }
+  }
+  T* qo = q_full + (long)t * H * DK;
+  for (int e = tid; e < H * RANK; e += 256) {
+    const int h = e / RANK, d = e - h * RANK;
+    qo[(long)h * DK + d] = q_lat[h * q_lat_head_stride + t * q_lat_tok_stride + d];
+  }
+  for (int e = tid; e < H * half; e += 256) {
+    const int h = e / half, i = e - h * half;
+    const T* qr = q + t * q_tok_stride + (long)h * q_head_stride + nope;
+    const float x1 = (float)qr[i], x2 = (float)qr[half + i];
+    qo[(long)h * DK + RANK + i] = (T)(x1 * cs[i] - x2 * cs[half + i]);
+    qo[(long)h * DK + RANK + half + i] = (T)(x2 * cs[i] + x1 * cs[half + i]);
+  }
+}
+
 template <typename T, int DK, int DV>
 int launch_mla(void* out, long out_stride, void* part_o, void* part_ml, const void* q, long q_stride,
                const void* k_cache, const void* v_cache, const int* block_table, int bt_stride, const int* token_seq,
@@ -288,6 +340,32 @@ VDAMD_API int vdamd_mla_cache_write(const void* x, long x_stride, void* k_cache,
                                                     slot_mapping, DK, DV, block_size);
   else
     return -3;
+  HIP_LAUNCH_CHECK();
+  return 0;
+}
+
+
+// q_full[T][H][RANK + ROPE] and the latent cache rows of T tokens (see mla_prep_kernel).  q[T][H][nope + ROPE]
+// with the given token / head strides; q_lat[H][T][RANK] with the given strides; latent[T][RANK + ROPE];
+// slot_mapping may be null (no cache bound: only q_full is produced).
+VDAMD_API int vdamd_mla_prep(void* q_full, const void* q, long q_tok_stride, int q_head_stride, int nope,
+                             const void* q_lat, long q_lat_head_stride, long q_lat_tok_stride, const void* latent,
+                             long latent_stride, const void* norm_w, float eps, const float* cos_sin,
+                             const int* positions, void* k_cache, void* v_cache, const int* slot_mapping, int T_,
+                             int H, int RANK, int ROPE, int block_size, int dtype, void* stream) {
+  if (T_ <= 0) return 0;
+  if (RANK % 16 || ROPE % 2 || (slot_mapping != nullptr && block_size % 8)) return -1;
+  hipStream_t st = (hipStream_t)stream;
+#define MLA_PREP(T__)                                                                                            \
+  mla_prep_kernel<T__><<<T_, 256, 0, st>>>((T__*)q_full, (const T__*)q, q_tok_stride, q_head_stride, nope,         \
+                                           (const T__*)q_lat, q_lat_head_stride, q_lat_tok_stride,                \
+                                           (const T__*)latent, latent_stride, (const T__*)norm_w, eps, cos_sin,   \
+                                           positions, (T__*)k_cache, (T__*)v_cache, slot_mapping, H, RANK, ROPE,  \
+                                           block_size)
+  if (dtype == DT_BF16) MLA_PREP(bf16_t);
+  else if (dtype == DT_F16) MLA_PREP(f16_t);
+  else return -3;
+#undef MLA_PREP
   HIP_LAUNCH_CHECK();
   return 0;
 }

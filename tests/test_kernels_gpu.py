@@ -1106,3 +1106,36 @@ def test_grouped_routing_kernel_matches_the_deepseek_formulas(e, k, n_group, top
     assert torch.equal(got_i.long().sort(-1).values, want_i.sort(-1).values)
     order_g, order_w = got_i.long().argsort(-1), want_i.argsort(-1)
     torch.testing.assert_close(got_w.gather(1, order_g), want_w.gather(1, order_w), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("h,nope,rank,rope", [(16, 128, 512, 64), (4, 64, 64, 32), (3, 16, 16, 8)])
+def test_latent_attention_prep_kernel_matches_its_parts(h, nope, rank, rope):
+    """Norm of the latent, rotation of the shared key part and of every head's query part, assembly of the
+    absorbed query and the write into both cache forms as one kernel, against the separate PyTorch steps."""
+    from vllm_distributed_amd.ops import hip as _hip
+    torch.manual_seed(rank)
+    t, bs, nblk, dtype = 21, 16, 8, torch.bfloat16
+    qbuf = torch.randn(t, h * (nope + rope) + 8, device=DEV).to(dtype)
+    q = qbuf[:, :h * (nope + rope)].view(t, h, nope + rope)                      # a strided view, as projections give
+    q_lat = torch.randn(h, t, rank, device=DEV).to(dtype)
+    latent = torch.randn(t, rank + rope, device=DEV).to(dtype)
+    w = (1 + 0.1 * torch.randn(rank, device=DEV)).to(dtype)
+    cos_sin = torch_ref.build_cos_sin_cache(rope, 512, 10000.0, None).to(DEV)
+    positions = torch.randint(0, 500, (t,), dtype=torch.int32, device=DEV)
+    slots = torch.randperm(nblk * bs)[:t].int().to(DEV)
+    slots[5] = -1
+    kc = torch.zeros(torch_ref.k_cache_shape(nblk, 1, rank + rope, bs), dtype=dtype, device=DEV)
+    vc = torch.zeros(torch_ref.v_cache_shape(nblk, 1, rank, bs), dtype=dtype, device=DEV)
+    kc_ref, vc_ref = kc.clone(), vc.clone()
+    got = _hip.mla_prep(q, nope, q_lat, latent, w, 1e-6, cos_sin, positions, kc, vc, slots)
+    c = torch_ref.rms_norm(latent[:, :rank].contiguous(), w, 1e-6)
+    q_rot = q[..., nope:].reshape(t, h * rope).clone()
+    k_rot = latent[:, rank:].clone()
+    torch_ref.rotary_embedding(positions, q_rot, k_rot, cos_sin, rope)
+    want = torch.cat([q_lat.transpose(0, 1), q_rot.view(t, h, rope)], dim=-1)
+    torch_ref.mla_cache_write(torch.cat([c, k_rot], dim=-1), kc_ref, vc_ref, slots)
+    torch.testing.assert_close(got.float(), want.float(), rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(kc.float(), kc_ref.float(), rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(vc.float(), vc_ref.float(), rtol=1e-2, atol=1e-2)
+    only_q = _hip.mla_prep(q, nope, q_lat, latent, w, 1e-6, cos_sin, positions, None, None, None)
+    assert torch.equal(only_q, got)

@@ -104,11 +104,20 @@ class MLAAttention(nn.Module):
 
     def _forward_latent(self, positions: torch.Tensor, q: torch.Tensor, latent: torch.Tensor) -> torch.Tensor:
         t, h = q.shape[0], self.num_heads
+        w_uk, w_uv_t = self._absorbed_weights()
+        if ops.mla_prep_ok(q) and self.cos_sin.dtype == torch.float32:
+            # GPU: norm, both rotations, the query's assembly and the cache write are one kernel
+            md = get_forward_context().attn_metadata
+            q_lat = torch.bmm(q[..., :self.nope].transpose(0, 1), w_uk)
+            q_full = ops.mla_prep(q, self.nope, q_lat, latent, self.kv_a_layernorm.weight, self.kv_a_layernorm.eps,
+                                  self.cos_sin, positions, self.attn.k_cache, self.attn.v_cache,
+                                  None if md is None else md.slot_mapping)
+            o_lat = q_full[..., :self.kv_rank].contiguous() if md is None else self.attn.attend(q_full)
+            return torch.bmm(o_lat.transpose(0, 1), w_uv_t).transpose(0, 1).reshape(t, h * self.v_dim)
         c = self.kv_a_layernorm(latent[:, :self.kv_rank].contiguous())
         q_rot = q[..., self.nope:].reshape(t, h * self.rope)
         k_rot = latent[:, self.kv_rank:].contiguous()
         ops.rotary_embedding(positions, q_rot, k_rot, self.cos_sin, self.rope)
-        w_uk, w_uv_t = self._absorbed_weights()
         q_lat = torch.bmm(q[..., :self.nope].transpose(0, 1), w_uk)                  # [h, t, rank]
         q_full = torch.cat([q_lat.transpose(0, 1), q_rot.view(t, h, self.rope)], dim=-1)
         o_lat = self.attn.forward_latent(q_full, torch.cat([c, k_rot], dim=-1))      # [t, h, rank]

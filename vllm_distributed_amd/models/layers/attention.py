@@ -191,6 +191,11 @@ class LatentAttention(Attention):
         if md is None:                          # memory-profiling pass: no cache bound
             return q[..., :self.v_dim].contiguous()
         ops.mla_cache_write(latent, self.k_cache, self.v_cache, md.slot_mapping)
+        return self.attend(q)
+
+    def attend(self, q: torch.Tensor) -> torch.Tensor:
+        """``q[T, H, rank + rope]`` against the cache (this step's rows already written) -> ``[T, H, rank]``."""
+        md = _CTX.attn_metadata
         rows, lens = md.token_rows(_CTX.positions)
         return ops.mla_attention(q, self.k_cache, self.v_cache, md.block_table, rows, lens, self.scale, md.max_seq_len)
 

@@ -596,3 +596,12 @@ def mla_attention(q, k_cache, v_cache, block_table, token_seq, seq_lens, scale, 
     if on_hip:
         return _hip.mla_attention(q, k_cache, v_cache, block_table, token_seq, seq_lens, scale, max_seq_len, out)
     return torch_ref.mla_attention(q, k_cache, v_cache, block_table, token_seq, seq_lens, scale, max_seq_len, out)
+
+
+def mla_prep_ok(x: torch.Tensor) -> bool:
+    """Whether the one-launch query assembly + latent cache write (HIP) takes this tensor."""
+    return _use_hip(x) and x.dtype in (torch.bfloat16, torch.float16)
+
+
+def mla_prep(q, nope, q_lat, latent, norm_weight, eps, cos_sin, positions, k_cache, v_cache, slot_mapping):
+    return _hip.mla_prep(q, nope, q_lat, latent, norm_weight, eps, cos_sin, positions, k_cache, v_cache, slot_mapping)

@@ -59,6 +59,7 @@ def load() -> ctypes.CDLL:
         "vdamd_moe_topk_grouped": [P, L, P, P, P, I, I, I, I, I, I, I, I, F, I, P],
         "vdamd_mla_attention": [P, L, P, P, P, L, P, P, P, I, P, P, F, I, I, I, I, I, I, I, P],
         "vdamd_mla_cache_write": [P, L, P, P, P, I, I, I, I, I, P],
+        "vdamd_mla_prep": [P, P, L, I, I, P, L, L, P, L, P, F, P, P, P, P, P, I, I, I, I, I, I, P],
         "vdamd_moe_combine_add_rms_norm": [P, L, P, L, P, P, P, I, I, I, I, I, P, P, F, I, P],
         "vdamd_fp4a16_gemm": [P, L, P, L, P, P, P, P, I, I, I, I, I, I, P],
         "vdamd_fp4_dequant": [P, P, P, P, I, I, I, P],
@@ -1146,4 +1147,33 @@ def mla_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
         v_cache.data_ptr(), block_table.data_ptr(), block_table.stride(0),
         None if token_seq is None else token_seq.data_ptr(), seq_lens.data_ptr(), float(scale), t, hq, dk, dv, bs,
         splits, _dt(q), _stream()), "mla_attention")
+    return out
+
+
+def mla_prep(q: torch.Tensor, nope: int, q_lat: torch.Tensor, latent: torch.Tensor, norm_weight: torch.Tensor,
+             eps: float, cos_sin: torch.Tensor, positions: torch.Tensor, k_cache: Optional[torch.Tensor],
+             v_cache: Optional[torch.Tensor], slot_mapping: Optional[torch.Tensor]) -> torch.Tensor:
+    """One launch between the projections and the attention of a latent-cache layer: the latent row of every
+    token normalised (first ``rank`` values) and rotated (last ``rope`` values) into both cache forms, and the
+    absorbed query ``[T, H, rank + rope] = [q_lat | rotated q[..., nope:]]`` returned.  ``q [T, H, nope + rope]``
+    and ``q_lat [H, T, rank]`` may be strided views; without a cache (``slot_mapping`` None) only the query is made."""
+    t, h, qd = q.shape
+    rank = q_lat.shape[2]
+    rope = qd - nope
+    assert q.stride(2) == 1 and q_lat.stride(2) == 1 and latent.stride(1) == 1 and latent.shape == (t, rank + rope)
+    assert q_lat.shape == (h, t, rank) and cos_sin.dtype == torch.float32 and cos_sin.shape[1] == rope
+    assert positions.dtype == torch.int32 and norm_weight.dtype == q.dtype == q_lat.dtype == latent.dtype
+    out = torch.empty((t, h, rank + rope), dtype=q.dtype, device=q.device)
+    bs = 8
+    if slot_mapping is not None:
+        bs = k_cache.shape[2]
+        assert k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.shape[3] == rank + rope
+        assert slot_mapping.dtype == torch.int32 and slot_mapping.numel() >= t and k_cache.dtype == q.dtype
+    _check(_LIB.vdamd_mla_prep(out.data_ptr(), q.data_ptr(), q.stride(0), q.stride(1), nope, q_lat.data_ptr(),
+                               q_lat.stride(0), q_lat.stride(1), latent.data_ptr(), latent.stride(0),
+                               norm_weight.data_ptr(), float(eps), cos_sin.data_ptr(), positions.data_ptr(),
+                               None if slot_mapping is None else k_cache.data_ptr(),
+                               None if slot_mapping is None else v_cache.data_ptr(),
+                               None if slot_mapping is None else slot_mapping.data_ptr(), t, h, rank, rope, bs,
+                               _dt(q), _stream()), "mla_prep")
     return out
