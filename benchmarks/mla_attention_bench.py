@@ -26,7 +26,7 @@ def bench(fn, iters=20):
     return a.elapsed_time(b) / iters * 1e3
 
 
-def case(batch, ctx, hq, q_len=1):
+def case(batch, ctx, hq, q_len=1, mode=None):
     nblk = batch * (-(-ctx // BS)) + 1
     kc = (torch.randn(torch_ref.k_cache_shape(nblk, 1, DK, BS), device=dev) * 0.3).bfloat16()
     vc = (torch.randn(torch_ref.v_cache_shape(nblk, 1, DV, BS), device=dev) * 0.3).bfloat16()
@@ -39,20 +39,24 @@ def case(batch, ctx, hq, q_len=1):
         rows = torch.arange(batch, dtype=torch.int32, device=dev).repeat_interleave(q_len)
         lens = (torch.arange(q_len, dtype=torch.int32, device=dev) + ctx - q_len + 1).repeat(batch)
     out = torch.empty(t, hq, DV, dtype=torch.bfloat16, device=dev)
-    us = bench(lambda: _hip.mla_attention(q, kc, vc, table, rows, lens, DK ** -0.5, ctx, out))
+    us = bench(lambda: _hip.mla_attention(q, kc, vc, table, rows, lens, DK ** -0.5, ctx, out, mode=mode))
     unique = batch * ctx * (DK + DV) * 2                      # each cached row once per sequence
-    streamed = int(lens.sum().item()) * (DK + DV) * 2 * (-(-hq // 16))    # ... and as the workgroups request it
+    # ... and once per (query token, 16-head tile): what mode 0 requests from the L2 (modes 1 / 2 a quarter of it)
+    streamed = int(lens.sum().item()) * (DK + DV) * 2 * (-(-hq // 16))
     flops = 2 * int(lens.sum().item()) * hq * (DK + DV)
-    splits = _hip.mla_num_splits(t, -(-hq // 16), ctx)
-    print(f"{'decode ' if q_len == 1 else 'prefill'} B={batch:5d} q={q_len:4d} ctx={ctx:6d} Hq={hq:3d}: {us:9.1f} us  "
-          f"{unique / us / 1e6:6.2f} TB/s of cache  {streamed / us / 1e6:6.2f} TB/s requested  "
-          f"{flops / us / 1e6:7.1f} TF/s  (splits={splits})", flush=True)
+    print(f"{'decode ' if q_len == 1 else 'prefill'} mode={'auto' if mode is None else mode} B={batch:5d} q={q_len:4d} ctx={ctx:6d} Hq={hq:3d}: {us:9.1f} us  "
+          f"{unique / us / 1e6:6.2f} TB/s of cache  {streamed / us / 1e6:6.2f} TB/s per-16-head-tile  "
+          f"{flops / us / 1e6:7.1f} TF/s", flush=True)
 
 
 if __name__ == "__main__":
     for hq in (16, 128):
         for batch, ctx in ((1, 4096), (1, 32768), (8, 4096), (32, 4096), (128, 4096), (256, 1024), (32, 32768)):
             case(batch, ctx, hq)
+            if hq >= 64:
+                case(batch, ctx, hq, mode=0)
     for hq in (16, 128):
-        case(1, 2048, hq, q_len=2048)
-        case(4, 4096, hq, q_len=512)
+        for mode in (None, 0):
+            case(1, 2048, hq, q_len=2048, mode=mode)
+            case(4, 4096, hq, q_len=512, mode=mode)
+            case(1, 32768, hq, q_len=2048, mode=mode)

@@ -179,6 +179,201 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Several query tiles per workgroup over ONE stream of cache fragments.  The kernel above requests every cached
+// row once per 16 query rows; wherever more rows share a sequence, that is the L2's bandwidth, not HBM's:
+//   * BY_TOKEN (prefill chunks, verification): the NQ tiles are NQ consecutive tokens of one sequence - the token
+//     whose position is a multiple of NQ (or the first of its sequence in the step) leads a workgroup, the
+//     workgroups of its followers exit at once; every tile masks with its own causal limit;
+//   * otherwise (decode, many heads per rank): the NQ tiles are NQ head tiles of one token.
+// Same split of the two reductions over the four waves; one wave per SIMD (the NQ accumulator sets and query
+// fragments take the registers the second wave had), all NQ partial score tiles exchanged behind one barrier.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int DK, int DV, int NQ, bool BY_TOKEN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void mla_attention_multi_kernel(
+    T* __restrict__ out, long out_stride, float* __restrict__ part_o, float* __restrict__ part_ml,
+    const T* __restrict__ q, long q_stride, const T* __restrict__ k_cache, const T* __restrict__ v_cache,
+    const int* __restrict__ block_table, int bt_stride, const int* __restrict__ token_seq,
+    const int* __restrict__ seq_lens, float scale_log2e, int T_, int Hq, int block_size, int num_splits) {
+  using V = typename Vec8<T>::type;
+  constexpr int KSTEPS = DK / 32;
+  constexpr int KS = (KSTEPS + 3) / 4;
+  constexpr int VT = DV / 64;
+  // [buffer][wave][tile][half][lane][4]: a lane's f32x4 sits next to its neighbours' (conflict-free b128 accesses)
+  __shared__ float s_part[2][4][NQ][2][64][4];
+
+  const int split = blockIdx.x;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r16 = lane & 15, g4 = lane >> 4;
+  // ---- this workgroup's tiles: (token, first head, visible keys); a tile with 0 keys is absent
+  int tok[NQ], qh0[NQ], slen[NQ];
+  // BY_TOKEN: leaders are (mostly) every NQ-th token, and consecutive workgroup ids go round the 8 XCDs: with
+  // t0 = id they would all land on two of them.  Walk the tokens residue class by residue class instead
+  // (ids 0 .. G-1 -> tokens 0, NQ, 2 NQ, ...; the next G ids -> 1, NQ + 1, ...).
+  int t0 = blockIdx.z;
+  if constexpr (BY_TOKEN) {
+    const int G = (T_ + NQ - 1) / NQ;
+    t0 = (int)(blockIdx.z % G) * NQ + (int)(blockIdx.z / G);
+    if (t0 >= T_) return;
+  }
+  const int seq_row = token_seq != nullptr ? token_seq[t0] : t0;
+  if constexpr (BY_TOKEN) {
+    const int pos0 = seq_lens[t0] - 1;
+    if (t0 > 0 && token_seq[t0 - 1] == seq_row && pos0 % NQ != 0) return;        // a follower: its leader covers it
+    bool live = true;
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+      const int t = t0 + n;
+      live = live && t < T_ && (n == 0 || (token_seq[t] == seq_row && (seq_lens[t] - 1) % NQ != 0));
+      tok[n] = live ? t : t0;
+      qh0[n] = blockIdx.y * 16;
+      slen[n] = live ? seq_lens[t] : 0;
+    }
+  } else {
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+      tok[n] = t0;
+      qh0[n] = (blockIdx.y * NQ + n) * 16;
+      slen[n] = qh0[n] < Hq ? seq_lens[t0] : 0;
+    }
+  }
+  int seq_len = 0;
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) seq_len = max(seq_len, slen[n]);
+  const int* bt_row = block_table + (long)seq_row * bt_stride;
+
+  const int n_groups = (seq_len + 31) >> 5;
+  const int gps = (n_groups + num_splits - 1) / num_splits;
+  const int g_begin = split * gps;
+  const int g_end = min(g_begin + gps, n_groups);
+
+  V qf[NQ][KS];
+  int kstep_off[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) kstep_off[s] = 32 * min(wid * KS + s, KSTEPS - 1) + 8 * g4;
+#pragma unroll
+  for (int n = 0; n < NQ; ++n)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      V z;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) z[j] = (T)0.f;
+      const bool have = wid * KS + s < KSTEPS && slen[n] > 0 && qh0[n] + r16 < Hq;
+      qf[n][s] = have ? ld8<T>(q + tok[n] * q_stride + (long)(qh0[n] + r16) * DK + kstep_off[s]) : z;
+    }
+  f32x4 acc[NQ][VT];
+  float m[NQ], l[NQ];
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) {
+    m[n] = MLA_NEG_BIG;
+    l[n] = 0.f;
+#pragma unroll
+    for (int i = 0; i < VT; ++i) acc[n][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int slab = block_size * 16;
+  struct Frag { V ka[KS], kb[KS], vf[VT]; };
+  auto load = [&](Frag& f, int g) {
+    const int base = g * 32;
+    const int key0 = base + 8 * (r16 >> 2) + (r16 & 3);
+    const int ka = min(key0, seq_len - 1), kb = min(key0 + 4, seq_len - 1);
+    const long ra = ((long)bt_row[ka / block_size] * block_size + (ka % block_size)) * DK;
+    const long rb = ((long)bt_row[kb / block_size] * block_size + (kb % block_size)) * DK;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      f.ka[s] = ld8<T>(k_cache + ra + kstep_off[s]);
+      f.kb[s] = ld8<T>(k_cache + rb + kstep_off[s]);
+    }
+    const int vkey = min(base + 8 * g4, seq_len - 1) & ~7;
+    const long vo = (long)bt_row[vkey / block_size] * (DV / 16) * slab + ((vkey % block_size) >> 3) * 128 + 8 * r16;
+#pragma unroll
+    for (int i = 0; i < VT; ++i) f.vf[i] = ld8<T>(v_cache + vo + (long)(wid * VT + i) * slab);
+  };
+
+  Frag cur, nxt;
+  if (g_begin < g_end) load(cur, g_begin);
+  for (int g = g_begin; g < g_end; ++g) {
+    load(nxt, min(g + 1, g_end - 1));
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        s0 = mfma16(cur.ka[s], qf[n][s], s0);
+        s1 = mfma16(cur.kb[s], qf[n][s], s1);
+      }
+      *reinterpret_cast<f32x4*>(&s_part[g & 1][wid][n][0][lane][0]) = s0;
+      *reinterpret_cast<f32x4*>(&s_part[g & 1][wid][n][1][lane][0]) = s1;
+    }
+    __syncthreads();
+    const int kidx0 = g * 32 + 8 * g4;
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+      f32x4 s0 = *reinterpret_cast<const f32x4*>(&s_part[g & 1][0][n][0][lane][0]);
+      f32x4 s1 = *reinterpret_cast<const f32x4*>(&s_part[g & 1][0][n][1][lane][0]);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        s0 += *reinterpret_cast<const f32x4*>(&s_part[g & 1][w][n][0][lane][0]);
+        s1 += *reinterpret_cast<const f32x4*>(&s_part[g & 1][w][n][1][lane][0]);
+      }
+      float p[8];
+      float tmax = MLA_NEG_BIG;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float sv = (j < 4 ? s0[j & 3] : s1[j & 3]) * scale_log2e;
+        p[j] = (kidx0 + j < slen[n]) ? sv : MLA_NEG_BIG;
+        tmax = fmaxf(tmax, p[j]);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m[n], tmax);
+      const float alpha = exp2f(m[n] - m_new);
+      float psum = 0.f;
+      V pf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float e = p[j] <= 0.5f * MLA_NEG_BIG ? 0.f : exp2f(p[j] - m_new);
+        psum += e;
+        pf[j] = (T)e;
+      }
+      l[n] = l[n] * alpha + psum;
+      m[n] = m_new;
+#pragma unroll
+      for (int i = 0; i < VT; ++i) {
+        acc[n][i] *= alpha;
+        acc[n][i] = mfma16(cur.vf[i], pf, acc[n][i]);
+      }
+    }
+    cur = nxt;
+  }
+
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) {
+    float lsum = l[n];
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    const int qh = qh0[n] + r16;
+    if (slen[n] <= 0 || qh >= Hq) continue;
+    if (num_splits == 1) {
+      const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+      T* orow = out + tok[n] * out_stride + (long)qh * DV + 4 * g4;
+#pragma unroll
+      for (int i = 0; i < VT; ++i) {
+        typename Vec4<T>::type o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (T)(acc[n][i][r] * inv);
+        *reinterpret_cast<typename Vec4<T>::type*>(orow + 16 * (wid * VT + i)) = o;
+      }
+    } else {
+      const long pidx = ((long)tok[n] * Hq + qh) * num_splits + split;
+#pragma unroll
+      for (int i = 0; i < VT; ++i)
+        *reinterpret_cast<f32x4*>(part_o + pidx * DV + 16 * (wid * VT + i) + 4 * g4) = acc[n][i];
+      if (wid == 0 && g4 == 0) { part_ml[2 * pidx] = m[n]; part_ml[2 * pidx + 1] = lsum; }
+    }
+  }
+}
+
 // Merge of the KV splits: out = sum_s o_s 2^(m_s - M) / sum_s l_s 2^(m_s - M).
 template <typename T, int DV>
 __global__ void mla_reduce_kernel(T* __restrict__ out, long out_stride, const float* __restrict__ part_o,
@@ -273,12 +468,24 @@ __global__ __launch_bounds__(256) void mla_prep_kernel(
 template <typename T, int DK, int DV>
 int launch_mla(void* out, long out_stride, void* part_o, void* part_ml, const void* q, long q_stride,
                const void* k_cache, const void* v_cache, const int* block_table, int bt_stride, const int* token_seq,
-               const int* seq_lens, float scale, int T_, int Hq, int block_size, int num_splits, hipStream_t st) {
-  dim3 grid(num_splits, (Hq + 15) / 16, T_);
-  mla_attention_kernel<T, DK, DV><<<grid, 256, 0, st>>>(
-      (T*)out, out_stride, (float*)part_o, (float*)part_ml, (const T*)q, q_stride, (const T*)k_cache,
-      (const T*)v_cache, block_table, bt_stride, token_seq, seq_lens, scale * 1.4426950408889634f, Hq, block_size,
-      num_splits);
+               const int* seq_lens, float scale, int T_, int Hq, int block_size, int num_splits, int mode,
+               hipStream_t st) {
+  const int q_tiles = (Hq + 15) / 16;
+  const float sl2 = scale * 1.4426950408889634f;
+  constexpr int NQ = 4;
+  if (mode == 1 && token_seq != nullptr) {          // NQ consecutive tokens of a sequence share the cache stream
+    mla_attention_multi_kernel<T, DK, DV, NQ, true><<<dim3(num_splits, q_tiles, T_), 256, 0, st>>>(
+        (T*)out, out_stride, (float*)part_o, (float*)part_ml, (const T*)q, q_stride, (const T*)k_cache,
+        (const T*)v_cache, block_table, bt_stride, token_seq, seq_lens, sl2, T_, Hq, block_size, num_splits);
+  } else if (mode == 2) {                           // NQ head tiles of a token share it
+    mla_attention_multi_kernel<T, DK, DV, NQ, false><<<dim3(num_splits, (q_tiles + NQ - 1) / NQ, T_), 256, 0, st>>>(
+        (T*)out, out_stride, (float*)part_o, (float*)part_ml, (const T*)q, q_stride, (const T*)k_cache,
+        (const T*)v_cache, block_table, bt_stride, token_seq, seq_lens, sl2, T_, Hq, block_size, num_splits);
+  } else {
+    mla_attention_kernel<T, DK, DV><<<dim3(num_splits, q_tiles, T_), 256, 0, st>>>(
+        (T*)out, out_stride, (float*)part_o, (float*)part_ml, (const T*)q, q_stride, (const T*)k_cache,
+        (const T*)v_cache, block_table, bt_stride, token_seq, seq_lens, sl2, Hq, block_size, num_splits);
+  }
   HIP_LAUNCH_CHECK();
   if (num_splits > 1) {
     mla_reduce_kernel<T, DV><<<dim3(Hq, T_), 128, 0, st>>>((T*)out, out_stride, (const float*)part_o,
@@ -292,11 +499,11 @@ template <typename T>
 int dispatch_mla(int DK, int DV, void* out, long out_stride, void* part_o, void* part_ml, const void* q, long q_stride,
                  const void* k_cache, const void* v_cache, const int* block_table, int bt_stride,
                  const int* token_seq, const int* seq_lens, float scale, int T_, int Hq, int block_size,
-                 int num_splits, hipStream_t st) {
+                 int num_splits, int mode, hipStream_t st) {
 #define MLA_CASE(DK_, DV_)                                                                                     \
   if (DK == DK_ && DV == DV_)                                                                                  \
     return launch_mla<T, DK_, DV_>(out, out_stride, part_o, part_ml, q, q_stride, k_cache, v_cache, block_table, \
-                                   bt_stride, token_seq, seq_lens, scale, T_, Hq, block_size, num_splits, st);
+                                   bt_stride, token_seq, seq_lens, scale, T_, Hq, block_size, num_splits, mode, st);
   MLA_CASE(576, 512) MLA_CASE(96, 64) MLA_CASE(320, 256)
 #undef MLA_CASE
   return -4;
@@ -307,11 +514,14 @@ int dispatch_mla(int DK, int DV, void* out, long out_stride, void* part_o, void*
 // out[T][Hq][DV] = softmax(scale * q[T][Hq][DK] . K^T) . V over the latent cache.  token_seq[T] (may be null:
 // token t uses block-table row t) and seq_lens[T] (keys 0 .. seq_lens[t] - 1 are visible to token t).
 // part_o / part_ml: num_splits * T * Hq * (DV | 2) floats when num_splits > 1.
+// mode 0: one workgroup per (token, 16 heads); 1: four consecutive tokens of a sequence per workgroup (needs
+// token_seq; positions inside a sequence must be consecutive); 2: four head tiles of a token per workgroup.
 // Supported (DK, DV): (576, 512) DeepSeek-V2 / V3, (320, 256), (96, 64).
 VDAMD_API int vdamd_mla_attention(void* out, long out_stride, void* part_o, void* part_ml, const void* q,
                                   long q_stride, const void* k_cache, const void* v_cache, const int* block_table,
                                   int bt_stride, const int* token_seq, const int* seq_lens, float scale, int T_,
-                                  int Hq, int DK, int DV, int block_size, int num_splits, int dtype, void* stream) {
+                                  int Hq, int DK, int DV, int block_size, int num_splits, int mode, int dtype,
+                                  void* stream) {
   if (T_ <= 0) return 0;
   if (block_size % 8 || num_splits < 1 || num_splits > MLA_MAX_SPLITS) return -1;
   if (num_splits > 1 && (part_o == nullptr || part_ml == nullptr)) return -2;
@@ -319,10 +529,10 @@ VDAMD_API int vdamd_mla_attention(void* out, long out_stride, void* part_o, void
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16)
     return dispatch_mla<bf16_t>(DK, DV, out, out_stride, part_o, part_ml, q, q_stride, k_cache, v_cache, block_table,
-                                bt_stride, token_seq, seq_lens, scale, T_, Hq, block_size, num_splits, st);
+                                bt_stride, token_seq, seq_lens, scale, T_, Hq, block_size, num_splits, mode, st);
   if (dtype == DT_F16)
     return dispatch_mla<f16_t>(DK, DV, out, out_stride, part_o, part_ml, q, q_stride, k_cache, v_cache, block_table,
-                               bt_stride, token_seq, seq_lens, scale, T_, Hq, block_size, num_splits, st);
+                               bt_stride, token_seq, seq_lens, scale, T_, Hq, block_size, num_splits, mode, st);
   return -3;
 }
 

@@ -1056,21 +1056,27 @@ def test_latent_attention_decode_prefill_and_cache_write(dk, dv, hq, bs, dtype):
     # ---- decode: one query per sequence
     q = torch.randn(len(lens), hq, dk, device=DEV).to(dtype)
     sl = torch.tensor(lens, dtype=torch.int32, device=DEV)
-    got = _hip.mla_attention(q, kc, vc, table, None, sl, scale, max(lens))
     ref = torch_ref.mla_attention(q.float(), kc.float(), vc.float(), table, None, sl, scale)
+    for mode in (None, 0, 2):             # by shape; a workgroup per 16 heads; four head tiles per workgroup
+        got = _hip.mla_attention(q, kc, vc, table, None, sl, scale, max(lens), mode=mode)
+        torch.testing.assert_close(got.float(), ref, rtol=2e-2, atol=2e-2)
+    got = _hip.mla_attention(q, kc, vc, table, None, sl, scale, max(lens), mode=2, splits=1)
     torch.testing.assert_close(got.float(), ref, rtol=2e-2, atol=2e-2)
-    assert _hip.mla_num_splits(len(lens), -(-hq // 16), max(lens)) > 1
-    # ---- prefill: the last 40 tokens of sequence 4 and the last 70 of sequence 5, causal
-    tok_seq, tok_len = [], []
-    for b, n_q in ((4, 40), (5, 70)):
+    assert _hip.mla_num_splits(len(lens), 1, max(lens)) > 1
+    # ---- a mixed step: three decode rows, then the last 41 tokens of sequence 4 and the last 70 of sequence 5,
+    # causal (four consecutive tokens of a sequence share a workgroup: chunks start at odd positions here, and
+    # single-token rows lead a workgroup of their own)
+    tok_seq, tok_len = [0, 1, 3], [lens[0], lens[1], lens[3]]
+    for b, n_q in ((4, 41), (5, 70)):
         tok_seq += [b] * n_q
         tok_len += list(range(lens[b] - n_q + 1, lens[b] + 1))
     ts = torch.tensor(tok_seq, dtype=torch.int32, device=DEV)
     tl = torch.tensor(tok_len, dtype=torch.int32, device=DEV)
     q = torch.randn(len(tok_seq), hq, dk, device=DEV).to(dtype)
-    got = _hip.mla_attention(q, kc, vc, table, ts, tl, scale, max(lens))
     ref = torch_ref.mla_attention(q.float(), kc.float(), vc.float(), table, ts, tl, scale)
-    torch.testing.assert_close(got.float(), ref, rtol=2e-2, atol=2e-2)
+    for mode, splits in ((None, None), (0, None), (1, 3), (2, None)):
+        got = _hip.mla_attention(q, kc, vc, table, ts, tl, scale, max(lens), mode=mode, splits=splits)
+        torch.testing.assert_close(got.float(), ref, rtol=2e-2, atol=2e-2)
 
 
 @pytest.mark.parametrize("e,k,n_group,topk_group,v3,renorm", [

@@ -57,7 +57,7 @@ def load() -> ctypes.CDLL:
         "vdamd_moe_combine": [P, L, P, L, P, P, P, I, I, I, I, I, P, I, P],
         "vdamd_bias_clamped_glu": [P, L, P, L, P, P, P, I, I, I, I, F, F, I, P],
         "vdamd_moe_topk_grouped": [P, L, P, P, P, I, I, I, I, I, I, I, I, F, I, P],
-        "vdamd_mla_attention": [P, L, P, P, P, L, P, P, P, I, P, P, F, I, I, I, I, I, I, I, P],
+        "vdamd_mla_attention": [P, L, P, P, P, L, P, P, P, I, P, P, F, I, I, I, I, I, I, I, I, P],
         "vdamd_mla_cache_write": [P, L, P, P, P, I, I, I, I, I, P],
         "vdamd_mla_prep": [P, P, L, I, I, P, L, L, P, L, P, F, P, P, P, P, P, I, I, I, I, I, I, P],
         "vdamd_moe_combine_add_rms_norm": [P, L, P, L, P, P, P, I, I, I, I, I, P, P, F, I, P],
@@ -1121,9 +1121,13 @@ def mla_num_splits(tokens: int, q_tiles: int, max_seq_len: int) -> int:
 
 def mla_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_table: torch.Tensor,
                   token_seq: Optional[torch.Tensor], seq_lens: torch.Tensor, scale: float, max_seq_len: int,
-                  out: Optional[torch.Tensor] = None, splits: Optional[int] = None) -> torch.Tensor:
+                  out: Optional[torch.Tensor] = None, splits: Optional[int] = None,
+                  mode: Optional[int] = None) -> torch.Tensor:
     """``q[T, Hq, DK]`` against the latent cache -> ``[T, Hq, DV]``; token ``t`` reads block-table row
-    ``token_seq[t]`` (``t`` itself when None) and sees keys ``0 .. seq_lens[t] - 1``."""
+    ``token_seq[t]`` (``t`` itself when None) and sees keys ``0 .. seq_lens[t] - 1``.  ``mode`` (default: by
+    shape): 0 = a workgroup per (token, 16 heads); 1 = four consecutive tokens of a sequence per workgroup
+    (steps with ``token_seq``: prefill chunks, verification - the tokens of a sequence must be adjacent rows at
+    consecutive positions); 2 = four head tiles of a token per workgroup (64 heads per rank and more)."""
     t, hq, dk = q.shape
     dv = v_cache.shape[2] * v_cache.shape[4]
     bs = k_cache.shape[2]
@@ -1135,8 +1139,12 @@ def mla_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
     if out is None:
         out = torch.empty((t, hq, dv), dtype=q.dtype, device=q.device)
     assert out.stride(2) == 1 and out.stride(1) == dv
+    q_tiles = -(-hq // 16)
+    if mode is None:
+        # (four head tiles per workgroup need enough workgroups left to fill the chip)
+        mode = 1 if token_seq is not None else (2 if q_tiles >= 4 and t * q_tiles >= 128 else 0)
     if splits is None:
-        splits = mla_num_splits(t, -(-hq // 16), max_seq_len)
+        splits = mla_num_splits(-(-t // 4) if mode == 1 else t, -(-q_tiles // 4) if mode == 2 else q_tiles, max_seq_len)
     part_o = part_ml = None
     if splits > 1:
         part_o = torch.empty((t * hq * splits, dv), dtype=torch.float32, device=q.device)
@@ -1146,7 +1154,7 @@ def mla_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
         None if part_ml is None else part_ml.data_ptr(), q.data_ptr(), q.stride(0), k_cache.data_ptr(),
         v_cache.data_ptr(), block_table.data_ptr(), block_table.stride(0),
         None if token_seq is None else token_seq.data_ptr(), seq_lens.data_ptr(), float(scale), t, hq, dk, dv, bs,
-        splits, _dt(q), _stream()), "mla_attention")
+        splits, int(mode), _dt(q), _stream()), "mla_attention")
     return out
 
 
