@@ -474,7 +474,8 @@ int launch_mla(void* out, long out_stride, void* part_o, void* part_ml, const vo
   const float sl2 = scale * 1.4426950408889634f;
   constexpr int NQ = 4;
   if (mode == 1 && token_seq != nullptr) {          // NQ consecutive tokens of a sequence share the cache stream
-    mla_attention_multi_kernel<T, DK, DV, NQ, true><<<dim3(num_splits, q_tiles, T_), 256, 0, st>>>(
+    // (ids walk the tokens residue class by residue class: (T_ + NQ - 1) / NQ ids per class)
+    mla_attention_multi_kernel<T, DK, DV, NQ, true><<<dim3(num_splits, q_tiles, (T_ + NQ - 1) / NQ * NQ), 256, 0, st>>>(
         (T*)out, out_stride, (float*)part_o, (float*)part_ml, (const T*)q, q_stride, (const T*)k_cache,
         (const T*)v_cache, block_table, bt_stride, token_seq, seq_lens, sl2, T_, Hq, block_size, num_splits);
   } else if (mode == 2) {                           // NQ head tiles of a token share it

@@ -1067,9 +1067,11 @@ def test_latent_attention_decode_prefill_and_cache_write(dk, dv, hq, bs, dtype):
     # causal (four consecutive tokens of a sequence share a workgroup: chunks start at odd positions here, and
     # single-token rows lead a workgroup of their own)
     tok_seq, tok_len = [0, 1, 3], [lens[0], lens[1], lens[3]]
-    for b, n_q in ((4, 41), (5, 70)):
+    # (114 rows; row 111 sits at a position that is a multiple of four: the leader with the highest workgroup id)
+    for b, n_q, first_pos in ((4, 41, lens[4] - 41), (5, 70, 1429)):
         tok_seq += [b] * n_q
-        tok_len += list(range(lens[b] - n_q + 1, lens[b] + 1))
+        tok_len += list(range(first_pos + 1, first_pos + n_q + 1))
+    assert len(tok_seq) == 114 and (tok_len[111] - 1) % 4 == 0
     ts = torch.tensor(tok_seq, dtype=torch.int32, device=DEV)
     tl = torch.tensor(tok_len, dtype=torch.int32, device=DEV)
     q = torch.randn(len(tok_seq), hq, dk, device=DEV).to(dtype)
