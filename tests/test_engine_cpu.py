@@ -609,6 +609,62 @@ def test_image_prompts_prefix_cache_preemption_and_refusals():
     plain.shutdown()
 
 
+def test_medusa_heads_draft_every_position_from_one_hidden_state(tmp_path):
+    """Medusa: head i reads the target's hidden state at a request's last kept position and names the token
+    i + 2 places on.  Pinned with heads whose residual block is silent and whose LM head is the target's with its
+    rows permuted: the target's own pick there is the token it just sampled, ``s``, so head i must draft
+    ``inverse_permutation_i[s]``.  The checkpoint is written under the Medusa repository's tensor names.
+    (No Medusa fixtures ship with the reference: parity with other implementations is unpinned.)"""
+    import json
+    import torch
+    from safetensors.torch import save_file
+    from vllm_distributed_amd import LLM, SamplingParams
+    kw = dict(model="llama-tiny", device="cpu", dtype="float32", max_model_len=256, num_gpu_blocks_override=128,
+              max_num_seqs=8, load_format="dummy")
+    prompts = [{"prompt_token_ids": [3, 9, 4, 7, 11, 5] * 6}, {"prompt_token_ids": list(range(20, 60))},
+               {"prompt_token_ids": [5, 6] * 20}]
+    sps = [SamplingParams(temperature=0.0, max_tokens=40, ignore_eos=True),
+           SamplingParams(temperature=0.0, max_tokens=23, ignore_eos=True),
+           SamplingParams(temperature=0.0, max_tokens=30, ignore_eos=True, logprobs=1)]      # one token at a time
+    ref = LLM(**kw)
+    want = [o.outputs[0].token_ids for o in ref.generate(prompts, sps)]
+    lm = ref.engine.core.executor.driver.worker.model_runner.model.lm_head.weight[:512].clone()
+    gen = torch.Generator().manual_seed(3)
+    perms = [torch.randperm(512, generator=gen) for _ in range(4)]
+    tensors = {}
+    for i, perm in enumerate(perms):
+        tensors[f"medusa_head.{i}.0.linear.weight"] = torch.zeros(256, 256)
+        tensors[f"medusa_head.{i}.0.linear.bias"] = torch.zeros(256)
+        tensors[f"medusa_head.{i}.1.weight"] = lm[perm].contiguous()
+    save_file(tensors, str(tmp_path / "model.safetensors"))
+    (tmp_path / "config.json").write_text(json.dumps({"model_type": "medusa", "hidden_size": 256, "vocab_size": 512,
+                                                      "num_heads": 4, "num_hidden_layers": 1, "torch_dtype": "float32"}))
+    # (the bundled target runs on deterministic random weights; the heads come from the file)
+    llm = LLM(speculative_config={"method": "medusa", "model": str(tmp_path), "num_speculative_tokens": 3,
+                                  "load_format": "auto"}, **kw)
+    runner = llm.engine.core.executor.driver.worker.model_runner
+    assert runner.get_kv_cache_spec().extra_bytes_per_block == 0 and runner.draft.k == 3
+    seen = _record_head_proposals(llm)
+    outs = llm.generate(prompts, sps)
+    assert [o.outputs[0].token_ids for o in outs] == want
+    inverse = [torch.argsort(p).tolist() for p in perms]
+    full = {o.request_id: list(o.prompt_token_ids) + list(o.outputs[0].token_ids) for o in outs}
+    checked = 0
+    for (rid, pos), drafts in seen.items():
+        if pos >= len(full[rid]):
+            continue
+        s = full[rid][pos]
+        assert drafts == [inverse[i][s] for i in range(len(drafts))], (rid, pos, s, drafts)
+        checked += 1
+    assert checked > 40 and llm.engine.core.scheduler.spec_stats["drafted"] > 0
+    # random heads from a bundled description: lossless all the same
+    rnd = LLM(speculative_config={"method": "medusa", "model": "medusa-llama-tiny", "num_speculative_tokens": 8}, **kw)
+    assert rnd.engine.core.executor.driver.worker.model_runner.draft.k == 4          # as many drafts as heads
+    assert [o.outputs[0].token_ids for o in rnd.generate(prompts, sps)] == want
+    for x in (ref, llm, rnd):
+        x.shutdown()
+
+
 def test_offline_n_best_of_and_beam_search():
     """``LLM.generate`` fans ``n`` / ``best_of`` out into requests that share the prompt; beam search runs
     on one-token requests: width 1 is greedy decoding, beams come back best first and every beam's

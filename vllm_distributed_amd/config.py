@@ -398,7 +398,9 @@ class SpeculativeConfig:
         to the target, with its own KV cache over the same blocks, and proposes greedily;
       * ``eagle``: an EAGLE head (``model``: its checkpoint) drafts from the target's hidden states;
       * ``mtp`` (``deepseek_mtp``): the multi-token-prediction module inside a DeepSeek-V3 checkpoint does
-        the same (``model`` defaults to the target's checkpoint)."""
+        the same (``model`` defaults to the target's checkpoint);
+      * ``medusa``: Medusa heads (``model``: their checkpoint), one per draft position, over the target's
+        last hidden state."""
     method: str = "ngram"
     num_speculative_tokens: int = 4
     prompt_lookup_max: int = 4
@@ -407,7 +409,7 @@ class SpeculativeConfig:
     load_format: Optional[str] = None        # of the draft model; default: the target's
     quantization: Optional[str] = None       # of the draft model
 
-    METHODS = ("ngram", "draft_model", "eagle", "mtp")
+    METHODS = ("ngram", "draft_model", "eagle", "mtp", "medusa")
 
     def __post_init__(self) -> None:
         if self.method in (None, "") or (self.method == "ngram" and self.model):
@@ -415,7 +417,7 @@ class SpeculativeConfig:
         self.method = {"[ngram]": "ngram", "deepseek_mtp": "mtp"}.get(self.method, self.method)
         if self.method not in self.METHODS:
             raise ValueError(f"speculative method {self.method!r} is not supported ({', '.join(self.METHODS)})")
-        if self.method in ("draft_model", "eagle") and not self.model:
+        if self.method in ("draft_model", "eagle", "medusa") and not self.model:
             raise ValueError(f"speculative method {self.method} needs a \"model\"")
         if not 1 <= self.num_speculative_tokens <= 16:
             raise ValueError("num_speculative_tokens must be between 1 and 16")
@@ -429,7 +431,7 @@ class SpeculativeConfig:
 
     @property
     def reads_target_hidden(self) -> bool:
-        return self.method in ("eagle", "mtp")
+        return self.method in ("eagle", "mtp", "medusa")
 
     @classmethod
     def from_value(cls, value) -> Optional["SpeculativeConfig"]:

@@ -48,6 +48,14 @@ def hf_weight_shapes(mc: ModelConfig) -> Dict[str, Tuple[int, ...]]:
 
 
 def _weight_shapes(c: dict, arch: str) -> Dict[str, Tuple[int, ...]]:
+    if arch == "MedusaModel":
+        h = c["hidden_size"]
+        out = {}
+        for i in range(int(c.get("num_heads") or 5)):
+            for j in range(int(c.get("num_hidden_layers") or 1)):
+                out[f"blocks.{i}.layers.{j}.weight"], out[f"blocks.{i}.layers.{j}.bias"] = (h, h), (h,)
+            out[f"lm_heads.{i}.weight"] = (c["vocab_size"], h)
+        return out
     if arch == "LlavaForConditionalGeneration":
         # the decoder's tensors under "language_model.", a CLIP vision tower and the two-layer projector
         text_arch = {"mistral": "MistralForCausalLM", "qwen2": "Qwen2ForCausalLM"}.get(c.get("model_type"), "LlamaForCausalLM")

@@ -62,6 +62,7 @@ _MODELS: Dict[str, Tuple[str, str]] = {
     # draft heads of speculative decoding (never a served model by themselves; worker/draft_model.py)
     "EagleLlamaForCausalLM": ("spec_heads", "EagleLlamaForCausalLM"),
     "DeepSeekMTP": ("spec_heads", "DeepSeekMTP"),
+    "MedusaModel": ("spec_heads", "MedusaModel"),
 }
 
 

@@ -1,6 +1,6 @@
 """Draft heads for speculative decoding that read the TARGET model's hidden states.
 
-Both heads here predict token ``i + 2`` from the pair (embedding of token ``i + 1``, the target's final hidden
+The first two heads here predict token ``i + 2`` from the pair (embedding of token ``i + 1``, the target's final hidden
 state at position ``i``): one cheap pass over a step's tokens yields a first draft per request, and feeding a
 head its own output as the next "hidden state" yields further ones.
 
@@ -13,21 +13,31 @@ head its own output as the next "hidden state" yields further ones.
   ``num_hidden_layers``: ``eh_proj([enorm(embed) ; hnorm(hidden)])`` -> one full decoder layer ->
   ``shared_head.norm`` -> LM head.  Embedding and head are the target's.
 
-vLLM serves both through ``--speculative-config '{"method": "eagle" | "mtp", ...}'``; the reference framework
-reaches them through the vLLM app it launches (/root/reference/src/launch.py:429).  The reference ships no
-fixtures for either: the tests pin these heads against plain PyTorch re-statements of the same formulas.
+* ``MedusaModel`` - Medusa (Cai et al., 2024): ``num_heads`` independent heads over the target's LAST hidden state,
+  head ``i`` = a few residual blocks ``x + SiLU(W x + b)`` and an LM head of its own, predicting token ``i + 2``.
+  No attention, no KV cache, no pass over the step's tokens: all drafts of a request come from one hidden state.
+  Names as vLLM writes them (``blocks.<i>.layers.<j>.{weight,bias}``, ``lm_heads.<i>.weight``) and as the Medusa
+  repository does (``medusa_head.<i>.<j>.linear.*``, ``medusa_head.<i>.<n>.weight`` for the LM head).
+
+vLLM serves them through ``--speculative-config '{"method": "eagle" | "mtp" | "medusa", ...}'``; the reference
+framework reaches them through the vLLM app it launches (/root/reference/src/launch.py:429).  The reference ships no
+fixtures for any: the tests pin these heads against plain PyTorch re-statements of the same formulas.
 """
 from __future__ import annotations
 
 from typing import List, Optional, Tuple
 
+import re
+
 import torch
+import torch.nn as nn
 
 from ..config import VllmConfig
 from .deepseek import DeepseekV3ForCausalLM
 from .layers.attention import RMSNorm
-from .layers.linear import ReplicatedLinear
+from .layers.linear import ParallelLMHead, ReplicatedLinear
 from .llama import LlamaForCausalLM
+from .utils import materialize
 
 
 class EagleLlamaForCausalLM(LlamaForCausalLM):
@@ -121,3 +131,71 @@ class DeepSeekMTP(DeepseekV3ForCausalLM):
         if rest.startswith(("enorm.", "hnorm.", "eh_proj.")):
             return rest
         return f"layers.{self.start_layer}.{rest}"
+
+
+class MedusaModel(nn.Module):
+    optional_parameters = ()
+    packed_quantization = False
+
+    def __init__(self, vllm_config: VllmConfig):
+        super().__init__()
+        mc = vllm_config.model_config
+        cfg, dtype = mc.hf_config, mc.torch_dtype
+        self.cfg = cfg
+        h = int(cfg["hidden_size"])
+        self.num_heads = int(cfg.get("num_heads") or cfg.get("medusa_num_heads") or 5)
+        self.num_blocks = int(cfg.get("num_hidden_layers") or cfg.get("medusa_num_layers") or 1)
+        self.blocks = nn.ModuleList(nn.ModuleList(ReplicatedLinear(h, h, True, dtype, quant=False)
+                                                  for _ in range(self.num_blocks)) for _ in range(self.num_heads))
+        self.lm_heads = nn.ModuleList(ParallelLMHead(int(cfg["vocab_size"]), h, dtype) for _ in range(self.num_heads))
+        self.start_layer = self.end_layer = 0
+        self.missing_optional: List[str] = []
+
+    def rebind_buffers(self) -> None:
+        pass
+
+    def attention_layers(self) -> list:
+        return []
+
+    @torch.inference_mode()
+    def forward(self, hidden: torch.Tensor, heads: int) -> torch.Tensor:
+        """``hidden[R, H]`` (the target's last hidden state per request) -> ``[R, heads]`` greedy draft tokens."""
+        out = []
+        for i in range(min(heads, self.num_heads)):
+            x = hidden
+            for blk in self.blocks[i]:
+                x = x + torch.nn.functional.silu(blk(x))
+            out.append(self.lm_heads[i].greedy_tokens(x))
+        return torch.stack(out, dim=1)
+
+    # ------------------------------------------------------------- weights
+    _ORIGINAL = re.compile(r"^medusa_head\.(\d+)\.(\d+)\.(?:linear\.)?(weight|bias)$")
+
+    def _owns_layer(self, name: str) -> bool:
+        return True
+
+    def map_weight_name(self, name: str) -> Optional[str]:
+        m = self._ORIGINAL.match(name)
+        if m is not None:
+            i, j, what = int(m.group(1)), int(m.group(2)), m.group(3)
+            return f"lm_heads.{i}.{what}" if j >= self.num_blocks else f"blocks.{i}.{j}.{what}"
+        name = name.replace(".layers.", ".") if name.startswith("blocks.") else name
+        if name.startswith(("blocks.", "lm_heads.")):
+            return name
+        return None
+
+    def load_weights(self, weights):
+        params = dict(self.named_parameters())
+        loaded = []
+        for name, w in weights:
+            mapped = self.map_weight_name(name)
+            if mapped is None or mapped not in params:
+                continue
+            p = params[mapped]
+            loader = getattr(p, "weight_loader", None)
+            if loader is None:
+                p.data.copy_(materialize(w))
+            else:
+                loader(p, w, None)
+            loaded.append(mapped)
+        return loaded

@@ -227,6 +227,40 @@ class HiddenStateProposer(DraftProposer):
         return [toks[j, :1 + int(room[j])].tolist() for j in range(r)]
 
 
+class MedusaProposer(HiddenStateProposer):
+    """Medusa heads (``models/spec_heads.py:MedusaModel``): every draft of a request comes from the target's
+    hidden state at its last kept position - no pass over the step's tokens, no cache of its own."""
+
+    def _draft_model_config(self, vllm_config: VllmConfig) -> ModelConfig:
+        dmc = DraftProposer._draft_model_config(self, vllm_config)
+        dmc.hf_config = dict(dmc.hf_config, architectures=["MedusaModel"])
+        return dmc
+
+    def bind_target(self, target: torch.nn.Module) -> None:
+        if int(self.model.cfg["hidden_size"]) != int(target.cfg["hidden_size"]):
+            raise ValueError(f"Medusa heads of width {self.model.cfg['hidden_size']} on a target of width "
+                             f"{target.cfg['hidden_size']}")
+        self.k = min(self.k, self.model.num_heads)
+
+    def kv_bytes_per_block(self, block_size: int, dtype_bytes: int) -> int:
+        return 0
+
+    def allocate_kv(self, num_blocks: int, block_size: int, dtype: torch.dtype, fp8: bool) -> None:
+        self.kv_caches = []
+
+    def run_step_tokens(self, md, shifted_ids, positions, hidden: torch.Tensor) -> torch.Tensor:
+        return hidden
+
+    def propose(self, feats: torch.Tensor, start_pos: np.ndarray, block_table: np.ndarray, num_blocks: np.ndarray,
+                block_size: int, max_model_len: int, to_dev) -> List[List[int]]:
+        r = int(start_pos.shape[0])
+        if r == 0:
+            return []
+        room = np.clip(max_model_len - 2 - start_pos, 0, self.k).astype(np.int64)      # drafts sit at start + 1 ...
+        toks = self.model(feats, self.k).cpu().numpy()
+        return [toks[j, :int(room[j])].tolist() for j in range(r)]
+
+
 def accepted_tails(tokens: np.ndarray, counts: Optional[np.ndarray],
                    drafts: Optional[List[Optional[List[int]]]]) -> Tuple[np.ndarray, np.ndarray]:
     """Per sampled request: the index (into ``tokens``) of the last token the step keeps, and how many

@@ -292,9 +292,10 @@ class ModelRunner:
             self.pp_link = PipelineLink(self.pp, self.device, use_rccl=envs.VDAMD_COMM_BACKEND in ("auto", "rccl"))
         sc = self.vllm_config.speculative_config
         if sc is not None and sc.worker_side:
-            from .draft_model import DraftProposer, HiddenStateProposer
+            from .draft_model import DraftProposer, HiddenStateProposer, MedusaProposer
             if sc.reads_target_hidden:
-                self.draft = HiddenStateProposer(self.vllm_config, self.device)
+                cls = MedusaProposer if sc.method == "medusa" else HiddenStateProposer
+                self.draft = cls(self.vllm_config, self.device)
                 self.draft.bind_target(self.model)
             else:
                 self.draft = DraftProposer(self.vllm_config, self.device)
