@@ -453,6 +453,19 @@ def test_spmd_moe_tensor_and_expert_parallel_sharing_one_gpu(ep):
         assert top in lp_tp and abs(lp_tp[top] - lp_ref[top]) < 0.15, (lp_ref, lp_tp)
 
 
+@pytest.mark.parametrize("ep", [False, True])
+def test_spmd_deepseek_latent_cache_tensor_parallel_sharing_one_gpu(ep):
+    """DeepSeek-V3 routing + multi-head latent attention at TP=2 on the HIP kernels: every rank caches the same
+    latent rows and attends with its half of the heads (absorbed up-projections cut per rank), the grouped
+    routing kernel feeds tensor-sharded or expert-parallel experts; against one rank."""
+    ref = _run_spmd_shared(1, False, model="deepseek-v3-tiny")[0]
+    got = _run_spmd_shared(2, False, model="deepseek-v3-tiny", ep=ep)
+    assert got[0]["tokens"] == got[1]["tokens"]
+    for lp_ref, lp_tp, toks in zip(ref["first_lp"], got[0]["first_lp"], ref["tokens"]):
+        top = str(toks[0])
+        assert top in lp_tp and abs(lp_tp[top] - lp_ref[top]) < 0.2, (lp_ref, lp_tp)
+
+
 def _shared_gpu_env(monkeypatch, **extra):
     env = dict(VLLM_SERVER_PORT=str(get_open_port()), VLLM_RPC_SECRET="test-secret", VLLM_HOST_IP="127.0.0.1",
                VLLM_LOGGING_LEVEL="WARNING", GLOO_SOCKET_IFNAME="lo", PYTHONPATH=ROOT, VDAMD_SHARE_DEVICE="1",
