@@ -106,6 +106,36 @@ def test_llava_with_images_on_gpu_tracks_cpu_reference(tmp_path):
     assert len(outs["cuda"][1].prompt_token_ids) == 4 + 32
 
 
+def test_deepseek_fresh_prompts_attend_in_the_expanded_form(monkeypatch):
+    """Latent cache, three ways for the prompt: fresh prompts expanded to per-head K / V through a scratch
+    cache and the paged prefill kernel (default), the latent kernel for every row, and prompts cut into 96-token
+    chunks (only a prompt's first chunk is fresh; a later step mixes decode rows, chunks behind a cached context
+    and a new prompt).  Same first-token distributions and the same continuation within bf16 noise."""
+    from vllm_distributed_amd import ops
+    prompts = [{"prompt_token_ids": [3 + (7 * i + 5 * j) % 400 for j in range(n)]} for i, n in enumerate((150, 90, 33, 201))]
+    sp = SamplingParams(temperature=0.0, max_tokens=12, ignore_eos=True, logprobs=20)
+    outs = {}
+    for tag, env, extra in (("expanded", "1", {}), ("latent", "0", {}), ("chunked", "1", {"max_num_batched_tokens": 96})):
+        monkeypatch.setenv("VDAMD_MLA_EXPAND_FRESH_PREFILL", env)
+        pstate.destroy_model_parallel()
+        before = dict(ops.attention_calls)
+        llm = LLM(model="deepseek-v3-tiny", dtype="bfloat16", gpu_memory_utilization=0.3, max_model_len=512,
+                  num_gpu_blocks_override=128, max_num_seqs=8, load_format="dummy", **extra)
+        assert getattr(llm.engine.core.executor.driver.worker.model_runner.model.attention_layers()[0], "latent", False)
+        from vllm_distributed_amd.models.deepseek import MLAAttention
+        calls = MLAAttention.fresh_prefills
+        outs[tag] = llm.generate(prompts, sp)
+        assert ops.attention_calls["reference_on_gpu"] == before["reference_on_gpu"]
+        assert (MLAAttention.fresh_prefills > calls) == (env == "1"), tag
+        llm.shutdown()
+        pstate.destroy_model_parallel()
+    for tag in ("latent", "chunked"):
+        for a, b in zip(outs["expanded"], outs[tag]):
+            la, lb = a.outputs[0].logprobs[0], b.outputs[0].logprobs[0]
+            common = set(la) & set(lb)
+            assert len(common) >= 8 and max(abs(la[t] - lb[t]) for t in common) < 0.3, tag
+
+
 def test_window_released_blocks_are_never_read_by_the_kernels():
     """Sliding-window model on the HIP kernels with a pool that only fits because blocks behind the
     window are recycled between the four sequences: tokens must equal a roomy run's (a kernel touching

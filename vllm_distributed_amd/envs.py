@@ -132,6 +132,10 @@ environment_variables: Dict[str, Callable[[], Any]] = {
     # keys and values in front of an ordinary paged cache (the only form for latent widths the kernel
     # is not built for on the GPU).
     "VDAMD_MLA_LATENT": _bool("VDAMD_MLA_LATENT", True),
+    # ... and prompts that start in the step (no cached context) attend in the per-head form on the
+    # LDS-staged prefill kernel, through a scratch cache, when the expanded head size is at most 128
+    # (not DeepSeek-V2 / V3's 192: measured slower there); 0 = the latent kernel for every row.
+    "VDAMD_MLA_EXPAND_FRESH_PREFILL": _bool("VDAMD_MLA_EXPAND_FRESH_PREFILL", True),
     "VDAMD_FUSED_REDUCE_NORM": _bool("VDAMD_FUSED_REDUCE_NORM", True),
     # The rotary + KV-cache kernel sums the K-split partial sums of the q/k/v projection itself (decode-sized batches).
     "VDAMD_FUSED_REDUCE_ROPE": _bool("VDAMD_FUSED_REDUCE_ROPE", True),

@@ -102,6 +102,70 @@ class MLAAttention(nn.Module):
             self._absorbed = (w[:, :self.nope, :].contiguous(), w[:, self.nope:, :].transpose(1, 2).contiguous())
         return self._absorbed
 
+    FRESH_PREFILL_MIN_TOKENS = 64
+    fresh_prefills = 0          # calls of the expanded path in this process (tests and stats read it)
+
+    def _expand_fresh_prefill(self, md) -> bool:
+        # Only where the expanded heads fit the LDS-staged prefill kernel (head size <= 128).  DeepSeek-V2 / V3's
+        # 192-wide keys would pad to 256, which the register-resident prefill kernel serves at ~135 TFLOP/s:
+        # measured on DeepSeek-V2-Lite, 4.1 ms per layer for an 8k prompt against 2.4 ms on the latent kernel
+        # (four tokens per workgroup), so those models stay on the latent kernel for prefill as well.
+        return (bool(envs.VDAMD_MLA_EXPAND_FRESH_PREFILL) and md.num_prefills > 0 and md.prefill_fresh
+                and md.num_prefill_tokens >= self.FRESH_PREFILL_MIN_TOKENS
+                and self._expanded_dim() <= 128 and ops.hip_supports_head_dim(self._expanded_dim()))
+
+    def _expanded_dim(self) -> int:
+        return next((d for d in Attention.KERNEL_HEAD_DIMS if d >= self.qk_dim), self.qk_dim)
+
+    @staticmethod
+    def _fresh_tables(md, positions: torch.Tensor, nd: int, bs: int):
+        """A scratch paged layout for the step's fresh prompts: sequence i gets whole blocks of its own, one after
+        the other.  (block table ``[prefills, blocks]``, slot of every prefill token, number of scratch blocks);
+        computed once per step."""
+        cached = getattr(md, "_fresh_prefill_tables", None)
+        if cached is None:
+            lens = md.seq_lens[nd:].long()
+            nblk = (lens + bs - 1) // bs
+            start = torch.cumsum(nblk, 0) - nblk
+            width = (md.max_prefill_query_len + bs - 1) // bs
+            table = (start[:, None] + torch.arange(width, device=lens.device)[None, :]).to(torch.int32)
+            rows = md.token_rows(positions)[0][nd:].long() - nd
+            slots = (start[rows] * bs + positions[nd:].long()).to(torch.int32)
+            total = (md.num_prefill_tokens + bs - 1) // bs + md.num_prefills
+            cached = md._fresh_prefill_tables = (table, slots, total, {})
+        return cached
+
+    def _fresh_prefill(self, md, positions: torch.Tensor, q: torch.Tensor, latent: torch.Tensor) -> torch.Tensor:
+        """Attention of the step's prefill rows (all of them prompt starts) in the expanded form: per-head
+        ``[k_nope | k_rope]`` and ``v`` from ``kv_b_proj``, written to a scratch cache in the ordinary layout and
+        read back by the paged prefill kernel.  ``q [Tp, H, nope + rope]`` unrotated -> ``[Tp, H * v_dim]``."""
+        tp, h, d = q.shape[0], self.num_heads, self._expanded_dim()
+        nd = md.num_decode_tokens
+        pos = positions[nd:]
+        bs = self.attn.k_cache.shape[2]
+        table, slots, total, scratch = self._fresh_tables(md, positions, nd, bs)
+        key = (h, d, q.dtype)
+        if key not in scratch:
+            # one pair per step, shared by the layers.  Zeroed: a V^T chunk holds 8 keys, and the ones past a
+            # sequence's end are multiplied by probabilities of exactly 0 - which only helps if they are finite
+            scratch[key] = (torch.zeros(ops.k_cache_shape(total, h, d, bs), dtype=q.dtype, device=q.device),
+                            torch.zeros(ops.v_cache_shape(total, h, d, bs), dtype=q.dtype, device=q.device))
+        MLAAttention.fresh_prefills += 1
+        sk, sv = scratch[key]
+        c = self.kv_a_layernorm(latent[:, :self.kv_rank].contiguous())
+        kv = self.kv_b_proj(c).view(tp, h, self.nope + self.v_dim)
+        q_rot = q[..., self.nope:].reshape(tp, h * self.rope)
+        k_rot = latent[:, self.kv_rank:].contiguous()
+        ops.rotary_embedding(pos, q_rot, k_rot, self.cos_sin, self.rope)
+        pad = d - self.qk_dim
+        qp = F.pad(torch.cat([q[..., :self.nope], q_rot.view(tp, h, self.rope)], dim=-1), (0, pad))
+        kp = F.pad(torch.cat([kv[..., :self.nope], k_rot.view(tp, 1, self.rope).expand(tp, h, self.rope)], dim=-1), (0, pad))
+        vp = F.pad(kv[..., self.nope:], (0, d - self.v_dim))
+        ops.reshape_and_cache(kp, vp, sk, sv, slots)
+        out = ops.paged_attention(qp, sk, sv, table, md.prefill_query_start_loc, md.seq_lens[nd:], self.attn.scale,
+                                  md.max_prefill_query_len, md.max_prefill_query_len)
+        return out.view(tp, h, d)[..., :self.v_dim].reshape(tp, h * self.v_dim)
+
     def _forward_latent(self, positions: torch.Tensor, q: torch.Tensor, latent: torch.Tensor) -> torch.Tensor:
         t, h = q.shape[0], self.num_heads
         w_uk, w_uv_t = self._absorbed_weights()
@@ -112,6 +176,19 @@ class MLAAttention(nn.Module):
             q_full = ops.mla_prep(q, self.nope, q_lat, latent, self.kv_a_layernorm.weight, self.kv_a_layernorm.eps,
                                   self.cos_sin, positions, self.attn.k_cache, self.attn.v_cache,
                                   None if md is None else md.slot_mapping)
+            if md is not None and self._expand_fresh_prefill(md):
+                # prompts that start in this step: their keys and values are all in hand, so attention runs in
+                # the per-head form on the LDS-staged prefill kernel (narrow heads only, see
+                # _expand_fresh_prefill); the latent rows above are cached for the steps that follow.  Decode
+                # rows of a mixed step still read the latent cache.
+                nd = md.num_decode_tokens
+                fresh = self._fresh_prefill(md, positions, q[nd:], latent[nd:])
+                if nd == 0:
+                    return fresh
+                o_lat = ops.mla_attention(q_full[:nd], self.attn.k_cache, self.attn.v_cache, md.block_table, None,
+                                          md.seq_lens, self.attn.scale, md.max_decode_seq_len)
+                dec = torch.bmm(o_lat.transpose(0, 1), w_uv_t).transpose(0, 1).reshape(nd, h * self.v_dim)
+                return torch.cat([dec, fresh], dim=0)
             o_lat = q_full[..., :self.kv_rank].contiguous() if md is None else self.attn.attend(q_full)
             return torch.bmm(o_lat.transpose(0, 1), w_uv_t).transpose(0, 1).reshape(t, h * self.v_dim)
         c = self.kv_a_layernorm(latent[:, :self.kv_rank].contiguous())

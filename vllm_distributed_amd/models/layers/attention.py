@@ -34,6 +34,8 @@ class AttentionMetadata:
     max_prefill_query_len: int = 0
     max_decode_seq_len: int = 0
     decode_workspace: Optional[torch.Tensor] = None
+    # every prefill sequence of the step starts at position 0 (no cached context, no earlier chunk)
+    prefill_fresh: bool = False
 
     def token_rows(self, positions: torch.Tensor):
         """Per token of the step: the block-table row it reads (None = its own index: a pure decode batch)

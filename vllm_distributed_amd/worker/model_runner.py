@@ -522,6 +522,7 @@ class ModelRunner:
             pq = p["qsl"][nd:] - p["qsl"][nd]
             md.prefill_query_start_loc = self._to_dev(pq)
             md.max_prefill_query_len = int(n_sched[nd:].max())
+            md.prefill_fresh = bool((p["seq_lens"][nd:] == n_sched[nd:]).all())
         input_ids = self._to_dev(p["input_ids"])
         self._patch_unknown_inputs(input_ids, p)
         positions = self._to_dev(p["positions"])
