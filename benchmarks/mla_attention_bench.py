@@ -26,10 +26,11 @@ def bench(fn, iters=20):
     return a.elapsed_time(b) / iters * 1e3
 
 
-def case(batch, ctx, hq, q_len=1, mode=None):
+def case(batch, ctx, hq, q_len=1, mode=None, kv8=False):
     nblk = batch * (-(-ctx // BS)) + 1
-    kc = (torch.randn(torch_ref.k_cache_shape(nblk, 1, DK, BS), device=dev) * 0.3).bfloat16()
-    vc = (torch.randn(torch_ref.v_cache_shape(nblk, 1, DV, BS), device=dev) * 0.3).bfloat16()
+    cdt = torch.float8_e4m3fn if kv8 else torch.bfloat16
+    kc = (torch.randn(torch_ref.k_cache_shape(nblk, 1, DK, BS), device=dev) * 0.3).to(cdt)
+    vc = (torch.randn(torch_ref.v_cache_shape(nblk, 1, DV, BS), device=dev) * 0.3).to(cdt)
     table = (torch.arange(batch * (-(-ctx // BS)), dtype=torch.int32, device=dev) + 1).view(batch, -1)
     t = batch * q_len
     q = torch.randn(t, hq, DK, device=dev).bfloat16()
@@ -40,11 +41,12 @@ def case(batch, ctx, hq, q_len=1, mode=None):
         lens = (torch.arange(q_len, dtype=torch.int32, device=dev) + ctx - q_len + 1).repeat(batch)
     out = torch.empty(t, hq, DV, dtype=torch.bfloat16, device=dev)
     us = bench(lambda: _hip.mla_attention(q, kc, vc, table, rows, lens, DK ** -0.5, ctx, out, mode=mode))
-    unique = batch * ctx * (DK + DV) * 2                      # each cached row once per sequence
+    width = 1 if kv8 else 2
+    unique = batch * ctx * (DK + DV) * width                  # each cached row once per sequence
     # ... and once per (query token, 16-head tile): what mode 0 requests from the L2 (modes 1 / 2 a quarter of it)
-    streamed = int(lens.sum().item()) * (DK + DV) * 2 * (-(-hq // 16))
+    streamed = int(lens.sum().item()) * (DK + DV) * width * (-(-hq // 16))
     flops = 2 * int(lens.sum().item()) * hq * (DK + DV)
-    print(f"{'decode ' if q_len == 1 else 'prefill'} mode={'auto' if mode is None else mode} B={batch:5d} q={q_len:4d} ctx={ctx:6d} Hq={hq:3d}: {us:9.1f} us  "
+    print(f"{'decode ' if q_len == 1 else 'prefill'} {'e4m3' if kv8 else 'bf16'} mode={'auto' if mode is None else mode} B={batch:5d} q={q_len:4d} ctx={ctx:6d} Hq={hq:3d}: {us:9.1f} us  "
           f"{unique / us / 1e6:6.2f} TB/s of cache  {streamed / us / 1e6:6.2f} TB/s per-16-head-tile  "
           f"{flops / us / 1e6:7.1f} TF/s", flush=True)
 
@@ -55,6 +57,9 @@ if __name__ == "__main__":
             case(batch, ctx, hq)
             if hq >= 64:
                 case(batch, ctx, hq, mode=0)
+    for batch, ctx in ((32, 4096), (128, 4096), (256, 1024), (32, 32768)):
+        case(batch, ctx, 16, kv8=True)
+    case(1, 2048, 16, q_len=2048, kv8=True)
     for hq in (16, 128):
         for mode in (None, 0):
             case(1, 2048, hq, q_len=2048, mode=mode)

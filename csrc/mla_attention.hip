@@ -36,10 +36,66 @@ namespace {
 constexpr float MLA_NEG_BIG = -1.0e30f;
 constexpr int MLA_MAX_SPLITS = 64;
 
-template <typename T, int DK, int DV>
+// An e4m3 cache (one byte per value, same layouts, scale 1: the normalised latent and the rotated key part are
+// O(1) numbers) halves the bytes a decode step streams; fragments are widened in registers on their way in.
+template <typename T>
+__device__ __forceinline__ typename Vec8<T>::type mla_fp8x8_to(uint2 w) {
+  union { uint32_t u[4]; typename Vec8<T>::type v; } r;
+  if constexpr (__is_same(T, bf16_t)) {
+    r.u[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.x, 1.f, false));
+    r.u[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.x, 1.f, true));
+    r.u[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.y, 1.f, false));
+    r.u[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.y, 1.f, true));
+  } else {
+    r.u[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.x, 1.f, false));
+    r.u[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.x, 1.f, true));
+    r.u[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.y, 1.f, false));
+    r.u[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.y, 1.f, true));
+  }
+  // (two wait states behind the packed converts: their results are not safe to read earlier, and the
+  // compiler's hazard table does not know it - see fp8x8_to in attention.hip)
+  asm volatile("s_nop 1" : "+v"(r.u[0]), "+v"(r.u[1]), "+v"(r.u[2]), "+v"(r.u[3]));
+  return r.v;
+}
+
+// 8 consecutive cache values from element offset `off`, as they are loaded (e4m3: 8 bytes, widened only where
+// they are used - a fragment requested one key group ahead must not be waited for at the request)
+template <typename T, bool KV8> struct MlaRaw { using type = typename Vec8<T>::type; };
+template <typename T> struct MlaRaw<T, true> { using type = uint2; };
+
+template <typename T, bool KV8>
+__device__ __forceinline__ typename MlaRaw<T, KV8>::type mla_ld(const void* cache, long off) {
+  if constexpr (KV8) {
+    return *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(cache) + off);
+  } else {
+    return ld8<T>(reinterpret_cast<const T*>(cache) + off);
+  }
+}
+
+template <typename T, bool KV8>
+__device__ __forceinline__ typename Vec8<T>::type mla_widen(typename MlaRaw<T, KV8>::type raw) {
+  if constexpr (KV8) {
+    return mla_fp8x8_to<T>(raw);
+  } else {
+    return raw;
+  }
+}
+
+// one value into the cache at element offset `off`
+template <typename T, bool KV8>
+__device__ __forceinline__ void mla_st(void* cache, long off, float v) {
+  if constexpr (KV8) {
+    const float c = fminf(fmaxf(v, -448.f), 448.f);
+    reinterpret_cast<uint8_t*>(cache)[off] = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(c, 0.f, 0, false) & 0xff);
+  } else {
+    reinterpret_cast<T*>(cache)[off] = (T)v;
+  }
+}
+
+template <typename T, int DK, int DV, bool KV8>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void mla_attention_kernel(
     T* __restrict__ out, long out_stride, float* __restrict__ part_o, float* __restrict__ part_ml,
-    const T* __restrict__ q, long q_stride, const T* __restrict__ k_cache, const T* __restrict__ v_cache,
+    const T* __restrict__ q, long q_stride, const void* __restrict__ k_cache, const void* __restrict__ v_cache,
     const int* __restrict__ block_table, int bt_stride, const int* __restrict__ token_seq,
     const int* __restrict__ seq_lens, float scale_log2e, int Hq, int block_size, int num_splits) {
   using V = typename Vec8<T>::type;
@@ -80,7 +136,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   float m = MLA_NEG_BIG, l = 0.f;
 
   const int slab = block_size * 16;            // elements of one 16-row slab of a V^T block
-  struct Frag { V ka[KS], kb[KS], vf[VT]; };
+  using R = typename MlaRaw<T, KV8>::type;
+  struct Frag { R ka[KS], kb[KS], vf[VT]; };
   auto load = [&](Frag& f, int g) {
     const int base = g * 32;
     // K rows of the two interleaved S^T tiles: tile 0 row i <-> key 8 (i >> 2) + (i & 3), tile 1 the same + 4
@@ -90,14 +147,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const long rb = ((long)bt_row[kb / block_size] * block_size + (kb % block_size)) * DK;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      f.ka[s] = ld8<T>(k_cache + ra + kstep_off[s]);
-      f.kb[s] = ld8<T>(k_cache + rb + kstep_off[s]);
+      f.ka[s] = mla_ld<T, KV8>(k_cache, ra + kstep_off[s]);
+      f.kb[s] = mla_ld<T, KV8>(k_cache, rb + kstep_off[s]);
     }
     // V^T: this lane's 8 keys are base + 8 g4 .. + 7 (inside one block: block_size % 8 == 0)
     const int vkey = min(base + 8 * g4, seq_len - 1) & ~7;
     const long vo = (long)bt_row[vkey / block_size] * (DV / 16) * slab + ((vkey % block_size) >> 3) * 128 + 8 * r16;
 #pragma unroll
-    for (int i = 0; i < VT; ++i) f.vf[i] = ld8<T>(v_cache + vo + (long)(wid * VT + i) * slab);
+    for (int i = 0; i < VT; ++i) f.vf[i] = mla_ld<T, KV8>(v_cache, vo + (long)(wid * VT + i) * slab);
   };
 
   Frag cur, nxt;
@@ -107,8 +164,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      s0 = mfma16(cur.ka[s], qf[s], s0);
-      s1 = mfma16(cur.kb[s], qf[s], s1);
+      s0 = mfma16(mla_widen<T, KV8>(cur.ka[s]), qf[s], s0);
+      s1 = mfma16(mla_widen<T, KV8>(cur.kb[s]), qf[s], s1);
     }
     float* mine = &s_part[g & 1][wid][lane][0];
     *reinterpret_cast<f32x4*>(mine) = s0;
@@ -150,7 +207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int i = 0; i < VT; ++i) {
       acc[i] *= alpha;
-      acc[i] = mfma16(cur.vf[i], pf, acc[i]);
+      acc[i] = mfma16(mla_widen<T, KV8>(cur.vf[i]), pf, acc[i]);
     }
     cur = nxt;
   }
@@ -189,10 +246,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // Same split of the two reductions over the four waves; one wave per SIMD (the NQ accumulator sets and query
 // fragments take the registers the second wave had), all NQ partial score tiles exchanged behind one barrier.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int DK, int DV, int NQ, bool BY_TOKEN>
+template <typename T, int DK, int DV, int NQ, bool BY_TOKEN, bool KV8>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void mla_attention_multi_kernel(
     T* __restrict__ out, long out_stride, float* __restrict__ part_o, float* __restrict__ part_ml,
-    const T* __restrict__ q, long q_stride, const T* __restrict__ k_cache, const T* __restrict__ v_cache,
+    const T* __restrict__ q, long q_stride, const void* __restrict__ k_cache, const void* __restrict__ v_cache,
     const int* __restrict__ block_table, int bt_stride, const int* __restrict__ token_seq,
     const int* __restrict__ seq_lens, float scale_log2e, int T_, int Hq, int block_size, int num_splits) {
   using V = typename Vec8<T>::type;
@@ -272,7 +329,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 
   const int slab = block_size * 16;
-  struct Frag { V ka[KS], kb[KS], vf[VT]; };
+  using R = typename MlaRaw<T, KV8>::type;
+  struct Frag { R ka[KS], kb[KS], vf[VT]; };
   auto load = [&](Frag& f, int g) {
     const int base = g * 32;
     const int key0 = base + 8 * (r16 >> 2) + (r16 & 3);
@@ -281,26 +339,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const long rb = ((long)bt_row[kb / block_size] * block_size + (kb % block_size)) * DK;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      f.ka[s] = ld8<T>(k_cache + ra + kstep_off[s]);
-      f.kb[s] = ld8<T>(k_cache + rb + kstep_off[s]);
+      f.ka[s] = mla_ld<T, KV8>(k_cache, ra + kstep_off[s]);
+      f.kb[s] = mla_ld<T, KV8>(k_cache, rb + kstep_off[s]);
     }
     const int vkey = min(base + 8 * g4, seq_len - 1) & ~7;
     const long vo = (long)bt_row[vkey / block_size] * (DV / 16) * slab + ((vkey % block_size) >> 3) * 128 + 8 * r16;
 #pragma unroll
-    for (int i = 0; i < VT; ++i) f.vf[i] = ld8<T>(v_cache + vo + (long)(wid * VT + i) * slab);
+    for (int i = 0; i < VT; ++i) f.vf[i] = mla_ld<T, KV8>(v_cache, vo + (long)(wid * VT + i) * slab);
   };
 
   Frag cur, nxt;
   if (g_begin < g_end) load(cur, g_begin);
   for (int g = g_begin; g < g_end; ++g) {
     load(nxt, min(g + 1, g_end - 1));
+    V ka[KS], kb[KS], vf[VT];                    // (an e4m3 cache: widened once, shared by the NQ tiles)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      ka[s] = mla_widen<T, KV8>(cur.ka[s]);
+      kb[s] = mla_widen<T, KV8>(cur.kb[s]);
+    }
+#pragma unroll
+    for (int i = 0; i < VT; ++i) vf[i] = mla_widen<T, KV8>(cur.vf[i]);
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        s0 = mfma16(cur.ka[s], qf[n][s], s0);
-        s1 = mfma16(cur.kb[s], qf[n][s], s1);
+        s0 = mfma16(ka[s], qf[n][s], s0);
+        s1 = mfma16(kb[s], qf[n][s], s1);
       }
       *reinterpret_cast<f32x4*>(&s_part[g & 1][wid][n][0][lane][0]) = s0;
       *reinterpret_cast<f32x4*>(&s_part[g & 1][wid][n][1][lane][0]) = s1;
@@ -341,7 +407,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int i = 0; i < VT; ++i) {
         acc[n][i] *= alpha;
-        acc[n][i] = mfma16(cur.vf[i], pf, acc[n][i]);
+        acc[n][i] = mfma16(vf[i], pf, acc[n][i]);
       }
     }
     cur = nxt;
@@ -393,9 +459,9 @@ __global__ void mla_reduce_kernel(T* __restrict__ out, long out_stride, const fl
 }
 
 // One token's latent row into both cache forms.  x[T][DK] (row stride in elements); slot < 0: skipped.
-template <typename T>
-__global__ void mla_cache_write_kernel(const T* __restrict__ x, long x_stride, T* __restrict__ k_cache,
-                                       T* __restrict__ v_cache, const int* __restrict__ slot_mapping, int DK, int DV,
+template <typename T, bool KV8>
+__global__ void mla_cache_write_kernel(const T* __restrict__ x, long x_stride, void* __restrict__ k_cache,
+                                       void* __restrict__ v_cache, const int* __restrict__ slot_mapping, int DK, int DV,
                                        int block_size) {
   const int t = blockIdx.x;
   const int slot = slot_mapping[t];
@@ -403,13 +469,13 @@ __global__ void mla_cache_write_kernel(const T* __restrict__ x, long x_stride, T
   const long blk = slot / block_size;
   const int off = slot % block_size;
   const T* row = x + t * x_stride;
-  T* krow = k_cache + ((long)blk * block_size + off) * DK;
+  const long krow = ((long)blk * block_size + off) * DK;
   const long slab = (long)block_size * 16;
-  T* vblk = v_cache + blk * (DV / 16) * slab + (off >> 3) * 128 + (off & 7);
+  const long vblk = blk * (DV / 16) * slab + (off >> 3) * 128 + (off & 7);
   for (int d = threadIdx.x; d < DK; d += blockDim.x) {
-    const T v = row[d];
-    krow[d] = v;
-    if (d < DV) vblk[(d >> 4) * slab + (d & 15) * 8] = v;
+    const float v = (float)row[d];
+    mla_st<T, KV8>(k_cache, krow + d, v);
+    if (d < DV) mla_st<T, KV8>(v_cache, vblk + (d >> 4) * slab + (d & 15) * 8, v);
   }
 }
 
@@ -418,12 +484,12 @@ __global__ void mla_cache_write_kernel(const T* __restrict__ x, long x_stride, T
 //     [cos | sin] table row of the token's position), and the resulting row written into both cache forms;
 //   * the absorbed query assembled per head: q_full[t][h] = [ q_lat[h][t] (RANK) | rotated q[t][h][nope:] (ROPE) ].
 // Replaces a norm, two slice copies, the rotary kernel, two concatenations and the cache write.
-template <typename T>
+template <typename T, bool KV8>
 __global__ __launch_bounds__(256) void mla_prep_kernel(
     T* __restrict__ q_full, const T* __restrict__ q, long q_tok_stride, int q_head_stride, int nope,
     const T* __restrict__ q_lat, long q_lat_head_stride, long q_lat_tok_stride, const T* __restrict__ latent,
     long latent_stride, const T* __restrict__ norm_w, float eps, const float* __restrict__ cos_sin,
-    const int* __restrict__ positions, T* __restrict__ k_cache, T* __restrict__ v_cache,
+    const int* __restrict__ positions, void* __restrict__ k_cache, void* __restrict__ v_cache,
     const int* __restrict__ slot_mapping, int H, int RANK, int ROPE, int block_size) {
   __shared__ float red[17];
   const int t = blockIdx.x, tid = threadIdx.x;
@@ -437,18 +503,18 @@ __global__ __launch_bounds__(256) void mla_prep_kernel(
   if (slot >= 0) {
     const long blk = slot / block_size;
     const int off = slot % block_size;
-    T* krow = k_cache + (blk * block_size + off) * DK;
+    const long krow = (blk * block_size + off) * DK;
     const long slab = (long)block_size * 16;
-    T* vblk = v_cache + blk * (RANK / 16) * slab + (off >> 3) * 128 + (off & 7);
+    const long vblk = blk * (RANK / 16) * slab + (off >> 3) * 128 + (off & 7);
     for (int d = tid; d < RANK; d += 256) {
-      const T v = (T)((float)lat[d] * rinv * (float)norm_w[d]);
-      krow[d] = v;
-      vblk[(d >> 4) * slab + (d & 15) * 8] = v;
+      const float v = (float)(T)((float)lat[d] * rinv * (float)norm_w[d]);      // rounded as the norm kernel rounds
+      mla_st<T, KV8>(k_cache, krow + d, v);
+      mla_st<T, KV8>(v_cache, vblk + (d >> 4) * slab + (d & 15) * 8, v);
     }
     for (int i = tid; i < half; i += 256) {
       const float x1 = (float)lat[RANK + i], x2 = (float)lat[RANK + half + i];
-      krow[RANK + i] = (T)(x1 * cs[i] - x2 * cs[half + i]);
-      krow[RANK + half + i] = (T)(x2 * cs[i] + x1 * cs[half + i]);
+      mla_st<T, KV8>(k_cache, krow + RANK + i, x1 * cs[i] - x2 * cs[half + i]);
+      mla_st<T, KV8>(k_cache, krow + RANK + half + i, x2 * cs[i] + x1 * cs[half + i]);
     }
   }
   T* qo = q_full + (long)t * H * DK;
@@ -465,7 +531,7 @@ __global__ __launch_bounds__(256) void mla_prep_kernel(
   }
 }
 
-template <typename T, int DK, int DV>
+template <typename T, int DK, int DV, bool KV8>
 int launch_mla(void* out, long out_stride, void* part_o, void* part_ml, const void* q, long q_stride,
                const void* k_cache, const void* v_cache, const int* block_table, int bt_stride, const int* token_seq,
                const int* seq_lens, float scale, int T_, int Hq, int block_size, int num_splits, int mode,
@@ -475,17 +541,17 @@ int launch_mla(void* out, long out_stride, void* part_o, void* part_ml, const vo
   constexpr int NQ = 4;
   if (mode == 1 && token_seq != nullptr) {          // NQ consecutive tokens of a sequence share the cache stream
     // (ids walk the tokens residue class by residue class: (T_ + NQ - 1) / NQ ids per class)
-    mla_attention_multi_kernel<T, DK, DV, NQ, true><<<dim3(num_splits, q_tiles, (T_ + NQ - 1) / NQ * NQ), 256, 0, st>>>(
-        (T*)out, out_stride, (float*)part_o, (float*)part_ml, (const T*)q, q_stride, (const T*)k_cache,
-        (const T*)v_cache, block_table, bt_stride, token_seq, seq_lens, sl2, T_, Hq, block_size, num_splits);
+    mla_attention_multi_kernel<T, DK, DV, NQ, true, KV8><<<dim3(num_splits, q_tiles, (T_ + NQ - 1) / NQ * NQ), 256, 0, st>>>(
+        (T*)out, out_stride, (float*)part_o, (float*)part_ml, (const T*)q, q_stride, k_cache, v_cache, block_table,
+        bt_stride, token_seq, seq_lens, sl2, T_, Hq, block_size, num_splits);
   } else if (mode == 2) {                           // NQ head tiles of a token share it
-    mla_attention_multi_kernel<T, DK, DV, NQ, false><<<dim3(num_splits, (q_tiles + NQ - 1) / NQ, T_), 256, 0, st>>>(
-        (T*)out, out_stride, (float*)part_o, (float*)part_ml, (const T*)q, q_stride, (const T*)k_cache,
-        (const T*)v_cache, block_table, bt_stride, token_seq, seq_lens, sl2, T_, Hq, block_size, num_splits);
+    mla_attention_multi_kernel<T, DK, DV, NQ, false, KV8><<<dim3(num_splits, (q_tiles + NQ - 1) / NQ, T_), 256, 0, st>>>(
+        (T*)out, out_stride, (float*)part_o, (float*)part_ml, (const T*)q, q_stride, k_cache, v_cache, block_table,
+        bt_stride, token_seq, seq_lens, sl2, T_, Hq, block_size, num_splits);
   } else {
-    mla_attention_kernel<T, DK, DV><<<dim3(num_splits, q_tiles, T_), 256, 0, st>>>(
-        (T*)out, out_stride, (float*)part_o, (float*)part_ml, (const T*)q, q_stride, (const T*)k_cache,
-        (const T*)v_cache, block_table, bt_stride, token_seq, seq_lens, sl2, Hq, block_size, num_splits);
+    mla_attention_kernel<T, DK, DV, KV8><<<dim3(num_splits, q_tiles, T_), 256, 0, st>>>(
+        (T*)out, out_stride, (float*)part_o, (float*)part_ml, (const T*)q, q_stride, k_cache, v_cache, block_table,
+        bt_stride, token_seq, seq_lens, sl2, Hq, block_size, num_splits);
   }
   HIP_LAUNCH_CHECK();
   if (num_splits > 1) {
@@ -497,14 +563,20 @@ int launch_mla(void* out, long out_stride, void* part_o, void* part_ml, const vo
 }
 
 template <typename T>
-int dispatch_mla(int DK, int DV, void* out, long out_stride, void* part_o, void* part_ml, const void* q, long q_stride,
-                 const void* k_cache, const void* v_cache, const int* block_table, int bt_stride,
+int dispatch_mla(int DK, int DV, int kv_fp8, void* out, long out_stride, void* part_o, void* part_ml, const void* q,
+                 long q_stride, const void* k_cache, const void* v_cache, const int* block_table, int bt_stride,
                  const int* token_seq, const int* seq_lens, float scale, int T_, int Hq, int block_size,
                  int num_splits, int mode, hipStream_t st) {
-#define MLA_CASE(DK_, DV_)                                                                                     \
-  if (DK == DK_ && DV == DV_)                                                                                  \
-    return launch_mla<T, DK_, DV_>(out, out_stride, part_o, part_ml, q, q_stride, k_cache, v_cache, block_table, \
-                                   bt_stride, token_seq, seq_lens, scale, T_, Hq, block_size, num_splits, mode, st);
+#define MLA_CASE(DK_, DV_)                                                                                        \
+  if (DK == DK_ && DV == DV_) {                                                                                   \
+    if (kv_fp8)                                                                                                   \
+      return launch_mla<T, DK_, DV_, true>(out, out_stride, part_o, part_ml, q, q_stride, k_cache, v_cache,       \
+                                           block_table, bt_stride, token_seq, seq_lens, scale, T_, Hq, block_size, \
+                                           num_splits, mode, st);                                                 \
+    return launch_mla<T, DK_, DV_, false>(out, out_stride, part_o, part_ml, q, q_stride, k_cache, v_cache,        \
+                                          block_table, bt_stride, token_seq, seq_lens, scale, T_, Hq, block_size, \
+                                          num_splits, mode, st);                                                  \
+  }
   MLA_CASE(576, 512) MLA_CASE(96, 64) MLA_CASE(320, 256)
 #undef MLA_CASE
   return -4;
@@ -522,39 +594,40 @@ VDAMD_API int vdamd_mla_attention(void* out, long out_stride, void* part_o, void
                                   long q_stride, const void* k_cache, const void* v_cache, const int* block_table,
                                   int bt_stride, const int* token_seq, const int* seq_lens, float scale, int T_,
                                   int Hq, int DK, int DV, int block_size, int num_splits, int mode, int dtype,
-                                  void* stream) {
+                                  int kv_fp8, void* stream) {
   if (T_ <= 0) return 0;
   if (block_size % 8 || num_splits < 1 || num_splits > MLA_MAX_SPLITS) return -1;
   if (num_splits > 1 && (part_o == nullptr || part_ml == nullptr)) return -2;
   if (q_stride % 8 || out_stride % 4) return -5;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16)
-    return dispatch_mla<bf16_t>(DK, DV, out, out_stride, part_o, part_ml, q, q_stride, k_cache, v_cache, block_table,
-                                bt_stride, token_seq, seq_lens, scale, T_, Hq, block_size, num_splits, mode, st);
+    return dispatch_mla<bf16_t>(DK, DV, kv_fp8, out, out_stride, part_o, part_ml, q, q_stride, k_cache, v_cache,
+                                block_table, bt_stride, token_seq, seq_lens, scale, T_, Hq, block_size, num_splits,
+                                mode, st);
   if (dtype == DT_F16)
-    return dispatch_mla<f16_t>(DK, DV, out, out_stride, part_o, part_ml, q, q_stride, k_cache, v_cache, block_table,
-                               bt_stride, token_seq, seq_lens, scale, T_, Hq, block_size, num_splits, mode, st);
+    return dispatch_mla<f16_t>(DK, DV, kv_fp8, out, out_stride, part_o, part_ml, q, q_stride, k_cache, v_cache,
+                               block_table, bt_stride, token_seq, seq_lens, scale, T_, Hq, block_size, num_splits,
+                               mode, st);
   return -3;
 }
 
+// kv_fp8: the caches hold OCP e4m3 bytes (values saturated at +-448, scale 1) instead of elements of the model type.
 VDAMD_API int vdamd_mla_cache_write(const void* x, long x_stride, void* k_cache, void* v_cache,
                                     const int* slot_mapping, int T_, int DK, int DV, int block_size, int dtype,
-                                    void* stream) {
+                                    int kv_fp8, void* stream) {
   if (T_ <= 0) return 0;
   if (block_size % 8 || DV % 16 || DV > DK) return -1;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DT_BF16)
-    mla_cache_write_kernel<bf16_t><<<T_, 256, 0, st>>>((const bf16_t*)x, x_stride, (bf16_t*)k_cache,
-                                                     (bf16_t*)v_cache, slot_mapping, DK, DV, block_size);
-  else if (dtype == DT_F16)
-    mla_cache_write_kernel<f16_t><<<T_, 256, 0, st>>>((const f16_t*)x, x_stride, (f16_t*)k_cache, (f16_t*)v_cache,
-                                                    slot_mapping, DK, DV, block_size);
-  else
-    return -3;
+#define MLA_CW(T__, KV8__)                                                                                   \
+  mla_cache_write_kernel<T__, KV8__><<<T_, 256, 0, st>>>((const T__*)x, x_stride, k_cache, v_cache, slot_mapping, \
+                                                         DK, DV, block_size)
+  if (dtype == DT_BF16) { if (kv_fp8) MLA_CW(bf16_t, true); else MLA_CW(bf16_t, false); }
+  else if (dtype == DT_F16) { if (kv_fp8) MLA_CW(f16_t, true); else MLA_CW(f16_t, false); }
+  else return -3;
+#undef MLA_CW
   HIP_LAUNCH_CHECK();
   return 0;
 }
-
 
 // q_full[T][H][RANK + ROPE] and the latent cache rows of T tokens (see mla_prep_kernel).  q[T][H][nope + ROPE]
 // with the given token / head strides; q_lat[H][T][RANK] with the given strides; latent[T][RANK + ROPE];
@@ -563,18 +636,18 @@ VDAMD_API int vdamd_mla_prep(void* q_full, const void* q, long q_tok_stride, int
                              const void* q_lat, long q_lat_head_stride, long q_lat_tok_stride, const void* latent,
                              long latent_stride, const void* norm_w, float eps, const float* cos_sin,
                              const int* positions, void* k_cache, void* v_cache, const int* slot_mapping, int T_,
-                             int H, int RANK, int ROPE, int block_size, int dtype, void* stream) {
+                             int H, int RANK, int ROPE, int block_size, int dtype, int kv_fp8, void* stream) {
   if (T_ <= 0) return 0;
   if (RANK % 16 || ROPE % 2 || (slot_mapping != nullptr && block_size % 8)) return -1;
   hipStream_t st = (hipStream_t)stream;
-#define MLA_PREP(T__)                                                                                            \
-  mla_prep_kernel<T__><<<T_, 256, 0, st>>>((T__*)q_full, (const T__*)q, q_tok_stride, q_head_stride, nope,         \
-                                           (const T__*)q_lat, q_lat_head_stride, q_lat_tok_stride,                \
-                                           (const T__*)latent, latent_stride, (const T__*)norm_w, eps, cos_sin,   \
-                                           positions, (T__*)k_cache, (T__*)v_cache, slot_mapping, H, RANK, ROPE,  \
-                                           block_size)
-  if (dtype == DT_BF16) MLA_PREP(bf16_t);
-  else if (dtype == DT_F16) MLA_PREP(f16_t);
+#define MLA_PREP(T__, KV8__)                                                                                     \
+  mla_prep_kernel<T__, KV8__><<<T_, 256, 0, st>>>((T__*)q_full, (const T__*)q, q_tok_stride, q_head_stride, nope,  \
+                                                  (const T__*)q_lat, q_lat_head_stride, q_lat_tok_stride,         \
+                                                  (const T__*)latent, latent_stride, (const T__*)norm_w, eps,     \
+                                                  cos_sin, positions, k_cache, v_cache, slot_mapping, H, RANK,    \
+                                                  ROPE, block_size)
+  if (dtype == DT_BF16) { if (kv_fp8) MLA_PREP(bf16_t, true); else MLA_PREP(bf16_t, false); }
+  else if (dtype == DT_F16) { if (kv_fp8) MLA_PREP(f16_t, true); else MLA_PREP(f16_t, false); }
   else return -3;
 #undef MLA_PREP
   HIP_LAUNCH_CHECK();

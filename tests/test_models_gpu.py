@@ -136,6 +136,29 @@ def test_deepseek_fresh_prompts_attend_in_the_expanded_form(monkeypatch):
             assert len(common) >= 8 and max(abs(la[t] - lb[t]) for t in common) < 0.3, tag
 
 
+def test_deepseek_latent_cache_in_e4m3():
+    """--kv-cache-dtype fp8 with the latent cache: half the bytes per cached token, first-token distributions
+    within fp8 noise of the bf16 cache's, decode from the captured graph."""
+    prompts = [{"prompt_token_ids": [3 + (7 * i + 5 * j) % 400 for j in range(n)]} for i, n in enumerate((150, 40, 97))]
+    sp = SamplingParams(temperature=0.0, max_tokens=10, ignore_eos=True, logprobs=20)
+    outs, per_token = {}, {}
+    for kv in ("auto", "fp8"):
+        pstate.destroy_model_parallel()
+        llm = LLM(model="deepseek-v3-tiny", dtype="bfloat16", gpu_memory_utilization=0.3, max_model_len=512,
+                  num_gpu_blocks_override=128, max_num_seqs=8, load_format="dummy", kv_cache_dtype=kv)
+        runner = llm.engine.core.executor.driver.worker.model_runner
+        per_token[kv] = runner.get_kv_cache_spec().bytes_per_token
+        assert runner.graphs and getattr(runner.model.attention_layers()[0], "latent", False)
+        outs[kv] = llm.generate(prompts, sp)
+        llm.shutdown()
+        pstate.destroy_model_parallel()
+    assert per_token["fp8"] * 2 == per_token["auto"]
+    for a, b in zip(outs["auto"], outs["fp8"]):
+        la, lb = a.outputs[0].logprobs[0], b.outputs[0].logprobs[0]
+        common = set(la) & set(lb)
+        assert len(common) >= 8 and max(abs(la[t] - lb[t]) for t in common) < 0.35
+
+
 def test_window_released_blocks_are_never_read_by_the_kernels():
     """Sliding-window model on the HIP kernels with a pool that only fits because blocks behind the
     window are recycled between the four sequences: tokens must equal a roomy run's (a kernel touching

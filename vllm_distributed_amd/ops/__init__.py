@@ -586,7 +586,7 @@ def mla_kernel_ok(dk: int, dv: int, dtype: torch.dtype) -> bool:
 
 def mla_cache_write(latent, k_cache, v_cache, slot_mapping):
     if _use_hip(latent) and latent.dtype in (torch.bfloat16, torch.float16):
-        return _hip.mla_cache_write(latent, k_cache, v_cache, slot_mapping)
+        return _hip.mla_cache_write(latent, k_cache, v_cache, slot_mapping)      # (the cache may be e4m3)
     return torch_ref.mla_cache_write(latent, k_cache, v_cache, slot_mapping)
 
 

@@ -57,9 +57,9 @@ def load() -> ctypes.CDLL:
         "vdamd_moe_combine": [P, L, P, L, P, P, P, I, I, I, I, I, P, I, P],
         "vdamd_bias_clamped_glu": [P, L, P, L, P, P, P, I, I, I, I, F, F, I, P],
         "vdamd_moe_topk_grouped": [P, L, P, P, P, I, I, I, I, I, I, I, I, F, I, P],
-        "vdamd_mla_attention": [P, L, P, P, P, L, P, P, P, I, P, P, F, I, I, I, I, I, I, I, I, P],
-        "vdamd_mla_cache_write": [P, L, P, P, P, I, I, I, I, I, P],
-        "vdamd_mla_prep": [P, P, L, I, I, P, L, L, P, L, P, F, P, P, P, P, P, I, I, I, I, I, I, P],
+        "vdamd_mla_attention": [P, L, P, P, P, L, P, P, P, I, P, P, F, I, I, I, I, I, I, I, I, I, P],
+        "vdamd_mla_cache_write": [P, L, P, P, P, I, I, I, I, I, I, P],
+        "vdamd_mla_prep": [P, P, L, I, I, P, L, L, P, L, P, F, P, P, P, P, P, I, I, I, I, I, I, I, P],
         "vdamd_moe_combine_add_rms_norm": [P, L, P, L, P, P, P, I, I, I, I, I, P, P, F, I, P],
         "vdamd_fp4a16_gemm": [P, L, P, L, P, P, P, P, I, I, I, I, I, I, P],
         "vdamd_fp4_dequant": [P, P, P, P, I, I, I, P],
@@ -1096,6 +1096,12 @@ def mla_supported(dk: int, dv: int, dtype: torch.dtype) -> bool:
     return (dk, dv) in MLA_KERNEL_DIMS and dtype in (torch.bfloat16, torch.float16)
 
 
+def _mla_fp8(k_cache: torch.Tensor, v_cache: torch.Tensor, dtype: torch.dtype) -> int:
+    """1 when the latent caches hold e4m3 bytes, 0 when elements of the model type."""
+    assert k_cache.dtype == v_cache.dtype and k_cache.dtype in (dtype, torch.float8_e4m3fn), (k_cache.dtype, dtype)
+    return int(k_cache.dtype == torch.float8_e4m3fn)
+
+
 def mla_cache_write(latent: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                     slot_mapping: torch.Tensor) -> None:
     """``latent[T, DK]`` (normalised c_kv | rotated k_rope) into the key-row cache and, its first DV values,
@@ -1104,10 +1110,12 @@ def mla_cache_write(latent: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.
     dv = v_cache.shape[2] * v_cache.shape[4]
     bs = k_cache.shape[2]
     assert latent.stride(1) == 1 and k_cache.shape[1] == 1 and k_cache.shape[3] == dk and k_cache.is_contiguous()
-    assert v_cache.is_contiguous() and v_cache.shape[3] * v_cache.shape[5] == bs and k_cache.dtype == latent.dtype
+    fp8 = _mla_fp8(k_cache, v_cache, latent.dtype)
+    assert v_cache.is_contiguous() and v_cache.shape[3] * v_cache.shape[5] == bs
     assert slot_mapping.dtype == torch.int32 and slot_mapping.numel() >= t
     _check(_LIB.vdamd_mla_cache_write(latent.data_ptr(), latent.stride(0), k_cache.data_ptr(), v_cache.data_ptr(),
-                                      slot_mapping.data_ptr(), t, dk, dv, bs, _dt(latent), _stream()), "mla_cache_write")
+                                      slot_mapping.data_ptr(), t, dk, dv, bs, _dt(latent), fp8, _stream()),
+           "mla_cache_write")
 
 
 def mla_num_splits(tokens: int, q_tiles: int, max_seq_len: int) -> int:
@@ -1154,7 +1162,7 @@ def mla_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
         None if part_ml is None else part_ml.data_ptr(), q.data_ptr(), q.stride(0), k_cache.data_ptr(),
         v_cache.data_ptr(), block_table.data_ptr(), block_table.stride(0),
         None if token_seq is None else token_seq.data_ptr(), seq_lens.data_ptr(), float(scale), t, hq, dk, dv, bs,
-        splits, int(mode), _dt(q), _stream()), "mla_attention")
+        splits, int(mode), _dt(q), _mla_fp8(k_cache, v_cache, q.dtype), _stream()), "mla_attention")
     return out
 
 
@@ -1172,16 +1180,17 @@ def mla_prep(q: torch.Tensor, nope: int, q_lat: torch.Tensor, latent: torch.Tens
     assert q_lat.shape == (h, t, rank) and cos_sin.dtype == torch.float32 and cos_sin.shape[1] == rope
     assert positions.dtype == torch.int32 and norm_weight.dtype == q.dtype == q_lat.dtype == latent.dtype
     out = torch.empty((t, h, rank + rope), dtype=q.dtype, device=q.device)
-    bs = 8
+    bs, fp8 = 8, 0
     if slot_mapping is not None:
         bs = k_cache.shape[2]
         assert k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.shape[3] == rank + rope
-        assert slot_mapping.dtype == torch.int32 and slot_mapping.numel() >= t and k_cache.dtype == q.dtype
+        assert slot_mapping.dtype == torch.int32 and slot_mapping.numel() >= t
+        fp8 = _mla_fp8(k_cache, v_cache, q.dtype)
     _check(_LIB.vdamd_mla_prep(out.data_ptr(), q.data_ptr(), q.stride(0), q.stride(1), nope, q_lat.data_ptr(),
                                q_lat.stride(0), q_lat.stride(1), latent.data_ptr(), latent.stride(0),
                                norm_weight.data_ptr(), float(eps), cos_sin.data_ptr(), positions.data_ptr(),
                                None if slot_mapping is None else k_cache.data_ptr(),
                                None if slot_mapping is None else v_cache.data_ptr(),
                                None if slot_mapping is None else slot_mapping.data_ptr(), t, h, rank, rope, bs,
-                               _dt(q), _stream()), "mla_prep")
+                               _dt(q), fp8, _stream()), "mla_prep")
     return out

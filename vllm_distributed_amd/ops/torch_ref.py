@@ -368,6 +368,11 @@ def mla_cache_write(latent: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.
     valid = slot_mapping[:latent.shape[0]] >= 0
     slots = slot_mapping[:latent.shape[0]][valid].long()
     blk, off = slots // bs, slots % bs
+    if k_cache.dtype == FP8_KV:      # e4m3 cache, scale 1, saturating; index assignment goes through the bytes
+        x = latent[valid].float().clamp_(-FP8_MAX, FP8_MAX).to(FP8_KV).view(torch.uint8)
+        k_cache.view(torch.uint8)[blk, 0, off, :] = x
+        v_cache.view(torch.uint8)[blk, 0, :, off // V_GROUP, :, off % V_GROUP] = x[:, :dv].unflatten(-1, (-1, V_ROWS))
+        return
     x = latent[valid].to(k_cache.dtype)
     k_cache[blk, 0, off, :] = x
     v_cache[blk, 0, :, off // V_GROUP, :, off % V_GROUP] = x[:, :dv].unflatten(-1, (-1, V_ROWS))
@@ -388,9 +393,15 @@ def mla_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
         mine = torch.nonzero(rows == b).flatten()
         n = int(lens[mine].max())
         blocks = block_table[b, :(n + bs - 1) // bs].long()
-        keys = k_cache[blocks, 0].reshape(-1, dk)[:n].float()
+        kb, vb = k_cache, v_cache
+        if k_cache.dtype == FP8_KV:
+            kb, vb = k_cache.view(torch.uint8), v_cache.view(torch.uint8)
+        keys = kb[blocks, 0].reshape(-1, dk)[:n]
         # [blocks, DV/16, bs/8, 16, 8] -> [blocks, bs/8, 8, DV/16, 16] -> [n, DV]
-        vals = v_cache[blocks, 0].permute(0, 2, 4, 1, 3).reshape(-1, dv)[:n].float()
+        vals = vb[blocks, 0].permute(0, 2, 4, 1, 3).reshape(-1, dv)[:n]
+        if k_cache.dtype == FP8_KV:
+            keys, vals = keys.contiguous().view(FP8_KV), vals.contiguous().view(FP8_KV)
+        keys, vals = keys.float(), vals.float()
         s = torch.einsum("thd,nd->thn", q[mine].float(), keys) * scale
         mask = torch.arange(n, device=q.device)[None, None, :] >= lens[mine][:, None, None]
         p = torch.softmax(s.masked_fill(mask, float("-inf")), dim=-1)

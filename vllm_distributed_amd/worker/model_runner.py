@@ -318,9 +318,6 @@ class ModelRunner:
             # one shared latent row per token, held in two layouts: (rank + rope) + rank values, which the
             # spec's "2 x heads x head_dim" states as one head of half that sum
             heads, width = 1, a.kv_values_per_token() // 2
-            if fp8:
-                raise NotImplementedError("an fp8 KV cache for the latent cache of multi-head latent attention "
-                                          "(VDAMD_MLA_LATENT=0 serves it with per-head keys and values)")
         return KVCacheSpec(num_layers=len(layers), num_kv_heads=heads, head_dim=width,
                            block_size=self.block_size, dtype_bytes=dtype_bytes,
                            sliding_window=max(windows) if windows and min(windows) > 0 else None,
