@@ -452,6 +452,8 @@ __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+#define PREFILL_LDS_D 128
+#define PREFILL_LDS_OCC 2
 #define PREFILL_LDS_NAME paged_prefill_lds_kernel
 #define PREFILL_LDS_BIAS 0
 #define PREFILL_LDS_EXTRA_PARAMS
@@ -466,6 +468,48 @@ __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
 #undef PREFILL_LDS_NAME
 #undef PREFILL_LDS_BIAS
 #undef PREFILL_LDS_EXTRA_PARAMS
+#undef PREFILL_LDS_D
+#undef PREFILL_LDS_OCC
+
+// head size 64 (Llama-3.2-1B, gpt-oss, ...): half the registers and LDS of the kernel above
+#define PREFILL_LDS_D 64
+#define PREFILL_LDS_OCC 2
+#define PREFILL_LDS_NAME paged_prefill_lds64_kernel
+#define PREFILL_LDS_BIAS 0
+#define PREFILL_LDS_EXTRA_PARAMS
+#include "attention_prefill_lds.inc"
+#undef PREFILL_LDS_NAME
+#undef PREFILL_LDS_BIAS
+#undef PREFILL_LDS_EXTRA_PARAMS
+#define PREFILL_LDS_NAME paged_prefill_lds64_bias_kernel
+#define PREFILL_LDS_BIAS 1
+#define PREFILL_LDS_EXTRA_PARAMS , const float *__restrict__ sinks, const float *__restrict__ alibi
+#include "attention_prefill_lds.inc"
+#undef PREFILL_LDS_NAME
+#undef PREFILL_LDS_BIAS
+#undef PREFILL_LDS_EXTRA_PARAMS
+#undef PREFILL_LDS_D
+#undef PREFILL_LDS_OCC
+
+// head size 256 (Gemma-2 / 3, padded odd sizes): 128 KB of LDS and ~330 registers, one workgroup per CU
+#define PREFILL_LDS_D 256
+#define PREFILL_LDS_OCC 1
+#define PREFILL_LDS_NAME paged_prefill_lds256_kernel
+#define PREFILL_LDS_BIAS 0
+#define PREFILL_LDS_EXTRA_PARAMS
+#include "attention_prefill_lds.inc"
+#undef PREFILL_LDS_NAME
+#undef PREFILL_LDS_BIAS
+#undef PREFILL_LDS_EXTRA_PARAMS
+#define PREFILL_LDS_NAME paged_prefill_lds256_bias_kernel
+#define PREFILL_LDS_BIAS 1
+#define PREFILL_LDS_EXTRA_PARAMS , const float *__restrict__ sinks, const float *__restrict__ alibi
+#include "attention_prefill_lds.inc"
+#undef PREFILL_LDS_NAME
+#undef PREFILL_LDS_BIAS
+#undef PREFILL_LDS_EXTRA_PARAMS
+#undef PREFILL_LDS_D
+#undef PREFILL_LDS_OCC
 
 template <typename T, int D, bool KV8>
 int launch_decode(void* out, float* ws, const void* q, long q_stride, const void* kc, const void* vc, const int* bt,
@@ -504,8 +548,12 @@ int launch_prefill(void* out, const void* q, long q_stride, const void* kc, cons
                    int window, float softcap, const float* sinks, const float* alibi, hipStream_t s) {
   const float sl2 = scale * 1.4426950408889634f;
   const int tiles = (max_q_len + 127) / 128;
-  if constexpr (D == 128) {
-    if (max_q_len > 32) {      // longer chunks: LDS-staged 32x32 MFMA kernel
+  if constexpr (D == 128 || D == 64 || D == 256) {
+    static const bool lds_kernel = [] {          // VDAMD_PREFILL_LDS=0: measure the fragment-direct kernel instead
+      const char* e = getenv("VDAMD_PREFILL_LDS");
+      return e == nullptr || atoi(e) != 0;
+    }();
+    if (max_q_len > 32 && lds_kernel) {      // longer chunks: LDS-staged 32x32 MFMA kernel
       static const int remap = [] {
         const char* e = getenv("VDAMD_PREFILL_XCD_REMAP");
         return e == nullptr ? 1 : atoi(e);
@@ -513,15 +561,19 @@ int launch_prefill(void* out, const void* q, long q_stride, const void* kc, cons
       const long total = (long)tiles * Hq * num_seqs;
       if (total > (1L << 30)) return -3;
       const int grid = remap ? (int)((total + 7) / 8 * 8) : (int)total;
-      if (sinks != nullptr || alibi != nullptr)
-        hipLaunchKernelGGL((paged_prefill_lds_bias_kernel<T, KV8>), dim3(grid), dim3(256), 0, s, (T*)out,
-                           (const T*)q, q_stride, kc, vc, bt, bt_stride, qsl, seq_lens, sl2, Hq,
-                           Hkv, block_size, out_stride, tiles, (int)total, remap, k_scales, v_scales, window, softcap,
-                           sinks, alibi);
-      else
-        hipLaunchKernelGGL((paged_prefill_lds_kernel<T, KV8>), dim3(grid), dim3(256), 0, s, (T*)out,
-                           (const T*)q, q_stride, kc, vc, bt, bt_stride, qsl, seq_lens, sl2, Hq,
-                           Hkv, block_size, out_stride, tiles, (int)total, remap, k_scales, v_scales, window, softcap);
+#define LDS_LAUNCH(PLAIN, BIAS)                                                                                  \
+  if (sinks != nullptr || alibi != nullptr)                                                                      \
+    hipLaunchKernelGGL((BIAS<T, KV8>), dim3(grid), dim3(256), 0, s, (T*)out, (const T*)q, q_stride, kc, vc, bt,  \
+                       bt_stride, qsl, seq_lens, sl2, Hq, Hkv, block_size, out_stride, tiles, (int)total, remap, \
+                       k_scales, v_scales, window, softcap, sinks, alibi);                                       \
+  else                                                                                                           \
+    hipLaunchKernelGGL((PLAIN<T, KV8>), dim3(grid), dim3(256), 0, s, (T*)out, (const T*)q, q_stride, kc, vc, bt, \
+                       bt_stride, qsl, seq_lens, sl2, Hq, Hkv, block_size, out_stride, tiles, (int)total, remap, \
+                       k_scales, v_scales, window, softcap)
+      if constexpr (D == 128) { LDS_LAUNCH(paged_prefill_lds_kernel, paged_prefill_lds_bias_kernel); }
+      else if constexpr (D == 64) { LDS_LAUNCH(paged_prefill_lds64_kernel, paged_prefill_lds64_bias_kernel); }
+      else { LDS_LAUNCH(paged_prefill_lds256_kernel, paged_prefill_lds256_bias_kernel); }
+#undef LDS_LAUNCH
       HIP_LAUNCH_CHECK();
       return 0;
     }

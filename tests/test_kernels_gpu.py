@@ -395,6 +395,40 @@ def test_attention_score_soft_cap(window):
         torch.testing.assert_close(got2.float(), ref2, rtol=3e-2, atol=3e-2)
 
 
+@pytest.mark.parametrize("d,hq,hkv,bs", [(64, 16, 2, 16), (256, 8, 4, 32), (256, 4, 4, 64)])
+@pytest.mark.parametrize("kv8", [False, True])
+def test_lds_prefill_kernel_at_head_sizes_64_and_256(d, hq, hkv, bs, kv8):
+    """The LDS-staged prefill kernel is built for head sizes 64, 128 and 256: window + soft cap (Gemma-2's
+    combination at 256), sinks + ALiBi (the bias form of the kernel), bf16 and e4m3 caches, full prompts and
+    chunks over a cached prefix, several key tiles per query tile and ragged last tiles."""
+    scale = 1.0 / math.sqrt(d)
+    cases = [(128, 128), (130, 130), (40, 300), (257, 600), (33, 33), (64, 1000)]
+    sls = [c[1] for c in cases]
+    kc, vc, bt = _make_paged(sls, hkv, d, bs)
+    kv_scales = None
+    if kv8:
+        kv_scales = (torch.rand(hkv, device=DEV) + 0.5, torch.rand(hkv, device=DEV) + 0.5)
+        kc, vc = kc.to(torch.float8_e4m3fn), vc.to(torch.float8_e4m3fn)
+    qsl = [0]
+    for ql, _ in cases:
+        qsl.append(qsl[-1] + ql)
+    q = _rand(qsl[-1], hq, d)
+    qsl_t = torch.tensor(qsl, device=DEV, dtype=torch.int32)
+    sl = torch.tensor(sls, device=DEV, dtype=torch.int32)
+    sinks = torch.randn(hq, device=DEV) * 2
+    alibi = torch.tensor([2.0 ** (-8.0 * (i + 1) / hq) for i in range(hq)], device=DEV)
+    plain = torch_ref.paged_attention(q.float(), kc, vc, bt, qsl_t, sl, scale, kv_scales)
+    for window, cap, snk, slopes in ((0, 0.0, None, None), (100, 0.0, None, None), (0, 4.0, None, None),
+                                     (70, 4.0, None, None), (0, 0.0, sinks, None), (0, 0.0, None, alibi),
+                                     (100, 0.0, sinks, alibi)):
+        ref = torch_ref.paged_attention(q.float(), kc, vc, bt, qsl_t, sl, scale, kv_scales, window, cap, snk, slopes)
+        if window or cap or snk is not None or slopes is not None:
+            assert (ref - plain).abs().max().item() > 0.02           # the feature under test changes the result
+        got = ops.paged_attention(q, kc, vc, bt, qsl_t, sl, scale, max(c[0] for c in cases), max(sls),
+                                  kv_scales=kv_scales, window=window, softcap=cap, sinks=snk, alibi_slopes=slopes)
+        torch.testing.assert_close(got.float(), ref, rtol=3e-2, atol=3e-2)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_argmax(dtype):
     logits = _rand(9, 128256, dtype=dtype)

@@ -752,11 +752,14 @@ def test_hot_attention_kernels_fit_the_register_file(tmp_path):
         if scratch:
             spilled[m.group(1)] = scratch
     hot = [k for k in spilled if ("paged_decode_kernel" in k or "paged_prefill_kernel" in k
-                                  or ("paged_prefill_lds_kernel" in k))]
+                                  or "paged_prefill_lds_kernel" in k or "paged_prefill_lds64" in k)]
     assert not hot, {k: spilled[k] for k in hot}
-    # known and accepted: the one-wave decode kernel at head size 256 (not a default path) and the LDS prefill
-    # kernel's sinks / ALiBi instantiation
-    assert all("wave_kernel" in k and "Li256E" in k or "lds_bias_kernel" in k for k in spilled), spilled
+    # known and accepted: the one-wave decode kernel at head size 256 (not a default path), the LDS prefill
+    # kernel's sinks / ALiBi instantiation, and the LDS prefill kernel at head size 256 (it holds the whole
+    # 512-register file and parks a few loop-invariant values; 1.2 - 2.1x the fragment-direct kernel regardless)
+    assert all("wave_kernel" in k and "Li256E" in k or "lds_bias_kernel" in k or "prefill_lds256" in k
+               for k in spilled), spilled
+    assert all(v <= 160 for k, v in spilled.items() if "prefill_lds" in k), spilled
 
 
 def test_eagle_head_checkpoint_in_the_authors_layout(tmp_path):
