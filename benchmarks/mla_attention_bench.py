@@ -1,11 +1,15 @@
 """Latent-cache attention (DeepSeek-V3 widths: 576-wide keys, 512-wide values) on one MI355X: microseconds and
 bytes of cache streamed per second, for decode batches at several context lengths and head counts per rank
 (128 heads = TP 1, 16 = TP 8), and for a prefill chunk.  Run on the GPU box: python benchmarks/mla_attention_bench.py"""
+import os
+import sys
+
 import torch
 
-from vllm_distributed_amd import ops
-from vllm_distributed_amd.ops import hip as _hip
-from vllm_distributed_amd.ops import torch_ref
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vllm_distributed_amd import ops  # noqa: E402
+from vllm_distributed_amd.ops import hip as _hip  # noqa: E402
+from vllm_distributed_amd.ops import torch_ref  # noqa: E402
 
 assert ops.hip_available(), "the HIP kernel library is not built"
 

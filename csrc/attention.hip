@@ -116,8 +116,12 @@ __device__ __forceinline__ void load_kv_group(KVFrag<T, D>& f, const void* __res
 
 // Score capping (Gemma-2): cap * tanh(score / cap) on the natural-log scale; `s2` and the result are
 // scores already multiplied by log2(e).
+// tanh(x) = 1 - 2 / (1 + e^(2x)) with x = s2 * ln2 / cap, so e^(2x) = 2^(s2 * 2 / cap): one exponential and one
+// reciprocal (absolute error ~1e-7 of the cap, far below a bf16 score's spacing) where the library's tanhf is a
+// branchy polynomial.
 __device__ __forceinline__ float soft_cap_log2(float s2, float cap) {
-  const float t = tanhf(s2 * (0.6931471805599453f / cap));
+  const float e = fast_exp2(s2 * (2.f / cap));
+  const float t = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + e);
   return t * (cap * 1.4426950408889634f);
 }
 
@@ -154,14 +158,14 @@ __device__ __forceinline__ void attend_loaded(
     tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m[n], tmax);
-    const float alpha = exp2f(m[n] - m_new);
+    const float alpha = fast_exp2(m[n] - m_new);
     float psum = 0.f;
     V pf;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       // (a row may have no visible key in a group below its window: its running max is still the
       // sentinel then, and the masked scores must not turn into exp2(0))
-      const float e = p[j] <= 0.5f * NEG_BIG ? 0.f : exp2f(p[j] - m_new);
+      const float e = p[j] <= 0.5f * NEG_BIG ? 0.f : fast_exp2(p[j] - m_new);
       psum += e;
       pf[j] = (T)e;
     }
@@ -261,12 +265,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (qi >= nq) continue;
     const float m0 = s_m[0][qi], m1 = s_m[1][qi], m2 = s_m[2][qi], m3 = s_m[3][qi];
     const float mm = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-    const float a0 = exp2f(m0 - mm), a1 = exp2f(m1 - mm), a2 = exp2f(m2 - mm), a3 = exp2f(m3 - mm);
+    const float a0 = fast_exp2(m0 - mm), a1 = fast_exp2(m1 - mm), a2 = fast_exp2(m2 - mm), a3 = fast_exp2(m3 - mm);
     const float o = (s_o[0][qi][d] * a0 + s_o[1][qi][d] * a1 + s_o[2][qi][d] * a2 + s_o[3][qi][d] * a3) * v_scale;
     float lt = s_l[0][qi] * a0 + s_l[1][qi] * a1 + s_l[2][qi] * a2 + s_l[3][qi] * a3;
     const int qh = qh0 + qi;
     if (num_splits == 1) {
-      if (sinks != nullptr) lt += exp2f(sinks[qh] * LOG2E_F - mm);       // (with splits: added by the merge kernel)
+      if (sinks != nullptr) lt += fast_exp2(sinks[qh] * LOG2E_F - mm);       // (with splits: added by the merge kernel)
       out[b * out_stride + (long)qh * D + d] = (T)(lt > 0.f ? o / lt : 0.f);
     } else {
       const long pidx = ((long)b * Hq + qh) * num_splits + split;
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
   lsum += __shfl_xor(lsum, 16, 64);
   lsum += __shfl_xor(lsum, 32, 64);
   if (r16 >= nq) return;
-  if (sinks != nullptr) lsum += exp2f(sinks[qh0 + r16] * LOG2E_F - m[0]);
+  if (sinks != nullptr) lsum += fast_exp2(sinks[qh0 + r16] * LOG2E_F - m[0]);
   const float inv = lsum > 0.f ? v_scale / lsum : 0.f;
   T* orow = out + b * out_stride + (long)(qh0 + r16) * D + 4 * g4;
 #pragma unroll
@@ -345,11 +349,11 @@ __global__ void decode_reduce_kernel(T* __restrict__ out, const float* __restric
   for (int s = 0; s < num_splits; ++s) mm = fmaxf(mm, part_ml[2 * (base + s)]);
   float o = 0.f, lt = 0.f;
   for (int s = 0; s < num_splits; ++s) {
-    const float a = exp2f(part_ml[2 * (base + s)] - mm);
+    const float a = fast_exp2(part_ml[2 * (base + s)] - mm);
     lt += part_ml[2 * (base + s) + 1] * a;
     o += part_o[(base + s) * D + d] * a;
   }
-  if (sinks != nullptr) lt += exp2f(sinks[qh] * LOG2E_F - mm);
+  if (sinks != nullptr) lt += fast_exp2(sinks[qh] * LOG2E_F - mm);
   out[b * out_stride + (long)qh * D + d] = (T)(lt > 0.f ? o / lt : 0.f);
 }
 
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(256) void paged_prefill_kernel(
     float lsum = l[n];
     lsum += __shfl_xor(lsum, 16, 64);
     lsum += __shfl_xor(lsum, 32, 64);
-    if (sinks != nullptr) lsum += exp2f(sinks[h] * LOG2E_F - m[n]);
+    if (sinks != nullptr) lsum += fast_exp2(sinks[h] * LOG2E_F - m[n]);
     const float inv = lsum > 0.f ? v_scale / lsum : 0.f;
     const int tok = t_wave + 16 * n + r16;
     if (tok < q_len) {

@@ -44,6 +44,11 @@ __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
+// 2^x as the one hardware instruction (v_exp_f32).  The library's exp2f wraps it in a compare, two selects, an
+// add and a scale so that results below 2^-126 come out as denormals; a softmax weight that small is zero for
+// every purpose here, and the wrapper is five of the eight VALU operations an attention kernel spends per score.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

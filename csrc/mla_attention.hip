@@ -193,12 +193,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m, tmax);
-    const float alpha = exp2f(m - m_new);
+    const float alpha = fast_exp2(m - m_new);
     float psum = 0.f;
     V pf;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float e = p[j] <= 0.5f * MLA_NEG_BIG ? 0.f : exp2f(p[j] - m_new);
+      const float e = p[j] <= 0.5f * MLA_NEG_BIG ? 0.f : fast_exp2(p[j] - m_new);
       psum += e;
       pf[j] = (T)e;
     }
@@ -393,12 +393,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
       const float m_new = fmaxf(m[n], tmax);
-      const float alpha = exp2f(m[n] - m_new);
+      const float alpha = fast_exp2(m[n] - m_new);
       float psum = 0.f;
       V pf;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float e = p[j] <= 0.5f * MLA_NEG_BIG ? 0.f : exp2f(p[j] - m_new);
+        const float e = p[j] <= 0.5f * MLA_NEG_BIG ? 0.f : fast_exp2(p[j] - m_new);
         psum += e;
         pf[j] = (T)e;
       }
@@ -449,11 +449,11 @@ __global__ void mla_reduce_kernel(T* __restrict__ out, long out_stride, const fl
   float mm = MLA_NEG_BIG;
   for (int s = 0; s < num_splits; ++s) mm = fmaxf(mm, part_ml[2 * (p0 + s)]);
   float lt = 0.f;
-  for (int s = 0; s < num_splits; ++s) lt += part_ml[2 * (p0 + s) + 1] * exp2f(part_ml[2 * (p0 + s)] - mm);
+  for (int s = 0; s < num_splits; ++s) lt += part_ml[2 * (p0 + s) + 1] * fast_exp2(part_ml[2 * (p0 + s)] - mm);
   const float inv = lt > 0.f ? 1.f / lt : 0.f;
   for (int d = threadIdx.x; d < DV; d += blockDim.x) {
     float o = 0.f;
-    for (int s = 0; s < num_splits; ++s) o += part_o[(p0 + s) * DV + d] * exp2f(part_ml[2 * (p0 + s)] - mm);
+    for (int s = 0; s < num_splits; ++s) o += part_o[(p0 + s) * DV + d] * fast_exp2(part_ml[2 * (p0 + s)] - mm);
     out[t * out_stride + (long)qh * DV + d] = (T)(o * inv);
   }
 }

@@ -51,9 +51,13 @@ def test_model_family_on_gpu_tracks_cpu_reference(model, tmp_path):
         kw = dict(dtype="bfloat16", gpu_memory_utilization=0.3) if dev == "cuda" else dict(dtype="float32", device="cpu")
         before = dict(ops.attention_calls)
         llm = LLM(model=str(tmp_path), max_model_len=256, num_gpu_blocks_override=64, max_num_seqs=8, **kw)
-        if dev == "cuda" and overrides:
+        if dev == "cuda":
+            # a family whose decode step cannot be captured (a host-to-device copy, a synchronising op) falls back
+            # to eager launches with a warning: every family here must capture
             runner = llm.engine.core.executor.driver.worker.model_runner
-            assert runner.graphs, "decode steps of the cut-down Qwen3-Coder must be hipGraph-captured"
+            why = runner.graph_fallback_reason or ""
+            assert runner.graphs or (not ops.hip_supports_head_dim(head_dim) and "no HIP attention kernel" in why), \
+                f"decode steps of {model} must be hipGraph-captured: {why}"
         outs[dev] = llm.generate(PROMPTS, SamplingParams(temperature=0.0, max_tokens=3, ignore_eos=True, logprobs=20))
         if dev == "cuda":
             # the comparison below must be about the HIP attention kernels wherever they take the head size;
@@ -74,7 +78,12 @@ def test_model_family_on_gpu_tracks_cpu_reference(model, tmp_path):
             # bf16 router logits can flip a near-tied expert choice on the MoE models: allow for it
             # (gpt-oss: top-2 of 8 experts behind a router with a bias, plus sinks; its expert block is pinned
             # against the per-expert loop on the same device in tests/test_quant_gpu.py)
+            # (gemma-tiny: embeddings times sqrt(hidden) into a tied head amplify bf16 rounding; its 80-token
+            # prompt measures 0.12 through the fragment-direct prefill kernel and 0.16 through the LDS-staged one,
+            # two kernels with the same error against fp32 on random data - scripts/dev/prefill_accuracy.py)
             tol = 0.15 if model in TIGHT else (0.4 if model == "gpt-oss-tiny" else 0.3)
+            if model == "gemma-tiny":
+                tol = 0.2
             assert max(abs(la[t] - lb[t]) for t in common) < tol, (model, step)
 
 

@@ -535,7 +535,9 @@ class VocabParallelEmbedding(nn.Module):
             dst = get_tp_group().stage_view((ids.shape[0], self.weight.shape[1]), self.weight.dtype)
         out = ops.embedding(ids, self.weight, self.vocab_start, masked=self.tp > 1, out=dst)
         if self.out_scale is not None:
-            out.mul_(torch.tensor(self.out_scale, dtype=out.dtype, device=out.device))
+            # (a host scalar rounded to the activation dtype: a device tensor made here would be a host-to-device
+            # copy in every step, which a hipGraph capture refuses)
+            out.mul_(float(torch.tensor(self.out_scale, dtype=out.dtype)))
         if reduce and self.tp > 1:
             out = tensor_model_parallel_all_reduce(out)
         return out
