@@ -252,7 +252,7 @@ __global__ __launch_bounds__(BG_THREADS) void big_gemm_kernel(
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const float g = a0[i][j][r];
-                v[r] = g / (1.f + __expf(-g)) * a1[i][j][r];
+                v[r] = fast_silu(g) * a1[i][j][r];
               }
             } else {
               const f32x4 a = h ? a1[i][j] : a0[i][j];

@@ -49,6 +49,13 @@ __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
 // every purpose here, and the wrapper is five of the eight VALU operations an attention kernel spends per score.
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// x * sigmoid(x) with the hardware reciprocal (1 ulp) in place of an IEEE division: the division's scale / fix-up
+// sequence is ten instructions per element, and every result here is rounded to 16 bits right after.
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.f + fast_exp2(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_silu(float x) { return x * fast_sigmoid(x); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

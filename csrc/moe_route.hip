@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void moe_topk_grouped_kernel(
   }
   if (sigmoid) {
 #pragma unroll
-    for (int i = 0; i < TOPK_MAX_VPL; ++i) sc[i] = 1.f / (1.f + __expf(-sc[i]));
+    for (int i = 0; i < TOPK_MAX_VPL; ++i) sc[i] = fast_sigmoid(sc[i]);
   } else {
     mx = wave_max(mx);
     float sum = 0.f;
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void bias_clamped_glu_kernel(T* __restrict__ o
   for (int i = 0; i < 8; ++i) {
     const float gate = fminf((float)(T)((float)g[i] + (float)bg[i]), limit);
     const float up = fminf(fmaxf((float)(T)((float)u[i] + (float)bu[i]), -limit), limit);
-    o[i] = (T)((up + 1.f) * gate / (1.f + __expf(-alpha * gate)));
+    o[i] = (T)((up + 1.f) * gate * fast_sigmoid(alpha * gate));
   }
   st8<T>(out + row * out_stride + c, o);
 }

@@ -180,7 +180,7 @@ __global__ void silu_and_mul_kernel(T* __restrict__ out, const T* __restrict__ x
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float a = (float)g[j];
-      o[j] = (T)((a / (1.f + __expf(-a))) * (float)u[j]);
+      o[j] = (T)(fast_silu(a) * (float)u[j]);
     }
     st8<T>(out + r * (long)F + 8 * c, o);
   }

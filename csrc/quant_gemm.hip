@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void w4a16_gemm_kernel(
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float gt = (float)bx[mt][s][j];
-            a[j] = (T)(gt / (1.f + __expf(-gt)) * (float)up[j]);
+            a[j] = (T)(fast_silu(gt) * (float)up[j]);
           }
           bx[mt][s] = a;
         }

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float gv = (float)gt[j];
-        gt[j] = (T)(gv / (1.f + __expf(-gv)) * (float)up[j]);
+        gt[j] = (T)(fast_silu(gv) * (float)up[j]);
       }
     }
     return gt;

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float gt = acc[0][r];
-      o[r] = (T)(gt / (1.f + __expf(-gt)) * acc[NTW - 1][r]);
+      o[r] = (T)(fast_silu(gt) * acc[NTW - 1][r]);
     }
     *reinterpret_cast<typename Vec4<T>::type*>(out + (long)m * out_stride + 16 * nt0 + 4 * g) = o;
   } else {
@@ -157,7 +157,7 @@ __global__ void stream_reduce_kernel(T* __restrict__ out, long out_stride, const
     }
     typename Vec4<T>::type o;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = (T)(sg[r] / (1.f + __expf(-sg[r])) * su[r]);
+    for (int r = 0; r < 4; ++r) o[r] = (T)(fast_silu(sg[r]) * su[r]);
     *reinterpret_cast<typename Vec4<T>::type*>(out + (long)m * out_stride + ng) = o;
   } else {
     const int n4 = N >> 2;
