@@ -70,6 +70,8 @@ if which in ("all", "prefill"):
     for n, ql, ctx in ((128, 128, 0), (16, 1024, 0), (4, 4096, 0), (1, 16384, 0), (8, 512, 4096)):
         prefill(n, ql, ctx, 64, 8)
     prefill(16, 1024, 0, 8, 1)
+if which == "prefill16k":          # one shape, for a counter run under rocprofv3 --pmc
+    prefill(1, 16384, 0, 64, 8)
 if which in ("all", "headsize"):
     # head sizes 64 (gpt-oss-120b: 64 / 8 heads) and 256 (Gemma-2-9B: 16 / 8 heads)
     for d, hq, hkv in ((64, 64, 8), (256, 16, 8), (128, 32, 8)):

@@ -557,7 +557,8 @@ int launch_prefill(void* out, const void* q, long q_stride, const void* kc, cons
       const char* e = getenv("VDAMD_PREFILL_LDS");
       return e == nullptr || atoi(e) != 0;
     }();
-    if (max_q_len > 32 && lds_kernel) {      // longer chunks: LDS-staged 32x32 MFMA kernel
+    // longer chunks: LDS-staged 32x32 MFMA kernel (it addresses the cache by shifts: power-of-two blocks)
+    if (max_q_len > 32 && lds_kernel && (block_size & (block_size - 1)) == 0) {
       static const int remap = [] {
         const char* e = getenv("VDAMD_PREFILL_XCD_REMAP");
         return e == nullptr ? 1 : atoi(e);
