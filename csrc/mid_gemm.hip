@@ -51,7 +51,7 @@ __global__ __launch_bounds__(MG_THREADS) void mid_gemm_kernel(
   if (tn >= ntn) return;
   const int m0 = blockIdx.y * BM, n0 = tn * BN + wid * 16 * FN;
   const int KT = K / MG_BK;
-  const int kt_lo = (int)((long)KT * ks / ksplit), kt_hi = (int)((long)KT * (ks + 1) / ksplit);
+  const int kt_lo = KT * ks / ksplit, kt_hi = KT * (ks + 1) / ksplit;
   const int nt = kt_hi - kt_lo;
 
   // W fragment rows of this lane (clamped: columns past N are computed and dropped)
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(MG_THREADS) void mid_gemm_deep_kernel(
   if (tn >= ntn) return;
   const int m0 = blockIdx.y * BM, n0 = tn * BN + wid * 16 * FN;
   const int KT = K / MG_BK;
-  const int kt_lo = (int)((long)KT * ks / ksplit), kt_hi = (int)((long)KT * (ks + 1) / ksplit);
+  const int kt_lo = KT * ks / ksplit, kt_hi = KT * (ks + 1) / ksplit;
   const int nt = kt_hi - kt_lo;
   if (nt <= 0) return;
   const int last = nt - 1;
@@ -328,7 +328,8 @@ __global__ void mid_reduce_kernel(T* __restrict__ out, long out_stride, const fl
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int n4 = N >> 2;
   if (idx >= (long)M * n4) return;
-  const int m = (int)(idx / n4), n = (int)(idx % n4) * 4;
+  const unsigned mu = (unsigned)idx / (unsigned)n4;        // (M * N / 4 < 2^31: no 64-bit division)
+  const int m = (int)mu, n = (int)((unsigned)idx - mu * (unsigned)n4) * 4;
   f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int k = 0; k < ksplit; ++k) s += *reinterpret_cast<const f32x4*>(partial + ((size_t)k * M + m) * N + n);
   typename Vec4<T>::type o;

@@ -169,10 +169,13 @@ __global__ void layer_norm_kernel(T* __restrict__ out, const T* __restrict__ x, 
 template <typename T>
 __global__ void silu_and_mul_kernel(T* __restrict__ out, const T* __restrict__ x, long T_rows, int F) {
   using V = typename Vec8<T>::type;
-  const long nvec_row = F >> 3;
-  const long total = T_rows * nvec_row;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / nvec_row, c = i - r * nvec_row;
+  // (32-bit index math - the launcher refuses more than 2^31 vectors: a 64-bit division per vector is a
+  // ~150-instruction routine in a kernel that otherwise spends ~40)
+  const unsigned nvec_row = F >> 3;
+  const unsigned total = (unsigned)T_rows * nvec_row;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned ru = i / nvec_row;
+    const long r = ru, c = i - ru * nvec_row;
     const T* xr = x + r * 2L * F;
     V g = ld8<T>(xr + 8 * c);
     V u = ld8<T>(xr + F + 8 * c);
@@ -272,6 +275,7 @@ VDAMD_API int vdamd_silu_and_mul(void* out, const void* x, long T, int F, int dt
   if (T == 0) return 0;
   if (F % 8 != 0) return -1;
   const long total = T * (long)(F >> 3);
+  if (total >= (1L << 31)) return -3;
   long blocks = (total + 255) / 256;
   if (blocks > 256 * 8) blocks = 256 * 8;     // 8 workgroups per CU, grid-stride the rest
   if (dtype == DT_BF16)

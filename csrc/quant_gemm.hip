@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void w4a16_gemm_kernel(
   const int KB = K >> 7, ntiles = N >> 4, NG = KB / kb_per_group;
   const int nt0 = blockIdx.x * W4_NTW;
   const int ks = blockIdx.y;
-  const int kb_lo = (int)((long)KB * ks / ksplit), kb_hi = (int)((long)KB * (ks + 1) / ksplit);
+  const int kb_lo = KB * ks / ksplit, kb_hi = KB * (ks + 1) / ksplit;
   const int span = kb_hi - kb_lo;
   const int w_lo = kb_lo + span * wid / W4_WAVES, w_hi = kb_lo + span * (wid + 1) / W4_WAVES;
   const int m0 = m_base;
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void w4a16_gemm_lds_kernel(
   const int KB = K >> 7, ntiles = N >> 4, NG = KB / kb_per_group;
   const int nt0 = (blockIdx.x * W4_WAVES + wid) * NTW;
   const int ks = blockIdx.y;
-  const int kb_lo = (int)((long)KB * ks / ksplit), kb_hi = (int)((long)KB * (ks + 1) / ksplit);
+  const int kb_lo = KB * ks / ksplit, kb_hi = KB * (ks + 1) / ksplit;
 
   int ntc[NTW];
 #pragma unroll
@@ -492,7 +492,8 @@ __global__ void w4a16_reduce_kernel(T* __restrict__ out, long out_stride, const 
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int n4 = N >> 2;
   if (idx >= (long)M * n4) return;
-  const int m = (int)(idx / n4), n = (int)(idx % n4) * 4;
+  const unsigned mu = (unsigned)idx / (unsigned)n4;        // (M * N / 4 < 2^31: no 64-bit division)
+  const int m = (int)mu, n = (int)((unsigned)idx - mu * (unsigned)n4) * 4;
   f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int k = 0; k < ksplit; ++k) s += *reinterpret_cast<const f32x4*>(partial + ((size_t)k * M + m) * N + n);
   typename Vec4<T>::type o;

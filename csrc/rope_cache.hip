@@ -80,16 +80,20 @@ __global__ void rope_cache_kernel(const int* __restrict__ positions, T* __restri
   const int cpp = half >> 3;                 // 8-element chunks per half head
   const int q_items = Hq * cpp, k_items = Hkv * cpp, v_items = WRITE_CACHE ? Hkv * (D >> 3) : 0;
   const int items = q_items + k_items + v_items;
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long t = gid / items;
-  if (t >= T_tokens) return;
-  const int item = (int)(gid - t * items);
+  // (32-bit index math: the launcher refuses T * items >= 2^31, and a 64-bit division is a ~150-instruction
+  // routine, three of which used to open every thread of a kernel that moves 48 bytes per thread)
+  const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned tu = gid / (unsigned)items;
+  if (tu >= (unsigned)T_tokens) return;
+  const long t = tu;
+  const int item = (int)(gid - tu * (unsigned)items);
   const int pos = ROTATE ? positions[t] : 0;
   const float* cs = cos_sin + (long)pos * D;   // [cos(half) | sin(half)]
-  long slot = -1;
+  int slot = -1;
   if (WRITE_CACHE) slot = slot_mapping[t];
-  const long blk = slot >= 0 ? slot / block_size : 0;
-  const int off = slot >= 0 ? (int)(slot % block_size) : 0;
+  const unsigned blk_u = slot >= 0 ? (unsigned)slot / (unsigned)block_size : 0u;
+  const long blk = blk_u;
+  const int off = slot >= 0 ? (int)((unsigned)slot - blk_u * (unsigned)block_size) : 0;
 
   {
     if (item < q_items + k_items) {
@@ -204,6 +208,7 @@ int launch(const int* positions, void* q, void* k, const void* v, long qs, long 
   // mode 0 and 2 write the cache (v items exist), mode 1 rotates only
   const long items = Hq * (D >> 4) + Hkv * (D >> 4) + (mode == 1 ? 0 : Hkv * (D >> 3));
   const long total = items * T_tokens;
+  if (total + 256 >= (1L << 31)) return -3;
   const int threads = 256;
   const unsigned blocks = (unsigned)((total + threads - 1) / threads);
 #define L(WC, ROT, K8)                                                                                          \

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(
   const int KB = K >> 7, ntiles = N >> 4;
   const int nt0 = (blockIdx.x * SG_WAVES + wid) * NTW;
   const int ks = blockIdx.y;
-  const int kb_lo = (int)((long)KB * ks / ksplit), kb_hi = (int)((long)KB * (ks + 1) / ksplit);
+  const int kb_lo = KB * ks / ksplit, kb_hi = KB * (ks + 1) / ksplit;
 
   const T* wrow[NTW];
 #pragma unroll
@@ -142,7 +142,8 @@ __global__ void skinny_reduce_kernel(T* __restrict__ out, long out_stride, const
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int n4 = N >> 2;
   if (idx >= (long)M * n4) return;
-  const int m = (int)(idx / n4), n = (int)(idx % n4) * 4;
+  const unsigned mu = (unsigned)idx / (unsigned)n4;        // (M * N / 4 < 2^31: no 64-bit division)
+  const int m = (int)mu, n = (int)((unsigned)idx - mu * (unsigned)n4) * 4;
   f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int k = 0; k < ksplit; ++k) s += *reinterpret_cast<const f32x4*>(partial + ((size_t)k * M + m) * N + n);
   typename Vec4<T>::type o;

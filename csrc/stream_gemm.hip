@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(
   const int nt0 = EPI == EPI_SILU_MUL ? blockIdx.x : blockIdx.x * NTW;
   const int tstep = EPI == EPI_SILU_MUL ? (ntiles >> 1) : 1;      // distance between this workgroup's tiles
   const int ks = blockIdx.y;
-  const int kb_lo = (int)((long)KB * ks / ksplit), kb_hi = (int)((long)KB * (ks + 1) / ksplit);
+  const int kb_lo = KB * ks / ksplit, kb_hi = KB * (ks + 1) / ksplit;
   const int iters = (kb_hi - kb_lo - wid + SW - 1) / SW;       // blocks kb_lo + wid, + SW, ...
 
   const T* wrow[NTW];
@@ -148,7 +148,8 @@ __global__ void stream_reduce_kernel(T* __restrict__ out, long out_stride, const
   if constexpr (EPI == EPI_SILU_MUL) {
     const int n4 = N >> 3;                       // output quads: N/2 columns
     if (idx >= (long)M * n4) return;
-    const int m = (int)(idx / n4), q = (int)(idx % n4);
+    const unsigned mu = (unsigned)idx / (unsigned)n4;
+    const int m = (int)mu, q = (int)((unsigned)idx - mu * (unsigned)n4);
     const int ng = 4 * q, nu = ng + (N >> 1);
     f32x4 sg = f32x4{0.f, 0.f, 0.f, 0.f}, su = sg;
     for (int k = 0; k < ksplit; ++k) {
@@ -162,7 +163,8 @@ __global__ void stream_reduce_kernel(T* __restrict__ out, long out_stride, const
   } else {
     const int n4 = N >> 2;
     if (idx >= (long)M * n4) return;
-    const int m = (int)(idx / n4), n = (int)(idx % n4) * 4;
+    const unsigned mu = (unsigned)idx / (unsigned)n4;        // (M * N / 4 < 2^31: no 64-bit division)
+  const int m = (int)mu, n = (int)((unsigned)idx - mu * (unsigned)n4) * 4;
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < ksplit; ++k) s += *reinterpret_cast<const f32x4*>(partial + ((size_t)k * M + m) * N + n);
     typename Vec4<T>::type o;
