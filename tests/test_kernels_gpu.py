@@ -231,8 +231,11 @@ def test_decode_softmax_rescale_branch_with_spiked_key():
         torch.testing.assert_close(got.float(), ref, rtol=2e-2, atol=2e-2)
 
 
-@pytest.mark.parametrize("hq,hkv,d,bs", [(32, 8, 128, 64), (8, 8, 64, 16), (6, 2, 128, 32), (32, 32, 96, 32), (8, 4, 256, 16)])
+@pytest.mark.parametrize("hq,hkv,d,bs", [(32, 8, 128, 64), (8, 8, 64, 16), (6, 2, 128, 32), (32, 32, 96, 32), (8, 4, 256, 16),
+                                         (8, 2, 128, 24), (8, 2, 128, 128), (4, 2, 256, 64), (8, 2, 64, 256)])
 def test_paged_attention_prefill_varlen_and_chunked(hq, hkv, d, bs):
+    # (block sizes: below, at and above the LDS kernel's 64-key tile - it looks a block up per chunk or per tile -
+    # and 24, not a power of two, which only the fragment-direct kernel addresses)
     # (q_len, seq_len): full prompts, a chunk continuing a cached prefix, a single token
     cases = [(5, 5), (128, 128), (130, 130), (40, 300), (1, 77), (257, 600), (33, 33)]
     seq_lens = [c[1] for c in cases]
