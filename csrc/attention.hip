@@ -456,6 +456,15 @@ __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+// 16 bytes per lane from global memory straight into LDS: the wave's 64 pieces land at lds_wave_base + 16 * lane
+typedef __attribute__((address_space(3))) void prefill_lds_void;
+typedef __attribute__((address_space(1))) void prefill_glb_void;
+__device__ __forceinline__ void prefill_dma16(const void* g, void* lds_wave_base) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (the builtin exists in the device pass only)
+  __builtin_amdgcn_global_load_lds((prefill_glb_void*)const_cast<void*>(g), (prefill_lds_void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+
 #define PREFILL_LDS_D 128
 #define PREFILL_LDS_OCC 2
 #define PREFILL_LDS_NAME paged_prefill_lds_kernel
