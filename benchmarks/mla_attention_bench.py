@@ -56,6 +56,13 @@ def case(batch, ctx, hq, q_len=1, mode=None, kv8=False):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "one":      # a single shape, for a counter run: one <prefill|decode> <heads>
+        hq = int(sys.argv[3])
+        if sys.argv[2] == "prefill":
+            case(1, 32768, hq, q_len=2048)
+        else:
+            case(128, 4096, hq)
+        sys.exit(0)
     for hq in (16, 128):
         for batch, ctx in ((1, 4096), (1, 32768), (8, 4096), (32, 4096), (128, 4096), (256, 1024), (32, 32768)):
             case(batch, ctx, hq)
