@@ -12,7 +12,7 @@ from vllm_distributed_amd.ops import hip  # noqa: E402
 
 hip.load()
 torch.manual_seed(0)
-variant = int(os.environ.get("VDAMD_BIG_GEMM_VARIANT", "5"))
+variant = int(os.environ.get("VDAMD_BIG_GEMM_VARIANT", "0"))
 m = 2048
 for (n, k) in ((8192, 8192), (57344, 8192)):
     buf = torch.empty((n, k + 128), dtype=torch.bfloat16, device="cuda")
