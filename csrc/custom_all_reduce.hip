@@ -195,6 +195,10 @@ __device__ __forceinline__ void reduce_norm_row(const Peers& peers, int world, l
   V vals[CAR_ROW_ITERS];
   float ss = 0.f;
   const int nvec = H >> 3;
+  // (the first piece of the norm weight travels with the row: behind the block-wide sum it would be a second
+  // trip to HBM in a kernel that is all latency at decode sizes; the wide one-pass form has only this piece)
+  V g0;
+  if ((int)threadIdx.x < nvec) g0 = ld8<T>(w + 8 * threadIdx.x);
 #pragma unroll
   for (int it = 0; it < CAR_ROW_ITERS; ++it) {
     const int i = threadIdx.x + it * blockDim.x;
@@ -217,7 +221,7 @@ __device__ __forceinline__ void reduce_norm_row(const Peers& peers, int world, l
   for (int it = 0; it < CAR_ROW_ITERS; ++it) {
     const int i = threadIdx.x + it * blockDim.x;
     if (i < nvec) {
-      V g = ld8<T>(w + 8 * i), o;
+      V g = it == 0 ? g0 : ld8<T>(w + 8 * i), o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = (T)((float)vals[it][j] * inv * (float)g[j]);
       st8<T>(out_row + 8 * i, o);

@@ -17,9 +17,16 @@ __global__ void rms_norm_kernel(T* __restrict__ out, const T* __restrict__ x, T*
   T* rr = ADD_RESIDUAL ? residual + row * (long)H : nullptr;
   T* orow = out + row * out_stride;
   using V = typename Vec8<T>::type;
-  V vals[NORM_MAX_ITERS];
+  V vals[NORM_MAX_ITERS], gw[NORM_MAX_ITERS];
   float ss = 0.f;
   const int nvec = H >> 3;
+  // (the norm weight is fetched with the row, not after the reduction: it is cold in every layer, and a load
+  // issued behind the block-wide sum is a second trip to HBM in a kernel that is all latency at decode sizes)
+#pragma unroll
+  for (int it = 0; it < NORM_MAX_ITERS; ++it) {
+    const int i = threadIdx.x + it * blockDim.x;
+    if (i < nvec) gw[it] = ld8<T>(w + 8 * i);
+  }
 #pragma unroll
   for (int it = 0; it < NORM_MAX_ITERS; ++it) {
     const int i = threadIdx.x + it * blockDim.x;
@@ -43,7 +50,7 @@ __global__ void rms_norm_kernel(T* __restrict__ out, const T* __restrict__ x, T*
     const int i = threadIdx.x + it * blockDim.x;
     if (i < nvec) {
       V v = vals[it];
-      V g = ld8<T>(w + 8 * i);
+      V g = gw[it];
       V o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = (T)((float)v[j] * inv * (float)g[j]);
@@ -65,9 +72,14 @@ __global__ void reduce_add_rms_norm_kernel(T* __restrict__ out, const float* __r
   T* rr = residual + row * (long)H;
   T* orow = out + row * out_stride;
   using V = typename Vec8<T>::type;
-  V vals[NORM_MAX_ITERS];
+  V vals[NORM_MAX_ITERS], gw[NORM_MAX_ITERS];
   float ss = 0.f;
   const int nvec = H >> 3;
+#pragma unroll
+  for (int it = 0; it < NORM_MAX_ITERS; ++it) {          // (norm weight with the row: see rms_norm_kernel)
+    const int i = threadIdx.x + it * blockDim.x;
+    if (i < nvec) gw[it] = ld8<T>(w + 8 * i);
+  }
 #pragma unroll
   for (int it = 0; it < NORM_MAX_ITERS; ++it) {
     const int i = threadIdx.x + it * blockDim.x;
@@ -108,7 +120,7 @@ __global__ void reduce_add_rms_norm_kernel(T* __restrict__ out, const float* __r
   for (int it = 0; it < NORM_MAX_ITERS; ++it) {
     const int i = threadIdx.x + it * blockDim.x;
     if (i < nvec) {
-      V g = ld8<T>(w + 8 * i), o;
+      V g = gw[it], o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = (T)((float)vals[it][j] * inv * (float)g[j]);
       st8<T>(orow + 8 * i, o);
