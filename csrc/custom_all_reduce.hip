@@ -187,12 +187,14 @@ __global__ __launch_bounds__(CAR_FLAT_THREADS) void twoshot_flat_kernel(Peers pe
 
 // ------------------------------------------------- all-reduce + residual add + RMSNorm
 // v = sum over ranks of stage[row] + residual[row];  residual[row] = v;  out[row] = v * rsqrt(mean(v^2)+eps) * w
-template <typename T>
+// ITERS: 16-byte pieces of the row per thread (1 in the wide form, where a workgroup has a thread per piece: the
+// four-piece form unrolled with every peer's loads hoisted to the top does not fit that form's 128 registers)
+template <typename T, int ITERS = CAR_ROW_ITERS>
 __device__ __forceinline__ void reduce_norm_row(const Peers& peers, int world, long stage_off, long row, int H,
                                                 T* __restrict__ res_row, const T* __restrict__ w, float eps,
                                                 T* __restrict__ out_row, T* __restrict__ shard_row, float* red) {
   using V = typename Vec8<T>::type;
-  V vals[CAR_ROW_ITERS];
+  V vals[ITERS];
   float ss = 0.f;
   const int nvec = H >> 3;
   // (the first piece of the norm weight travels with the row: behind the block-wide sum it would be a second
@@ -200,7 +202,7 @@ __device__ __forceinline__ void reduce_norm_row(const Peers& peers, int world, l
   V g0;
   if ((int)threadIdx.x < nvec) g0 = ld8<T>(w + 8 * threadIdx.x);
 #pragma unroll
-  for (int it = 0; it < CAR_ROW_ITERS; ++it) {
+  for (int it = 0; it < ITERS; ++it) {
     const int i = threadIdx.x + it * blockDim.x;
     if (i < nvec) {
       float acc[8];
@@ -218,7 +220,7 @@ __device__ __forceinline__ void reduce_norm_row(const Peers& peers, int world, l
   ss = block_sum(ss, red);
   const float inv = rsqrtf(ss / (float)H + eps);
 #pragma unroll
-  for (int it = 0; it < CAR_ROW_ITERS; ++it) {
+  for (int it = 0; it < ITERS; ++it) {
     const int i = threadIdx.x + it * blockDim.x;
     if (i < nvec) {
       V g = it == 0 ? g0 : ld8<T>(w + 8 * i), o;
@@ -230,21 +232,21 @@ __device__ __forceinline__ void reduce_norm_row(const Peers& peers, int world, l
   }
 }
 
-template <typename T, bool FENCE_START>
-__global__ void oneshot_norm_kernel(Peers peers, Signal* self, int rank, int world, long stage_off, T* out,
+template <typename T, bool FENCE_START, int ITERS>
+__global__ __launch_bounds__(ITERS == 1 ? 1024 : 512) void oneshot_norm_kernel(Peers peers, Signal* self, int rank, int world, long stage_off, T* out,
                                     T* residual, const T* w, float eps, int rows, int H) {
   __shared__ float red[17];
   const uint32_t epoch = self->epoch[blockIdx.x] + 1;
   cross_barrier<FENCE_START>(peers, self, rank, world, epoch);
   for (long row = blockIdx.x; row < rows; row += gridDim.x)
-    reduce_norm_row<T>(peers, world, stage_off, row, H, residual + row * (long)H, w, eps, out + row * (long)H,
-                       nullptr, red);
+    reduce_norm_row<T, ITERS>(peers, world, stage_off, row, H, residual + row * (long)H, w, eps,
+                              out + row * (long)H, nullptr, red);
   if (threadIdx.x == 0) self->epoch[blockIdx.x] = epoch;
 }
 
 // Rank r owns rows [r*per, (r+1)*per): `residual` holds only those ([per, H], row-sharded).
-template <typename T, bool FENCE_START>
-__global__ void twoshot_norm_kernel(Peers peers, Signal* self, int rank, int world, long stage_off, long shard_off,
+template <typename T, bool FENCE_START, int ITERS>
+__global__ __launch_bounds__(ITERS == 1 ? 1024 : 512) void twoshot_norm_kernel(Peers peers, Signal* self, int rank, int world, long stage_off, long shard_off,
                                     T* out, T* residual, const T* w, float eps, int rows, int H, int per) {
   __shared__ float red[17];
   using V = typename Vec8<T>::type;
@@ -253,8 +255,8 @@ __global__ void twoshot_norm_kernel(Peers peers, Signal* self, int rank, int wor
   const int lo = min(rank * per, rows), cnt = min(lo + per, rows) - lo;
   T* my_shard = reinterpret_cast<T*>(peers.data[rank] + shard_off);
   for (int lr = blockIdx.x; lr < cnt; lr += gridDim.x)
-    reduce_norm_row<T>(peers, world, stage_off, lo + lr, H, residual + lr * (long)H, w, eps,
-                       out + (lo + lr) * (long)H, my_shard + lr * (long)H, red);
+    reduce_norm_row<T, ITERS>(peers, world, stage_off, lo + lr, H, residual + lr * (long)H, w, eps,
+                              out + (lo + lr) * (long)H, my_shard + lr * (long)H, red);
   ++epoch;
   cross_barrier<true>(peers, self, rank, world, epoch);
   const int nvec = H >> 3;
@@ -312,7 +314,7 @@ inline int row_threads(int H) {
   int t = ((H >> 3) + CAR_ROW_ITERS - 1) / CAR_ROW_ITERS;
   t = (t + 63) / 64 * 64;
   if (t < 64) t = 64;
-  if (t > 1024) t = 1024;
+  if (t > 512) t = 512;       // (the several-pieces-per-thread kernels are built for at most 512 threads)
   return t;
 }
 
@@ -455,7 +457,7 @@ VDAMD_API int vdamd_car_fused_norm(void* ctx, int parity, const void* in, void* 
   Context* c = (Context*)ctx;
   if (rows == 0) return 0;
   const size_t bytes = (size_t)rows * H * 2;
-  if (H % 8 != 0 || H > 8 * 1024 * CAR_ROW_ITERS || bytes > c->cap) return -1;
+  if (H % 8 != 0 || H > 8 * 512 * CAR_ROW_ITERS || bytes > c->cap) return -1;
   if (dtype != DT_BF16 && dtype != DT_F16) return -2;
   int rc = stage_input(c, parity, in, bytes, s);
   if (rc != 0) return rc;
@@ -470,16 +472,20 @@ VDAMD_API int vdamd_car_fused_norm(void* ctx, int parity, const void* in, void* 
     threads = ((H >> 3) + 63) / 64 * 64;
     if (threads > 1024) threads = 1024;
   }
-#define RUN(TY, FS)                                                                                              \
-  if (two_shot)                                                                                                  \
-    hipLaunchKernelGGL((twoshot_norm_kernel<TY, FS>), dim3(blocks), dim3(threads), 0, s, c->peers, c->self_sig,  \
-                       c->rank, c->world, stage_off, shard_off, (TY*)out, (TY*)residual, (const TY*)w, eps,      \
-                       rows, H, per);                                                                            \
-  else                                                                                                           \
-    hipLaunchKernelGGL((oneshot_norm_kernel<TY, FS>), dim3(blocks), dim3(threads), 0, s, c->peers, c->self_sig,  \
+  const bool one_piece = threads * 8 >= H;      // a thread per 16-byte piece
+  if (!one_piece && threads > 512) threads = 512;
+#define RUN(TY, FS, IT)                                                                                             \
+  if (two_shot)                                                                                                     \
+    hipLaunchKernelGGL((twoshot_norm_kernel<TY, FS, IT>), dim3(blocks), dim3(threads), 0, s, c->peers, c->self_sig, \
+                       c->rank, c->world, stage_off, shard_off, (TY*)out, (TY*)residual, (const TY*)w, eps,         \
+                       rows, H, per);                                                                               \
+  else                                                                                                              \
+    hipLaunchKernelGGL((oneshot_norm_kernel<TY, FS, IT>), dim3(blocks), dim3(threads), 0, s, c->peers, c->self_sig, \
                        c->rank, c->world, stage_off, (TY*)out, (TY*)residual, (const TY*)w, eps, rows, H)
-  if (dtype == DT_BF16) { if (fence_start) { RUN(bf16_t, true); } else { RUN(bf16_t, false); } }
-  else { if (fence_start) { RUN(f16_t, true); } else { RUN(f16_t, false); } }
+#define RUN_FS(TY, IT) if (fence_start) { RUN(TY, true, IT); } else { RUN(TY, false, IT); }
+  if (dtype == DT_BF16) { if (one_piece) { RUN_FS(bf16_t, 1) } else { RUN_FS(bf16_t, CAR_ROW_ITERS) } }
+  else { if (one_piece) { RUN_FS(f16_t, 1) } else { RUN_FS(f16_t, CAR_ROW_ITERS) } }
+#undef RUN_FS
 #undef RUN
   HIP_LAUNCH_CHECK();
   return 0;

@@ -211,7 +211,7 @@ class GroupCoordinator:
         """Whether ``all_reduce_add_rms_norm`` takes a ``[rows, hidden]`` message (peer-mapped path)."""
         car = self.custom_ar
         return (car is not None and envs.VDAMD_FUSED_ALL_REDUCE_NORM and dtype in (torch.bfloat16, torch.float16)
-                and hidden % 8 == 0 and hidden <= 32768 and car.fits(rows * hidden * 2)
+                and hidden % 8 == 0 and hidden <= 16384 and car.fits(rows * hidden * 2)
                 and rows * hidden * 2 <= car.use_bytes)
 
     def all_reduce_add_rms_norm(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float,
