@@ -70,6 +70,8 @@ if which in ("all", "prefill"):
     for n, ql, ctx in ((128, 128, 0), (16, 1024, 0), (4, 4096, 0), (1, 16384, 0), (8, 512, 4096)):
         prefill(n, ql, ctx, 64, 8)
     prefill(16, 1024, 0, 8, 1)
+if which == "decode2048":          # the headline step's decode attention, for a counter run
+    decode(2048, 160, 64, 8)
 if which == "prefill16k":          # one shape, for a counter run under rocprofv3 --pmc
     prefill(1, 16384, 0, 64, 8)
 if which in ("all", "headsize"):

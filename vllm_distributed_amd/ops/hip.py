@@ -724,6 +724,10 @@ def mid_supported(x: torch.Tensor, w: torch.Tensor) -> bool:
 _MID_TILE_US = {(256, 256): 1.6, (256, 128): 1.05, (128, 256): 1.2, (128, 128): 0.75, (64, 256): 1.0}
 
 
+# K-split counts the choice is made from (VDAMD_MID_KSPLITS=1,2,4,8,16 restricts it, for A/B measurements)
+_MID_KSPLITS = tuple(int(v) for v in os.environ.get("VDAMD_MID_KSPLITS", "1,2,3,4,5,6,7,8,12,16").split(","))
+
+
 def _mid_estimate(m: int, n: int, k: int, bm: int, bn: int, ksplit: int) -> float:
     """Modelled run time in us: rounds of workgroups x K tiles x time per tile (at least the HBM time
     of W), plus the fp32 slab round trip and the reduce launch when K is split."""
@@ -741,7 +745,9 @@ def mid_choose(m: int, n: int, k: int) -> Tuple[int, int, int]:
     for (bm, bn) in _MID_TILE_US:
         if bm < min(m, 256) or (bm == 64 and m > 48 and k < 2 * n):
             continue
-        for ksplit in (1, 2, 4, 8, 16):
+        # (counts that are not powers of two as well: a 70B qkv projection's 40 column tiles fill 240 of the
+        # 256 CUs at 6, 160 at 4)
+        for ksplit in _MID_KSPLITS:
             if k // 64 // ksplit < 4:
                 break
             e = _mid_estimate(m, n, k, bm, bn, ksplit)
