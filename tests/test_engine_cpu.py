@@ -457,6 +457,114 @@ def _record_head_proposals(llm):
     return seen
 
 
+def test_eagle3_head_reads_three_depths_of_the_residual_stream():
+    """EAGLE-3: ``fc`` over the target's residual stream in front of three of its layers, one decoder layer whose
+    attention reads ``[input_layernorm(embed) ; hidden_norm(hidden)]``, ``norm`` + an LM head over a reduced draft
+    vocabulary, ``d2t`` back to target ids.  Whatever the head proposes, the text is greedy decoding's, and the
+    drafts do not depend on how the prompts were chunked.  The wiring is pinned with a silenced layer (zero output
+    projections: the feature is ``fc(taps)`` and stays that for every further draft):
+      * taps moved to layers (0, 1, 2) and ``fc`` reading the first one through a random matrix: the tap in front
+        of layer 0 is the embedding of the token AT the position, so every draft after a step is
+        ``d2t-mapped argmax(lm_head(norm(A emb[token at the last kept position])))``, computed on the host;
+      * ``fc`` zero and the attention live on one half of its input at a time: with the embedding half of the
+        q / k / v weights zeroed nothing reaches the output (every draft is the mapped id of draft 0), with the
+        hidden half zeroed the drafts follow the tokens - the concatenation is ``[embeds ; hidden]``.
+    No EAGLE-3 fixtures ship with the reference: parity with other implementations is unpinned."""
+    import torch
+    from vllm_distributed_amd import LLM, SamplingParams
+    kw = dict(model="llama-tiny", device="cpu", dtype="float32", max_model_len=256, num_gpu_blocks_override=128,
+              max_num_seqs=8, load_format="dummy")
+    prompts = [{"prompt_token_ids": [3, 9, 4, 7, 11, 5] * 6}, {"prompt_token_ids": list(range(20, 60))},
+               {"prompt_token_ids": [5, 6] * 20}, {"prompt_token_ids": list(range(100, 117))}]
+    sps = [SamplingParams(temperature=0.0, max_tokens=40, ignore_eos=True),
+           SamplingParams(temperature=0.0, max_tokens=23, ignore_eos=True),
+           SamplingParams(temperature=0.0, max_tokens=40, ignore_eos=True, logprobs=1),
+           SamplingParams(temperature=0.0, max_tokens=30, ignore_eos=True)]
+    ref = LLM(**kw)
+    want = [o.outputs[0].token_ids for o in ref.generate(prompts, sps)]
+    ref.shutdown()
+    spec_cfg = {"method": "eagle3", "model": "eagle3-llama-tiny", "num_speculative_tokens": 3}
+
+    logs = []
+    for extra in ({}, {"max_num_batched_tokens": 16}):
+        llm = LLM(speculative_config=spec_cfg, **kw, **extra)
+        runner = llm.engine.core.executor.driver.worker.model_runner
+        head, target = runner.draft.model, runner.model
+        assert target.aux_hidden_layers == (1, 2, 3) and head.fc.weight.shape == (256, 768)
+        assert head.embed_tokens is target.embed_tokens and head.lm_head is not target.lm_head
+        assert head.lm_head.weight.shape[0] >= 128 and head.layers["0"].self_attn.qkv_proj.weight.shape[1] == 512
+        d2t = head.d2t
+        assert d2t.dtype == torch.int64 and bool((d2t[1:] + 1 >= d2t[:-1]).all()) and int(d2t[-1]) + 127 < 512
+        assert runner.get_kv_cache_spec().extra_bytes_per_block > 0
+        seen = _record_head_proposals(llm)
+        outs = llm.generate(prompts, sps)
+        assert [o.outputs[0].token_ids for o in outs] == want
+        st = llm.engine.core.scheduler.spec_stats
+        assert st["drafted"] > 0 and st["accepted"] < st["drafted"]
+        targets = set((torch.arange(128) + d2t).tolist())
+        assert all(t in targets for d in seen.values() for t in d)          # drafts are ids of the draft vocabulary
+        order = {o.request_id: i for i, o in enumerate(outs)}
+        logs.append({(order[r], pos): d for (r, pos), d in seen.items()})
+        assert target.path_counts["plain"] > 0 and len(target.path_counts) == 1
+        llm.shutdown()
+    assert len(logs[0]) > 60 and logs[0] == logs[1]
+
+    def silenced(llm):
+        runner = llm.engine.core.executor.driver.worker.model_runner
+        head, target = runner.draft.model, runner.model
+        with torch.no_grad():
+            layer = head.layers["0"]
+            layer.self_attn.o_proj.weight.zero_()
+            layer.mlp.down_proj.weight.zero_()
+            head.fc.weight.zero_()
+        return head, target
+
+    # ---- tap alignment, fc, norm, LM head and d2t
+    llm = LLM(speculative_config=spec_cfg, **kw)
+    head, target = silenced(llm)
+    target.aux_hidden_layers = (0, 1, 2)
+    h = 256
+    a = torch.randn(h, h, generator=torch.Generator().manual_seed(5)) / h ** 0.5
+    with torch.no_grad():
+        head.fc.weight[:, :h] = a
+    emb = target.embed_tokens.weight.float()
+    feat = emb @ a.T
+    normed = feat * torch.rsqrt(feat.pow(2).mean(-1, keepdim=True) + head.norm.eps) * head.norm.weight.float()
+    pick = (normed @ head.lm_head.weight.float().T)[:, :128].argmax(-1)
+    g = (pick + head.d2t[pick]).tolist()
+    seen = _record_head_proposals(llm)
+    outs = llm.generate(prompts, sps)
+    assert [o.outputs[0].token_ids for o in outs] == want
+    full = {o.request_id: list(o.prompt_token_ids) + list(o.outputs[0].token_ids) for o in outs}
+    checked = 0
+    for (rid, pos), drafts in seen.items():
+        if pos >= len(full[rid]):
+            continue
+        assert drafts == [g[full[rid][pos - 1]]] * len(drafts), (rid, pos, drafts)
+        checked += 1
+    assert checked > 60
+    llm.shutdown()
+
+    # ---- the attention's input is [embeds ; hidden]
+    for zero_half in ("embeds", "hidden"):
+        llm = LLM(speculative_config=spec_cfg, **kw)
+        head, target = silenced(llm)
+        with torch.no_grad():
+            layer = head.layers["0"]
+            torch.nn.init.normal_(layer.self_attn.o_proj.weight, std=0.1, generator=torch.Generator().manual_seed(7))
+            w = layer.self_attn.qkv_proj.weight
+            (w[:, :h] if zero_half == "embeds" else w[:, h:]).zero_()
+        seen = _record_head_proposals(llm)
+        outs = llm.generate(prompts, sps)
+        assert [o.outputs[0].token_ids for o in outs] == want
+        firsts = {d[0] for d in seen.values() if d}
+        if zero_half == "embeds":
+            assert firsts == {int(head.d2t[0])}, firsts       # fc is zero: nothing but zeros reaches the LM head
+        else:
+            assert len(firsts) > 8, firsts
+        llm.shutdown()
+
+
 def test_eagle_and_mtp_heads_draft_from_the_targets_hidden_states():
     """Heads that read (next token, target hidden state) pairs.  Whatever they propose, the text is greedy
     decoding's.  The wiring is pinned with heads whose layer is silenced (zero output projections), so the

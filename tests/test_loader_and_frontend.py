@@ -799,3 +799,46 @@ def test_eagle_head_checkpoint_in_the_authors_layout(tmp_path):
     assert llm.engine.core.scheduler.spec_stats["drafted"] > 0
     ref.shutdown()
     llm.shutdown()
+
+
+def test_eagle3_head_checkpoint_in_the_authors_layout(tmp_path):
+    """Published EAGLE-3 heads: ``fc.weight`` (3 H wide), the layer under ``midlayer.`` with ``hidden_norm`` and a
+    q / k / v input of 2 H, ``norm.weight``, an LM head over the draft vocabulary, the int64 ``d2t`` offsets and a
+    boolean ``t2d`` mask, no embedding: the file loads through the safetensors reader (``d2t`` keeps its integers),
+    the embedding is the target's, and decoding with it is lossless.  (Synthetic tensors of those names and
+    shapes: no EAGLE-3 checkpoint ships with the reference.)"""
+    import json
+    import torch
+    from safetensors.torch import save_file
+    from vllm_distributed_amd import LLM, SamplingParams
+    from vllm_distributed_amd.config import ModelConfig
+    from vllm_distributed_amd.models.loader import dummy_weights_iterator, save_dummy_checkpoint
+    target_dir, head_dir = str(tmp_path / "target"), tmp_path / "head"
+    save_dummy_checkpoint(ModelConfig(model="llama-tiny", dtype="float32", load_format="dummy"), target_dir)
+    hmc = ModelConfig(model="eagle3-llama-tiny", dtype="float32", load_format="dummy")
+    tensors = {n: w.contiguous() for n, w in dummy_weights_iterator(hmc, torch.device("cpu"))}
+    assert {"fc.weight", "d2t", "norm.weight", "lm_head.weight", "midlayer.hidden_norm.weight",
+            "midlayer.self_attn.q_proj.weight"} <= set(tensors) and "embed_tokens.weight" not in tensors
+    assert tensors["d2t"].dtype == torch.int64 and tensors["midlayer.self_attn.q_proj.weight"].shape == (256, 512)
+    t2d = torch.zeros(512, dtype=torch.bool)
+    t2d[torch.arange(128) + tensors["d2t"]] = True
+    tensors["t2d"] = t2d
+    head_dir.mkdir()
+    save_file(tensors, str(head_dir / "model.safetensors"))
+    (head_dir / "config.json").write_text(json.dumps(hmc.hf_config))
+    kw = dict(model=target_dir, device="cpu", dtype="float32", max_model_len=128, num_gpu_blocks_override=64,
+              max_num_seqs=4)
+    prompts = [{"prompt_token_ids": list(range(30, 50))}, {"prompt_token_ids": [7, 8, 9] * 5}]
+    sp = SamplingParams(temperature=0.0, max_tokens=24, ignore_eos=True)
+    ref = LLM(**kw)
+    want = [o.outputs[0].token_ids for o in ref.generate(prompts, sp)]
+    llm = LLM(speculative_config={"method": "eagle3", "model": str(head_dir), "num_speculative_tokens": 2}, **kw)
+    runner = llm.engine.core.executor.driver.worker.model_runner
+    head = runner.draft.model
+    assert head.embed_tokens is runner.model.embed_tokens and head.lm_head is not runner.model.lm_head
+    assert torch.equal(head.d2t, tensors["d2t"]) and int(head.d2t[-1]) > 0
+    assert torch.equal(head.layers["0"].hidden_norm.weight, tensors["midlayer.hidden_norm.weight"])
+    assert [o.outputs[0].token_ids for o in llm.generate(prompts, sp)] == want
+    assert llm.engine.core.scheduler.spec_stats["drafted"] > 0
+    ref.shutdown()
+    llm.shutdown()

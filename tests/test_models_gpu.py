@@ -215,6 +215,7 @@ def test_draft_model_speculation_on_gpu_with_graph_decode():
 
 @pytest.mark.parametrize("target,spec", [
     ("llama-tiny", {"method": "eagle", "model": "eagle-llama-tiny", "num_speculative_tokens": 3}),
+    ("llama-tiny", {"method": "eagle3", "model": "eagle3-llama-tiny", "num_speculative_tokens": 3}),
     ("deepseek-v3-mtp-tiny", {"method": "mtp", "num_speculative_tokens": 2})])
 def test_hidden_state_heads_on_gpu(target, spec):
     """EAGLE head / DeepSeek multi-token-prediction module on the HIP kernels, next to a target whose
@@ -230,8 +231,12 @@ def test_hidden_state_heads_on_gpu(target, spec):
     ref.shutdown()
     pstate.destroy_model_parallel()
     llm = LLM(speculative_config=spec, **kw)
+    runner = llm.engine.core.executor.driver.worker.model_runner
+    assert runner.graphs, runner.graph_fallback_reason
     got = [o.outputs[0].token_ids for o in llm.generate(prompts, sp)]
     st = llm.engine.core.scheduler.spec_stats
+    if spec["method"] == "eagle3":       # the three taps of the graph's step travel with its output
+        assert all(g.aux is not None and g.aux.shape[1] == 3 * 256 for g in runner.graphs.values())
     llm.shutdown()
     pstate.destroy_model_parallel()
     assert st["drafted"] > 0 and [len(g) for g in got] == [32, 32]

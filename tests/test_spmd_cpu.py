@@ -124,10 +124,13 @@ def test_spmd_tp2_llava_with_images_matches_single_process():
 
 
 @pytest.mark.slow
-def test_spmd_tp2_eagle_head_speculation_matches_single_process():
-    """An EAGLE head sharded like the target, sharing its vocabulary-parallel embedding and LM head."""
+@pytest.mark.parametrize("method", ["eagle", "eagle3"])
+def test_spmd_tp2_eagle_head_speculation_matches_single_process(method):
+    """An EAGLE head sharded like the target, sharing its vocabulary-parallel embedding (and, EAGLE-1, its LM head;
+    an EAGLE-3 head's own one over the draft vocabulary is sharded by rows, and the target runs the tapped plain
+    layer loop on every rank)."""
     ref = _run(1)[0]
-    got = _run(2, spec='{"method": "eagle", "model": "eagle-llama-tiny", "num_speculative_tokens": 3}')
+    got = _run(2, spec='{"method": "%s", "model": "%s-llama-tiny", "num_speculative_tokens": 3}' % (method, method))
     assert got[0][0] == ref[0] and got[0][2] == ref[2] and got[1] == got[0]
 
 

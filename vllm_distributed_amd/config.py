@@ -397,6 +397,7 @@ class SpeculativeConfig:
       * ``draft_model``: a smaller model with the same vocabulary (``model``) runs on the workers next
         to the target, with its own KV cache over the same blocks, and proposes greedily;
       * ``eagle``: an EAGLE head (``model``: its checkpoint) drafts from the target's hidden states;
+      * ``eagle3``: an EAGLE-3 head does, from the residual stream at three depths of the target;
       * ``mtp`` (``deepseek_mtp``): the multi-token-prediction module inside a DeepSeek-V3 checkpoint does
         the same (``model`` defaults to the target's checkpoint);
       * ``medusa``: Medusa heads (``model``: their checkpoint), one per draft position, over the target's
@@ -409,7 +410,7 @@ class SpeculativeConfig:
     load_format: Optional[str] = None        # of the draft model; default: the target's
     quantization: Optional[str] = None       # of the draft model
 
-    METHODS = ("ngram", "draft_model", "eagle", "mtp", "medusa")
+    METHODS = ("ngram", "draft_model", "eagle", "eagle3", "mtp", "medusa")
 
     def __post_init__(self) -> None:
         if self.method in (None, "") or (self.method == "ngram" and self.model):
@@ -417,7 +418,7 @@ class SpeculativeConfig:
         self.method = {"[ngram]": "ngram", "deepseek_mtp": "mtp"}.get(self.method, self.method)
         if self.method not in self.METHODS:
             raise ValueError(f"speculative method {self.method!r} is not supported ({', '.join(self.METHODS)})")
-        if self.method in ("draft_model", "eagle", "medusa") and not self.model:
+        if self.method in ("draft_model", "eagle", "eagle3", "medusa") and not self.model:
             raise ValueError(f"speculative method {self.method} needs a \"model\"")
         if not 1 <= self.num_speculative_tokens <= 16:
             raise ValueError("num_speculative_tokens must be between 1 and 16")
@@ -431,7 +432,7 @@ class SpeculativeConfig:
 
     @property
     def reads_target_hidden(self) -> bool:
-        return self.method in ("eagle", "mtp", "medusa")
+        return self.method in ("eagle", "eagle3", "mtp", "medusa")
 
     @classmethod
     def from_value(cls, value) -> Optional["SpeculativeConfig"]:

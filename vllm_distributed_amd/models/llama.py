@@ -341,6 +341,10 @@ class LlamaForCausalLM(nn.Module):
         # forwards (eager calls and graph captures) per form of the TP collectives: get_stats reports it
         import collections
         self.path_counts = collections.Counter()
+        # layers whose INPUT (the residual stream in front of them) a draft head reads (EAGLE-3): a forward leaves
+        # them side by side in ``last_aux [T, len * H]``; such a model runs the plain layer loop on one stage
+        self.aux_hidden_layers: Tuple[int, ...] = ()
+        self.last_aux: Optional[torch.Tensor] = None
 
     # ---- what differs between the Llama-shaped families (see llama_variants.py)
     def layer_range(self, cfg: dict, vllm_config: VllmConfig) -> Tuple[int, int]:
@@ -379,10 +383,11 @@ class LlamaForCausalLM(nn.Module):
 
     def forward(self, input_ids: Optional[torch.Tensor], positions: torch.Tensor,
                 intermediate: Optional[IntermediateTensors] = None):
-        fused = self.fused_tp_mode(positions.shape[0]) if self.tp_fusions else None
+        aux = self.aux_hidden_layers
+        fused = self.fused_tp_mode(positions.shape[0]) if self.tp_fusions and not aux else None
         if fused is not None:
             return self.forward_fused_tp(input_ids, positions, intermediate, sharded=fused)
-        if intermediate is None and self.sequence_parallel_ok(positions.shape[0]):
+        if intermediate is None and not aux and self.sequence_parallel_ok(positions.shape[0]):
             self.path_counts["sequence_parallel"] += 1
             return self.forward_sequence_parallel(input_ids, positions)
         self.path_counts["plain"] += 1
@@ -391,8 +396,14 @@ class LlamaForCausalLM(nn.Module):
             residual = None
         else:
             hidden, residual = intermediate.hidden, intermediate.residual
-        for layer in self.layers.values():
+        taps = {}
+        for idx, layer in self.layers.items():
+            if aux and int(idx) in aux:
+                h = hidden if hidden is None or isinstance(hidden, torch.Tensor) else hidden.materialize()
+                taps[int(idx)] = residual if h is None else (h if residual is None else h + residual)
             hidden, residual = layer(positions, hidden, residual)
+        if aux:
+            self.last_aux = torch.cat([taps[i] for i in aux], dim=-1)
         if not self.is_last:
             if hidden is None:                  # the last GEMM already added its product into the residual
                 hidden = torch.zeros_like(residual)

@@ -56,6 +56,22 @@ def _weight_shapes(c: dict, arch: str) -> Dict[str, Tuple[int, ...]]:
                 out[f"blocks.{i}.layers.{j}.weight"], out[f"blocks.{i}.layers.{j}.bias"] = (h, h), (h,)
             out[f"lm_heads.{i}.weight"] = (c["vocab_size"], h)
         return out
+    if arch in ("Eagle3LlamaForCausalLM", "LlamaForCausalLMEagle3"):
+        # the names of the published EAGLE-3 heads: one decoder layer under "midlayer.", no embedding of its own
+        h, th = int(c["hidden_size"]), int(c.get("target_hidden_size") or c["hidden_size"])
+        heads, kvh = int(c["num_attention_heads"]), int(c.get("num_key_value_heads") or c["num_attention_heads"])
+        hd, inter = int(c.get("head_dim") or h // heads), int(c["intermediate_size"])
+        dv = int(c.get("draft_vocab_size") or c["vocab_size"])
+        out = {"fc.weight": (h, 3 * th), "norm.weight": (h,), "lm_head.weight": (dv, h), "d2t": (dv,)}
+        m = "midlayer."
+        out[m + "self_attn.q_proj.weight"] = (heads * hd, 2 * h)
+        out[m + "self_attn.k_proj.weight"] = out[m + "self_attn.v_proj.weight"] = (kvh * hd, 2 * h)
+        out[m + "self_attn.o_proj.weight"] = (h, heads * hd)
+        out[m + "mlp.gate_proj.weight"] = out[m + "mlp.up_proj.weight"] = (inter, h)
+        out[m + "mlp.down_proj.weight"] = (h, inter)
+        for n in ("input_layernorm", "hidden_norm", "post_attention_layernorm"):
+            out[m + n + ".weight"] = (h,)
+        return out
     if arch == "LlavaForConditionalGeneration":
         # the decoder's tensors under "language_model.", a CLIP vision tower and the two-layer projector
         text_arch = {"mistral": "MistralForCausalLM", "qwen2": "Qwen2ForCausalLM"}.get(c.get("model_type"), "LlamaForCausalLM")
@@ -451,6 +467,11 @@ def dummy_weights_iterator(mc: ModelConfig, device: torch.device,
             # the divisor keeps activations near unit variance
             yield base + ".weight_global_scale", torch.full((1,), 64.0 * 2.93 * 1.05 * in_f ** 0.5,
                                                             dtype=torch.float32, device=device)
+            continue
+        if name == "d2t":
+            # an EAGLE-3 draft vocabulary: a sorted random subset of the target's ids, as offsets from the draft ids
+            ids = torch.randperm(int(mc.hf_config["vocab_size"]), generator=gen, device=device)[:shape[0]].sort().values
+            yield name, (ids - torch.arange(shape[0], device=device)).to(torch.int64)
             continue
         if re.search(r"(layernorm|layer_norm|norm)\.weight$", name):
             w = 1.0 + 0.05 * (torch.rand(shape, generator=gen, device=device, dtype=torch.float32) - 0.5)

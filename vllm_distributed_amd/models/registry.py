@@ -61,6 +61,8 @@ _MODELS: Dict[str, Tuple[str, str]] = {
     "LlavaForConditionalGeneration": ("llava", "LlavaForConditionalGeneration"),
     # draft heads of speculative decoding (never a served model by themselves; worker/draft_model.py)
     "EagleLlamaForCausalLM": ("spec_heads", "EagleLlamaForCausalLM"),
+    "Eagle3LlamaForCausalLM": ("spec_heads", "Eagle3LlamaForCausalLM"),
+    "LlamaForCausalLMEagle3": ("spec_heads", "Eagle3LlamaForCausalLM"),
     "DeepSeekMTP": ("spec_heads", "DeepSeekMTP"),
     "MedusaModel": ("spec_heads", "MedusaModel"),
 }

@@ -83,6 +83,100 @@ class EagleLlamaForCausalLM(LlamaForCausalLM):
         return name
 
 
+class Eagle3LlamaForCausalLM(LlamaForCausalLM):
+    """EAGLE-3 (Li et al., 2025): the head reads the target's residual stream at THREE depths (by default before
+    layers 2, L / 2 and L - 3), folds them with ``fc`` (3 H_target -> H), and runs one decoder layer whose attention
+    takes ``[input_layernorm(embed) ; hidden_norm(hidden)]`` (2 H wide); ``norm`` + an LM head over a reduced draft
+    vocabulary give the logits, ``d2t[i]`` is the offset from draft id ``i`` to its target id.  Further drafts feed the
+    head its own pre-norm output.  Checkpoint names (``yuhuili/EAGLE3-*``): ``fc.weight``, ``midlayer.*`` (the
+    layer, with ``hidden_norm`` next to the usual two norms), ``norm.weight``, ``lm_head.weight``, ``d2t``, ``t2d``
+    (unused here), optionally ``embed_tokens.weight`` (else the target's).  vLLM serves it through
+    ``--speculative-config '{"method": "eagle3", ...}'``, the reference through the vLLM app it launches
+    (/root/reference/src/launch.py:429); no fixture ships with either: pinned against a PyTorch re-statement."""
+    optional_parameters = ("embed_tokens.weight",)
+
+    def __init__(self, vllm_config: VllmConfig):
+        mc = vllm_config.model_config
+        cfg = mc.hf_config
+        # (the base constructor builds no LM head for a tied model: this head's own one is over the draft vocabulary)
+        mc.hf_config = dict(cfg, tie_word_embeddings=True)
+        try:
+            super().__init__(vllm_config)
+        finally:
+            mc.hf_config = cfg
+        self.cfg = cfg
+        dtype = mc.torch_dtype
+        h = int(cfg["hidden_size"])
+        self.target_hidden = int(cfg.get("target_hidden_size") or h)
+        self.draft_vocab = int(cfg.get("draft_vocab_size") or cfg["vocab_size"])
+        eps = cfg.get("rms_norm_eps", 1e-6)
+        self.fc = ReplicatedLinear(3 * self.target_hidden, h, False, dtype, quant=False)
+        (layer,) = self.layers.values()
+        a = layer.self_attn
+        from .layers.linear import QKVParallelLinear
+        heads, kvh = int(cfg["num_attention_heads"]), int(cfg.get("num_key_value_heads") or cfg["num_attention_heads"])
+        a.qkv_proj = QKVParallelLinear(2 * h, a.head_dim, heads, kvh, bool(cfg.get("attention_bias", False)), dtype)
+        layer.hidden_norm = RMSNorm(h, eps, dtype)
+        self.lm_head = ParallelLMHead(self.draft_vocab, h, dtype)
+        self.tie = False
+        # draft id -> target id offset; identity until a checkpoint brings the table
+        self.register_buffer("d2t", torch.zeros(self.draft_vocab, dtype=torch.int64), persistent=False)
+        self.missing_optional: List[str] = []
+
+    # the target's layers whose INPUT (residual stream) the head reads, for a target of ``n`` layers
+    def aux_layers(self, n: int) -> Tuple[int, int, int]:
+        ids = (self.cfg.get("eagle_config") or {}).get("eagle_aux_hidden_state_layer_ids")
+        return tuple(int(i) for i in ids) if ids else (2, n // 2, n - 3)
+
+    def forward(self, input_ids: torch.Tensor, positions: torch.Tensor, hidden_in: torch.Tensor) -> torch.Tensor:
+        """``hidden_in``: the target's three residual streams side by side ``[T, 3 H_target]`` (a step's tokens), or
+        this head's previous output ``[T, H]``.  Returns the pre-norm feature: the input of ``compute_logits`` and
+        the ``hidden_in`` of the next draft step."""
+        hidden_in = hidden_in.to(self.fc.weight.dtype)
+        if hidden_in.shape[-1] == 3 * self.target_hidden:
+            hidden_in = self.fc(hidden_in)
+        (layer,) = self.layers.values()
+        embeds = layer.input_layernorm(self.embed_tokens(input_ids))
+        x = torch.cat([embeds, layer.hidden_norm(hidden_in)], dim=-1)
+        attn = layer.self_attn(positions, x)
+        hidden, residual = layer.post_attention_layernorm(attn, hidden_in)
+        hidden = layer.mlp(hidden)
+        return hidden + residual
+
+    def fused_tp_mode(self, num_tokens: int) -> Optional[bool]:
+        return None
+
+    def sequence_parallel_ok(self, num_tokens: int) -> bool:
+        return False
+
+    def compute_logits(self, feature: torch.Tensor) -> torch.Tensor:
+        return self.lm_head.logits(self.norm(feature))
+
+    def map_draft_ids(self, ids: torch.Tensor) -> torch.Tensor:
+        """Greedy picks over the draft vocabulary -> ids of the target's vocabulary."""
+        return (ids.long() + self.d2t[ids.long()]).to(ids.dtype)
+
+    def map_weight_name(self, name: str) -> Optional[str]:
+        if name.startswith("model."):
+            name = name[len("model."):]
+        if name == "t2d":
+            return None
+        if name == "d2t":
+            return name                          # (a buffer, not a parameter: taken by load_weights below)
+        if name.startswith("midlayer."):
+            name = f"layers.{self.start_layer}." + name[len("midlayer."):]
+        return super().map_weight_name(name)
+
+    def load_weights(self, weights):
+        def rest():
+            for name, w in weights:
+                if name in ("d2t", "model.d2t"):
+                    self.d2t.copy_(materialize(w).to(torch.int64))
+                    continue
+                yield name, w
+        return super().load_weights(rest())
+
+
 class DeepSeekMTP(DeepseekV3ForCausalLM):
     """One multi-token-prediction module of a DeepSeek-V3 checkpoint: the tensors under
     ``model.layers.<num_hidden_layers>.``.  Built as a one-layer instance of the target family, so the layer's

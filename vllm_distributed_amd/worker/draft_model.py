@@ -142,9 +142,12 @@ class HiddenStateProposer(DraftProposer):
     ``k - 1`` single-token passes follow, each fed the previous draft and the head's own previous feature.
     Embedding and LM head are the target's unless the head's checkpoint brings its own."""
     needs_hidden = True
+    # True: the head reads the target's residual stream at several depths (``model.last_aux``) instead of its output
+    wants_aux = False
 
     def _draft_model_config(self, vllm_config: VllmConfig) -> ModelConfig:
         sc, mc = vllm_config.speculative_config, vllm_config.model_config
+        self.wants_aux = sc.method == "eagle3"
         if sc.method == "mtp":
             if int(mc.hf_config.get("num_nextn_predict_layers") or 0) < 1:
                 raise ValueError(f"{mc.model} has no multi-token-prediction module (num_nextn_predict_layers)")
@@ -156,13 +159,27 @@ class HiddenStateProposer(DraftProposer):
         if dmc.hf_config.get("model_type") not in ("llama", "mistral", "qwen2", "qwen3"):
             raise ValueError(f"EAGLE head {sc.model!r}: model_type {dmc.hf_config.get('model_type')!r} is not one "
                              f"of the Llama-shaped families this head is written for")
-        dmc.hf_config = dict(dmc.hf_config, architectures=["EagleLlamaForCausalLM"])
+        arch = "Eagle3LlamaForCausalLM" if sc.method == "eagle3" else "EagleLlamaForCausalLM"
+        dmc.hf_config = dict(dmc.hf_config, architectures=[arch])
         return dmc
 
     def bind_target(self, target: torch.nn.Module) -> None:
         """Share what the head's checkpoint did not bring."""
         head = self.model
-        if int(head.cfg["hidden_size"]) != int(target.cfg["hidden_size"]):
+        if self.wants_aux:
+            if int(head.target_hidden) != int(target.cfg["hidden_size"]):
+                raise ValueError(f"EAGLE-3 head written for a target of width {head.target_hidden}, this one is "
+                                 f"{target.cfg['hidden_size']} wide")
+            if not (getattr(target, "is_first", True) and getattr(target, "is_last", True)) \
+                    or not hasattr(target, "aux_hidden_layers"):
+                raise ValueError("an EAGLE-3 head needs a Llama-shaped target on one pipeline stage")
+            n = int(target.cfg["num_hidden_layers"])
+            taps = tuple(head.aux_layers(n))
+            if len(taps) != 3 or not all(0 <= i < n for i in taps):
+                raise ValueError(f"EAGLE-3 reads three of the target's {n} layers, got {taps}")
+            target.aux_hidden_layers = taps
+        if int(head.cfg["hidden_size"]) != int(target.cfg["hidden_size"]) and not (
+                self.wants_aux and "embed_tokens.weight" not in set(getattr(head, "missing_optional", ()))):
             raise ValueError(f"draft head width {head.cfg['hidden_size']} != target width {target.cfg['hidden_size']}")
         missing = set(getattr(head, "missing_optional", ()))
         if "embed_tokens.weight" in missing:
@@ -197,7 +214,8 @@ class HiddenStateProposer(DraftProposer):
         limit = np.minimum(num_blocks.astype(np.int64) * block_size, max_model_len - 1)
         room = np.clip(limit - start_pos, 0, self.k - 1).astype(np.int64)       # passes a row may still run
         steps = int(room.max())
-        cur = self.model.compute_logits(feats).float().argmax(dim=-1).to(torch.int32)
+        to_target = getattr(self.model, "map_draft_ids", None) or (lambda ids: ids)     # (a reduced draft vocabulary)
+        cur = to_target(self.model.compute_logits(feats).float().argmax(dim=-1).to(torch.int32))
         outs = [cur]
         if steps > 0:
             width = int(min(block_table.shape[1], (int((start_pos + steps).max()) + block_size - 1) // block_size + 1))
@@ -221,7 +239,7 @@ class HiddenStateProposer(DraftProposer):
                 feats = self.model(cur, positions, feats)
             finally:
                 set_forward_context(None)
-            cur = self.model.compute_logits(feats).float().argmax(dim=-1).to(torch.int32)
+            cur = to_target(self.model.compute_logits(feats).float().argmax(dim=-1).to(torch.int32))
             outs.append(cur)
         toks = torch.stack(outs, dim=1).cpu().numpy()            # [r, 1 + steps]: the one host sync of the loop
         return [toks[j, :1 + int(room[j])].tolist() for j in range(r)]

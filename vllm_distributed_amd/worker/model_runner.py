@@ -220,6 +220,7 @@ class DecodeGraph:
         self.batch_size = batch_size
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.output: Optional[Any] = None
+        self.aux: Optional[torch.Tensor] = None      # the model's ``last_aux`` of the captured step (EAGLE-3)
 
 
 class ModelRunner:
@@ -297,6 +298,8 @@ class ModelRunner:
                 cls = MedusaProposer if sc.method == "medusa" else HiddenStateProposer
                 self.draft = cls(self.vllm_config, self.device)
                 self.draft.bind_target(self.model)
+                if getattr(self.draft, "wants_aux", False):
+                    self.comm_stream = None       # (the tapped layer loop is the plain one: no overlapped form)
             else:
                 self.draft = DraftProposer(self.vllm_config, self.device)
         if self.vllm_config.lora_config is not None:
@@ -735,6 +738,8 @@ class ModelRunner:
         shifted.index_copy_(0, self._to_dev(ends, torch.int64), self._to_dev(follow.astype(np.int32)).to(shifted.dtype))
         if sel is not None:
             shifted.index_copy_(0, self._to_dev(smp_idx, torch.int64), tokens.to(shifted.dtype))
+        if getattr(self.draft, "wants_aux", False):
+            hidden = self.model.last_aux          # the residual stream at three depths, side by side
         feats = self.draft.run_step_tokens(md, shifted, positions[:total], hidden[:total])
         if sel is None:
             return None
@@ -1244,6 +1249,7 @@ class ModelRunner:
         # invalidate this capture
         with torch.cuda.graph(g.graph, pool=self.graph_pool, capture_error_mode="thread_local"):
             g.output = run()
+            g.aux = getattr(self.model, "last_aux", None)
         set_forward_context(None)
         if self.graph_pool is None:
             self.graph_pool = g.graph.pool()
@@ -1279,6 +1285,8 @@ class ModelRunner:
                 return None
             return g.output
         g.graph.replay()
+        if g.aux is not None:
+            self.model.last_aux = g.aux
         return g.output
 
     # ----------------------------------------------------------------- warmup
