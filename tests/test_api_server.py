@@ -606,7 +606,7 @@ def test_chat_completions_with_image_parts():
                                                           {"type": "text", "text": text}]}],
                 "max_tokens": 8, "temperature": 0, "ignore_eos": True}
 
-    async def main(model, expect_images):
+    async def main(model, expect_images, image_tokens=16):
         args = build_parser().parse_args(
             (f"serve {model} --device cpu --dtype float32 --max-model-len 256 --block-size 16 "
              "--num-gpu-blocks-override 64 --port 0 --disable-frontend-multiprocessing").split())
@@ -629,7 +629,8 @@ def test_chat_completions_with_image_parts():
                 text = [x["choices"][0]["message"]["content"] for x in (a, b, a2)]
                 assert text[0] == text[2] and text[0] != text[1]
                 # one placeholder line ("<511>" + newline) became 16 image positions + the newline
-                assert a["usage"]["prompt_tokens"] == plain["usage"]["prompt_tokens"] + 16 + 1
+                # (an any-resolution model: as many as the 40 x 50 picture's aspect leaves of its tile grid)
+                assert a["usage"]["prompt_tokens"] == plain["usage"]["prompt_tokens"] + image_tokens + 1
                 r = await c.post("/v1/chat/completions", json=body("https://example.com/cat.png"))
                 assert r.status_code == 400 and "data: URL" in r.text
                 r = await c.post("/v1/chat/completions", json=body("data:image/png;base64,AAAA"))
@@ -637,6 +638,12 @@ def test_chat_completions_with_image_parts():
                 t = (await c.post("/tokenize", json={"messages": body(data_url(1))["messages"]})).json()
                 assert t["tokens"].count(511) == 1
     asyncio.run(main("llava-tiny", True))
+    pstate.destroy_model_parallel()
+    from vllm_distributed_amd.multimodal import anyres_tokens
+    n = anyres_tokens({"vision_config": {"image_size": 28, "patch_size": 7},
+                       "image_grid_pinpoints": [[28, 56], [56, 28], [56, 56], [84, 28], [28, 84]]}, (40, 50))
+    assert n > 16
+    asyncio.run(main("llava-next-tiny", True, n))
     pstate.destroy_model_parallel()
     asyncio.run(main("llama-tiny", False))
     pstate.destroy_model_parallel()

@@ -249,6 +249,91 @@ def test_llava_matches_transformers_with_images(tmp_path):
         assert len(outs[0].prompt_token_ids) == 6 + 16 and len(outs[1].prompt_token_ids) == 5 + 32
 
 
+def test_llava_next_matches_transformers_with_images_of_several_aspects(tmp_path):
+    """A small random LLaVA-NeXT against ``transformers.LlavaNextForConditionalGeneration`` on the same weights:
+    wide, tall and near-square images (each picks another of the tiled resolutions and unpads another side), one
+    and two images per prompt, whole and in 8-token chunks.  The views come from this package's own any-resolution
+    preprocessing, which is compared with transformers' image processor first; the number of placeholder tokens
+    per image comes from ``multimodal.anyres_tokens`` (transformers refuses a prompt whose count is off)."""
+    import numpy as np
+    from PIL import Image
+    if not hasattr(transformers, "LlavaNextForConditionalGeneration"):
+        pytest.skip("transformers has no LLaVA-NeXT")
+    from vllm_distributed_amd.multimodal import AnyResImageProcessor, ClipImageProcessor, anyres_tokens
+    pins = [[28, 56], [56, 28], [56, 56], [84, 28], [28, 84]]
+    text = transformers.LlamaConfig(**dict(BASE, rope_theta=10000.0))
+    vision = transformers.CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=3, num_attention_heads=4,
+                                           image_size=28, patch_size=7, projection_dim=16)
+    cfg = transformers.LlavaNextConfig(vision_config=vision, text_config=text, image_token_index=319,
+                                       vision_feature_layer=-2, vision_feature_select_strategy="default",
+                                       image_grid_pinpoints=pins)
+    torch.manual_seed(78)
+    model = transformers.LlavaNextForConditionalGeneration(cfg).eval().float()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    model.save_pretrained(str(tmp_path), safe_serialization=True)
+    rng = np.random.default_rng(4)
+    imgs = [Image.fromarray((rng.random(s) * 255).astype("uint8")) for s in ((40, 90, 3), (70, 29, 3), (50, 46, 3), (20, 37, 3))]
+    proc = AnyResImageProcessor(ClipImageProcessor(28, 28), pins)
+    mine = [proc(im) for im in imgs]
+    sizes = [(im.size[1], im.size[0]) for im in imgs]
+    n_tok = [anyres_tokens({"vision_config": {"image_size": 28, "patch_size": 7}, "image_grid_pinpoints": pins}, s) for s in sizes]
+    assert len(set(m.shape[0] for m in mine)) > 1 and len(set(n_tok)) > 2, (n_tok, [m.shape for m in mine])
+    try:
+        hf_proc = transformers.LlavaNextImageProcessor(size={"shortest_edge": 28}, crop_size={"height": 28, "width": 28},
+                                                       image_grid_pinpoints=pins)
+        for im, px, sz in zip(imgs, mine, sizes):
+            ref = hf_proc(images=im, return_tensors="np")
+            assert tuple(ref["image_sizes"][0]) == sz and ref["pixel_values"][0].shape == px.shape
+            assert np.abs(ref["pixel_values"][0] - px.astype(np.float32)).max() < 2e-3     # (fp16 rounding)
+    except (ImportError, AttributeError):
+        pass                         # (no PIL-based image processor in this transformers build)
+    cases = [([5, 9, 319, 17, 33, 2, 90], [0]), ([7, 319, 300, 2, 319, 41, 8], [1, 2]), ([3, 319, 4], [3]),
+             (list(range(10, 40)), [])]
+    ref_lp, ref_tokens = [], []
+    with torch.no_grad():
+        for ids, pics in cases:
+            full, k = [], 0
+            for t in ids:
+                if t == 319:
+                    full += [319] * n_tok[pics[k]]
+                    k += 1
+                else:
+                    full.append(t)
+            kw = {}
+            if pics:
+                most = max(mine[i].shape[0] for i in pics)
+                px = np.zeros((len(pics), most, 3, 28, 28), dtype=np.float32)
+                for j, i in enumerate(pics):
+                    px[j, :mine[i].shape[0]] = mine[i].astype(np.float32)
+                kw = {"pixel_values": torch.from_numpy(px), "image_sizes": torch.tensor([sizes[i] for i in pics])}
+            x = torch.tensor([full])
+            ref_lp.append(model(input_ids=x, **kw).logits[0, -1].float().log_softmax(-1))
+            gen = model.generate(input_ids=x, max_new_tokens=4, do_sample=False, pad_token_id=0, **kw)
+            ref_tokens.append(gen[0, len(full):].tolist())
+    prompts = [{"prompt_token_ids": ids, **({"multi_modal_data": {"image": [imgs[i] for i in pics]}} if pics else {})}
+               for ids, pics in cases]
+    sp = SamplingParams(temperature=0.0, max_tokens=4, ignore_eos=True, logprobs=10)
+    for extra in ({}, {"max_num_batched_tokens": 8}):
+        llm = LLM(model=str(tmp_path), dtype="float32", device="cpu", max_model_len=256, num_gpu_blocks_override=64,
+                  max_num_seqs=8, **extra)
+        try:
+            outs = llm.generate(prompts, sp)
+        finally:
+            llm.shutdown()
+            pstate.destroy_model_parallel()
+        for out, lp, toks in zip(outs, ref_lp, ref_tokens):
+            got = out.outputs[0].logprobs[0]
+            top = torch.topk(lp, 5).indices.tolist()
+            assert set(top) <= set(got), (top, sorted(got))
+            for t in top:
+                assert abs(got[t] - lp[t].item()) < 3e-3, (t, got[t], lp[t].item())
+            assert list(out.outputs[0].token_ids) == toks
+        assert len(outs[0].prompt_token_ids) == 6 + n_tok[0] and len(outs[1].prompt_token_ids) == 5 + n_tok[1] + n_tok[2]
+
+
 @pytest.mark.parametrize("name", ["deepseek-v3", "deepseek-v2"])
 @pytest.mark.parametrize("latent", [True, False])
 def test_deepseek_latent_and_expanded_caches_match_transformers(name, latent, tmp_path, monkeypatch):

@@ -87,12 +87,14 @@ def test_model_family_on_gpu_tracks_cpu_reference(model, tmp_path):
             assert max(abs(la[t] - lb[t]) for t in common) < tol, (model, step)
 
 
-def test_llava_with_images_on_gpu_tracks_cpu_reference(tmp_path):
+@pytest.mark.parametrize("name", ["llava-tiny", "llava-next-tiny"])
+def test_llava_with_images_on_gpu_tracks_cpu_reference(name, tmp_path):
     """Vision tower + projector + decoder in bf16 on the GPU (the decoder on the HIP kernels, prompts chunked at
-    32 tokens so that a chunk boundary falls inside each image) against the fp32 CPU run of the same checkpoint."""
+    32 tokens so that a chunk boundary falls inside each image) against the fp32 CPU run of the same checkpoint.
+    LLaVA-NeXT: base view + tiles per image, stitched, unpadded and closed with newline embeddings on the device."""
     import numpy as np
     from PIL import Image
-    mc = ModelConfig(model="llava-tiny", dtype="float32", load_format="dummy")
+    mc = ModelConfig(model=name, dtype="float32", load_format="dummy")
     save_dummy_checkpoint(mc, str(tmp_path))
     rng = np.random.default_rng(11)
     pics = [Image.fromarray((rng.random(s) * 255).astype("uint8")) for s in ((40, 60, 3), (31, 28, 3))]
@@ -112,7 +114,11 @@ def test_llava_with_images_on_gpu_tracks_cpu_reference(tmp_path):
         la, lb = a.outputs[0].logprobs[0], b.outputs[0].logprobs[0]
         common = set(la) & set(lb)
         assert len(common) >= 8 and max(abs(la[t] - lb[t]) for t in common) < 0.15
-    assert len(outs["cuda"][1].prompt_token_ids) == 4 + 32
+    if name == "llava-tiny":
+        assert len(outs["cuda"][1].prompt_token_ids) == 4 + 32
+    else:
+        assert len(outs["cuda"][1].prompt_token_ids) > 4 + 2 * 32      # 16 base patches + the tile grid, per image
+        assert [len(o.prompt_token_ids) for o in outs["cuda"]] == [len(o.prompt_token_ids) for o in outs["cpu"]]
 
 
 def test_deepseek_fresh_prompts_attend_in_the_expanded_form(monkeypatch):

@@ -113,13 +113,14 @@ def test_spmd_tp2_draft_model_speculation_matches_single_process():
 
 
 @pytest.mark.slow
-def test_spmd_tp2_llava_with_images_matches_single_process():
+@pytest.mark.parametrize("name", ["llava-tiny", "llava-next-tiny"])
+def test_spmd_tp2_llava_with_images_matches_single_process(name):
     """The vision tower is replicated, the decoder sharded: steps that carry image rows leave the fused /
     sequence-parallel forms of the embedding (forced here) for the plain one, and TP=2 reproduces TP=1."""
-    ref = _run(1, model="llava-tiny", images=True)[0]
-    plain = _run(1, model="llava-tiny")[0]
+    ref = _run(1, model=name, images=True)[0]
+    plain = _run(1, model=name)[0]
     assert ref[2] == plain[2] and ref[0] != plain[0]
-    got = _run(2, model="llava-tiny", images=True, sp="force")
+    got = _run(2, model=name, images=True, sp="force")
     assert got[0] == ref and got[1] == ref
 
 

@@ -86,7 +86,7 @@ def normalize_hf_config(cfg: Dict[str, Any]) -> None:
     """Key spellings that differ between ``transformers`` releases, mapped onto the ones the model
     code reads (in place): newer releases write ``num_local_experts`` / ``dtype`` / a ``rope_parameters``
     block where older checkpoints have ``num_experts`` / ``torch_dtype`` / ``rope_theta`` + ``rope_scaling``."""
-    if cfg.get("model_type") == "llava" and "mm_model_type" not in cfg:
+    if cfg.get("model_type") in ("llava", "llava_next") and "mm_model_type" not in cfg:
         # a vision-language wrapper: the decoder's keys move to the top level, where every accessor reads them
         # (transformers fills an absent text_config / vision_config with the Llama-7B / CLIP ViT-B defaults)
         given = dict(cfg.get("text_config") or {})
@@ -94,7 +94,13 @@ def normalize_hf_config(cfg: Dict[str, Any]) -> None:
         defaults = {"model_type": "llama", "hidden_size": 4096, "intermediate_size": 11008, "num_hidden_layers": 32,
                     "num_attention_heads": 32, "rms_norm_eps": 1e-6, "vocab_size": 32000,
                     "max_position_embeddings": 2048, "rope_theta": 10000.0, "tie_word_embeddings": False}
-        cfg["mm_model_type"] = "llava"
+        cfg["mm_model_type"] = cfg["model_type"]
+        if cfg["mm_model_type"] == "llava_next":
+            # (transformers' defaults: CLIP ViT-L/14 at 336 and these five tiled resolutions)
+            cfg.setdefault("image_grid_pinpoints", [[336, 672], [672, 336], [672, 672], [1008, 336], [336, 1008]])
+            cfg["vision_config"] = dict({"hidden_size": 1024, "intermediate_size": 4096, "num_hidden_layers": 24,
+                                         "num_attention_heads": 16, "image_size": 336, "patch_size": 14},
+                                        **(cfg.get("vision_config") or {}))
         cfg["model_type"] = given.get("model_type", "llama")
         for k, v in given.items():              # what the decoder's own config says wins over the wrapper's copy
             cfg[k] = v
@@ -104,7 +110,8 @@ def normalize_hf_config(cfg: Dict[str, Any]) -> None:
         cfg["vision_config"] = dict({"hidden_size": 768, "intermediate_size": 3072, "num_hidden_layers": 12,
                                      "num_attention_heads": 12, "image_size": 224, "patch_size": 32,
                                      "layer_norm_eps": 1e-5, "hidden_act": "quick_gelu"}, **(cfg.get("vision_config") or {}))
-        cfg.setdefault("architectures", ["LlavaForConditionalGeneration"])
+        cfg.setdefault("architectures", ["LlavaNextForConditionalGeneration" if cfg["mm_model_type"] == "llava_next"
+                                         else "LlavaForConditionalGeneration"])
     # GPT-2 era spellings
     for old, new in (("n_embd", "hidden_size"), ("n_head", "num_attention_heads"), ("n_layer", "num_hidden_layers"),
                      ("n_positions", "max_position_embeddings"),

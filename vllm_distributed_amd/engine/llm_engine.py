@@ -139,12 +139,19 @@ class LLMEngine:
             raise ValueError("multi_modal_data: only {\"image\": ...} is supported")
         if not isinstance(images, (list, tuple)):
             images = [images]
+        anyres = cfg.get("mm_model_type") == "llava_next"
         if getattr(self, "_image_processor", None) is None:
             from ..config import resolve_model_path
             self._image_processor = mm.ClipImageProcessor.from_model(resolve_model_path(self.model_config.model),
                                                                      cfg["vision_config"])
-        pixels = [self._image_processor(mm.load_image(im)) for im in images]
+            if anyres:
+                self._image_processor = mm.AnyResImageProcessor(self._image_processor, cfg["image_grid_pinpoints"])
+        loaded = [mm.load_image(im) for im in images]
+        pixels = [self._image_processor(im) for im in loaded]
         token = int(cfg.get("image_token_index", cfg.get("image_token_id", 32000)))
+        if anyres:          # as many embeddings as the image's own aspect leaves of its tile grid
+            sizes = [(im.size[1], im.size[0]) for im in loaded]
+            return mm.expand_image_placeholders(ids, pixels, token, [mm.anyres_tokens(cfg, s) for s in sizes], sizes)
         return mm.expand_image_placeholders(ids, pixels, token, mm.tokens_per_image(cfg))
 
     def _resolve_token_lists(self, params: SamplingParams) -> None:

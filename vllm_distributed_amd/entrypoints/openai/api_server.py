@@ -283,6 +283,7 @@ async def init_app_state(engine: AsyncLLM, vllm_config, state, args: argparse.Na
     # tokenizer's spelling of the placeholder token in the prompt text
     hf = vllm_config.model_config.hf_config
     state.takes_images = hf.get("mm_model_type") is not None
+    state.anyres_cfg = hf if hf.get("mm_model_type") == "llava_next" else None
     state.image_placeholder = "<image>"
     if state.takes_images:
         from ...multimodal import tokens_per_image
@@ -813,7 +814,15 @@ def _register_routes(app: FastAPI, dev_mode: bool = False) -> None:
         n_prompt = len(prompt_ids)
         if images:
             full_prompt["multi_modal_data"] = {"image": images}
-            n_prompt += len(images) * (st.tokens_per_image - 1)     # each placeholder widens to one image's embeddings
+            # each placeholder widens to its image's embeddings (any-resolution models: as many as its aspect leaves)
+            if st.anyres_cfg is not None:
+                from ...multimodal import anyres_tokens, load_image
+                try:
+                    n_prompt += sum(anyres_tokens(st.anyres_cfg, load_image(im).size[::-1]) - 1 for im in images)
+                except ValueError as e:
+                    return _error(str(e))
+            else:
+                n_prompt += len(images) * (st.tokens_per_image - 1)
         gens = [engine.generate(full_prompt, _nth_params(sp, j),
                                 rid if n == 1 else f"{rid}-{j}", req.priority,
                                 st.loras.get(req.model) if req.model else None) for j in range(n)]

@@ -207,3 +207,46 @@ class LlavaForConditionalGeneration(LlamaForCausalLM):
         else:
             return False
         return True
+
+
+class LlavaNextForConditionalGeneration(LlavaForConditionalGeneration):
+    """LLaVA-NeXT (LLaVA-1.6): any-resolution input.  An image arrives as a base view plus the tiles of the best of
+    ``image_grid_pinpoints`` (``multimodal.AnyResImageProcessor``); every view goes through the tower and the
+    projector, the tiles' patch grids are stitched into one, the padding the image got on its way to that resolution
+    is cut off again, the learned ``image_newline`` vector closes every row, and the base view's patches go in front.
+    The number of embeddings therefore depends on the image's aspect (``multimodal.anyres_tokens``).  The reference
+    serves it through the vLLM app it launches (/root/reference/src/launch.py:429); pinned against transformers in
+    ``tests/test_hf_parity.py``."""
+
+    def __init__(self, vllm_config: VllmConfig):
+        super().__init__(vllm_config)
+        if self.select_full:
+            raise NotImplementedError("LLaVA-NeXT with vision_feature_select_strategy=full")
+        if self.is_first:
+            dtype = vllm_config.model_config.torch_dtype
+            self.image_newline = nn.Parameter(torch.empty(self.cfg["hidden_size"], dtype=dtype), requires_grad=False)
+
+    @torch.inference_mode()
+    def encode_anyres_image(self, pixels: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
+        """``[1 + tiles, 3, S, S]`` views of one image of ``size`` (height, width) -> ``[tokens, hidden]``."""
+        from ..multimodal import anyres_unpadded_grid, select_best_resolution
+        feats = self.encode_images(pixels)                      # [1 + tiles, per * per, H]
+        v = self.cfg["vision_config"]
+        side = int(v["image_size"])
+        per = side // int(v["patch_size"])
+        bh, bw = select_best_resolution(size, self.cfg["image_grid_pinpoints"])
+        gh, gw = bh // side, bw // side
+        if feats.shape[0] != 1 + gh * gw or feats.shape[1] != per * per:
+            raise RuntimeError(f"{feats.shape[0]} views of {feats.shape[1]} patches for a {gh} x {gw} tile grid")
+        h = feats.shape[-1]
+        grid = feats[1:].view(gh, gw, per, per, h).permute(0, 2, 1, 3, 4).reshape(gh * per, gw * per, h)
+        rows, cols = anyres_unpadded_grid(size, (gh * per, gw * per))
+        top, left = (gh * per - rows) // 2, (gw * per - cols) // 2
+        grid = grid[top:top + rows, left:left + cols]
+        newline = self.image_newline.to(grid.dtype).view(1, 1, h).expand(rows, 1, h)
+        return torch.cat([feats[0], torch.cat([grid, newline], dim=1).reshape(rows * (cols + 1), h)], dim=0)
+
+    def map_weight_name(self, name: str) -> Optional[str]:
+        if name in ("image_newline", "model.image_newline"):
+            return "image_newline"
+        return super().map_weight_name(name)

@@ -72,6 +72,10 @@ def _weight_shapes(c: dict, arch: str) -> Dict[str, Tuple[int, ...]]:
         for n in ("input_layernorm", "hidden_norm", "post_attention_layernorm"):
             out[m + n + ".weight"] = (h,)
         return out
+    if arch == "LlavaNextForConditionalGeneration":
+        out = _weight_shapes(c, "LlavaForConditionalGeneration")
+        out["image_newline"] = (c["hidden_size"],)
+        return out
     if arch == "LlavaForConditionalGeneration":
         # the decoder's tensors under "language_model.", a CLIP vision tower and the two-layer projector
         text_arch = {"mistral": "MistralForCausalLM", "qwen2": "Qwen2ForCausalLM"}.get(c.get("model_type"), "LlamaForCausalLM")

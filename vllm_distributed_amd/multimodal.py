@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import base64
 import hashlib
+import math
 import io
 import json
 import os
@@ -35,8 +36,9 @@ class MultiModalInput:
     """One image of a request: where its placeholder tokens sit in the prompt, and its pixels."""
     offset: int
     length: int
-    pixel_values: np.ndarray            # [3, H, W] float16, normalised
+    pixel_values: np.ndarray            # [3, H, W] float16, normalised ([1 + tiles, 3, H, W]: any-resolution models)
     mm_hash: int
+    image_size: Optional[Tuple[int, int]] = None      # (height, width) of the original image, where the model unpads
 
 
 def load_image(src: Any):
@@ -110,6 +112,75 @@ class ClipImageProcessor:
         return ((x - self.mean) / self.std).astype(np.float16)
 
 
+# ------------------------------------------------------------------ any-resolution tiling (LLaVA-NeXT)
+def select_best_resolution(size: Tuple[int, int], candidates: Sequence[Sequence[int]]) -> Tuple[int, int]:
+    """The (height, width) among ``candidates`` that keeps most of the image's pixels after an aspect-preserving
+    fit, and wastes the least area among those (LLaVA-NeXT's ``image_grid_pinpoints`` rule)."""
+    h, w = size
+    best, best_fit, best_waste = None, -1, None
+    for ch, cw in candidates:
+        scale = min(cw / w, ch / h)
+        dw, dh = int(w * scale), int(h * scale)
+        fit = min(dw * dh, w * h)
+        waste = cw * ch - fit
+        if fit > best_fit or (fit == best_fit and waste < best_waste):
+            best, best_fit, best_waste = (int(ch), int(cw)), fit, waste
+    return best
+
+
+def anyres_unpadded_grid(size: Tuple[int, int], grid: Tuple[int, int]) -> Tuple[int, int]:
+    """Rows and columns of a ``grid`` (rows, columns) of patch features that are left once the padding the image
+    got on its way to the tiled resolution is cut off again (the model's ``unpad_image``)."""
+    oh, ow = size
+    ch, cw = grid
+    if ow / oh > cw / ch:
+        nh = int(round(oh * (cw / ow), 7))
+        pad = (ch - nh) // 2
+        return ch - 2 * pad, cw
+    nw = int(round(ow * (ch / oh), 7))
+    pad = (cw - nw) // 2
+    return ch, cw - 2 * pad
+
+
+def anyres_tokens(cfg: Dict[str, Any], size: Tuple[int, int]) -> int:
+    """Embeddings one image of ``size`` (height, width) yields: the base view's patches, then the unpadded tile
+    grid with one ``image_newline`` per row."""
+    v = cfg["vision_config"]
+    side, per = int(v.get("image_size", 336)), int(v.get("image_size", 336)) // int(v.get("patch_size", 14))
+    bh, bw = select_best_resolution(size, cfg["image_grid_pinpoints"])
+    rows, cols = anyres_unpadded_grid(size, (bh // side * per, bw // side * per))
+    return per * per + rows * (cols + 1)
+
+
+class AnyResImageProcessor:
+    """LLaVA-NeXT preprocessing: the image resized into the best of the model's tiled resolutions (aspect kept,
+    padded with black to the full grid) and cut into tiles, behind a base view of the whole image squeezed to one
+    tile; every view then gets the CLIP preprocessing.  Returns ``[1 + tiles, 3, S, S]`` float16."""
+
+    def __init__(self, clip: ClipImageProcessor, pinpoints: Sequence[Sequence[int]]):
+        self.clip, self.pinpoints = clip, [tuple(int(x) for x in p) for p in pinpoints]
+
+    def __call__(self, image) -> np.ndarray:
+        from PIL import Image
+        img = image.convert("RGB")
+        w, h = img.size
+        side = self.clip.crop
+        bh, bw = select_best_resolution((h, w), self.pinpoints)
+        scale_w, scale_h = bw / w, bh / h
+        if scale_w < scale_h:
+            nw, nh = bw, min(math.ceil(h * scale_w), bh)
+        else:
+            nh, nw = bh, min(math.ceil(w * scale_h), bw)
+        resized = img.resize((nw, nh), Image.BICUBIC)
+        canvas = Image.new("RGB", (bw, bh), (0, 0, 0))
+        canvas.paste(resized, ((bw - nw) // 2, (bh - nh) // 2))
+        views = [img.resize((side, side), Image.BICUBIC)]
+        for top in range(0, bh, side):
+            for left in range(0, bw, side):
+                views.append(canvas.crop((left, top, left + side, top + side)))
+        return np.stack([self.clip(v) for v in views])
+
+
 def image_hash(pixels: np.ndarray) -> int:
     return int.from_bytes(hashlib.blake2b(np.ascontiguousarray(pixels).tobytes(), digest_size=8).digest(), "little")
 
@@ -120,15 +191,22 @@ def tokens_per_image(cfg: Dict[str, Any]) -> int:
     return n + (1 if cfg.get("vision_feature_select_strategy", "default") == "full" else 0)
 
 
-def expand_image_placeholders(ids: Sequence[int], images: List[np.ndarray], image_token: int,
-                              per_image: int) -> Tuple[List[int], List[MultiModalInput]]:
-    """Every ``image_token`` in ``ids`` becomes ``per_image`` copies; the k-th occurrence belongs to the k-th
-    image.  A prompt whose placeholders are already expanded (runs of exactly ``per_image``) is taken as it is."""
+def expand_image_placeholders(ids: Sequence[int], images: List[np.ndarray], image_token: int, per_image,
+                              sizes: Optional[List[Tuple[int, int]]] = None) -> Tuple[List[int], List[MultiModalInput]]:
+    """Every ``image_token`` in ``ids`` becomes as many copies as its image yields embeddings (``per_image``: one
+    number, or one per image); the k-th occurrence belongs to the k-th image.  A prompt whose placeholders are
+    already expanded (runs of exactly those lengths) is taken as it is."""
+    counts = [int(per_image)] * len(images) if isinstance(per_image, int) else [int(c) for c in per_image]
+    sizes = sizes or [None] * len(images)
     where = [i for i, t in enumerate(ids) if t == image_token]
-    if len(where) == len(images) * per_image and per_image > 1 and images:
-        runs = [where[k * per_image:(k + 1) * per_image] for k in range(len(images))]
-        if all(r[-1] - r[0] == per_image - 1 for r in runs):
-            return list(ids), [MultiModalInput(r[0], per_image, px, image_hash(px)) for r, px in zip(runs, images)]
+    if images and len(where) == sum(counts) and min(counts) > 1:
+        runs, at = [], 0
+        for c in counts:
+            runs.append(where[at:at + c])
+            at += c
+        if all(r[-1] - r[0] == c - 1 for r, c in zip(runs, counts)):
+            return list(ids), [MultiModalInput(r[0], c, px, image_hash(px), sz)
+                               for r, c, px, sz in zip(runs, counts, images, sizes)]
     if len(where) != len(images):
         raise ValueError(f"the prompt has {len(where)} image placeholder(s) for {len(images)} image(s)")
     out: List[int] = []
@@ -136,8 +214,8 @@ def expand_image_placeholders(ids: Sequence[int], images: List[np.ndarray], imag
     k = 0
     for t in ids:
         if t == image_token:
-            items.append(MultiModalInput(len(out), per_image, images[k], image_hash(images[k])))
-            out.extend([image_token] * per_image)
+            items.append(MultiModalInput(len(out), counts[k], images[k], image_hash(images[k]), sizes[k]))
+            out.extend([image_token] * counts[k])
             k += 1
         else:
             out.append(t)

@@ -437,8 +437,12 @@ class ModelRunner:
                     continue
                 emb = self._mm_embeds.get((rid, k))
                 if emb is None:
-                    px = torch.from_numpy(np.ascontiguousarray(m.pixel_values)).unsqueeze(0)
-                    emb = self._mm_embeds[(rid, k)] = self.model.encode_images(px.to(self.device))[0]
+                    px = torch.from_numpy(np.ascontiguousarray(m.pixel_values)).to(self.device)
+                    if px.dim() == 4:       # an any-resolution image: base view + tiles, packed by the model
+                        emb = self.model.encode_anyres_image(px, m.image_size)
+                    else:
+                        emb = self.model.encode_images(px.unsqueeze(0))[0]
+                    self._mm_embeds[(rid, k)] = emb
                     if emb.shape[0] != m.length:
                         raise RuntimeError(f"image of {rid}: {emb.shape[0]} features for {m.length} placeholder tokens")
                 rows.append(np.arange(a - lo, z - lo, dtype=np.int64) + int(p["qsl"][i]))
