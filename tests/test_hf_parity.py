@@ -128,6 +128,9 @@ CASES = {
     "stablelm": ("StableLmConfig", dict(BASE, use_qkv_bias=True)),
     "nemotron": ("NemotronConfig", dict(BASE, attention_bias=True, mlp_bias=True)),
     "cohere": ("CohereConfig", dict(BASE, logit_scale=0.25, pad_token_id=0)),
+    # a window (shorter than the prompts) on three of four layers, no positional embedding on the global one
+    "cohere2": ("Cohere2Config", dict(BASE, num_hidden_layers=4, logit_scale=0.25, pad_token_id=0, sliding_window=16,
+                                      layer_types=["sliding_attention"] * 3 + ["full_attention"])),
     # attention sinks, q/k/v/o biases, a window on every other layer, YaRN; experts with biases and the clamped
     # SwiGLU, stacked and column-interleaved in the checkpoint; router with a bias, softmax over the chosen logits
     "gpt-oss": ("GptOssConfig", dict(BASE, head_dim=16, num_hidden_layers=3, intermediate_size=48, num_local_experts=6,

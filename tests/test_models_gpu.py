@@ -35,7 +35,8 @@ TIGHT = {"llama-tiny", "opt-tiny", "phi3-tiny", "gemma-tiny", "granite-tiny", "g
                                    "gpt-neox-tiny", "starcoder2-tiny", "mistral-window-tiny", "qwen2-moe-tiny",
                                    "phi-tiny", "gemma3-tiny", "phi2-tiny", "gemma2-tiny",
                                    "glm-tiny", "helium-tiny", "smollm3-tiny", "glm4-tiny", "olmo2-tiny",
-                                   "exaone4-tiny", "nemotron-tiny", "stablelm-tiny", "cohere-tiny", "arcee-tiny",
+                                   "exaone4-tiny", "nemotron-tiny", "stablelm-tiny", "cohere-tiny", "cohere2-tiny",
+                                   "arcee-tiny",
                                    "deepseek-v3-tiny", "glm4-moe-tiny", "falcon-tiny", "gptj-tiny",
                                    "gpt-bigcode-tiny", "gpt-oss-tiny",
                                    "bloom-tiny", "mpt-tiny", "falcon-rw-tiny"])

@@ -24,7 +24,7 @@ from .utils import IntermediateTensors, get_pp_layer_range, materialize
 
 
 # families whose rotary embedding pairs ADJACENT dimensions (2i, 2i + 1) instead of (i, i + d/2)
-INTERLEAVED_ROPE_TYPES = ("helium", "ernie4_5", "ernie4_5_moe", "glm", "glm4", "cohere")
+INTERLEAVED_ROPE_TYPES = ("helium", "ernie4_5", "ernie4_5_moe", "glm", "glm4", "cohere", "cohere2")
 # families whose ``attention_bias`` means q / k / v only
 NO_O_BIAS_TYPES = ("glm", "glm4", "glm4_moe")
 # families with an RMSNorm over each head of q and k before the rotation ...

@@ -391,3 +391,19 @@ class CohereForCausalLM(LlamaForCausalLM):
         y = super().compute_logits(hidden)
         s = self.cfg.get("logit_scale")
         return y if s in (None, 1.0) else y * float(s)
+class Cohere2ForCausalLM(_PerLayerRope, CohereForCausalLM):
+    """Command-R7B / Command-A: Cohere's parallel block with a sliding window on most layers (``layer_types``, or
+    every layer but each ``sliding_window_pattern``-th) - and the global layers carry no positional embedding."""
+
+    def __init__(self, vllm_config):
+        cfg = vllm_config.model_config.hf_config
+        if not cfg.get("layer_types"):
+            every = int(cfg.get("sliding_window_pattern") or 4)
+            cfg["layer_types"] = ["full_attention" if (i + 1) % every == 0 else "sliding_attention"
+                                  for i in range(int(cfg["num_hidden_layers"]))]
+        super().__init__(vllm_config)
+
+    def layer_table(self, layer_idx: int) -> str:
+        return "cos_sin_cache" if self.cfg["layer_types"][layer_idx] == "sliding_attention" else "cos_sin_identity"
+
+

@@ -335,7 +335,7 @@ def _weight_shapes(c: dict, arch: str) -> Dict[str, Tuple[int, ...]]:
                       "olmo2": ("post_attention_layernorm", "post_feedforward_layernorm"),
                       "olmo3": ("post_attention_layernorm", "post_feedforward_layernorm"),
                       "exaone4": ("post_attention_layernorm", "post_feedforward_layernorm"),
-                      "cohere": ("input_layernorm",), "olmo": ()}.get(mt, ("input_layernorm", "post_attention_layernorm"))
+                      "cohere": ("input_layernorm",), "cohere2": ("input_layernorm",), "olmo": ()}.get(mt, ("input_layernorm", "post_attention_layernorm"))
     eagle = arch == "EagleLlamaForCausalLM"       # a draft head: no embedding / head / final norm of its own
     if eagle:
         norms = ("input_layernorm", "post_attention_layernorm")
