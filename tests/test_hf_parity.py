@@ -192,6 +192,56 @@ def test_family_matches_transformers(name, tmp_path):
         assert list(out.outputs[0].token_ids) == toks, (name, out.outputs[0].token_ids, toks)
 
 
+@pytest.mark.parametrize("mode", ["short", "long"])
+def test_phi3_longrope_matches_transformers(mode, tmp_path):
+    """LongRoPE (Phi-3 128k / Phi-3.5 / Phi-4-mini: per-frequency divisors, a short and a long set, a temperature on
+    cos / sin, partial rotation): served inside the original context the short set applies, served beyond it the
+    long one - each against transformers on sequences of that kind (prompts shorter / longer than the original
+    context of 32)."""
+    if not hasattr(transformers, "Phi3Config"):
+        pytest.skip("transformers has no Phi-3")
+    torch.manual_seed(99)
+    n = 12 // 2                                     # rotated pairs: head_dim 16, partial_rotary_factor 0.75
+    scaling = dict(rope_type="longrope", short_factor=[1.0 + 0.05 * i for i in range(n)],
+                   long_factor=[1.5 + 0.6 * i for i in range(n)])
+    kw = dict(BASE, pad_token_id=0, max_position_embeddings=256, original_max_position_embeddings=32,
+              partial_rotary_factor=0.75)
+    try:
+        cfg = transformers.Phi3Config(**kw, rope_parameters=dict(scaling, rope_theta=10000.0, partial_rotary_factor=0.75,
+                                                                 original_max_position_embeddings=32))
+    except (TypeError, ValueError, KeyError):
+        cfg = transformers.Phi3Config(**kw, rope_scaling=dict(scaling, type="longrope"))
+    model = transformers.AutoModelForCausalLM.from_config(cfg).eval().float()
+    with torch.no_grad():
+        for _, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    model.save_pretrained(str(tmp_path), safe_serialization=True)
+    prompts = [[5, 9, 200, 17, 33, 2, 90], list(range(10, 30))] if mode == "short" else \
+        [list(range(10, 60)), [7 + (3 * i) % 300 for i in range(75)]]
+    ref_lp, ref_tokens = [], []
+    with torch.no_grad():
+        for p in prompts:
+            ids = torch.tensor([p])
+            ref_lp.append(model(ids).logits[0, -1].float().log_softmax(-1))
+            gen = model.generate(ids, max_new_tokens=4, do_sample=False, pad_token_id=0)
+            ref_tokens.append(gen[0, len(p):].tolist())
+    llm = LLM(model=str(tmp_path), dtype="float32", device="cpu", max_model_len=32 if mode == "short" else 128,
+              num_gpu_blocks_override=64, max_num_seqs=8)
+    try:
+        outs = llm.generate(prompts, SamplingParams(temperature=0.0, max_tokens=4, ignore_eos=True, logprobs=10))
+    finally:
+        llm.shutdown()
+        pstate.destroy_model_parallel()
+    for out, lp, toks in zip(outs, ref_lp, ref_tokens):
+        got = out.outputs[0].logprobs[0]
+        top = torch.topk(lp, 5).indices.tolist()
+        assert set(top) <= set(got), (mode, top, sorted(got))
+        for t in top:
+            assert abs(got[t] - lp[t].item()) < 4e-3, (mode, t, got[t], lp[t].item())      # (scores carry the squared temperature)
+        assert list(out.outputs[0].token_ids) == toks, (mode, out.outputs[0].token_ids, toks)
+
+
 def test_llava_matches_transformers_with_images(tmp_path):
     """A small random LLaVA (CLIP tower, tapped at the second-to-last layer, two-layer projector, Llama decoder)
     against ``transformers.LlavaForConditionalGeneration`` on the same weights: pixels from this package's own

@@ -138,6 +138,12 @@ def normalize_hf_config(cfg: Dict[str, Any]) -> None:
         for k in ("partial_rotary_factor",):
             if k in rp and cfg.get(k) is None:
                 cfg[k] = rp[k]
+    rs = cfg.get("rope_scaling")
+    if isinstance(rs, dict) and rs.get("rope_type", rs.get("type")) in ("longrope", "su"):
+        # LongRoPE (Phi-3 128k, Phi-3.5, Phi-4-mini): the table builder needs the two context lengths of the config
+        rs = cfg["rope_scaling"] = dict(rs)
+        rs.setdefault("original_max_position_embeddings", cfg.get("original_max_position_embeddings"))
+        rs.setdefault("max_position_embeddings", cfg.get("max_position_embeddings"))
 
 
 def layer_sliding_window(c: Dict[str, Any], layer_idx: int) -> Optional[int]:

@@ -106,6 +106,25 @@ def build_cos_sin_cache(head_dim: int, max_pos: int, theta: float,
             t = torch.arange(max_pos, dtype=torch.float64)
             freqs = torch.outer(t, inv_freq)
             return (torch.cat([freqs.cos(), freqs.sin()], dim=-1) * float(mscale)).float()
+        elif rtype in ("longrope", "su"):
+            # LongRoPE: one divisor per frequency, a "short" set for sequences inside the original context and a
+            # "long" one beyond it, and a temperature on cos / sin.  transformers switches sets when a sequence
+            # grows past the original context (its cached keys keep the other rotation); here the table is built
+            # once for the served context: the long set throughout when ``max_pos`` exceeds the original context,
+            # the short one otherwise - what a sequence longer / shorter than that gets there.
+            old = int(rope_scaling.get("original_max_position_embeddings") or max_pos)
+            full = int(rope_scaling.get("max_position_embeddings") or max_pos)
+            factor = float(rope_scaling.get("factor") or full / old)
+            ext = rope_scaling["long_factor" if max_pos > old else "short_factor"]
+            if len(ext) != rd // 2:
+                raise ValueError(f"LongRoPE lists {len(ext)} factors for {rd // 2} frequencies")
+            inv_freq = inv_freq / torch.tensor(ext, dtype=torch.float64)
+            mscale = rope_scaling.get("attention_factor")
+            if mscale is None:
+                mscale = 1.0 if factor <= 1.0 else math.sqrt(1 + math.log(factor) / math.log(old))
+            t = torch.arange(max_pos, dtype=torch.float64)
+            freqs = torch.outer(t, inv_freq)
+            return (torch.cat([freqs.cos(), freqs.sin()], dim=-1) * float(mscale)).float()
         elif rtype not in (None, "default"):
             raise ValueError(f"rope scaling type {rtype!r} is not supported")
     t = torch.arange(max_pos, dtype=torch.float64)
