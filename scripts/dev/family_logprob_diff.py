@@ -13,7 +13,7 @@ if __name__ == "__main__":
         open(os.path.join(tmp, "config.json"), "w").write(json.dumps(mc.hf_config))
         outs = {}
         for dev in ("cuda", "cpu"):
-            kw = dict(dtype="bfloat16", gpu_memory_utilization=0.3) if dev == "cuda" else dict(dtype="float32", device="cpu")
+            kw = dict(dtype=os.environ.get("GPU_DTYPE", "bfloat16"), gpu_memory_utilization=0.3) if dev == "cuda" else dict(dtype="float32", device="cpu")
             llm = LLM(model=tmp, max_model_len=256, num_gpu_blocks_override=64, max_num_seqs=8, **kw)
             outs[dev] = llm.generate(PROMPTS, SamplingParams(temperature=0.0, max_tokens=3, ignore_eos=True, logprobs=20))
             llm.shutdown()

@@ -128,6 +128,9 @@ CASES = {
     "stablelm": ("StableLmConfig", dict(BASE, use_qkv_bias=True)),
     "nemotron": ("NemotronConfig", dict(BASE, attention_bias=True, mlp_bias=True)),
     "cohere": ("CohereConfig", dict(BASE, logit_scale=0.25, pad_token_id=0)),
+    # LayerNorms with biases, biases on q / k / v / o and the LM head, the two-softmax "sparsemixer" router
+    "phimoe": ("PhimoeConfig", dict(BASE, intermediate_size=48, num_local_experts=6, num_experts_per_tok=2,
+                                    attention_bias=True, lm_head_bias=True, router_jitter_noise=0.05, pad_token_id=0)),
     # a window (shorter than the prompts) on three of four layers, no positional embedding on the global one
     "cohere2": ("Cohere2Config", dict(BASE, num_hidden_layers=4, logit_scale=0.25, pad_token_id=0, sliding_window=16,
                                       layer_types=["sliding_attention"] * 3 + ["full_attention"])),

@@ -35,7 +35,7 @@ TIGHT = {"llama-tiny", "opt-tiny", "phi3-tiny", "gemma-tiny", "granite-tiny", "g
                                    "gpt-neox-tiny", "starcoder2-tiny", "mistral-window-tiny", "qwen2-moe-tiny",
                                    "phi-tiny", "gemma3-tiny", "phi2-tiny", "gemma2-tiny",
                                    "glm-tiny", "helium-tiny", "smollm3-tiny", "glm4-tiny", "olmo2-tiny",
-                                   "exaone4-tiny", "nemotron-tiny", "stablelm-tiny", "cohere-tiny", "cohere2-tiny",
+                                   "exaone4-tiny", "nemotron-tiny", "stablelm-tiny", "cohere-tiny", "cohere2-tiny", "phimoe-tiny",
                                    "arcee-tiny",
                                    "deepseek-v3-tiny", "glm4-moe-tiny", "falcon-tiny", "gptj-tiny",
                                    "gpt-bigcode-tiny", "gpt-oss-tiny",
@@ -82,7 +82,9 @@ def test_model_family_on_gpu_tracks_cpu_reference(model, tmp_path):
             # (gemma-tiny: embeddings times sqrt(hidden) into a tied head amplify bf16 rounding; its 80-token
             # prompt measures 0.12 through the fragment-direct prefill kernel and 0.16 through the LDS-staged one,
             # two kernels with the same error against fp32 on random data - scripts/dev/prefill_accuracy.py)
-            tol = 0.15 if model in TIGHT else (0.4 if model == "gpt-oss-tiny" else 0.3)
+            # (phimoe: the router's thresholds are hard; in fp16 the same GPU run is within 0.01 of the reference,
+            # in bf16 one flipped expert at one position measures 0.33 - scripts/dev/family_logprob_diff.py)
+            tol = 0.15 if model in TIGHT else (0.4 if model in ("gpt-oss-tiny", "phimoe-tiny") else 0.3)
             if model == "gemma-tiny":
                 tol = 0.2
             assert max(abs(la[t] - lb[t]) for t in common) < tol, (model, step)

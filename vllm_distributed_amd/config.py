@@ -324,7 +324,7 @@ class ModelConfig:
                 "falcon": "FalconForCausalLM", "ernie4_5_moe": "Ernie4_5_MoeForCausalLM", "granitemoe": "GraniteMoeForCausalLM", "gpt_bigcode": "GPTBigCodeForCausalLM", "gptj": "GPTJForCausalLM", "glm4_moe": "Glm4MoeForCausalLM", "dots1": "Dots1ForCausalLM", "deepseek_v2": "DeepseekV2ForCausalLM", "deepseek_v3": "DeepseekV3ForCausalLM",
                 "olmo2": "Olmo2ForCausalLM", "olmo": "OlmoForCausalLM", "olmoe": "OlmoeForCausalLM", "olmo3": "Olmo3ForCausalLM", "exaone4": "Exaone4ForCausalLM",
                 "stablelm": "StableLmForCausalLM", "nemotron": "NemotronForCausalLM",
-                "cohere": "CohereForCausalLM", "cohere2": "Cohere2ForCausalLM",
+                "cohere": "CohereForCausalLM", "cohere2": "Cohere2ForCausalLM", "phimoe": "PhimoeForCausalLM",
                 "qwen3": "Qwen3ForCausalLM", "mistral": "MistralForCausalLM",
                 "mixtral": "MixtralForCausalLM", "phi3": "Phi3ForCausalLM", "gpt_oss": "GptOssForCausalLM",
                 "bloom": "BloomForCausalLM", "mpt": "MptForCausalLM"}.get(mt, mt)

@@ -317,7 +317,7 @@ def _weight_shapes(c: dict, arch: str) -> Dict[str, Tuple[int, ...]]:
                 lin(q + "mlp.shared_experts.down_proj", h, mi * ns)
         return shapes
     moe = arch in ("Qwen3MoeForCausalLM", "Qwen2MoeForCausalLM", "OlmoeForCausalLM")
-    mixtral = arch == "MixtralForCausalLM"
+    mixtral = arch in ("MixtralForCausalLM", "PhimoeForCausalLM")
     phi3 = arch == "Phi3ForCausalLM"
     mt = c.get("model_type")
     qkv_bias = (bool(c.get("attention_bias", False)) or mt in ("qwen2", "qwen2_moe")
@@ -326,7 +326,7 @@ def _weight_shapes(c: dict, arch: str) -> Dict[str, Tuple[int, ...]]:
     if o_bias is None:
         o_bias = bool(c.get("attention_bias", False)) and mt not in ("glm", "glm4")
     mlp_bias = bool(c.get("mlp_bias", False))
-    norm_bias = mt in ("stablelm", "nemotron")              # LayerNorm families
+    norm_bias = mt in ("stablelm", "nemotron", "phimoe")    # LayerNorm families
     # which norms a layer has, by family
     norms = {"gemma2": 4, "gemma3_text": 4}.get(mt) and (
         "input_layernorm", "post_attention_layernorm", "pre_feedforward_layernorm", "post_feedforward_layernorm")
@@ -350,6 +350,8 @@ def _weight_shapes(c: dict, arch: str) -> Dict[str, Tuple[int, ...]]:
         shapes["model.norm.bias"] = (h,)
     if not c.get("tie_word_embeddings", False) and not eagle:
         shapes["lm_head.weight"] = (c["vocab_size"], h)
+        if mt == "phimoe" and c.get("lm_head_bias"):
+            shapes["lm_head.bias"] = (c["vocab_size"],)
 
     def linear(name: str, out_f: int, in_f: int, bias: bool) -> None:
         shapes[name + ".weight"] = (out_f, in_f)

@@ -128,3 +128,68 @@ class GraniteMoeForCausalLM(MixtralForCausalLM):
                 loaded.append(mapped)
         dense = LlamaForCausalLM.load_weights(self, others())
         return loaded + dense
+
+
+# ------------------------------------------------------------------------------------------------- Phi-3.5-MoE
+class SparseMixerMoE(FusedMoE):
+    """Phi-3.5-MoE's router (``sparsemixer`` at inference).  The first expert is the arg-max; its weight is its share
+    of a softmax over the experts whose logit lies within ``2 * jitter_eps`` (relative) of the maximum.  The second
+    expert is chosen the same way among the rest, with a softmax of its own: the two weights are not renormalised."""
+    custom_routing = True
+    jitter_eps = 0.01
+
+    def router_logits(self, x: torch.Tensor) -> torch.Tensor:
+        # fp32: the thresholds below are hard, and a 16-bit logit puts an expert on the wrong side of one
+        return torch.nn.functional.linear(x.float(), self.gate.weight.float())
+
+    def route(self, logits: torch.Tensor):
+        def pick(scores: torch.Tensor):
+            top, idx = scores.max(dim=-1, keepdim=True)
+            factor = logits.abs().clamp(min=top)
+            far = ((top - logits) / factor) > (2 * self.jitter_eps)
+            gates = torch.softmax(scores.masked_fill(far, float("-inf")), dim=-1)
+            return gates.gather(-1, idx), idx
+        w1, i1 = pick(logits)
+        w2, i2 = pick(logits.scatter(-1, i1, float("-inf")))
+        return torch.cat([w1, w2], dim=-1), torch.cat([i1, i2], dim=-1)
+
+
+class PhimoeForCausalLM(MixtralForCausalLM):
+    """Phi-3.5-MoE: Mixtral's layout (experts ``block_sparse_moe.experts.N.w1 / w3 / w2``, router
+    ``block_sparse_moe.gate``) with LayerNorms (weight and bias), biases on the attention projections and the LM
+    head, LongRoPE, and the ``sparsemixer`` router."""
+    tp_fusions = False
+
+    def __init__(self, vllm_config: VllmConfig):
+        cfg = vllm_config.model_config.hf_config
+        if int(cfg.get("num_experts_per_tok") or 2) != 2:
+            raise NotImplementedError("Phi-MoE routing is written for two experts per token")
+        super().__init__(vllm_config)
+        if self.is_last and cfg.get("lm_head_bias") and self.lm_head is not None:
+            from .layers.linear import ParallelLMHead
+            self.lm_head = ParallelLMHead(cfg["vocab_size"], cfg["hidden_size"], vllm_config.model_config.torch_dtype,
+                                          bias=True)
+
+    def make_final_norm(self, cfg: dict, dtype: torch.dtype) -> nn.Module:
+        from .layers.attention import LayerNorm
+        return LayerNorm(cfg["hidden_size"], cfg.get("rms_norm_eps", 1e-5), dtype)
+
+
+def _phimoe_layer():
+    from .layers.attention import LayerNorm
+    from .llama_variants import BranchNormLayer
+
+    class PhimoeDecoderLayer(BranchNormLayer):
+        def make_norm(self, cfg: dict, dtype: torch.dtype) -> nn.Module:
+            return LayerNorm(cfg["hidden_size"], cfg.get("rms_norm_eps", 1e-5), dtype)
+
+        def make_mlp(self, cfg: dict, dtype: torch.dtype) -> nn.Module:
+            moe = SparseMixerMoE(cfg["hidden_size"], cfg["intermediate_size"], cfg["num_local_experts"], 2, False, dtype,
+                                 expert_parallel=_EP)
+            moe.jitter_eps = float(cfg.get("router_jitter_noise") or 0.01)
+            return moe
+
+    return PhimoeDecoderLayer
+
+
+PhimoeForCausalLM.layer_cls = _phimoe_layer()
