@@ -335,6 +335,8 @@ def test_rope_scaling_tables_match_transformers(scaling):
 def test_unknown_rope_scaling_is_rejected():
     from vllm_distributed_amd.ops import build_cos_sin_cache
     with pytest.raises(ValueError, match="not supported"):
+        build_cos_sin_cache(128, 64, 10000.0, {"rope_type": "ntk-by-parts", "factor": 2.0})
+    with pytest.raises(ValueError, match="short_factor"):        # LongRoPE without its factor lists
         build_cos_sin_cache(128, 64, 10000.0, {"rope_type": "longrope", "factor": 2.0})
 
 

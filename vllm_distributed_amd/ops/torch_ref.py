@@ -115,7 +115,10 @@ def build_cos_sin_cache(head_dim: int, max_pos: int, theta: float,
             old = int(rope_scaling.get("original_max_position_embeddings") or max_pos)
             full = int(rope_scaling.get("max_position_embeddings") or max_pos)
             factor = float(rope_scaling.get("factor") or full / old)
-            ext = rope_scaling["long_factor" if max_pos > old else "short_factor"]
+            which = "long_factor" if max_pos > old else "short_factor"
+            if not rope_scaling.get(which):
+                raise ValueError(f"LongRoPE scaling needs short_factor and long_factor lists ({which} is missing)")
+            ext = rope_scaling[which]
             if len(ext) != rd // 2:
                 raise ValueError(f"LongRoPE lists {len(ext)} factors for {rd // 2} frequencies")
             inv_freq = inv_freq / torch.tensor(ext, dtype=torch.float64)
