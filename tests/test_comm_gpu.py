@@ -285,6 +285,7 @@ eng = LLMEngine.from_engine_args(EngineArgs(
     num_gpu_blocks_override=64, max_num_seqs=8, tensor_parallel_size=tp,
     distributed_executor_backend="spmd" if tp > 1 else "uni", enable_expert_parallel=os.environ.get("EP") == "1",
     async_scheduling=os.environ.get("ASYNC") == "1", gpu_memory_utilization=0.2,
+    speculative_config=json.loads(os.environ.get("SPEC", "null")),
     hf_overrides=json.loads(os.environ.get("OVERRIDES", "{{}}"))))
 g = SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True, logprobs=int(os.environ.get("LOGPROBS", "8")))
 ids = [eng.add_request(None, p, g) for p in ([5, 9, 200, 17], list(range(10, 90)), [7, 7])]
@@ -361,6 +362,21 @@ def test_spmd_tensor_parallel_ranks_sharing_one_gpu_match_single_rank():
             # that run exercises the fall-back to eager decode after a failed capture)
             assert got[0]["graphs"], got[0]["fallback"]
         _assert_distributions_close(ref["first_lp"], got[0]["first_lp"])
+
+
+@pytest.mark.parametrize("method", ["eagle", "eagle3"])
+def test_spmd_speculative_heads_tensor_parallel_sharing_one_gpu(method):
+    """EAGLE / EAGLE-3 heads next to a sharded target over the peer-mapped collectives, decode from captured
+    graphs: both ranks produce the same tokens, and the greedy text starts as the single-rank run's does.  (The
+    EAGLE-3 target runs the tapped plain layer loop - its all-reduces are the unfused peer-mapped ones - and its
+    graphs carry the three taps.)"""
+    spec = json.dumps({"method": method, "model": f"{method}-llama-tiny", "num_speculative_tokens": 3})
+    ref = _run_spmd_shared(1, False)[0]
+    got = _run_spmd_shared(2, False, extra_env={"SPEC": spec})
+    assert got[0]["tokens"] == got[1]["tokens"]
+    assert got[0]["direct_ar"] and got[0]["graphs"], got[0]["fallback"]
+    for a, b in zip(got[0]["tokens"], ref["tokens"]):
+        assert len(a) == len(b) and a[:2] == b[:2], (a, b)       # (bf16 sums in another order: the first tokens)
 
 
 @pytest.mark.parametrize("tp,pp", [(1, 2), (2, 1)])
