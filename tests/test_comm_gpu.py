@@ -300,7 +300,8 @@ runner = eng.core.executor.driver.worker.model_runner
 print("RESULT " + json.dumps(dict(tokens=[final[i] for i in ids], first_lp=[first_lp[i] for i in ids],
                                   direct_ar=pstate.get_tp_group().custom_ar is not None,
                                   rccl=pstate.get_tp_group().rccl is not None,
-                                  graphs=list(runner.graph_sizes), fallback=runner.graph_fallback_reason)), flush=True)
+                                  graphs=list(runner.graph_sizes), fallback=runner.graph_fallback_reason,
+                                  paths=dict(getattr(runner.model, "path_counts", {{}})))), flush=True)
 eng.shutdown()
 """
 
@@ -375,6 +376,9 @@ def test_spmd_speculative_heads_tensor_parallel_sharing_one_gpu(method):
     got = _run_spmd_shared(2, False, extra_env={"SPEC": spec})
     assert got[0]["tokens"] == got[1]["tokens"]
     assert got[0]["direct_ar"] and got[0]["graphs"], got[0]["fallback"]
+    # decode-sized steps keep the fused all-reduce + norm (EAGLE-3: the taps are copies of the replicated residual
+    # stream); an EAGLE-3 target's larger, row-sharded steps take the plain loop
+    assert got[0]["paths"].get("fused_replicated", 0) > 0, got[0]["paths"]
     for a, b in zip(got[0]["tokens"], ref["tokens"]):
         assert len(a) == len(b) and a[:2] == b[:2], (a, b)       # (bf16 sums in another order: the first tokens)
 

@@ -384,7 +384,9 @@ class LlamaForCausalLM(nn.Module):
     def forward(self, input_ids: Optional[torch.Tensor], positions: torch.Tensor,
                 intermediate: Optional[IntermediateTensors] = None):
         aux = self.aux_hidden_layers
-        fused = self.fused_tp_mode(positions.shape[0]) if self.tp_fusions and not aux else None
+        fused = self.fused_tp_mode(positions.shape[0]) if self.tp_fusions else None
+        if aux and fused:
+            fused = None        # (row-sharded residual stream: the taps would need a gather - the plain loop instead)
         if fused is not None:
             return self.forward_fused_tp(input_ids, positions, intermediate, sharded=fused)
         if intermediate is None and not aux and self.sequence_parallel_ok(positions.shape[0]):
@@ -465,12 +467,17 @@ class LlamaForCausalLM(nn.Module):
             return tp.all_reduce_add_rms_norm(x, res, norm.weight, norm.eps, sharded)
 
         norm = layers[0].input_layernorm if layers else self.norm
+        aux, taps = self.aux_hidden_layers, {}
         for li, layer in enumerate(layers):
             normed = add_norm(part, norm)
+            if aux and self.start_layer + li in aux:
+                taps[self.start_layer + li] = res.clone()       # the residual stream in front of this layer (replicated)
             part = layer.self_attn(positions, normed, reduce=False, staged=True)
             normed = add_norm(part, layer.post_attention_layernorm)
             part = layer.mlp(normed, reduce=False, staged=True)
             norm = layers[li + 1].input_layernorm if li + 1 < len(layers) else (self.norm if self.is_last else None)
+        if aux:
+            self.last_aux = torch.cat([taps[i] for i in aux], dim=-1)
         if not self.is_last:
             hidden = part if reduced else tp.all_reduce(part)
             if sharded and not reduced:

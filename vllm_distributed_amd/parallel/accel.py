@@ -156,7 +156,9 @@ def _calibrate_direct(group: GroupCoordinator, car) -> None:
                 use = s
             else:
                 prefix_use = False
-        car.one_shot_bytes = one_shot
+        # (below half the smallest size timed there is no measurement, and a noisy first row must not send
+        # few-kilobyte decode messages through the two-barrier form)
+        car.one_shot_bytes = max(one_shot, 16 << 10)
         car.use_bytes = use if group.rccl is not None else car.max_bytes
         car.calibration = [dict(bytes=s, one_shot_us=round(o, 1) if o != float("inf") else None, two_shot_us=round(t, 1),
                                 rccl_us=round(l, 1) if l != float("inf") else None)
