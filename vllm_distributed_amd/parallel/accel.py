@@ -159,7 +159,7 @@ def _calibrate_direct(group: GroupCoordinator, car) -> None:
         # (below half the smallest size timed there is no measurement, and a noisy first row must not send
         # few-kilobyte decode messages through the two-barrier form)
         car.one_shot_bytes = max(one_shot, 16 << 10)
-        car.use_bytes = use if group.rccl is not None else car.max_bytes
+        car.use_bytes = max(use, 16 << 10) if group.rccl is not None else car.max_bytes
         car.calibration = [dict(bytes=s, one_shot_us=round(o, 1) if o != float("inf") else None, two_shot_us=round(t, 1),
                                 rccl_us=round(l, 1) if l != float("inf") else None)
                            for s, (o, t, l) in zip(sizes, worst)]
