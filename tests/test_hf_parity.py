@@ -114,6 +114,11 @@ CASES = {
                                              embedding_multiplier=6.0, residual_multiplier=0.4,
                                              attention_multiplier=0.1, logits_scaling=4.0, tie_word_embeddings=True,
                                              attention_bias=True, pad_token_id=0)),
+    "granite-moe-shared": ("GraniteMoeSharedConfig", dict(BASE, intermediate_size=32, num_local_experts=4,
+                                                          num_experts_per_tok=2, shared_intermediate_size=48,
+                                                          embedding_multiplier=6.0, residual_multiplier=0.4,
+                                                          attention_multiplier=0.1, logits_scaling=4.0,
+                                                          tie_word_embeddings=True, pad_token_id=0)),
     "ernie4_5-moe": ("Ernie4_5_MoeConfig", dict(BASE, num_hidden_layers=3, moe_intermediate_size=32, moe_num_experts=8,
                                                 moe_k=2, moe_num_shared_experts=1, moe_layer_start_index=1,
                                                 pad_token_id=0)),

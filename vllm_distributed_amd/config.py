@@ -321,7 +321,7 @@ class ModelConfig:
                 "helium": "HeliumForCausalLM", "ernie4_5": "Ernie4_5ForCausalLM", "glm": "GlmForCausalLM",
                 "seed_oss": "SeedOssForCausalLM", "ministral": "MinistralForCausalLM",
                 "smollm3": "SmolLM3ForCausalLM", "arcee": "ArceeForCausalLM", "glm4": "Glm4ForCausalLM",
-                "falcon": "FalconForCausalLM", "ernie4_5_moe": "Ernie4_5_MoeForCausalLM", "granitemoe": "GraniteMoeForCausalLM", "gpt_bigcode": "GPTBigCodeForCausalLM", "gptj": "GPTJForCausalLM", "glm4_moe": "Glm4MoeForCausalLM", "dots1": "Dots1ForCausalLM", "deepseek_v2": "DeepseekV2ForCausalLM", "deepseek_v3": "DeepseekV3ForCausalLM",
+                "falcon": "FalconForCausalLM", "ernie4_5_moe": "Ernie4_5_MoeForCausalLM", "granitemoe": "GraniteMoeForCausalLM", "granitemoeshared": "GraniteMoeSharedForCausalLM", "gpt_bigcode": "GPTBigCodeForCausalLM", "gptj": "GPTJForCausalLM", "glm4_moe": "Glm4MoeForCausalLM", "dots1": "Dots1ForCausalLM", "deepseek_v2": "DeepseekV2ForCausalLM", "deepseek_v3": "DeepseekV3ForCausalLM",
                 "olmo2": "Olmo2ForCausalLM", "olmo": "OlmoForCausalLM", "olmoe": "OlmoeForCausalLM", "olmo3": "Olmo3ForCausalLM", "exaone4": "Exaone4ForCausalLM",
                 "stablelm": "StableLmForCausalLM", "nemotron": "NemotronForCausalLM",
                 "cohere": "CohereForCausalLM", "cohere2": "Cohere2ForCausalLM", "phimoe": "PhimoeForCausalLM",

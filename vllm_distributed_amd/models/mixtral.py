@@ -130,6 +130,45 @@ class GraniteMoeForCausalLM(MixtralForCausalLM):
         return loaded + dense
 
 
+class _MoEWithSharedMLP(FusedMoE):
+    """Routed experts plus one dense SwiGLU MLP every token goes through (GraniteMoeShared)."""
+
+    def __init__(self, hidden: int, inter: int, experts: int, top_k: int, shared_inter: int, dtype: torch.dtype):
+        super().__init__(hidden, inter, experts, top_k, True, dtype, expert_parallel=_EP)
+        from .llama import LlamaMLP
+        self.shared = LlamaMLP(hidden, shared_inter, dtype)
+
+    def forward(self, x: torch.Tensor, reduce: bool = True, staged: bool = False, deferred: bool = False):
+        return super().forward(x, reduce, staged) + self.shared(x, reduce, staged)
+
+
+class GraniteMoeSharedDecoderLayer(MixtralDecoderLayer):
+    def _make_mlp(self, cfg: dict, dtype: torch.dtype) -> nn.Module:
+        shared = int(cfg.get("shared_intermediate_size") or 0)
+        if shared <= 0:
+            return super()._make_mlp(cfg, dtype)
+        return _MoEWithSharedMLP(cfg["hidden_size"], cfg["intermediate_size"], cfg["num_local_experts"],
+                                 cfg["num_experts_per_tok"], shared, dtype)
+
+
+class GraniteMoeSharedForCausalLM(GraniteMoeForCausalLM):
+    """GraniteMoE with a shared dense MLP next to the experts (``shared_mlp.input_linear`` = [gate ; up],
+    ``shared_mlp.output_linear``); the residual multiplier is folded into its output weights as well."""
+    layer_cls = GraniteMoeSharedDecoderLayer
+
+    def map_weight_name(self, name: str) -> Optional[str]:
+        name = name.replace(".shared_mlp.input_linear.", ".mlp.shared.gate_up_proj.") \
+                   .replace(".shared_mlp.output_linear.", ".mlp.shared.down_proj.")
+        return super().map_weight_name(name)
+
+    def transform_weight(self, name: str, w):
+        mult = float(self.cfg.get("residual_multiplier") or 1.0)
+        if name.endswith(".mlp.shared.down_proj.weight") and mult != 1.0:
+            from .utils import materialize
+            return materialize(w).float().mul(mult)
+        return super().transform_weight(name, w)
+
+
 # ------------------------------------------------------------------------------------------------- Phi-3.5-MoE
 class SparseMixerMoE(FusedMoE):
     """Phi-3.5-MoE's router (``sparsemixer`` at inference).  The first expert is the arg-max; its weight is its share

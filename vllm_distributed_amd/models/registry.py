@@ -60,6 +60,7 @@ _MODELS: Dict[str, Tuple[str, str]] = {
     # vision-language: CLIP tower + projector in front of the Llama decoder
     "Cohere2ForCausalLM": ("llama_variants", "Cohere2ForCausalLM"),
     "PhimoeForCausalLM": ("mixtral", "PhimoeForCausalLM"),
+    "GraniteMoeSharedForCausalLM": ("mixtral", "GraniteMoeSharedForCausalLM"),
     "LlavaForConditionalGeneration": ("llava", "LlavaForConditionalGeneration"),
     "LlavaNextForConditionalGeneration": ("llava", "LlavaNextForConditionalGeneration"),
     # draft heads of speculative decoding (never a served model by themselves; worker/draft_model.py)
