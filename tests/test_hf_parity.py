@@ -133,6 +133,11 @@ CASES = {
     "stablelm": ("StableLmConfig", dict(BASE, use_qkv_bias=True)),
     "nemotron": ("NemotronConfig", dict(BASE, attention_bias=True, mlp_bias=True)),
     "cohere": ("CohereConfig", dict(BASE, logit_scale=0.25, pad_token_id=0)),
+    # nested attention / expert settings, fused and clamped Wqkv, experts stacked in three tensors (down transposed)
+    "dbrx": ("DbrxConfig", dict(d_model=64, n_heads=4, n_layers=2, max_seq_len=128, vocab_size=320, pad_token_id=0,
+                                attn_config=dict(kv_n_heads=2, clip_qkv=0.8, rope_theta=10000.0),
+                                ffn_config=dict(ffn_hidden_size=48, moe_num_experts=6, moe_top_k=2,
+                                                moe_normalize_expert_weights=1.0))),
     # LayerNorms with biases, biases on q / k / v / o and the LM head, the two-softmax "sparsemixer" router
     "phimoe": ("PhimoeConfig", dict(BASE, intermediate_size=48, num_local_experts=6, num_experts_per_tok=2,
                                     attention_bias=True, lm_head_bias=True, router_jitter_noise=0.05, pad_token_id=0)),

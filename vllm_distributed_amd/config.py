@@ -112,6 +112,18 @@ def normalize_hf_config(cfg: Dict[str, Any]) -> None:
                                      "layer_norm_eps": 1e-5, "hidden_act": "quick_gelu"}, **(cfg.get("vision_config") or {}))
         cfg.setdefault("architectures", ["LlavaNextForConditionalGeneration" if cfg["mm_model_type"] == "llava_next"
                                          else "LlavaForConditionalGeneration"])
+    if cfg.get("model_type") == "dbrx":
+        # DBRX nests its attention and expert settings
+        a, f = cfg.get("attn_config") or {}, cfg.get("ffn_config") or {}
+        cfg.setdefault("num_key_value_heads", a.get("kv_n_heads"))
+        if cfg.get("num_key_value_heads") is None:
+            cfg["num_key_value_heads"] = a.get("kv_n_heads", 1)
+        for k, v in (("clip_qkv", a.get("clip_qkv")), ("rope_theta", a.get("rope_theta", 10000.0)),
+                     ("intermediate_size", f.get("ffn_hidden_size")), ("num_local_experts", f.get("moe_num_experts")),
+                     ("num_experts_per_tok", f.get("moe_top_k")), ("hidden_act", (f.get("ffn_act_fn") or {}).get("name", "silu"))):
+            if cfg.get(k) is None and v is not None:
+                cfg[k] = v
+        cfg.setdefault("tie_word_embeddings", False)
     # GPT-2 era spellings
     for old, new in (("n_embd", "hidden_size"), ("n_head", "num_attention_heads"), ("n_layer", "num_hidden_layers"),
                      ("n_positions", "max_position_embeddings"),
@@ -321,7 +333,7 @@ class ModelConfig:
                 "helium": "HeliumForCausalLM", "ernie4_5": "Ernie4_5ForCausalLM", "glm": "GlmForCausalLM",
                 "seed_oss": "SeedOssForCausalLM", "ministral": "MinistralForCausalLM",
                 "smollm3": "SmolLM3ForCausalLM", "arcee": "ArceeForCausalLM", "glm4": "Glm4ForCausalLM",
-                "falcon": "FalconForCausalLM", "ernie4_5_moe": "Ernie4_5_MoeForCausalLM", "granitemoe": "GraniteMoeForCausalLM", "granitemoeshared": "GraniteMoeSharedForCausalLM", "gpt_bigcode": "GPTBigCodeForCausalLM", "gptj": "GPTJForCausalLM", "glm4_moe": "Glm4MoeForCausalLM", "dots1": "Dots1ForCausalLM", "deepseek_v2": "DeepseekV2ForCausalLM", "deepseek_v3": "DeepseekV3ForCausalLM",
+                "falcon": "FalconForCausalLM", "ernie4_5_moe": "Ernie4_5_MoeForCausalLM", "dbrx": "DbrxForCausalLM", "granitemoe": "GraniteMoeForCausalLM", "granitemoeshared": "GraniteMoeSharedForCausalLM", "gpt_bigcode": "GPTBigCodeForCausalLM", "gptj": "GPTJForCausalLM", "glm4_moe": "Glm4MoeForCausalLM", "dots1": "Dots1ForCausalLM", "deepseek_v2": "DeepseekV2ForCausalLM", "deepseek_v3": "DeepseekV3ForCausalLM",
                 "olmo2": "Olmo2ForCausalLM", "olmo": "OlmoForCausalLM", "olmoe": "OlmoeForCausalLM", "olmo3": "Olmo3ForCausalLM", "exaone4": "Exaone4ForCausalLM",
                 "stablelm": "StableLmForCausalLM", "nemotron": "NemotronForCausalLM",
                 "cohere": "CohereForCausalLM", "cohere2": "Cohere2ForCausalLM", "phimoe": "PhimoeForCausalLM",

@@ -232,3 +232,80 @@ def _phimoe_layer():
 
 
 PhimoeForCausalLM.layer_cls = _phimoe_layer()
+
+
+# -------------------------------------------------------------------------------------------------------- DBRX
+def _dbrx_layer():
+    from .layers.attention import LayerNorm
+    from .llama_variants import BranchNormLayer
+
+    class DbrxDecoderLayer(BranchNormLayer):
+        def make_norm(self, cfg: dict, dtype: torch.dtype) -> nn.Module:
+            return LayerNorm(cfg["hidden_size"], 1e-5, dtype, bias=False)
+
+        def make_mlp(self, cfg: dict, dtype: torch.dtype) -> nn.Module:
+            return FusedMoE(cfg["hidden_size"], cfg["intermediate_size"], cfg["num_local_experts"],
+                            cfg["num_experts_per_tok"], True, dtype, expert_parallel=_EP)
+
+    return DbrxDecoderLayer
+
+
+class DbrxForCausalLM(MixtralForCausalLM):
+    """DBRX: bias-free LayerNorms, a fused and clamped ``Wqkv``, 16 experts of which 4 run, their weights stacked
+    over experts in three tensors (``w1`` gate and ``v1`` up as ``[E * I, H]``, ``w2`` down as ``[E * I, H]`` too,
+    i.e. transposed), router weights renormalised to sum one."""
+    tp_fusions = False
+    layer_cls = _dbrx_layer()
+
+    def __init__(self, vllm_config: VllmConfig):
+        cfg = vllm_config.model_config.hf_config
+        norm = float((cfg.get("ffn_config") or {}).get("moe_normalize_expert_weights") or 0.0)
+        if norm != 1.0:
+            raise NotImplementedError(f"DBRX with moe_normalize_expert_weights={norm} (only the 1-norm)")
+        if vllm_config.model_config.quantization in ("awq", "nvfp4"):
+            raise NotImplementedError("packed 4-bit DBRX checkpoints (stacked expert tensors)")
+        super().__init__(vllm_config)
+
+    def make_final_norm(self, cfg: dict, dtype: torch.dtype) -> nn.Module:
+        from .layers.attention import LayerNorm
+        return LayerNorm(cfg["hidden_size"], 1e-5, dtype, bias=False)
+
+    _RENAMES = ((".norm_attn_norm.attn.Wqkv.", ".self_attn.qkv_proj."), (".norm_attn_norm.attn.out_proj.", ".self_attn.o_proj."),
+                (".norm_attn_norm.norm_1.", ".input_layernorm."), (".norm_attn_norm.norm_2.", ".post_attention_layernorm."),
+                (".ffn.router.layer.", ".mlp.gate."), (".ffn.experts.mlp.", ".mlp.experts."))
+
+    def map_weight_name(self, name: str) -> Optional[str]:
+        if name.startswith("transformer."):
+            name = "model." + name[len("transformer."):]
+        name = name.replace("model.blocks.", "model.layers.").replace("model.wte.", "model.embed_tokens.") \
+                   .replace("model.norm_f.", "model.norm.")
+        for old, new in self._RENAMES:
+            name = name.replace(old, new)
+        return super().map_weight_name(name)
+
+    def load_weights(self, weights: Iterable[Tuple[str, torch.Tensor]]) -> List[str]:
+        from .utils import materialize
+        params: Dict[str, nn.Parameter] = dict(self.named_parameters())
+        ne, loaded = int(self.cfg["num_local_experts"]), []
+
+        def others():
+            for name, w in weights:
+                mapped = self.map_weight_name(name)
+                which = mapped.rsplit(".", 1)[-1] if mapped and ".mlp.experts." in mapped else None
+                if which not in ("w1", "v1", "w2"):
+                    yield name, w
+                    continue
+                if not self._owns_layer(mapped):
+                    continue
+                prefix = mapped[:mapped.index(".mlp.")] + ".mlp"
+                t = materialize(w)
+                t = t.view(ne, t.shape[0] // ne, t.shape[1])
+                for e in range(ne):
+                    if which == "w2":
+                        p = params[prefix + ".w2"]
+                        p.weight_loader(p, t[e].t().contiguous(), (e, 0))
+                    else:
+                        p = params[prefix + ".w13"]
+                        p.weight_loader(p, t[e], (e, 0 if which == "w1" else 1))
+                loaded.append(mapped)
+        return loaded + LlamaForCausalLM.load_weights(self, others())

@@ -60,6 +60,7 @@ _MODELS: Dict[str, Tuple[str, str]] = {
     # vision-language: CLIP tower + projector in front of the Llama decoder
     "Cohere2ForCausalLM": ("llama_variants", "Cohere2ForCausalLM"),
     "PhimoeForCausalLM": ("mixtral", "PhimoeForCausalLM"),
+    "DbrxForCausalLM": ("mixtral", "DbrxForCausalLM"),
     "GraniteMoeSharedForCausalLM": ("mixtral", "GraniteMoeSharedForCausalLM"),
     "LlavaForConditionalGeneration": ("llava", "LlavaForConditionalGeneration"),
     "LlavaNextForConditionalGeneration": ("llava", "LlavaNextForConditionalGeneration"),
